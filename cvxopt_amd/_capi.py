@@ -1,0 +1,151 @@
+"""ctypes binding of include/mi355kkt.h (the C ABI of libmi355kkt.so).
+
+Fails loudly: no library -> ImportError at first use; no GPU -> RuntimeError from create().
+"""
+import ctypes as C
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmi355kkt.so")
+
+EINVAL, EHIP, ENOMEM, ENOTIMPL = -1, -2, -3, -4
+CHOL2, CHOL, LDL, LDL2 = 0, 1, 2, 3
+
+_lib = None
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_i64_p = C.POINTER(C.c_int64)
+c_float_p = C.POINTER(C.c_float)
+
+
+class Scaling(C.Structure):
+    _fields_ = [("d", c_double_p), ("di", c_double_p), ("v", c_double_p), ("beta", c_double_p),
+                ("r", c_double_p), ("rti", c_double_p)]
+
+
+# name -> (restype, argtypes); this table is also what tests check against include/mi355kkt.h
+SIGNATURES = {
+    "mi355kkt_version": (C.c_int, []),
+    "mi355kkt_last_error": (C.c_char_p, []),
+    "mi355kkt_device_count": (C.c_int, []),
+    "mi355kkt_device_info": (C.c_int, [C.c_int, C.c_char_p, C.c_int, c_int_p, C.POINTER(C.c_size_t)]),
+    "mi355kkt_dev_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "mi355kkt_dev_free": (C.c_int, [C.c_void_p]),
+    "mi355kkt_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi355kkt_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi355kkt_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi355kkt_device_synchronize": (C.c_int, []),
+    "mi355kkt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  c_int_p, C.c_int, c_int_p]),
+    "mi355kkt_destroy": (None, [C.c_void_p]),
+    "mi355kkt_set_G_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_set_G_csc": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p, c_double_p]),
+    "mi355kkt_set_A_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_set_G_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_set_A_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_set_H_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_set_H_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_set_kktreg": (C.c_int, [C.c_void_p, C.c_double]),
+    "mi355kkt_factor": (C.c_int, [C.c_void_p, C.POINTER(Scaling)]),
+    "mi355kkt_factor_device": (C.c_int, [C.c_void_p, C.POINTER(Scaling)]),
+    "mi355kkt_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355kkt_solve_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355kkt_sync": (C.c_int, [C.c_void_p]),
+    "mi355kkt_is_singular_mode": (C.c_int, [C.c_void_p]),
+    "mi355kkt_get_timings": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
+    "mi355kkt_get_factor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_op_syrk_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_int64, C.c_void_p, C.c_int64, c_float_p]),
+    "mi355kkt_op_potrf": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_int_p, c_float_p]),
+    "mi355kkt_op_trsm_lower": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                         c_float_p]),
+    "mi355kkt_op_gemv_t_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, c_float_p]),
+    "mi355kkt_op_gemv_n_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, c_float_p]),
+}
+
+
+def lib():
+    """Loads libmi355kkt.so once.  If torch is (or can be) imported it is imported FIRST so that the
+    process holds exactly one HIP runtime (torch bundles its own libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("cvxopt_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` or `bash cvxopt_amd/csrc/build.sh` (there is NO CPU fallback)" % LIB_PATH)
+    if "torch" not in sys.modules and os.environ.get("CVXOPT_AMD_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().mi355kkt_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    """Maps C return codes onto the reference's exception classes (SURVEY.md 8(b) 'Errors')."""
+    if rc == 0:
+        return
+    if rc > 0:
+        raise ArithmeticError(int(rc))            # singular / not positive definite (lapack.c:32-34)
+    msg = "%s: %s" % (what, last_error())
+    if rc == EINVAL:
+        raise ValueError(msg)
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    if rc == ENOTIMPL:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count():
+    return lib().mi355kkt_device_count()
+
+
+class DeviceBuffer(object):
+    """A block of HBM owned through the C ABI (used by tests / bench to keep inputs resident)."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().mi355kkt_dev_malloc(C.byref(p), self.nbytes), "dev_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_array(cls, a):
+        import numpy as np
+        a = np.ascontiguousarray(a) if not (a.flags.f_contiguous or a.flags.c_contiguous) else a
+        b = cls(a.nbytes)
+        check(lib().mi355kkt_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes), "memcpy_h2d")
+        return b
+
+    def to_array(self, shape, dtype="float64", order="F"):
+        import numpy as np
+        out = np.empty(shape, dtype=dtype, order=order)
+        assert out.nbytes <= self.nbytes
+        check(lib().mi355kkt_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes), "memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().mi355kkt_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

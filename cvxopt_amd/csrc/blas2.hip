@@ -1,0 +1,316 @@
+// HBM-bound level-2 kernels of solve() for gfx950 (reference src/python/misc.py:1489-1565):
+//   gemv_t_scaled   zs = w .* z; x += G' (w .* zs)       misc.py:1513 scale(z) + :1524 base.gemv(Gs, z, x, trans='T')
+//   gemv_n_scaled   z := alpha w .* (G x) + beta zs   misc.py:1563 base.gemv(Gs, x, z, beta=-1)
+//   trsm_lower      x := L^-1 x / L^-T x   misc.py:1529 / :1555 blas.trsv  (and :1470 blas.trsm for Asct)
+// G is never rescaled in memory: Gs = diag(w) G is applied on the fly, so the 1 GB G block is read
+// exactly once per product and no Gs copy is written.
+#include "kkt_common.h"
+
+namespace mi355kkt {
+
+struct __attribute__((aligned(8))) d2u { double x, y; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// zs = w .* z and zss = w .* zs   (w == nullptr: zs = z, zss unused)
+__global__ __launch_bounds__(256) void scale_vec_kernel(const double* __restrict__ w, const double* __restrict__ z,
+                                                        double* __restrict__ zs, double* __restrict__ zss, int m) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) {
+        if (w) {
+            const double t = w[i] * z[i];
+            zs[i] = t;
+            zss[i] = w[i] * t;
+        } else {
+            zs[i] = z[i];
+        }
+    }
+}
+
+// one wave per column: y[j] += sum_i G[i,j] zs[i]
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ G, int64_t ldg, int m, int n,
+                                                     const double* __restrict__ zs, double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const double* __restrict__ g = G + (int64_t)j * ldg;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = lane * 2;
+    for (; i + 384 + 1 < m; i += 512) {   // 4 x (64 lanes x 2 doubles)
+        const d2u a0 = *reinterpret_cast<const d2u*>(g + i);
+        const d2u a1 = *reinterpret_cast<const d2u*>(g + i + 128);
+        const d2u a2 = *reinterpret_cast<const d2u*>(g + i + 256);
+        const d2u a3 = *reinterpret_cast<const d2u*>(g + i + 384);
+        const d2u z0 = *reinterpret_cast<const d2u*>(zs + i);
+        const d2u z1 = *reinterpret_cast<const d2u*>(zs + i + 128);
+        const d2u z2 = *reinterpret_cast<const d2u*>(zs + i + 256);
+        const d2u z3 = *reinterpret_cast<const d2u*>(zs + i + 384);
+        s0 += a0.x * z0.x + a0.y * z0.y;
+        s1 += a1.x * z1.x + a1.y * z1.y;
+        s2 += a2.x * z2.x + a2.y * z2.y;
+        s3 += a3.x * z3.x + a3.y * z3.y;
+    }
+    for (; i < m; i += 128) {
+        s0 += g[i] * zs[i];
+        if (i + 1 < m) s1 += g[i + 1] * zs[i + 1];
+    }
+    const double s = wave_sum((s0 + s1) + (s2 + s3));
+    if (lane == 0) y[j] += s;
+}
+
+constexpr int GN_COLS = 256;   // columns per chunk of the row-parallel product
+// partial[chunk][i] = sum_{j in chunk} G[i,j] x[j]; each thread owns two rows
+__global__ __launch_bounds__(256) void gemv_n_partial_kernel(const double* __restrict__ G, int64_t ldg, int m,
+                                                             int n, const double* __restrict__ x,
+                                                             double* __restrict__ partial) {
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 2;
+    const int j0 = blockIdx.y * GN_COLS;
+    const int j1 = min(n, j0 + GN_COLS);
+    if (i >= m) return;
+    const bool two = (i + 1 < m);
+    double s0 = 0.0, s1 = 0.0;
+    const double* __restrict__ g = G + i + (int64_t)j0 * ldg;
+    if (two) {
+        int j = j0;
+        for (; j + 3 < j1; j += 4) {
+            const d2u a0 = *reinterpret_cast<const d2u*>(g);
+            const d2u a1 = *reinterpret_cast<const d2u*>(g + ldg);
+            const d2u a2 = *reinterpret_cast<const d2u*>(g + 2 * ldg);
+            const d2u a3 = *reinterpret_cast<const d2u*>(g + 3 * ldg);
+            const double x0 = x[j], x1 = x[j + 1], x2 = x[j + 2], x3 = x[j + 3];
+            s0 += a0.x * x0;
+            s1 += a0.y * x0;
+            s0 += a1.x * x1;
+            s1 += a1.y * x1;
+            s0 += a2.x * x2;
+            s1 += a2.y * x2;
+            s0 += a3.x * x3;
+            s1 += a3.y * x3;
+            g += 4 * ldg;
+        }
+        for (; j < j1; ++j) {
+            const d2u a0 = *reinterpret_cast<const d2u*>(g);
+            s0 += a0.x * x[j];
+            s1 += a0.y * x[j];
+            g += ldg;
+        }
+        partial[(int64_t)blockIdx.y * m + i] = s0;
+        partial[(int64_t)blockIdx.y * m + i + 1] = s1;
+    } else {
+        for (int j = j0; j < j1; ++j) {
+            s0 += g[0] * x[j];
+            g += ldg;
+        }
+        partial[(int64_t)blockIdx.y * m + i] = s0;
+    }
+}
+
+// z[i] = alpha * w[i] * sum_c partial[c][i] + beta * zs[i]   (z may alias zs)
+__global__ __launch_bounds__(256) void gemv_n_finish_kernel(const double* __restrict__ partial, int nchunks, int m,
+                                                            const double* __restrict__ w, const double* zs,
+                                                            double* z, double alpha, double beta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    double s = 0.0;
+    for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * m + i];
+    z[i] = alpha * (w ? w[i] * s : s) + beta * zs[i];
+}
+
+size_t gemv_work_doubles(int m, int n) {
+    const size_t nchunks = (size_t)((n + GN_COLS - 1) / GN_COLS);
+    return (nchunks ? nchunks : 1) * (size_t)(m > 0 ? m : 1);
+}
+
+// zs := w .* z (kept for the final z update);  y += (diag(w) G)' zs = G' (w .* zs).
+// work: >= m doubles (only used when w != nullptr).
+int launch_gemv_t_scaled(const double* G, int64_t ldg, int m, int n, const double* w, const double* z,
+                         double* zs, double* y, double* work, hipStream_t st) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((m + 255) / 256), dim3(256), 0, st, w, z, zs, work, m);
+    KKT_HIP_CHECK(hipGetLastError());
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((n + 3) / 4), dim3(256), 0, st, G, ldg, m, n, w ? work : zs, y);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_gemv_n_scaled(const double* G, int64_t ldg, int m, int n, const double* w, const double* x,
+                         const double* zs, double* z, double alpha, double beta, double* work, hipStream_t st) {
+    if (m <= 0) return 0;
+    const int nchunks = (n + GN_COLS - 1) / GN_COLS;
+    if (nchunks > 0) {
+        hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((m + 511) / 512, nchunks), dim3(256), 0, st, G, ldg, m, n, x,
+                           work);
+        KKT_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(gemv_n_finish_kernel, dim3((m + 255) / 256), dim3(256), 0, st, work, nchunks, m, w, zs, z,
+                       alpha, beta);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ===================================================================================================
+// Triangular solves with the Cholesky factor, blocked by 128; the 128x128 diagonal solve runs inside
+// ONE wave (lane = row, x_j broadcast with readlane, no LDS, no barriers) in two 64-row halves.
+// ===================================================================================================
+constexpr int TB = 128;
+
+__device__ __forceinline__ double bcast(double v, int srclane) {
+    return __shfl(v, srclane, 64);
+}
+
+// forward substitution on a <=64 x <=64 lower block held column-major at Lb (ldl); lane i owns b_i.
+// The lane's row of the block is preloaded into registers (coalesced per column) so that the
+// 64-step dependency chain is readlane + fma only.
+__device__ __forceinline__ double tri_fwd64(const double* __restrict__ Lb, int64_t ldl, int nb, double b, int lane) {
+    double lrow[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) lrow[j] = (j < lane && lane < nb) ? Lb[lane + (int64_t)j * ldl] : 0.0;
+    const double dinv = (lane < nb) ? 1.0 / Lb[lane + (int64_t)lane * ldl] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const double xj = bcast(b * dinv, j);
+        if (lane == j) b = xj;
+        b -= lrow[j] * xj;   // lrow[j] == 0 for lanes <= j and for j >= nb
+    }
+    return b;
+}
+
+// backward substitution with the transpose: solves Lb' x = b (Lb lower); lane i preloads column i.
+__device__ __forceinline__ double tri_bwd64(const double* __restrict__ Lb, int64_t ldl, int nb, double b, int lane) {
+    double lcol[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) lcol[j] = (j > lane && j < nb) ? Lb[j + (int64_t)lane * ldl] : 0.0;
+    const double dinv = (lane < nb) ? 1.0 / Lb[lane + (int64_t)lane * ldl] : 0.0;
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+        const double xj = bcast(b * dinv, j);
+        if (lane == j) b = xj;
+        b -= lcol[j] * xj;
+    }
+    return b;
+}
+
+// Forward step for block row k0: x_k := L_kk^-1 x_k, one wave per right-hand side.
+__global__ __launch_bounds__(64) void trsv_diag_fwd_kernel(const double* __restrict__ L, int64_t ldl, int k0, int nb,
+                                                           double* __restrict__ X, int64_t ldx) {
+    const int lane = threadIdx.x;
+    double* x = X + (int64_t)blockIdx.x * ldx + k0;
+    const double* Lkk = L + k0 + (int64_t)k0 * ldl;
+    const int n0 = min(nb, 64), n1 = nb - n0;
+    double b0 = (lane < n0) ? x[lane] : 0.0;
+    b0 = tri_fwd64(Lkk, ldl, n0, b0, lane);
+    if (lane < n0) x[lane] = b0;
+    if (n1 > 0) {
+        double b1 = (lane < n1) ? x[64 + lane] : 0.0;
+#pragma unroll 8
+        for (int j = 0; j < n0; ++j) {
+            const double l = (lane < n1) ? Lkk[64 + lane + (int64_t)j * ldl] : 0.0;
+            b1 -= l * bcast(b0, j);
+        }
+        b1 = tri_fwd64(Lkk + 64 + 64 * ldl, ldl, n1, b1, lane);
+        if (lane < n1) x[64 + lane] = b1;
+    }
+}
+
+// x[k0+nb : n) -= L[k0+nb : n, k0 : k0+nb) x_k   (row-parallel, two rows per thread)
+__global__ __launch_bounds__(256) void trsv_update_fwd_kernel(const double* __restrict__ L, int64_t ldl, int n, int k0,
+                                                              int nb, double* __restrict__ X, int64_t ldx) {
+    __shared__ double xs[TB];
+    double* x = X + (int64_t)blockIdx.y * ldx;
+    if (threadIdx.x < nb) xs[threadIdx.x] = x[k0 + threadIdx.x];
+    __syncthreads();
+    const int i = k0 + nb + (blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= n) return;
+    const double* __restrict__ l = L + i + (int64_t)k0 * ldl;
+    if (i + 1 < n) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int j = 0; j < nb; ++j) {
+            const d2u a = *reinterpret_cast<const d2u*>(l + (int64_t)j * ldl);
+            s0 += a.x * xs[j];
+            s1 += a.y * xs[j];
+        }
+        x[i] -= s0;
+        x[i + 1] -= s1;
+    } else {
+        double s0 = 0.0;
+        for (int j = 0; j < nb; ++j) s0 += l[(int64_t)j * ldl] * xs[j];
+        x[i] -= s0;
+    }
+}
+
+// Backward step for block k0:  x_k := L_kk^-T ( x_k - L[k0+nb:n, k0:k0+nb)' x[k0+nb:n) )
+// stage 1: one wave per column c of the block computes the long dot product (coalesced)
+__global__ __launch_bounds__(256) void trsv_dot_bwd_kernel(const double* __restrict__ L, int64_t ldl, int n, int k0,
+                                                           int nb, double* __restrict__ X, int64_t ldx) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nb) return;
+    double* x = X + (int64_t)blockIdx.y * ldx;
+    const double* __restrict__ l = L + (int64_t)(k0 + c) * ldl;
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = k0 + nb + lane; i < n; i += 128) {
+        s0 += l[i] * x[i];
+        if (i + 64 < n) s1 += l[i + 64] * x[i + 64];
+    }
+    const double s = wave_sum(s0 + s1);
+    if (lane == 0) x[k0 + c] -= s;
+}
+
+__global__ __launch_bounds__(64) void trsv_diag_bwd_kernel(const double* __restrict__ L, int64_t ldl, int k0, int nb,
+                                                           double* __restrict__ X, int64_t ldx) {
+    const int lane = threadIdx.x;
+    double* x = X + (int64_t)blockIdx.x * ldx + k0;
+    const double* Lkk = L + k0 + (int64_t)k0 * ldl;
+    const int n0 = min(nb, 64), n1 = nb - n0;
+    double b1 = 0.0;
+    if (n1 > 0) {
+        b1 = (lane < n1) ? x[64 + lane] : 0.0;
+        b1 = tri_bwd64(Lkk + 64 + 64 * ldl, ldl, n1, b1, lane);
+        if (lane < n1) x[64 + lane] = b1;
+    }
+    double b0 = (lane < n0) ? x[lane] : 0.0;
+    if (n1 > 0) {
+        // b0_i -= sum_j L[64+j][i] x1_j : column i of the lower-left block, contiguous in j
+#pragma unroll 8
+        for (int j = 0; j < n1; ++j) {
+            const double l = (lane < n0) ? Lkk[64 + j + (int64_t)lane * ldl] : 0.0;
+            b0 -= l * bcast(b1, j);
+        }
+    }
+    b0 = tri_bwd64(Lkk, ldl, n0, b0, lane);
+    if (lane < n0) x[lane] = b0;
+}
+
+int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs, int trans,
+                      hipStream_t st) {
+    if (n <= 0 || nrhs <= 0) return 0;
+    if (!trans) {
+        for (int k0 = 0; k0 < n; k0 += TB) {
+            const int nb = (n - k0 < TB) ? (n - k0) : TB;
+            hipLaunchKernelGGL(trsv_diag_fwd_kernel, dim3(nrhs), dim3(64), 0, st, L, ldl, k0, nb, X, ldx);
+            const int rem = n - k0 - nb;
+            if (rem > 0)
+                hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((rem + 511) / 512, nrhs), dim3(256), 0, st, L, ldl, n,
+                                   k0, nb, X, ldx);
+        }
+    } else {
+        const int nblk = (n + TB - 1) / TB;
+        for (int kb = nblk - 1; kb >= 0; --kb) {
+            const int k0 = kb * TB;
+            const int nb = (n - k0 < TB) ? (n - k0) : TB;
+            if (n - k0 - nb > 0)
+                hipLaunchKernelGGL(trsv_dot_bwd_kernel, dim3((nb + 3) / 4, nrhs), dim3(256), 0, st, L, ldl, n, k0, nb, X,
+                                   ldx);
+            hipLaunchKernelGGL(trsv_diag_bwd_kernel, dim3(nrhs), dim3(64), 0, st, L, ldl, k0, nb, X, ldx);
+        }
+    }
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mi355kkt

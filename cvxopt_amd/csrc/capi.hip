@@ -1,0 +1,571 @@
+// C ABI of libmi355kkt (see include/mi355kkt.h): solver handle, factor(), solve(), stand-alone ops.
+//
+// Device engine = reduced ("Schur complement") form shared by every factory flavour
+// (reference misc.py:1352-1567 is the closest restatement; Appendix A of SURVEY.md):
+//     S = H + Gs' Gs                Gs = W^-T G            -> syrk_tn_kernel (scaling fused)
+//     S = L L'                                             -> launch_potrf
+//     Asct = L^-1 A',  K = Asct' Asct = Lk Lk'  (p > 0)    -> trsm_lower, syrk_tn_kernel, launch_potrf
+//   solve:  zs = W^-T bz;  x = L^-1 (bx + Gs' zs [+ A' by]);  y = K^-1 (Asct' x - by);
+//           x = L^-T (x - Asct y);  z = Gs x - zs
+// G and A stay resident in HBM; per factor() only W (O(cdim) doubles) crosses PCIe, per solve() only
+// x, y, z.
+#include <cmath>
+#include <cstdarg>
+#include <mutex>
+
+#include "../../include/mi355kkt.h"
+#include "kkt_common.h"
+
+namespace mi355kkt {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- tiny element-wise helpers -------------------------------------------------------------------
+__global__ void scal_kernel(double* x, int n, double a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] *= a;
+}
+__global__ void diag_add_kernel(double* A, int64_t lda, int n, double a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) A[i + (int64_t)i * lda] += a;
+}
+__global__ void scaled_copy_kernel(const double* x, double* y, int n, double a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) y[i] = a * x[i];
+}
+// out (n x p, ld n) = A' where A is p x n (lda)
+__global__ void transpose_kernel(const double* __restrict__ A, int64_t lda, int p, int n, double* __restrict__ out) {
+    __shared__ double t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx over n (cols of A), by over p (rows of A)
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int i = by + threadIdx.x, j = bx + r;   // A[i, j]
+        t[r][threadIdx.x] = (i < p && j < n) ? A[i + (int64_t)j * lda] : 0.0;
+    }
+    __syncthreads();
+    for (int r = threadIdx.y; r < 32; r += 8) {
+        const int j = bx + threadIdx.x, i = by + r;   // out[j, i]
+        if (j < n && i < p) out[j + (int64_t)i * n] = t[threadIdx.x][r];
+    }
+}
+
+static inline dim3 g1(int n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace mi355kkt
+
+using namespace mi355kkt;
+
+struct mi355kkt_solver {
+    int device = 0, kind = 0;
+    int n = 0, p = 0, ml = 0, cdim = 0;
+    std::vector<int> q, s;
+    int num_cus = 256;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[6] = {};
+    // constants
+    const double* dG = nullptr;  int64_t ldG = 0;  double* G_owned = nullptr;
+    const double* dA = nullptr;  int64_t ldA = 0;  double* A_owned = nullptr;
+    const double* dH = nullptr;  int64_t ldH = 0;  double* H_owned = nullptr;
+    double kktreg = 0.0;
+    // per-factor state
+    double* dW = nullptr;      // effective diagonal scaling of the 'l' block (di, possibly / sqrt(1+reg))
+    double* dS = nullptr;      // n x n: S then its Cholesky factor L
+    double* dAsct = nullptr;   // n x p
+    double* dK = nullptr;      // p x p
+    bool firstcall = true, singular = false, factored = false;
+    // workspaces
+    double *dx = nullptr, *dy = nullptr, *dz = nullptr, *dzs = nullptr, *dtn = nullptr, *dtp = nullptr, *dwork = nullptr;
+    double* hbuf = nullptr;    // pinned: max(n + p + cdim, W size)
+    size_t hbuf_doubles = 0;
+    SyrkPlan planS, planAtA, planK;
+    PotrfWork pw;
+    float t_syrk = 0, t_potrf = 0, t_schur = 0, t_factor = 0, t_solve = 0;
+};
+
+static int bind(const mi355kkt_solver* h) {
+    KKT_HIP_CHECK(hipSetDevice(h->device));
+    return 0;
+}
+
+extern "C" {
+
+int mi355kkt_version(void) { return 100; }
+const char* mi355kkt_last_error(void) { return g_err; }
+
+int mi355kkt_device_count(void) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int mi355kkt_device_info(int device, char* name, int len, int* num_cus, size_t* mem_bytes) {
+    hipDeviceProp_t prop;
+    KKT_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    if (name && len > 0) {
+        snprintf(name, (size_t)len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (num_cus) *num_cus = prop.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = prop.totalGlobalMem;
+    return 0;
+}
+
+int mi355kkt_dev_malloc(void** ptr, size_t bytes) {
+    KKT_HIP_CHECK(hipMalloc(ptr, bytes ? bytes : 8));
+    return 0;
+}
+int mi355kkt_dev_free(void* ptr) {
+    if (ptr) KKT_HIP_CHECK(hipFree(ptr));
+    return 0;
+}
+int mi355kkt_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    if (bytes) KKT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+int mi355kkt_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    if (bytes) KKT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+int mi355kkt_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+    if (bytes) KKT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    return 0;
+}
+int mi355kkt_device_synchronize(void) {
+    KKT_HIP_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+
+static size_t dmax(size_t a, size_t b) { return a > b ? a : b; }
+
+int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, int ml, int nq, const int* q, int ns,
+                    const int* s) {
+    if (!out || n < 0 || p < 0 || ml < 0 || nq < 0 || ns < 0 || kind < 0 || kind > 3) {
+        set_last_error("mi355kkt_create: invalid argument");
+        return MI355KKT_EINVAL;
+    }
+    if (mi355kkt_device_count() <= device) {
+        set_last_error("mi355kkt_create: HIP device %d not available (count=%d)", device, mi355kkt_device_count());
+        return MI355KKT_EHIP;
+    }
+    mi355kkt_solver* h = new mi355kkt_solver();
+    h->device = device;
+    h->kind = kind;
+    h->n = n;
+    h->p = p;
+    h->ml = ml;
+    int64_t cdim = ml;
+    for (int k = 0; k < nq; ++k) {
+        if (q[k] < 1) { delete h; set_last_error("q[%d] < 1", k); return MI355KKT_EINVAL; }
+        h->q.push_back(q[k]);
+        cdim += q[k];
+    }
+    for (int k = 0; k < ns; ++k) {
+        if (s[k] < 0) { delete h; set_last_error("s[%d] < 0", k); return MI355KKT_EINVAL; }
+        h->s.push_back(s[k]);
+        cdim += (int64_t)s[k] * s[k];
+    }
+    if (cdim > INT32_MAX) { delete h; set_last_error("cdim overflows int"); return MI355KKT_EINVAL; }
+    h->cdim = (int)cdim;
+    int rc = 0;
+    auto fail = [&](int code) { mi355kkt_destroy(h); return code; };
+    if (hipSetDevice(device) != hipSuccess) return fail(MI355KKT_EHIP);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(MI355KKT_EHIP);
+    h->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) return fail(MI355KKT_EHIP);
+    for (auto& e : h->ev)
+        if (hipEventCreate(&e) != hipSuccess) return fail(MI355KKT_EHIP);
+    auto alloc = [&](double** ptr, size_t doubles) -> int {
+        if (hipMalloc(ptr, sizeof(double) * dmax(doubles, 1)) != hipSuccess) {
+            set_last_error("hipMalloc of %zu doubles failed", doubles);
+            return MI355KKT_ENOMEM;
+        }
+        return 0;
+    };
+    const size_t N = (size_t)n, P = (size_t)p, C = (size_t)h->cdim;
+    if ((rc = alloc(&h->dW, C))) return fail(rc);
+    if ((rc = alloc(&h->dS, N * N))) return fail(rc);
+    if ((rc = alloc(&h->dAsct, N * P))) return fail(rc);
+    if ((rc = alloc(&h->dK, P * P))) return fail(rc);
+    if ((rc = alloc(&h->dx, N))) return fail(rc);
+    if ((rc = alloc(&h->dy, P))) return fail(rc);
+    if ((rc = alloc(&h->dz, C))) return fail(rc);
+    if ((rc = alloc(&h->dzs, C))) return fail(rc);
+    if ((rc = alloc(&h->dtn, N))) return fail(rc);
+    if ((rc = alloc(&h->dtp, P))) return fail(rc);
+    if ((rc = alloc(&h->dwork, dmax(gemv_work_doubles(h->cdim, n), gemv_work_doubles(n, p))))) return fail(rc);
+    h->hbuf_doubles = dmax(N + P + C, 2 * C) + 8;
+    if (hipHostMalloc(&h->hbuf, sizeof(double) * h->hbuf_doubles) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    if ((rc = potrf_work_init(h->pw))) return fail(rc);
+    if ((rc = build_syrk_plan(h->planS, n, h->cdim, h->num_cus))) return fail(rc);
+    if (p > 0) {
+        if ((rc = build_syrk_plan(h->planAtA, n, p, h->num_cus))) return fail(rc);
+        if ((rc = build_syrk_plan(h->planK, p, n, h->num_cus))) return fail(rc);
+    }
+    *out = h;
+    return 0;
+}
+
+void mi355kkt_destroy(mi355kkt_solver* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->st) (void)hipStreamSynchronize(h->st);
+    double* bufs[] = {h->G_owned, h->A_owned, h->H_owned, h->dW, h->dS, h->dAsct, h->dK,
+                      h->dx, h->dy, h->dz, h->dzs, h->dtn, h->dtp, h->dwork};
+    for (double* b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->hbuf) (void)hipHostFree(h->hbuf);
+    potrf_work_free(h->pw);
+    free_syrk_plan(h->planS);
+    free_syrk_plan(h->planAtA);
+    free_syrk_plan(h->planK);
+    for (auto& e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->st) (void)hipStreamDestroy(h->st);
+    delete h;
+}
+
+static int upload_dense(double** owned, const double* src, int64_t ld, int rows, int cols, hipStream_t st) {
+    if (*owned) { (void)hipFree(*owned); *owned = nullptr; }
+    const size_t bytes = sizeof(double) * dmax((size_t)rows * cols, 1);
+    KKT_HIP_CHECK(hipMalloc(owned, bytes));
+    if (rows > 0 && cols > 0)
+        KKT_HIP_CHECK(hipMemcpy2D(*owned, sizeof(double) * rows, src, sizeof(double) * ld, sizeof(double) * rows, cols,
+                                  hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mi355kkt_set_G_dense(mi355kkt_solver* h, const double* G, int64_t ldG) {
+    if (!h || (!G && h->cdim > 0 && h->n > 0) || ldG < (h->cdim > 1 ? h->cdim : 1)) {
+        set_last_error("set_G_dense: invalid argument");
+        return MI355KKT_EINVAL;
+    }
+    if (int e = bind(h)) return e;
+    if (int e = upload_dense(&h->G_owned, G, ldG, h->cdim, h->n, h->st)) return e;
+    h->dG = h->G_owned;
+    h->ldG = h->cdim > 1 ? h->cdim : 1;
+    return 0;
+}
+
+int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t* rowind, const double* values) {
+    if (!h || !colptr) { set_last_error("set_G_csc: invalid argument"); return MI355KKT_EINVAL; }
+    std::vector<double> dense((size_t)h->cdim * h->n, 0.0);
+    for (int j = 0; j < h->n; ++j)
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+            if (rowind[k] < 0 || rowind[k] >= h->cdim) { set_last_error("set_G_csc: row index out of range"); return MI355KKT_EINVAL; }
+            dense[(size_t)j * h->cdim + rowind[k]] += values[k];
+        }
+    return mi355kkt_set_G_dense(h, dense.data(), h->cdim > 1 ? h->cdim : 1);
+}
+
+int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA) {
+    if (!h || (!A && h->p > 0 && h->n > 0) || ldA < (h->p > 1 ? h->p : 1)) {
+        set_last_error("set_A_dense: invalid argument");
+        return MI355KKT_EINVAL;
+    }
+    if (int e = bind(h)) return e;
+    if (int e = upload_dense(&h->A_owned, A, ldA, h->p, h->n, h->st)) return e;
+    h->dA = h->A_owned;
+    h->ldA = h->p > 1 ? h->p : 1;
+    return 0;
+}
+
+int mi355kkt_set_G_device(mi355kkt_solver* h, const double* dG, int64_t ldG) {
+    if (!h || ldG < (h->cdim > 1 ? h->cdim : 1)) { set_last_error("set_G_device: invalid argument"); return MI355KKT_EINVAL; }
+    h->dG = dG;
+    h->ldG = ldG;
+    return 0;
+}
+int mi355kkt_set_A_device(mi355kkt_solver* h, const double* dA, int64_t ldA) {
+    if (!h || ldA < (h->p > 1 ? h->p : 1)) { set_last_error("set_A_device: invalid argument"); return MI355KKT_EINVAL; }
+    h->dA = dA;
+    h->ldA = ldA;
+    return 0;
+}
+
+int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) {
+    if (!h) return MI355KKT_EINVAL;
+    if (int e = bind(h)) return e;
+    if (!H) {
+        h->dH = nullptr;
+        return 0;
+    }
+    if (ldH < (h->n > 1 ? h->n : 1)) { set_last_error("set_H_dense: ldH too small"); return MI355KKT_EINVAL; }
+    if (!h->H_owned) KKT_HIP_CHECK(hipMalloc(&h->H_owned, sizeof(double) * dmax((size_t)h->n * h->n, 1)));
+    if (h->n > 0)
+        KKT_HIP_CHECK(hipMemcpy2D(h->H_owned, sizeof(double) * h->n, H, sizeof(double) * ldH, sizeof(double) * h->n,
+                                  h->n, hipMemcpyHostToDevice));
+    h->dH = h->H_owned;
+    h->ldH = h->n > 1 ? h->n : 1;
+    return 0;
+}
+int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH) {
+    if (!h) return MI355KKT_EINVAL;
+    h->dH = dH;
+    h->ldH = ldH;
+    return 0;
+}
+int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg) {
+    if (!h || !(reg >= 0.0)) { set_last_error("set_kktreg: reg must be >= 0"); return MI355KKT_EINVAL; }
+    h->kktreg = reg;
+    return 0;
+}
+
+// info word -> host (synchronises the stream)
+static int fetch_info(mi355kkt_solver* h, int* info) {
+    KKT_HIP_CHECK(hipMemcpyAsync(h->pw.h_info, h->pw.d_info, sizeof(int), hipMemcpyDeviceToHost, h->st));
+    KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+    *info = *h->pw.h_info;
+    return 0;
+}
+
+// assemble S = H + [reg I] + Gs' Gs [+ A'A]
+static int assemble_S(mi355kkt_solver* h, bool add_AtA) {
+    if (int e = launch_syrk_scaled(h->planS, h->dG, h->ldG, h->ml > 0 ? h->dW : nullptr, h->dS, h->n, h->dH, h->ldH, h->st))
+        return e;
+    if (h->kktreg != 0.0 && h->n > 0) hipLaunchKernelGGL(diag_add_kernel, g1(h->n), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->n, h->kktreg);
+    if (add_AtA && h->p > 0)
+        if (int e = launch_syrk_scaled(h->planAtA, h->dA, h->ldA, nullptr, h->dS, h->n, h->dS, h->n, h->st)) return e;
+    return 0;
+}
+
+int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
+    if (!h || !W) { set_last_error("factor: null argument"); return MI355KKT_EINVAL; }
+    if (!h->q.empty() || !h->s.empty()) {
+        set_last_error("factor: second-order / semidefinite cones not implemented on the device yet");
+        return MI355KKT_ENOTIMPL;
+    }
+    if (h->ml > 0 && !W->di) { set_last_error("factor: W.di missing"); return MI355KKT_EINVAL; }
+    if ((h->cdim > 0 && h->n > 0 && !h->dG) || (h->p > 0 && h->n > 0 && !h->dA)) {
+        set_last_error("factor: G / A not set");
+        return MI355KKT_EINVAL;
+    }
+    if (int e = bind(h)) return e;
+    h->factored = false;
+    const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);   // K[z,z] = -(1+reg): fold into the row scaling
+    KKT_HIP_CHECK(hipEventRecord(h->ev[0], h->st));
+    if (h->ml > 0) hipLaunchKernelGGL(scaled_copy_kernel, g1(h->ml), dim3(256), 0, h->st, W->di, h->dW, h->ml, zscale);
+    if (int e = assemble_S(h, h->singular)) return e;
+    KKT_HIP_CHECK(hipEventRecord(h->ev[1], h->st));
+    if (int e = launch_potrf(h->dS, h->n, h->n, h->pw, h->st)) return e;
+    KKT_HIP_CHECK(hipEventRecord(h->ev[2], h->st));
+    int info = 0;
+    if (int e = fetch_info(h, &info)) return e;
+    if (info > 0 && h->firstcall && !h->singular && h->p > 0) {
+        // reference misc.py:1433-1447: singular S on the first call -> S += A'A for good
+        h->singular = true;
+        if (int e = assemble_S(h, true)) return e;
+        if (int e = launch_potrf(h->dS, h->n, h->n, h->pw, h->st)) return e;
+        KKT_HIP_CHECK(hipEventRecord(h->ev[2], h->st));
+        if (int e = fetch_info(h, &info)) return e;
+    }
+    h->firstcall = false;
+    if (info > 0) return info;
+    if (h->p > 0) {
+        // Asct = L^-1 A'
+        hipLaunchKernelGGL(transpose_kernel, dim3((h->n + 31) / 32, (h->p + 31) / 32), dim3(32, 8), 0, h->st, h->dA,
+                           h->ldA, h->p, h->n, h->dAsct);
+        if (int e = launch_trsm_lower(h->dS, h->n, h->n, h->dAsct, h->n, h->p, 0, h->st)) return e;
+        // K = Asct' Asct [+ reg I]
+        if (int e = launch_syrk_scaled(h->planK, h->dAsct, h->n, nullptr, h->dK, h->p, nullptr, 0, h->st)) return e;
+        if (h->kktreg != 0.0) hipLaunchKernelGGL(diag_add_kernel, g1(h->p), dim3(256), 0, h->st, h->dK, (int64_t)h->p, h->p, h->kktreg);
+        if (int e = launch_potrf(h->dK, h->p, h->p, h->pw, h->st)) return e;
+    }
+    KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
+    if (int e = fetch_info(h, &info)) return e;
+    (void)hipEventElapsedTime(&h->t_syrk, h->ev[0], h->ev[1]);
+    (void)hipEventElapsedTime(&h->t_potrf, h->ev[1], h->ev[2]);
+    (void)hipEventElapsedTime(&h->t_schur, h->ev[2], h->ev[3]);
+    (void)hipEventElapsedTime(&h->t_factor, h->ev[0], h->ev[3]);
+    if (info > 0) return info;
+    h->factored = true;
+    return 0;
+}
+
+int mi355kkt_factor(mi355kkt_solver* h, const mi355kkt_scaling* W) {
+    if (!h || !W) { set_last_error("factor: null argument"); return MI355KKT_EINVAL; }
+    if (h->ml > 0 && !W->di) { set_last_error("factor: W.di missing"); return MI355KKT_EINVAL; }
+    if (int e = bind(h)) return e;
+    mi355kkt_scaling Wd = {};
+    if (h->ml > 0) {
+        memcpy(h->hbuf, W->di, sizeof(double) * h->ml);
+        // staged into dzs (free between solves) so that dW can hold the effective scaling
+        KKT_HIP_CHECK(hipMemcpyAsync(h->dzs, h->hbuf, sizeof(double) * h->ml, hipMemcpyHostToDevice, h->st));
+        Wd.di = h->dzs;
+    }
+    return mi355kkt_factor_device(h, &Wd);
+}
+
+int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz) {
+    if (!h) return MI355KKT_EINVAL;
+    if (!h->factored) { set_last_error("solve: no valid factorisation"); return MI355KKT_EINVAL; }
+    if (int e = bind(h)) return e;
+    hipStream_t st = h->st;
+    const int n = h->n, p = h->p, m = h->cdim;
+    KKT_HIP_CHECK(hipEventRecord(h->ev[4], st));
+    // zs = W^-T bz ;  x += Gs' zs                                     (misc.py:1513, :1524)
+    if (int e = launch_gemv_t_scaled(h->dG, h->ldG, m, n, h->dW, dz, h->dzs, dx, h->dwork, st)) return e;
+    if (h->singular && p > 0)                                       // x += A' by  (:1527)
+        if (int e = launch_gemv_t_scaled(h->dA, h->ldA, p, n, nullptr, dy, h->dtp, dx, nullptr, st)) return e;
+    if (int e = launch_trsm_lower(h->dS, n, n, dx, n, 1, 0, st)) return e;          // :1529
+    if (p > 0) {
+        // y := K^-1 (Asct' x - y)                                     (:1541-1543)
+        hipLaunchKernelGGL(scal_kernel, g1(p), dim3(256), 0, st, dy, p, -1.0);
+        if (int e = launch_gemv_t_scaled(h->dAsct, n, n, p, nullptr, dx, h->dtn, dy, nullptr, st)) return e;
+        if (int e = launch_trsm_lower(h->dK, p, p, dy, p, 1, 0, st)) return e;
+        if (int e = launch_trsm_lower(h->dK, p, p, dy, p, 1, 1, st)) return e;
+        // x := x - Asct y                                             (:1553)
+        if (int e = launch_gemv_n_scaled(h->dAsct, n, n, p, nullptr, dy, dx, dx, -1.0, 1.0, h->dwork, st)) return e;
+    }
+    if (int e = launch_trsm_lower(h->dS, n, n, dx, n, 1, 1, st)) return e;          // :1555
+    // z := Gs x - zs   (/ sqrt(1+reg) when the z-block pivot is -(1+reg))       (:1563)
+    const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);
+    if (int e = launch_gemv_n_scaled(h->dG, h->ldG, m, n, h->dW, dx, h->dzs, dz, zscale, -zscale, h->dwork, st)) return e;
+    KKT_HIP_CHECK(hipEventRecord(h->ev[5], st));
+    return 0;
+}
+
+int mi355kkt_sync(mi355kkt_solver* h) {
+    if (!h) return MI355KKT_EINVAL;
+    KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+    return 0;
+}
+
+int mi355kkt_solve(mi355kkt_solver* h, double* x, double* y, double* z) {
+    if (!h) return MI355KKT_EINVAL;
+    if (!h->factored) { set_last_error("solve: no valid factorisation"); return MI355KKT_EINVAL; }
+    if (int e = bind(h)) return e;
+    const size_t n = h->n, p = h->p, m = h->cdim;
+    if ((n && !x) || (p && !y) || (m && !z)) { set_last_error("solve: null vector"); return MI355KKT_EINVAL; }
+    double* hb = h->hbuf;
+    if (n) memcpy(hb, x, sizeof(double) * n);
+    if (p) memcpy(hb + n, y, sizeof(double) * p);
+    if (m) memcpy(hb + n + p, z, sizeof(double) * m);
+    if (n) KKT_HIP_CHECK(hipMemcpyAsync(h->dx, hb, sizeof(double) * n, hipMemcpyHostToDevice, h->st));
+    if (p) KKT_HIP_CHECK(hipMemcpyAsync(h->dy, hb + n, sizeof(double) * p, hipMemcpyHostToDevice, h->st));
+    if (m) KKT_HIP_CHECK(hipMemcpyAsync(h->dz, hb + n + p, sizeof(double) * m, hipMemcpyHostToDevice, h->st));
+    if (int e = mi355kkt_solve_device(h, h->dx, h->dy, h->dz)) return e;
+    if (n) KKT_HIP_CHECK(hipMemcpyAsync(hb, h->dx, sizeof(double) * n, hipMemcpyDeviceToHost, h->st));
+    if (p) KKT_HIP_CHECK(hipMemcpyAsync(hb + n, h->dy, sizeof(double) * p, hipMemcpyDeviceToHost, h->st));
+    if (m) KKT_HIP_CHECK(hipMemcpyAsync(hb + n + p, h->dz, sizeof(double) * m, hipMemcpyDeviceToHost, h->st));
+    KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+    if (n) memcpy(x, hb, sizeof(double) * n);
+    if (p) memcpy(y, hb + n, sizeof(double) * p);
+    if (m) memcpy(z, hb + n + p, sizeof(double) * m);
+    return 0;
+}
+
+int mi355kkt_is_singular_mode(const mi355kkt_solver* h) { return (h && h->singular) ? 1 : 0; }
+
+int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n) {
+    if (!h || !out) return 0;
+    (void)hipStreamSynchronize(h->st);
+    if (hipEventQuery(h->ev[5]) == hipSuccess && hipEventQuery(h->ev[4]) == hipSuccess)
+        (void)hipEventElapsedTime(&h->t_solve, h->ev[4], h->ev[5]);
+    const float v[5] = {h->t_syrk, h->t_potrf, h->t_schur, h->t_factor, h->t_solve};
+    int k = 0;
+    for (; k < n && k < 5; ++k) out[k] = v[k];
+    return k;
+}
+
+int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL) {
+    if (!h || !L || ldL < h->n) return MI355KKT_EINVAL;
+    if (int e = bind(h)) return e;
+    KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+    if (h->n > 0)
+        KKT_HIP_CHECK(hipMemcpy2D(L, sizeof(double) * ldL, h->dS, sizeof(double) * h->n, sizeof(double) * h->n, h->n,
+                                  hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- stand-alone operators -----------------------------------------------------------------------------
+struct OpTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    float* ms;
+    explicit OpTimer(float* m) : ms(m) {
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, nullptr);
+    }
+    int finish() {
+        (void)hipEventRecord(b, nullptr);
+        hipError_t e = hipEventSynchronize(b);
+        float t = 0;
+        (void)hipEventElapsedTime(&t, a, b);
+        if (ms) *ms = t;
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+        if (e != hipSuccess) {
+            set_last_error("op failed: %s", hipGetErrorString(e));
+            return MI355KKT_EHIP;
+        }
+        return 0;
+    }
+};
+
+static int cur_num_cus() {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    return prop.multiProcessorCount;
+}
+
+int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
+                            int64_t ldH, double* dS, int64_t ldS, float* ms) {
+    static SyrkPlan plan;   // cached for repeated calls with one shape (profiling loops)
+    if (plan.n != n || plan.K != m || !plan.d_items)
+        if (int e = build_syrk_plan(plan, n, m, cur_num_cus())) return e;
+    OpTimer t(ms);
+    if (int e = launch_syrk_scaled(plan, dG, ldG, ddi, dS, ldS, dH, ldH, nullptr)) return e;
+    return t.finish();
+}
+
+int mi355kkt_op_potrf(double* dA, int64_t ldA, int n, int* info, float* ms) {
+    PotrfWork w;
+    if (int e = potrf_work_init(w)) return e;
+    OpTimer t(ms);
+    int rc = launch_potrf(dA, ldA, n, w, nullptr);
+    if (!rc) rc = t.finish();
+    if (!rc) {
+        if (hipMemcpy(w.h_info, w.d_info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = MI355KKT_EHIP;
+        if (info) *info = *w.h_info;
+    }
+    potrf_work_free(w);
+    return rc;
+}
+
+int mi355kkt_op_trsm_lower(const double* dL, int64_t ldL, int n, double* dX, int64_t ldX, int nrhs, int trans,
+                           float* ms) {
+    OpTimer t(ms);
+    if (int e = launch_trsm_lower(dL, ldL, n, dX, ldX, nrhs, trans, nullptr)) return e;
+    return t.finish();
+}
+
+int mi355kkt_op_gemv_t_scaled(const double* dG, int64_t ldG, int m, int n, const double* dw, const double* dz,
+                              double* dzs, double* dy, float* ms) {
+    double* work = nullptr;
+    KKT_HIP_CHECK(hipMalloc(&work, sizeof(double) * (size_t)(m > 0 ? m : 1)));
+    OpTimer t(ms);
+    int rc = launch_gemv_t_scaled(dG, ldG, m, n, dw, dz, dzs, dy, work, nullptr);
+    if (!rc) rc = t.finish();
+    (void)hipFree(work);
+    return rc;
+}
+
+int mi355kkt_op_gemv_n_scaled(const double* dG, int64_t ldG, int m, int n, const double* dw, const double* dx,
+                              const double* dzs, double* dz, float* ms) {
+    double* work = nullptr;
+    KKT_HIP_CHECK(hipMalloc(&work, sizeof(double) * gemv_work_doubles(m, n)));
+    OpTimer t(ms);
+    int rc = launch_gemv_n_scaled(dG, ldG, m, n, dw, dx, dzs, dz, 1.0, -1.0, work, nullptr);
+    if (!rc) rc = t.finish();
+    (void)hipFree(work);
+    return rc;
+}
+
+}  // extern "C"

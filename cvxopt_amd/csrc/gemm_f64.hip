@@ -1,0 +1,438 @@
+// FP64 MFMA (v_mfma_f64_16x16x4_f64) level-3 kernels for gfx950 / MI355X.
+//
+//   syrk_tn_kernel     S(lower) = P(lower) + Gs' Gs,  Gs = diag(di) G applied while staging
+//                      (replaces reference misc.py:1418 `Gs = diag(di) G` + :1422/:1451 base.syrk +
+//                       :1426/:1455 `S += H`; and misc.py:1271-1276 scale+syrk+`K += H` for 'l' cones)
+//   nt_update_kernel   C -= A B'   (Cholesky trailing / panel updates; the dsyrk/dgemm inside dpotrf,
+//                       reference src/C/lapack.c:1508)
+//
+// One 256-thread workgroup (4 waves, 2x2) owns a 128x128 tile of C; each wave owns 64x64 = 4x4 MFMA
+// tiles (16 accumulators of 4 doubles = 128 VGPRs).  Operand tiles are staged global -> registers ->
+// LDS (the scaling by di rides on the register hop), double buffered, one barrier per 16-deep k-step.
+// MFMA operand roles are chosen so that the D layout (col = lane&15) runs along C's contiguous (row)
+// dimension: A-operand <- C-column block (J), B-operand <- C-row block (I).
+#include "kkt_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+
+namespace mi355kkt {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(8))) d2u { double x, y; };   // 8-byte aligned pair (dwordx4 load)
+
+#define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------
+// 64x64 wave tile: acc[t][u] += Js[t-th 16 rows][k] * Is[u-th 16 rows][k] over one BK slab.
+//   SI / SK: LDS element strides along the tile index / along k.
+// ---------------------------------------------------------------------------------------------------
+template <int SI, int SK>
+__device__ __forceinline__ void wave_mma(const double* __restrict__ Js, const double* __restrict__ Is,
+                                         d4 (&acc)[4][4], int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 4) {
+        double a[4], b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a[t] = Js[(t * 16 + li) * SI + (kk + lk) * SK];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = Is[(u * 16 + li) * SI + (kk + lk) * SK];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[t][u] = MFMA_F64(a[t], b[u], acc[t][u]);
+    }
+}
+
+__device__ __forceinline__ void zero_acc(d4 (&acc)[4][4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = d4{0.0, 0.0, 0.0, 0.0};
+}
+
+// ===================================================================================================
+// Scaled SYRK, "TN": S[i,j] = P[i,j] + sum_k di[k]^2 G[k,i] G[k,j],  G column-major (k contiguous)
+// ===================================================================================================
+// staging map: thread -> columns (tid>>3) + 32 r (r = 0..3), k pair (tid&7)*2
+template <bool FAST>
+__device__ __forceinline__ void tn_load(const double* __restrict__ G, int64_t ldg, int col0, int n,
+                                        int k, int kend, int sc, double (&reg)[8]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int c = col0 + sc + 32 * r;
+        const double* p = G + (int64_t)c * ldg + k;
+        if (FAST) {
+            const d2u v = *reinterpret_cast<const d2u*>(p);
+            reg[2 * r] = v.x;
+            reg[2 * r + 1] = v.y;
+        } else {
+            const bool cok = c < n;
+            reg[2 * r] = (cok && k < kend) ? p[0] : 0.0;
+            reg[2 * r + 1] = (cok && k + 1 < kend) ? p[1] : 0.0;
+        }
+    }
+}
+
+__device__ __forceinline__ void tn_store(double* __restrict__ Xs, int sc, int sk, const double (&reg)[8],
+                                         double w0, double w1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        d2 v = {reg[2 * r] * w0, reg[2 * r + 1] * w1};
+        *reinterpret_cast<d2*>(Xs + (sc + 32 * r) * LDT_K + sk) = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
+    const double* __restrict__ G, int64_t ldg, const double* __restrict__ di, int n, int fast_ok,
+    const SyrkItem* __restrict__ items, double* __restrict__ C, int64_t ldc,
+    const double* __restrict__ P, int64_t ldp, double* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const SyrkItem it = items[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wj = wave >> 1, wi = wave & 1;
+    const int i0 = it.ti * TILE, j0 = it.tj * TILE;
+    const bool diag = (it.ti == it.tj);
+    const int sc = tid >> 3, sk = (tid & 7) * 2;
+    const bool tile_fast = fast_ok && (i0 + TILE <= n) && (j0 + TILE <= n);
+
+    // stage s: J operand at smem + s*2*STAGE, I operand right after (aliased for diagonal tiles)
+    const int ioff = diag ? 0 : STAGE_DOUBLES;
+    auto sJ = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES; };
+    auto sI = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES + ioff; };
+
+    d4 acc[4][4];
+    zero_acc(acc);
+
+    const int nkt = (it.k1 - it.k0 + BK - 1) / BK;
+    double rJ[8], rI[8], w0 = 1.0, w1 = 1.0;
+
+    auto fetch = [&](int kt) {
+        const int k = it.k0 + kt * BK + sk;
+        const bool fast = tile_fast && (it.k0 + (kt + 1) * BK <= it.k1);
+        if (fast) {
+            tn_load<true>(G, ldg, j0, n, k, it.k1, sc, rJ);
+            if (!diag) tn_load<true>(G, ldg, i0, n, k, it.k1, sc, rI);
+        } else {
+            tn_load<false>(G, ldg, j0, n, k, it.k1, sc, rJ);
+            if (!diag) tn_load<false>(G, ldg, i0, n, k, it.k1, sc, rI);
+        }
+        if (di) {
+            w0 = (k < it.k1) ? di[k] : 0.0;
+            w1 = (k + 1 < it.k1) ? di[k + 1] : 0.0;
+        }
+    };
+    auto stash = [&](int s) {
+        tn_store(sJ(s), sc, sk, rJ, w0, w1);
+        if (!diag) tn_store(sI(s), sc, sk, rI, w0, w1);
+    };
+
+    if (nkt > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) fetch(kt + 1);
+        wave_mma<LDT_K, 1>(sJ(cur) + wj * 64 * LDT_K, sI(cur) + wi * 64 * LDT_K, acc, lane);
+        if (kt + 1 < nkt) stash(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds D[row=(lane>>4)+4r -> j][col=lane&15 -> i]
+    const int li = lane & 15, lq = lane >> 4;
+    if (it.slot < 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + wi * 64 + u * 16 + li;
+                    const int j = j0 + wj * 64 + t * 16 + lq + 4 * r;
+                    if (i < n && j < n && i >= j) {
+                        double v = acc[t][u][r];
+                        if (P) v += P[i + (int64_t)j * ldp];
+                        C[i + (int64_t)j * ldc] = v;
+                    }
+                }
+    } else {
+        double* S = slabs + (int64_t)it.slot * TILE * TILE;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int il = wi * 64 + u * 16 + li;
+                    const int jl = wj * 64 + t * 16 + lq + 4 * r;
+                    S[il + jl * TILE] = acc[t][u][r];
+                }
+    }
+}
+
+// Deterministic fix-up for split tiles: C = P + slab[first] + slab[first+1] + ...  (fixed order)
+__global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkItem* __restrict__ tiles, int n,
+                                                          const double* __restrict__ slabs,
+                                                          double* __restrict__ C, int64_t ldc,
+                                                          const double* __restrict__ P, int64_t ldp) {
+    const SyrkItem it = tiles[blockIdx.x];
+    const int i0 = it.ti * TILE, j0 = it.tj * TILE;
+    for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+        const int il = e & (TILE - 1), jl = e >> 7;
+        const int i = i0 + il, j = j0 + jl;
+        if (i < n && j < n && i >= j) {
+            double v = P ? P[i + (int64_t)j * ldp] : 0.0;
+            for (int s = 0; s < it.nparts; ++s) v += slabs[(int64_t)(it.first + s) * TILE * TILE + e];
+            C[i + (int64_t)j * ldc] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Host: static schedule.  Tiles of the lower triangle are ordered by 8x8 super-tiles so that the
+// workgroups one XCD runs concurrently (ids = x mod 8, observed dispatch) share operand panels in
+// that XCD's private L2; whole rounds run unsplit tiles, the remainder is split along k so the last
+// round is also full (hybrid stream-K), with slabs summed in a fixed order by syrk_reduce_kernel.
+// ---------------------------------------------------------------------------------------------------
+int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus) {
+    free_syrk_plan(plan);
+    plan.n = n;
+    plan.K = K;
+    if (n <= 0) return 0;
+    const int nt = (n + TILE - 1) / TILE;
+    std::vector<std::pair<int, int>> seq;
+    const int ns = (nt + 7) / 8;
+    for (int SI = 0; SI < ns; ++SI)
+        for (int SJ = 0; SJ <= SI; ++SJ)
+            for (int a = 0; a < 8; ++a)
+                for (int b = 0; b < 8; ++b) {
+                    const int ti = SI * 8 + a, tj = SJ * 8 + b;
+                    if (ti < nt && tj <= ti) seq.emplace_back(ti, tj);
+                }
+    const int T = (int)seq.size();
+    const int slots = std::max(8, 2 * num_cus);
+    const int nfull = (T / slots) * slots;
+    const int R = T - nfull;
+    const int max_split = std::max(1, K / (8 * BK));   // at least 8 k-steps per piece
+    int split = 1;
+    if (R > 0) split = std::max(1, std::min(slots / R, max_split));
+
+    std::vector<SyrkItem> ordered_full, items, split_tiles;
+    for (int t = 0; t < nfull; ++t) ordered_full.push_back({seq[t].first, seq[t].second, 0, K, -1, 0, 0, 0});
+    // XCD-contiguous permutation of the full tiles: id -> xcd = id % 8 gets a contiguous chunk
+    {
+        const int N = nfull, q = N / 8, r = N % 8;
+        items.resize(N);
+        for (int id = 0; id < N; ++id) {
+            const int x = id % 8, l = id / 8;
+            const int pos = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
+            items[id] = ordered_full[pos];
+        }
+    }
+    int nslabs = 0;
+    for (int t = nfull; t < T; ++t) {
+        if (split == 1) {
+            items.push_back({seq[t].first, seq[t].second, 0, K, -1, 0, 0, 0});
+            continue;
+        }
+        // k-chunks aligned to BK
+        const int nkt = (K + BK - 1) / BK;
+        const int parts = std::min(split, nkt);
+        SyrkItem st = {seq[t].first, seq[t].second, 0, K, -1, nslabs, parts, 0};
+        for (int s = 0; s < parts; ++s) {
+            const int ka = (int)((int64_t)nkt * s / parts) * BK;
+            const int kb = std::min(K, (int)((int64_t)nkt * (s + 1) / parts) * BK);
+            items.push_back({seq[t].first, seq[t].second, ka, kb, nslabs + s, nslabs, parts, 0});
+        }
+        nslabs += parts;
+        split_tiles.push_back(st);
+    }
+    plan.nitems = (int)items.size();
+    plan.nslabs = nslabs;
+    plan.nsplit_tiles = (int)split_tiles.size();
+    KKT_HIP_CHECK(hipMalloc(&plan.d_items, sizeof(SyrkItem) * std::max<size_t>(1, items.size())));
+    KKT_HIP_CHECK(hipMemcpy(plan.d_items, items.data(), sizeof(SyrkItem) * items.size(), hipMemcpyHostToDevice));
+    if (!split_tiles.empty()) {
+        KKT_HIP_CHECK(hipMalloc(&plan.d_split_tiles, sizeof(SyrkItem) * split_tiles.size()));
+        KKT_HIP_CHECK(hipMemcpy(plan.d_split_tiles, split_tiles.data(), sizeof(SyrkItem) * split_tiles.size(),
+                                hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(hipMalloc(&plan.d_slabs, sizeof(double) * (size_t)nslabs * TILE * TILE));
+    }
+    return 0;
+}
+
+void free_syrk_plan(SyrkPlan& plan) {
+    if (plan.d_items) (void)hipFree(plan.d_items);
+    if (plan.d_split_tiles) (void)hipFree(plan.d_split_tiles);
+    if (plan.d_slabs) (void)hipFree(plan.d_slabs);
+    plan = SyrkPlan();
+}
+
+static constexpr size_t kGemmLds = sizeof(double) * 4 * STAGE_DOUBLES;   // 73,728 B
+
+int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const double* di, double* C,
+                       int64_t ldc, const double* P, int64_t ldp, hipStream_t st) {
+    if (plan.n == 0) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_tn_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        attr_set = true;
+    }
+    const int fast_ok = ((reinterpret_cast<uintptr_t>(G) & 7) == 0) ? 1 : 0;   // 8-byte aligned pairs suffice
+    hipLaunchKernelGGL(syrk_tn_kernel, dim3(plan.nitems), dim3(256), kGemmLds, st, G, ldg, di, plan.n, fast_ok,
+                       plan.d_items, C, ldc, P, ldp, plan.d_slabs);
+    KKT_HIP_CHECK(hipGetLastError());
+    if (plan.nsplit_tiles) {
+        hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.nsplit_tiles), dim3(256), 0, st, plan.d_split_tiles,
+                           plan.n, plan.d_slabs, C, ldc, P, ldp);
+        KKT_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+// ===================================================================================================
+// "NT" update: C -= A B'   (A: rows of C, M-major; B: cols of C, M-major; K small)
+// ===================================================================================================
+// staging map: thread -> idx pair (tid&63)*2, k = (tid>>6) + 4 r
+template <bool FAST>
+__device__ __forceinline__ void nt_load(const double* __restrict__ X, int64_t ldx, int row0, int nrows,
+                                        int k0, int K, int tid, double (&reg)[8]) {
+    const int ip = (tid & 63) * 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + (tid >> 6) + 4 * r;
+        const double* p = X + (int64_t)k * ldx + row0 + ip;
+        if (FAST) {
+            const d2u v = *reinterpret_cast<const d2u*>(p);
+            reg[2 * r] = v.x;
+            reg[2 * r + 1] = v.y;
+        } else {
+            const bool kok = k < K;
+            reg[2 * r] = (kok && row0 + ip < nrows) ? p[0] : 0.0;
+            reg[2 * r + 1] = (kok && row0 + ip + 1 < nrows) ? p[1] : 0.0;
+        }
+    }
+}
+
+__device__ __forceinline__ void nt_store(double* __restrict__ Xs, int tid, const double (&reg)[8]) {
+    const int ip = (tid & 63) * 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = (tid >> 6) + 4 * r;
+        d2 v = {reg[2 * r], reg[2 * r + 1]};
+        *reinterpret_cast<d2*>(Xs + k * LDT_M + ip) = v;
+    }
+}
+
+// SYM: A == B, lower-triangular tile set (linear triangular blockIdx.x), only i >= j written.
+template <bool SYM>
+__global__ __launch_bounds__(256, 2) void nt_update_kernel(double* __restrict__ C, int64_t ldc,
+                                                           const double* __restrict__ A, int64_t lda,
+                                                           const double* __restrict__ B, int64_t ldb,
+                                                           int M, int N, int K, int fast_ok) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int ti, tj;
+    if (SYM) {
+        const int t = blockIdx.x;
+        ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        while (ti * (ti + 1) / 2 > t) --ti;
+        tj = t - ti * (ti + 1) / 2;
+    } else {
+        ti = blockIdx.x;
+        tj = blockIdx.y;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wj = wave >> 1, wi = wave & 1;
+    const int i0 = ti * TILE, j0 = tj * TILE;
+    const bool diag = SYM && (ti == tj);
+    const bool tile_fast = fast_ok && (i0 + TILE <= M) && (j0 + TILE <= N);
+
+    const int ioff = diag ? 0 : STAGE_DOUBLES;
+    auto sJ = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES; };
+    auto sI = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES + ioff; };
+    d4 acc[4][4];
+    zero_acc(acc);
+    const int nkt = (K + BK - 1) / BK;
+    double rJ[8], rI[8];
+    auto fetch = [&](int kt) {
+        const bool fast = tile_fast && ((kt + 1) * BK <= K);
+        if (fast) {
+            nt_load<true>(B, ldb, j0, N, kt * BK, K, tid, rJ);
+            if (!diag) nt_load<true>(A, lda, i0, M, kt * BK, K, tid, rI);
+        } else {
+            nt_load<false>(B, ldb, j0, N, kt * BK, K, tid, rJ);
+            if (!diag) nt_load<false>(A, lda, i0, M, kt * BK, K, tid, rI);
+        }
+    };
+    auto stash = [&](int s) {
+        nt_store(sJ(s), tid, rJ);
+        if (!diag) nt_store(sI(s), tid, rI);
+    };
+    if (nkt > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) fetch(kt + 1);
+        wave_mma<1, LDT_M>(sJ(cur) + wj * 64, sI(cur) + wi * 64, acc, lane);
+        if (kt + 1 < nkt) stash(cur ^ 1);
+        __syncthreads();
+    }
+    const int li = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi * 64 + u * 16 + li;
+                const int j = j0 + wj * 64 + t * 16 + lq + 4 * r;
+                if (i < M && j < N && (!SYM || i >= j)) C[i + (int64_t)j * ldc] -= acc[t][u][r];
+            }
+}
+
+static int nt_attr() {
+    static bool done = false;
+    if (!done) {
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        done = true;
+    }
+    return 0;
+}
+
+int launch_syrk_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, int nrows, int K,
+                          hipStream_t st) {
+    if (nrows <= 0 || K <= 0) return 0;
+    if (int e = nt_attr()) return e;
+    const int nt = (nrows + TILE - 1) / TILE;
+    const int fast_ok = ((reinterpret_cast<uintptr_t>(A) & 7) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(nt_update_kernel<true>, dim3(nt * (nt + 1) / 2), dim3(256), kGemmLds, st, C, ldc, A, lda,
+                       A, lda, nrows, nrows, K, fast_ok);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
+                          int M, int N, int K, hipStream_t st) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    if (int e = nt_attr()) return e;
+    const int fast_ok = (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 7) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(nt_update_kernel<false>, dim3((M + TILE - 1) / TILE, (N + TILE - 1) / TILE), dim3(256),
+                       kGemmLds, st, C, ldc, A, lda, B, ldb, M, N, K, fast_ok);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mi355kkt

@@ -1,0 +1,88 @@
+// Shared declarations for the MI355X (gfx950) KKT backend.  Internal header (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace mi355kkt {
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void set_last_error(const char* fmt, ...);
+
+#define KKT_HIP_CHECK(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            ::mi355kkt::set_last_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,     \
+                                       hipGetErrorString(_e));                           \
+            return -2; /* MI355KKT_EHIP */                                               \
+        }                                                                                \
+    } while (0)
+
+// ---- tile geometry of the FP64 MFMA kernels -----------------------------------------------------
+constexpr int TILE = 128;      // C tile (both dims) owned by one 256-thread workgroup
+constexpr int BK = 16;         // k-depth staged per LDS buffer
+constexpr int LDT_K = BK + 2;  // K-major LDS layout: [idx][k], stride 18 doubles  (ds_read_b64 conflict-free)
+constexpr int LDT_M = TILE + 16;  // M-major LDS layout: [k][idx], stride 144 doubles (conflict-free)
+constexpr int STAGE_DOUBLES = TILE * LDT_K;   // == BK * LDT_M == 2304 doubles per operand per stage
+static_assert(TILE * LDT_K == BK * LDT_M, "both LDS layouts must use the same footprint");
+
+struct SyrkItem {  // one workgroup's job in the scaled SYRK
+    int ti, tj;    // tile row (C rows, i) / tile column (C cols, j); ti >= tj
+    int k0, k1;    // contraction range [k0, k1)
+    int slot;      // <0: final (write C = P + acc); >=0: partial slab index
+    int first;     // for partial items: index of first slab of this tile; count in `nparts`
+    int nparts;
+    int pad;
+};
+
+struct SyrkPlan {
+    int n = 0, K = 0;
+    int nitems = 0, nslabs = 0, nsplit_tiles = 0;
+    SyrkItem* d_items = nullptr;       // device copy, XCD-friendly order
+    SyrkItem* d_split_tiles = nullptr; // one entry per split tile (first/nparts used by the reducer)
+    double* d_slabs = nullptr;         // nslabs * TILE*TILE doubles
+};
+
+int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus);
+void free_syrk_plan(SyrkPlan& plan);
+
+// C(lower) = P(lower) + Gs' Gs with Gs = diag(di) G   (di == nullptr: no scaling; P == nullptr: 0)
+int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const double* di,
+                       double* C, int64_t ldc, const double* P, int64_t ldp, hipStream_t st);
+
+// C(lower tiles of an nrows x nrows block) -= A A' where A is nrows x K (column-major, lda)
+int launch_syrk_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, int nrows, int K,
+                          hipStream_t st);
+// C (M x N, all tiles) -= A B'  with A: M x K (lda), B: N x K (ldb)
+int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
+                          int64_t ldb, int M, int N, int K, hipStream_t st);
+
+// ---- dense Cholesky -----------------------------------------------------------------------------
+struct PotrfWork {
+    int* d_info = nullptr;   // device int: 0 ok, >0 first failing pivot (1-based, LAPACK convention)
+    int* h_info = nullptr;   // pinned host mirror
+};
+int potrf_work_init(PotrfWork& w);
+void potrf_work_free(PotrfWork& w);
+// In-place lower Cholesky of the n x n column-major matrix A (only tril referenced/overwritten).
+// Asynchronous on `st`; *w.d_info is updated on device.  Returns 0 or a negative error code.
+int launch_potrf(double* A, int64_t lda, int n, PotrfWork& w, hipStream_t st);
+
+// ---- level-2 pieces of solve() --------------------------------------------------------------------
+// zs := w .* z;  y[0:n) += G' (w .* zs)   (G m x n); work >= m doubles
+int launch_gemv_t_scaled(const double* G, int64_t ldg, int m, int n, const double* w,
+                         const double* z, double* zs, double* y, double* work, hipStream_t st);
+// z := alpha * w .* (G x) + beta * zs    (z may alias zs)
+int launch_gemv_n_scaled(const double* G, int64_t ldg, int m, int n, const double* w,
+                         const double* x, const double* zs, double* z, double alpha, double beta,
+                         double* work, hipStream_t st);
+size_t gemv_work_doubles(int m, int n);
+// x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
+int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
+                      int trans, hipStream_t st);
+
+}  // namespace mi355kkt

@@ -1,0 +1,294 @@
+"""Host-side mirror of the reference's KKT-solver factories (reference src/python/misc.py).
+
+    kkt_chol2(G, dims, A, mnl=0)                 misc.py:1352
+    kkt_chol (G, dims, A, mnl=0)                 misc.py:1213
+    kkt_ldl  (G, dims, A, mnl=0, kktreg=None)    misc.py:1055
+    kkt_ldl2 (G, dims, A, mnl=0)                 misc.py:1128
+
+Each returns `factor(W, H=None, Df=None)` which returns `solve(x, y, z)`; same argument meaning, same
+in-place contract (x, y, z := ux, uy, W*uz) and the same exceptions as the reference (ArithmeticError
+for a singular / indefinite factorisation, ValueError / TypeError for bad arguments), so they can be
+passed as `kktsolver=` callables or installed over `cvxopt.misc.kkt_*` (see install()).
+
+Arguments are accepted through the buffer protocol (`cvxopt.matrix`, NumPy arrays) or, for sparse
+G / A / H, through the `.CCS` attribute of `cvxopt.spmatrix`; this module never imports cvxopt.
+All arithmetic happens in libmi355kkt.so on the GPU -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+
+options = {"device": None}   # None -> $CVXOPT_AMD_DEVICE, else $LOCAL_RANK, else 0
+
+
+def _device():
+    d = options.get("device")
+    if d is None:
+        d = os.environ.get("CVXOPT_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+    return int(d)
+
+
+def _size(M):
+    if hasattr(M, "size") and isinstance(M.size, tuple):
+        return M.size
+    return tuple(np.shape(M))
+
+
+def _is_sparse(M):
+    return hasattr(M, "CCS")
+
+
+def _dense_view(M, what):
+    """2-D float64 column-major ndarray view (zero copy for cvxopt 'd' matrices and F-ordered arrays)."""
+    if _is_sparse(M):
+        raise TypeError("%s: sparse matrix passed where a dense view was requested" % what)
+    if hasattr(M, "typecode") and M.typecode != 'd':
+        raise TypeError("%s must be a 'd' matrix" % what)
+    a = np.asarray(M)
+    if a.dtype != np.float64:
+        raise TypeError("%s must have typecode 'd' / dtype float64" % what)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1, order='F')
+    if a.ndim != 2:
+        raise TypeError("%s must be a matrix" % what)
+    if not a.flags.f_contiguous:
+        a = np.asfortranarray(a)
+    return a
+
+
+def _vec(M, n, what):
+    """Writable 1-D float64 view of an n-vector (cvxopt n x 1 'd' matrix or ndarray)."""
+    if hasattr(M, "typecode") and M.typecode != 'd':
+        raise TypeError("%s must be a 'd' matrix" % what)
+    a = np.asarray(M)
+    if a.dtype != np.float64:
+        raise TypeError("%s must have typecode 'd' / dtype float64" % what)
+    if a.size != n:
+        raise ValueError("%s must have length %d (got %d)" % (what, n, a.size))
+    v = a.reshape(-1, order='F') if a.flags.f_contiguous else a.reshape(-1)
+    if v.size and not np.shares_memory(v, a):
+        raise TypeError("%s must be contiguous" % what)
+    return v
+
+
+def _csc_parts(M):
+    cp, ri, v = M.CCS
+    colptr = np.ascontiguousarray(np.array(cp, dtype=np.int64).ravel())
+    rowind = np.ascontiguousarray(np.array(ri, dtype=np.int64).ravel())
+    vals = np.ascontiguousarray(np.array(v, dtype=np.float64).ravel())
+    return colptr, rowind, vals
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data if a.size else None)
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_capi.c_double_p) if a is not None and a.size else None
+
+
+class _Engine(object):
+    """One device solver handle = one reference factory closure (misc.py:1080-1083 'allocate once')."""
+
+    def __init__(self, kind, G, dims, A, mnl=0, kktreg=None):
+        if mnl:
+            raise NotImplementedError("cvxopt_amd: nonlinear blocks (mnl > 0, cvxprog.cp/cpl) are outside "
+                                      "the accelerated path; use the reference CPU kktsolver")
+        self.L = _capi.lib()
+        self.dims = {'l': int(dims['l']), 'q': [int(k) for k in dims['q']], 's': [int(k) for k in dims['s']]}
+        p, n = _size(A)
+        cdim = self.dims['l'] + sum(self.dims['q']) + sum(k * k for k in self.dims['s'])
+        gm, gn = _size(G)
+        if gn != n or gm != cdim:
+            raise TypeError("G must be a 'd' matrix of size (%d, %d)" % (cdim, n))
+        self.n, self.p, self.cdim, self.kind = n, p, cdim, kind
+        q = (C.c_int * max(1, len(self.dims['q'])))(*self.dims['q'])
+        s = (C.c_int * max(1, len(self.dims['s'])))(*self.dims['s'])
+        h = C.c_void_p()
+        if _capi.device_count() <= 0:
+            raise RuntimeError("cvxopt_amd: no HIP device visible (there is no CPU fallback)")
+        _capi.check(self.L.mi355kkt_create(C.byref(h), _device(), kind, n, p, self.dims['l'],
+                                           len(self.dims['q']), q, len(self.dims['s']), s), "mi355kkt_create")
+        self.h = h
+        # constants are copied to HBM once, at factory time
+        if _is_sparse(G):
+            cp, ri, v = _csc_parts(G)
+            _capi.check(self.L.mi355kkt_set_G_csc(h, cp.ctypes.data_as(_capi.c_i64_p),
+                                                  ri.ctypes.data_as(_capi.c_i64_p),
+                                                  v.ctypes.data_as(_capi.c_double_p)), "set_G_csc")
+        else:
+            g = _dense_view(G, "G")
+            _capi.check(self.L.mi355kkt_set_G_dense(h, _ptr(g), max(1, g.shape[0])), "set_G_dense")
+        if p:
+            a = self._densify(A, "A")
+            _capi.check(self.L.mi355kkt_set_A_dense(h, _ptr(a), max(1, a.shape[0])), "set_A_dense")
+        if kktreg:
+            _capi.check(self.L.mi355kkt_set_kktreg(h, float(kktreg)), "set_kktreg")
+        self._H_tag = None
+
+    @staticmethod
+    def _densify(M, what):
+        if _is_sparse(M):
+            cp, ri, v = _csc_parts(M)
+            m, n = _size(M)
+            out = np.zeros((m, n), order='F')
+            for j in range(n):
+                out[ri[cp[j]:cp[j + 1]], j] += v[cp[j]:cp[j + 1]]
+            return out
+        return _dense_view(M, what)
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.mi355kkt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- H upload with change detection ------------------------------------------------------------
+    def _fingerprint(self, H, a):
+        n = a.shape[0]
+        step = max(1, (n * n) // 65536)
+        flat = a.reshape(-1, order='F')
+        return (id(H), a.ctypes.data, float(np.sum(np.diagonal(a))), float(np.sum(flat[::step])))
+
+    def _set_H(self, H):
+        if H is None:
+            _capi.check(self.L.mi355kkt_set_H_dense(self.h, None, 1), "set_H_dense")
+            self._H_tag = None
+            return
+        hm, hn = _size(H)
+        if hm != self.n or hn != self.n:
+            raise TypeError("H must be a 'd' matrix of size (%d, %d)" % (self.n, self.n))
+        a = self._densify(H, "H")
+        tag = self._fingerprint(H, a)
+        if tag == self._H_tag:
+            return                      # same object, same storage, same sampled content: already in HBM
+        _capi.check(self.L.mi355kkt_set_H_dense(self.h, _ptr(a), max(1, a.shape[0])), "set_H_dense")
+        self._H_tag = tag
+
+    # ---- factor / solve ----------------------------------------------------------------------------
+    def _scaling(self, W):
+        keep = []
+        sc = _capi.Scaling()
+
+        def flat(x, n):
+            a = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, order='F'))
+            if a.size != n:
+                raise ValueError("scaling component has wrong length")
+            keep.append(a)
+            return _dptr(a)
+        ml = self.dims['l']
+        if ml:
+            sc.di = flat(W['di'], ml)
+            sc.d = flat(W['d'], ml)
+        if self.dims['q']:
+            v = np.concatenate([np.asarray(vk, dtype=np.float64).reshape(-1, order='F') for vk in W['v']])
+            sc.v = flat(v, sum(self.dims['q']))
+            sc.beta = flat(np.array([float(b) for b in W['beta']]), len(self.dims['q']))
+        if self.dims['s']:
+            tot = sum(k * k for k in self.dims['s'])
+            sc.r = flat(np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, order='F') for r in W['r']]), tot)
+            sc.rti = flat(np.concatenate([np.asarray(r, dtype=np.float64).reshape(-1, order='F') for r in W['rti']]), tot)
+        return sc, keep
+
+    def factor(self, W, H=None, Df=None):
+        if Df is not None:
+            raise NotImplementedError("cvxopt_amd: Df (nonlinear constraints) is outside the accelerated path")
+        self._set_H(H)
+        sc, keep = self._scaling(W)
+        _capi.check(self.L.mi355kkt_factor(self.h, C.byref(sc)), "mi355kkt_factor")
+        del keep
+        n, p, cdim, L, h = self.n, self.p, self.cdim, self.L, self.h
+
+        def solve(x, y, z):
+            xv, yv, zv = _vec(x, n, "x"), _vec(y, p, "y"), _vec(z, cdim, "z")
+            _capi.check(L.mi355kkt_solve(h, _ptr(xv), _ptr(yv), _ptr(zv)), "mi355kkt_solve")
+        return solve
+
+    def timings(self):
+        out = (C.c_float * 5)()
+        self.L.mi355kkt_get_timings(self.h, out, 5)
+        return dict(zip(("assemble_ms", "potrf_ms", "schur_ms", "factor_ms", "solve_ms"), [float(v) for v in out]))
+
+
+def _factory(kind, G, dims, A, mnl=0, kktreg=None):
+    eng = _Engine(kind, G, dims, A, mnl, kktreg)
+
+    def factor(W, H=None, Df=None):
+        return eng.factor(W, H, Df)
+    factor.engine = eng          # exposes timings()/close() without changing the reference call shape
+    return factor
+
+
+def kkt_chol2(G, dims, A, mnl=0):
+    """Mirror of misc.kkt_chol2 (misc.py:1352): LP cone only; S = H + G'W^-1W^-T G, K = A S^-1 A'."""
+    if dims['q'] or dims['s']:
+        raise ValueError("kktsolver option 'kkt_chol2' is implemented only for problems with no "
+                         "second-order or semidefinite cone constraints")     # misc.py:1381-1384
+    return _factory(_capi.CHOL2, G, dims, A, mnl)
+
+
+def kkt_chol(G, dims, A, mnl=0):
+    """Mirror of misc.kkt_chol (misc.py:1213)."""
+    return _factory(_capi.CHOL, G, dims, A, mnl)
+
+
+def kkt_ldl(G, dims, A, mnl=0, kktreg=None):
+    """Mirror of misc.kkt_ldl (misc.py:1055), including the kktreg diagonal regularisation."""
+    return _factory(_capi.LDL, G, dims, A, mnl, kktreg)
+
+
+def kkt_ldl2(G, dims, A, mnl=0):
+    """Mirror of misc.kkt_ldl2 (misc.py:1128)."""
+    return _factory(_capi.LDL2, G, dims, A, mnl)
+
+
+# ---- ready-made kktsolver callables for the drivers --------------------------------------------------
+def kktsolver_qp(G, dims, A, P, kind="chol2", kktreg=None):
+    """`kktsolver` callable for solvers.coneqp (coneprog.py:1969-1981 does `factor(W, P)`)."""
+    fac = {"chol2": kkt_chol2, "chol": kkt_chol, "ldl2": kkt_ldl2}.get(kind)
+    factor = kkt_ldl(G, dims, A, kktreg=kktreg) if kind == "ldl" else fac(G, dims, A)
+
+    def kktsolver(W):
+        return factor(W, P)
+    kktsolver.engine = factor.engine
+    return kktsolver
+
+
+def kktsolver_lp(G, dims, A, kind="chol", kktreg=None):
+    """`kktsolver` callable for solvers.conelp (coneprog.py:571-585 does `factor(W)`)."""
+    fac = {"chol2": kkt_chol2, "chol": kkt_chol, "ldl2": kkt_ldl2}.get(kind)
+    factor = kkt_ldl(G, dims, A, kktreg=kktreg) if kind == "ldl" else fac(G, dims, A)
+
+    def kktsolver(W):
+        return factor(W)
+    kktsolver.engine = factor.engine
+    return kktsolver
+
+
+# ---- drop-in: route kktsolver='chol'|'chol2'|'ldl'|'ldl2' to the GPU ------------------------------------
+_saved = {}
+
+
+def install(misc_module=None):
+    """Rebinds cvxopt.misc.kkt_{chol,chol2,ldl,ldl2}; coneprog resolves them at call time
+    (reference coneprog.py:574-583, :1972-1979) so the string names become GPU-backed."""
+    if misc_module is None:
+        import cvxopt.misc as misc_module
+    for name, f in (("kkt_chol", kkt_chol), ("kkt_chol2", kkt_chol2), ("kkt_ldl", kkt_ldl), ("kkt_ldl2", kkt_ldl2)):
+        if (id(misc_module), name) not in _saved:
+            _saved[(id(misc_module), name)] = (misc_module, getattr(misc_module, name))
+        setattr(misc_module, name, f)
+
+
+def uninstall():
+    for (_, name), (mod, orig) in list(_saved.items()):
+        setattr(mod, name, orig)
+    _saved.clear()

@@ -1,0 +1,140 @@
+/* mi355kkt.h -- C ABI of the MI355X-native KKT-solve backend for CVXOPT's cone solvers.
+ *
+ * The library replaces, for ONE hot path, what the reference reaches through its Python plug-in hook
+ *     f = kktsolver(W);  f(x, y, z)        (reference src/python/coneprog.py:323-344, :1658-1685)
+ * i.e. the closures built by the factories
+ *     misc.kkt_chol2   src/python/misc.py:1352-1567      misc.kkt_chol  src/python/misc.py:1213-1349
+ *     misc.kkt_ldl     src/python/misc.py:1055-1125      misc.kkt_ldl2  src/python/misc.py:1128-1210
+ * and everything underneath them on that path (misc_solvers.scale src/C/misc_solvers.c:85-244,
+ * base.gemm/base.syrk src/C/base.c:476/:742, blas.syrk/trsv/trsm/gemv src/C/blas.c:3039/:1806/:3742/:872,
+ * lapack.potrf/potrs src/C/lapack.c:1471/:1553).  Nothing like this ABI exists in the reference (it is
+ * in-process Python + Fortran BLAS); INTEGRATION.md shows the binding a cvxopt maintainer would add.
+ *
+ * Conventions (same as the reference, src/C/cvxopt.h:46-69): FP64, column-major, 0-based.
+ * The KKT system solved is
+ *     [ H   A'  G'   ] [ ux ]   [ bx ]
+ *     [ A   0   0    ] [ uy ] = [ by ]        W = Nesterov-Todd scaling,
+ *     [ G   0  -W'W  ] [ uz ]   [ bz ]
+ * and solve() overwrites (x, y, z) = (bx, by, bz) with (ux, uy, W uz) exactly as the hook requires.
+ *
+ * Return codes: 0 ok; >0 LAPACK-style "leading minor of order info is not positive definite"
+ * (the Python layer raises ArithmeticError(info), reference src/C/lapack.c:32-34); <0 errors below.
+ * All functions are plain C, take plain pointers and sizes, and are thread-compatible per handle.
+ */
+#ifndef MI355KKT_H
+#define MI355KKT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355KKT_OK 0
+#define MI355KKT_EINVAL (-1)  /* bad argument (ValueError / TypeError in the Python layer)  */
+#define MI355KKT_EHIP (-2)    /* HIP runtime failure; see mi355kkt_last_error()              */
+#define MI355KKT_ENOMEM (-3)
+#define MI355KKT_ENOTIMPL (-4)
+
+/* factorisation flavour requested by the host-side factory (all share the device engine; the
+ * flavour fixes the regularisation semantics and which reference factory is mirrored) */
+#define MI355KKT_CHOL2 0 /* misc.kkt_chol2: S = H + G'W^-1W^-T G, K = A S^-1 A'  (misc.py:1352)      */
+#define MI355KKT_CHOL 1  /* misc.kkt_chol : same reduced system (QR elimination of A in the ref.)   */
+#define MI355KKT_LDL 2   /* misc.kkt_ldl  : 3x3 quasi-definite LDL', static order z|x|y, + kktreg   */
+#define MI355KKT_LDL2 3  /* misc.kkt_ldl2 : 2x2 reduced LDL'                                         */
+
+typedef struct mi355kkt_solver mi355kkt_solver;
+
+/* Nesterov-Todd scaling, flat arrays (reference W dict: coneprog.py:327-334).  Host or device
+ * pointers depending on the entry point.  Unused parts may be NULL. */
+typedef struct mi355kkt_scaling {
+    const double* d;    /* ml            W['d']   */
+    const double* di;   /* ml            W['di']  */
+    const double* v;    /* sum(q)        W['v'][k] concatenated                         */
+    const double* beta; /* nq            W['beta']                                      */
+    const double* r;    /* sum(s_k^2)    W['r'][k] column-major, concatenated           */
+    const double* rti;  /* sum(s_k^2)    W['rti'][k]                                    */
+} mi355kkt_scaling;
+
+/* ---- library / device ------------------------------------------------------------------------ */
+int mi355kkt_version(void);
+const char* mi355kkt_last_error(void);
+int mi355kkt_device_count(void);
+/* fills name (<= len bytes), number of compute units, global memory in bytes */
+int mi355kkt_device_info(int device, char* name, int len, int* num_cus, size_t* mem_bytes);
+
+/* ---- raw device memory helpers (so a host language without a HIP binding can keep data in HBM) -- */
+int mi355kkt_dev_malloc(void** ptr, size_t bytes);
+int mi355kkt_dev_free(void* ptr);
+int mi355kkt_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int mi355kkt_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int mi355kkt_memcpy_d2d(void* dst, const void* src, size_t bytes);
+int mi355kkt_device_synchronize(void);
+
+/* ---- solver handle: mirrors `factor = misc.kkt_<name>(G, dims, A[, mnl][, kktreg])` ------------- */
+/* dims = {'l': ml, 'q': q[0..nq), 's': s[0..ns)};  n variables, p equalities.  G is cdim x n with
+ * cdim = ml + sum(q) + sum(s_k^2). */
+int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, int ml, int nq, const int* q,
+                    int ns, const int* s);
+void mi355kkt_destroy(mi355kkt_solver* h);
+
+/* constants captured at factory time (copied to HBM; caller keeps ownership of the host arrays) */
+int mi355kkt_set_G_dense(mi355kkt_solver* h, const double* G, int64_t ldG);         /* cdim x n  */
+int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t* rowind,
+                       const double* values);                                        /* CCS, cdim x n */
+int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA);         /* p x n     */
+/* device-resident variants: the solver borrows the pointers (no copy); they must outlive the handle */
+int mi355kkt_set_G_device(mi355kkt_solver* h, const double* dG, int64_t ldG);
+int mi355kkt_set_A_device(mi355kkt_solver* h, const double* dA, int64_t ldA);
+
+/* H (= P for coneqp; NULL means H = 0, as in conelp).  Only the lower triangle is referenced
+ * (reference coneprog.py:1475-1477).  Copied to HBM; call again whenever H changes. */
+int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH);
+int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH);
+/* diagonal regularisation of kkt_ldl (reference misc.py:1095-1098): K[x,x] += reg, K[y,y] -= reg,
+ * K[z,z] = -1 - reg.  0 disables it. */
+int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg);
+
+/* factor(W, H): NT scaling + assembly + Cholesky/LDL' on the device.  `W` holds HOST pointers.
+ * Returns 0, or info > 0 when a pivot is not positive (=> ArithmeticError(info)). */
+int mi355kkt_factor(mi355kkt_solver* h, const mi355kkt_scaling* W);
+/* same with DEVICE pointers in W (nothing crosses PCIe except the info word) */
+int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W);
+
+/* solve(x, y, z): in place on HOST vectors of length n, p, cdim */
+int mi355kkt_solve(mi355kkt_solver* h, double* x, double* y, double* z);
+/* in place on DEVICE vectors; asynchronous on the solver's stream until mi355kkt_sync() */
+int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz);
+int mi355kkt_sync(mi355kkt_solver* h);
+
+/* 1 if the first factorisation hit a singular S and switched to S + A'A (reference misc.py:1433-1447) */
+int mi355kkt_is_singular_mode(const mi355kkt_solver* h);
+
+/* Timings of the last factor()/solve() in milliseconds, measured with HIP events on the solver's
+ * stream: out[0] scale+assemble (SYRK), out[1] Cholesky of S, out[2] Schur complement K (p > 0),
+ * out[3] whole factor (device), out[4] whole last solve (device).  Returns number written. */
+int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n);
+/* copies the factored S (lower Cholesky factor L in tril) to a host n x n buffer -- tests only */
+int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL);
+
+/* ---- stand-alone device operators (each is one stage of factor()/solve(); used by the per-kernel
+ * parity tests and by the profiler).  All pointers are DEVICE pointers; calls are synchronous. ---- */
+/* S(lower) = H(lower) + G' diag(di)^2 G ;  di or H may be NULL */
+int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
+                            int64_t ldH, double* dS, int64_t ldS, float* ms);
+/* in-place lower Cholesky; *info as LAPACK dpotrf */
+int mi355kkt_op_potrf(double* dA, int64_t ldA, int n, int* info, float* ms);
+/* X := L^-1 X (trans = 0) or L^-T X (trans = 1) */
+int mi355kkt_op_trsm_lower(const double* dL, int64_t ldL, int n, double* dX, int64_t ldX, int nrhs, int trans,
+                           float* ms);
+/* zs := w .* z, y += (diag(w) G)' zs   and   z := w .* (G x) - zs   (the two products of solve()) */
+int mi355kkt_op_gemv_t_scaled(const double* dG, int64_t ldG, int m, int n, const double* dw, const double* dz,
+                              double* dzs, double* dy, float* ms);
+int mi355kkt_op_gemv_n_scaled(const double* dG, int64_t ldG, int m, int n, const double* dw, const double* dx,
+                              const double* dzs, double* dz, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355KKT_H */

@@ -1,0 +1,48 @@
+#!/usr/bin/env bash
+# TEST INFRASTRUCTURE ONLY -- builds the *real* reference (cvxopt @ /root/reference) into
+# oracle/_ref/ so tests and bench.py's cpu_baseline leg can run the reference CPU kktsolvers.
+#
+# Nothing is copied into the tracked tree: the C sources are compiled where they lie under
+# /root/reference/src/C (reference build lines: setup.py:92-258, dense modules only), the
+# reference's Python drivers are byte-compiled (sourceless .pyc) into oracle/_ref/cvxopt/, and
+# oracle/_ref/ is git-ignored.  CHOLMOD/UMFPACK/AMD need SuiteSparse (third-party, not vendored,
+# CI pin v7.11.0: .github/workflows/linux_build.yml:12) which is absent here -> the `cholmod`
+# module is replaced by oracle/cholmod_shim.py (SciPy-backed, ours).
+#
+# BLAS/LAPACK: MKL's single dynamic library (LP64 Fortran symbols dpotrf_ ...) at /opt/conda/lib.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF="${CVXOPT_REFERENCE:-/root/reference}"
+OUT="$HERE/_ref/cvxopt"
+if [ ! -d "$REF/src/C" ]; then
+  echo "build_ref: $REF not present (GPU box?) -- keeping prebuilt $OUT" >&2
+  exit 0
+fi
+PYINC="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')"
+SUFFIX="$(python3 -c 'import sysconfig; print(sysconfig.get_config_var("EXT_SUFFIX"))')"
+MKLDIR="${MKLDIR:-/opt/conda/lib}"
+mkdir -p "$OUT"
+build() { # name srcs...
+  local name=$1; shift
+  local tgt="$OUT/$name$SUFFIX"
+  local newest; newest=$(ls -t "$@" "$REF/src/C/cvxopt.h" "$REF/src/C/misc.h" | head -1)
+  if [ -f "$tgt" ] && [ "$tgt" -nt "$newest" ]; then return; fi
+  echo "build_ref: $name"
+  gcc -O2 -fPIC -shared -w -I"$PYINC" -I"$REF/src/C" "$@" -o "$tgt" \
+      -L"$MKLDIR" -Wl,-rpath,"$MKLDIR" -lmkl_rt -lm
+}
+build base         "$REF/src/C/base.c" "$REF/src/C/dense.c" "$REF/src/C/sparse.c"
+build blas         "$REF/src/C/blas.c"
+build lapack       "$REF/src/C/lapack.c"
+build misc_solvers "$REF/src/C/misc_solvers.c"
+# Python drivers: byte-compile only (no source copies).
+python3 - "$REF/src/python" "$OUT" <<'PY'
+import sys, os, py_compile
+src, out = sys.argv[1], sys.argv[2]
+for f in sorted(os.listdir(src)):
+    if f.endswith('.py') and f not in ('msk.py',):
+        py_compile.compile(os.path.join(src, f), cfile=os.path.join(out, f + 'c'),
+                           dfile='cvxopt/' + f, doraise=True, optimize=0)
+PY
+cp "$HERE/cholmod_shim.py" "$OUT/cholmod.py"
+echo "build_ref: done -> $OUT"
