@@ -19,6 +19,10 @@ def load():
     if not available():
         raise ImportError("oracle/_ref/cvxopt missing: run `bash oracle/build_ref.sh` "
                           "(needs /root/reference; prebuilt files travel to the GPU box)")
+    # The reference is linked against MKL's single dynamic library; its default Intel-OpenMP threading
+    # layer silently corrupts results when libgomp (torch) lives in the same process.  Must be set
+    # before libmkl_rt is first used.
+    os.environ.setdefault("MKL_THREADING_LAYER", "GNU")
     if _REF not in sys.path:
         sys.path.insert(0, _REF)
     import cvxopt
