@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: "KKT factor+solve ms/iter (and IPM iters/sec), dense QP n=8192".
+
+A "step" is one pass of the hot path = what one coneqp IPM iteration asks of the kktsolver hook on a
+dense LP-cone QP: 1 factor(W, P) + 2 solve(x, y, z)   (reference coneprog.py:2256, :2360; refinement 0).
+Workload at N=1: BASELINE configs[1] (n=8192, m=16384, p=0).  Inputs (G, P, the scaling di, the
+right-hand sides) are resident in HBM when the timed region starts; only the 4-byte `info` word crosses
+PCIe per factor.  N>1: one process per GPU, every rank runs its own replica of the workload
+("replicas only": a single factorisation does not shard; independent problems do), weak scaling,
+value = KKT iterations/s summed over ranks.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel: the FP64-MFMA scaled SYRK, timed live with
+HIP events on the solver's stream) and `cpu_baseline` (the real reference kkt_chol2 + MKL from oracle/_ref,
+timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 32 FLOP/clk x 2.4 GHz (v_mfma_f64_16x16x4_f64: 64 cyc) = AMD spec
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--m", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2, help="reference CPU iterations timed (bounded sample)")
+    return ap.parse_args()
+
+
+def cpu_baseline(pr, W_np, n, m, iters):
+    """Reference misc.kkt_chol2 (MKL) on the host: iters x (factor + 2 solves), same inputs."""
+    import numpy as np
+    try:
+        from oracle import refloader
+        cvx = refloader.load()
+        from cvxopt import matrix, spmatrix, misc
+        kind = "reference"
+    except Exception:
+        cvx = None
+        kind = "port"
+    rng = np.random.default_rng(1)
+    ts = []
+    if kind == "reference":
+        P, G = matrix(pr['P']), matrix(pr['G'])
+        A = spmatrix([], [], [], (0, n))
+        W = {'d': matrix(W_np['d']), 'di': matrix(W_np['di']), 'v': [], 'beta': [], 'r': [], 'rti': []}
+        factor = misc.kkt_chol2(G, pr['dims'], A)
+        for it in range(iters + 1):                 # first call allocates; not timed (reference firstcall branch)
+            t0 = time.perf_counter()
+            solve = factor(W, P)
+            for _ in range(2):
+                x, y, z = matrix(rng.standard_normal(n)), matrix(0.0, (0, 1)), matrix(rng.standard_normal(m))
+                solve(x, y, z)
+            ts.append(time.perf_counter() - t0)
+        ts = ts[1:]
+    else:
+        from oracle import kkt_oracle as ko
+        o = ko.KktChol2(pr['G'], pr['dims'], np.zeros((0, n)))
+        for it in range(iters):
+            t0 = time.perf_counter()
+            solve = o.factor(W_np, pr['P'])
+            for _ in range(2):
+                solve(rng.standard_normal(n), np.zeros(0), rng.standard_normal(m))
+            ts.append(time.perf_counter() - t0)
+    try:
+        import ctypes
+        mkl = ctypes.CDLL("/opt/conda/lib/libmkl_rt.so")
+        cores = int(mkl.MKL_Get_Max_Threads())
+    except Exception:
+        cores = os.cpu_count() or 1
+    ms = 1e3 * sum(ts) / len(ts)
+    return {"value": round(ms, 2), "unit": "ms/iter (factor + 2 solves)", "cores": cores, "kind": kind,
+            "sample": "%d KKT iterations of the same n=%d, m=%d workload, kktsolver='chol2', same W" % (len(ts), n, m),
+            "iters_per_s": round(1e3 / ms, 4)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    import torch                                   # plumbing only: device selection + torch.distributed
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from cvxopt_amd import kkt, synth, _capi
+    kkt.options["device"] = local_rank
+    n, m = args.n, args.m
+
+    # ---- synthetic inputs, seeded per rank; uploaded once ---------------------------
+    t_gen = time.perf_counter()
+    pr = synth.dense_qp(n, m, seed=rank)
+    W_np = synth.random_scaling(pr['dims'], seed=100 + rank, spread=1.0)
+    rng = np.random.default_rng(7 + rank)
+    factor = kkt.kkt_chol2(pr['G'], pr['dims'], np.zeros((0, n)))
+    eng = factor.engine
+    dP = _capi.DeviceBuffer.from_array(pr['P'])
+    eng.set_H_device(dP.ptr, n)
+    d_di = _capi.DeviceBuffer.from_array(W_np['di'])
+    rhs = [( _capi.DeviceBuffer.from_array(rng.standard_normal(n)), _capi.DeviceBuffer.from_array(rng.standard_normal(m)))
+           for _ in range(2)]
+    d_y = _capi.DeviceBuffer(8)
+    t_gen = time.perf_counter() - t_gen
+
+    syrk_ms = []
+
+    def step():
+        eng.factor_device(di_ptr=d_di.ptr)
+        for dx, dz in rhs:
+            eng.solve_device(dx.ptr, d_y.ptr, dz.ptr)
+        eng.sync()
+        syrk_ms.append(eng.timings()["syrk_kernel_ms"])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        _capi.lib().mi355kkt_device_synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    del syrk_ms[:]
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = eng.timings()
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        kernel_ms = sum(syrk_ms) / max(1, len(syrk_ms))
+        flops = float(m) * n * n                      # algorithmic flops of the lower-triangular SYRK
+        achieved = flops / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "pmc_syrk_latest.json")
+        if os.path.exists(pj):
+            try:
+                d = json.load(open(pj))
+                if d.get("n") == n and d.get("m") == m:
+                    traffic = d.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        out = {
+            "metric": "KKT factor+solve ms/iter (and IPM iters/sec), dense QP n=%d" % n,
+            "value": round(world * args.steps / elapsed, 4),
+            "unit": "KKT iterations/s (1 factor + 2 solves each; ms/iter in ms_per_step)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: coneqp dense QP n=%d, m=%d, p=0, LP cone; kktsolver hook "
+                                   "= 1 factor(W,P) + 2 solve(x,y,z) per step, inputs resident in HBM" % (n, m),
+                       "replicas": world, "formulation": "reduced S = P + G'D^2G, Cholesky (kkt_chol2/ldl engine)"},
+            "phases_ms": {k: round(v, 3) for k, v in tm.items()},
+            "roofline": {"kernel": "syrk_tn_kernel (S = P + G' diag(di)^2 G, FP64 MFMA)", "bound": "mfma",
+                         "achieved": round(achieved, 2), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "kernel_ms": round(kernel_ms, 3), "flops_per_launch": flops},
+        }
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(pr, W_np, n, m, args.cpu_iters)
+                out["speedup_vs_cpu"] = round(out["cpu_baseline"]["value"] / ms_per_step, 2)
+            except Exception as e:                     # the baseline must never take the GPU number down
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,7 +67,7 @@ struct mi355kkt_solver {
     std::vector<int> q, s;
     int num_cus = 256;
     hipStream_t st = nullptr;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};   // 0-3 factor phases, 4-5 solve, 6-7 around the dominant SYRK kernel
     // constants
     const double* dG = nullptr;  int64_t ldG = 0;  double* G_owned = nullptr;
     const double* dA = nullptr;  int64_t ldA = 0;  double* A_owned = nullptr;
@@ -85,7 +85,7 @@ struct mi355kkt_solver {
     size_t hbuf_doubles = 0;
     SyrkPlan planS, planAtA, planK;
     PotrfWork pw;
-    float t_syrk = 0, t_potrf = 0, t_schur = 0, t_factor = 0, t_solve = 0;
+    float t_syrk = 0, t_potrf = 0, t_schur = 0, t_factor = 0, t_solve = 0, t_syrk_kernel = 0;
 };
 
 static int bind(const mi355kkt_solver* h) {
@@ -326,7 +326,7 @@ static int fetch_info(mi355kkt_solver* h, int* info) {
 
 // assemble S = H + [reg I] + Gs' Gs [+ A'A]
 static int assemble_S(mi355kkt_solver* h, bool add_AtA) {
-    if (int e = launch_syrk_scaled(h->planS, h->dG, h->ldG, h->ml > 0 ? h->dW : nullptr, h->dS, h->n, h->dH, h->ldH, h->st))
+    if (int e = launch_syrk_scaled(h->planS, h->dG, h->ldG, h->ml > 0 ? h->dW : nullptr, h->dS, h->n, h->dH, h->ldH, h->st, &h->ev[6]))
         return e;
     if (h->kktreg != 0.0 && h->n > 0) hipLaunchKernelGGL(diag_add_kernel, g1(h->n), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->n, h->kktreg);
     if (add_AtA && h->p > 0)
@@ -382,6 +382,7 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     (void)hipEventElapsedTime(&h->t_potrf, h->ev[1], h->ev[2]);
     (void)hipEventElapsedTime(&h->t_schur, h->ev[2], h->ev[3]);
     (void)hipEventElapsedTime(&h->t_factor, h->ev[0], h->ev[3]);
+    (void)hipEventElapsedTime(&h->t_syrk_kernel, h->ev[6], h->ev[7]);
     if (info > 0) return info;
     h->factored = true;
     return 0;
@@ -467,9 +468,9 @@ int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n) {
     (void)hipStreamSynchronize(h->st);
     if (hipEventQuery(h->ev[5]) == hipSuccess && hipEventQuery(h->ev[4]) == hipSuccess)
         (void)hipEventElapsedTime(&h->t_solve, h->ev[4], h->ev[5]);
-    const float v[5] = {h->t_syrk, h->t_potrf, h->t_schur, h->t_factor, h->t_solve};
+    const float v[6] = {h->t_syrk, h->t_potrf, h->t_schur, h->t_factor, h->t_solve, h->t_syrk_kernel};
     int k = 0;
-    for (; k < n && k < 5; ++k) out[k] = v[k];
+    for (; k < n && k < 6; ++k) out[k] = v[k];
     return k;
 }
 
@@ -524,6 +525,8 @@ int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const d
     if (int e = launch_syrk_scaled(plan, dG, ldG, ddi, dS, ldS, dH, ldH, nullptr)) return e;
     return t.finish();
 }
+
+int mi355kkt_op_mfma_f64_peak(int iters, float* tflops) { return run_mfma_f64_peak(iters, cur_num_cus(), tflops); }
 
 int mi355kkt_op_potrf(double* dA, int64_t ldA, int n, int* info, float* ms) {
     PotrfWork w;

@@ -276,7 +276,7 @@ void free_syrk_plan(SyrkPlan& plan) {
 static constexpr size_t kGemmLds = sizeof(double) * 4 * STAGE_DOUBLES;   // 73,728 B
 
 int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const double* di, double* C,
-                       int64_t ldc, const double* P, int64_t ldp, hipStream_t st) {
+                       int64_t ldc, const double* P, int64_t ldp, hipStream_t st, hipEvent_t* kernel_events) {
     if (plan.n == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
@@ -285,9 +285,11 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
         attr_set = true;
     }
     const int fast_ok = ((reinterpret_cast<uintptr_t>(G) & 7) == 0) ? 1 : 0;   // 8-byte aligned pairs suffice
+    if (kernel_events) KKT_HIP_CHECK(hipEventRecord(kernel_events[0], st));
     hipLaunchKernelGGL(syrk_tn_kernel, dim3(plan.nitems), dim3(256), kGemmLds, st, G, ldg, di, plan.n, fast_ok,
                        plan.d_items, C, ldc, P, ldp, plan.d_slabs);
     KKT_HIP_CHECK(hipGetLastError());
+    if (kernel_events) KKT_HIP_CHECK(hipEventRecord(kernel_events[1], st));
     if (plan.nsplit_tiles) {
         hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.nsplit_tiles), dim3(256), 0, st, plan.d_split_tiles,
                            plan.n, plan.d_slabs, C, ldc, P, ldp);
@@ -432,6 +434,48 @@ int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, 
     hipLaunchKernelGGL(nt_update_kernel<false>, dim3((M + TILE - 1) / TILE, (N + TILE - 1) / TILE), dim3(256),
                        kGemmLds, st, C, ldc, A, lda, B, ldb, M, N, K, fast_ok);
     KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Microbenchmark: issue-bound v_mfma_f64_16x16x4_f64 rate (8 independent accumulators per wave,
+// 2 waves per SIMD).  Confirms the FP64 matrix peak that bench.py's roofline line divides by.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void mfma_f64_peak_kernel(double* out, int iters) {
+    d4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = MFMA_F64(a, b, acc[i]);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) out[0] = s;   // keep the chain alive
+}
+
+int run_mfma_f64_peak(int iters, int num_cus, float* tflops) {
+    double* d = nullptr;
+    KKT_HIP_CHECK(hipMalloc(&d, 8));
+    hipEvent_t a, b;
+    KKT_HIP_CHECK(hipEventCreate(&a));
+    KKT_HIP_CHECK(hipEventCreate(&b));
+    const int blocks = num_cus * 2;
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d, 16);   // warm-up
+    KKT_HIP_CHECK(hipEventRecord(a, nullptr));
+    hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, d, iters);
+    KKT_HIP_CHECK(hipEventRecord(b, nullptr));
+    KKT_HIP_CHECK(hipEventSynchronize(b));
+    float ms = 0;
+    KKT_HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
+    if (tflops) *tflops = (float)(flops / (ms * 1e-3) / 1e12);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(d);
     return 0;
 }
 

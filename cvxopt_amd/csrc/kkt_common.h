@@ -51,8 +51,10 @@ int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus);
 void free_syrk_plan(SyrkPlan& plan);
 
 // C(lower) = P(lower) + Gs' Gs with Gs = diag(di) G   (di == nullptr: no scaling; P == nullptr: 0)
+// kernel_events (optional): two events recorded immediately around the syrk_tn_kernel launch.
 int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const double* di,
-                       double* C, int64_t ldc, const double* P, int64_t ldp, hipStream_t st);
+                       double* C, int64_t ldc, const double* P, int64_t ldp, hipStream_t st,
+                       hipEvent_t* kernel_events = nullptr);
 
 // C(lower tiles of an nrows x nrows block) -= A A' where A is nrows x K (column-major, lda)
 int launch_syrk_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, int nrows, int K,
@@ -60,6 +62,8 @@ int launch_syrk_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, 
 // C (M x N, all tiles) -= A B'  with A: M x K (lda), B: N x K (ldb)
 int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                           int64_t ldb, int M, int N, int K, hipStream_t st);
+
+int run_mfma_f64_peak(int iters, int num_cus, float* tflops);
 
 // ---- dense Cholesky -----------------------------------------------------------------------------
 struct PotrfWork {

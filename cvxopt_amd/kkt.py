@@ -212,10 +212,29 @@ class _Engine(object):
             _capi.check(L.mi355kkt_solve(h, _ptr(xv), _ptr(yv), _ptr(zv)), "mi355kkt_solve")
         return solve
 
+    # ---- device-resident entry points (inputs already in HBM; used by bench.py and the batch driver) ----
+    def set_H_device(self, ptr, ld):
+        _capi.check(self.L.mi355kkt_set_H_device(self.h, C.c_void_p(ptr), ld), "set_H_device")
+        self._H_tag = None
+
+    def factor_device(self, di_ptr=None, d_ptr=None, v_ptr=None, beta_ptr=None):
+        sc = _capi.Scaling()
+        cast = lambda p: C.cast(C.c_void_p(p), _capi.c_double_p) if p else None
+        sc.di, sc.d, sc.v, sc.beta = cast(di_ptr), cast(d_ptr), cast(v_ptr), cast(beta_ptr)
+        _capi.check(self.L.mi355kkt_factor_device(self.h, C.byref(sc)), "mi355kkt_factor_device")
+
+    def solve_device(self, x_ptr, y_ptr, z_ptr):
+        _capi.check(self.L.mi355kkt_solve_device(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr), C.c_void_p(z_ptr)),
+                    "mi355kkt_solve_device")
+
+    def sync(self):
+        _capi.check(self.L.mi355kkt_sync(self.h), "mi355kkt_sync")
+
     def timings(self):
-        out = (C.c_float * 5)()
-        self.L.mi355kkt_get_timings(self.h, out, 5)
-        return dict(zip(("assemble_ms", "potrf_ms", "schur_ms", "factor_ms", "solve_ms"), [float(v) for v in out]))
+        out = (C.c_float * 6)()
+        self.L.mi355kkt_get_timings(self.h, out, 6)
+        return dict(zip(("assemble_ms", "potrf_ms", "schur_ms", "factor_ms", "solve_ms", "syrk_kernel_ms"),
+                        [float(v) for v in out]))
 
 
 def _factory(kind, G, dims, A, mnl=0, kktreg=None):

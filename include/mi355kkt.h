@@ -113,7 +113,8 @@ int mi355kkt_is_singular_mode(const mi355kkt_solver* h);
 
 /* Timings of the last factor()/solve() in milliseconds, measured with HIP events on the solver's
  * stream: out[0] scale+assemble (SYRK), out[1] Cholesky of S, out[2] Schur complement K (p > 0),
- * out[3] whole factor (device), out[4] whole last solve (device).  Returns number written. */
+ * out[3] whole factor (device), out[4] whole last solve (device), out[5] the syrk_tn_kernel launch alone
+ * (the dominant kernel; bench.py's roofline line).  Returns number written. */
 int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n);
 /* copies the factored S (lower Cholesky factor L in tril) to a host n x n buffer -- tests only */
 int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL);
@@ -123,6 +124,8 @@ int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL);
 /* S(lower) = H(lower) + G' diag(di)^2 G ;  di or H may be NULL */
 int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
                             int64_t ldH, double* dS, int64_t ldS, float* ms);
+/* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
+int mi355kkt_op_mfma_f64_peak(int iters, float* tflops);
 /* in-place lower Cholesky; *info as LAPACK dpotrf */
 int mi355kkt_op_potrf(double* dA, int64_t ldA, int n, int* info, float* ms);
 /* X := L^-1 X (trans = 0) or L^-T X (trans = 1) */

@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol declared in
+include/mi355kkt.h, the ctypes table covers exactly that set, and the host mirror fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "mi355kkt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi355kkt_[a-zA-Z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_surface():
+    syms = header_symbols()
+    for must in ("mi355kkt_create", "mi355kkt_destroy", "mi355kkt_set_G_dense", "mi355kkt_set_A_dense",
+                 "mi355kkt_set_H_dense", "mi355kkt_factor", "mi355kkt_solve", "mi355kkt_factor_device",
+                 "mi355kkt_solve_device", "mi355kkt_set_kktreg"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from cvxopt_amd import _capi
+    L = _capi.lib()
+    for s in header_symbols():
+        assert hasattr(L, s), "libmi355kkt.so does not export %s" % s
+    assert L.mi355kkt_version() >= 100
+
+
+def test_ctypes_table_matches_header():
+    from cvxopt_amd import _capi
+    assert sorted(_capi.SIGNATURES.keys()) == header_symbols()
+
+
+def test_no_torch_types_in_the_abi():
+    src = open(os.path.join(ROOT, "include", "mi355kkt.h")).read()
+    assert "torch" not in src.lower() and "at::" not in src and "#include <hip" not in src
+
+
+def test_create_without_gpu_fails_loudly():
+    from cvxopt_amd import _capi, kkt
+    if _capi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(RuntimeError):
+        kkt.kkt_chol2(np.zeros((4, 3), order='F'), {'l': 4, 'q': [], 's': []}, np.zeros((0, 3)))
+    h = ctypes.c_void_p()
+    rc = _capi.lib().mi355kkt_create(ctypes.byref(h), 0, 0, 3, 0, 4, 0, None, 0, None)
+    assert rc == _capi.EHIP and not h.value
+    assert b"not available" in _capi.lib().mi355kkt_last_error()
+
+
+def test_argument_errors_mirror_the_reference():
+    from cvxopt_amd import kkt
+    with pytest.raises(ValueError):                      # misc.py:1381-1384
+        kkt.kkt_chol2(np.zeros((5, 3), order='F'), {'l': 2, 'q': [3], 's': []}, np.zeros((0, 3)))
+    with pytest.raises(NotImplementedError):             # mnl > 0 is cvxprog territory
+        kkt.kkt_chol(np.zeros((5, 3), order='F'), {'l': 5, 'q': [], 's': []}, np.zeros((0, 3)), mnl=2)
+    with pytest.raises(ValueError):
+        kkt._vec(np.zeros(4), 5, "x")
+    with pytest.raises(TypeError):
+        kkt._vec(np.zeros(4, dtype=np.float32), 4, "x")
+    with pytest.raises(ArithmeticError):
+        from cvxopt_amd import _capi
+        _capi.check(7, "factor")
+
+
+def test_install_and_uninstall_rebind_factories():
+    import types
+    import cvxopt_amd
+    fake = types.SimpleNamespace(kkt_chol=1, kkt_chol2=2, kkt_ldl=3, kkt_ldl2=4, kkt_qr=5)
+    cvxopt_amd.install(fake)
+    assert fake.kkt_chol2 is cvxopt_amd.kkt_chol2 and fake.kkt_ldl is cvxopt_amd.kkt_ldl and fake.kkt_qr == 5
+    cvxopt_amd.uninstall()
+    assert (fake.kkt_chol, fake.kkt_chol2, fake.kkt_ldl, fake.kkt_ldl2) == (1, 2, 3, 4)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "cvxopt_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no oracle", ""), f
+                assert "import cvxopt\n" not in txt and "from cvxopt " not in txt or f == "kkt.py", f

@@ -1,0 +1,58 @@
+#!/usr/bin/env python
+"""Turns rocprofv3's rocpd sqlite output into the text/JSON summaries committed under profiles/.
+
+    python tools/rocpd_summary.py stats  <results.db> <out.md>           # == `--kernel-trace --stats` table
+    python tools/rocpd_summary.py pmc    <fetch.db> <write.db> <kernel-substring> <out.json> n m
+
+PMC correction (guide MI355X_MICROARCH.md, section HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
+FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced streaming read -> doubled here.
+"""
+import json
+import sqlite3
+import sys
+
+
+def stats(db, out):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                       "from kernels group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
+    for name, n, s, a, mn, mx in rows:
+        lines.append("| `%s` | %d | %.3f | %.2f | %.2f | %.2f | %.1f |" % (name[:90], n, s / 1e6, a / 1e3, mn / 1e3,
+                                                                          mx / 1e3, 100.0 * s / tot))
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:14]))
+
+
+def pmc_per_kernel(db, counter, substr):
+    cur = sqlite3.connect(db).cursor()
+    cols = [c[1] for c in cur.execute("pragma table_info('counters_collection')")]
+    namecol = "kernel_name" if "kernel_name" in cols else "name"
+    q = "select %s, counter_name, value, dispatch_id from counters_collection" % namecol
+    per = {}
+    for kname, cname, val, did in cur.execute(q):
+        if cname == counter and substr in kname:
+            per[did] = per.get(did, 0.0) + float(val)
+    vals = list(per.values())
+    return vals
+
+
+def pmc(fetch_db, write_db, substr, out, n, m):
+    f = pmc_per_kernel(fetch_db, "FETCH_SIZE", substr)
+    w = pmc_per_kernel(write_db, "WRITE_SIZE", substr)
+    favg = sum(f) / max(1, len(f))
+    wavg = sum(w) / max(1, len(w))
+    rec = {"kernel": substr, "n": int(n), "m": int(m), "launches_sampled": [len(f), len(w)],
+           "FETCH_SIZE_KiB_avg": favg, "WRITE_SIZE_KiB_avg": wavg,
+           "correction": "FETCH_SIZE x2 on gfx950 (guide: counts 128-B requests as 64 B); WRITE_SIZE uncalibrated, x1",
+           "hbm_bytes_per_launch": 2.0 * favg * 1024.0 + wavg * 1024.0}
+    json.dump(rec, open(out, "w"), indent=1)
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(*sys.argv[2:9])
