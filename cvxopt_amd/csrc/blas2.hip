@@ -159,8 +159,10 @@ int launch_gemv_n_scaled(const double* G, int64_t ldg, int m, int n, const doubl
 // ===================================================================================================
 constexpr int TB = 128;
 
-__device__ __forceinline__ double bcast(double v, int srclane) {
-    return __shfl(v, srclane, 64);
+__device__ __forceinline__ double bcast(double v, int srclane) {   // srclane wave-uniform: v_readlane, no LDS
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
 }
 
 // forward substitution on a <=64 x <=64 lower block held column-major at Lb (ldl); lane i owns b_i.
@@ -195,24 +197,41 @@ __device__ __forceinline__ double tri_bwd64(const double* __restrict__ Lb, int64
     return b;
 }
 
-// Forward step for block row k0: x_k := L_kk^-1 x_k, one wave per right-hand side.
+// Forward step for block row k0: x_k := L_kk^-1 x_k, one wave per right-hand side.  Every global load of
+// the 128x128 block (row of L11, L21, L22 per lane) is issued before the first dependent instruction.
 __global__ __launch_bounds__(64) void trsv_diag_fwd_kernel(const double* __restrict__ L, int64_t ldl, int k0, int nb,
                                                            double* __restrict__ X, int64_t ldx) {
     const int lane = threadIdx.x;
     double* x = X + (int64_t)blockIdx.x * ldx + k0;
     const double* Lkk = L + k0 + (int64_t)k0 * ldl;
     const int n0 = min(nb, 64), n1 = nb - n0;
+    double r11[64], r21[64], r22[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) r11[j] = (j < lane && lane < n0) ? Lkk[lane + (int64_t)j * ldl] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) r21[j] = (lane < n1) ? Lkk[64 + lane + (int64_t)j * ldl] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) r22[j] = (j < lane && lane < n1) ? Lkk[64 + lane + (int64_t)(64 + j) * ldl] : 0.0;
+    const double d0 = (lane < n0) ? Lkk[lane + (int64_t)lane * ldl] : 1.0;
+    const double d1 = (lane < n1) ? Lkk[64 + lane + (int64_t)(64 + lane) * ldl] : 1.0;
     double b0 = (lane < n0) ? x[lane] : 0.0;
-    b0 = tri_fwd64(Lkk, ldl, n0, b0, lane);
+    double b1 = (lane < n1) ? x[64 + lane] : 0.0;
+    const double i0 = 1.0 / d0, i1 = 1.0 / d1;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) {
+        const double xj = bcast(b0 * i0, j);
+        if (lane == j) b0 = xj;
+        b0 = fma(-r11[j], xj, b0);
+        b1 = fma(-r21[j], xj, b1);
+    }
     if (lane < n0) x[lane] = b0;
     if (n1 > 0) {
-        double b1 = (lane < n1) ? x[64 + lane] : 0.0;
-#pragma unroll 8
-        for (int j = 0; j < n0; ++j) {
-            const double l = (lane < n1) ? Lkk[64 + lane + (int64_t)j * ldl] : 0.0;
-            b1 -= l * bcast(b0, j);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const double xj = bcast(b1 * i1, j);
+            if (lane == j) b1 = xj;
+            b1 = fma(-r22[j], xj, b1);
         }
-        b1 = tri_fwd64(Lkk + 64 + 64 * ldl, ldl, n1, b1, lane);
         if (lane < n1) x[64 + lane] = b1;
     }
 }
@@ -222,13 +241,14 @@ __global__ __launch_bounds__(256) void trsv_update_fwd_kernel(const double* __re
                                                               int nb, double* __restrict__ X, int64_t ldx) {
     __shared__ double xs[TB];
     double* x = X + (int64_t)blockIdx.y * ldx;
-    if (threadIdx.x < nb) xs[threadIdx.x] = x[k0 + threadIdx.x];
+    for (int t = threadIdx.x; t < nb; t += blockDim.x) xs[t] = x[k0 + t];
     __syncthreads();
-    const int i = k0 + nb + (blockIdx.x * 256 + threadIdx.x) * 2;
+    const int i = k0 + nb + (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (i >= n) return;
     const double* __restrict__ l = L + i + (int64_t)k0 * ldl;
     if (i + 1 < n) {
         double s0 = 0.0, s1 = 0.0;
+#pragma unroll 16
         for (int j = 0; j < nb; ++j) {
             const d2u a = *reinterpret_cast<const d2u*>(l + (int64_t)j * ldl);
             s0 += a.x * xs[j];
@@ -267,22 +287,35 @@ __global__ __launch_bounds__(64) void trsv_diag_bwd_kernel(const double* __restr
     double* x = X + (int64_t)blockIdx.x * ldx + k0;
     const double* Lkk = L + k0 + (int64_t)k0 * ldl;
     const int n0 = min(nb, 64), n1 = nb - n0;
-    double b1 = 0.0;
+    // lane i owns column i of each sub-block (transpose solve): c22 = L22[j][i], c21 = L21[j][i], c11 = L11[j][i]
+    double c11[64], c21[64], c22[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) c22[j] = (j > lane && j < n1) ? Lkk[64 + j + (int64_t)(64 + lane) * ldl] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) c21[j] = (j < n1 && lane < n0) ? Lkk[64 + j + (int64_t)lane * ldl] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 64; ++j) c11[j] = (j > lane && j < n0) ? Lkk[j + (int64_t)lane * ldl] : 0.0;
+    const double d0 = (lane < n0) ? Lkk[lane + (int64_t)lane * ldl] : 1.0;
+    const double d1 = (lane < n1) ? Lkk[64 + lane + (int64_t)(64 + lane) * ldl] : 1.0;
+    double b0 = (lane < n0) ? x[lane] : 0.0;
+    double b1 = (lane < n1) ? x[64 + lane] : 0.0;
+    const double i0 = 1.0 / d0, i1 = 1.0 / d1;
     if (n1 > 0) {
-        b1 = (lane < n1) ? x[64 + lane] : 0.0;
-        b1 = tri_bwd64(Lkk + 64 + 64 * ldl, ldl, n1, b1, lane);
+#pragma unroll
+        for (int j = 63; j >= 0; --j) {
+            const double xj = bcast(b1 * i1, j);
+            if (lane == j) b1 = xj;
+            b1 = fma(-c22[j], xj, b1);
+            b0 = fma(-c21[j], xj, b0);
+        }
         if (lane < n1) x[64 + lane] = b1;
     }
-    double b0 = (lane < n0) ? x[lane] : 0.0;
-    if (n1 > 0) {
-        // b0_i -= sum_j L[64+j][i] x1_j : column i of the lower-left block, contiguous in j
-#pragma unroll 8
-        for (int j = 0; j < n1; ++j) {
-            const double l = (lane < n0) ? Lkk[64 + j + (int64_t)lane * ldl] : 0.0;
-            b0 -= l * bcast(b1, j);
-        }
+#pragma unroll
+    for (int j = 63; j >= 0; --j) {
+        const double xj = bcast(b0 * i0, j);
+        if (lane == j) b0 = xj;
+        b0 = fma(-c11[j], xj, b0);
     }
-    b0 = tri_bwd64(Lkk, ldl, n0, b0, lane);
     if (lane < n0) x[lane] = b0;
 }
 
@@ -295,7 +328,7 @@ int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ld
             hipLaunchKernelGGL(trsv_diag_fwd_kernel, dim3(nrhs), dim3(64), 0, st, L, ldl, k0, nb, X, ldx);
             const int rem = n - k0 - nb;
             if (rem > 0)
-                hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((rem + 511) / 512, nrhs), dim3(256), 0, st, L, ldl, n,
+                hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((rem + 127) / 128, nrhs), dim3(64), 0, st, L, ldl, n,
                                    k0, nb, X, ldx);
         }
     } else {

@@ -69,6 +69,7 @@ int run_mfma_f64_peak(int iters, int num_cus, float* tflops);
 struct PotrfWork {
     int* d_info = nullptr;   // device int: 0 ok, >0 first failing pivot (1-based, LAPACK convention)
     int* h_info = nullptr;   // pinned host mirror
+    double* d_dinv = nullptr; // reciprocal pivots of the current diagonal block (potf2 -> trsm)
 };
 int potrf_work_init(PotrfWork& w);
 void potrf_work_free(PotrfWork& w);

@@ -1,7 +1,8 @@
 """Developer probe (not a test): per-stage timings at a given size through the C ABI."""
 import ctypes as C, sys, time
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cvxopt_amd import _capi, kkt, synth
 
 def main(n, m, reps=3):
