@@ -10,7 +10,7 @@ The compute lives in libmi355kkt.so (hand-written HIP for gfx950 behind the C AB
 include/mi355kkt.h).  There is no CPU fallback: importing works everywhere, but creating a solver
 without the library or without a GPU raises.
 """
-from .kkt import (kkt_chol, kkt_chol2, kkt_ldl, kkt_ldl2, install, uninstall,   # noqa: F401
+from .kkt import (kkt_chol, kkt_chol2, kkt_ldl, kkt_ldl2, kkt_qr, install, uninstall,   # noqa: F401
                   kktsolver_qp, kktsolver_lp)
 from . import synth   # noqa: F401
 

@@ -17,8 +17,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 // zs = w .* z and zss = w .* zs   (w == nullptr: zs = z, zss unused)
-__global__ __launch_bounds__(256) void scale_vec_kernel(const double* __restrict__ w, const double* __restrict__ z,
-                                                        double* __restrict__ zs, double* __restrict__ zss, int m) {
+__global__ __launch_bounds__(256) void scale_vec_kernel(const double* __restrict__ w, const double* z, double* zs,
+                                                        double* __restrict__ zss, int m) {   // z may alias zs
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < m) {
         if (w) {

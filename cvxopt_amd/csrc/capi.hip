@@ -75,6 +75,12 @@ struct mi355kkt_solver {
     double kktreg = 0.0;
     // per-factor state
     double* dW = nullptr;      // effective diagonal scaling of the 'l' block (di, possibly / sqrt(1+reg))
+    // second-order cones: Gs = W^-T G is materialised (the cone transform is not diagonal)
+    ConeLayout cl;
+    double* dGs = nullptr;     // cdim x n, only when nq > 0
+    double* dV = nullptr;      // concatenated v_k
+    double* dBeta = nullptr;   // beta_k
+    double* dWst = nullptr;    // staging for host-side W (di | v | beta)
     double* dS = nullptr;      // n x n: S then its Cholesky factor L
     double* dAsct = nullptr;   // n x p
     double* dK = nullptr;      // p x p
@@ -199,7 +205,14 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     if ((rc = alloc(&h->dtn, N))) return fail(rc);
     if ((rc = alloc(&h->dtp, P))) return fail(rc);
     if ((rc = alloc(&h->dwork, dmax(gemv_work_doubles(h->cdim, n), gemv_work_doubles(n, p))))) return fail(rc);
-    h->hbuf_doubles = dmax(N + P + C, 2 * C) + 8;
+    if ((rc = alloc(&h->dWst, C + (size_t)nq + 8))) return fail(rc);
+    if (nq > 0) {
+        if ((rc = alloc(&h->dGs, C * N))) return fail(rc);
+        if ((rc = alloc(&h->dV, C))) return fail(rc);
+        if ((rc = alloc(&h->dBeta, (size_t)nq))) return fail(rc);
+        if ((rc = cone_layout_build(h->cl, ml, h->q))) return fail(rc);
+    }
+    h->hbuf_doubles = dmax(N + P + C, 2 * C + (size_t)nq) + 8;
     if (hipHostMalloc(&h->hbuf, sizeof(double) * h->hbuf_doubles) != hipSuccess) return fail(MI355KKT_ENOMEM);
     if ((rc = potrf_work_init(h->pw))) return fail(rc);
     if ((rc = build_syrk_plan(h->planS, n, h->cdim, h->num_cus))) return fail(rc);
@@ -216,7 +229,8 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     (void)hipSetDevice(h->device);
     if (h->st) (void)hipStreamSynchronize(h->st);
     double* bufs[] = {h->G_owned, h->A_owned, h->H_owned, h->dW, h->dS, h->dAsct, h->dK,
-                      h->dx, h->dy, h->dz, h->dzs, h->dtn, h->dtp, h->dwork};
+                      h->dx, h->dy, h->dz, h->dzs, h->dtn, h->dtp, h->dwork, h->dWst, h->dGs, h->dV, h->dBeta};
+    cone_layout_free(h->cl);
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (h->hbuf) (void)hipHostFree(h->hbuf);
@@ -326,7 +340,15 @@ static int fetch_info(mi355kkt_solver* h, int* info) {
 
 // assemble S = H + [reg I] + Gs' Gs [+ A'A]
 static int assemble_S(mi355kkt_solver* h, bool add_AtA) {
-    if (int e = launch_syrk_scaled(h->planS, h->dG, h->ldG, h->ml > 0 ? h->dW : nullptr, h->dS, h->n, h->dH, h->ldH, h->st, &h->ev[6]))
+    if (!h->q.empty()) {
+        // Gs = W^-T G once (HBM-bound), then the unscaled SYRK on Gs
+        if (int e = launch_cone_scale(h->cl, h->dG, h->ldG, h->dGs, h->cdim, h->n, h->dW, h->dV, h->dBeta,
+                                      1.0 / std::sqrt(1.0 + h->kktreg), h->st))
+            return e;
+        if (int e = launch_syrk_scaled(h->planS, h->dGs, h->cdim, nullptr, h->dS, h->n, h->dH, h->ldH, h->st, &h->ev[6]))
+            return e;
+    } else if (int e = launch_syrk_scaled(h->planS, h->dG, h->ldG, h->ml > 0 ? h->dW : nullptr, h->dS, h->n, h->dH,
+                                          h->ldH, h->st, &h->ev[6]))
         return e;
     if (h->kktreg != 0.0 && h->n > 0) hipLaunchKernelGGL(diag_add_kernel, g1(h->n), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->n, h->kktreg);
     if (add_AtA && h->p > 0)
@@ -336,11 +358,12 @@ static int assemble_S(mi355kkt_solver* h, bool add_AtA) {
 
 int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     if (!h || !W) { set_last_error("factor: null argument"); return MI355KKT_EINVAL; }
-    if (!h->q.empty() || !h->s.empty()) {
-        set_last_error("factor: second-order / semidefinite cones not implemented on the device yet");
+    if (!h->s.empty()) {
+        set_last_error("factor: semidefinite ('s') cones are not implemented on the device yet");
         return MI355KKT_ENOTIMPL;
     }
     if (h->ml > 0 && !W->di) { set_last_error("factor: W.di missing"); return MI355KKT_EINVAL; }
+    if (!h->q.empty() && (!W->v || !W->beta)) { set_last_error("factor: W.v / W.beta missing"); return MI355KKT_EINVAL; }
     if ((h->cdim > 0 && h->n > 0 && !h->dG) || (h->p > 0 && h->n > 0 && !h->dA)) {
         set_last_error("factor: G / A not set");
         return MI355KKT_EINVAL;
@@ -349,7 +372,15 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     h->factored = false;
     const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);   // K[z,z] = -(1+reg): fold into the row scaling
     KKT_HIP_CHECK(hipEventRecord(h->ev[0], h->st));
-    if (h->ml > 0) hipLaunchKernelGGL(scaled_copy_kernel, g1(h->ml), dim3(256), 0, h->st, W->di, h->dW, h->ml, zscale);
+    if (!h->q.empty()) {
+        // cone path: dW keeps the raw di (the 1/sqrt(1+reg) factor is applied by launch_cone_scale)
+        if (h->ml > 0) hipLaunchKernelGGL(scaled_copy_kernel, g1(h->ml), dim3(256), 0, h->st, W->di, h->dW, h->ml, 1.0);
+        KKT_HIP_CHECK(hipMemcpyAsync(h->dV, W->v, sizeof(double) * h->cl.vlen, hipMemcpyDeviceToDevice, h->st));
+        KKT_HIP_CHECK(hipMemcpyAsync(h->dBeta, W->beta, sizeof(double) * h->q.size(), hipMemcpyDeviceToDevice, h->st));
+        if (int e = cone_layout_set_beta(h->cl, h->dBeta, h->st)) return e;
+    } else if (h->ml > 0) {
+        hipLaunchKernelGGL(scaled_copy_kernel, g1(h->ml), dim3(256), 0, h->st, W->di, h->dW, h->ml, zscale);
+    }
     if (int e = assemble_S(h, h->singular)) return e;
     KKT_HIP_CHECK(hipEventRecord(h->ev[1], h->st));
     if (int e = launch_potrf(h->dS, h->n, h->n, h->pw, h->st)) return e;
@@ -393,11 +424,19 @@ int mi355kkt_factor(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     if (h->ml > 0 && !W->di) { set_last_error("factor: W.di missing"); return MI355KKT_EINVAL; }
     if (int e = bind(h)) return e;
     mi355kkt_scaling Wd = {};
-    if (h->ml > 0) {
-        memcpy(h->hbuf, W->di, sizeof(double) * h->ml);
-        // staged into dzs (free between solves) so that dW can hold the effective scaling
-        KKT_HIP_CHECK(hipMemcpyAsync(h->dzs, h->hbuf, sizeof(double) * h->ml, hipMemcpyHostToDevice, h->st));
-        Wd.di = h->dzs;
+    const size_t ml = h->ml, vlen = h->cl.vlen, nq = h->q.size();
+    if (nq > 0 && (!W->v || !W->beta)) { set_last_error("factor: W.v / W.beta missing"); return MI355KKT_EINVAL; }
+    if (ml) memcpy(h->hbuf, W->di, sizeof(double) * ml);
+    if (nq) {
+        memcpy(h->hbuf + ml, W->v, sizeof(double) * vlen);
+        memcpy(h->hbuf + ml + vlen, W->beta, sizeof(double) * nq);
+    }
+    if (ml + vlen + nq)
+        KKT_HIP_CHECK(hipMemcpyAsync(h->dWst, h->hbuf, sizeof(double) * (ml + vlen + nq), hipMemcpyHostToDevice, h->st));
+    if (ml) Wd.di = h->dWst;
+    if (nq) {
+        Wd.v = h->dWst + ml;
+        Wd.beta = h->dWst + ml + vlen;
     }
     return mi355kkt_factor_device(h, &Wd);
 }
@@ -410,7 +449,16 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     const int n = h->n, p = h->p, m = h->cdim;
     KKT_HIP_CHECK(hipEventRecord(h->ev[4], st));
     // zs = W^-T bz ;  x += Gs' zs                                     (misc.py:1513, :1524)
-    if (int e = launch_gemv_t_scaled(h->dG, h->ldG, m, n, h->dW, dz, h->dzs, dx, h->dwork, st)) return e;
+    const bool cones = !h->q.empty();
+    const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);
+    const double* Gmat = cones ? h->dGs : h->dG;
+    const int64_t ldGm = cones ? (int64_t)h->cdim : h->ldG;
+    const double* wvec = cones ? nullptr : h->dW;
+    if (cones) {
+        if (int e = launch_cone_scale(h->cl, dz, m, h->dzs, m, 1, h->dW, h->dV, h->dBeta, zscale, st)) return e;
+        if (int e = launch_gemv_t_scaled(Gmat, ldGm, m, n, nullptr, h->dzs, h->dzs, dx, h->dwork, st)) return e;
+    } else if (int e = launch_gemv_t_scaled(h->dG, h->ldG, m, n, h->dW, dz, h->dzs, dx, h->dwork, st))
+        return e;
     if (h->singular && p > 0)                                       // x += A' by  (:1527)
         if (int e = launch_gemv_t_scaled(h->dA, h->ldA, p, n, nullptr, dy, h->dtp, dx, nullptr, st)) return e;
     if (int e = launch_trsm_lower(h->dS, n, n, dx, n, 1, 0, st)) return e;          // :1529
@@ -425,8 +473,7 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     }
     if (int e = launch_trsm_lower(h->dS, n, n, dx, n, 1, 1, st)) return e;          // :1555
     // z := Gs x - zs   (/ sqrt(1+reg) when the z-block pivot is -(1+reg))       (:1563)
-    const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);
-    if (int e = launch_gemv_n_scaled(h->dG, h->ldG, m, n, h->dW, dx, h->dzs, dz, zscale, -zscale, h->dwork, st)) return e;
+    if (int e = launch_gemv_n_scaled(Gmat, ldGm, m, n, wvec, dx, h->dzs, dz, zscale, -zscale, h->dwork, st)) return e;
     KKT_HIP_CHECK(hipEventRecord(h->ev[5], st));
     return 0;
 }
@@ -524,6 +571,20 @@ int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const d
     OpTimer t(ms);
     if (int e = launch_syrk_scaled(plan, dG, ldG, ddi, dS, ldS, dH, ldH, nullptr)) return e;
     return t.finish();
+}
+
+int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
+                           const double* dv, const double* dbeta, float* ms) {
+    ConeLayout cl;
+    std::vector<int> qq(q, q + nq);
+    if (int e = cone_layout_build(cl, ml, qq)) return e;
+    int rc = 0;
+    if (nq > 0) rc = cone_layout_set_beta(cl, dbeta, nullptr);
+    OpTimer t(ms);
+    if (!rc) rc = launch_cone_scale(cl, dX, ldX, dX, ldX, ncols, ddi, dv, dbeta, 1.0, nullptr);
+    if (!rc) rc = t.finish();
+    cone_layout_free(cl);
+    return rc;
 }
 
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops) { return run_mfma_f64_peak(iters, cur_num_cus(), tflops); }

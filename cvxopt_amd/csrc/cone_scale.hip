@@ -1,0 +1,172 @@
+// Nesterov-Todd scaling W^-T applied to a block of columns, on the device (HBM-bound):
+// the replacement of misc_solvers.scale(x, W, trans='T', inverse='I') (reference
+// src/C/misc_solvers.c:85-244) for the 'l' and 'q' cones, as used by the kktsolvers
+// (misc.py:1093, :1116, :1271, :1306, :1513).
+//   'l' rows:   y = di .* x                                        (misc_solvers.c:132-141)
+//   'q' cone k: y = (1/beta) (2 Jv (Jv)'x - J x),  J = diag(1,-1,...,-1)   (misc_solvers.c:144-183)
+// W_k^-1 is symmetric, so the same kernel serves trans = 'N' and 'T'.
+// Where the reference makes one dgemv + one dger + ncols dscal calls PER CONE (2 M BLAS-1 calls for
+// 1024 cones x 2048 columns), this is one launch: each (cone, column) pair is one coalesced read and
+// one coalesced write of the cone's rows.
+#include "kkt_common.h"
+
+namespace mi355kkt {
+
+// out[:, j] = W^-T in[:, j] for the l rows: plain diagonal scaling
+__global__ __launch_bounds__(256) void scale_l_kernel(const double* __restrict__ in, int64_t ldi,
+                                                      double* __restrict__ out, int64_t ldo, int ml, int ncols,
+                                                      const double* __restrict__ di, double extra) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i < ml && j < ncols) out[i + (int64_t)j * ldo] = extra * di[i] * in[i + (int64_t)j * ldi];
+}
+
+// small cones (dimension <= 32): one thread per (cone, column); cone rows are contiguous in the column.
+// grid: (ceil(ncones/64), ncols); cone descriptors: off[k] (row offset), dim[k], voff[k] (offset into v)
+__global__ __launch_bounds__(64) void scale_q_small_kernel(const double* __restrict__ in, int64_t ldi,
+                                                           double* __restrict__ out, int64_t ldo, int ncones,
+                                                           const int* __restrict__ off, const int* __restrict__ dim,
+                                                           const int* __restrict__ voff, const double* __restrict__ v,
+                                                           const double* __restrict__ beta, int ncols, double extra) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (k >= ncones || j >= ncols) return;
+    const int m = dim[k];
+    const double* __restrict__ x = in + off[k] + (int64_t)j * ldi;
+    double* __restrict__ y = out + off[k] + (int64_t)j * ldo;
+    const double* __restrict__ vk = v + voff[k];
+    double xv[32];
+    double w = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < m) {
+            xv[i] = x[i];
+            w += (i == 0 ? vk[0] : -vk[i]) * xv[i];       // w = (Jv)' x
+        }
+    }
+    const double s = extra / beta[k];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < m) {
+            const double jv = (i == 0 ? vk[0] : -vk[i]);
+            const double jx = (i == 0 ? xv[0] : -xv[i]);
+            y[i] = s * (2.0 * jv * w - jx);
+        }
+    }
+}
+
+// large cones: one wave per (cone, column), lanes stride the cone's rows
+__global__ __launch_bounds__(256) void scale_q_large_kernel(const double* __restrict__ in, int64_t ldi,
+                                                            double* __restrict__ out, int64_t ldo, int ncones,
+                                                            const int* __restrict__ cone_ids,
+                                                            const int* __restrict__ off, const int* __restrict__ dim,
+                                                            const int* __restrict__ voff, const double* __restrict__ v,
+                                                            const double* __restrict__ beta, int ncols, double extra) {
+    const int lane = threadIdx.x & 63;
+    const int kk = blockIdx.x;
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (kk >= ncones || j >= ncols) return;
+    const int k = cone_ids[kk];
+    const int m = dim[k];
+    const double* __restrict__ x = in + off[k] + (int64_t)j * ldi;
+    double* __restrict__ y = out + off[k] + (int64_t)j * ldo;
+    const double* __restrict__ vk = v + voff[k];
+    double w = 0.0;
+    for (int i = lane; i < m; i += 64) w += (i == 0 ? vk[0] : -vk[i]) * x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    const double s = extra / beta[k];
+    for (int i = lane; i < m; i += 64) {
+        const double jv = (i == 0 ? vk[0] : -vk[i]);
+        const double jx = (i == 0 ? x[0] : -x[i]);
+        y[i] = s * (2.0 * jv * w - jx);
+    }
+}
+
+int cone_layout_build(ConeLayout& cl, int ml, const std::vector<int>& q) {
+    cone_layout_free(cl);
+    cl.ml = ml;
+    cl.nq = (int)q.size();
+    if (cl.nq == 0) return 0;
+    std::vector<int> off(cl.nq), dim(q), voff(cl.nq), small_ids, large_ids;
+    int o = ml, vo = 0;
+    for (int k = 0; k < cl.nq; ++k) {
+        off[k] = o;
+        voff[k] = vo;
+        o += q[k];
+        vo += q[k];
+        (q[k] <= 32 ? small_ids : large_ids).push_back(k);
+    }
+    cl.vlen = vo;
+    // the small-cone kernel indexes cones densely: build a compacted descriptor set for it
+    std::vector<int> s_off, s_dim, s_voff, s_beta_idx;
+    for (int k : small_ids) {
+        s_off.push_back(off[k]);
+        s_dim.push_back(dim[k]);
+        s_voff.push_back(voff[k]);
+    }
+    cl.n_small = (int)small_ids.size();
+    cl.n_large = (int)large_ids.size();
+    auto up = [&](int** d, const std::vector<int>& h) -> int {
+        KKT_HIP_CHECK(hipMalloc(d, sizeof(int) * (h.size() ? h.size() : 1)));
+        if (!h.empty()) KKT_HIP_CHECK(hipMemcpy(*d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (int e = up(&cl.d_off, off)) return e;
+    if (int e = up(&cl.d_dim, dim)) return e;
+    if (int e = up(&cl.d_voff, voff)) return e;
+    if (int e = up(&cl.d_small_ids, small_ids)) return e;
+    if (int e = up(&cl.d_large_ids, large_ids)) return e;
+    if (int e = up(&cl.d_s_off, s_off)) return e;
+    if (int e = up(&cl.d_s_dim, s_dim)) return e;
+    if (int e = up(&cl.d_s_voff, s_voff)) return e;
+    // beta for the compacted small set is gathered on the device at factor time (beta changes per factor)
+    KKT_HIP_CHECK(hipMalloc(&cl.d_s_beta, sizeof(double) * (cl.n_small ? cl.n_small : 1)));
+    return 0;
+}
+
+void cone_layout_free(ConeLayout& cl) {
+    int* ip[] = {cl.d_off, cl.d_dim, cl.d_voff, cl.d_small_ids, cl.d_large_ids, cl.d_s_off, cl.d_s_dim, cl.d_s_voff};
+    for (int* p : ip)
+        if (p) (void)hipFree(p);
+    if (cl.d_s_beta) (void)hipFree(cl.d_s_beta);
+    cl = ConeLayout();
+}
+
+__global__ void gather_beta_kernel(const double* __restrict__ beta, const int* __restrict__ ids, double* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = beta[ids[i]];
+}
+
+int cone_layout_set_beta(ConeLayout& cl, const double* d_beta, hipStream_t st) {
+    if (cl.n_small > 0) {
+        hipLaunchKernelGGL(gather_beta_kernel, dim3((cl.n_small + 255) / 256), dim3(256), 0, st, d_beta, cl.d_small_ids,
+                           cl.d_s_beta, cl.n_small);
+        KKT_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+// out(:, 0:ncols) = extra * W^-T in(:, 0:ncols)   for the l + q rows (in and out may alias)
+int launch_cone_scale(const ConeLayout& cl, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
+                      const double* d_di, const double* d_v, const double* d_beta, double extra, hipStream_t st) {
+    if (ncols <= 0) return 0;
+    if (cl.ml > 0) {
+        hipLaunchKernelGGL(scale_l_kernel, dim3((cl.ml + 255) / 256, ncols), dim3(256), 0, st, in, ldi, out, ldo, cl.ml,
+                           ncols, d_di, extra);
+        KKT_HIP_CHECK(hipGetLastError());
+    }
+    if (cl.n_small > 0) {
+        hipLaunchKernelGGL(scale_q_small_kernel, dim3((cl.n_small + 63) / 64, ncols), dim3(64), 0, st, in, ldi, out, ldo,
+                           cl.n_small, cl.d_s_off, cl.d_s_dim, cl.d_s_voff, d_v, cl.d_s_beta, ncols, extra);
+        KKT_HIP_CHECK(hipGetLastError());
+    }
+    if (cl.n_large > 0) {
+        hipLaunchKernelGGL(scale_q_large_kernel, dim3(cl.n_large, (ncols + 3) / 4), dim3(256), 0, st, in, ldi, out, ldo,
+                           cl.n_large, cl.d_large_ids, cl.d_off, cl.d_dim, cl.d_voff, d_v, d_beta, ncols, extra);
+        KKT_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
+}  // namespace mi355kkt

@@ -90,4 +90,20 @@ size_t gemv_work_doubles(int m, int n);
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st);
 
+
+// ---- second-order-cone scaling --------------------------------------------------------------------
+struct ConeLayout {
+    int ml = 0, nq = 0, vlen = 0, n_small = 0, n_large = 0;
+    int *d_off = nullptr, *d_dim = nullptr, *d_voff = nullptr;         // per cone (original numbering)
+    int *d_small_ids = nullptr, *d_large_ids = nullptr;                // cones of dimension <= 32 / > 32
+    int *d_s_off = nullptr, *d_s_dim = nullptr, *d_s_voff = nullptr;   // compacted descriptors of the small cones
+    double* d_s_beta = nullptr;                                        // beta gathered for the small cones
+};
+int cone_layout_build(ConeLayout& cl, int ml, const std::vector<int>& q);
+void cone_layout_free(ConeLayout& cl);
+int cone_layout_set_beta(ConeLayout& cl, const double* d_beta, hipStream_t st);
+// out = extra * W^-T in on the l + q rows, for ncols columns (in/out may alias)
+int launch_cone_scale(const ConeLayout& cl, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
+                      const double* d_di, const double* d_v, const double* d_beta, double extra, hipStream_t st);
+
 }  // namespace mi355kkt

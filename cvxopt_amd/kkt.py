@@ -4,6 +4,7 @@
     kkt_chol (G, dims, A, mnl=0)                 misc.py:1213
     kkt_ldl  (G, dims, A, mnl=0, kktreg=None)    misc.py:1055
     kkt_ldl2 (G, dims, A, mnl=0)                 misc.py:1128
+    kkt_qr   (G, dims, A)                        misc.py:1570
 
 Each returns `factor(W, H=None, Df=None)` which returns `solve(x, y, z)`; same argument meaning, same
 in-place contract (x, y, z := ux, uy, W*uz) and the same exceptions as the reference (ArithmeticError
@@ -269,6 +270,17 @@ def kkt_ldl2(G, dims, A, mnl=0):
     return _factory(_capi.LDL2, G, dims, A, mnl)
 
 
+def kkt_qr(G, dims, A):
+    """Mirror of misc.kkt_qr (misc.py:1570; conelp only, H = 0).  Same KKT system, solved by the device
+    engine's reduced Cholesky form instead of two QR factorisations."""
+    fac = _factory(_capi.CHOL, G, dims, A, 0)
+
+    def factor(W):
+        return fac(W, None)
+    factor.engine = fac.engine
+    return factor
+
+
 # ---- ready-made kktsolver callables for the drivers --------------------------------------------------
 def kktsolver_qp(G, dims, A, P, kind="chol2", kktreg=None):
     """`kktsolver` callable for solvers.coneqp (coneprog.py:1969-1981 does `factor(W, P)`)."""
@@ -301,7 +313,8 @@ def install(misc_module=None):
     (reference coneprog.py:574-583, :1972-1979) so the string names become GPU-backed."""
     if misc_module is None:
         import cvxopt.misc as misc_module
-    for name, f in (("kkt_chol", kkt_chol), ("kkt_chol2", kkt_chol2), ("kkt_ldl", kkt_ldl), ("kkt_ldl2", kkt_ldl2)):
+    for name, f in (("kkt_chol", kkt_chol), ("kkt_chol2", kkt_chol2), ("kkt_ldl", kkt_ldl), ("kkt_ldl2", kkt_ldl2),
+                    ("kkt_qr", kkt_qr)):
         if (id(misc_module), name) not in _saved:
             _saved[(id(misc_module), name)] = (misc_module, getattr(misc_module, name))
         setattr(misc_module, name, f)

@@ -124,6 +124,9 @@ int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL);
 /* S(lower) = H(lower) + G' diag(di)^2 G ;  di or H may be NULL */
 int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
                             int64_t ldH, double* dS, int64_t ldS, float* ms);
+/* X(:, 0:ncols) := W^-T X on the 'l' and 'q' rows, in place (misc_solvers.scale, trans='T', inverse='I') */
+int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
+                           const double* dv, const double* dbeta, float* ms);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops);
 /* in-place lower Cholesky; *info as LAPACK dpotrf */

@@ -72,9 +72,10 @@ def test_argument_errors_mirror_the_reference():
 def test_install_and_uninstall_rebind_factories():
     import types
     import cvxopt_amd
-    fake = types.SimpleNamespace(kkt_chol=1, kkt_chol2=2, kkt_ldl=3, kkt_ldl2=4, kkt_qr=5)
+    fake = types.SimpleNamespace(kkt_chol=1, kkt_chol2=2, kkt_ldl=3, kkt_ldl2=4, kkt_qr=5, other=6)
     cvxopt_amd.install(fake)
-    assert fake.kkt_chol2 is cvxopt_amd.kkt_chol2 and fake.kkt_ldl is cvxopt_amd.kkt_ldl and fake.kkt_qr == 5
+    assert fake.kkt_chol2 is cvxopt_amd.kkt_chol2 and fake.kkt_ldl is cvxopt_amd.kkt_ldl and fake.other == 6
+    assert fake.kkt_qr is cvxopt_amd.kkt_qr
     cvxopt_amd.uninstall()
     assert (fake.kkt_chol, fake.kkt_chol2, fake.kkt_ldl, fake.kkt_ldl2) == (1, 2, 3, 4)
 

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from cvxopt_amd import kkt, synth
+from helpers import relerr as _relerr  # noqa: F401
 from oracle import kkt_oracle as ko
 
 pytestmark = pytest.mark.gpu
@@ -194,3 +195,94 @@ def test_install_routes_string_names_to_gpu(ref_cvxopt):
     for g in (got, got_ldl):
         assert g['iterations'] == ref['iterations']
         assert abs(g['primal objective'] - ref['primal objective']) <= 1e-9 * abs(ref['primal objective'])
+
+
+# ---- second-order cones (BASELINE config 3) ------------------------------------------------------------
+from helpers import load_golden, dims_of, w_of   # noqa: E402
+
+
+@pytest.mark.parametrize("case", ["scale1", "scale3"])
+def test_cone_scale_op_matches_reference_golden(capi, case):
+    import ctypes as C
+    rec = load_golden(case)
+    dims = dims_of(rec)
+    W = w_of(rec, dims)
+    x = np.asfortranarray(rec['x'])
+    dX = capi.DeviceBuffer.from_array(x)
+    q = (C.c_int * len(dims['q']))(*dims['q'])
+    ddi = capi.DeviceBuffer.from_array(W['di'] if dims['l'] else np.zeros(1))
+    dv = capi.DeviceBuffer.from_array(np.concatenate(W['v']))
+    db = capi.DeviceBuffer.from_array(np.array(W['beta']))
+    capi.check(capi.lib().mi355kkt_op_cone_scale(dims['l'], len(dims['q']), q, dX.ptr, x.shape[0], x.shape[1],
+                                                ddi.ptr, dv.ptr, db.ptr, None), "op_cone_scale")
+    got = dX.to_array(x.shape)
+    assert relerr(got, rec['out_TI']) < 1e-13
+
+
+@pytest.mark.parametrize("case,kinds", [("kkt_soc", ["chol", "ldl", "ldl2"]), ("kkt_soc_many", ["chol", "ldl"]),
+                                        ("kkt_lp_p5", ["chol2", "chol", "ldl", "ldl2"])])
+def test_hook_matches_reference_golden(case, kinds):
+    rec = load_golden(case)
+    dims = dims_of(rec)
+    W = w_of(rec, dims)
+    G, A, H = np.asfortranarray(rec['G']), np.asfortranarray(rec['A']), np.asfortranarray(rec['H'])
+    for kind in kinds:
+        f = getattr(kkt, 'kkt_' + kind)(G, dims, A)
+        x, y, z = rec['bx'].copy(), rec['by'].copy(), rec['bz'].copy()
+        f(W, H)(x, y, z)
+        assert relerr(x, rec['x_' + kind]) < 1e-9 and relerr(y, rec['y_' + kind]) < 1e-9
+        assert relerr(z, rec['z_' + kind]) < 1e-9
+        f.engine.close()
+    f = kkt.kkt_ldl(G, dims, A, kktreg=1e-3)
+    x, y, z = rec['bx'].copy(), rec['by'].copy(), rec['bz'].copy()
+    f(W, H)(x, y, z)
+    assert relerr(x, rec['x_ldlreg']) < 1e-9 and relerr(z, rec['z_ldlreg']) < 1e-9
+    f.engine.close()
+
+
+@pytest.mark.parametrize("n,ml,q,p", [(40, 0, [8] * 6, 0), (64, 10, [3, 40, 5, 100], 4), (200, 0, [4] * 100, 0),
+                                      (128, 7, [1, 2, 33], 3)])
+def test_soc_factor_solve_matches_oracle(n, ml, q, p):
+    dims = {'l': ml, 'q': q, 's': []}
+    m = ml + sum(q)
+    rng = np.random.default_rng(n + m)
+    G = np.asfortranarray(rng.standard_normal((m, n)))
+    A = np.asfortranarray(rng.standard_normal((p, n)))
+    B = rng.standard_normal((n, n))
+    H = np.asfortranarray(B @ B.T / n + 0.05 * np.eye(n))
+    f = kkt.kkt_chol(G, dims, A)
+    for it in range(2):
+        W = synth.random_scaling(dims, seed=it, spread=1.0)
+        rhs = rand_rhs(rng, n, p, m)
+        x, y, z = (u.copy() for u in rhs)
+        f(W, H)(x, y, z)
+        xo, yo, zo = (u.copy() for u in rhs)
+        ko.KktLdl(G, dims, A).factor(W, H)(xo, yo, zo)
+        for g, r in zip((x, y, z), (xo, yo, zo)):
+            assert relerr(g, r) < 1e-8, relerr(g, r)
+        res = ko.kkt_residual(H, A, G, W, dims, rhs[0], rhs[1], rhs[2], x, y, z)
+        # accuracy bar = the reference's own reduced (normal-equations) formulation, misc.kkt_chol
+        xc, yc, zc = (u.copy() for u in rhs)
+        ko.KktChol(G, dims, A).factor(W, H)(xc, yc, zc)
+        res_ref = ko.kkt_residual(H, A, G, W, dims, rhs[0], rhs[1], rhs[2], xc, yc, zc)
+        assert res < max(RESID_TOL, 10.0 * res_ref), (res, res_ref)
+    f.engine.close()
+
+
+@pytest.mark.parametrize("name", ["conelp_socp_small", "conelp_socp_mid"])
+def test_conelp_socp_drop_in(ref_cvxopt, name):
+    """BASELINE config 3 (scaled down): solvers.conelp on a SOCP with the GPU kktsolver vs the golden
+    reference run (kktsolver='chol' on the CPU): same status / iterations / objectives."""
+    from cvxopt import matrix, solvers
+    g = load_golden(name)
+    pr = synth.socp(int(g['n']), int(g['N']), int(g['r']), seed=int(g['seed']), ml=int(g['ml']))
+    c, G, h = matrix(pr['c']), matrix(pr['G']), matrix(pr['h'])
+    A = ref_cvxopt.spmatrix([], [], [], (0, int(g['n'])))
+    for kind in ("chol", "qr"):
+        ks = kkt.kktsolver_lp(G, pr['dims'], A, kind="chol")
+        sol = solvers.conelp(c, G, h, pr['dims'], kktsolver=ks)
+        assert sol['status'] == 'optimal' and int(g['status_optimal']) == 1
+        assert sol['iterations'] == int(g['iterations'])
+        assert abs(sol['primal objective'] - float(g['pobj'])) <= 1e-8 * max(1.0, abs(float(g['pobj'])))
+        assert relerr(np.array(sol['x']).ravel(), g['x']) < 1e-6
+        ks.engine.close()
