@@ -56,6 +56,13 @@ SIGNATURES = {
     "mi355kkt_is_singular_mode": (C.c_int, [C.c_void_p]),
     "mi355kkt_get_timings": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
     "mi355kkt_get_factor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_batch_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi355kkt_batch_destroy": (None, [C.c_void_p]),
+    "mi355kkt_batch_set_problem": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mi355kkt_batch_factor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, c_int_p]),
+    "mi355kkt_batch_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mi355kkt_batch_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mi355kkt_batch_last_factor_ms": (C.c_float, [C.c_void_p]),
     "mi355kkt_op_syrk_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_int64, c_float_p]),
     "mi355kkt_op_cone_scale": (C.c_int, [C.c_int, C.c_int, c_int_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,

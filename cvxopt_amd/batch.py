@@ -1,0 +1,311 @@
+"""Batched mode: many independent dense LP-cone QPs of one shape (BASELINE configs[4]).
+
+    min 1/2 x'P_b x + q_b'x   s.t.  G_b x <= h_b            b = 0 .. B-1,  no equalities
+
+There is no reference API for a batch; parity is per problem against individual
+`solvers.coneqp` calls.  The KKT work (the hot path: S_b = P_b + G_b'D_b^2 G_b, Cholesky, two solves per
+iteration for every problem) runs as batched HIP kernels behind `mi355kkt_batch_*`; the O(B*m) cone-vector
+bookkeeping of the interior-point loop is restated here in lock-step NumPy, operation for operation
+after reference src/python/coneprog.py:2044-2547 ('l' cone, p = 0, refinement 0, Mehrotra correction on)
+and src/python/misc.py:284-287, :444-464 (compute_scaling / update_scaling, 'l' blocks).
+
+Array convention: everything is packed problem-major, `Gt[b]` is G_b' (n x ml, C order) so that the raw
+buffer is G_b column-major -- the layout the C ABI wants.  `pack_problems` builds it from ordinary arrays.
+
+Multi-GPU: `coneqp_batch_sharded` partitions the batch into contiguous shards, one per rank of a
+torch.distributed group (RCCL on GPUs; gloo in the CPU tests), scatters the problem data from the root,
+solves the local shard and gathers the results -- there is no collective inside the IPM.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+# ---------------------------------------------------------------------------------------------------
+# KKT back end: batched factor / solve on the GPU
+# ---------------------------------------------------------------------------------------------------
+class BatchKkt(object):
+    """B independent kkt_chol2-style solvers (p = 0, LP cone) behind the batched C ABI."""
+
+    def __init__(self, Gt, P=None, device=0):
+        self.L = _capi.lib()
+        Gt = np.ascontiguousarray(Gt, dtype=np.float64)
+        self.B, self.n, self.m = Gt.shape
+        if _capi.device_count() <= 0:
+            raise RuntimeError("cvxopt_amd.batch: no HIP device visible (there is no CPU fallback)")
+        h = C.c_void_p()
+        _capi.check(self.L.mi355kkt_batch_create(C.byref(h), device, self.B, self.n, self.m), "batch_create")
+        self.h = h
+        Pp = None
+        if P is not None:
+            P = np.ascontiguousarray(P, dtype=np.float64)        # symmetric: C order == column-major
+            assert P.shape == (self.B, self.n, self.n)
+            Pp = P.ctypes.data
+        _capi.check(self.L.mi355kkt_batch_set_problem(h, Gt.ctypes.data, Pp, 0), "batch_set_problem")
+
+    def factor(self, di):
+        di = np.ascontiguousarray(di, dtype=np.float64)
+        info = np.zeros(self.B, dtype=np.int32)
+        _capi.check(self.L.mi355kkt_batch_factor(self.h, di.ctypes.data, 0, info.ctypes.data_as(_capi.c_int_p)),
+                    "batch_factor")
+        return info
+
+    def solve(self, x, z):
+        assert x.flags.c_contiguous and z.flags.c_contiguous and x.dtype == np.float64 and z.dtype == np.float64
+        _capi.check(self.L.mi355kkt_batch_solve(self.h, x.ctypes.data, z.ctypes.data, 0), "batch_solve")
+
+    def products(self, x, z):
+        """(G x, G' z, P x) for every problem, computed next to the data in HBM."""
+        x = np.ascontiguousarray(x)
+        z = np.ascontiguousarray(z)
+        Gx, GTz, Px = np.empty((self.B, self.m)), np.empty((self.B, self.n)), np.empty((self.B, self.n))
+        _capi.check(self.L.mi355kkt_batch_products(self.h, x.ctypes.data, z.ctypes.data, Gx.ctypes.data, GTz.ctypes.data,
+                                                   Px.ctypes.data, 0), "batch_products")
+        return Gx, GTz, Px
+
+    def factor_ms(self):
+        return float(self.L.mi355kkt_batch_last_factor_ms(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi355kkt_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def pack_problems(problems):
+    """list of dicts with P (n x n), q, G (m x n), h  ->  packed arrays (P, q, Gt, h)."""
+    P = np.stack([np.asarray(p['P'], dtype=float) for p in problems])
+    q = np.stack([np.asarray(p['q'], dtype=float).ravel() for p in problems])
+    Gt = np.stack([np.ascontiguousarray(np.asarray(p['G'], dtype=float).T) for p in problems])
+    h = np.stack([np.asarray(p['h'], dtype=float).ravel() for p in problems])
+    return P, q, Gt, h
+
+
+# ---------------------------------------------------------------------------------------------------
+# lock-step interior-point loop (host bookkeeping, device KKT)
+# ---------------------------------------------------------------------------------------------------
+def coneqp_batch(P, q, Gt, h, kkt=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, device=0):
+    """Solves the B problems in lock step.  Returns a dict of arrays: x (B,n), s, z (B,m), status (B,)
+    ('optimal' | 'unknown'), iterations, primal objective, dual objective, gap."""
+    B, n = q.shape
+    m = h.shape[1]
+    own = kkt is None
+    if own:
+        kkt = BatchKkt(Gt, P, device=device)
+    Psym = None
+    if not hasattr(kkt, "products"):      # host products (tests): only tril(P) is meaningful (coneprog.py:1475-1477)
+        Psym = P if P is not None else np.zeros((B, n, n))
+        Psym = np.tril(Psym) + np.transpose(np.tril(Psym, -1), (0, 2, 1))
+
+    def Gx(x):           # (B,n) -> (B,m)
+        return np.einsum('bnm,bn->bm', Gt, x)
+
+    def GTz(z):          # (B,m) -> (B,n)
+        return np.einsum('bnm,bm->bn', Gt, z)
+
+    def dot(a, b):
+        return np.einsum('bi,bi->b', a, b)
+
+    resx0 = np.maximum(1.0, np.sqrt(dot(q, q)))                      # coneprog.py:1998-2000
+    resz0 = np.maximum(1.0, np.sqrt(dot(h, h)))
+
+    # ---- starting point: W = I (coneprog.py:2055-2106)
+    info = kkt.factor(np.ones((B, m)))
+    if np.any(info > 0):
+        raise ValueError("Rank([P; A; G]) < n for problems %s" % np.nonzero(info > 0)[0][:8])
+    x = -q.copy()
+    z = h.copy()
+    kkt.solve(x, z)
+    s = -z
+    nrms = np.sqrt(dot(s, s))
+    ts = np.max(-s, axis=1)
+    shift = ts >= -1e-8 * np.maximum(nrms, 1.0)
+    s[shift] += (1.0 + ts[shift])[:, None]
+    nrmz = np.sqrt(dot(z, z))
+    tz = np.max(-z, axis=1)
+    shift = tz >= -1e-8 * np.maximum(nrmz, 1.0)
+    z[shift] += (1.0 + tz[shift])[:, None]
+
+    gap = dot(s, z)
+    active = np.ones(B, dtype=bool)
+    out = {'x': np.zeros((B, n)), 's': np.zeros((B, m)), 'z': np.zeros((B, m)),
+           'status': np.array(['unknown'] * B, dtype=object), 'iterations': np.zeros(B, dtype=int),
+           'primal objective': np.zeros(B), 'dual objective': np.zeros(B), 'gap': np.zeros(B)}
+    d = np.ones((B, m))
+    lmbda = np.ones((B, m))
+
+    def finish(mask, status, it, pcost, dcost):
+        out['x'][mask], out['s'][mask], out['z'][mask] = x[mask], s[mask], z[mask]
+        out['status'][mask] = status
+        out['iterations'][mask] = it
+        out['primal objective'][mask], out['dual objective'][mask], out['gap'][mask] = pcost[mask], dcost[mask], gap[mask]
+
+    for it in range(maxiters + 1):
+        # residuals and stopping test (coneprog.py:2170-2234)
+        if hasattr(kkt, "products"):
+            gx, gtz, px = kkt.products(x, z)
+        else:
+            gx, gtz, px = Gx(x), GTz(z), np.einsum('bij,bj->bi', Psym, x)
+        rx = q + px
+        f0 = 0.5 * (dot(x, rx) + dot(x, q))
+        rx = rx + gtz
+        resx = np.sqrt(dot(rx, rx))
+        rz = s + gx - h
+        resz = np.sqrt(dot(rz, rz))
+        pcost = f0
+        dcost = f0 + dot(z, rz) - gap
+        with np.errstate(divide='ignore', invalid='ignore'):
+            relgap = np.where(pcost < 0.0, gap / -pcost, np.where(dcost > 0.0, gap / dcost, np.inf))
+        pres = resz / resz0
+        dres = resx / resx0
+        done = (pres <= feastol) & (dres <= feastol) & ((gap <= abstol) | (relgap <= reltol))
+        if it == maxiters:
+            finish(active & ~done, 'unknown', it, pcost, dcost)
+            finish(active & done, 'optimal', it, pcost, dcost)
+            active[:] = False
+        else:
+            finish(active & done, 'optimal', it, pcost, dcost)
+            active &= ~done
+        if not active.any():
+            break
+
+        if it == 0:                                                    # misc.py:284-287
+            d = np.sqrt(s / z)
+            lmbda = np.sqrt(s * z)
+        lmbdasq = lmbda * lmbda                                        # misc.ssqr
+        di = 1.0 / d
+        di_safe = np.where(active[:, None], di, 1.0)                   # finished problems keep a benign system
+        info = kkt.factor(di_safe)
+        bad = active & (info > 0)
+        if bad.any():                                                  # coneprog.py:2256-2275
+            if it == 0:
+                raise ValueError("Rank([P; A; G]) < n for problems %s" % np.nonzero(bad)[0][:8])
+            finish(bad, 'unknown', it, pcost, dcost)
+            active &= ~bad
+            if not active.any():
+                break
+
+        mu = gap / m
+        sigma = np.zeros(B)
+        ws3 = np.zeros((B, m))
+        for i in (0, 1):                                               # coneprog.py:2360-2456
+            ds = -lmbdasq + (sigma * mu)[:, None]
+            if i == 1:
+                ds = ds - ws3
+            dx = -rx.copy()
+            dz = -rz.copy()
+            ds = ds / lmbda                                            # sinv
+            dz = dz - d * ds                                           # z -= W' s
+            dx = np.ascontiguousarray(dx)
+            dz = np.ascontiguousarray(dz)
+            kkt.solve(dx, dz)                                          # f3
+            ds = ds - dz
+            dsdz = dot(ds, dz)
+            if i == 0:
+                ws3 = ds * dz                                          # sprod
+            ds = ds / lmbda                                            # scale2
+            dz = dz / lmbda
+            t = np.maximum(0.0, np.maximum(np.max(-ds, axis=1), np.max(-dz, axis=1)))
+            with np.errstate(divide='ignore'):
+                step = np.where(t == 0.0, 1.0, np.minimum(1.0, (1.0 if i == 0 else 0.99) / t))
+            if i == 0:
+                with np.errstate(divide='ignore', invalid='ignore'):
+                    sigma = np.minimum(1.0, np.maximum(0.0, 1.0 - step + dsdz / gap * step ** 2)) ** 3
+                sigma = np.where(np.isfinite(sigma), sigma, 0.0)
+
+        upd = active[:, None]
+        x = np.where(upd, x + step[:, None] * dx, x)
+        ds = (1.0 + step[:, None] * ds) * lmbda                        # coneprog.py:2471-2491
+        dz = (1.0 + step[:, None] * dz) * lmbda
+        with np.errstate(invalid='ignore'):
+            ds = np.sqrt(ds)                                           # misc.py:450-464
+            dz = np.sqrt(dz)
+        d_new = d * ds / dz
+        l_new = ds * dz
+        d = np.where(upd, d_new, d)
+        lmbda = np.where(upd, l_new, lmbda)
+        s = np.where(upd, d * lmbda, s)                                # coneprog.py:2525-2545
+        z = np.where(upd, lmbda / d, z)
+        gap = np.where(active, dot(lmbda, lmbda), gap)
+    if own:
+        kkt.close()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# sharding over ranks (RCCL / gloo): scatter the batch, solve locally, gather
+# ---------------------------------------------------------------------------------------------------
+def shard_bounds(B, world):
+    """Contiguous shards; the first B % world ranks get one extra problem."""
+    base, rem = divmod(B, world)
+    starts = [r * base + min(r, rem) for r in range(world + 1)]
+    return [(starts[r], starts[r + 1]) for r in range(world)]
+
+
+def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, device_of_rank=None, **opts):
+    """P, q, Gt, h are only read on `root` (other ranks may pass None).  Every rank returns the FULL
+    gathered result dict on root and its local shard's dict elsewhere."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    meta = [None]
+    if rank == root:
+        meta = [(q.shape[0], q.shape[1], h.shape[1], P is not None)]
+    dist.broadcast_object_list(meta, src=root, group=group)
+    B, n, m, hasP = meta[0]
+    bounds = shard_bounds(B, world)
+    lo, hi = bounds[rank]
+
+    def scatter(arr, tail_shape):
+        recv = torch.empty((hi - lo,) + tail_shape, dtype=torch.float64, device=dev)
+        if rank == root:
+            chunks = [torch.from_numpy(np.ascontiguousarray(arr[a:b])).to(dev) for a, b in bounds]
+            # dist.scatter needs equal sizes: pad to the largest shard
+            mx = max(b - a for a, b in bounds)
+            padded = []
+            for c in chunks:
+                if c.shape[0] < mx:
+                    c = torch.cat([c, torch.zeros((mx - c.shape[0],) + tail_shape, dtype=torch.float64, device=dev)])
+                padded.append(c.contiguous())
+            buf = torch.empty((mx,) + tail_shape, dtype=torch.float64, device=dev)
+            dist.scatter(buf, padded, src=root, group=group)
+        else:
+            mx = max(b - a for a, b in bounds)
+            buf = torch.empty((mx,) + tail_shape, dtype=torch.float64, device=dev)
+            dist.scatter(buf, None, src=root, group=group)
+        recv.copy_(buf[:hi - lo])
+        return recv.cpu().numpy()
+
+    q_l = scatter(q, (n,))
+    h_l = scatter(h, (m,))
+    G_l = scatter(Gt, (n, m))
+    P_l = scatter(P, (n, n)) if hasP else None
+
+    if hi > lo:
+        if local_solver is None:
+            device = device_of_rank(rank) if device_of_rank else (torch.cuda.current_device() if backend == "nccl" else 0)
+            res = coneqp_batch(P_l, q_l, G_l, h_l, device=device, **opts)
+        else:
+            res = local_solver(P_l, q_l, G_l, h_l, **opts)
+    else:
+        res = {'x': np.zeros((0, n)), 's': np.zeros((0, m)), 'z': np.zeros((0, m)), 'status': np.zeros(0, dtype=object),
+               'iterations': np.zeros(0, dtype=int), 'primal objective': np.zeros(0), 'dual objective': np.zeros(0),
+               'gap': np.zeros(0)}
+    gathered = [None] * world if rank == root else None
+    dist.gather_object(res, gathered, dst=root, group=group)
+    if rank != root:
+        return res
+    full = {}
+    for k in res:
+        full[k] = np.concatenate([g[k] for g in gathered])
+    return full

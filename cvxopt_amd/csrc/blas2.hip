@@ -33,7 +33,11 @@ __global__ __launch_bounds__(256) void scale_vec_kernel(const double* __restrict
 
 // one wave per column: y[j] += sum_i G[i,j] zs[i]
 __global__ __launch_bounds__(256) void gemv_t_kernel(const double* __restrict__ G, int64_t ldg, int m, int n,
-                                                     const double* __restrict__ zs, double* __restrict__ y) {
+                                                     const double* __restrict__ zs, double* __restrict__ y,
+                                                     int64_t sG) {
+    G += (int64_t)blockIdx.z * sG;               // batched problems: vectors are packed back to back
+    zs += (int64_t)blockIdx.z * m;
+    y += (int64_t)blockIdx.z * n;
     const int lane = threadIdx.x & 63;
     const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n) return;
@@ -66,7 +70,10 @@ constexpr int GN_COLS = 256;   // columns per chunk of the row-parallel product
 // partial[chunk][i] = sum_{j in chunk} G[i,j] x[j]; each thread owns two rows
 __global__ __launch_bounds__(256) void gemv_n_partial_kernel(const double* __restrict__ G, int64_t ldg, int m,
                                                              int n, const double* __restrict__ x,
-                                                             double* __restrict__ partial) {
+                                                             double* __restrict__ partial, int64_t sG) {
+    G += (int64_t)blockIdx.z * sG;
+    x += (int64_t)blockIdx.z * n;
+    partial += (int64_t)blockIdx.z * gridDim.y * m;
     const int i = (blockIdx.x * 256 + threadIdx.x) * 2;
     const int j0 = blockIdx.y * GN_COLS;
     const int j1 = min(n, j0 + GN_COLS);
@@ -115,9 +122,16 @@ __global__ __launch_bounds__(256) void gemv_n_finish_kernel(const double* __rest
                                                             double* z, double alpha, double beta) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= m) return;
+    {   // batched problems along blockIdx.z
+        const int64_t bz = blockIdx.z;
+        partial += bz * nchunks * m;
+        if (w) w += bz * m;
+        zs += bz * m;
+        z += bz * m;
+    }
     double s = 0.0;
     for (int c = 0; c < nchunks; ++c) s += partial[(int64_t)c * m + i];
-    z[i] = alpha * (w ? w[i] * s : s) + beta * zs[i];
+    z[i] = alpha * (w ? w[i] * s : s) + (beta != 0.0 ? beta * zs[i] : 0.0);
 }
 
 size_t gemv_work_doubles(int m, int n) {
@@ -128,27 +142,29 @@ size_t gemv_work_doubles(int m, int n) {
 // zs := w .* z (kept for the final z update);  y += (diag(w) G)' zs = G' (w .* zs).
 // work: >= m doubles (only used when w != nullptr).
 int launch_gemv_t_scaled(const double* G, int64_t ldg, int m, int n, const double* w, const double* z,
-                         double* zs, double* y, double* work, hipStream_t st) {
+                         double* zs, double* y, double* work, hipStream_t st, int nbatch, int64_t sG) {
     if (m <= 0) return 0;
-    hipLaunchKernelGGL(scale_vec_kernel, dim3((m + 255) / 256), dim3(256), 0, st, w, z, zs, work, m);
+    const int64_t mt = (int64_t)m * nbatch;      // w, z, zs, work are [nbatch][m], contiguous
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((unsigned)((mt + 255) / 256)), dim3(256), 0, st, w, z, zs, work, (int)mt);
     KKT_HIP_CHECK(hipGetLastError());
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(gemv_t_kernel, dim3((n + 3) / 4), dim3(256), 0, st, G, ldg, m, n, w ? work : zs, y);
+    hipLaunchKernelGGL(gemv_t_kernel, dim3((n + 3) / 4, 1, nbatch), dim3(256), 0, st, G, ldg, m, n, w ? work : zs, y, sG);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_gemv_n_scaled(const double* G, int64_t ldg, int m, int n, const double* w, const double* x,
-                         const double* zs, double* z, double alpha, double beta, double* work, hipStream_t st) {
+                         const double* zs, double* z, double alpha, double beta, double* work, hipStream_t st,
+                         int nbatch, int64_t sG) {
     if (m <= 0) return 0;
     const int nchunks = (n + GN_COLS - 1) / GN_COLS;
     if (nchunks > 0) {
-        hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((m + 511) / 512, nchunks), dim3(256), 0, st, G, ldg, m, n, x,
-                           work);
+        hipLaunchKernelGGL(gemv_n_partial_kernel, dim3((m + 511) / 512, nchunks, nbatch), dim3(256), 0, st, G, ldg, m, n,
+                           x, work, sG);
         KKT_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(gemv_n_finish_kernel, dim3((m + 255) / 256), dim3(256), 0, st, work, nchunks, m, w, zs, z,
-                       alpha, beta);
+    hipLaunchKernelGGL(gemv_n_finish_kernel, dim3((m + 255) / 256, 1, nbatch), dim3(256), 0, st, work, nchunks, m, w, zs,
+                       z, alpha, beta);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -200,7 +216,10 @@ __device__ __forceinline__ double tri_bwd64(const double* __restrict__ Lb, int64
 // Forward step for block row k0: x_k := L_kk^-1 x_k, one wave per right-hand side.  Every global load of
 // the 128x128 block (row of L11, L21, L22 per lane) is issued before the first dependent instruction.
 __global__ __launch_bounds__(64) void trsv_diag_fwd_kernel(const double* __restrict__ L, int64_t ldl, int k0, int nb,
-                                                           double* __restrict__ X, int64_t ldx) {
+                                                           double* __restrict__ X, int64_t ldx, int64_t sL,
+                                                           int64_t sX) {
+    L += (int64_t)blockIdx.z * sL;
+    X += (int64_t)blockIdx.z * sX;
     const int lane = threadIdx.x;
     double* x = X + (int64_t)blockIdx.x * ldx + k0;
     const double* Lkk = L + k0 + (int64_t)k0 * ldl;
@@ -238,7 +257,10 @@ __global__ __launch_bounds__(64) void trsv_diag_fwd_kernel(const double* __restr
 
 // x[k0+nb : n) -= L[k0+nb : n, k0 : k0+nb) x_k   (row-parallel, two rows per thread)
 __global__ __launch_bounds__(256) void trsv_update_fwd_kernel(const double* __restrict__ L, int64_t ldl, int n, int k0,
-                                                              int nb, double* __restrict__ X, int64_t ldx) {
+                                                              int nb, double* __restrict__ X, int64_t ldx, int64_t sL,
+                                                              int64_t sX) {
+    L += (int64_t)blockIdx.z * sL;
+    X += (int64_t)blockIdx.z * sX;
     __shared__ double xs[TB];
     double* x = X + (int64_t)blockIdx.y * ldx;
     for (int t = threadIdx.x; t < nb; t += blockDim.x) xs[t] = x[k0 + t];
@@ -266,7 +288,10 @@ __global__ __launch_bounds__(256) void trsv_update_fwd_kernel(const double* __re
 // Backward step for block k0:  x_k := L_kk^-T ( x_k - L[k0+nb:n, k0:k0+nb)' x[k0+nb:n) )
 // stage 1: one wave per column c of the block computes the long dot product (coalesced)
 __global__ __launch_bounds__(256) void trsv_dot_bwd_kernel(const double* __restrict__ L, int64_t ldl, int n, int k0,
-                                                           int nb, double* __restrict__ X, int64_t ldx) {
+                                                           int nb, double* __restrict__ X, int64_t ldx, int64_t sL,
+                                                           int64_t sX) {
+    L += (int64_t)blockIdx.z * sL;
+    X += (int64_t)blockIdx.z * sX;
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= nb) return;
@@ -282,7 +307,10 @@ __global__ __launch_bounds__(256) void trsv_dot_bwd_kernel(const double* __restr
 }
 
 __global__ __launch_bounds__(64) void trsv_diag_bwd_kernel(const double* __restrict__ L, int64_t ldl, int k0, int nb,
-                                                           double* __restrict__ X, int64_t ldx) {
+                                                           double* __restrict__ X, int64_t ldx, int64_t sL,
+                                                           int64_t sX) {
+    L += (int64_t)blockIdx.z * sL;
+    X += (int64_t)blockIdx.z * sX;
     const int lane = threadIdx.x;
     double* x = X + (int64_t)blockIdx.x * ldx + k0;
     const double* Lkk = L + k0 + (int64_t)k0 * ldl;
@@ -320,16 +348,16 @@ __global__ __launch_bounds__(64) void trsv_diag_bwd_kernel(const double* __restr
 }
 
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs, int trans,
-                      hipStream_t st) {
+                      hipStream_t st, int nbatch, int64_t sL, int64_t sX) {
     if (n <= 0 || nrhs <= 0) return 0;
     if (!trans) {
         for (int k0 = 0; k0 < n; k0 += TB) {
             const int nb = (n - k0 < TB) ? (n - k0) : TB;
-            hipLaunchKernelGGL(trsv_diag_fwd_kernel, dim3(nrhs), dim3(64), 0, st, L, ldl, k0, nb, X, ldx);
+            hipLaunchKernelGGL(trsv_diag_fwd_kernel, dim3(nrhs, 1, nbatch), dim3(64), 0, st, L, ldl, k0, nb, X, ldx, sL, sX);
             const int rem = n - k0 - nb;
             if (rem > 0)
-                hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((rem + 127) / 128, nrhs), dim3(64), 0, st, L, ldl, n,
-                                   k0, nb, X, ldx);
+                hipLaunchKernelGGL(trsv_update_fwd_kernel, dim3((rem + 127) / 128, nrhs, nbatch), dim3(64), 0, st, L, ldl,
+                                   n, k0, nb, X, ldx, sL, sX);
         }
     } else {
         const int nblk = (n + TB - 1) / TB;
@@ -337,9 +365,9 @@ int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ld
             const int k0 = kb * TB;
             const int nb = (n - k0 < TB) ? (n - k0) : TB;
             if (n - k0 - nb > 0)
-                hipLaunchKernelGGL(trsv_dot_bwd_kernel, dim3((nb + 3) / 4, nrhs), dim3(256), 0, st, L, ldl, n, k0, nb, X,
-                                   ldx);
-            hipLaunchKernelGGL(trsv_diag_bwd_kernel, dim3(nrhs), dim3(64), 0, st, L, ldl, k0, nb, X, ldx);
+                hipLaunchKernelGGL(trsv_dot_bwd_kernel, dim3((nb + 3) / 4, nrhs, nbatch), dim3(256), 0, st, L, ldl, n, k0,
+                                   nb, X, ldx, sL, sX);
+            hipLaunchKernelGGL(trsv_diag_bwd_kernel, dim3(nrhs, 1, nbatch), dim3(64), 0, st, L, ldl, k0, nb, X, ldx, sL, sX);
         }
     }
     KKT_HIP_CHECK(hipGetLastError());

@@ -40,6 +40,12 @@ __global__ void scaled_copy_kernel(const double* x, double* y, int n, double a) 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) y[i] = a * x[i];
 }
+// mirror the lower triangle of nbatch n x n matrices into their upper triangles (batched along blockIdx.z)
+__global__ void symmetrize_kernel(double* A, int n, int64_t bstride) {
+    A += (int64_t)blockIdx.z * bstride;
+    const int i = blockIdx.x * 16 + threadIdx.x, j = blockIdx.y * 16 + threadIdx.y;
+    if (i < n && j < n && i > j) A[j + (int64_t)i * n] = A[i + (int64_t)j * n];
+}
 // out (n x p, ld n) = A' where A is p x n (lda)
 __global__ void transpose_kernel(const double* __restrict__ A, int64_t lda, int p, int n, double* __restrict__ out) {
     __shared__ double t[32][33];
@@ -530,6 +536,173 @@ int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL) {
                                   hipMemcpyDeviceToHost));
     return 0;
 }
+
+// ---- batched LP-cone QP engine (BASELINE config 5: many independent small dense problems) -------------
+}  // extern "C"
+
+struct mi355kkt_batch {
+    int device = 0, nbatch = 0, n = 0, ml = 0, num_cus = 256;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {};
+    double *dG = nullptr, *dH = nullptr, *dS = nullptr, *dW = nullptr;
+    double *dx = nullptr, *dz = nullptr, *dzs = nullptr, *dwork = nullptr, *dt1 = nullptr, *dt2 = nullptr;
+    bool hasH = false;
+    SyrkPlan plan;
+    PotrfWork pw;
+    float t_factor = 0;
+};
+
+extern "C" {
+
+int mi355kkt_batch_create(mi355kkt_batch** out, int device, int nbatch, int n, int ml) {
+    if (!out || nbatch < 1 || n < 1 || ml < 0) { set_last_error("batch_create: invalid argument"); return MI355KKT_EINVAL; }
+    if (mi355kkt_device_count() <= device) { set_last_error("batch_create: HIP device %d not available", device); return MI355KKT_EHIP; }
+    mi355kkt_batch* b = new mi355kkt_batch();
+    b->device = device; b->nbatch = nbatch; b->n = n; b->ml = ml;
+    auto fail = [&](int code) { mi355kkt_batch_destroy(b); return code; };
+    if (hipSetDevice(device) != hipSuccess) return fail(MI355KKT_EHIP);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(MI355KKT_EHIP);
+    b->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(MI355KKT_EHIP);
+    for (auto& e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(MI355KKT_EHIP);
+    const size_t B = nbatch, N = n, M = ml;
+    auto alloc = [&](double** p, size_t d) { return hipMalloc(p, sizeof(double) * (d ? d : 1)) == hipSuccess ? 0 : MI355KKT_ENOMEM; };
+    int rc;
+    if ((rc = alloc(&b->dG, B * M * N))) return fail(rc);
+    if ((rc = alloc(&b->dH, B * N * N))) return fail(rc);
+    if ((rc = alloc(&b->dS, B * N * N))) return fail(rc);
+    if ((rc = alloc(&b->dW, B * M))) return fail(rc);
+    if ((rc = alloc(&b->dx, B * N))) return fail(rc);
+    if ((rc = alloc(&b->dz, B * M))) return fail(rc);
+    if ((rc = alloc(&b->dzs, B * M))) return fail(rc);
+    if ((rc = alloc(&b->dwork, B * dmax(gemv_work_doubles(ml, n), gemv_work_doubles(n, n))))) return fail(rc);
+    if ((rc = alloc(&b->dt1, B * dmax(N, M)))) return fail(rc);
+    if ((rc = alloc(&b->dt2, B * dmax(N, M)))) return fail(rc);
+    if ((rc = potrf_work_init_batched(b->pw, nbatch))) return fail(rc);
+    if ((rc = build_syrk_plan(b->plan, n, ml, b->num_cus, /*allow_split=*/false))) return fail(rc);
+    *out = b;
+    return 0;
+}
+
+void mi355kkt_batch_destroy(mi355kkt_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->st) (void)hipStreamSynchronize(b->st);
+    double* bufs[] = {b->dG, b->dH, b->dS, b->dW, b->dx, b->dz, b->dzs, b->dwork, b->dt1, b->dt2};
+    for (double* p : bufs) if (p) (void)hipFree(p);
+    potrf_work_free(b->pw);
+    free_syrk_plan(b->plan);
+    for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    if (b->st) (void)hipStreamDestroy(b->st);
+    delete b;
+}
+
+/* G: nbatch blocks of ml x n (column-major, contiguous); H: nbatch blocks of n x n (lower triangle used) or NULL.
+ * is_device != 0: the pointers are device pointers (copied device-to-device). */
+int mi355kkt_batch_set_problem(mi355kkt_batch* b, const double* G, const double* H, int is_device) {
+    if (!b || !G) { set_last_error("batch_set_problem: null argument"); return MI355KKT_EINVAL; }
+    KKT_HIP_CHECK(hipSetDevice(b->device));
+    const hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const size_t B = b->nbatch, N = b->n, M = b->ml;
+    if (M) KKT_HIP_CHECK(hipMemcpy(b->dG, G, sizeof(double) * B * M * N, kind));
+    b->hasH = (H != nullptr);
+    if (H) {
+        KKT_HIP_CHECK(hipMemcpy(b->dH, H, sizeof(double) * B * N * N, kind));
+        // only tril(H) is meaningful on input; mirror it so that H x is a plain product (SYRK reads tril only)
+        hipLaunchKernelGGL(symmetrize_kernel, dim3((b->n + 15) / 16, (b->n + 15) / 16, b->nbatch), dim3(16, 16), 0, b->st,
+                           b->dH, b->n, (int64_t)(N * N));
+        KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+    }
+    return 0;
+}
+
+/* The residual products of the IPM loop for every problem (reference coneprog.py:2170-2186, fP / fG):
+ * Gx[b] = G_b x_b,  GTz[b] = G_b' z_b,  Hx[b] = H_b x_b.  Any output may be NULL.  Host or device arrays. */
+int mi355kkt_batch_products(mi355kkt_batch* b, const double* x, const double* z, double* Gx, double* GTz, double* Hx,
+                            int is_device) {
+    if (!b) return MI355KKT_EINVAL;
+    KKT_HIP_CHECK(hipSetDevice(b->device));
+    const size_t B = b->nbatch, N = b->n, M = b->ml;
+    const int64_t sG = (int64_t)(M * N), sH = (int64_t)(N * N);
+    const double *dx = x, *dz = z;
+    if (!is_device) {
+        if (x) { KKT_HIP_CHECK(hipMemcpyAsync(b->dx, x, sizeof(double) * B * N, hipMemcpyHostToDevice, b->st)); dx = b->dx; }
+        if (z && M) { KKT_HIP_CHECK(hipMemcpyAsync(b->dz, z, sizeof(double) * B * M, hipMemcpyHostToDevice, b->st)); dz = b->dz; }
+    }
+    auto out_dev = [&](double* user, double* scratch) { return is_device ? user : scratch; };
+    if (Gx && M) {
+        double* o = out_dev(Gx, b->dzs);
+        if (int e = launch_gemv_n_scaled(b->dG, (int64_t)M, b->ml, b->n, nullptr, dx, o, o, 1.0, 0.0, b->dwork, b->st, b->nbatch, sG)) return e;
+        if (!is_device) KKT_HIP_CHECK(hipMemcpyAsync(Gx, o, sizeof(double) * B * M, hipMemcpyDeviceToHost, b->st));
+    }
+    if (GTz) {
+        double* o = out_dev(GTz, b->dt1);
+        KKT_HIP_CHECK(hipMemsetAsync(o, 0, sizeof(double) * B * N, b->st));
+        if (M)
+            if (int e = launch_gemv_t_scaled(b->dG, (int64_t)M, b->ml, b->n, nullptr, dz, b->dt2, o, nullptr, b->st, b->nbatch, sG)) return e;
+        if (!is_device) KKT_HIP_CHECK(hipMemcpyAsync(GTz, o, sizeof(double) * B * N, hipMemcpyDeviceToHost, b->st));
+    }
+    if (Hx) {
+        double* o = out_dev(Hx, b->dt2);
+        if (b->hasH) {
+            // dt2 may be in use as gemv_t scratch above: order on the stream makes that safe
+            if (int e = launch_gemv_n_scaled(b->dH, (int64_t)N, b->n, b->n, nullptr, dx, o, o, 1.0, 0.0, b->dwork, b->st, b->nbatch, sH)) return e;
+        } else {
+            KKT_HIP_CHECK(hipMemsetAsync(o, 0, sizeof(double) * B * N, b->st));
+        }
+        if (!is_device) KKT_HIP_CHECK(hipMemcpyAsync(Hx, o, sizeof(double) * B * N, hipMemcpyDeviceToHost, b->st));
+    }
+    KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+    return 0;
+}
+
+/* di: [nbatch][ml]; info: [nbatch] (host), 0 or the failing pivot of that problem.  Returns 0 or <0. */
+int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, int* info) {
+    if (!b || (!di && b->ml)) { set_last_error("batch_factor: null argument"); return MI355KKT_EINVAL; }
+    KKT_HIP_CHECK(hipSetDevice(b->device));
+    const size_t B = b->nbatch, N = b->n, M = b->ml;
+    KKT_HIP_CHECK(hipEventRecord(b->ev[0], b->st));
+    if (M) KKT_HIP_CHECK(hipMemcpyAsync(b->dW, di, sizeof(double) * B * M, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->st));
+    BatchStrides bs;
+    bs.a = (int64_t)(M * N); bs.b = (int64_t)M; bs.c = (int64_t)(N * N); bs.d = (int64_t)(N * N);
+    if (int e = launch_syrk_scaled(b->plan, b->dG, M ? (int64_t)M : 1, M ? b->dW : nullptr, b->dS, (int64_t)N,
+                                   b->hasH ? b->dH : nullptr, (int64_t)N, b->st, nullptr, b->nbatch, bs))
+        return e;
+    if (int e = launch_potrf_batched(b->dS, (int64_t)N, b->n, b->nbatch, (int64_t)(N * N), b->pw, b->st)) return e;
+    KKT_HIP_CHECK(hipEventRecord(b->ev[1], b->st));
+    KKT_HIP_CHECK(hipMemcpyAsync(b->pw.h_info, b->pw.d_info, sizeof(int) * B, hipMemcpyDeviceToHost, b->st));
+    KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+    (void)hipEventElapsedTime(&b->t_factor, b->ev[0], b->ev[1]);
+    if (info) memcpy(info, b->pw.h_info, sizeof(int) * B);
+    return 0;
+}
+
+/* x: [nbatch][n], z: [nbatch][ml], in place: (bx, bz) -> (ux, W uz) per problem (p = 0). */
+int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device) {
+    if (!b || !x || (!z && b->ml)) { set_last_error("batch_solve: null argument"); return MI355KKT_EINVAL; }
+    KKT_HIP_CHECK(hipSetDevice(b->device));
+    const size_t B = b->nbatch, N = b->n, M = b->ml;
+    double *dx = x, *dz = z;
+    if (!is_device) {
+        KKT_HIP_CHECK(hipMemcpyAsync(b->dx, x, sizeof(double) * B * N, hipMemcpyHostToDevice, b->st));
+        if (M) KKT_HIP_CHECK(hipMemcpyAsync(b->dz, z, sizeof(double) * B * M, hipMemcpyHostToDevice, b->st));
+        dx = b->dx; dz = b->dz;
+    }
+    const int64_t sG = (int64_t)(M * N), sL = (int64_t)(N * N);
+    if (int e = launch_gemv_t_scaled(b->dG, M ? (int64_t)M : 1, b->ml, b->n, b->dW, dz, b->dzs, dx, b->dwork, b->st, b->nbatch, sG)) return e;
+    if (int e = launch_trsm_lower(b->dS, (int64_t)N, b->n, dx, (int64_t)N, 1, 0, b->st, b->nbatch, sL, (int64_t)N)) return e;
+    if (int e = launch_trsm_lower(b->dS, (int64_t)N, b->n, dx, (int64_t)N, 1, 1, b->st, b->nbatch, sL, (int64_t)N)) return e;
+    if (int e = launch_gemv_n_scaled(b->dG, M ? (int64_t)M : 1, b->ml, b->n, b->dW, dx, b->dzs, dz, 1.0, -1.0, b->dwork, b->st, b->nbatch, sG)) return e;
+    if (!is_device) {
+        KKT_HIP_CHECK(hipMemcpyAsync(x, b->dx, sizeof(double) * B * N, hipMemcpyDeviceToHost, b->st));
+        if (M) KKT_HIP_CHECK(hipMemcpyAsync(z, b->dz, sizeof(double) * B * M, hipMemcpyDeviceToHost, b->st));
+    }
+    KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+    return 0;
+}
+
+float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b) { return b ? b->t_factor : 0.0f; }
 
 // ---- stand-alone operators -----------------------------------------------------------------------------
 struct OpTimer {

@@ -89,9 +89,16 @@ __device__ __forceinline__ void tn_store(double* __restrict__ Xs, int sc, int sk
 __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
     const double* __restrict__ G, int64_t ldg, const double* __restrict__ di, int n, int fast_ok,
     const SyrkItem* __restrict__ items, double* __restrict__ C, int64_t ldc,
-    const double* __restrict__ P, int64_t ldp, double* __restrict__ slabs) {
+    const double* __restrict__ P, int64_t ldp, double* __restrict__ slabs, BatchStrides bs) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const SyrkItem it = items[blockIdx.x];
+    {   // batched problems along blockIdx.z (all strides 0 for a single problem)
+        const int64_t bz = blockIdx.z;
+        G += bz * bs.a;
+        if (di) di += bz * bs.b;
+        C += bz * bs.c;
+        if (P) P += bz * bs.d;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wj = wave >> 1, wi = wave & 1;
     const int i0 = it.ti * TILE, j0 = it.tj * TILE;
@@ -199,7 +206,7 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkItem* __rest
 // that XCD's private L2; whole rounds run unsplit tiles, the remainder is split along k so the last
 // round is also full (hybrid stream-K), with slabs summed in a fixed order by syrk_reduce_kernel.
 // ---------------------------------------------------------------------------------------------------
-int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus) {
+int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split) {
     free_syrk_plan(plan);
     plan.n = n;
     plan.K = K;
@@ -220,7 +227,7 @@ int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus) {
     const int R = T - nfull;
     const int max_split = std::max(1, K / (8 * BK));   // at least 8 k-steps per piece
     int split = 1;
-    if (R > 0) split = std::max(1, std::min(slots / R, max_split));
+    if (R > 0 && allow_split) split = std::max(1, std::min(slots / R, max_split));
 
     std::vector<SyrkItem> ordered_full, items, split_tiles;
     for (int t = 0; t < nfull; ++t) ordered_full.push_back({seq[t].first, seq[t].second, 0, K, -1, 0, 0, 0});
@@ -276,7 +283,8 @@ void free_syrk_plan(SyrkPlan& plan) {
 static constexpr size_t kGemmLds = sizeof(double) * 4 * STAGE_DOUBLES;   // 73,728 B
 
 int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const double* di, double* C,
-                       int64_t ldc, const double* P, int64_t ldp, hipStream_t st, hipEvent_t* kernel_events) {
+                       int64_t ldc, const double* P, int64_t ldp, hipStream_t st, hipEvent_t* kernel_events,
+                       int nbatch, BatchStrides bs) {
     if (plan.n == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
@@ -286,8 +294,12 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
     }
     const int fast_ok = ((reinterpret_cast<uintptr_t>(G) & 7) == 0) ? 1 : 0;   // 8-byte aligned pairs suffice
     if (kernel_events) KKT_HIP_CHECK(hipEventRecord(kernel_events[0], st));
-    hipLaunchKernelGGL(syrk_tn_kernel, dim3(plan.nitems), dim3(256), kGemmLds, st, G, ldg, di, plan.n, fast_ok,
-                       plan.d_items, C, ldc, P, ldp, plan.d_slabs);
+    if (nbatch > 1 && plan.nsplit_tiles) {
+        set_last_error("launch_syrk_scaled: batched launch needs an unsplit plan");
+        return -1;
+    }
+    hipLaunchKernelGGL(syrk_tn_kernel, dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di, plan.n,
+                       fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs);
     KKT_HIP_CHECK(hipGetLastError());
     if (kernel_events) KKT_HIP_CHECK(hipEventRecord(kernel_events[1], st));
     if (plan.nsplit_tiles) {
@@ -337,8 +349,11 @@ template <bool SYM>
 __global__ __launch_bounds__(256, 2) void nt_update_kernel(double* __restrict__ C, int64_t ldc,
                                                            const double* __restrict__ A, int64_t lda,
                                                            const double* __restrict__ B, int64_t ldb,
-                                                           int M, int N, int K, int fast_ok) {
+                                                           int M, int N, int K, int fast_ok, int64_t bstride) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    C += (int64_t)blockIdx.z * bstride;     // batched problems: C, A, B live in the same matrix
+    A += (int64_t)blockIdx.z * bstride;
+    B += (int64_t)blockIdx.z * bstride;
     int ti, tj;
     if (SYM) {
         const int t = blockIdx.x;
@@ -415,24 +430,24 @@ static int nt_attr() {
 }
 
 int launch_syrk_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, int nrows, int K,
-                          hipStream_t st) {
+                          hipStream_t st, int nbatch, int64_t bstride) {
     if (nrows <= 0 || K <= 0) return 0;
     if (int e = nt_attr()) return e;
     const int nt = (nrows + TILE - 1) / TILE;
     const int fast_ok = ((reinterpret_cast<uintptr_t>(A) & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(nt_update_kernel<true>, dim3(nt * (nt + 1) / 2), dim3(256), kGemmLds, st, C, ldc, A, lda,
-                       A, lda, nrows, nrows, K, fast_ok);
+    hipLaunchKernelGGL(nt_update_kernel<true>, dim3(nt * (nt + 1) / 2, 1, nbatch), dim3(256), kGemmLds, st, C, ldc, A,
+                       lda, A, lda, nrows, nrows, K, fast_ok, bstride);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, const double* B, int64_t ldb,
-                          int M, int N, int K, hipStream_t st) {
+                          int M, int N, int K, hipStream_t st, int nbatch, int64_t bstride) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (int e = nt_attr()) return e;
     const int fast_ok = (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(nt_update_kernel<false>, dim3((M + TILE - 1) / TILE, (N + TILE - 1) / TILE), dim3(256),
-                       kGemmLds, st, C, ldc, A, lda, B, ldb, M, N, K, fast_ok);
+    hipLaunchKernelGGL(nt_update_kernel<false>, dim3((M + TILE - 1) / TILE, (N + TILE - 1) / TILE, nbatch), dim3(256),
+                       kGemmLds, st, C, ldc, A, lda, B, ldb, M, N, K, fast_ok, bstride);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

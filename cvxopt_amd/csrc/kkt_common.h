@@ -30,6 +30,8 @@ constexpr int LDT_M = TILE + 16;  // M-major LDS layout: [k][idx], stride 144 do
 constexpr int STAGE_DOUBLES = TILE * LDT_K;   // == BK * LDT_M == 2304 doubles per operand per stage
 static_assert(TILE * LDT_K == BK * LDT_M, "both LDS layouts must use the same footprint");
 
+struct BatchStrides { int64_t a = 0, b = 0, c = 0, d = 0; };   // element strides between batched problems
+
 struct SyrkItem {  // one workgroup's job in the scaled SYRK
     int ti, tj;    // tile row (C rows, i) / tile column (C cols, j); ti >= tj
     int k0, k1;    // contraction range [k0, k1)
@@ -47,21 +49,22 @@ struct SyrkPlan {
     double* d_slabs = nullptr;         // nslabs * TILE*TILE doubles
 };
 
-int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus);
+int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split = true);
 void free_syrk_plan(SyrkPlan& plan);
 
 // C(lower) = P(lower) + Gs' Gs with Gs = diag(di) G   (di == nullptr: no scaling; P == nullptr: 0)
 // kernel_events (optional): two events recorded immediately around the syrk_tn_kernel launch.
 int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const double* di,
                        double* C, int64_t ldc, const double* P, int64_t ldp, hipStream_t st,
-                       hipEvent_t* kernel_events = nullptr);
+                       hipEvent_t* kernel_events = nullptr, int nbatch = 1, BatchStrides bs = BatchStrides());
+// (batched: strides a = G, b = di, c = C, d = P between consecutive problems, along blockIdx.z)
 
 // C(lower tiles of an nrows x nrows block) -= A A' where A is nrows x K (column-major, lda)
 int launch_syrk_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, int nrows, int K,
-                          hipStream_t st);
+                          hipStream_t st, int nbatch = 1, int64_t bstride = 0);
 // C (M x N, all tiles) -= A B'  with A: M x K (lda), B: N x K (ldb)
 int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
-                          int64_t ldb, int M, int N, int K, hipStream_t st);
+                          int64_t ldb, int M, int N, int K, hipStream_t st, int nbatch = 1, int64_t bstride = 0);
 
 int run_mfma_f64_peak(int iters, int num_cus, float* tflops);
 
@@ -76,19 +79,23 @@ void potrf_work_free(PotrfWork& w);
 // In-place lower Cholesky of the n x n column-major matrix A (only tril referenced/overwritten).
 // Asynchronous on `st`; *w.d_info is updated on device.  Returns 0 or a negative error code.
 int launch_potrf(double* A, int64_t lda, int n, PotrfWork& w, hipStream_t st);
+// nbatch matrices `bstride` doubles apart; w.d_info / w.d_dinv must hold nbatch ints / nbatch*2048 doubles
+int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st);
+int potrf_work_init_batched(PotrfWork& w, int nbatch);
 
 // ---- level-2 pieces of solve() --------------------------------------------------------------------
 // zs := w .* z;  y[0:n) += G' (w .* zs)   (G m x n); work >= m doubles
 int launch_gemv_t_scaled(const double* G, int64_t ldg, int m, int n, const double* w,
-                         const double* z, double* zs, double* y, double* work, hipStream_t st);
+                         const double* z, double* zs, double* y, double* work, hipStream_t st,
+                         int nbatch = 1, int64_t sG = 0);   // batched: vectors are contiguous (stride m / n)
 // z := alpha * w .* (G x) + beta * zs    (z may alias zs)
 int launch_gemv_n_scaled(const double* G, int64_t ldg, int m, int n, const double* w,
                          const double* x, const double* zs, double* z, double alpha, double beta,
-                         double* work, hipStream_t st);
+                         double* work, hipStream_t st, int nbatch = 1, int64_t sG = 0);
 size_t gemv_work_doubles(int m, int n);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
-                      int trans, hipStream_t st);
+                      int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);
 
 
 // ---- second-order-cone scaling --------------------------------------------------------------------

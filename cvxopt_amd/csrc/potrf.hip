@@ -47,8 +47,12 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& d, double& inv) {
 //   (c) all four waves apply the rank-16 update to the remaining columns with v_mfma_f64_16x16x4_f64
 // linv_out[blk][k][g] = inv(L_d)[g][k] (16x16 diagonal blocks, zero upper) is exported for trsm_panel_kernel.
 __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int64_t lda, int nb, int col0,
-                                                    int* __restrict__ info, double* __restrict__ linv_out) {
+                                                    int* __restrict__ info, double* __restrict__ linv_out,
+                                                    int64_t bstride) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    A += (int64_t)blockIdx.z * bstride;          // batched problems along blockIdx.z
+    info += blockIdx.z;
+    if (linv_out) linv_out += (int64_t)blockIdx.z * 2048;
     double* As = smem;                       // NB x PLD, column-major, lower triangle valid
     double* Ld = smem + NB * PLD;            // 16 x 16 current diagonal block, Ld[c * 16 + k] = L[c][k]
     double* dinv = Ld + 256;                 // 16 reciprocal pivots of the current micro panel
@@ -199,7 +203,11 @@ constexpr int TRSM_ROWS = 64;
 __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restrict__ L,
                                                          const double* __restrict__ linv,
                                                          double* __restrict__ B, int64_t lda, int mrows,
-                                                         const int* __restrict__ info) {
+                                                         const int* __restrict__ info, int64_t bstride) {
+    L += (int64_t)blockIdx.z * bstride;
+    B += (int64_t)blockIdx.z * bstride;
+    linv += (int64_t)blockIdx.z * 2048;
+    info += blockIdx.z;
     if (*info != 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -245,13 +253,15 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restric
     }
 }
 
-int potrf_work_init(PotrfWork& w) {
-    KKT_HIP_CHECK(hipMalloc(&w.d_info, sizeof(int)));
-    KKT_HIP_CHECK(hipMalloc(&w.d_dinv, sizeof(double) * 8 * 256));   // inverses of the 16x16 diagonal blocks
-    KKT_HIP_CHECK(hipHostMalloc(&w.h_info, sizeof(int)));
-    *w.h_info = 0;
+int potrf_work_init_batched(PotrfWork& w, int nbatch) {
+    KKT_HIP_CHECK(hipMalloc(&w.d_info, sizeof(int) * nbatch));
+    KKT_HIP_CHECK(hipMalloc(&w.d_dinv, sizeof(double) * 8 * 256 * nbatch));   // inverses of the 16x16 diagonal blocks
+    KKT_HIP_CHECK(hipHostMalloc(&w.h_info, sizeof(int) * nbatch));
+    memset(w.h_info, 0, sizeof(int) * nbatch);
     return 0;
 }
+
+int potrf_work_init(PotrfWork& w) { return potrf_work_init_batched(w, 1); }
 
 void potrf_work_free(PotrfWork& w) {
     if (w.d_info) (void)hipFree(w.d_info);
@@ -260,7 +270,7 @@ void potrf_work_free(PotrfWork& w) {
     w = PotrfWork();
 }
 
-int launch_potrf(double* A, int64_t lda, int n, PotrfWork& w, hipStream_t st) {
+int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t lds = sizeof(double) * (NB * PLD + 256 + 16) + 16;
     if (!attr_set) {
@@ -268,17 +278,18 @@ int launch_potrf(double* A, int64_t lda, int n, PotrfWork& w, hipStream_t st) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    KKT_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int), st));
+    KKT_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int) * nbatch, st));
     // Outer panels of 256 columns = two 128-column sub-panels; the trailing matrix is touched once per
     // outer panel with a rank-256 update (halves the C read-modify-write traffic of a rank-128 scheme).
     auto panel = [&](int k0, int nb) -> int {   // factor diagonal block at k0 and solve the rows below it
         double* Akk = A + k0 + (int64_t)k0 * lda;
-        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), lds, st, Akk, lda, nb, k0, w.d_info, w.d_dinv);
+        hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, nbatch), dim3(256), lds, st, Akk, lda, nb, k0, w.d_info, w.d_dinv,
+                           bstride);
         KKT_HIP_CHECK(hipGetLastError());
         const int m = n - k0 - nb;
         if (m > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Akk, w.d_dinv,
-                               Akk + nb, lda, m, w.d_info);
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS, 1, nbatch), dim3(256), 0, st, Akk,
+                               w.d_dinv, Akk + nb, lda, m, w.d_info, bstride);
             KKT_HIP_CHECK(hipGetLastError());
         }
         return 0;
@@ -291,17 +302,21 @@ int launch_potrf(double* A, int64_t lda, int n, PotrfWork& w, hipStream_t st) {
         const int nb2 = (n - k1 < NB) ? (n - k1) : NB;
         // columns k1 .. k1+nb2 of the trailing matrix get the rank-nb1 update now (needed by the 2nd sub-panel)
         if (int e = launch_gemm_nt_update(A + k1 + (int64_t)k1 * lda, lda, A + k1 + (int64_t)k0 * lda, lda,
-                                          A + k1 + (int64_t)k0 * lda, lda, n - k1, nb2, nb1, st))
+                                          A + k1 + (int64_t)k0 * lda, lda, n - k1, nb2, nb1, st, nbatch, bstride))
             return e;
         if (int e = panel(k1, nb2)) return e;
         const int k2 = k1 + nb2;
         if (k2 >= n) break;
         // rank-(nb1+nb2) update of everything to the right of the outer panel
         if (int e = launch_syrk_nt_update(A + k2 + (int64_t)k2 * lda, lda, A + k2 + (int64_t)k0 * lda, lda, n - k2,
-                                          nb1 + nb2, st))
+                                          nb1 + nb2, st, nbatch, bstride))
             return e;
     }
     return 0;
+}
+
+int launch_potrf(double* A, int64_t lda, int n, PotrfWork& w, hipStream_t st) {
+    return launch_potrf_batched(A, lda, n, 1, 0, w, st);
 }
 
 }  // namespace mi355kkt

@@ -119,6 +119,21 @@ int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n);
 /* copies the factored S (lower Cholesky factor L in tril) to a host n x n buffer -- tests only */
 int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL);
 
+/* ---- batched mode: nbatch independent dense LP-cone problems of one shape (BASELINE configs[4]) ---------
+ * No reference API exists for this; per problem it is exactly factor()/solve() of the
+ * kkt_chol2 hook with p = 0: S_b = H_b + G_b' diag(di_b)^2 G_b = L_b L_b', launched as batched kernels
+ * (one blockIdx.z slice per problem).  Arrays are packed problem after problem, column-major inside. */
+typedef struct mi355kkt_batch mi355kkt_batch;
+int mi355kkt_batch_create(mi355kkt_batch** out, int device, int nbatch, int n, int ml);
+void mi355kkt_batch_destroy(mi355kkt_batch* b);
+int mi355kkt_batch_set_problem(mi355kkt_batch* b, const double* G, const double* H, int is_device);
+int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, int* info);
+int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device);
+/* residual products of the IPM loop (coneprog.py:2170-2186): Gx = G x, GTz = G' z, Hx = H x per problem */
+int mi355kkt_batch_products(mi355kkt_batch* b, const double* x, const double* z, double* Gx, double* GTz, double* Hx,
+                            int is_device);
+float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b);
+
 /* ---- stand-alone device operators (each is one stage of factor()/solve(); used by the per-kernel
  * parity tests and by the profiler).  All pointers are DEVICE pointers; calls are synchronous. ---- */
 /* S(lower) = H(lower) + G' diag(di)^2 G ;  di or H may be NULL */

@@ -1,0 +1,68 @@
+"""Batched mode on the GPU (BASELINE configs[4], scaled down): batched HIP factor/solve vs the per-problem
+CPU back end, and the lock-step coneqp_batch vs individual reference runs."""
+import numpy as np
+import pytest
+
+from cvxopt_amd import synth
+from cvxopt_amd.batch import BatchKkt, coneqp_batch, pack_problems
+from batch_helpers import NumpyBatchKkt
+from helpers import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("B,n,m", [(1, 64, 128), (5, 100, 230), (16, 256, 512), (3, 130, 61), (64, 512, 1024)])
+def test_batched_factor_solve_matches_cpu(B, n, m):
+    probs = [synth.dense_qp(n, m, seed=100 + i) for i in range(B)]
+    P, q, Gt, h = pack_problems(probs)
+    rng = np.random.default_rng(B + n)
+    di = 10.0 ** rng.uniform(-1.5, 1.5, (B, m))
+    g, c = BatchKkt(Gt, P), NumpyBatchKkt(Gt, P)
+    assert np.all(g.factor(di) == 0) and np.all(c.factor(di) == 0)
+    x, z = rng.standard_normal((B, n)), rng.standard_normal((B, m))
+    xg, zg, xc, zc = x.copy(), z.copy(), x.copy(), z.copy()
+    g.solve(xg, zg)
+    c.solve(xc, zc)
+    for b in range(B):
+        assert relerr(xg[b], xc[b]) < 1e-8 and relerr(zg[b], zc[b]) < 1e-8, b
+    g.close()
+
+
+def test_batched_factor_reports_per_problem_failures():
+    B, n, m = 4, 40, 20                       # rank(G) = 20 < 40 and P = 0 for problems 1 and 3
+    probs = [synth.dense_qp(n, m, seed=i) for i in range(B)]
+    P, q, Gt, h = pack_problems(probs)
+    P[1] = 0.0
+    P[3] = 0.0
+    g = BatchKkt(Gt, P)
+    info = g.factor(np.ones((B, m)))
+    assert info[0] == 0 and info[2] == 0 and info[1] > 0 and info[3] > 0
+    ref = NumpyBatchKkt(Gt, P).factor(np.ones((B, m)))
+    # S is exactly rank 20: the first non-positive pivot is a rounding-level quantity (21 or 22)
+    assert abs(int(info[1]) - int(ref[1])) <= 2 and abs(int(info[3]) - int(ref[3])) <= 2 and info[1] > 20
+    g.close()
+
+
+def test_coneqp_batch_gpu_matches_golden_reference_run():
+    g = load_golden("coneqp_qp256")
+    pr = synth.dense_qp(int(g['n']), int(g['m']), seed=int(g['seed']))
+    P, q, Gt, h = pack_problems([pr])
+    res = coneqp_batch(P, q, Gt, h)
+    assert res['status'][0] == 'optimal' and res['iterations'][0] == int(g['iterations'])
+    assert abs(res['primal objective'][0] - float(g['pobj'])) <= 1e-9 * abs(float(g['pobj']))
+    assert relerr(res['x'][0], g['x']) < 1e-7
+
+
+def test_coneqp_batch_gpu_matches_individual_reference_runs(ref_cvxopt):
+    from cvxopt import matrix, solvers
+    probs = [synth.dense_qp(48, 100, seed=20 + i) for i in range(12)]
+    probs[5]['h'] = probs[5]['h'] * 30.0
+    probs[7]['q'] = probs[7]['q'] * 1e-3
+    P, q, Gt, h = pack_problems(probs)
+    res = coneqp_batch(P, q, Gt, h)
+    for b, pr in enumerate(probs):
+        ref = solvers.coneqp(matrix(pr['P']), matrix(pr['q']), matrix(pr['G']), matrix(pr['h']), kktsolver='chol2')
+        assert res['status'][b] == ref['status']
+        assert res['iterations'][b] == ref['iterations'], b
+        assert abs(res['primal objective'][b] - ref['primal objective']) <= 1e-9 * max(1, abs(ref['primal objective']))
+        assert relerr(res['x'][b], np.array(ref['x']).ravel()) < 1e-7
