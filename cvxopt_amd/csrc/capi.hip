@@ -189,7 +189,13 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(MI355KKT_EHIP);
     h->num_cus = prop.multiProcessorCount;
-    if (hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess) return fail(MI355KKT_EHIP);
+    {   // main stream at the highest priority: its panel kernels overtake the low-priority bulk updates
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&h->st, hipStreamNonBlocking, greatest) != hipSuccess &&
+            hipStreamCreateWithFlags(&h->st, hipStreamNonBlocking) != hipSuccess)
+            return fail(MI355KKT_EHIP);
+    }
     for (auto& e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return fail(MI355KKT_EHIP);
     auto alloc = [&](double** ptr, size_t doubles) -> int {
@@ -759,6 +765,8 @@ int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX
     cone_layout_free(cl);
     return rc;
 }
+
+int mi355kkt_debug_potf2_skip(int mask) { return mi355kkt::set_potf2_skip(mask); }
 
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops) { return run_mfma_f64_peak(iters, cur_num_cus(), tflops); }
 

@@ -371,11 +371,8 @@ __global__ __launch_bounds__(256, 2) void nt_update_kernel(double* __restrict__ 
     const bool diag = SYM && (ti == tj);
     const bool tile_fast = fast_ok && (i0 + TILE <= M) && (j0 + TILE <= N);
 
-    const int ioff = diag ? 0 : STAGE_DOUBLES;
     auto sJ = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES; };
-    auto sI = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES + ioff; };
-    d4 acc[4][4];
-    zero_acc(acc);
+    auto sI = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES + STAGE_DOUBLES; };
     const int nkt = (K + BK - 1) / BK;
     double rJ[8], rI[8];
     auto fetch = [&](int kt) {
@@ -388,23 +385,19 @@ __global__ __launch_bounds__(256, 2) void nt_update_kernel(double* __restrict__ 
             if (!diag) nt_load<false>(A, lda, i0, M, kt * BK, K, tid, rI);
         }
     };
-    auto stash = [&](int s) {
-        nt_store(sJ(s), tid, rJ);
-        if (!diag) nt_store(sI(s), tid, rI);
+    auto stash = [&](int s) {      // the J operand is stored negated: the MFMAs then accumulate C - A B'
+        double nJ[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nJ[q] = -rJ[q];
+        nt_store(sJ(s), tid, nJ);
+        if (diag) nt_store(sI(s), tid, rJ);
+        else nt_store(sI(s), tid, rI);
     };
-    if (nkt > 0) {
-        fetch(0);
-        stash(0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) fetch(kt + 1);
-        wave_mma<1, LDT_M>(sJ(cur) + wj * 64, sI(cur) + wi * 64, acc, lane);
-        if (kt + 1 < nkt) stash(cur ^ 1);
-        __syncthreads();
-    }
+    if (nkt > 0) fetch(0);
+    // accumulators start as the C tile: its loads fly together with the first operand fetch, and the
+    // epilogue is store-only (no read-modify-write latency at the tail of every tile)
     const int li = lane & 15, lq = lane >> 4;
+    d4 acc[4][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -413,7 +406,26 @@ __global__ __launch_bounds__(256, 2) void nt_update_kernel(double* __restrict__ 
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + wi * 64 + u * 16 + li;
                 const int j = j0 + wj * 64 + t * 16 + lq + 4 * r;
-                if (i < M && j < N && (!SYM || i >= j)) C[i + (int64_t)j * ldc] -= acc[t][u][r];
+                acc[t][u][r] = (i < M && j < N && (!SYM || i >= j)) ? C[i + (int64_t)j * ldc] : 0.0;
+            }
+    if (nkt > 0) stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) fetch(kt + 1);
+        wave_mma<1, LDT_M>(sJ(cur) + wj * 64, sI(cur) + wi * 64, acc, lane);
+        if (kt + 1 < nkt) stash(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi * 64 + u * 16 + li;
+                const int j = j0 + wj * 64 + t * 16 + lq + 4 * r;
+                if (i < M && j < N && (!SYM || i >= j)) C[i + (int64_t)j * ldc] = acc[t][u][r];
             }
 }
 

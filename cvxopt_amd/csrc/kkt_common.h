@@ -72,8 +72,12 @@ int run_mfma_f64_peak(int iters, int num_cus, float* tflops);
 struct PotrfWork {
     int* d_info = nullptr;   // device int: 0 ok, >0 first failing pivot (1-based, LAPACK convention)
     int* h_info = nullptr;   // pinned host mirror
-    double* d_dinv = nullptr; // reciprocal pivots of the current diagonal block (potf2 -> trsm)
+    double* d_dinv = nullptr; // inverses of the 16x16 diagonal blocks of the current panel (potf2 -> trsm)
+    // look-ahead: the bulk of each trailing update runs on `side` while the next panel is factored on the main stream
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_panel, ev_bulk;
 };
+int set_potf2_skip(int v);   // developer ablation switch
 int potrf_work_init(PotrfWork& w);
 void potrf_work_free(PotrfWork& w);
 // In-place lower Cholesky of the n x n column-major matrix A (only tril referenced/overwritten).

@@ -15,6 +15,9 @@ namespace mi355kkt {
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+__device__ int g_potf2_skip = 0;   // developer ablation switch (bit0 a, bit1 b, bit2 c, bit3 inverses); 0 in production
+int set_potf2_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_potf2_skip), &v, sizeof(int)) == hipSuccess ? 0 : -2; }
+
 constexpr int NB = 128;
 constexpr int PLD = 144;   // LDS leading dimension of the diagonal block (== 16 mod 32: conflict-free frags)
 
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
     double* dinv = Ld + 256;                 // 16 reciprocal pivots of the current micro panel
     int* flag = reinterpret_cast<int*>(dinv + 16);
     if (*info != 0) return;
+    const int skip = g_potf2_skip;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) *flag = 0;
     {   // block -> LDS, 16 independent loads in flight per thread (the whole nb x nb square; only tril is used)
@@ -74,76 +78,70 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
     __syncthreads();
     for (int jb = 0; jb < nb; jb += 16) {
         const int pw = min(16, nb - jb);
-        // ---- (a) 16x16 diagonal block in wave 0, lane i <-> row jb+i
-        if (wave == 0) {
+        // ---- (a) 16x16 diagonal block in wave 0, lane i <-> row jb + (i & 15)  (lanes >= 16 mirror lanes 0..15).
+        //      Written without per-element predicates: the strict upper triangle of the block carries garbage that
+        //      never reaches the lower triangle (each update only mixes entries of one row).
+        if (wave == 0 && !(skip & 1)) {
+            const int l15 = lane & 15;
             double a[16];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = (lane < pw && c <= lane) ? As[(jb + c) * PLD + jb + lane] : ((c == lane) ? 1.0 : 0.0);
+            for (int c = 0; c < 16; ++c) a[c] = As[(jb + c) * PLD + jb + l15];
+            if (pw < 16) {                       // ragged last block: rows >= pw act as identity rows
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] = (l15 < pw) ? ((c < pw) ? a[c] : 0.0) : ((c == l15) ? 1.0 : 0.0);
+            }
             int bad = 0;
-            double dv[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
+                __builtin_amdgcn_sched_barrier(0);
                 const double p = readlane_d(a[j], j);
-                if (!(p > 0.0) && j < pw && bad == 0) bad = j + 1;   // uniform (p is wave-uniform)
+                if (!(p > 0.0) && bad == 0) bad = j + 1;             // uniform (p is wave-uniform)
                 double d, inv;
                 sqrt_rsqrt(bad ? 1.0 : p, d, inv);
-                const double l = a[j] * inv;
-                a[j] = (lane == j) ? d : l;
-                dv[j] = inv;
+                const double l = a[j] * inv;                         // lane j: p / sqrt(p) = L[j][j]
+                a[j] = l;
                 if (lane == 0) dinv[j] = inv;
 #pragma unroll
                 for (int c = j + 1; c < 16; ++c) {
-                    const double lc = readlane_d(l, c);
-                    a[c] = fma(-l, lc, a[c]);
+                    a[c] = fma(-l, readlane_d(l, c), a[c]);
+                    if (((c - j) & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // <= 4 broadcast values live in SGPRs
                 }
             }
             if (bad) {
                 if (lane == 0) *flag = jb + bad;
-            } else {
+            } else if (lane < pw) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (lane < pw && c <= lane) {
-                        As[(jb + c) * PLD + jb + lane] = a[c];
-                        Ld[lane * 16 + c] = a[c];
-                    }
-                }
-                // inverse of the 16x16 diagonal block (lower), for the MFMA triangular solves:
-                // row-oriented forward recurrence, rows of M broadcast with v_readlane.
-                double mrow[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) mrow[j] = (j == lane) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const double dk = dv[k];
-                    const double lik = (lane > k) ? a[k] : 0.0;
-#pragma unroll
-                    for (int j = 0; j <= k; ++j) {
-                        const double mkj = readlane_d(mrow[j], k) * dk;
-                        mrow[j] = (lane == k) ? mkj : fma(-lik, mkj, mrow[j]);
-                    }
-                }
-                if (linv_out && lane < 16) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        linv_out[(jb / 16) * 256 + j * 16 + lane] = (j <= lane && lane < pw) ? mrow[j] : 0.0;
-                }
+                for (int c = 0; c < 16; ++c)
+                    if (c < pw) As[(jb + c) * PLD + jb + lane] = a[c];
             }
         }
         __syncthreads();
         if (*flag) break;
-        // ---- (b) rows below the diagonal block: x L_d' = r, one row per thread
-        {
+        // ---- (b) rows below the diagonal block: x L_d' = r, one row per thread.  Column k+1 of L_d is
+        //      prefetched from LDS (wave-wide broadcast reads) into a second register set while column k is
+        //      applied, so the FMAs never wait on an LDS round trip.
+        if (jb + 16 < nb && wave * 64 < nb - jb - 16 && !(skip & 2)) {
             const int row = jb + 16 + tid;
-            if (row < nb) {
-                double x[16];
+            const int rr = min(row, NB - 1);
+            double x[16];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) x[c] = As[(jb + c) * PLD + row];
+            for (int c = 0; c < 16; ++c) x[c] = As[(jb + c) * PLD + rr];
+            double colA[16], colB[16];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    x[k] *= dinv[k];
+            for (int c = 0; c < 16; ++c) colA[c] = As[jb * PLD + jb + c];
 #pragma unroll
-                    for (int c = k + 1; c < 16; ++c) x[c] = fma(-x[k], Ld[c * 16 + k], x[c]);
+            for (int k = 0; k < 16; ++k) {
+                double(&cur)[16] = (k & 1) ? colB : colA;
+                double(&nxt)[16] = (k & 1) ? colA : colB;
+                if (k < 15) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) nxt[c] = As[(jb + k + 1) * PLD + jb + c];
                 }
+                x[k] *= dinv[k];
+#pragma unroll
+                for (int c = k + 1; c < 16; ++c) x[c] = fma(-x[k], cur[c], x[c]);
+            }
+            if (row < nb) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c)
                     if (c < pw) As[(jb + c) * PLD + row] = x[c];
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
         const int ntr = nt - t0;
         const int ntiles = ntr * (ntr + 1) / 2;
         const int li = lane & 15, lq = lane >> 4;
-        for (int t = wave; t < ntiles; t += 4) {
+        for (int t = wave; t < ((skip & 4) ? 0 : ntiles); t += 4) {
             int a = 0, rem = t;                  // t -> (ct = t0 + a, rt = ct + rem), column-major triangle
             while (rem >= ntr - a) {
                 rem -= ntr - a;
@@ -179,6 +177,39 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
     if (*flag) {
         if (tid == 0) *info = col0 + *flag;
         return;
+    }
+    // inverses of the 16x16 diagonal blocks for the MFMA triangular solves (trsm_panel_kernel): row-oriented
+    // forward recurrence, rows of M broadcast with v_readlane; blocks are independent -> two per wave.
+    if (linv_out && !(skip & 8)) {
+        for (int jb = wave * 16; jb < nb; jb += 64) {
+            const int pw = min(16, nb - jb);
+            const int l15 = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const double v = As[(jb + c) * PLD + jb + l15];
+                a[c] = (c < l15 && l15 < pw) ? v : 0.0;                  // strictly lower part of row l15
+            }
+            const double myinv = (l15 < pw) ? 1.0 / As[(jb + l15) * PLD + jb + l15] : 1.0;
+            double mrow[16];                                             // unscaled row: e_i - sum_k L[i][k] M[k][:]
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mrow[j] = (j == l15) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) {
+                __builtin_amdgcn_sched_barrier(0);
+                const double dk = readlane_d(myinv, k);
+#pragma unroll
+                for (int j = 0; j <= k; ++j) {
+                    mrow[j] = fma(-a[k], readlane_d(mrow[j], k) * dk, mrow[j]);
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    linv_out[(jb / 16) * 256 + j * 16 + lane] = (lane < pw) ? mrow[j] * myinv : 0.0;
+            }
+        }
     }
     {
         const int r = tid & (NB - 1), c0 = tid >> 7;
@@ -258,6 +289,12 @@ int potrf_work_init_batched(PotrfWork& w, int nbatch) {
     KKT_HIP_CHECK(hipMalloc(&w.d_dinv, sizeof(double) * 8 * 256 * nbatch));   // inverses of the 16x16 diagonal blocks
     KKT_HIP_CHECK(hipHostMalloc(&w.h_info, sizeof(int) * nbatch));
     memset(w.h_info, 0, sizeof(int) * nbatch);
+    {   // the bulk updates yield to the critical-path kernels of the main stream at workgroup granularity
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, least) != hipSuccess)
+            KKT_HIP_CHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+    }
     return 0;
 }
 
@@ -267,6 +304,9 @@ void potrf_work_free(PotrfWork& w) {
     if (w.d_info) (void)hipFree(w.d_info);
     if (w.d_dinv) (void)hipFree(w.d_dinv);
     if (w.h_info) (void)hipHostFree(w.h_info);
+    for (auto e : w.ev_panel) (void)hipEventDestroy(e);
+    for (auto e : w.ev_bulk) (void)hipEventDestroy(e);
+    if (w.side) (void)hipStreamDestroy(w.side);
     w = PotrfWork();
 }
 
@@ -294,6 +334,57 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
         }
         return 0;
     };
+    // ---- look-ahead variant (single large matrix): the update of the NEXT outer panel's columns stays on
+    //      `st`; the rest of the trailing update runs on w.side, concurrently with the next panel's
+    //      potf2 / trsm (which occupy only a few compute units).
+    if (nbatch == 1 && n >= 8 * NB && w.side) {
+        const int nsteps = (n + 2 * NB - 1) / (2 * NB);
+        while ((int)w.ev_panel.size() < nsteps + 1) {
+            hipEvent_t e1, e2;
+            KKT_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+            KKT_HIP_CHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+            w.ev_panel.push_back(e1);
+            w.ev_bulk.push_back(e2);
+        }
+        int step = 0;
+        bool bulk_pending = false;
+        for (int k0 = 0; k0 < n; k0 += 2 * NB, ++step) {
+            const int nb1 = (n - k0 < NB) ? (n - k0) : NB;
+            if (int e = panel(k0, nb1)) return e;
+            const int k1 = k0 + nb1;
+            if (k1 >= n) break;
+            const int nb2 = (n - k1 < NB) ? (n - k1) : NB;
+            if (int e = launch_gemm_nt_update(A + k1 + (int64_t)k1 * lda, lda, A + k1 + (int64_t)k0 * lda, lda,
+                                              A + k1 + (int64_t)k0 * lda, lda, n - k1, nb2, nb1, st))
+                return e;
+            if (int e = panel(k1, nb2)) return e;
+            const int k2 = k1 + nb2;
+            if (k2 >= n) break;
+            KKT_HIP_CHECK(hipEventRecord(w.ev_panel[step], st));          // panel `step` complete
+            const int K = nb1 + nb2;
+            const int wnext = (n - k2 < 2 * NB) ? (n - k2) : 2 * NB;      // width of the next outer panel
+            const double* Lp = A + k2 + (int64_t)k0 * lda;                // rows k2.., panel columns
+            // the previous bulk update wrote the region both updates below touch
+            if (bulk_pending) KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_bulk[step - 1], 0));
+            // (i) next panel's columns, on the main stream
+            if (int e = launch_gemm_nt_update(A + k2 + (int64_t)k2 * lda, lda, Lp, lda, Lp, lda, n - k2, wnext, K, st))
+                return e;
+            // (ii) everything to the right of it, on the side stream
+            const int k3 = k2 + wnext;
+            if (k3 < n) {
+                KKT_HIP_CHECK(hipStreamWaitEvent(w.side, w.ev_panel[step], 0));
+                if (int e = launch_syrk_nt_update(A + k3 + (int64_t)k3 * lda, lda, A + k3 + (int64_t)k0 * lda, lda, n - k3, K,
+                                                  w.side))
+                    return e;
+                KKT_HIP_CHECK(hipEventRecord(w.ev_bulk[step], w.side));
+                bulk_pending = true;
+            } else {
+                bulk_pending = false;
+            }
+        }
+        if (bulk_pending) KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_bulk[step > 0 ? step - 1 : 0], 0));
+        return 0;
+    }
     for (int k0 = 0; k0 < n; k0 += 2 * NB) {
         const int nb1 = (n - k0 < NB) ? (n - k0) : NB;
         if (int e = panel(k0, nb1)) return e;

@@ -142,6 +142,8 @@ int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const d
 /* X(:, 0:ncols) := W^-T X on the 'l' and 'q' rows, in place (misc_solvers.scale, trans='T', inverse='I') */
 int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
                            const double* dv, const double* dbeta, float* ms);
+/* developer ablation switch for potf2_kernel phases (timing experiments only; results are wrong when != 0) */
+int mi355kkt_debug_potf2_skip(int mask);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops);
 /* in-place lower Cholesky; *info as LAPACK dpotrf */
