@@ -11,6 +11,7 @@
 // x, y, z.
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <mutex>
 
 #include "../../include/mi355kkt.h"
@@ -745,10 +746,20 @@ static int cur_num_cus() {
 int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
                             int64_t ldH, double* dS, int64_t ldS, float* ms) {
     static SyrkPlan plan;   // cached for repeated calls with one shape (profiling loops)
-    if (plan.n != n || plan.K != m || !plan.d_items)
-        if (int e = build_syrk_plan(plan, n, m, cur_num_cus())) return e;
+    int kc = m;             // developer experiment: MI355KKT_SYRK_KCHUNK=<rows per launch> (must divide m)
+    if (const char* e = getenv("MI355KKT_SYRK_KCHUNK")) {
+        const int v = atoi(e);
+        if (v > 0 && m % v == 0) kc = v;
+    }
+    if (plan.n != n || plan.K != kc || !plan.d_items)
+        if (int e = build_syrk_plan(plan, n, kc, cur_num_cus())) return e;
     OpTimer t(ms);
-    if (int e = launch_syrk_scaled(plan, dG, ldG, ddi, dS, ldS, dH, ldH, nullptr)) return e;
+    for (int k0 = 0; k0 < m || k0 == 0; k0 += (kc > 0 ? kc : 1)) {
+        if (int e = launch_syrk_scaled(plan, dG + k0, ldG, ddi ? ddi + k0 : nullptr, dS, ldS, k0 == 0 ? dH : dS,
+                                       k0 == 0 ? ldH : ldS, nullptr))
+            return e;
+        if (m == 0) break;
+    }
     return t.finish();
 }
 
@@ -767,6 +778,7 @@ int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX
 }
 
 int mi355kkt_debug_potf2_skip(int mask) { return mi355kkt::set_potf2_skip(mask); }
+int mi355kkt_debug_syrk_skip(int mask) { return mi355kkt::set_syrk_skip(mask); }
 
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops) { return run_mfma_f64_peak(iters, cur_num_cus(), tflops); }
 

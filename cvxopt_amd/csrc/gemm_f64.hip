@@ -25,6 +25,9 @@ struct __attribute__((aligned(8))) d2u { double x, y; };   // 8-byte aligned pai
 
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
+__device__ int g_syrk_skip = 0;   // developer ablation switch (bit0 no global fetch, bit1 no LDS stash, bit2 no barrier); 0 in production
+int set_syrk_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_syrk_skip), &v, sizeof(int)) == hipSuccess ? 0 : -2; }
+
 // ---------------------------------------------------------------------------------------------------
 // 64x64 wave tile: acc[t][u] += Js[t-th 16 rows][k] * Is[u-th 16 rows][k] over one BK slab.
 //   SI / SK: LDS element strides along the tile index / along k.
@@ -142,12 +145,77 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
         stash(0);
     }
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) fetch(kt + 1);
-        wave_mma<LDT_K, 1>(sJ(cur) + wj * 64 * LDT_K, sI(cur) + wi * 64 * LDT_K, acc, lane);
-        if (kt + 1 < nkt) stash(cur ^ 1);
-        __syncthreads();
+    const int skip = g_syrk_skip;
+    if (tile_fast && ((it.k1 - it.k0) % BK) == 0 && !skip) {
+        // ---- software-pipelined main loop (interior tiles): the 8 global loads of tile kt+1 are issued one
+        //      after every second MFMA quad of the first half, the 8 {scale, ds_write} units that stage it into
+        //      the other LDS buffer after every second quad of the second half; sched_barriers pin that order so
+        //      VMEM / VALU / LDS-write issue hides under the 64-cycle MFMAs instead of in front of the barrier.
+        const double* gp[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gp[r] = G + (int64_t)(j0 + sc + 32 * r) * ldg + it.k0 + sk + BK;        // J operand, tile kt+1
+            gp[4 + r] = G + (int64_t)(i0 + sc + 32 * r) * ldg + it.k0 + sk + BK;    // I operand
+        }
+        const double* dp = di ? di + it.k0 + sk + BK : nullptr;
+        const int li = lane & 15, lk = lane >> 4;
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const bool has_next = kt + 1 < nkt;
+            const double* __restrict__ Js = sJ(cur) + wj * 64 * LDT_K;
+            const double* __restrict__ Is = sI(cur) + wi * 64 * LDT_K;
+            double* nJ = sJ(cur ^ 1);
+            double* nI = sI(cur ^ 1);
+            d2u ld[8];
+            d2u wv = {1.0, 1.0};
+            double a[2][4], b[2][4];          // operand fragments, double buffered across the 4-deep k groups
+#pragma unroll
+            for (int t = 0; t < 4; ++t) a[0][t] = Js[(t * 16 + li) * LDT_K + lk];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[0][u] = Is[(u * 16 + li) * LDT_K + lk];
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                const int pb = (kk / 4) & 1;
+                if (kk + 4 < BK) {            // prefetch the next group's fragments before this group's MFMAs
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a[pb ^ 1][t] = Js[(t * 16 + li) * LDT_K + kk + 4 + lk];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) b[pb ^ 1][u] = Is[(u * 16 + li) * LDT_K + kk + 4 + lk];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) acc[t][u] = MFMA_F64(a[pb][t], b[pb][u], acc[t][u]);
+                    const int q = (kk / 4) * 4 + t;          // quad index 0..15 (compile-time after unrolling)
+                    if (has_next) {
+                        if (q < 8) {
+                            if (q < 4 || !diag) ld[q] = *reinterpret_cast<const d2u*>(gp[q]);
+                            if (q == 7 && dp) wv = *reinterpret_cast<const d2u*>(dp);
+                        } else {
+                            const int s8 = q - 8;
+                            if (s8 < 4 || !diag) {
+                                d2 v = {ld[s8].x * wv.x, ld[s8].y * wv.y};
+                                double* dst = (s8 < 4 ? nJ : nI) + (sc + 32 * (s8 & 3)) * LDT_K + sk;
+                                *reinterpret_cast<d2*>(dst) = v;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) gp[r] += BK;
+            if (dp) dp += BK;
+            __syncthreads();
+        }
+    } else {
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt && !(skip & 1)) fetch(kt + 1);
+            wave_mma<LDT_K, 1>(sJ(cur) + wj * 64 * LDT_K, sI(cur) + wi * 64 * LDT_K, acc, lane);
+            if (kt + 1 < nkt && !(skip & 2)) stash(cur ^ 1);
+            if (!(skip & 4)) __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds D[row=(lane>>4)+4r -> j][col=lane&15 -> i]

@@ -78,6 +78,7 @@ struct PotrfWork {
     std::vector<hipEvent_t> ev_panel, ev_bulk;
 };
 int set_potf2_skip(int v);   // developer ablation switch
+int set_syrk_skip(int v);    // developer ablation switch
 int potrf_work_init(PotrfWork& w);
 void potrf_work_free(PotrfWork& w);
 // In-place lower Cholesky of the n x n column-major matrix A (only tril referenced/overwritten).
