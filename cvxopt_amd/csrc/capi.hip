@@ -88,6 +88,9 @@ struct mi355kkt_solver {
     double* dV = nullptr;      // concatenated v_k
     double* dBeta = nullptr;   // beta_k
     double* dWst = nullptr;    // staging for host-side W (di | v | beta)
+    // sparse mode (config 4): S is factored by the supernodal multifrontal engine instead of the dense one
+    bool sparse = false;
+    SparseEngine sp;
     double* dS = nullptr;      // n x n: S then its Cholesky factor L
     double* dAsct = nullptr;   // n x p
     double* dK = nullptr;      // p x p
@@ -208,7 +211,6 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     };
     const size_t N = (size_t)n, P = (size_t)p, C = (size_t)h->cdim;
     if ((rc = alloc(&h->dW, C))) return fail(rc);
-    if ((rc = alloc(&h->dS, N * N))) return fail(rc);
     if ((rc = alloc(&h->dAsct, N * P))) return fail(rc);
     if ((rc = alloc(&h->dK, P * P))) return fail(rc);
     if ((rc = alloc(&h->dx, N))) return fail(rc);
@@ -217,7 +219,7 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     if ((rc = alloc(&h->dzs, C))) return fail(rc);
     if ((rc = alloc(&h->dtn, N))) return fail(rc);
     if ((rc = alloc(&h->dtp, P))) return fail(rc);
-    if ((rc = alloc(&h->dwork, dmax(gemv_work_doubles(h->cdim, n), gemv_work_doubles(n, p))))) return fail(rc);
+    if ((rc = alloc(&h->dwork, C + 8))) return fail(rc);   // grown to the dense GEMV workspace on first dense use
     if ((rc = alloc(&h->dWst, C + (size_t)nq + 8))) return fail(rc);
     if (nq > 0) {
         if ((rc = alloc(&h->dGs, C * N))) return fail(rc);
@@ -228,7 +230,6 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     h->hbuf_doubles = dmax(N + P + C, 2 * C + (size_t)nq) + 8;
     if (hipHostMalloc(&h->hbuf, sizeof(double) * h->hbuf_doubles) != hipSuccess) return fail(MI355KKT_ENOMEM);
     if ((rc = potrf_work_init(h->pw))) return fail(rc);
-    if ((rc = build_syrk_plan(h->planS, n, h->cdim, h->num_cus))) return fail(rc);
     if (p > 0) {
         if ((rc = build_syrk_plan(h->planAtA, n, p, h->num_cus))) return fail(rc);
         if ((rc = build_syrk_plan(h->planK, p, n, h->num_cus))) return fail(rc);
@@ -244,6 +245,7 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     double* bufs[] = {h->G_owned, h->A_owned, h->H_owned, h->dW, h->dS, h->dAsct, h->dK,
                       h->dx, h->dy, h->dz, h->dzs, h->dtn, h->dtp, h->dwork, h->dWst, h->dGs, h->dV, h->dBeta};
     cone_layout_free(h->cl);
+    sparse_engine_free(h->sp);
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (h->hbuf) (void)hipHostFree(h->hbuf);
@@ -288,6 +290,32 @@ int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t*
             dense[(size_t)j * h->cdim + rowind[k]] += values[k];
         }
     return mi355kkt_set_G_dense(h, dense.data(), h->cdim > 1 ? h->cdim : 1);
+}
+
+int mi355kkt_set_sparse_problem(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
+                                const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues) {
+    if (!h || !gcolptr) { set_last_error("set_sparse_problem: null argument"); return MI355KKT_EINVAL; }
+    if (h->p != 0 || !h->q.empty() || !h->s.empty()) {
+        set_last_error("set_sparse_problem: the sparse engine handles LP cones without equality constraints");
+        return MI355KKT_ENOTIMPL;
+    }
+    if (int e = bind(h)) return e;
+    for (int j = 0; j < h->n; ++j)
+        for (int64_t k = gcolptr[j]; k < gcolptr[j + 1]; ++k)
+            if (growind[k] < 0 || growind[k] >= h->cdim) { set_last_error("set_sparse_problem: G row index out of range"); return MI355KKT_EINVAL; }
+    if (int e = sparse_engine_create(h->sp, h->n, h->cdim, gcolptr, growind, gvalues, hcolptr, hrowind, hvalues)) return e;
+    h->sparse = true;
+    h->firstcall = true;
+    return 0;
+}
+
+int mi355kkt_sparse_stats(const mi355kkt_solver* h, int64_t* nnzL, int* nsupernodes, int* nlevels, double* flops) {
+    if (!h || !h->sparse) return MI355KKT_EINVAL;
+    if (nnzL) *nnzL = h->sp.sym.nnzL;
+    if (nsupernodes) *nsupernodes = h->sp.sym.ns;
+    if (nlevels) *nlevels = h->sp.sym.nlevels;
+    if (flops) *flops = h->sp.sym.flops;
+    return 0;
 }
 
 int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA) {
@@ -377,11 +405,36 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     }
     if (h->ml > 0 && !W->di) { set_last_error("factor: W.di missing"); return MI355KKT_EINVAL; }
     if (!h->q.empty() && (!W->v || !W->beta)) { set_last_error("factor: W.v / W.beta missing"); return MI355KKT_EINVAL; }
+    if (h->sparse) {
+        if (int e = bind(h)) return e;
+        h->factored = false;
+        KKT_HIP_CHECK(hipEventRecord(h->ev[0], h->st));
+        if (h->ml > 0) hipLaunchKernelGGL(scaled_copy_kernel, g1(h->ml), dim3(256), 0, h->st, W->di, h->dW, h->ml, 1.0);
+        int sinfo = 0;
+        if (int e = sparse_engine_factor(h->sp, h->dW, h->st, &sinfo)) return e;
+        KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
+        KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+        (void)hipEventElapsedTime(&h->t_factor, h->ev[0], h->ev[3]);
+        h->t_syrk = h->t_potrf = h->t_schur = h->t_syrk_kernel = 0;
+        h->firstcall = false;
+        if (sinfo > 0) return sinfo;
+        h->factored = true;
+        return 0;
+    }
     if ((h->cdim > 0 && h->n > 0 && !h->dG) || (h->p > 0 && h->n > 0 && !h->dA)) {
         set_last_error("factor: G / A not set");
         return MI355KKT_EINVAL;
     }
     if (int e = bind(h)) return e;
+    if (!h->dS) {   // dense engine state is created on first use (a sparse-mode handle never pays for it)
+        const size_t N = (size_t)h->n;
+        KKT_HIP_CHECK(hipMalloc(&h->dS, sizeof(double) * dmax(N * N, 1)));
+        (void)hipFree(h->dwork);
+        h->dwork = nullptr;
+        KKT_HIP_CHECK(hipMalloc(&h->dwork, sizeof(double) * dmax(dmax(gemv_work_doubles(h->cdim, h->n), gemv_work_doubles(h->n, h->p)),
+                                                                 (size_t)h->cdim + 8)));
+        if (int e = build_syrk_plan(h->planS, h->n, h->cdim, h->num_cus)) return e;
+    }
     h->factored = false;
     const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);   // K[z,z] = -(1+reg): fold into the row scaling
     KKT_HIP_CHECK(hipEventRecord(h->ev[0], h->st));
@@ -461,6 +514,13 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     hipStream_t st = h->st;
     const int n = h->n, p = h->p, m = h->cdim;
     KKT_HIP_CHECK(hipEventRecord(h->ev[4], st));
+    if (h->sparse) {                                                // misc.py:1513-1563, sparse branch
+        if (int e = sparse_engine_gemv_t(h->sp, h->dW, dz, h->dzs, h->dwork, dx, st)) return e;
+        if (int e = sparse_engine_solve(h->sp, dx, st)) return e;
+        if (int e = sparse_engine_gemv_n(h->sp, h->dW, dx, h->dzs, dz, st)) return e;
+        KKT_HIP_CHECK(hipEventRecord(h->ev[5], st));
+        return 0;
+    }
     // zs = W^-T bz ;  x += Gs' zs                                     (misc.py:1513, :1524)
     const bool cones = !h->q.empty();
     const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);

@@ -103,6 +103,42 @@ int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ld
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);
 
 
+// ---- sparse Cholesky (sparse_chol.hip) -------------------------------------------------------------
+struct SparseSymbolic {
+    int n = 0, m = 0, ns = 0, nlevels = 0;
+    int64_t nnzL = 0;
+    double flops = 0.0;
+    std::vector<int> perm, iperm;                 // perm[new] = old
+    std::vector<int> sn_first;                    // ns + 1
+    std::vector<int64_t> sn_rowptr;               // ns + 1
+    std::vector<int> sn_rows, sn_parent, sn_level, level_ptr, level_sn;
+    std::vector<int64_t> panel_off, upd_off, relmap_off;
+    std::vector<int> child_ptr, child_list, relmap;
+    std::vector<int64_t> asm_slot, asm_ptr;       // numeric assembly: one entry per structural nonzero of S
+    std::vector<int> asm_a, asm_b, asm_r;
+};
+struct SparseEngine {
+    SparseSymbolic sym;
+    int n = 0, m = 0;
+    int *d_sn_first = nullptr, *d_sn_rows = nullptr, *d_child_ptr = nullptr, *d_child_list = nullptr, *d_relmap = nullptr,
+        *d_level_sn = nullptr, *d_asm_a = nullptr, *d_asm_b = nullptr, *d_asm_r = nullptr, *d_perm = nullptr,
+        *d_gri = nullptr, *d_gci = nullptr, *d_gnzmap = nullptr, *d_info = nullptr, *h_info = nullptr;
+    int64_t *d_sn_rowptr = nullptr, *d_panel_off = nullptr, *d_upd_off = nullptr, *d_relmap_off = nullptr,
+            *d_asm_slot = nullptr, *d_asm_ptr = nullptr, *d_gcp = nullptr, *d_grp = nullptr, *d_rem_off = nullptr;
+    double *d_gv = nullptr, *d_hv = nullptr, *d_rem = nullptr, *d_panels = nullptr, *d_upd = nullptr, *d_xp = nullptr;
+};
+int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const int64_t* gri, const int64_t* hcp,
+                     const int64_t* hri);
+int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, const int64_t* gri, const double* gv,
+                         const int64_t* hcp, const int64_t* hri, const double* hv);
+void sparse_engine_free(SparseEngine& E);
+int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, int* info);
+int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st);
+int sparse_engine_gemv_t(SparseEngine& E, const double* d_w, const double* d_z, double* d_zs, double* d_zss, double* d_x,
+                         hipStream_t st);
+int sparse_engine_gemv_n(SparseEngine& E, const double* d_w, const double* d_x, const double* d_zs, double* d_z,
+                         hipStream_t st);
+
 // ---- second-order-cone scaling --------------------------------------------------------------------
 struct ConeLayout {
     int ml = 0, nq = 0, vlen = 0, n_small = 0, n_large = 0;

@@ -1,0 +1,787 @@
+// Sparse Cholesky for the sparse branch of kkt_chol2 (reference src/python/misc.py:1405-1462, :1528-1558):
+// the device replacement of cholmod.symbolic / cholmod.numeric / cholmod.solve (reference src/C/cholmod.c:273-558).
+// CHOLMOD itself (SuiteSparse, third party, not vendored) is not restated; what is reproduced is the contract
+// "analyse S once, refactor numerically every iteration, solve with the factor" and the unique result L L' = P S P'.
+//
+//   host, once per factory (symbolic_analyze):
+//       pattern of S = H + G'D^2G (lower, CSC)  ->  nested-dissection ordering (BFS level-structure separators,
+//       George 1973)  ->  elimination tree, postorder, column structures  ->  fundamental supernodes (+ relaxed
+//       amalgamation of small chains)  ->  per supernode: columns, row list, children, extend-add index maps,
+//       levels of the supernodal tree, and the gather lists that turn (H values, G values, di) into S values.
+//   device, every factor():  assemble_S_kernel (S values straight into the supernodal panels) and one
+//       front_kernel launch per tree level (multifrontal: one workgroup per frontal matrix: extend-add of the
+//       children's update matrices, blocked dense partial Cholesky, update matrix left for the parent).
+//   device, every solve():   level-by-level forward (leaves -> root) and backward (root -> leaves) supernodal
+//       substitution; children's right-hand-side updates are extend-added by the parent (deterministic, no atomics).
+#include <algorithm>
+#include <numeric>
+#include <queue>
+
+#include "kkt_common.h"
+
+namespace mi355kkt {
+
+// =====================================================================================================
+// host: symbolic analysis
+// =====================================================================================================
+namespace {
+
+// lower-triangular pattern of S = H + G'G (values irrelevant) as adjacency lists of the full symmetric graph
+void build_graph(int n, int m, const int64_t* gcp, const int64_t* gri, const int64_t* hcp, const int64_t* hri,
+                 std::vector<std::vector<int>>& adj) {
+    adj.assign(n, {});
+    // rows of G -> cliques
+    std::vector<std::vector<int>> rows(m);
+    for (int j = 0; j < n; ++j)
+        for (int64_t k = gcp[j]; k < gcp[j + 1]; ++k) rows[gri[k]].push_back(j);
+    for (int r = 0; r < m; ++r) {
+        const auto& c = rows[r];
+        for (size_t a = 0; a < c.size(); ++a)
+            for (size_t b = 0; b < c.size(); ++b)
+                if (a != b) adj[c[a]].push_back(c[b]);
+    }
+    if (hcp)
+        for (int j = 0; j < n; ++j)
+            for (int64_t k = hcp[j]; k < hcp[j + 1]; ++k) {
+                const int i = (int)hri[k];
+                if (i > j) {   // only the lower triangle of H is meaningful
+                    adj[i].push_back(j);
+                    adj[j].push_back(i);
+                }
+            }
+    for (auto& a : adj) {
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+    }
+}
+
+// Nested dissection (George 1973, automatic version): the separator of a connected part is one level of a BFS
+// level structure rooted at a pseudo-peripheral node; the two sides are ordered first (recursively), the separator
+// last.  Parts of <= 48 nodes are ordered in BFS order.
+struct Dissector {
+    const std::vector<std::vector<int>>& adj;
+    std::vector<int> part, level;
+    std::vector<int>& order;
+    int next_id = 1;
+    Dissector(const std::vector<std::vector<int>>& a, std::vector<int>& o) : adj(a), part(a.size(), 0), level(a.size(), -1), order(o) {}
+
+    // BFS inside part `id` from root; fills levels, leaves level[] set for the visited nodes
+    void bfs(int root, int id, std::vector<std::vector<int>>& levels) {
+        levels.clear();
+        std::vector<int> cur{root};
+        level[root] = 0;
+        while (!cur.empty()) {
+            levels.push_back(cur);
+            std::vector<int> nxt;
+            for (int v : cur)
+                for (int u : adj[v])
+                    if (part[u] == id && level[u] < 0) {
+                        level[u] = (int)levels.size();
+                        nxt.push_back(u);
+                    }
+            cur.swap(nxt);
+        }
+    }
+    void clear(const std::vector<std::vector<int>>& levels) {
+        for (auto& L : levels)
+            for (int v : L) level[v] = -1;
+    }
+    void run(std::vector<int>& nodes, int depth) {
+        if (nodes.empty()) return;
+        const int id = next_id++;
+        for (int v : nodes) part[v] = id;
+        std::vector<std::vector<int>> levels;
+        // connected components
+        std::vector<std::vector<int>> comps;
+        for (int v : nodes)
+            if (level[v] < 0) {
+                bfs(v, id, levels);
+                std::vector<int> c;
+                for (auto& L : levels) c.insert(c.end(), L.begin(), L.end());
+                comps.push_back(std::move(c));
+            }
+        for (int v : nodes) level[v] = -1;
+        if (comps.size() > 1) {
+            for (auto& c : comps) run(c, depth);
+            return;
+        }
+        if ((int)nodes.size() <= 48 || depth > 60) {
+            bfs(nodes[0], id, levels);
+            for (auto& L : levels)
+                for (int v : L) order.push_back(v);
+            clear(levels);
+            return;
+        }
+        int root = nodes[0];
+        for (int sweep = 0; sweep < 3; ++sweep) {
+            bfs(root, id, levels);
+            int best = levels.back()[0];
+            for (int v : levels.back())
+                if (adj[v].size() < adj[best].size()) best = v;
+            clear(levels);
+            if (best == root) break;
+            root = best;
+        }
+        bfs(root, id, levels);
+        clear(levels);
+        if (levels.size() < 3) {   // (nearly) complete graph: no useful separator
+            for (auto& L : levels)
+                for (int v : L) order.push_back(v);
+            return;
+        }
+        const size_t total = nodes.size();
+        std::vector<size_t> prefix(levels.size() + 1, 0);
+        for (size_t l = 0; l < levels.size(); ++l) prefix[l + 1] = prefix[l] + levels[l].size();
+        size_t best_l = levels.size() / 2;
+        double best_cost = 1e300;
+        for (size_t l = 1; l + 1 < levels.size(); ++l) {
+            const double a = (double)prefix[l], b = (double)(total - prefix[l + 1]);
+            const double imbalance = std::abs(a - b) / (double)total;
+            const double cost = (double)levels[l].size() * (1.0 + 4.0 * imbalance);
+            if (imbalance < 0.6 && cost < best_cost) {
+                best_cost = cost;
+                best_l = l;
+            }
+        }
+        std::vector<int> left, right, sep = levels[best_l];
+        for (size_t l = 0; l < best_l; ++l) left.insert(left.end(), levels[l].begin(), levels[l].end());
+        for (size_t l = best_l + 1; l < levels.size(); ++l) right.insert(right.end(), levels[l].begin(), levels[l].end());
+        run(left, depth + 1);
+        run(right, depth + 1);
+        for (int v : sep) order.push_back(v);
+    }
+};
+
+}  // namespace
+
+int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const int64_t* gri, const int64_t* hcp,
+                     const int64_t* hri) {
+    S = SparseSymbolic();
+    S.n = n;
+    S.m = m;
+    if (n == 0) return 0;
+    std::vector<std::vector<int>> adj;
+    build_graph(n, m, gcp, gri, hcp, hri, adj);
+    // ---- ordering
+    std::vector<int> nodes(n), order;
+    std::iota(nodes.begin(), nodes.end(), 0);
+    order.reserve(n);
+    {
+        Dissector nd(adj, order);
+        nd.run(nodes, 0);
+    }
+    if ((int)order.size() != n) {
+        set_last_error("symbolic_analyze: ordering produced %zu of %d nodes", order.size(), n);
+        return -1;
+    }
+    S.perm = order;                 // perm[new] = old
+    S.iperm.assign(n, 0);
+    for (int k = 0; k < n; ++k) S.iperm[order[k]] = k;
+    // ---- permuted lower pattern (CSC): column j holds rows i > j
+    std::vector<std::vector<int>> low(n);
+    for (int v = 0; v < n; ++v) {
+        const int j = S.iperm[v];
+        for (int u : adj[v]) {
+            const int i = S.iperm[u];
+            if (i > j) low[j].push_back(i);
+        }
+    }
+    for (auto& c : low) std::sort(c.begin(), c.end());
+    // ---- elimination tree (Liu) via path compression on the permuted pattern
+    std::vector<int> parent(n, -1), anc(n, -1);
+    {
+        // need row-wise access: for each i, the columns j < i with S_ij != 0
+        std::vector<std::vector<int>> rowcols(n);
+        for (int j = 0; j < n; ++j)
+            for (int i : low[j]) rowcols[i].push_back(j);
+        for (int i = 0; i < n; ++i)
+            for (int j : rowcols[i]) {
+                int r = j;
+                while (anc[r] != -1 && anc[r] != i) {
+                    const int nx = anc[r];
+                    anc[r] = i;
+                    r = nx;
+                }
+                if (anc[r] == -1) {
+                    anc[r] = i;
+                    parent[r] = i;
+                }
+            }
+    }
+    // ---- column structures struct(j) = rows > j of L(:, j): own pattern U children's structures
+    std::vector<std::vector<int>> child(n);
+    for (int j = 0; j < n; ++j)
+        if (parent[j] >= 0) child[parent[j]].push_back(j);
+    std::vector<std::vector<int>> st(n);
+    {
+        std::vector<int> flag(n, -1);
+        for (int j = 0; j < n; ++j) {   // parents have larger indices: natural order is a valid topological order
+            std::vector<int>& s = st[j];
+            flag[j] = j;
+            for (int i : low[j])
+                if (flag[i] != j) { flag[i] = j; s.push_back(i); }
+            for (int c : child[j])
+                for (int i : st[c])
+                    if (i != j && flag[i] != j) { flag[i] = j; s.push_back(i); }
+            std::sort(s.begin(), s.end());
+        }
+    }
+    // ---- supernodes: j+1 joins j's supernode when parent[j] == j+1, j is the only child of j+1 and
+    //      struct(j) == {j+1} U struct(j+1) (fundamental); small chains are also merged when the fill is small.
+    std::vector<int> sn_first;   // first column of each supernode
+    std::vector<int> sn_of(n, 0);
+    const int MAXW = 256;
+    for (int j = 0; j < n; ++j) {
+        bool join = false;
+        if (j > 0 && parent[j - 1] == j && child[j].size() == 1) {
+            const int first = sn_first.back();
+            const bool exact = st[j - 1].size() == st[j].size() + 1;
+            const bool relaxed = (j - first) < 8 && st[j - 1].size() <= st[j].size() + 3;   // tiny extra fill
+            if ((exact || relaxed) && (j - first) < MAXW) join = true;
+        }
+        if (!join) sn_first.push_back(j);
+        sn_of[j] = (int)sn_first.size() - 1;
+    }
+    const int ns = (int)sn_first.size();
+    S.ns = ns;
+    S.sn_first = sn_first;
+    S.sn_first.push_back(n);
+    // rows of supernode s: its own columns followed by the union of its columns' structures outside the supernode
+    S.sn_rowptr.assign(ns + 1, 0);
+    std::vector<std::vector<int>> snrows(ns);
+    {
+        std::vector<int> flag(n, -1);
+        for (int s = 0; s < ns; ++s) {
+            const int f = S.sn_first[s], l = S.sn_first[s + 1];
+            std::vector<int>& r = snrows[s];
+            for (int j = f; j < l; ++j) r.push_back(j);
+            std::vector<int> below;
+            for (int j = f; j < l; ++j)
+                for (int i : st[j])
+                    if (i >= l && flag[i] != s) { flag[i] = s; below.push_back(i); }
+            std::sort(below.begin(), below.end());
+            r.insert(r.end(), below.begin(), below.end());
+            S.sn_rowptr[s + 1] = S.sn_rowptr[s] + (int64_t)r.size();
+        }
+    }
+    S.sn_rows.resize(S.sn_rowptr[ns]);
+    for (int s = 0; s < ns; ++s) std::copy(snrows[s].begin(), snrows[s].end(), S.sn_rows.begin() + S.sn_rowptr[s]);
+    // supernodal tree: parent = supernode of the first row below the supernode
+    S.sn_parent.assign(ns, -1);
+    std::vector<std::vector<int>> snchild(ns);
+    for (int s = 0; s < ns; ++s) {
+        const int w = S.sn_first[s + 1] - S.sn_first[s];
+        if ((int)snrows[s].size() > w) {
+            S.sn_parent[s] = sn_of[snrows[s][w]];
+            snchild[S.sn_parent[s]].push_back(s);
+        }
+    }
+    // levels (height from the leaves), panel / update-matrix offsets
+    S.sn_level.assign(ns, 0);
+    int maxlevel = 0;
+    for (int s = 0; s < ns; ++s) {   // children have smaller indices
+        for (int c : snchild[s]) S.sn_level[s] = std::max(S.sn_level[s], S.sn_level[c] + 1);
+        maxlevel = std::max(maxlevel, S.sn_level[s]);
+    }
+    S.nlevels = maxlevel + 1;
+    S.level_ptr.assign(S.nlevels + 1, 0);
+    for (int s = 0; s < ns; ++s) S.level_ptr[S.sn_level[s] + 1]++;
+    for (int l = 0; l < S.nlevels; ++l) S.level_ptr[l + 1] += S.level_ptr[l];
+    S.level_sn.resize(ns);
+    {
+        std::vector<int> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
+        for (int s = 0; s < ns; ++s) S.level_sn[pos[S.sn_level[s]]++] = s;
+    }
+    S.panel_off.assign(ns + 1, 0);
+    S.upd_off.assign(ns + 1, 0);
+    for (int s = 0; s < ns; ++s) {
+        const int64_t h = S.sn_rowptr[s + 1] - S.sn_rowptr[s], w = S.sn_first[s + 1] - S.sn_first[s];
+        S.panel_off[s + 1] = S.panel_off[s] + h * w;
+        S.upd_off[s + 1] = S.upd_off[s] + (h - w) * (h - w);
+        S.flops += (double)w * h * h;   // rough
+    }
+    // children lists + extend-add maps: position of each below-row of child c inside the parent's row list
+    S.child_ptr.assign(ns + 1, 0);
+    for (int s = 0; s < ns; ++s) S.child_ptr[s + 1] = S.child_ptr[s] + (int)snchild[s].size();
+    S.child_list.resize(S.child_ptr[ns]);
+    S.relmap_off.assign(ns + 1, 0);
+    for (int s = 0; s < ns; ++s) {
+        std::copy(snchild[s].begin(), snchild[s].end(), S.child_list.begin() + S.child_ptr[s]);
+        const int64_t h = S.sn_rowptr[s + 1] - S.sn_rowptr[s], w = S.sn_first[s + 1] - S.sn_first[s];
+        S.relmap_off[s + 1] = S.relmap_off[s] + (h - w);
+    }
+    S.relmap.resize(S.relmap_off[ns]);
+    {
+        std::vector<int> where(n, -1);
+        for (int p = 0; p < ns; ++p) {
+            for (size_t k = 0; k < snrows[p].size(); ++k) where[snrows[p][k]] = (int)k;
+            for (int c : snchild[p]) {
+                const int w = S.sn_first[c + 1] - S.sn_first[c];
+                for (size_t k = w; k < snrows[c].size(); ++k) {
+                    const int pos = where[snrows[c][k]];
+                    if (pos < 0) {
+                        set_last_error("symbolic_analyze: child row missing in parent front");
+                        return -1;
+                    }
+                    S.relmap[S.relmap_off[c] + (k - w)] = pos;
+                }
+            }
+            for (int r : snrows[p]) where[r] = -1;
+        }
+    }
+    // ---- numeric assembly lists: every structural nonzero of S in (permuted) column j, row i >= j, gets a slot in
+    //      its supernode's panel; contributions: H entries and products G_ra G_rb di_r^2.
+    //      Sorted by target slot (CSR over targets) so that one thread sums one entry in a fixed order.
+    struct Contrib { int64_t slot; int a, b, r; };   // a = G nz index (or H nz index with b = -1)
+    std::vector<Contrib> cs;
+    auto slot_of = [&](int inew, int jnew) -> int64_t {   // i >= j (permuted)
+        const int s = sn_of[jnew];
+        const std::vector<int>& r = snrows[s];
+        const int64_t h = (int64_t)r.size();
+        const int col = jnew - S.sn_first[s];
+        const auto it = std::lower_bound(r.begin() + (inew >= S.sn_first[s + 1] ? (S.sn_first[s + 1] - S.sn_first[s]) : 0),
+                                         r.end(), inew);
+        int pos;
+        if (inew < S.sn_first[s + 1]) pos = inew - S.sn_first[s];
+        else {
+            if (it == r.end() || *it != inew) return -1;
+            pos = (int)(it - r.begin());
+        }
+        return S.panel_off[s] + (int64_t)col * h + pos;
+    };
+    {
+        std::vector<std::vector<std::pair<int, int>>> rows(m);   // (column, nz index)
+        for (int j = 0; j < n; ++j)
+            for (int64_t k = gcp[j]; k < gcp[j + 1]; ++k) rows[gri[k]].push_back({j, (int)k});
+        for (int r = 0; r < m; ++r)
+            for (auto& pa : rows[r])
+                for (auto& pb : rows[r]) {
+                    const int ia = S.iperm[pa.first], ib = S.iperm[pb.first];
+                    if (ia < ib) continue;
+                    const int64_t sl = slot_of(ia, ib);
+                    if (sl < 0) { set_last_error("symbolic_analyze: G'G entry outside the symbolic pattern"); return -1; }
+                    cs.push_back({sl, pa.second, pb.second, r});
+                }
+        if (hcp)
+            for (int j = 0; j < n; ++j)
+                for (int64_t k = hcp[j]; k < hcp[j + 1]; ++k) {
+                    const int i = (int)hri[k];
+                    if (i < j) continue;   // lower triangle only
+                    int ia = S.iperm[i], ib = S.iperm[j];
+                    if (ia < ib) std::swap(ia, ib);
+                    const int64_t sl = slot_of(ia, ib);
+                    if (sl < 0) { set_last_error("symbolic_analyze: H entry outside the symbolic pattern"); return -1; }
+                    cs.push_back({sl, (int)k, -1, 0});
+                }
+    }
+    std::stable_sort(cs.begin(), cs.end(), [](const Contrib& x, const Contrib& y) { return x.slot < y.slot; });
+    for (size_t k = 0; k < cs.size();) {
+        size_t e = k;
+        while (e < cs.size() && cs[e].slot == cs[k].slot) ++e;
+        S.asm_slot.push_back(cs[k].slot);
+        S.asm_ptr.push_back((int64_t)k);
+        k = e;
+    }
+    S.asm_ptr.push_back((int64_t)cs.size());
+    S.asm_a.resize(cs.size());
+    S.asm_b.resize(cs.size());
+    S.asm_r.resize(cs.size());
+    for (size_t k = 0; k < cs.size(); ++k) {
+        S.asm_a[k] = cs[k].a;
+        S.asm_b[k] = cs[k].b;
+        S.asm_r[k] = cs[k].r;
+    }
+    S.nnzL = S.panel_off[ns];
+    return 0;
+}
+
+// =====================================================================================================
+// device: numeric factorisation and solves
+// =====================================================================================================
+__global__ __launch_bounds__(256) void sp_assemble_kernel(int64_t ntargets, const int64_t* __restrict__ slot,
+                                                          const int64_t* __restrict__ ptr, const int* __restrict__ a,
+                                                          const int* __restrict__ b, const int* __restrict__ r,
+                                                          const double* __restrict__ gv, const double* __restrict__ hv,
+                                                          const double* __restrict__ di, double* __restrict__ panels) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= ntargets) return;
+    double s = 0.0;
+    for (int64_t k = ptr[t]; k < ptr[t + 1]; ++k) {
+        if (b[k] < 0) s += hv[a[k]];
+        else {
+            const double d = di[r[k]];
+            s += (d * gv[a[k]]) * (d * gv[b[k]]);      // (di G)_ra (di G)_rb, as the reference forms Gs first
+        }
+    }
+    panels[slot[t]] = s;
+}
+
+struct SpDev {   // device copies of the symbolic structure (plain pointers for the kernels)
+    const int* sn_first;
+    const int64_t* sn_rowptr;
+    const int* sn_rows;
+    const int64_t* panel_off;
+    const int64_t* upd_off;
+    const int* child_ptr;
+    const int* child_list;
+    const int64_t* relmap_off;
+    const int* relmap;
+    const int* level_sn;
+};
+
+// One workgroup = one frontal matrix.  F = [ L-panel (h x w) | U (h-w x h-w) ]: the panel already holds the
+// entries of S; U starts as the extend-add of the children's update matrices.
+__global__ __launch_bounds__(256) void sp_front_kernel(SpDev d, int level_begin, double* __restrict__ panels,
+                                                       double* __restrict__ upd, int* __restrict__ info) {
+    const int s = d.level_sn[level_begin + blockIdx.x];
+    const int tid = threadIdx.x;
+    const int w = d.sn_first[s + 1] - d.sn_first[s];
+    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
+    const int hu = h - w;
+    double* __restrict__ P = panels + d.panel_off[s];   // h x w, column-major
+    double* __restrict__ U = upd + d.upd_off[s];        // hu x hu, column-major (lower part used)
+    __shared__ double piv;
+    __shared__ int bad;
+    if (tid == 0) bad = 0;
+    // ---- U := 0, then extend-add the children (their update matrices and the part that lands in the panel)
+    for (int64_t e = tid; e < (int64_t)hu * hu; e += 256) U[e] = 0.0;
+    __syncthreads();
+    for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
+        const int c = d.child_list[ci];
+        const int wc = d.sn_first[c + 1] - d.sn_first[c];
+        const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - wc;
+        const double* __restrict__ Uc = upd + d.upd_off[c];
+        const int* __restrict__ rm = d.relmap + d.relmap_off[c];
+        for (int64_t e = tid; e < (int64_t)hc * hc; e += 256) {
+            const int i = (int)(e % hc), j = (int)(e / hc);
+            if (i < j) continue;
+            const int pi = rm[i], pj = rm[j];            // positions in this front; pi >= pj (row lists are sorted)
+            const double v = Uc[i + (int64_t)j * hc];
+            if (pj < w) P[pi + (int64_t)pj * h] += v;
+            else U[(pi - w) + (int64_t)(pj - w) * hu] += v;
+        }
+        __syncthreads();   // children are added one after the other: deterministic, no atomics
+    }
+    // ---- blocked partial Cholesky of the first w columns (block size 16)
+    for (int jb = 0; jb < w; jb += 16) {
+        const int pw = min(16, w - jb);
+        for (int jj = 0; jj < pw; ++jj) {
+            const int j = jb + jj;
+            if (tid == 0) {
+                const double a = P[j + (int64_t)j * h];
+                if (!(a > 0.0)) { if (!bad) bad = d.sn_first[s] + j + 1; piv = 1.0; }
+                else piv = sqrt(a);
+            }
+            __syncthreads();
+            const double dj = piv, inv = 1.0 / piv;
+            for (int i = j + tid; i < h; i += 256) P[i + (int64_t)j * h] = (i == j) ? dj : P[i + (int64_t)j * h] * inv;
+            __syncthreads();
+            // rank-1 update restricted to the remaining columns of this block
+            const int nc = jb + pw - 1 - j;
+            for (int64_t e = tid; e < (int64_t)nc * (h - j - 1); e += 256) {
+                const int c = j + 1 + (int)(e / (h - j - 1)), i = j + 1 + (int)(e % (h - j - 1));
+                if (i >= c) P[i + (int64_t)c * h] -= P[i + (int64_t)j * h] * P[c + (int64_t)j * h];
+            }
+            __syncthreads();
+        }
+        // rank-pw update of the columns to the right inside the panel ...
+        const int c0 = jb + pw;
+        for (int64_t e = tid; e < (int64_t)(w - c0) * (h - c0); e += 256) {
+            const int c = c0 + (int)(e / (h - c0)), i = c0 + (int)(e % (h - c0));
+            if (i < c) continue;
+            double sacc = 0.0;
+            for (int k = jb; k < jb + pw; ++k) sacc += P[i + (int64_t)k * h] * P[c + (int64_t)k * h];
+            P[i + (int64_t)c * h] -= sacc;
+        }
+        // ... and of the update matrix
+        for (int64_t e = tid; e < (int64_t)hu * hu; e += 256) {
+            const int i = (int)(e % hu), c = (int)(e / hu);
+            if (i < c) continue;
+            double sacc = 0.0;
+            for (int k = jb; k < jb + pw; ++k) sacc += P[(w + i) + (int64_t)k * h] * P[(w + c) + (int64_t)k * h];
+            U[i + (int64_t)c * hu] -= sacc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && bad) atomicMin(info, bad);      // smallest failing column (info starts at INT_MAX)
+}
+
+// forward substitution, one workgroup per supernode of a level:  y_s = L11^-1 (b_s + children updates),
+// then the front's right-hand-side remainder r_s = (children updates below) - L21 y_s is left for the parent.
+__global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, const double* __restrict__ panels,
+                                                     double* __restrict__ x, double* __restrict__ rem,
+                                                     const int64_t* __restrict__ rem_off) {
+    const int s = d.level_sn[level_begin + blockIdx.x];
+    const int tid = threadIdx.x;
+    const int f = d.sn_first[s];
+    const int w = d.sn_first[s + 1] - f;
+    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
+    const int hu = h - w;
+    const double* __restrict__ P = panels + d.panel_off[s];
+    double* __restrict__ R = rem + rem_off[s];          // hu entries
+    for (int i = tid; i < hu; i += 256) R[i] = 0.0;
+    __syncthreads();
+    for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
+        const int c = d.child_list[ci];
+        const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
+        const double* __restrict__ Rc = rem + rem_off[c];
+        const int* __restrict__ rm = d.relmap + d.relmap_off[c];
+        for (int i = tid; i < hc; i += 256) {
+            const int p = rm[i];
+            if (p < w) x[f + p] += Rc[i];
+            else R[p - w] += Rc[i];
+        }
+        __syncthreads();
+    }
+    // dense forward substitution on the w x w triangle (column sweep)
+    for (int j = 0; j < w; ++j) {
+        __shared__ double xj;
+        if (tid == 0) {
+            xj = x[f + j] / P[j + (int64_t)j * h];
+            x[f + j] = xj;
+        }
+        __syncthreads();
+        const double v = xj;
+        for (int i = j + 1 + tid; i < w; i += 256) x[f + i] -= P[i + (int64_t)j * h] * v;
+        __syncthreads();
+    }
+    // remainder: R -= L21 y
+    for (int i = tid; i < hu; i += 256) {
+        double sacc = 0.0;
+        for (int j = 0; j < w; ++j) sacc += P[(w + i) + (int64_t)j * h] * x[f + j];
+        R[i] -= sacc;
+    }
+}
+
+// backward substitution (root level first):  x_s = L11^-T (y_s - L21' x[rows below])
+__global__ __launch_bounds__(256) void sp_bwd_kernel(SpDev d, int level_begin, const double* __restrict__ panels,
+                                                     double* __restrict__ x) {
+    const int s = d.level_sn[level_begin + blockIdx.x];
+    const int tid = threadIdx.x;
+    const int f = d.sn_first[s];
+    const int w = d.sn_first[s + 1] - f;
+    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
+    const double* __restrict__ P = panels + d.panel_off[s];
+    const int* __restrict__ rows = d.sn_rows + d.sn_rowptr[s];
+    // y_j -= sum_{i >= w} L[i][j] x[rows[i]]   (one column per thread, columns are contiguous)
+    for (int j = tid; j < w; j += 256) {
+        double sacc = 0.0;
+        for (int i = w; i < h; ++i) sacc += P[i + (int64_t)j * h] * x[rows[i]];
+        x[f + j] -= sacc;
+    }
+    __syncthreads();
+    for (int j = w - 1; j >= 0; --j) {
+        __shared__ double xj;
+        if (tid == 0) {
+            xj = x[f + j] / P[j + (int64_t)j * h];
+            x[f + j] = xj;
+        }
+        __syncthreads();
+        const double v = xj;
+        for (int i = tid; i < j; i += 256) x[f + i] -= P[j + (int64_t)i * h] * v;
+        __syncthreads();
+    }
+}
+
+__global__ void sp_permute_kernel(const double* __restrict__ in, double* __restrict__ out, const int* __restrict__ map, int n,
+                                  int gather) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (gather) out[i] = in[map[i]];     // out[new] = in[perm[new]]
+    else out[map[i]] = in[i];            // out[perm[new]] = in[new]
+}
+
+// y += G' (w .* z)  and  z_out = w .* (G x) - zs  for CSC G (HBM-bound, tiny)
+__global__ __launch_bounds__(256) void sp_gemv_t_kernel(int n, const int64_t* __restrict__ cp, const int* __restrict__ ri,
+                                                        const double* __restrict__ gv, const double* __restrict__ zss,
+                                                        double* __restrict__ y) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int64_t k = cp[j]; k < cp[j + 1]; ++k) s += gv[k] * zss[ri[k]];
+    y[j] += s;
+}
+__global__ __launch_bounds__(256) void sp_gemv_n_kernel(int m, const int64_t* __restrict__ rp, const int* __restrict__ ci,
+                                                        const int* __restrict__ nzmap, const double* __restrict__ gv,
+                                                        const double* __restrict__ x, const double* __restrict__ w,
+                                                        const double* __restrict__ zs, double* __restrict__ z) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    double s = 0.0;
+    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) s += gv[nzmap[k]] * x[ci[k]];
+    z[r] = w[r] * s - zs[r];
+}
+__global__ void sp_scale2_kernel(const double* __restrict__ w, const double* __restrict__ z, double* __restrict__ zs,
+                                 double* __restrict__ zss, int m) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) {
+        const double t = w[i] * z[i];
+        zs[i] = t;
+        zss[i] = w[i] * t;
+    }
+}
+
+// ---- host-side driver object -----------------------------------------------------------------------------
+template <class T>
+static int up(T** d, const std::vector<T>& h) {
+    KKT_HIP_CHECK(hipMalloc(d, sizeof(T) * (h.size() ? h.size() : 1)));
+    if (!h.empty()) KKT_HIP_CHECK(hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, const int64_t* gri, const double* gv,
+                         const int64_t* hcp, const int64_t* hri, const double* hv) {
+    sparse_engine_free(E);
+    if (int e = symbolic_analyze(E.sym, n, m, gcp, gri, hcp, hri)) return e;
+    SparseSymbolic& S = E.sym;
+    E.n = n;
+    E.m = m;
+    const int64_t gnnz = gcp[n], hnnz = hcp ? hcp[n] : 0;
+    if (int e = up(&E.d_sn_first, S.sn_first)) return e;
+    if (int e = up(&E.d_sn_rowptr, S.sn_rowptr)) return e;
+    if (int e = up(&E.d_sn_rows, S.sn_rows)) return e;
+    if (int e = up(&E.d_panel_off, S.panel_off)) return e;
+    if (int e = up(&E.d_upd_off, S.upd_off)) return e;
+    if (int e = up(&E.d_child_ptr, S.child_ptr)) return e;
+    if (int e = up(&E.d_child_list, S.child_list)) return e;
+    if (int e = up(&E.d_relmap_off, S.relmap_off)) return e;
+    if (int e = up(&E.d_relmap, S.relmap)) return e;
+    if (int e = up(&E.d_level_sn, S.level_sn)) return e;
+    if (int e = up(&E.d_asm_slot, S.asm_slot)) return e;
+    if (int e = up(&E.d_asm_ptr, S.asm_ptr)) return e;
+    if (int e = up(&E.d_asm_a, S.asm_a)) return e;
+    if (int e = up(&E.d_asm_b, S.asm_b)) return e;
+    if (int e = up(&E.d_asm_r, S.asm_r)) return e;
+    if (int e = up(&E.d_perm, S.perm)) return e;
+    {   // G in CSC (values + int rows) and CSR (for G x)
+        std::vector<double> gvals(gv, gv + gnnz), hvals;
+        if (hv) hvals.assign(hv, hv + hnnz);
+        std::vector<int64_t> cpv(gcp, gcp + n + 1);
+        std::vector<int> riv(gnnz);
+        for (int64_t k = 0; k < gnnz; ++k) riv[k] = (int)gri[k];
+        std::vector<int64_t> rp(m + 1, 0);
+        for (int64_t k = 0; k < gnnz; ++k) rp[gri[k] + 1]++;
+        for (int r = 0; r < m; ++r) rp[r + 1] += rp[r];
+        std::vector<int> ci(gnnz), nzmap(gnnz);
+        std::vector<int64_t> pos(rp.begin(), rp.end() - 1);
+        for (int j = 0; j < n; ++j)
+            for (int64_t k = gcp[j]; k < gcp[j + 1]; ++k) {
+                const int64_t p = pos[gri[k]]++;
+                ci[p] = j;
+                nzmap[p] = (int)k;
+            }
+        if (int e = up(&E.d_gv, gvals)) return e;
+        if (int e = up(&E.d_hv, hvals)) return e;
+        if (int e = up(&E.d_gcp, cpv)) return e;
+        if (int e = up(&E.d_gri, riv)) return e;
+        if (int e = up(&E.d_grp, rp)) return e;
+        if (int e = up(&E.d_gci, ci)) return e;
+        if (int e = up(&E.d_gnzmap, nzmap)) return e;
+    }
+    // remainders of the forward substitution: one (h - w) vector per supernode
+    std::vector<int64_t> rem_off(S.ns + 1, 0);
+    for (int s = 0; s < S.ns; ++s)
+        rem_off[s + 1] = rem_off[s] + (S.sn_rowptr[s + 1] - S.sn_rowptr[s]) - (S.sn_first[s + 1] - S.sn_first[s]);
+    if (int e = up(&E.d_rem_off, rem_off)) return e;
+    KKT_HIP_CHECK(hipMalloc(&E.d_rem, sizeof(double) * (rem_off[S.ns] ? rem_off[S.ns] : 1)));
+    KKT_HIP_CHECK(hipMalloc(&E.d_panels, sizeof(double) * (S.panel_off[S.ns] ? S.panel_off[S.ns] : 1)));
+    KKT_HIP_CHECK(hipMalloc(&E.d_upd, sizeof(double) * (S.upd_off[S.ns] ? S.upd_off[S.ns] : 1)));
+    KKT_HIP_CHECK(hipMalloc(&E.d_xp, sizeof(double) * (n ? n : 1)));
+    KKT_HIP_CHECK(hipMalloc(&E.d_info, sizeof(int)));
+    KKT_HIP_CHECK(hipHostMalloc(&E.h_info, sizeof(int)));
+    return 0;
+}
+
+void sparse_engine_free(SparseEngine& E) {
+    void* ptrs[] = {E.d_sn_first, E.d_sn_rowptr, E.d_sn_rows, E.d_panel_off, E.d_upd_off, E.d_child_ptr, E.d_child_list,
+                    E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
+                    E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
+                    E.d_panels, E.d_upd, E.d_xp, E.d_info};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (E.h_info) (void)hipHostFree(E.h_info);
+    E = SparseEngine();
+}
+
+static SpDev devview(const SparseEngine& E) {
+    SpDev d;
+    d.sn_first = E.d_sn_first;
+    d.sn_rowptr = E.d_sn_rowptr;
+    d.sn_rows = E.d_sn_rows;
+    d.panel_off = E.d_panel_off;
+    d.upd_off = E.d_upd_off;
+    d.child_ptr = E.d_child_ptr;
+    d.child_list = E.d_child_list;
+    d.relmap_off = E.d_relmap_off;
+    d.relmap = E.d_relmap;
+    d.level_sn = E.d_level_sn;
+    return d;
+}
+
+// numeric refactorisation with the current scaling di (device pointer); *info as LAPACK potrf (permuted column)
+int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, int* info) {
+    const SparseSymbolic& S = E.sym;
+    if (E.n == 0) { if (info) *info = 0; return 0; }
+    KKT_HIP_CHECK(hipMemsetAsync(E.d_panels, 0, sizeof(double) * (S.panel_off[S.ns] ? S.panel_off[S.ns] : 1), st));
+    const int imax = 0x7fffffff;
+    KKT_HIP_CHECK(hipMemcpyAsync(E.d_info, &imax, sizeof(int), hipMemcpyHostToDevice, st));
+    const int64_t nt = (int64_t)S.asm_slot.size();
+    if (nt > 0)
+        hipLaunchKernelGGL(sp_assemble_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, nt, E.d_asm_slot,
+                           E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r, E.d_gv, E.d_hv, d_di, E.d_panels);
+    const SpDev d = devview(E);
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
+        if (cnt > 0)
+            hipLaunchKernelGGL(sp_front_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_upd,
+                               E.d_info);
+    }
+    KKT_HIP_CHECK(hipGetLastError());
+    KKT_HIP_CHECK(hipMemcpyAsync(E.h_info, E.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipStreamSynchronize(st));
+    if (info) *info = (*E.h_info == imax) ? 0 : *E.h_info;
+    return 0;
+}
+
+// x := S^-1 x  (x: device vector of length n, original ordering)
+int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st) {
+    const SparseSymbolic& S = E.sym;
+    if (E.n == 0) return 0;
+    const SpDev d = devview(E);
+    const dim3 g((E.n + 255) / 256);
+    hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, d_x, E.d_xp, E.d_perm, E.n, 1);
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
+        if (cnt > 0)
+            hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp, E.d_rem,
+                               E.d_rem_off);
+    }
+    for (int l = S.nlevels - 1; l >= 0; --l) {
+        const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
+        if (cnt > 0) hipLaunchKernelGGL(sp_bwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp);
+    }
+    hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, E.d_xp, d_x, E.d_perm, E.n, 0);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// the two sparse products of solve():  zs = w.*z, x += G'(w.*zs)   and   z = w.*(G x) - zs
+int sparse_engine_gemv_t(SparseEngine& E, const double* d_w, const double* d_z, double* d_zs, double* d_zss, double* d_x,
+                         hipStream_t st) {
+    if (E.m > 0) hipLaunchKernelGGL(sp_scale2_kernel, dim3((E.m + 255) / 256), dim3(256), 0, st, d_w, d_z, d_zs, d_zss, E.m);
+    if (E.n > 0 && E.m > 0)
+        hipLaunchKernelGGL(sp_gemv_t_kernel, dim3((E.n + 255) / 256), dim3(256), 0, st, E.n, E.d_gcp, E.d_gri, E.d_gv, d_zss,
+                           d_x);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int sparse_engine_gemv_n(SparseEngine& E, const double* d_w, const double* d_x, const double* d_zs, double* d_z,
+                         hipStream_t st) {
+    if (E.m > 0)
+        hipLaunchKernelGGL(sp_gemv_n_kernel, dim3((E.m + 255) / 256), dim3(256), 0, st, E.m, E.d_grp, E.d_gci, E.d_gnzmap,
+                           E.d_gv, d_x, d_w, d_zs, d_z);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace mi355kkt

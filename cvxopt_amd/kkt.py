@@ -115,11 +115,13 @@ class _Engine(object):
                                            len(self.dims['q']), q, len(self.dims['s']), s), "mi355kkt_create")
         self.h = h
         # constants are copied to HBM once, at factory time
+        self._G_csc = None
+        self._mode = "dense"
         if _is_sparse(G):
-            cp, ri, v = _csc_parts(G)
-            _capi.check(self.L.mi355kkt_set_G_csc(h, cp.ctypes.data_as(_capi.c_i64_p),
-                                                  ri.ctypes.data_as(_capi.c_i64_p),
-                                                  v.ctypes.data_as(_capi.c_double_p)), "set_G_csc")
+            # like the reference (misc.py:1401-1411) the sparse engine is chosen by the TYPES of G and H, which
+            # are only both known at the first factor(W, H) call: keep the CCS parts until then
+            self._G_csc = _csc_parts(G)
+            self._mode = "undecided"
         else:
             g = _dense_view(G, "G")
             _capi.check(self.L.mi355kkt_set_G_dense(h, _ptr(g), max(1, g.shape[0])), "set_G_dense")
@@ -159,7 +161,52 @@ class _Engine(object):
         flat = a.reshape(-1, order='F')
         return (id(H), a.ctypes.data, float(np.sum(np.diagonal(a))), float(np.sum(flat[::step])))
 
+    def _upload_G_csc_dense(self):
+        cp, ri, v = self._G_csc
+        _capi.check(self.L.mi355kkt_set_G_csc(self.h, cp.ctypes.data_as(_capi.c_i64_p), ri.ctypes.data_as(_capi.c_i64_p),
+                                              v.ctypes.data_as(_capi.c_double_p)), "set_G_csc")
+
+    def _decide_mode(self, H):
+        """First factor() with a sparse G: sparse engine iff H is sparse or absent, LP cone only, p = 0
+        (reference: S is an spmatrix exactly when neither G nor H is dense, misc.py:1401-1411)."""
+        sparse_ok = (H is None or _is_sparse(H)) and self.p == 0 and not self.dims['q'] and not self.dims['s'] \
+            and self.kind in (_capi.CHOL2, _capi.CHOL)
+        if sparse_ok:
+            gcp, gri, gv = self._G_csc
+            hp = (None, None, None)
+            if H is not None:
+                hp = _csc_parts(H)
+            as_i64 = lambda a: a.ctypes.data_as(_capi.c_i64_p) if a is not None else None
+            as_f64 = lambda a: a.ctypes.data_as(_capi.c_double_p) if a is not None else None
+            _capi.check(self.L.mi355kkt_set_sparse_problem(self.h, as_i64(gcp), as_i64(gri), as_f64(gv), as_i64(hp[0]),
+                                                           as_i64(hp[1]), as_f64(hp[2])), "set_sparse_problem")
+            self._mode = "sparse"
+            self._H_tag = self._sparse_tag(H)
+        else:
+            self._upload_G_csc_dense()
+            self._mode = "dense"
+
+    @staticmethod
+    def _sparse_tag(H):
+        if H is None:
+            return ("sparse", None, None, None)
+        v = _csc_parts(H)[2]
+        return ("sparse", id(H), float(np.sum(v)), int(v.size))
+
+    def sparse_stats(self):
+        nnzL, ns, nl, fl = C.c_int64(), C.c_int(), C.c_int(), C.c_double()
+        _capi.check(self.L.mi355kkt_sparse_stats(self.h, C.byref(nnzL), C.byref(ns), C.byref(nl), C.byref(fl)), "sparse_stats")
+        return {"nnzL": nnzL.value, "supernodes": ns.value, "levels": nl.value, "flops": fl.value}
+
     def _set_H(self, H):
+        if self._mode == "undecided":
+            self._decide_mode(H)
+        if self._mode == "sparse":
+            if self._sparse_tag(H)[2:] != self._H_tag[2:]:
+                # H changed: rebuild the sparse problem (pattern and values) -- rare (cp/cpl style callers)
+                self._mode = "undecided"
+                self._decide_mode(H)
+            return
         if H is None:
             _capi.check(self.L.mi355kkt_set_H_dense(self.h, None, 1), "set_H_dense")
             self._H_tag = None

@@ -84,6 +84,13 @@ int mi355kkt_set_G_dense(mi355kkt_solver* h, const double* G, int64_t ldG);     
 int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t* rowind,
                        const double* values);                                        /* CCS, cdim x n */
 int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA);         /* p x n     */
+/* Sparse mode (reference misc.py:1405-1462 sparse branch of kkt_chol2 -> cholmod.symbolic/numeric/solve,
+ * src/C/cholmod.c:273-558): G (cdim x n) and H (n x n, lower triangle used; NULL = 0) in CCS.  Runs the symbolic
+ * analysis (ordering, supernodes) once; factor()/solve() then use the supernodal multifrontal device engine.
+ * LP cone, p = 0 only. */
+int mi355kkt_set_sparse_problem(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
+                                const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues);
+int mi355kkt_sparse_stats(const mi355kkt_solver* h, int64_t* nnzL, int* nsupernodes, int* nlevels, double* flops);
 /* device-resident variants: the solver borrows the pointers (no copy); they must outlive the handle */
 int mi355kkt_set_G_device(mi355kkt_solver* h, const double* dG, int64_t ldG);
 int mi355kkt_set_A_device(mi355kkt_solver* h, const double* dA, int64_t ldA);

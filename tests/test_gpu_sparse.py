@@ -1,0 +1,133 @@
+"""Sparse path (BASELINE configs[3] class: sparse coneqp via cvxopt.spmatrix, supernodal HIP Cholesky).
+ssget id 1288 cannot be fetched offline; the stand-in of the same class is a 2-D / 3-D Laplacian P with box
+constraints G = [I; -I].  Parity: the sparse device engine against (i) the dense device engine
+and the dense oracle on the same problem, (ii) the unmodified reference running its own sparse kkt_chol2 branch
+(sp_dgemm / sp_dsyrk assembly + the SciPy-backed cholmod shim)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from cvxopt_amd import kkt, synth
+from oracle import kkt_oracle as ko
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+class FakeSp(object):
+    """minimal stand-in for cvxopt.spmatrix (size + CCS) so the hook can be driven without cvxopt"""
+
+    def __init__(self, A):
+        A = sp.csc_matrix(A)
+        A.sort_indices()
+        self.size = A.shape
+        self.CCS = (A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(float))
+        self._A = A
+
+    def __len__(self):
+        return self._A.nnz
+
+
+def laplace2d(nx, ny, shift=1e-2):
+    ex, ey = np.ones(nx), np.ones(ny)
+    Tx = sp.diags([-ex[:-1], 2 * ex, -ex[:-1]], [-1, 0, 1])
+    Ty = sp.diags([-ey[:-1], 2 * ey, -ey[:-1]], [-1, 0, 1])
+    return (sp.kron(sp.eye(ny), Tx) + sp.kron(Ty, sp.eye(nx)) + shift * sp.eye(nx * ny)).tocsc()
+
+
+def laplace3d(k, shift=1e-2):
+    e = np.ones(k)
+    T = sp.diags([-e[:-1], 2 * e, -e[:-1]], [-1, 0, 1])
+    I = sp.eye(k)
+    return (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T) + shift * sp.eye(k ** 3)).tocsc()
+
+
+def box(n):
+    return sp.vstack([sp.eye(n), -sp.eye(n)]).tocsc()
+
+
+@pytest.mark.parametrize("maker,arg", [(laplace2d, (7, 5)), (laplace2d, (40, 33)), (laplace3d, (9,)), (laplace2d, (150, 120))])
+def test_sparse_factor_solve_matches_dense_oracle(maker, arg):
+    P = maker(*arg)
+    n = P.shape[0]
+    G = box(n)
+    dims = {'l': 2 * n, 'q': [], 's': []}
+    A = np.zeros((0, n))
+    f = kkt.kkt_chol2(FakeSp(G), dims, A)
+    rng = np.random.default_rng(n)
+    for it in range(2):
+        W = synth.random_scaling(dims, seed=it, spread=1.5)
+        bx, bz = rng.standard_normal(n), rng.standard_normal(2 * n)
+        x, y, z = bx.copy(), np.zeros(0), bz.copy()
+        f(W, FakeSp(sp.tril(P)))(x, y, z)
+        assert f.engine._mode == "sparse"
+        if n <= 3000:
+            xo, yo, zo = bx.copy(), np.zeros(0), bz.copy()
+            ko.KktChol2(G.toarray(), dims, A).factor(W, P.toarray())(xo, yo, zo)
+            assert relerr(x, xo) < 1e-9 and relerr(z, zo) < 1e-9
+        # residual of the reduced system (size independent)
+        S = (P + G.T @ sp.diags(W['di'] ** 2) @ G).tocsc()
+        rhs = bx + G.T @ (W['di'] ** 2 * bz)
+        assert np.linalg.norm(S @ x - rhs) / np.linalg.norm(rhs) < 1e-11
+        assert relerr(z, W['di'] * (G @ x) - W['di'] * bz) < 1e-12
+    st = f.engine.sparse_stats()
+    assert st['nnzL'] >= n and st['supernodes'] >= 1
+    f.engine.close()
+
+
+def test_sparse_general_G_pattern_and_dense_engine_agree():
+    """G with off-diagonal couplings (S gets fill from G'D^2G) -- sparse engine vs the dense device engine."""
+    rng = np.random.default_rng(3)
+    n, m = 300, 500
+    G = sp.random(m, n, density=0.01, random_state=4, format='csc') + sp.vstack([sp.eye(n), sp.csc_matrix((m - n, n))])
+    P = laplace2d(20, 15)
+    dims = {'l': m, 'q': [], 's': []}
+    A = np.zeros((0, n))
+    W = synth.random_scaling(dims, seed=1, spread=1.0)
+    bx, bz = rng.standard_normal(n), rng.standard_normal(m)
+    fs = kkt.kkt_chol2(FakeSp(G), dims, A)
+    xs, ys, zs = bx.copy(), np.zeros(0), bz.copy()
+    fs(W, FakeSp(sp.tril(P)))(xs, ys, zs)
+    assert fs.engine._mode == "sparse"
+    fd = kkt.kkt_chol2(np.asfortranarray(G.toarray()), dims, A)
+    xd, yd, zd = bx.copy(), np.zeros(0), bz.copy()
+    fd(W, np.asfortranarray(P.toarray()))(xd, yd, zd)
+    assert relerr(xs, xd) < 1e-9 and relerr(zs, zd) < 1e-9
+    fs.engine.close()
+    fd.engine.close()
+
+
+def test_sparse_not_positive_definite_raises():
+    n = 50
+    P = sp.csc_matrix((n, n))
+    G = sp.vstack([sp.eye(n, format="csr")[:20], -sp.eye(n, format="csr")[:20]]).tocsc()       # only 20 of 50 variables constrained, P = 0
+    dims = {'l': 40, 'q': [], 's': []}
+    f = kkt.kkt_chol2(FakeSp(G), dims, np.zeros((0, n)))
+    with pytest.raises(ArithmeticError):
+        f(synth.random_scaling(dims, seed=0), None)
+    f.engine.close()
+
+
+def test_sparse_coneqp_drop_in_matches_reference_sparse_branch(ref_cvxopt):
+    """The unmodified reference runs its own sparse kkt_chol2 branch (cholmod shim); same iterates expected.
+    Reference probe: 2-D Laplacian box-QP n=400: optimal, 7 iterations, pobj -4.881627878645e+02."""
+    from cvxopt import matrix, spmatrix, solvers, sparse
+    nx = 20
+    P = laplace2d(nx, nx)
+    n = nx * nx
+    Pc = sp.tril(P).tocoo()
+    Pcv = spmatrix(list(Pc.data), list(map(int, Pc.row)), list(map(int, Pc.col)), (n, n))
+    Gc = box(n).tocoo()
+    Gcv = spmatrix(list(Gc.data), list(map(int, Gc.row)), list(map(int, Gc.col)), (2 * n, n))
+    q = matrix(-np.ones(n))
+    h = matrix(np.ones(2 * n))
+    ref = solvers.coneqp(Pcv, q, Gcv, h, kktsolver='chol2')
+    A = spmatrix([], [], [], (0, n))
+    ks = kkt.kktsolver_qp(Gcv, {'l': 2 * n, 'q': [], 's': []}, A, Pcv)
+    got = solvers.coneqp(Pcv, q, Gcv, h, kktsolver=ks)
+    assert ks.engine._mode == "sparse"
+    assert got['status'] == ref['status'] == 'optimal'
+    assert got['iterations'] == ref['iterations']
+    assert abs(got['primal objective'] - ref['primal objective']) <= 1e-9 * abs(ref['primal objective'])
+    assert relerr(np.array(got['x']).ravel(), np.array(ref['x']).ravel()) < 1e-7
+    ks.engine.close()
