@@ -84,6 +84,7 @@ void potrf_work_free(PotrfWork& w);
 // In-place lower Cholesky of the n x n column-major matrix A (only tril referenced/overwritten).
 // Asynchronous on `st`; *w.d_info is updated on device.  Returns 0 or a negative error code.
 int launch_potrf(double* A, int64_t lda, int n, PotrfWork& w, hipStream_t st);
+int launch_potrf_partial(double* F, int64_t ld, int h, int ncols, PotrfWork& w, hipStream_t st);
 // nbatch matrices `bstride` doubles apart; w.d_info / w.d_dinv must hold nbatch ints / nbatch*2048 doubles
 int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st);
 int potrf_work_init_batched(PotrfWork& w, int nbatch);
@@ -113,6 +114,9 @@ struct SparseSymbolic {
     std::vector<int64_t> sn_rowptr;               // ns + 1
     std::vector<int> sn_rows, sn_parent, sn_level, level_ptr, level_sn;
     std::vector<int64_t> panel_off, upd_off, relmap_off;
+    std::vector<int> upd_ld, level_nsmall;
+    std::vector<char> big;
+    int64_t store_doubles = 0;
     std::vector<int> child_ptr, child_list, relmap;
     std::vector<int64_t> asm_slot, asm_ptr;       // numeric assembly: one entry per structural nonzero of S
     std::vector<int> asm_a, asm_b, asm_r;
@@ -122,7 +126,12 @@ struct SparseEngine {
     int n = 0, m = 0;
     int *d_sn_first = nullptr, *d_sn_rows = nullptr, *d_child_ptr = nullptr, *d_child_list = nullptr, *d_relmap = nullptr,
         *d_level_sn = nullptr, *d_asm_a = nullptr, *d_asm_b = nullptr, *d_asm_r = nullptr, *d_perm = nullptr,
-        *d_gri = nullptr, *d_gci = nullptr, *d_gnzmap = nullptr, *d_info = nullptr, *h_info = nullptr;
+        *d_gri = nullptr, *d_gci = nullptr, *d_gnzmap = nullptr, *d_info = nullptr, *h_info = nullptr, *d_upd_ld = nullptr;
+    static constexpr int NSTREAMS = 8;
+    PotrfWork pws[NSTREAMS];
+    hipStream_t streams[NSTREAMS] = {};
+    hipEvent_t ev_done[NSTREAMS] = {};
+    hipEvent_t ev_level = nullptr;
     int64_t *d_sn_rowptr = nullptr, *d_panel_off = nullptr, *d_upd_off = nullptr, *d_relmap_off = nullptr,
             *d_asm_slot = nullptr, *d_asm_ptr = nullptr, *d_gcp = nullptr, *d_grp = nullptr, *d_rem_off = nullptr;
     double *d_gv = nullptr, *d_hv = nullptr, *d_rem = nullptr, *d_panels = nullptr, *d_upd = nullptr, *d_xp = nullptr;

@@ -234,7 +234,7 @@ constexpr int TRSM_ROWS = 64;
 __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restrict__ L,
                                                          const double* __restrict__ linv,
                                                          double* __restrict__ B, int64_t lda, int mrows,
-                                                         const int* __restrict__ info, int64_t bstride) {
+                                                         const int* __restrict__ info, int64_t bstride, int nb) {
     L += (int64_t)blockIdx.z * bstride;
     B += (int64_t)blockIdx.z * bstride;
     linv += (int64_t)blockIdx.z * 2048;
@@ -247,25 +247,31 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restric
     const int row = min(row0 + li, mrows - 1);
     const bool active = row0 + li < mrows;
     d4 x[8];
+    const bool full = (nb == NB);
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
+        if (16 * cb >= nb) break;                    // ragged panels (sparse fronts): fewer 16-column blocks
         d4 acc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = B[row + (int64_t)(16 * cb + lq + 4 * r) * lda];
+        for (int r = 0; r < 4; ++r) {
+            const int col = 16 * cb + lq + 4 * r;
+            acc[r] = (full || col < nb) ? B[row + (int64_t)col * lda] : 0.0;
+        }
 #pragma unroll
         for (int c = 0; c < cb; ++c) {
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                const double av = -L[(16 * cb + li) + (int64_t)(16 * c + 4 * s4 + lq) * lda];
-                acc = MFMA_F64(av, x[c][s4], acc);
+                const double lv = (full || 16 * cb + li < nb) ? L[(16 * cb + li) + (int64_t)(16 * c + 4 * s4 + lq) * lda] : 0.0;
+                acc = MFMA_F64(-lv, x[c][s4], acc);
             }
         }
         double mi[4], ld[4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
             mi[s4] = linv[cb * 256 + (4 * s4 + lq) * 16 + li];                       // Linv_d[li][4s+lq]
-            const double lv = L[(16 * cb + li) + (int64_t)(16 * cb + 4 * s4 + lq) * lda];
-            ld[s4] = (4 * s4 + lq <= li) ? -lv : 0.0;                                // -L_d[li][4s+lq], tril only
+            const bool in = (4 * s4 + lq <= li) && (full || 16 * cb + li < nb);
+            const double lv = in ? L[(16 * cb + li) + (int64_t)(16 * cb + 4 * s4 + lq) * lda] : 0.0;
+            ld[s4] = -lv;                                                            // -L_d[li][4s+lq], tril only
         }
         d4 x0 = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -279,7 +285,10 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restric
         x[cb] = xx;
         if (active) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) B[row + (int64_t)(16 * cb + lq + 4 * r) * lda] = xx[r];
+            for (int r = 0; r < 4; ++r) {
+                const int col = 16 * cb + lq + 4 * r;
+                if (full || col < nb) B[row + (int64_t)col * lda] = xx[r];
+            }
         }
     }
 }
@@ -329,7 +338,7 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
         const int m = n - k0 - nb;
         if (m > 0) {
             hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS, 1, nbatch), dim3(256), 0, st, Akk,
-                               w.d_dinv, Akk + nb, lda, m, w.d_info, bstride);
+                               w.d_dinv, Akk + nb, lda, m, w.d_info, bstride, nb);
             KKT_HIP_CHECK(hipGetLastError());
         }
         return 0;
@@ -403,6 +412,31 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
                                           nb1 + nb2, st, nbatch, bstride))
             return e;
     }
+    return 0;
+}
+
+// Partial factorisation of a frontal matrix: eliminate the first `ncols` columns of the h x h matrix F (lower), leaving
+// the Schur complement in F[ncols:, ncols:].  Same kernels as launch_potrf; *w.d_info is NOT reset here.
+int launch_potrf_partial(double* F, int64_t ld, int h, int ncols, PotrfWork& w, hipStream_t st) {
+    static bool attr_set = false;
+    constexpr size_t lds = sizeof(double) * (NB * PLD + 256 + 16) + 16;
+    if (!attr_set) {
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    for (int k0 = 0; k0 < ncols; k0 += NB) {
+        const int nb = (ncols - k0 < NB) ? (ncols - k0) : NB;
+        double* Fkk = F + k0 + (int64_t)k0 * ld;
+        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), lds, st, Fkk, ld, nb, k0, w.d_info, w.d_dinv, (int64_t)0);
+        const int m = h - k0 - nb;
+        if (m > 0) {
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Fkk, w.d_dinv,
+                               Fkk + nb, ld, m, w.d_info, (int64_t)0, nb);
+            if (int e = launch_syrk_nt_update(Fkk + nb + (int64_t)nb * ld, ld, Fkk + nb, ld, m, nb, st)) return e;
+        }
+    }
+    KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }
 

@@ -292,13 +292,40 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         std::vector<int> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
         for (int s = 0; s < ns; ++s) S.level_sn[pos[S.sn_level[s]]++] = s;
     }
+    // storage: one buffer.  Small front: panel (h x w, ld h) followed by its update matrix (hu x hu, ld hu).
+    // Big front (handled by the dense MFMA kernels): the whole h x h frontal matrix, panel = its first w columns,
+    // update matrix = its trailing block (ld h).
     S.panel_off.assign(ns + 1, 0);
-    S.upd_off.assign(ns + 1, 0);
+    S.upd_off.assign(ns, 0);
+    S.upd_ld.assign(ns, 0);
+    S.big.assign(ns, 0);
+    int64_t off = 0;
     for (int s = 0; s < ns; ++s) {
         const int64_t h = S.sn_rowptr[s + 1] - S.sn_rowptr[s], w = S.sn_first[s + 1] - S.sn_first[s];
-        S.panel_off[s + 1] = S.panel_off[s] + h * w;
-        S.upd_off[s + 1] = S.upd_off[s] + (h - w) * (h - w);
-        S.flops += (double)w * h * h;   // rough
+        const double fl = (double)w * h * h;
+        S.flops += fl;   // rough
+        S.nnzL += h * w;
+        S.panel_off[s] = off;
+        if (fl >= 1.0e6 && h >= 96) {
+            S.big[s] = 1;
+            S.upd_off[s] = off + w + w * h;
+            S.upd_ld[s] = (int)h;
+            off += h * h;
+        } else {
+            S.upd_off[s] = off + h * w;
+            S.upd_ld[s] = (int)(h - w);
+            off += h * w + (h - w) * (h - w);
+        }
+        off = (off + 1) & ~(int64_t)1;   // keep 16-byte alignment of every front
+    }
+    S.panel_off[ns] = off;
+    S.store_doubles = off;
+    // inside a level: small fronts first (one batched launch), big fronts after them (dense kernels, one by one)
+    S.level_nsmall.assign(S.nlevels, 0);
+    for (int l = 0; l < S.nlevels; ++l) {
+        std::stable_partition(S.level_sn.begin() + S.level_ptr[l], S.level_sn.begin() + S.level_ptr[l + 1],
+                              [&](int sn) { return !S.big[sn]; });
+        for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) S.level_nsmall[l] += !S.big[S.level_sn[k]];
     }
     // children lists + extend-add maps: position of each below-row of child c inside the parent's row list
     S.child_ptr.assign(ns + 1, 0);
@@ -391,7 +418,6 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         S.asm_b[k] = cs[k].b;
         S.asm_r[k] = cs[k].r;
     }
-    S.nnzL = S.panel_off[ns];
     return 0;
 }
 
@@ -422,6 +448,7 @@ struct SpDev {   // device copies of the symbolic structure (plain pointers for 
     const int* sn_rows;
     const int64_t* panel_off;
     const int64_t* upd_off;
+    const int* upd_ld;
     const int* child_ptr;
     const int* child_list;
     const int64_t* relmap_off;
@@ -431,15 +458,15 @@ struct SpDev {   // device copies of the symbolic structure (plain pointers for 
 
 // One workgroup = one frontal matrix.  F = [ L-panel (h x w) | U (h-w x h-w) ]: the panel already holds the
 // entries of S; U starts as the extend-add of the children's update matrices.
-__global__ __launch_bounds__(256) void sp_front_kernel(SpDev d, int level_begin, double* __restrict__ panels,
-                                                       double* __restrict__ upd, int* __restrict__ info) {
+__global__ __launch_bounds__(256) void sp_front_kernel(SpDev d, int level_begin, double* panels, double* upd,
+                                                       int* __restrict__ info) {
     const int s = d.level_sn[level_begin + blockIdx.x];
     const int tid = threadIdx.x;
     const int w = d.sn_first[s + 1] - d.sn_first[s];
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
     const int hu = h - w;
     double* __restrict__ P = panels + d.panel_off[s];   // h x w, column-major
-    double* __restrict__ U = upd + d.upd_off[s];        // hu x hu, column-major (lower part used)
+    double* __restrict__ U = upd + d.upd_off[s];        // hu x hu (ld = hu for these small fronts), lower part used
     __shared__ double piv;
     __shared__ int bad;
     if (tid == 0) bad = 0;
@@ -451,12 +478,13 @@ __global__ __launch_bounds__(256) void sp_front_kernel(SpDev d, int level_begin,
         const int wc = d.sn_first[c + 1] - d.sn_first[c];
         const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - wc;
         const double* __restrict__ Uc = upd + d.upd_off[c];
+        const int ldc = d.upd_ld[c];
         const int* __restrict__ rm = d.relmap + d.relmap_off[c];
         for (int64_t e = tid; e < (int64_t)hc * hc; e += 256) {
             const int i = (int)(e % hc), j = (int)(e / hc);
             if (i < j) continue;
             const int pi = rm[i], pj = rm[j];            // positions in this front; pi >= pj (row lists are sorted)
-            const double v = Uc[i + (int64_t)j * hc];
+            const double v = Uc[i + (int64_t)j * ldc];
             if (pj < w) P[pi + (int64_t)pj * h] += v;
             else U[(pi - w) + (int64_t)(pj - w) * hu] += v;
         }
@@ -504,6 +532,27 @@ __global__ __launch_bounds__(256) void sp_front_kernel(SpDev d, int level_begin,
         __syncthreads();
     }
     if (tid == 0 && bad) atomicMin(info, bad);      // smallest failing column (info starts at INT_MAX)
+}
+
+// extend-add of ONE child's update matrix into a big parent front (F is h x h, ld h); launched child by child
+__global__ __launch_bounds__(256) void sp_extend_add_kernel(SpDev d, int s, int c, double* store) {
+    const int w = d.sn_first[s + 1] - d.sn_first[s];
+    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
+    const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
+    double* __restrict__ F = store + d.panel_off[s];
+    const double* __restrict__ Uc = store + d.upd_off[c];
+    const int ldc = d.upd_ld[c];
+    const int* __restrict__ rm = d.relmap + d.relmap_off[c];
+    (void)w;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)hc * hc; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e % hc), j = (int)(e / hc);
+        if (i < j) continue;
+        F[rm[i] + (int64_t)rm[j] * h] += Uc[i + (int64_t)j * ldc];
+    }
+}
+
+__global__ void sp_merge_info_kernel(const int* __restrict__ local, int offset, int* __restrict__ global) {
+    if (*local > 0) atomicMin(global, offset + *local);
 }
 
 // forward substitution, one workgroup per supernode of a level:  y_s = L11^-1 (b_s + children updates),
@@ -642,6 +691,7 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     if (int e = up(&E.d_sn_rows, S.sn_rows)) return e;
     if (int e = up(&E.d_panel_off, S.panel_off)) return e;
     if (int e = up(&E.d_upd_off, S.upd_off)) return e;
+    if (int e = up(&E.d_upd_ld, S.upd_ld)) return e;
     if (int e = up(&E.d_child_ptr, S.child_ptr)) return e;
     if (int e = up(&E.d_child_list, S.child_list)) return e;
     if (int e = up(&E.d_relmap_off, S.relmap_off)) return e;
@@ -684,8 +734,14 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
         rem_off[s + 1] = rem_off[s] + (S.sn_rowptr[s + 1] - S.sn_rowptr[s]) - (S.sn_first[s + 1] - S.sn_first[s]);
     if (int e = up(&E.d_rem_off, rem_off)) return e;
     KKT_HIP_CHECK(hipMalloc(&E.d_rem, sizeof(double) * (rem_off[S.ns] ? rem_off[S.ns] : 1)));
-    KKT_HIP_CHECK(hipMalloc(&E.d_panels, sizeof(double) * (S.panel_off[S.ns] ? S.panel_off[S.ns] : 1)));
-    KKT_HIP_CHECK(hipMalloc(&E.d_upd, sizeof(double) * (S.upd_off[S.ns] ? S.upd_off[S.ns] : 1)));
+    KKT_HIP_CHECK(hipMalloc(&E.d_panels, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
+    E.d_upd = nullptr;          // update matrices live in the same buffer (offsets are absolute)
+    for (int k = 0; k < SparseEngine::NSTREAMS; ++k) {
+        if (int e = potrf_work_init(E.pws[k])) return e;
+        KKT_HIP_CHECK(hipStreamCreateWithFlags(&E.streams[k], hipStreamNonBlocking));
+        KKT_HIP_CHECK(hipEventCreateWithFlags(&E.ev_done[k], hipEventDisableTiming));
+    }
+    KKT_HIP_CHECK(hipEventCreateWithFlags(&E.ev_level, hipEventDisableTiming));
     KKT_HIP_CHECK(hipMalloc(&E.d_xp, sizeof(double) * (n ? n : 1)));
     KKT_HIP_CHECK(hipMalloc(&E.d_info, sizeof(int)));
     KKT_HIP_CHECK(hipHostMalloc(&E.h_info, sizeof(int)));
@@ -694,12 +750,18 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
 
 void sparse_engine_free(SparseEngine& E) {
     void* ptrs[] = {E.d_sn_first, E.d_sn_rowptr, E.d_sn_rows, E.d_panel_off, E.d_upd_off, E.d_child_ptr, E.d_child_list,
-                    E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
+                    E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
                     E.d_panels, E.d_upd, E.d_xp, E.d_info};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
+    for (int k = 0; k < SparseEngine::NSTREAMS; ++k) {
+        potrf_work_free(E.pws[k]);
+        if (E.streams[k]) (void)hipStreamDestroy(E.streams[k]);
+        if (E.ev_done[k]) (void)hipEventDestroy(E.ev_done[k]);
+    }
+    if (E.ev_level) (void)hipEventDestroy(E.ev_level);
     E = SparseEngine();
 }
 
@@ -710,6 +772,7 @@ static SpDev devview(const SparseEngine& E) {
     d.sn_rows = E.d_sn_rows;
     d.panel_off = E.d_panel_off;
     d.upd_off = E.d_upd_off;
+    d.upd_ld = E.d_upd_ld;
     d.child_ptr = E.d_child_ptr;
     d.child_list = E.d_child_list;
     d.relmap_off = E.d_relmap_off;
@@ -722,7 +785,7 @@ static SpDev devview(const SparseEngine& E) {
 int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, int* info) {
     const SparseSymbolic& S = E.sym;
     if (E.n == 0) { if (info) *info = 0; return 0; }
-    KKT_HIP_CHECK(hipMemsetAsync(E.d_panels, 0, sizeof(double) * (S.panel_off[S.ns] ? S.panel_off[S.ns] : 1), st));
+    KKT_HIP_CHECK(hipMemsetAsync(E.d_panels, 0, sizeof(double) * (S.store_doubles ? S.store_doubles : 1), st));
     const int imax = 0x7fffffff;
     KKT_HIP_CHECK(hipMemcpyAsync(E.d_info, &imax, sizeof(int), hipMemcpyHostToDevice, st));
     const int64_t nt = (int64_t)S.asm_slot.size();
@@ -731,10 +794,38 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
                            E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r, E.d_gv, E.d_hv, d_di, E.d_panels);
     const SpDev d = devview(E);
     for (int l = 0; l < S.nlevels; ++l) {
-        const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
-        if (cnt > 0)
-            hipLaunchKernelGGL(sp_front_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_upd,
+        const int nsmall = S.level_nsmall[l];
+        if (nsmall > 0)
+            hipLaunchKernelGGL(sp_front_kernel, dim3(nsmall), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_panels,
                                E.d_info);
+        const int nbig = S.level_ptr[l + 1] - S.level_ptr[l] - nsmall;
+        if (nbig > 0) {
+            // big fronts of one level are independent: spread them over a few streams (each with its own potrf
+            // workspace); they start after everything issued so far and the level ends when all of them are done
+            KKT_HIP_CHECK(hipEventRecord(E.ev_level, st));
+            const int nuse = std::min(nbig, (int)SparseEngine::NSTREAMS);
+            for (int q = 0; q < nuse; ++q) KKT_HIP_CHECK(hipStreamWaitEvent(E.streams[q], E.ev_level, 0));
+            for (int k = S.level_ptr[l] + nsmall, q = 0; k < S.level_ptr[l + 1]; ++k, q = (q + 1) % nuse) {
+                hipStream_t sq = E.streams[q];
+                const int sn = S.level_sn[k];
+                const int w = S.sn_first[sn + 1] - S.sn_first[sn];
+                const int h = (int)(S.sn_rowptr[sn + 1] - S.sn_rowptr[sn]);
+                for (int ci = S.child_ptr[sn]; ci < S.child_ptr[sn + 1]; ++ci) {   // child by child: deterministic
+                    const int c = S.child_list[ci];
+                    const int64_t hc = (S.sn_rowptr[c + 1] - S.sn_rowptr[c]) - (S.sn_first[c + 1] - S.sn_first[c]);
+                    if (hc <= 0) continue;
+                    const int64_t blocks = std::min<int64_t>((hc * hc + 255) / 256, 4096);
+                    hipLaunchKernelGGL(sp_extend_add_kernel, dim3((unsigned)blocks), dim3(256), 0, sq, d, sn, c, E.d_panels);
+                }
+                KKT_HIP_CHECK(hipMemsetAsync(E.pws[q].d_info, 0, sizeof(int), sq));
+                if (int e = launch_potrf_partial(E.d_panels + S.panel_off[sn], h, h, w, E.pws[q], sq)) return e;
+                hipLaunchKernelGGL(sp_merge_info_kernel, dim3(1), dim3(1), 0, sq, E.pws[q].d_info, S.sn_first[sn], E.d_info);
+            }
+            for (int q = 0; q < nuse; ++q) {
+                KKT_HIP_CHECK(hipEventRecord(E.ev_done[q], E.streams[q]));
+                KKT_HIP_CHECK(hipStreamWaitEvent(st, E.ev_done[q], 0));
+            }
+        }
     }
     KKT_HIP_CHECK(hipGetLastError());
     KKT_HIP_CHECK(hipMemcpyAsync(E.h_info, E.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
