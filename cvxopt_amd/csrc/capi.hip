@@ -823,6 +823,18 @@ int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const d
     return t.finish();
 }
 
+/* host-only: the symbolic analysis of the sparse engine (ordering + supernodes) for the pattern of H + G'G */
+int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
+                         const int64_t* hrowind, int* perm, int64_t* nnzL, int* nsupernodes, int* nlevels) {
+    SparseSymbolic S;
+    if (int e = symbolic_analyze(S, n, m, gcolptr, growind, hcolptr, hrowind)) return e;
+    if (perm) for (int k = 0; k < n; ++k) perm[k] = S.perm[k];
+    if (nnzL) *nnzL = S.nnzL;
+    if (nsupernodes) *nsupernodes = S.ns;
+    if (nlevels) *nlevels = S.nlevels;
+    return 0;
+}
+
 int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
                            const double* dv, const double* dbeta, float* ms) {
     ConeLayout cl;

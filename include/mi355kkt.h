@@ -146,6 +146,9 @@ float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b);
 /* S(lower) = H(lower) + G' diag(di)^2 G ;  di or H may be NULL */
 int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
                             int64_t ldH, double* dS, int64_t ldS, float* ms);
+/* host-only: symbolic analysis of the sparse engine (nested-dissection ordering perm[new] = old, supernodal nnz(L)) */
+int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
+                         const int64_t* hrowind, int* perm, int64_t* nnzL, int* nsupernodes, int* nlevels);
 /* X(:, 0:ncols) := W^-T X on the 'l' and 'q' rows, in place (misc_solvers.scale, trans='T', inverse='I') */
 int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
                            const double* dv, const double* dbeta, float* ms);
