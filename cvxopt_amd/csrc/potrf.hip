@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
 //   diagonal block by inverse + one step of fixed-precision iterative refinement (backward stable,
 //   Skeel 1980):  X0 = R Linv';  E = R - X0 Ld';  X = X0 + E Linv'                (12 MFMAs)
 constexpr int TRSM_ROWS = 64;
+template <bool full>     // full: nb == 128 (every panel of a dense potrf); ragged panels only occur in sparse fronts
 __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restrict__ L,
                                                          const double* __restrict__ linv,
                                                          double* __restrict__ B, int64_t lda, int mrows,
@@ -247,10 +248,9 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restric
     const int row = min(row0 + li, mrows - 1);
     const bool active = row0 + li < mrows;
     d4 x[8];
-    const bool full = (nb == NB);
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
-        if (16 * cb >= nb) break;                    // ragged panels (sparse fronts): fewer 16-column blocks
+        if (!full && 16 * cb >= nb) break;           // ragged panels (sparse fronts): fewer 16-column blocks
         d4 acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -337,8 +337,12 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
         KKT_HIP_CHECK(hipGetLastError());
         const int m = n - k0 - nb;
         if (m > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS, 1, nbatch), dim3(256), 0, st, Akk,
-                               w.d_dinv, Akk + nb, lda, m, w.d_info, bstride, nb);
+            if (nb == NB)
+                hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS, 1, nbatch), dim3(256), 0, st,
+                                   Akk, w.d_dinv, Akk + nb, lda, m, w.d_info, bstride, nb);
+            else
+                hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS, 1, nbatch), dim3(256), 0, st,
+                                   Akk, w.d_dinv, Akk + nb, lda, m, w.d_info, bstride, nb);
             KKT_HIP_CHECK(hipGetLastError());
         }
         return 0;
@@ -431,8 +435,12 @@ int launch_potrf_partial(double* F, int64_t ld, int h, int ncols, PotrfWork& w, 
         hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), lds, st, Fkk, ld, nb, k0, w.d_info, w.d_dinv, (int64_t)0);
         const int m = h - k0 - nb;
         if (m > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Fkk, w.d_dinv,
-                               Fkk + nb, ld, m, w.d_info, (int64_t)0, nb);
+            if (nb == NB)
+                hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Fkk,
+                                   w.d_dinv, Fkk + nb, ld, m, w.d_info, (int64_t)0, nb);
+            else
+                hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Fkk,
+                                   w.d_dinv, Fkk + nb, ld, m, w.d_info, (int64_t)0, nb);
             if (int e = launch_syrk_nt_update(Fkk + nb + (int64_t)nb * ld, ld, Fkk + nb, ld, m, nb, st)) return e;
         }
     }
