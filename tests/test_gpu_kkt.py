@@ -286,3 +286,63 @@ def test_conelp_socp_drop_in(ref_cvxopt, name):
         assert abs(sol['primal objective'] - float(g['pobj'])) <= 1e-8 * max(1.0, abs(float(g['pobj'])))
         assert relerr(np.array(sol['x']).ravel(), g['x']) < 1e-6
         ks.engine.close()
+
+
+# ---- edge cases of the boundary ----------------------------------------------------------------------
+def test_no_inequalities_and_tiny_problems():
+    """cdim = 0 (G is 0 x n): the KKT system is [H A'; A 0]; also n = 1."""
+    rng = np.random.default_rng(1)
+    for n, p in [(6, 2), (1, 0), (130, 5)]:
+        B = rng.standard_normal((n, n))
+        H = np.asfortranarray(B @ B.T + np.eye(n))
+        A = np.asfortranarray(rng.standard_normal((p, n)))
+        G = np.zeros((0, n), order='F')
+        dims = {'l': 0, 'q': [], 's': []}
+        W = {'d': np.zeros(0), 'di': np.zeros(0), 'v': [], 'beta': [], 'r': [], 'rti': []}
+        f = kkt.kkt_chol2(G, dims, A)
+        bx, by = rng.standard_normal(n), rng.standard_normal(p)
+        x, y, z = bx.copy(), by.copy(), np.zeros(0)
+        f(W, H)(x, y, z)
+        K = np.block([[H, A.T], [A, np.zeros((p, p))]])
+        ref = np.linalg.solve(K, np.concatenate([bx, by]))
+        assert relerr(x, ref[:n]) < 1e-10 and relerr(y, ref[n:]) < 1e-9
+        f.engine.close()
+
+
+def test_non_contiguous_and_wrong_dtype_inputs_are_rejected_or_copied():
+    n, m = 20, 30
+    pr = synth.dense_qp(n, m, seed=0)
+    Gc = np.ascontiguousarray(pr['G'])                   # C-ordered: must be accepted (copied to column-major)
+    f = kkt.kkt_chol2(Gc, pr['dims'], np.zeros((0, n)))
+    W = synth.random_scaling(pr['dims'], seed=0)
+    x, y, z = np.ones(n), np.zeros(0), np.ones(m)
+    f(W, pr['P'])(x, y, z)
+    xo, yo, zo = np.ones(n), np.zeros(0), np.ones(m)
+    ko.KktChol2(pr['G'], pr['dims'], np.zeros((0, n))).factor(W, pr['P'])(xo, yo, zo)
+    assert relerr(x, xo) < 1e-9
+    with pytest.raises(TypeError):
+        f(W, pr['P'])(np.ones(n, dtype=np.float32), y, z)
+    with pytest.raises(ValueError):
+        f(W, pr['P'])(np.ones(n + 1), y, z)
+    with pytest.raises(TypeError):
+        kkt.kkt_chol2(pr['G'][:, :-1], pr['dims'], np.zeros((0, n)))
+    f.engine.close()
+
+
+def test_w_is_reread_on_every_factor_call():
+    """misc.update_scaling mutates W in place (misc.py:450-464): the hook must never cache W by identity."""
+    n, m = 40, 90
+    pr = synth.dense_qp(n, m, seed=3)
+    W = synth.random_scaling(pr['dims'], seed=1)
+    f = kkt.kkt_chol2(pr['G'], pr['dims'], np.zeros((0, n)))
+    rng = np.random.default_rng(0)
+    for it in range(3):
+        W['d'] *= rng.uniform(0.5, 2.0, m)               # same dict, same arrays, new values
+        W['di'][:] = 1.0 / W['d']
+        bx, bz = rng.standard_normal(n), rng.standard_normal(m)
+        x, y, z = bx.copy(), np.zeros(0), bz.copy()
+        f(W, pr['P'])(x, y, z)
+        xo, yo, zo = bx.copy(), np.zeros(0), bz.copy()
+        ko.KktChol2(pr['G'], pr['dims'], np.zeros((0, n))).factor(W, pr['P'])(xo, yo, zo)
+        assert relerr(x, xo) < 1e-9 and relerr(z, zo) < 1e-9
+    f.engine.close()
