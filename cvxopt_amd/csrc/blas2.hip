@@ -347,6 +347,179 @@ __global__ __launch_bounds__(64) void trsv_diag_bwd_kernel(const double* __restr
     if (lane < n0) x[lane] = b0;
 }
 
+// ===================================================================================================
+// Persistent single-launch triangular solve (one right-hand side): workgroup k owns block row k (forward)
+// or block column k (backward) of the 128-blocked factor, streams its off-diagonal blocks while it waits
+// for the x blocks it depends on, solves its diagonal block inside the workgroup and publishes x_k.
+// Inter-workgroup hand-off follows the guide's placement-independent recipe (cdna_hip_programming.md G16):
+// producer: plain stores -> __syncthreads -> one lane: agent-scope release fence, s_waitcnt vmcnt(0), relaxed
+// agent-scope flag store; consumer: one lane polls the flag relaxed (bounded, s_sleep) -> agent-scope acquire
+// fence -> __syncthreads -> plain loads.  All nblk <= #CUs workgroups are co-resident (128 threads, no LDS
+// pressure); every spin is bounded and a timeout sets *err instead of hanging the GPU.
+// ===================================================================================================
+typedef unsigned int u32;
+#define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ bool wait_flag(const u32* flag, u32 epoch, int* err) {
+    // called by ONE lane; returns false on timeout
+    for (unsigned spins = 0; spins < (1u << 24); ++spins) {
+        if (__hip_atomic_load(flag, RLX_AGENT) == epoch) return true;
+        __builtin_amdgcn_s_sleep(2);
+    }
+    atomicExch(err, 1);
+    return false;
+}
+
+__device__ __forceinline__ void publish_flag(u32* flag, u32 epoch) {
+    // called by ONE lane after a __syncthreads() that follows the payload stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(flag, epoch, RLX_AGENT);
+}
+
+template <bool TRANS>
+__global__ __launch_bounds__(128) void trsv_persistent_kernel(const double* __restrict__ L, int64_t ldl, int n,
+                                                              double* x, u32* flags, u32 epoch, int* err) {
+    __shared__ double xs[TB];
+    __shared__ int ok;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = (n + TB - 1) / TB;
+    const int k = TRANS ? (nblk - 1 - (int)blockIdx.x) : (int)blockIdx.x;   // dispatch order ~ dependency order
+    const int k0 = k * TB;
+    const int nb = min(TB, n - k0);
+    const int idx = k0 + tid;                         // my row (forward) / my column (backward)
+    const bool mine = tid < nb;
+    double acc = mine ? x[idx] : 0.0;
+    // ---- diagonal block operands: issue their loads now (independent of everything), use them at the end
+    const double* Lkk = L + k0 + (int64_t)k0 * ldl;
+    const int n0 = min(nb, 64), n1 = nb - n0;
+    double ra[64], rb[64];
+    if (!TRANS) {
+        if (wave == 0) {   // rows 0..63: row of L11
+#pragma unroll
+            for (int j = 0; j < 64; ++j) ra[j] = (j < lane && lane < n0) ? Lkk[lane + (int64_t)j * ldl] : 0.0;
+        } else {           // rows 64..127: row of L21 (ra) and of L22 (rb)
+#pragma unroll
+            for (int j = 0; j < 64; ++j) ra[j] = (lane < n1) ? Lkk[64 + lane + (int64_t)j * ldl] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) rb[j] = (j < lane && lane < n1) ? Lkk[64 + lane + (int64_t)(64 + j) * ldl] : 0.0;
+        }
+    } else {
+        if (wave == 1) {   // columns 64..127: column of L22 (solved first)
+#pragma unroll
+            for (int j = 0; j < 64; ++j) ra[j] = (j > lane && j < n1) ? Lkk[64 + j + (int64_t)(64 + lane) * ldl] : 0.0;
+        } else {           // columns 0..63: column of L21 (ra) and of L11 (rb)
+#pragma unroll
+            for (int j = 0; j < 64; ++j) ra[j] = (j < n1 && lane < n0) ? Lkk[64 + j + (int64_t)lane * ldl] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) rb[j] = (j > lane && j < n0) ? Lkk[j + (int64_t)lane * ldl] : 0.0;
+        }
+    }
+    const int dpos = (wave == 0) ? lane : 64 + lane;
+    const double dg = (dpos < nb) ? Lkk[dpos + (int64_t)dpos * ldl] : 1.0;
+    // ---- off-diagonal blocks, in dependency order
+    const int nsteps = TRANS ? (nblk - 1 - k) : k;
+    for (int s = 0; s < nsteps; ++s) {
+        const int j = TRANS ? (nblk - 1 - s) : s;      // block whose solution we consume
+        const int j0 = j * TB;
+        const int jb = min(TB, n - j0);
+        // prefetch the first half of my strip of block (k,j) before waiting
+        double l0[64];
+        if (!TRANS) {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) l0[c] = (mine && c < jb) ? L[idx + (int64_t)(j0 + c) * ldl] : 0.0;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) l0[c] = (mine && c < jb) ? L[j0 + c + (int64_t)idx * ldl] : 0.0;
+        }
+        if (tid == 0) ok = wait_flag(flags + j, epoch, err) ? 1 : 0;
+        __syncthreads();
+        if (!ok) return;                                // timeout: give up (err is set)
+        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __syncthreads();
+        xs[tid] = (tid < jb) ? x[j0 + tid] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 64; ++c) acc = fma(-l0[c], xs[c], acc);
+        if (jb > 64) {
+            if (!TRANS) {
+#pragma unroll 16
+                for (int c = 64; c < TB; ++c) {
+                    const double l = (mine && c < jb) ? L[idx + (int64_t)(j0 + c) * ldl] : 0.0;
+                    acc = fma(-l, xs[c], acc);
+                }
+            } else {
+#pragma unroll 16
+                for (int c = 64; c < TB; ++c) {
+                    const double l = (mine && c < jb) ? L[j0 + c + (int64_t)idx * ldl] : 0.0;
+                    acc = fma(-l, xs[c], acc);
+                }
+            }
+        }
+        __syncthreads();                               // xs is reused by the next step
+    }
+    // ---- diagonal block: two 64-wide halves, the first half's solution goes through LDS to the second
+    const double dinv = 1.0 / dg;
+    if (!TRANS) {
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const double xj = bcast(acc * dinv, j);
+                if (lane == j) acc = xj;
+                acc = fma(-ra[j], xj, acc);
+            }
+            xs[lane] = acc;
+        }
+        __syncthreads();
+        if (wave == 1 && n1 > 0) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) acc = fma(-ra[j], xs[j], acc);
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                const double xj = bcast(acc * dinv, j);
+                if (lane == j) acc = xj;
+                acc = fma(-rb[j], xj, acc);
+            }
+        }
+    } else {
+        if (wave == 1 && n1 > 0) {
+#pragma unroll
+            for (int j = 63; j >= 0; --j) {
+                const double xj = bcast(acc * dinv, j);
+                if (lane == j) acc = xj;
+                acc = fma(-ra[j], xj, acc);
+            }
+        }
+        if (wave == 1) xs[lane] = (n1 > 0) ? acc : 0.0;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < 64; ++j) acc = fma(-ra[j], xs[j], acc);
+#pragma unroll
+            for (int j = 63; j >= 0; --j) {
+                const double xj = bcast(acc * dinv, j);
+                if (lane == j) acc = xj;
+                acc = fma(-rb[j], xj, acc);
+            }
+        }
+    }
+    if (mine) x[idx] = acc;
+    __syncthreads();
+    if (tid == 0) publish_flag(flags + k, epoch);
+}
+
+int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
+                           unsigned int epoch, int* err, hipStream_t st) {
+    const int nblk = (n + TB - 1) / TB;
+    if (nblk <= 0) return 0;
+    if (trans)
+        hipLaunchKernelGGL(trsv_persistent_kernel<true>, dim3(nblk), dim3(128), 0, st, L, ldl, n, x, flags, epoch, err);
+    else
+        hipLaunchKernelGGL(trsv_persistent_kernel<false>, dim3(nblk), dim3(128), 0, st, L, ldl, n, x, flags, epoch, err);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs, int trans,
                       hipStream_t st, int nbatch, int64_t sL, int64_t sX) {
     if (n <= 0 || nrhs <= 0) return 0;

@@ -88,6 +88,11 @@ struct mi355kkt_solver {
     double* dV = nullptr;      // concatenated v_k
     double* dBeta = nullptr;   // beta_k
     double* dWst = nullptr;    // staging for host-side W (di | v | beta)
+    // persistent triangular solves: hand-off flags (one word per 128-block), launch epoch, timeout word
+    unsigned int* dflags = nullptr;
+    unsigned int epoch = 0;
+    int* derr = nullptr;
+    int* herr = nullptr;   // pinned
     // sparse mode (config 4): S is factored by the supernodal multifrontal engine instead of the dense one
     bool sparse = false;
     SparseEngine sp;
@@ -221,6 +226,15 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     if ((rc = alloc(&h->dtp, P))) return fail(rc);
     if ((rc = alloc(&h->dwork, C + 8))) return fail(rc);   // grown to the dense GEMV workspace on first dense use
     if ((rc = alloc(&h->dWst, C + (size_t)nq + 8))) return fail(rc);
+    {
+        const size_t nfl = N / 128 + 2;
+        if (hipMalloc(&h->dflags, sizeof(unsigned int) * nfl) != hipSuccess) return fail(MI355KKT_ENOMEM);
+        if (hipMemset(h->dflags, 0, sizeof(unsigned int) * nfl) != hipSuccess) return fail(MI355KKT_EHIP);
+        if (hipMalloc(&h->derr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
+        if (hipMemset(h->derr, 0, sizeof(int)) != hipSuccess) return fail(MI355KKT_EHIP);
+        if (hipHostMalloc(&h->herr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
+        *h->herr = 0;
+    }
     if (nq > 0) {
         if ((rc = alloc(&h->dGs, C * N))) return fail(rc);
         if ((rc = alloc(&h->dV, C))) return fail(rc);
@@ -246,6 +260,9 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
                       h->dx, h->dy, h->dz, h->dzs, h->dtn, h->dtp, h->dwork, h->dWst, h->dGs, h->dV, h->dBeta};
     cone_layout_free(h->cl);
     sparse_engine_free(h->sp);
+    if (h->dflags) (void)hipFree(h->dflags);
+    if (h->derr) (void)hipFree(h->derr);
+    if (h->herr) (void)hipHostFree(h->herr);
     for (double* b : bufs)
         if (b) (void)hipFree(b);
     if (h->hbuf) (void)hipHostFree(h->hbuf);
@@ -534,7 +551,13 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
         return e;
     if (h->singular && p > 0)                                       // x += A' by  (:1527)
         if (int e = launch_gemv_t_scaled(h->dA, h->ldA, p, n, nullptr, dy, h->dtp, dx, nullptr, st)) return e;
-    if (int e = launch_trsm_lower(h->dS, n, n, dx, n, 1, 0, st)) return e;          // :1529
+    // triangular solves with L: one persistent launch each when every 128-block can own a resident workgroup
+    const bool persistent = (n + 127) / 128 <= h->num_cus && !getenv("MI355KKT_NO_PERSISTENT_TRSV");
+    auto tri_solve = [&](int trans) -> int {
+        if (persistent) return launch_trsv_persistent(h->dS, n, n, dx, trans, h->dflags, ++h->epoch, h->derr, st);
+        return launch_trsm_lower(h->dS, n, n, dx, n, 1, trans, st);
+    };
+    if (int e = tri_solve(0)) return e;                                             // :1529
     if (p > 0) {
         // y := K^-1 (Asct' x - y)                                     (:1541-1543)
         hipLaunchKernelGGL(scal_kernel, g1(p), dim3(256), 0, st, dy, p, -1.0);
@@ -544,17 +567,28 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
         // x := x - Asct y                                             (:1553)
         if (int e = launch_gemv_n_scaled(h->dAsct, n, n, p, nullptr, dy, dx, dx, -1.0, 1.0, h->dwork, st)) return e;
     }
-    if (int e = launch_trsm_lower(h->dS, n, n, dx, n, 1, 1, st)) return e;          // :1555
+    if (int e = tri_solve(1)) return e;                                             // :1555
     // z := Gs x - zs   (/ sqrt(1+reg) when the z-block pivot is -(1+reg))       (:1563)
     if (int e = launch_gemv_n_scaled(Gmat, ldGm, m, n, wvec, dx, h->dzs, dz, zscale, -zscale, h->dwork, st)) return e;
     KKT_HIP_CHECK(hipEventRecord(h->ev[5], st));
     return 0;
 }
 
+static int check_handoff(mi355kkt_solver* h) {   // stream must be idle
+    if (*h->herr) {
+        *h->herr = 0;
+        (void)hipMemset(h->derr, 0, sizeof(int));
+        set_last_error("persistent triangular solve: hand-off timeout (a workgroup was not co-resident?)");
+        return MI355KKT_EHIP;
+    }
+    return 0;
+}
+
 int mi355kkt_sync(mi355kkt_solver* h) {
     if (!h) return MI355KKT_EINVAL;
+    KKT_HIP_CHECK(hipMemcpyAsync(h->herr, h->derr, sizeof(int), hipMemcpyDeviceToHost, h->st));
     KKT_HIP_CHECK(hipStreamSynchronize(h->st));
-    return 0;
+    return check_handoff(h);
 }
 
 int mi355kkt_solve(mi355kkt_solver* h, double* x, double* y, double* z) {
@@ -574,7 +608,9 @@ int mi355kkt_solve(mi355kkt_solver* h, double* x, double* y, double* z) {
     if (n) KKT_HIP_CHECK(hipMemcpyAsync(hb, h->dx, sizeof(double) * n, hipMemcpyDeviceToHost, h->st));
     if (p) KKT_HIP_CHECK(hipMemcpyAsync(hb + n, h->dy, sizeof(double) * p, hipMemcpyDeviceToHost, h->st));
     if (m) KKT_HIP_CHECK(hipMemcpyAsync(hb + n + p, h->dz, sizeof(double) * m, hipMemcpyDeviceToHost, h->st));
+    KKT_HIP_CHECK(hipMemcpyAsync(h->herr, h->derr, sizeof(int), hipMemcpyDeviceToHost, h->st));
     KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+    if (int e = check_handoff(h)) return e;
     if (n) memcpy(x, hb, sizeof(double) * n);
     if (p) memcpy(y, hb + n, sizeof(double) * p);
     if (m) memcpy(z, hb + n + p, sizeof(double) * m);

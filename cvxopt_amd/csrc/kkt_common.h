@@ -99,6 +99,10 @@ int launch_gemv_n_scaled(const double* G, int64_t ldg, int m, int n, const doubl
                          const double* x, const double* zs, double* z, double alpha, double beta,
                          double* work, hipStream_t st, int nbatch = 1, int64_t sG = 0);
 size_t gemv_work_doubles(int m, int n);
+// single right-hand side, single launch (needs ceil(n/128) co-resident workgroups: callers check against #CUs);
+// flags: ceil(n/128) words zeroed once at allocation, epoch: a fresh non-zero value per launch, err: device int
+int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
+                           unsigned int epoch, int* err, hipStream_t st);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);

@@ -346,3 +346,44 @@ def test_w_is_reread_on_every_factor_call():
         ko.KktChol2(pr['G'], pr['dims'], np.zeros((0, n))).factor(W, pr['P'])(xo, yo, zo)
         assert relerr(x, xo) < 1e-9 and relerr(z, zo) < 1e-9
     f.engine.close()
+
+
+@pytest.mark.parametrize("n,m", [(2000, 2500), (127, 300), (129, 10), (3333, 100)])
+def test_persistent_triangular_solves_stress(n, m):
+    """The single-launch trsv hands x blocks between workgroups (agent-scope release/acquire): hammer it with
+    repeated solves on the same factor and check every one against the oracle solution of the same system."""
+    rng = np.random.default_rng(n)
+    G = np.asfortranarray(rng.standard_normal((m, n)))
+    H = np.asfortranarray(np.diag(rng.uniform(1.0, 2.0, n)))
+    dims = {'l': m, 'q': [], 's': []}
+    A = np.zeros((0, n))
+    W = synth.random_scaling(dims, seed=1, spread=0.5)
+    f = kkt.kkt_chol2(G, dims, A)
+    s = f(W, H)
+    o = ko.KktChol2(G, dims, A).factor(W, H)
+    worst = 0.0
+    for it in range(60):
+        bx, bz = rng.standard_normal(n), rng.standard_normal(m)
+        x, y, z = bx.copy(), np.zeros(0), bz.copy()
+        s(x, y, z)
+        xo, yo, zo = bx.copy(), np.zeros(0), bz.copy()
+        o(xo, yo, zo)
+        worst = max(worst, relerr(x, xo), relerr(z, zo))
+    assert worst < 1e-9, worst
+    f.engine.close()
+
+
+def test_multi_kernel_trsv_path_still_matches(monkeypatch):
+    monkeypatch.setenv("MI355KKT_NO_PERSISTENT_TRSV", "1")
+    n, m = 700, 900
+    pr = synth.dense_qp(n, m, seed=4)
+    W = synth.random_scaling(pr['dims'], seed=2)
+    f = kkt.kkt_chol2(pr['G'], pr['dims'], np.zeros((0, n)))
+    rng = np.random.default_rng(0)
+    bx, bz = rng.standard_normal(n), rng.standard_normal(m)
+    x, y, z = bx.copy(), np.zeros(0), bz.copy()
+    f(W, pr['P'])(x, y, z)
+    xo, yo, zo = bx.copy(), np.zeros(0), bz.copy()
+    ko.KktChol2(pr['G'], pr['dims'], np.zeros((0, n))).factor(W, pr['P'])(xo, yo, zo)
+    assert relerr(x, xo) < 1e-9 and relerr(z, zo) < 1e-9
+    f.engine.close()
