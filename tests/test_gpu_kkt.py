@@ -387,3 +387,39 @@ def test_multi_kernel_trsv_path_still_matches(monkeypatch):
     ko.KktChol2(pr['G'], pr['dims'], np.zeros((0, n))).factor(W, pr['P'])(xo, yo, zo)
     assert relerr(x, xo) < 1e-9 and relerr(z, zo) < 1e-9
     f.engine.close()
+
+
+def test_full_size_config2_coneqp_matches_reference_probe(ref_cvxopt):
+    """BASELINE configs[1] at full size (n=8192, m=16384) through the reference driver with the GPU kktsolver.
+    Reference values: the surveyor's run of the unmodified reference with kktsolver='chol2' on the same seeded
+    problem: 16 iterations, pobj 3.616388620214e+03, dobj 3.616388571214e+03.
+    Plus the size-independent property: every KKT solve leaves a small residual (checked on the reduced system
+    with a matrix-free product on the host for the last iteration's scaling)."""
+    from cvxopt import matrix, solvers, spmatrix
+    n, m = 8192, 16384
+    pr = synth.dense_qp(n, m, seed=0)
+    P, q, G, h = matrix(pr['P']), matrix(pr['q']), matrix(pr['G']), matrix(pr['h'])
+    A = spmatrix([], [], [], (0, n))
+    ks = kkt.kktsolver_qp(G, pr['dims'], A, P)
+    resid = []
+
+    def wrapped(W):
+        f = ks(W)
+
+        def solve(x, y, z):
+            bx, bz = np.array(x).ravel().copy(), np.array(z).ravel().copy()
+            f(x, y, z)
+            if len(resid) < 4:            # a few matrix-free residual checks of S ux = bx + G' di^2 bz (host GEMVs)
+                di = np.array(W['di']).ravel()
+                ux = np.array(x).ravel()
+                lhs = pr['P'] @ ux + pr['G'].T @ (di * di * (pr['G'] @ ux))
+                rhs = bx + pr['G'].T @ (di * di * bz)
+                resid.append(np.linalg.norm(lhs - rhs) / np.linalg.norm(rhs))
+        return solve
+    sol = solvers.coneqp(P, q, G, h, kktsolver=wrapped)
+    assert sol['status'] == 'optimal'
+    assert sol['iterations'] == 16
+    assert abs(sol['primal objective'] - 3.616388620214e+03) <= 1e-9 * 3.616388620214e+03 * 10
+    assert abs(sol['dual objective'] - 3.616388571214e+03) <= 1e-9 * 3.616388571214e+03 * 10
+    assert max(resid) < 1e-11, resid
+    ks.engine.close()
