@@ -87,6 +87,8 @@ struct mi355kkt_solver {
     double* dGs = nullptr;     // cdim x n, only when nq > 0
     double* dV = nullptr;      // concatenated v_k
     double* dBeta = nullptr;   // beta_k
+    double* dRti = nullptr;    // concatenated rti_k ('s' cones)
+    int krows = 0;             // rows of the scaled constraint matrix the SYRK contracts over (packed for 's' cones)
     double* dWst = nullptr;    // staging for host-side W (di | v | beta)
     // persistent triangular solves: hand-off flags (one word per 128-block), launch epoch, timeout word
     unsigned int* dflags = nullptr;
@@ -225,7 +227,7 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     if ((rc = alloc(&h->dtn, N))) return fail(rc);
     if ((rc = alloc(&h->dtp, P))) return fail(rc);
     if ((rc = alloc(&h->dwork, C + 8))) return fail(rc);   // grown to the dense GEMV workspace on first dense use
-    if ((rc = alloc(&h->dWst, C + (size_t)nq + 8))) return fail(rc);
+    if ((rc = alloc(&h->dWst, 2 * C + (size_t)nq + 8))) return fail(rc);
     {
         const size_t nfl = N / 128 + 2;
         if (hipMalloc(&h->dflags, sizeof(unsigned int) * nfl) != hipSuccess) return fail(MI355KKT_ENOMEM);
@@ -235,13 +237,19 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
         if (hipHostMalloc(&h->herr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
         *h->herr = 0;
     }
-    if (nq > 0) {
+    h->krows = h->cdim;
+    if (nq > 0 || ns > 0) {
         if ((rc = alloc(&h->dGs, C * N))) return fail(rc);
         if ((rc = alloc(&h->dV, C))) return fail(rc);
         if ((rc = alloc(&h->dBeta, (size_t)nq))) return fail(rc);
+        if ((rc = alloc(&h->dRti, C))) return fail(rc);
         if ((rc = cone_layout_build(h->cl, ml, h->q))) return fail(rc);
+        int lq = ml;
+        for (int v : h->q) lq += v;
+        if ((rc = cone_layout_build_s(h->cl, lq, h->s))) return fail(rc);
+        h->krows = h->cl.cdim_packed;
     }
-    h->hbuf_doubles = dmax(N + P + C, 2 * C + (size_t)nq) + 8;
+    h->hbuf_doubles = dmax(N + P + C, 2 * C + (size_t)nq) + C + 8;
     if (hipHostMalloc(&h->hbuf, sizeof(double) * h->hbuf_doubles) != hipSuccess) return fail(MI355KKT_ENOMEM);
     if ((rc = potrf_work_init(h->pw))) return fail(rc);
     if (p > 0) {
@@ -257,7 +265,7 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     (void)hipSetDevice(h->device);
     if (h->st) (void)hipStreamSynchronize(h->st);
     double* bufs[] = {h->G_owned, h->A_owned, h->H_owned, h->dW, h->dS, h->dAsct, h->dK,
-                      h->dx, h->dy, h->dz, h->dzs, h->dtn, h->dtp, h->dwork, h->dWst, h->dGs, h->dV, h->dBeta};
+                      h->dx, h->dy, h->dz, h->dzs, h->dtn, h->dtp, h->dwork, h->dWst, h->dGs, h->dV, h->dBeta, h->dRti};
     cone_layout_free(h->cl);
     sparse_engine_free(h->sp);
     if (h->dflags) (void)hipFree(h->dflags);
@@ -398,12 +406,12 @@ static int fetch_info(mi355kkt_solver* h, int* info) {
 
 // assemble S = H + [reg I] + Gs' Gs [+ A'A]
 static int assemble_S(mi355kkt_solver* h, bool add_AtA) {
-    if (!h->q.empty()) {
-        // Gs = W^-T G once (HBM-bound), then the unscaled SYRK on Gs
-        if (int e = launch_cone_scale(h->cl, h->dG, h->ldG, h->dGs, h->cdim, h->n, h->dW, h->dV, h->dBeta,
-                                      1.0 / std::sqrt(1.0 + h->kktreg), h->st))
-            return e;
-        if (int e = launch_syrk_scaled(h->planS, h->dGs, h->cdim, nullptr, h->dS, h->n, h->dH, h->ldH, h->st, &h->ev[6]))
+    if (!h->q.empty() || !h->s.empty()) {
+        // Gs = W^-T G once (HBM-bound; 's' rows land in packed storage), then the unscaled SYRK on Gs
+        const double zs = 1.0 / std::sqrt(1.0 + h->kktreg);
+        if (int e = launch_cone_scale(h->cl, h->dG, h->ldG, h->dGs, h->krows, h->n, h->dW, h->dV, h->dBeta, zs, h->st)) return e;
+        if (int e = launch_sdp_scale_pack(h->cl, h->dG, h->ldG, h->dGs, h->krows, h->n, h->dRti, zs, h->st)) return e;
+        if (int e = launch_syrk_scaled(h->planS, h->dGs, h->krows, nullptr, h->dS, h->n, h->dH, h->ldH, h->st, &h->ev[6]))
             return e;
     } else if (int e = launch_syrk_scaled(h->planS, h->dG, h->ldG, h->ml > 0 ? h->dW : nullptr, h->dS, h->n, h->dH,
                                           h->ldH, h->st, &h->ev[6]))
@@ -416,10 +424,7 @@ static int assemble_S(mi355kkt_solver* h, bool add_AtA) {
 
 int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     if (!h || !W) { set_last_error("factor: null argument"); return MI355KKT_EINVAL; }
-    if (!h->s.empty()) {
-        set_last_error("factor: semidefinite ('s') cones are not implemented on the device yet");
-        return MI355KKT_ENOTIMPL;
-    }
+    if (!h->s.empty() && !W->rti) { set_last_error("factor: W.rti missing"); return MI355KKT_EINVAL; }
     if (h->ml > 0 && !W->di) { set_last_error("factor: W.di missing"); return MI355KKT_EINVAL; }
     if (!h->q.empty() && (!W->v || !W->beta)) { set_last_error("factor: W.v / W.beta missing"); return MI355KKT_EINVAL; }
     if (h->sparse) {
@@ -450,17 +455,21 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
         h->dwork = nullptr;
         KKT_HIP_CHECK(hipMalloc(&h->dwork, sizeof(double) * dmax(dmax(gemv_work_doubles(h->cdim, h->n), gemv_work_doubles(h->n, h->p)),
                                                                  (size_t)h->cdim + 8)));
-        if (int e = build_syrk_plan(h->planS, h->n, h->cdim, h->num_cus)) return e;
+        if (int e = build_syrk_plan(h->planS, h->n, h->krows, h->num_cus)) return e;
     }
     h->factored = false;
     const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);   // K[z,z] = -(1+reg): fold into the row scaling
     KKT_HIP_CHECK(hipEventRecord(h->ev[0], h->st));
-    if (!h->q.empty()) {
-        // cone path: dW keeps the raw di (the 1/sqrt(1+reg) factor is applied by launch_cone_scale)
+    if (!h->q.empty() || !h->s.empty()) {
+        // cone path: dW keeps the raw di (the 1/sqrt(1+reg) factor is applied by the scaling kernels)
         if (h->ml > 0) hipLaunchKernelGGL(scaled_copy_kernel, g1(h->ml), dim3(256), 0, h->st, W->di, h->dW, h->ml, 1.0);
-        KKT_HIP_CHECK(hipMemcpyAsync(h->dV, W->v, sizeof(double) * h->cl.vlen, hipMemcpyDeviceToDevice, h->st));
-        KKT_HIP_CHECK(hipMemcpyAsync(h->dBeta, W->beta, sizeof(double) * h->q.size(), hipMemcpyDeviceToDevice, h->st));
-        if (int e = cone_layout_set_beta(h->cl, h->dBeta, h->st)) return e;
+        if (!h->q.empty()) {
+            KKT_HIP_CHECK(hipMemcpyAsync(h->dV, W->v, sizeof(double) * h->cl.vlen, hipMemcpyDeviceToDevice, h->st));
+            KKT_HIP_CHECK(hipMemcpyAsync(h->dBeta, W->beta, sizeof(double) * h->q.size(), hipMemcpyDeviceToDevice, h->st));
+            if (int e = cone_layout_set_beta(h->cl, h->dBeta, h->st)) return e;
+        }
+        if (!h->s.empty())
+            KKT_HIP_CHECK(hipMemcpyAsync(h->dRti, W->rti, sizeof(double) * h->cl.rlen, hipMemcpyDeviceToDevice, h->st));
     } else if (h->ml > 0) {
         hipLaunchKernelGGL(scaled_copy_kernel, g1(h->ml), dim3(256), 0, h->st, W->di, h->dW, h->ml, zscale);
     }
@@ -507,20 +516,23 @@ int mi355kkt_factor(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     if (h->ml > 0 && !W->di) { set_last_error("factor: W.di missing"); return MI355KKT_EINVAL; }
     if (int e = bind(h)) return e;
     mi355kkt_scaling Wd = {};
-    const size_t ml = h->ml, vlen = h->cl.vlen, nq = h->q.size();
+    const size_t ml = h->ml, vlen = h->cl.vlen, nq = h->q.size(), rlen = h->cl.rlen;
     if (nq > 0 && (!W->v || !W->beta)) { set_last_error("factor: W.v / W.beta missing"); return MI355KKT_EINVAL; }
+    if (rlen > 0 && !W->rti) { set_last_error("factor: W.rti missing"); return MI355KKT_EINVAL; }
     if (ml) memcpy(h->hbuf, W->di, sizeof(double) * ml);
     if (nq) {
         memcpy(h->hbuf + ml, W->v, sizeof(double) * vlen);
         memcpy(h->hbuf + ml + vlen, W->beta, sizeof(double) * nq);
     }
-    if (ml + vlen + nq)
-        KKT_HIP_CHECK(hipMemcpyAsync(h->dWst, h->hbuf, sizeof(double) * (ml + vlen + nq), hipMemcpyHostToDevice, h->st));
+    if (rlen) memcpy(h->hbuf + ml + vlen + nq, W->rti, sizeof(double) * rlen);
+    if (ml + vlen + nq + rlen)
+        KKT_HIP_CHECK(hipMemcpyAsync(h->dWst, h->hbuf, sizeof(double) * (ml + vlen + nq + rlen), hipMemcpyHostToDevice, h->st));
     if (ml) Wd.di = h->dWst;
     if (nq) {
         Wd.v = h->dWst + ml;
         Wd.beta = h->dWst + ml + vlen;
     }
+    if (rlen) Wd.rti = h->dWst + ml + vlen + nq;
     return mi355kkt_factor_device(h, &Wd);
 }
 
@@ -539,14 +551,17 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
         return 0;
     }
     // zs = W^-T bz ;  x += Gs' zs                                     (misc.py:1513, :1524)
-    const bool cones = !h->q.empty();
+    const bool cones = !h->q.empty() || !h->s.empty();
+    const bool sdp = !h->s.empty();
     const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);
     const double* Gmat = cones ? h->dGs : h->dG;
-    const int64_t ldGm = cones ? (int64_t)h->cdim : h->ldG;
+    const int64_t ldGm = cones ? (int64_t)h->krows : h->ldG;
     const double* wvec = cones ? nullptr : h->dW;
+    const int mk = cones ? h->krows : m;        // rows of the (packed) scaled constraint space
     if (cones) {
-        if (int e = launch_cone_scale(h->cl, dz, m, h->dzs, m, 1, h->dW, h->dV, h->dBeta, zscale, st)) return e;
-        if (int e = launch_gemv_t_scaled(Gmat, ldGm, m, n, nullptr, h->dzs, h->dzs, dx, h->dwork, st)) return e;
+        if (int e = launch_cone_scale(h->cl, dz, m, h->dzs, mk, 1, h->dW, h->dV, h->dBeta, zscale, st)) return e;
+        if (int e = launch_sdp_scale_pack(h->cl, dz, m, h->dzs, mk, 1, h->dRti, zscale, st)) return e;
+        if (int e = launch_gemv_t_scaled(Gmat, ldGm, mk, n, nullptr, h->dzs, h->dzs, dx, h->dwork, st)) return e;
     } else if (int e = launch_gemv_t_scaled(h->dG, h->ldG, m, n, h->dW, dz, h->dzs, dx, h->dwork, st))
         return e;
     if (h->singular && p > 0)                                       // x += A' by  (:1527)
@@ -569,7 +584,14 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     }
     if (int e = tri_solve(1)) return e;                                             // :1555
     // z := Gs x - zs   (/ sqrt(1+reg) when the z-block pivot is -(1+reg))       (:1563)
-    if (int e = launch_gemv_n_scaled(Gmat, ldGm, m, n, wvec, dx, h->dzs, dz, zscale, -zscale, h->dwork, st)) return e;
+    if (sdp) {
+        // packed result in place, then l/q rows copied and the 's' blocks unpacked (lower triangles) into z
+        if (int e = launch_gemv_n_scaled(Gmat, ldGm, mk, n, wvec, dx, h->dzs, h->dzs, zscale, -zscale, h->dwork, st)) return e;
+        if (h->cl.lq_rows > 0)
+            KKT_HIP_CHECK(hipMemcpyAsync(dz, h->dzs, sizeof(double) * h->cl.lq_rows, hipMemcpyDeviceToDevice, st));
+        if (int e = launch_sdp_unpack(h->cl, h->dzs, dz, st)) return e;
+    } else if (int e = launch_gemv_n_scaled(Gmat, ldGm, mk, n, wvec, dx, h->dzs, dz, zscale, -zscale, h->dwork, st))
+        return e;
     KKT_HIP_CHECK(hipEventRecord(h->ev[5], st));
     return 0;
 }

@@ -83,8 +83,125 @@ __global__ __launch_bounds__(256) void scale_q_large_kernel(const double* __rest
     }
 }
 
+// ---- 's' (semidefinite) blocks: x_k := vec(rti' mat(x_k) rti) (misc_solvers.c:187-240, trans='T', inverse='I'), written
+//      straight into packed-lower storage with off-diagonals scaled by sqrt(2) (misc_solvers.c:412-550, pack/pack2),
+//      which is the row space the SYRK and the GEMVs work in.  One workgroup per (block, column).
+constexpr int SDP_MAXN = 80;
+__global__ __launch_bounds__(256) void sdp_scale_pack_kernel(const double* __restrict__ in, int64_t ldi,
+                                                             double* __restrict__ out, int64_t ldo, const int* __restrict__ sdim,
+                                                             const int* __restrict__ soff, const int* __restrict__ spoff,
+                                                             const int* __restrict__ sroff, const double* __restrict__ rti,
+                                                             double extra) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int k = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const int nk = sdim[k];
+    double* X = sm;
+    double* T = sm + nk * nk;
+    const double* __restrict__ x = in + soff[k] + (int64_t)j * ldi;
+    const double* __restrict__ Rm = rti + sroff[k];
+    for (int e = tid; e < nk * nk; e += 256) {
+        const int a = e % nk, b = e / nk;
+        if (a >= b) {                      // only the lower triangle of mat(x_k) is referenced
+            const double v = x[e];
+            X[a * nk + b] = v;
+            X[b * nk + a] = v;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < nk * nk; e += 256) {      // T = X R
+        const int a = e % nk, b = e / nk;
+        double s = 0.0;
+        for (int c = 0; c < nk; ++c) s += X[a * nk + c] * Rm[c + b * nk];
+        T[a + b * nk] = s;
+    }
+    __syncthreads();
+    double* __restrict__ y = out + spoff[k] + (int64_t)j * ldo;
+    const double r2 = 1.4142135623730951;
+    for (int e = tid; e < nk * nk; e += 256) {      // Y = R' T, lower triangle, packed
+        const int a = e % nk, b = e / nk;
+        if (a < b) continue;
+        double s = 0.0;
+        for (int c = 0; c < nk; ++c) s += Rm[c + a * nk] * T[c + b * nk];
+        const int idx = b * nk - (b * (b - 1)) / 2 + (a - b);
+        y[idx] = extra * ((a == b) ? s : r2 * s);
+    }
+}
+
+// packed -> unpacked for the 's' part of a single vector (misc_solvers.c:552-601): lower triangle only
+__global__ __launch_bounds__(256) void sdp_unpack_kernel(const double* __restrict__ packed, double* __restrict__ out,
+                                                         const int* __restrict__ sdim, const int* __restrict__ soff,
+                                                         const int* __restrict__ spoff) {
+    const int k = blockIdx.x, nk = sdim[k];
+    const double ir2 = 0.70710678118654752;
+    for (int e = threadIdx.x; e < nk * nk; e += 256) {
+        const int a = e % nk, b = e / nk;
+        if (a < b) continue;
+        const int idx = b * nk - (b * (b - 1)) / 2 + (a - b);
+        const double v = packed[spoff[k] + idx];
+        out[soff[k] + e] = (a == b) ? v : ir2 * v;
+    }
+}
+
+int cone_layout_build_s(ConeLayout& cl, int lq_rows, const std::vector<int>& s) {
+    cl.ns = (int)s.size();
+    cl.lq_rows = lq_rows;
+    cl.cdim_packed = lq_rows;
+    cl.rlen = 0;
+    cl.s_maxn = 0;
+    if (cl.ns == 0) return 0;
+    std::vector<int> sdim(s), soff(cl.ns), spoff(cl.ns), sroff(cl.ns);
+    int o = lq_rows, po = lq_rows, ro = 0;
+    for (int k = 0; k < cl.ns; ++k) {
+        soff[k] = o;
+        spoff[k] = po;
+        sroff[k] = ro;
+        o += s[k] * s[k];
+        po += s[k] * (s[k] + 1) / 2;
+        ro += s[k] * s[k];
+        cl.s_maxn = std::max(cl.s_maxn, s[k]);
+    }
+    cl.cdim_packed = po;
+    cl.rlen = ro;
+    auto up = [&](int** d, const std::vector<int>& h) -> int {
+        KKT_HIP_CHECK(hipMalloc(d, sizeof(int) * (h.size() ? h.size() : 1)));
+        if (!h.empty()) KKT_HIP_CHECK(hipMemcpy(*d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+        return 0;
+    };
+    if (int e = up(&cl.d_sdim, sdim)) return e;
+    if (int e = up(&cl.d_soff, soff)) return e;
+    if (int e = up(&cl.d_spoff, spoff)) return e;
+    if (int e = up(&cl.d_sroff, sroff)) return e;
+    return 0;
+}
+
+int launch_sdp_scale_pack(const ConeLayout& cl, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
+                          const double* d_rti, double extra, hipStream_t st) {
+    if (cl.ns == 0 || ncols <= 0) return 0;
+    if (cl.s_maxn > SDP_MAXN) {
+        set_last_error("semidefinite blocks larger than %d x %d are not supported on the device yet", SDP_MAXN, SDP_MAXN);
+        return -4;
+    }
+    static bool attr = false;
+    const size_t lds = sizeof(double) * 2 * SDP_MAXN * SDP_MAXN;
+    if (!attr) {
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sdp_scale_pack_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL(sdp_scale_pack_kernel, dim3(cl.ns, ncols), dim3(256), sizeof(double) * 2 * cl.s_maxn * cl.s_maxn, st, in,
+                       ldi, out, ldo, cl.d_sdim, cl.d_soff, cl.d_spoff, cl.d_sroff, d_rti, extra);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_sdp_unpack(const ConeLayout& cl, const double* packed, double* out, hipStream_t st) {
+    if (cl.ns == 0) return 0;
+    hipLaunchKernelGGL(sdp_unpack_kernel, dim3(cl.ns), dim3(256), 0, st, packed, out, cl.d_sdim, cl.d_soff, cl.d_spoff);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int cone_layout_build(ConeLayout& cl, int ml, const std::vector<int>& q) {
-    cone_layout_free(cl);
     cl.ml = ml;
     cl.nq = (int)q.size();
     if (cl.nq == 0) return 0;
@@ -130,6 +247,9 @@ void cone_layout_free(ConeLayout& cl) {
     for (int* p : ip)
         if (p) (void)hipFree(p);
     if (cl.d_s_beta) (void)hipFree(cl.d_s_beta);
+    int* sp[] = {cl.d_sdim, cl.d_soff, cl.d_spoff, cl.d_sroff};
+    for (int* p : sp)
+        if (p) (void)hipFree(p);
     cl = ConeLayout();
 }
 

@@ -159,7 +159,15 @@ struct ConeLayout {
     int *d_small_ids = nullptr, *d_large_ids = nullptr;                // cones of dimension <= 32 / > 32
     int *d_s_off = nullptr, *d_s_dim = nullptr, *d_s_voff = nullptr;   // compacted descriptors of the small cones
     double* d_s_beta = nullptr;                                        // beta gathered for the small cones
+    // semidefinite blocks
+    int ns = 0, lq_rows = 0, cdim_packed = 0, rlen = 0, s_maxn = 0;
+    int *d_sdim = nullptr, *d_soff = nullptr, *d_spoff = nullptr, *d_sroff = nullptr;
 };
+int cone_layout_build_s(ConeLayout& cl, int lq_rows, const std::vector<int>& s);
+// out(packed rows of the 's' blocks, ncols columns) = extra * pack(rti' mat(in) rti)
+int launch_sdp_scale_pack(const ConeLayout& cl, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
+                          const double* d_rti, double extra, hipStream_t st);
+int launch_sdp_unpack(const ConeLayout& cl, const double* packed, double* out, hipStream_t st);
 int cone_layout_build(ConeLayout& cl, int ml, const std::vector<int>& q);
 void cone_layout_free(ConeLayout& cl);
 int cone_layout_set_beta(ConeLayout& cl, const double* d_beta, hipStream_t st);

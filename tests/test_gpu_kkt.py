@@ -423,3 +423,82 @@ def test_full_size_config2_coneqp_matches_reference_probe(ref_cvxopt):
     assert abs(sol['dual objective'] - 3.616388571214e+03) <= 1e-9 * 3.616388571214e+03 * 10
     assert max(resid) < 1e-11, resid
     ks.engine.close()
+
+
+# ---- semidefinite ('s') cones ----------------------------------------------------------------------------
+def _pack_sym(z, dims):
+    return ko.pack(ko._symmetrize_s(z.copy(), dims), dims)
+
+
+def test_sdp_hook_matches_reference_golden():
+    rec = load_golden("kkt_sdp")
+    dims = dims_of(rec)
+    W = w_of(rec, dims)
+    G, A, H = np.asfortranarray(rec['G']), np.asfortranarray(rec['A']), np.asfortranarray(rec['H'])
+    for kind in ("chol", "ldl", "ldl2"):
+        f = getattr(kkt, 'kkt_' + kind)(G, dims, A)
+        x, y, z = rec['bx'].copy(), rec['by'].copy(), rec['bz'].copy()
+        f(W, H)(x, y, z)
+        assert relerr(x, rec['x_' + kind]) < 1e-9 and relerr(y, rec['y_' + kind]) < 1e-9
+        assert relerr(_pack_sym(z, dims), _pack_sym(rec['z_' + kind], dims)) < 1e-9
+        f.engine.close()
+    f = kkt.kkt_ldl(G, dims, A, kktreg=1e-3)
+    x, y, z = rec['bx'].copy(), rec['by'].copy(), rec['bz'].copy()
+    f(W, H)(x, y, z)
+    assert relerr(x, rec['x_ldlreg']) < 1e-9
+    assert relerr(_pack_sym(z, dims), _pack_sym(rec['z_ldlreg'], dims)) < 1e-9
+    f.engine.close()
+
+
+@pytest.mark.parametrize("dims,n,p", [({'l': 0, 'q': [], 's': [5]}, 8, 0), ({'l': 4, 'q': [3, 6], 's': [2, 7, 12]}, 30, 3),
+                                      ({'l': 0, 'q': [], 's': [40, 1]}, 100, 0)])
+def test_sdp_factor_solve_matches_oracle(dims, n, p):
+    m = ko.cdim(dims)
+    rng = np.random.default_rng(n + m)
+    G = np.asfortranarray(rng.standard_normal((m, n)))
+    for c in range(n):
+        G[:, c] = ko._symmetrize_s(G[:, c], dims)
+    A = np.asfortranarray(rng.standard_normal((p, n)))
+    B = rng.standard_normal((n, n))
+    H = np.asfortranarray(B @ B.T / n + 0.1 * np.eye(n))
+    f = kkt.kkt_chol(G, dims, A)
+    for it in range(2):
+        W = synth.random_scaling(dims, seed=it, spread=0.7)
+        bx, by = rng.standard_normal(n), rng.standard_normal(p)
+        bz = ko._symmetrize_s(rng.standard_normal(m), dims)
+        x, y, z = bx.copy(), by.copy(), bz.copy()
+        f(W, H)(x, y, z)
+        xo, yo, zo = bx.copy(), by.copy(), bz.copy()
+        ko.KktChol(G, dims, A).factor(W, H)(xo, yo, zo)
+        # random r / rti are not well conditioned: forward error bound loose, backward error (KKT residual) tight
+        assert relerr(x, xo) < 1e-6 and relerr(y, yo) < 1e-6
+        assert relerr(_pack_sym(z, dims), _pack_sym(zo, dims)) < 1e-6
+        zs, zos = ko._symmetrize_s(z, dims), ko._symmetrize_s(zo, dims)
+        res = ko.kkt_residual(H, A, G, W, dims, bx, by, bz, x, y, zs)
+        res_ref = ko.kkt_residual(H, A, G, W, dims, bx, by, bz, xo, yo, zos)
+        assert res < max(RESID_TOL, 10.0 * res_ref), (res, res_ref)
+    f.engine.close()
+
+
+def test_sdp_drop_in_matches_reference(ref_cvxopt):
+    """solvers.sdp (reference doc example, doc/source/coneprog.rst sdp section / examples/doc/chap8/sdp.py data) with
+    the GPU kktsolver routed through install(): same status / iterations / objective as the CPU default."""
+    from cvxopt import matrix, solvers, misc
+    import cvxopt_amd
+    c = matrix([1., -1., 1.])
+    G = [matrix([[-7., -11., -11., 3.], [7., -18., -18., 8.], [-2., -8., -8., 1.]])]
+    G += [matrix([[-21., -11., 0., -11., 10., 8., 0., 8., 5.], [0., 10., 16., 10., -10., -10., 16., -10., 3.],
+                  [-5., 2., -17., 2., -6., 8., -17., 8., 6.]])]
+    h = [matrix([[33., -9.], [-9., 26.]]), matrix([[14., 9., 40.], [9., 91., 10.], [40., 10., 15.]])]
+    ref = solvers.sdp(c, Gs=G, hs=h, kktsolver='chol')
+    cvxopt_amd.install(misc)
+    try:
+        got = solvers.sdp(c, Gs=G, hs=h, kktsolver='chol')
+        got_default = solvers.sdp(c, Gs=G, hs=h)             # default 'qr' -> kkt_qr mirror
+    finally:
+        cvxopt_amd.uninstall()
+    for g in (got, got_default):
+        assert g['status'] == ref['status'] == 'optimal'
+        assert abs(g['primal objective'] - ref['primal objective']) <= 1e-7 * max(1, abs(ref['primal objective']))
+        assert relerr(np.array(g['x']).ravel(), np.array(ref['x']).ravel()) < 1e-6
+    assert got['iterations'] == ref['iterations']
