@@ -94,7 +94,7 @@ def main():
     import numpy as np
     import torch                                   # plumbing only: device selection + torch.distributed
     dist = None
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):   # launched by torch.distributed.run
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
