@@ -66,3 +66,17 @@ def test_coneqp_batch_gpu_matches_individual_reference_runs(ref_cvxopt):
         assert res['iterations'][b] == ref['iterations'], b
         assert abs(res['primal objective'][b] - ref['primal objective']) <= 1e-9 * max(1, abs(ref['primal objective']))
         assert relerr(res['x'][b], np.array(ref['x']).ravel()) < 1e-7
+
+
+def test_sharded_batch_on_rccl():
+    """coneqp_batch_sharded on the real nccl (= RCCL) backend, launched like bench.py is (torch.distributed.run)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29531",
+                          os.path.join(here, "run_batch_sharded_nccl.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "SHARDED_NCCL_OK" in out.stdout
