@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 
 namespace mi355kkt {
 
@@ -349,6 +350,7 @@ void free_syrk_plan(SyrkPlan& plan) {
 }
 
 static constexpr size_t kGemmLds = sizeof(double) * 4 * STAGE_DOUBLES;   // 73,728 B
+static constexpr size_t kGemmLdsWide = 84 * 1024;                        // > 80 KiB: one workgroup per CU
 
 int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const double* di, double* C,
                        int64_t ldc, const double* P, int64_t ldp, hipStream_t st, hipEvent_t* kernel_events,
@@ -501,7 +503,7 @@ static int nt_attr() {
     static bool done = false;
     if (!done) {
         KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLdsWide));
         KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
         done = true;
@@ -510,12 +512,15 @@ static int nt_attr() {
 }
 
 int launch_syrk_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, int nrows, int K,
-                          hipStream_t st, int nbatch, int64_t bstride) {
+                          hipStream_t st, int nbatch, int64_t bstride, bool one_wg_per_cu) {
     if (nrows <= 0 || K <= 0) return 0;
     if (int e = nt_attr()) return e;
     const int nt = (nrows + TILE - 1) / TILE;
     const int fast_ok = ((reinterpret_cast<uintptr_t>(A) & 7) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(nt_update_kernel<true>, dim3(nt * (nt + 1) / 2, 1, nbatch), dim3(256), kGemmLds, st, C, ldc, A,
+    // one_wg_per_cu: ask for > half of the LDS so that a background (look-ahead) update leaves half of every CU
+    // to the critical-path kernels of the other stream
+    const size_t lds = one_wg_per_cu ? kGemmLdsWide : kGemmLds;
+    hipLaunchKernelGGL(nt_update_kernel<true>, dim3(nt * (nt + 1) / 2, 1, nbatch), dim3(256), lds, st, C, ldc, A,
                        lda, A, lda, nrows, nrows, K, fast_ok, bstride);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;

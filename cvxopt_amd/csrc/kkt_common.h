@@ -61,7 +61,7 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
 
 // C(lower tiles of an nrows x nrows block) -= A A' where A is nrows x K (column-major, lda)
 int launch_syrk_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, int nrows, int K,
-                          hipStream_t st, int nbatch = 1, int64_t bstride = 0);
+                          hipStream_t st, int nbatch = 1, int64_t bstride = 0, bool one_wg_per_cu = false);
 // C (M x N, all tiles) -= A B'  with A: M x K (lda), B: N x K (ldb)
 int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, const double* B,
                           int64_t ldb, int M, int N, int K, hipStream_t st, int nbatch = 1, int64_t bstride = 0);
@@ -74,8 +74,8 @@ struct PotrfWork {
     int* h_info = nullptr;   // pinned host mirror
     double* d_dinv = nullptr; // inverses of the 16x16 diagonal blocks of the current panel (potf2 -> trsm)
     // look-ahead: the bulk of each trailing update runs on `side` while the next panel is factored on the main stream
-    hipStream_t side = nullptr;
-    std::vector<hipEvent_t> ev_panel, ev_bulk;
+    hipStream_t side = nullptr, aux = nullptr;
+    std::vector<hipEvent_t> ev_panel, ev_bulk, ev_t1, ev_usr, ev_ir;
 };
 int set_potf2_skip(int v);   // developer ablation switch
 int set_syrk_skip(int v);    // developer ablation switch

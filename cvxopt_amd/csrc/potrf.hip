@@ -8,6 +8,8 @@
 //   nt_update_kernel  trailing update A22 -= L21 L21' on the matrix cores (gemm_f64.hip)
 // A non-positive pivot sets *info = (1-based column) exactly like LAPACK's info > 0; every later
 // kernel of the sequence returns immediately once *info != 0.
+#include <cstdlib>
+
 #include "kkt_common.h"
 
 namespace mi355kkt {
@@ -303,6 +305,8 @@ int potrf_work_init_batched(PotrfWork& w, int nbatch) {
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, least) != hipSuccess)
             KKT_HIP_CHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+        if (hipStreamCreateWithPriority(&w.aux, hipStreamNonBlocking, greatest) != hipSuccess)
+            KKT_HIP_CHECK(hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
     }
     return 0;
 }
@@ -315,7 +319,11 @@ void potrf_work_free(PotrfWork& w) {
     if (w.h_info) (void)hipHostFree(w.h_info);
     for (auto e : w.ev_panel) (void)hipEventDestroy(e);
     for (auto e : w.ev_bulk) (void)hipEventDestroy(e);
+    for (auto e : w.ev_t1) (void)hipEventDestroy(e);
+    for (auto e : w.ev_usr) (void)hipEventDestroy(e);
+    for (auto e : w.ev_ir) (void)hipEventDestroy(e);
     if (w.side) (void)hipStreamDestroy(w.side);
+    if (w.aux) (void)hipStreamDestroy(w.aux);
     w = PotrfWork();
 }
 
@@ -350,7 +358,106 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
     // ---- look-ahead variant (single large matrix): the update of the NEXT outer panel's columns stays on
     //      `st`; the rest of the trailing update runs on w.side, concurrently with the next panel's
     //      potf2 / trsm (which occupy only a few compute units).
-    if (nbatch == 1 && n >= 8 * NB && w.side) {
+    const char* mode_env = getenv("MI355KKT_POTRF_STREAMS");
+    const int lookahead_streams = mode_env ? atoi(mode_env) : 2;
+    if (nbatch == 1 && n >= 8 * NB && w.side && w.aux && lookahead_streams == 3) {
+        // Three streams.  st (critical path): potf2 -> trsm -> diagonal-block-only updates -> next potf2 ...
+        // w.aux: the rest of the skinny updates (rows below the next diagonal block) - overlaps with the next potf2.
+        // w.side (low priority, one workgroup per CU): the bulk rank-256 update of everything further right.
+        const int nsteps = (n + 2 * NB - 1) / (2 * NB);
+        auto grow = [&](std::vector<hipEvent_t>& v) -> int {
+            while ((int)v.size() < nsteps + 1) {
+                hipEvent_t e1;
+                KKT_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+                v.push_back(e1);
+            }
+            return 0;
+        };
+        if (int e = grow(w.ev_panel)) return e;
+        if (int e = grow(w.ev_bulk)) return e;
+        if (int e = grow(w.ev_t1)) return e;
+        if (int e = grow(w.ev_usr)) return e;
+        if (int e = grow(w.ev_ir)) return e;
+        auto potf2 = [&](int k0, int nb) {
+            hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), lds, st, A + k0 + (int64_t)k0 * lda, lda, nb, k0, w.d_info,
+                               w.d_dinv, (int64_t)0);
+        };
+        auto trsm = [&](int k0, int nb) {
+            const int m = n - k0 - nb;
+            if (m <= 0) return;
+            double* Akk = A + k0 + (int64_t)k0 * lda;
+            if (nb == NB)
+                hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Akk, w.d_dinv,
+                                   Akk + nb, lda, m, w.d_info, (int64_t)0, nb);
+            else
+                hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Akk, w.d_dinv,
+                                   Akk + nb, lda, m, w.d_info, (int64_t)0, nb);
+        };
+        // C[r0:r0+M, c0:c0+N] -= L[r0:.., kp:kp+K] L[c0:.., kp:kp+K]'
+        auto upd = [&](int r0, int M, int c0, int N, int kp, int K, hipStream_t s_) -> int {
+            if (M <= 0 || N <= 0) return 0;
+            return launch_gemm_nt_update(A + r0 + (int64_t)c0 * lda, lda, A + r0 + (int64_t)kp * lda, lda,
+                                         A + c0 + (int64_t)kp * lda, lda, M, N, K, s_);
+        };
+        int step = 0;
+        bool bulk_pending = false, ir_pending = false;
+        for (int k0 = 0; k0 < n; k0 += 2 * NB, ++step) {
+            const int nb1 = (n - k0 < NB) ? (n - k0) : NB;
+            potf2(k0, nb1);
+            if (ir_pending) KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_ir[step - 1], 0));   // rows below were updated on aux
+            trsm(k0, nb1);
+            const int k1 = k0 + nb1;
+            if (k1 >= n) break;
+            const int nb2 = (n - k1 < NB) ? (n - k1) : NB;
+            KKT_HIP_CHECK(hipEventRecord(w.ev_t1[step], st));
+            // sub-panel 2: its diagonal block on the critical path, the rows below it on aux
+            if (int e = upd(k1, nb2, k1, nb2, k0, nb1, st)) return e;
+            KKT_HIP_CHECK(hipStreamWaitEvent(w.aux, w.ev_t1[step], 0));
+            if (int e = upd(k1 + nb2, n - k1 - nb2, k1, nb2, k0, nb1, w.aux)) return e;
+            KKT_HIP_CHECK(hipEventRecord(w.ev_usr[step], w.aux));
+            potf2(k1, nb2);
+            KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_usr[step], 0));
+            trsm(k1, nb2);
+            const int k2 = k1 + nb2;
+            if (k2 >= n) { ir_pending = false; break; }
+            KKT_HIP_CHECK(hipEventRecord(w.ev_panel[step], st));          // outer panel `step` complete
+            const int K = nb1 + nb2;
+            const int wnext = (n - k2 < 2 * NB) ? (n - k2) : 2 * NB;      // width of the next outer panel
+            const int d1 = (wnext < NB) ? wnext : NB;                     // its first diagonal block
+            if (bulk_pending) {
+                KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_bulk[step - 1], 0));
+                KKT_HIP_CHECK(hipStreamWaitEvent(w.aux, w.ev_bulk[step - 1], 0));
+            }
+            // next panel: first diagonal block on the critical path, all rows below it (both sub-panels' columns) on aux
+            if (int e = upd(k2, d1, k2, d1, k0, K, st)) return e;
+            KKT_HIP_CHECK(hipStreamWaitEvent(w.aux, w.ev_panel[step], 0));
+            if (int e = upd(k2 + d1, n - k2 - d1, k2, wnext, k0, K, w.aux)) return e;
+            KKT_HIP_CHECK(hipEventRecord(w.ev_ir[step], w.aux));
+            ir_pending = true;
+            // everything to the right of the next panel: bulk, low priority, one workgroup per CU
+            const int k3 = k2 + wnext;
+            if (k3 < n) {
+                KKT_HIP_CHECK(hipStreamWaitEvent(w.side, w.ev_panel[step], 0));
+                if (int e = launch_syrk_nt_update(A + k3 + (int64_t)k3 * lda, lda, A + k3 + (int64_t)k0 * lda, lda, n - k3, K,
+                                                  w.side, 1, 0, getenv("MI355KKT_BULK_2WG") == nullptr))
+                    return e;
+                KKT_HIP_CHECK(hipEventRecord(w.ev_bulk[step], w.side));
+                bulk_pending = true;
+            } else {
+                bulk_pending = false;
+            }
+        }
+        // join: nothing may be in flight on aux / side when the caller's stream continues
+        hipEvent_t ej = w.ev_t1[nsteps];
+        KKT_HIP_CHECK(hipEventRecord(ej, w.aux));
+        KKT_HIP_CHECK(hipStreamWaitEvent(st, ej, 0));
+        hipEvent_t eb = w.ev_usr[nsteps];
+        KKT_HIP_CHECK(hipEventRecord(eb, w.side));
+        KKT_HIP_CHECK(hipStreamWaitEvent(st, eb, 0));
+        KKT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (nbatch == 1 && n >= 8 * NB && w.side && lookahead_streams == 2) {
         const int nsteps = (n + 2 * NB - 1) / (2 * NB);
         while ((int)w.ev_panel.size() < nsteps + 1) {
             hipEvent_t e1, e2;
