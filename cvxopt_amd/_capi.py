@@ -65,6 +65,9 @@ SIGNATURES = {
     "mi355kkt_batch_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mi355kkt_batch_products": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mi355kkt_batch_last_factor_ms": (C.c_float, [C.c_void_p]),
+    "mi355kkt_batch_coneqp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_int_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, c_int_p]),
     "mi355kkt_op_syrk_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_int64, c_float_p]),
     "mi355kkt_op_symbolic": (C.c_int, [C.c_int, C.c_int, c_i64_p, c_i64_p, c_i64_p, c_i64_p, c_int_p, c_i64_p, c_int_p, c_int_p]),

@@ -68,6 +68,29 @@ class BatchKkt(object):
     def factor_ms(self):
         return float(self.L.mi355kkt_batch_last_factor_ms(self.h))
 
+    def coneqp(self, q, h, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):
+        """The whole interior-point loop on the device (`mi355kkt_batch_coneqp`): same result dict as
+        `coneqp_batch`; only the count of active problems crosses PCIe per iteration."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        B, n, m = self.B, self.n, self.m
+        assert q.shape == (B, n) and h.shape == (B, m)
+        x, s, z = np.zeros((B, n)), np.zeros((B, m)), np.zeros((B, m))
+        status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        pc, dc, gap = np.zeros(B), np.zeros(B), np.zeros(B)
+        nrun = C.c_int(0)
+        ip = _capi.c_int_p
+        rc = self.L.mi355kkt_batch_coneqp(self.h, q.ctypes.data, h.ctypes.data, int(maxiters), float(abstol),
+                                          float(reltol), float(feastol), x.ctypes.data, s.ctypes.data, z.ctypes.data,
+                                          status.ctypes.data_as(ip), iters.ctypes.data_as(ip), pc.ctypes.data,
+                                          dc.ctypes.data, gap.ctypes.data, C.byref(nrun))
+        if rc == 1:
+            raise ValueError("Rank([P; A; G]) < n (%s)" % _capi.last_error())
+        _capi.check(rc, "batch_coneqp")
+        names = np.array(['unknown', 'optimal', 'unknown', 'unknown'], dtype=object)
+        return {'x': x, 's': s, 'z': z, 'status': names[status], 'iterations': iters.astype(int),
+                'primal objective': pc, 'dual objective': dc, 'gap': gap, 'lockstep iterations': nrun.value}
+
     def close(self):
         if getattr(self, "h", None):
             self.L.mi355kkt_batch_destroy(self.h)
@@ -92,14 +115,23 @@ def pack_problems(problems):
 # ---------------------------------------------------------------------------------------------------
 # lock-step interior-point loop (host bookkeeping, device KKT)
 # ---------------------------------------------------------------------------------------------------
-def coneqp_batch(P, q, Gt, h, kkt=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, device=0):
+def coneqp_batch(P, q, Gt, h, kkt=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, device=0,
+                 resident=False):
     """Solves the B problems in lock step.  Returns a dict of arrays: x (B,n), s, z (B,m), status (B,)
-    ('optimal' | 'unknown'), iterations, primal objective, dual objective, gap."""
+    ('optimal' | 'unknown'), iterations, primal objective, dual objective, gap.
+    resident=True runs the bookkeeping on the device as well (BatchKkt.coneqp); the NumPy loop below is the
+    readable restatement the device loop is tested against."""
     B, n = q.shape
     m = h.shape[1]
     own = kkt is None
     if own:
         kkt = BatchKkt(Gt, P, device=device)
+    if resident:
+        try:
+            return kkt.coneqp(q, h, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol)
+        finally:
+            if own:
+                kkt.close()
     Psym = None
     if not hasattr(kkt, "products"):      # host products (tests): only tril(P) is meaningful (coneprog.py:1475-1477)
         Psym = P if P is not None else np.zeros((B, n, n))
@@ -294,6 +326,7 @@ def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, dev
     if hi > lo:
         if local_solver is None:
             device = device_of_rank(rank) if device_of_rank else (torch.cuda.current_device() if backend == "nccl" else 0)
+            opts.setdefault("resident", True)          # whole loop on the rank's GPU; only results come back
             res = coneqp_batch(P_l, q_l, G_l, h_l, device=device, **opts)
         else:
             res = local_solver(P_l, q_l, G_l, h_l, **opts)
@@ -307,5 +340,8 @@ def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, dev
         return res
     full = {}
     for k in res:
-        full[k] = np.concatenate([g[k] for g in gathered])
+        if k == 'lockstep iterations':
+            full[k] = max(g.get(k, 0) for g in gathered)
+        else:
+            full[k] = np.concatenate([g[k] for g in gathered])
     return full

@@ -42,6 +42,14 @@ __global__ void scaled_copy_kernel(const double* x, double* y, int n, double a) 
     if (i < n) y[i] = a * x[i];
 }
 // mirror the lower triangle of nbatch n x n matrices into their upper triangles (batched along blockIdx.z)
+__global__ void fill_kernel(double* x, double a, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = a;
+}
+__global__ void axpby_kernel(double* y, const double* x, double a, int64_t n) {   // y = a x
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = a * x[i];
+}
 __global__ void symmetrize_kernel(double* A, int n, int64_t bstride) {
     A += (int64_t)blockIdx.z * bstride;
     const int i = blockIdx.x * 16 + threadIdx.x, j = blockIdx.y * 16 + threadIdx.y;
@@ -675,6 +683,11 @@ struct mi355kkt_batch {
     SyrkPlan plan;
     PotrfWork pw;
     float t_factor = 0;
+    bool defer_sync = false;          // set by the device-resident loop: the public calls then only enqueue
+    IpmState ipm;                     // allocated on the first mi355kkt_batch_coneqp call
+    double* ipm_f64 = nullptr;
+    int* ipm_i32 = nullptr;
+    int* h_pinned = nullptr;
 };
 
 extern "C" {
@@ -716,6 +729,9 @@ void mi355kkt_batch_destroy(mi355kkt_batch* b) {
     if (b->st) (void)hipStreamSynchronize(b->st);
     double* bufs[] = {b->dG, b->dH, b->dS, b->dW, b->dx, b->dz, b->dzs, b->dwork, b->dt1, b->dt2};
     for (double* p : bufs) if (p) (void)hipFree(p);
+    if (b->ipm_f64) (void)hipFree(b->ipm_f64);
+    if (b->ipm_i32) (void)hipFree(b->ipm_i32);
+    if (b->h_pinned) (void)hipHostFree(b->h_pinned);
     potrf_work_free(b->pw);
     free_syrk_plan(b->plan);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
@@ -778,7 +794,7 @@ int mi355kkt_batch_products(mi355kkt_batch* b, const double* x, const double* z,
         }
         if (!is_device) KKT_HIP_CHECK(hipMemcpyAsync(Hx, o, sizeof(double) * B * N, hipMemcpyDeviceToHost, b->st));
     }
-    KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+    if (!b->defer_sync) KKT_HIP_CHECK(hipStreamSynchronize(b->st));
     return 0;
 }
 
@@ -796,6 +812,7 @@ int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, in
         return e;
     if (int e = launch_potrf_batched(b->dS, (int64_t)N, b->n, b->nbatch, (int64_t)(N * N), b->pw, b->st)) return e;
     KKT_HIP_CHECK(hipEventRecord(b->ev[1], b->st));
+    if (b->defer_sync) return 0;
     KKT_HIP_CHECK(hipMemcpyAsync(b->pw.h_info, b->pw.d_info, sizeof(int) * B, hipMemcpyDeviceToHost, b->st));
     KKT_HIP_CHECK(hipStreamSynchronize(b->st));
     (void)hipEventElapsedTime(&b->t_factor, b->ev[0], b->ev[1]);
@@ -823,7 +840,93 @@ int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device)
         KKT_HIP_CHECK(hipMemcpyAsync(x, b->dx, sizeof(double) * B * N, hipMemcpyDeviceToHost, b->st));
         if (M) KKT_HIP_CHECK(hipMemcpyAsync(z, b->dz, sizeof(double) * B * M, hipMemcpyDeviceToHost, b->st));
     }
-    KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+    if (!b->defer_sync) KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+    return 0;
+}
+
+static int ipm_alloc(mi355kkt_batch* b) {
+    if (b->ipm_f64) return 0;
+    const size_t B = b->nbatch, N = b->n, M = b->ml ? b->ml : 1;
+    const size_t nd = B * (7 * N + 13 * M + 8);
+    if (hipMalloc(&b->ipm_f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
+    if (hipMalloc(&b->ipm_i32, sizeof(int) * (4 * B + 1)) != hipSuccess) return MI355KKT_ENOMEM;
+    if (hipHostMalloc(&b->h_pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
+    IpmState& S = b->ipm;
+    S.n = b->n; S.m = b->ml;
+    double* p = b->ipm_f64;
+    auto take = [&](size_t k) { double* r = p; p += k; return r; };
+    S.q = take(B * N); S.x = take(B * N); S.rx = take(B * N); S.dx = take(B * N);
+    S.GTz = take(B * N); S.Px = take(B * N); S.x_out = take(B * N);
+    S.h = take(B * M); S.s = take(B * M); S.z = take(B * M); S.rz = take(B * M); S.dz = take(B * M); S.ds = take(B * M);
+    S.lmbda = take(B * M); S.d = take(B * M); S.di = take(B * M); S.ws3 = take(B * M); S.Gx = take(B * M);
+    S.s_out = take(B * M); S.z_out = take(B * M);
+    S.gap = take(B); S.resx0 = take(B); S.resz0 = take(B); S.step = take(B); S.sigma = take(B);
+    S.pcost = take(B); S.dcost = take(B); S.gap_out = take(B);
+    int* q = b->ipm_i32;
+    S.active = q; S.status = q + B; S.iters = q + 2 * B; S.freeze = q + 3 * B; S.nactive = q + 4 * B;
+    return 0;
+}
+
+/* The whole LP-cone coneqp loop (reference coneprog.py:2044-2547 with dims = {'l': ml}, no equalities) for every problem
+ * of the batch, iterates and bookkeeping resident in HBM; per iteration only the count of still-active problems returns to
+ * the host.  q: [nbatch][n], h: [nbatch][ml] (host).  Outputs (host): x [nbatch][n], s, z [nbatch][ml], status [nbatch]
+ * (1 optimal, 2 unknown: iteration limit, 3 unknown: singular KKT matrix), iters, pcost, dcost, gap [nbatch].
+ * Returns 0, <0 on error, or 1 when the very first factorisation failed for some problem (Rank([P; G]) < n;
+ * coneprog.py:2065-2066 raises ValueError). */
+int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, int maxiters, double abstol, double reltol,
+                          double feastol, double* x, double* s, double* z, int* status, int* iters, double* pcost,
+                          double* dcost, double* gap, int* iterations_run) {
+    if (!b || !q || (!h && b->ml) || !x || !status || !iters) { set_last_error("batch_coneqp: null argument"); return MI355KKT_EINVAL; }
+    if (b->ml < 1) { set_last_error("batch_coneqp: needs at least one inequality"); return MI355KKT_EINVAL; }
+    KKT_HIP_CHECK(hipSetDevice(b->device));
+    if (int e = ipm_alloc(b)) return e;
+    const size_t B = b->nbatch, N = b->n, M = b->ml;
+    const IpmState& S = b->ipm;
+    struct Guard { mi355kkt_batch* b; ~Guard() { b->defer_sync = false; } } guard{b};
+    hipStream_t st = b->st;
+    KKT_HIP_CHECK(hipMemcpyAsync(S.q, q, sizeof(double) * B * N, hipMemcpyHostToDevice, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.h, h, sizeof(double) * B * M, hipMemcpyHostToDevice, st));
+    KKT_HIP_CHECK(hipMemsetAsync(b->ipm_i32, 0, sizeof(int) * (4 * B + 1), st));
+    b->defer_sync = true;
+    // ---- starting point: W = I  (coneprog.py:2055-2106)
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((B * M + 255) / 256)), dim3(256), 0, st, S.di, 1.0, (int64_t)(B * M));
+    if (int e = mi355kkt_batch_factor(b, S.di, 1, nullptr)) return e;
+    KKT_HIP_CHECK(hipMemcpyAsync(b->pw.h_info, b->pw.d_info, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st, S.x, S.q, -1.0, (int64_t)(B * N));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.z, S.h, sizeof(double) * B * M, hipMemcpyDeviceToDevice, st));
+    if (int e = mi355kkt_batch_solve(b, S.x, S.z, 1)) return e;
+    ipm_launch_start(S, (int)B, st);
+    KKT_HIP_CHECK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < B; ++i)
+        if (b->pw.h_info[i] > 0) { set_last_error("batch_coneqp: Rank([P; G]) < n for problem %zu", i); return 1; }
+    int it = 0;
+    for (; it <= maxiters; ++it) {
+        if (int e = mi355kkt_batch_products(b, S.x, S.z, S.Gx, S.GTz, S.Px, 1)) return e;
+        KKT_HIP_CHECK(hipMemsetAsync(S.nactive, 0, sizeof(int), st));
+        ipm_launch_residual(S, (int)B, it, maxiters, abstol, reltol, feastol, st);
+        KKT_HIP_CHECK(hipMemcpyAsync(b->h_pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
+        KKT_HIP_CHECK(hipStreamSynchronize(st));
+        if (b->h_pinned[0] == 0) break;
+        if (int e = mi355kkt_batch_factor(b, S.di, 1, nullptr)) return e;
+        ipm_launch_info(S, b->pw.d_info, it, (int)B, st);
+        for (int i01 = 0; i01 < 2; ++i01) {
+            ipm_launch_rhs(S, (int)B, i01, st);
+            if (int e = mi355kkt_batch_solve(b, S.dx, S.dz, 1)) return e;
+            ipm_launch_post(S, (int)B, i01, st);
+        }
+        ipm_launch_update(S, (int)B, st);
+    }
+    b->defer_sync = false;
+    KKT_HIP_CHECK(hipMemcpyAsync(x, S.x_out, sizeof(double) * B * N, hipMemcpyDeviceToHost, st));
+    if (s) KKT_HIP_CHECK(hipMemcpyAsync(s, S.s_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
+    if (z) KKT_HIP_CHECK(hipMemcpyAsync(z, S.z_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(status, S.status, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(iters, S.iters, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    if (pcost) KKT_HIP_CHECK(hipMemcpyAsync(pcost, S.pcost, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    if (dcost) KKT_HIP_CHECK(hipMemcpyAsync(dcost, S.dcost, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    if (gap) KKT_HIP_CHECK(hipMemcpyAsync(gap, S.gap_out, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipStreamSynchronize(st));
+    if (iterations_run) *iterations_run = it;
     return 0;
 }
 

@@ -175,4 +175,27 @@ int cone_layout_set_beta(ConeLayout& cl, const double* d_beta, hipStream_t st);
 int launch_cone_scale(const ConeLayout& cl, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
                       const double* d_di, const double* d_v, const double* d_beta, double extra, hipStream_t st);
 
+// ---- device-resident LP-cone coneqp loop for a batch (batch_ipm.hip) --------------------------------
+struct IpmState {
+    int n = 0, m = 0;
+    // problem data and iterates, [B][n] / [B][m]
+    double *q = nullptr, *h = nullptr, *x = nullptr, *s = nullptr, *z = nullptr;
+    double *rx = nullptr, *rz = nullptr, *dx = nullptr, *dz = nullptr, *ds = nullptr;
+    double *lmbda = nullptr, *d = nullptr, *di = nullptr, *ws3 = nullptr;
+    double *Gx = nullptr, *GTz = nullptr, *Px = nullptr;
+    double *x_out = nullptr, *s_out = nullptr, *z_out = nullptr;
+    // per problem scalars [B]
+    double *gap = nullptr, *resx0 = nullptr, *resz0 = nullptr, *step = nullptr, *sigma = nullptr;
+    double *pcost = nullptr, *dcost = nullptr, *gap_out = nullptr;
+    int *active = nullptr, *status = nullptr, *iters = nullptr, *freeze = nullptr;
+    int* nactive = nullptr;    // one word: problems still iterating after the stopping test
+};
+void ipm_launch_start(const IpmState& S, int B, hipStream_t st);
+void ipm_launch_residual(const IpmState& S, int B, int it, int maxiters, double abstol, double reltol, double feastol,
+                         hipStream_t st);
+void ipm_launch_info(const IpmState& S, const int* d_info, int it, int B, hipStream_t st);
+void ipm_launch_rhs(const IpmState& S, int B, int i01, hipStream_t st);
+void ipm_launch_post(const IpmState& S, int B, int i01, hipStream_t st);
+void ipm_launch_update(const IpmState& S, int B, hipStream_t st);
+
 }  // namespace mi355kkt

@@ -140,6 +140,15 @@ int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device)
 int mi355kkt_batch_products(mi355kkt_batch* b, const double* x, const double* z, double* Gx, double* GTz, double* Hx,
                             int is_device);
 float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b);
+/* The whole coneqp loop (coneprog.py:2044-2547, dims = {'l': ml}, no equality constraints) for every problem of the
+ * batch with iterates, scaling and step bookkeeping resident in HBM; after set_problem().  q: [nbatch][n],
+ * h: [nbatch][ml] (host).  Outputs (host): x [nbatch][n], s, z [nbatch][ml], status [nbatch] (1 optimal, 2 unknown:
+ * iteration limit, 3 unknown: singular KKT matrix), iters, pcost, dcost, gap [nbatch]; *iterations_run = lock-step
+ * iterations executed.  Returns 0; <0 on error; 1 if the initial factorisation failed (Rank([P; G]) < n, the
+ * ValueError of coneprog.py:2065-2066). */
+int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, int maxiters, double abstol, double reltol,
+                          double feastol, double* x, double* s, double* z, int* status, int* iters, double* pcost,
+                          double* dcost, double* gap, int* iterations_run);
 
 /* ---- stand-alone device operators (each is one stage of factor()/solve(); used by the per-kernel
  * parity tests and by the profiler).  All pointers are DEVICE pointers; calls are synchronous. ---- */

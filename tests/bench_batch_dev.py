@@ -30,3 +30,10 @@ t = time.perf_counter() - t
 print("coneqp_batch: %.2f s, iterations min/mean/max %d/%.1f/%d, all optimal %s, %.1f problem-iterations/s" % (
     t, res['iterations'].min(), res['iterations'].mean(), res['iterations'].max(), bool(np.all(res['status'] == 'optimal')),
     res['iterations'].sum() / t))
+for r in range(2):
+    t = time.perf_counter()
+    res2 = coneqp_batch(P, q, Gt, h, kkt=k, resident=True)
+    t = time.perf_counter() - t
+    print("resident loop: %.3f s, iterations max %d, all optimal %s, %.1f problem-iterations/s, same iters %s" % (
+        t, res2['iterations'].max(), bool(np.all(res2['status'] == 'optimal')), res2['iterations'].sum() / t,
+        bool(np.array_equal(res2['iterations'], res['iterations']))))

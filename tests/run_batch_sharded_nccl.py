@@ -24,7 +24,7 @@ res = coneqp_batch_sharded(P, q, Gt, h)
 if rank == 0:
     ref = coneqp_batch(P, q, Gt, h, device=local)
     assert np.array_equal(res['iterations'], ref['iterations'])
-    assert np.allclose(res['x'], ref['x'], rtol=0, atol=1e-12)
+    assert np.allclose(res['x'], ref['x'], rtol=1e-9, atol=1e-11)      # resident loop vs NumPy loop: rounding only
     assert all(s == 'optimal' for s in res['status'])
     print("SHARDED_NCCL_OK world=%d problems=%d iterations=%s" % (world, len(res['iterations']), res['iterations'].tolist()))
 dist.barrier()

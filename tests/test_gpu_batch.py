@@ -68,6 +68,60 @@ def test_coneqp_batch_gpu_matches_individual_reference_runs(ref_cvxopt):
         assert relerr(res['x'][b], np.array(ref['x']).ravel()) < 1e-7
 
 
+def test_resident_loop_matches_lockstep_numpy_loop():
+    """mi355kkt_batch_coneqp (bookkeeping on the device) vs coneqp_batch's NumPy restatement, both on the GPU KKT
+    back end: same per-problem iteration counts, iterates to rounding."""
+    probs = [synth.dense_qp(64, 150, seed=300 + i) for i in range(24)]
+    probs[3]['h'] = probs[3]['h'] * 50.0
+    probs[11]['q'] = probs[11]['q'] * 1e-4
+    probs[17]['P'] = probs[17]['P'] * 1e3
+    P, q, Gt, h = pack_problems(probs)
+    host = coneqp_batch(P, q, Gt, h)
+    dev = coneqp_batch(P, q, Gt, h, resident=True)
+    assert list(dev['status']) == list(host['status'])
+    assert np.array_equal(dev['iterations'], host['iterations'])
+    assert dev['lockstep iterations'] == host['iterations'].max()
+    for b in range(len(probs)):
+        assert relerr(dev['x'][b], host['x'][b]) < 1e-9, b
+        assert relerr(dev['s'][b], host['s'][b]) < 1e-7 and relerr(dev['z'][b], host['z'][b]) < 1e-7, b
+    assert np.allclose(dev['primal objective'], host['primal objective'], rtol=1e-10, atol=1e-12)
+    assert np.allclose(dev['dual objective'], host['dual objective'], rtol=1e-9, atol=1e-10)
+    assert np.allclose(dev['gap'], host['gap'], rtol=1e-6, atol=1e-14)
+
+
+def test_resident_loop_matches_individual_reference_runs(ref_cvxopt):
+    from cvxopt import matrix, solvers
+    probs = [synth.dense_qp(40, 90, seed=60 + i) for i in range(9)]
+    probs[2]['h'] = probs[2]['h'] * 20.0
+    P, q, Gt, h = pack_problems(probs)
+    res = coneqp_batch(P, q, Gt, h, resident=True)
+    for b, pr in enumerate(probs):
+        ref = solvers.coneqp(matrix(pr['P']), matrix(pr['q']), matrix(pr['G']), matrix(pr['h']), kktsolver='chol2')
+        assert res['status'][b] == ref['status']
+        assert res['iterations'][b] == ref['iterations'], b
+        assert abs(res['primal objective'][b] - ref['primal objective']) <= 1e-9 * max(1, abs(ref['primal objective']))
+        assert abs(res['dual objective'][b] - ref['dual objective']) <= 1e-8 * max(1, abs(ref['dual objective']))
+        assert relerr(res['x'][b], np.array(ref['x']).ravel()) < 1e-7
+        assert relerr(res['s'][b], np.array(ref['s']).ravel()) < 1e-6
+        assert relerr(res['z'][b], np.array(ref['z']).ravel()) < 1e-6
+
+
+def test_resident_loop_iteration_limit_and_rank_failure():
+    probs = [synth.dense_qp(32, 64, seed=i) for i in range(4)]
+    P, q, Gt, h = pack_problems(probs)
+    host = coneqp_batch(P, q, Gt, h, maxiters=3)
+    dev = coneqp_batch(P, q, Gt, h, maxiters=3, resident=True)
+    assert list(dev['status']) == list(host['status']) == ['unknown'] * 4
+    assert np.array_equal(dev['iterations'], host['iterations']) and np.all(dev['iterations'] == 3)
+    for b in range(4):
+        assert relerr(dev['x'][b], host['x'][b]) < 1e-10
+    probs = [synth.dense_qp(40, 20, seed=i) for i in range(3)]      # rank(G) < n with P = 0
+    P, q, Gt, h = pack_problems(probs)
+    P[1] = 0.0
+    with pytest.raises(ValueError):
+        coneqp_batch(P, q, Gt, h, resident=True)
+
+
 def test_sharded_batch_on_rccl():
     """coneqp_batch_sharded on the real nccl (= RCCL) backend, launched like bench.py is (torch.distributed.run)."""
     import os
