@@ -16,6 +16,7 @@
 
 #include "../../include/mi355kkt.h"
 #include "kkt_common.h"
+#include <functional>
 
 namespace mi355kkt {
 
@@ -76,6 +77,45 @@ static inline dim3 g1(int n) { return dim3((unsigned)((n + 255) / 256)); }
 
 using namespace mi355kkt;
 
+// state of the device-resident interior-point loop (batch_ipm.hip) for B problems of one shape
+struct IpmWork {
+    IpmState S;
+    double* f64 = nullptr;
+    int* i32 = nullptr;       // active | status | iters | freeze | nactive | info
+    int* pinned = nullptr;
+    int B = 0;
+};
+static void ipm_free(IpmWork& w) {
+    if (w.f64) (void)hipFree(w.f64);
+    if (w.i32) (void)hipFree(w.i32);
+    if (w.pinned) (void)hipHostFree(w.pinned);
+    w = IpmWork();
+}
+static int ipm_alloc(IpmWork& w, int nbatch, int n, int m) {
+    if (w.f64) return 0;
+    const size_t B = nbatch, N = n, M = m ? m : 1;
+    const size_t nd = B * (7 * N + 13 * M + 8);
+    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
+    if (hipMalloc(&w.i32, sizeof(int) * (5 * B + 1)) != hipSuccess) return MI355KKT_ENOMEM;
+    if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
+    w.B = nbatch;
+    IpmState& S = w.S;
+    S.n = n; S.m = m;
+    double* p = w.f64;
+    auto take = [&](size_t k) { double* r = p; p += k; return r; };
+    S.q = take(B * N); S.x = take(B * N); S.rx = take(B * N); S.dx = take(B * N);
+    S.GTz = take(B * N); S.Px = take(B * N); S.x_out = take(B * N);
+    S.h = take(B * M); S.s = take(B * M); S.z = take(B * M); S.rz = take(B * M); S.dz = take(B * M); S.ds = take(B * M);
+    S.lmbda = take(B * M); S.d = take(B * M); S.di = take(B * M); S.ws3 = take(B * M); S.Gx = take(B * M);
+    S.s_out = take(B * M); S.z_out = take(B * M);
+    S.gap = take(B); S.resx0 = take(B); S.resz0 = take(B); S.step = take(B); S.sigma = take(B);
+    S.pcost = take(B); S.dcost = take(B); S.gap_out = take(B);
+    int* q = w.i32;
+    S.active = q; S.status = q + B; S.iters = q + 2 * B; S.freeze = q + 3 * B; S.nactive = q + 4 * B;
+    return 0;
+}
+static int* ipm_info_words(IpmWork& w) { return w.i32 + 4 * (size_t)w.B + 1; }
+
 struct mi355kkt_solver {
     int device = 0, kind = 0;
     int n = 0, p = 0, ml = 0, cdim = 0;
@@ -117,6 +157,9 @@ struct mi355kkt_solver {
     SyrkPlan planS, planAtA, planK;
     PotrfWork pw;
     float t_syrk = 0, t_potrf = 0, t_schur = 0, t_factor = 0, t_solve = 0, t_syrk_kernel = 0;
+    IpmWork ipm;               // device-resident coneqp loop (mi355kkt_coneqp_lp), allocated on first use
+    double* dHsym = nullptr;   // full symmetric copy of H for the residual product P x
+    double* dIpmWork = nullptr;
 };
 
 static int bind(const mi355kkt_solver* h) {
@@ -276,6 +319,9 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
                       h->dx, h->dy, h->dz, h->dzs, h->dtn, h->dtp, h->dwork, h->dWst, h->dGs, h->dV, h->dBeta, h->dRti};
     cone_layout_free(h->cl);
     sparse_engine_free(h->sp);
+    ipm_free(h->ipm);
+    if (h->dHsym) (void)hipFree(h->dHsym);
+    if (h->dIpmWork) (void)hipFree(h->dIpmWork);
     if (h->dflags) (void)hipFree(h->dflags);
     if (h->derr) (void)hipFree(h->derr);
     if (h->herr) (void)hipHostFree(h->herr);
@@ -684,10 +730,7 @@ struct mi355kkt_batch {
     PotrfWork pw;
     float t_factor = 0;
     bool defer_sync = false;          // set by the device-resident loop: the public calls then only enqueue
-    IpmState ipm;                     // allocated on the first mi355kkt_batch_coneqp call
-    double* ipm_f64 = nullptr;
-    int* ipm_i32 = nullptr;
-    int* h_pinned = nullptr;
+    IpmWork ipm;                      // allocated on the first mi355kkt_batch_coneqp call
 };
 
 extern "C" {
@@ -729,9 +772,7 @@ void mi355kkt_batch_destroy(mi355kkt_batch* b) {
     if (b->st) (void)hipStreamSynchronize(b->st);
     double* bufs[] = {b->dG, b->dH, b->dS, b->dW, b->dx, b->dz, b->dzs, b->dwork, b->dt1, b->dt2};
     for (double* p : bufs) if (p) (void)hipFree(p);
-    if (b->ipm_f64) (void)hipFree(b->ipm_f64);
-    if (b->ipm_i32) (void)hipFree(b->ipm_i32);
-    if (b->h_pinned) (void)hipHostFree(b->h_pinned);
+    ipm_free(b->ipm);
     potrf_work_free(b->pw);
     free_syrk_plan(b->plan);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
@@ -844,90 +885,151 @@ int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device)
     return 0;
 }
 
-static int ipm_alloc(mi355kkt_batch* b) {
-    if (b->ipm_f64) return 0;
-    const size_t B = b->nbatch, N = b->n, M = b->ml ? b->ml : 1;
-    const size_t nd = B * (7 * N + 13 * M + 8);
-    if (hipMalloc(&b->ipm_f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
-    if (hipMalloc(&b->ipm_i32, sizeof(int) * (4 * B + 1)) != hipSuccess) return MI355KKT_ENOMEM;
-    if (hipHostMalloc(&b->h_pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
-    IpmState& S = b->ipm;
-    S.n = b->n; S.m = b->ml;
-    double* p = b->ipm_f64;
-    auto take = [&](size_t k) { double* r = p; p += k; return r; };
-    S.q = take(B * N); S.x = take(B * N); S.rx = take(B * N); S.dx = take(B * N);
-    S.GTz = take(B * N); S.Px = take(B * N); S.x_out = take(B * N);
-    S.h = take(B * M); S.s = take(B * M); S.z = take(B * M); S.rz = take(B * M); S.dz = take(B * M); S.ds = take(B * M);
-    S.lmbda = take(B * M); S.d = take(B * M); S.di = take(B * M); S.ws3 = take(B * M); S.Gx = take(B * M);
-    S.s_out = take(B * M); S.z_out = take(B * M);
-    S.gap = take(B); S.resx0 = take(B); S.resz0 = take(B); S.step = take(B); S.sigma = take(B);
-    S.pcost = take(B); S.dcost = take(B); S.gap_out = take(B);
-    int* q = b->ipm_i32;
-    S.active = q; S.status = q + B; S.iters = q + 2 * B; S.freeze = q + 3 * B; S.nactive = q + 4 * B;
+}  // extern "C"
+
+// The interior-point loop itself, shared by the batched and the single-problem entry points.  `ops` supplies the KKT
+// work on the caller's stream: products (fills S.Gx, S.GTz, S.Px from S.x, S.z), factor (from S.di; must leave the
+// per-problem info words at d_info, on the device) and solve (in place on S.dx, S.dz).
+struct IpmOps {
+    std::function<int()> products;
+    std::function<int(const double* di, int* d_info, int* h_info_first)> factor;
+    std::function<int(double* dx, double* dz)> solve;
+};
+struct IpmHostOut {
+    double *x, *s, *z; int *status, *iters; double *pcost, *dcost, *gap; int* iterations_run;
+};
+static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, const double* h, int maxiters, double abstol,
+                   double reltol, double feastol, const IpmHostOut& o) {
+    const IpmState& S = w.S;
+    const size_t B = w.B, N = S.n, M = S.m;
+    int* d_info = ipm_info_words(w);
+    KKT_HIP_CHECK(hipMemcpyAsync(S.q, q, sizeof(double) * B * N, hipMemcpyHostToDevice, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.h, h, sizeof(double) * B * M, hipMemcpyHostToDevice, st));
+    KKT_HIP_CHECK(hipMemsetAsync(w.i32, 0, sizeof(int) * (5 * B + 1), st));
+    // ---- starting point: W = I  (coneprog.py:2055-2106)
+    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((B * M + 255) / 256)), dim3(256), 0, st, S.di, 1.0, (int64_t)(B * M));
+    int first_bad = -1;
+    if (int e = ops.factor(S.di, d_info, &first_bad)) return e;
+    if (first_bad >= 0) { set_last_error("coneqp: Rank([P; G]) < n (problem %d)", first_bad); return 1; }
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st, S.x, S.q, -1.0, (int64_t)(B * N));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.z, S.h, sizeof(double) * B * M, hipMemcpyDeviceToDevice, st));
+    if (int e = ops.solve(S.x, S.z)) return e;
+    ipm_launch_start(S, (int)B, st);
+    int it = 0;
+    for (; it <= maxiters; ++it) {
+        if (int e = ops.products()) return e;
+        KKT_HIP_CHECK(hipMemsetAsync(S.nactive, 0, sizeof(int), st));
+        ipm_launch_residual(S, (int)B, it, maxiters, abstol, reltol, feastol, st);
+        KKT_HIP_CHECK(hipMemcpyAsync(w.pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
+        KKT_HIP_CHECK(hipStreamSynchronize(st));
+        if (w.pinned[0] == 0) break;
+        if (int e = ops.factor(S.di, d_info, nullptr)) return e;
+        ipm_launch_info(S, d_info, it, (int)B, st);
+        for (int i01 = 0; i01 < 2; ++i01) {
+            ipm_launch_rhs(S, (int)B, i01, st);
+            if (int e = ops.solve(S.dx, S.dz)) return e;
+            ipm_launch_post(S, (int)B, i01, st);
+        }
+        ipm_launch_update(S, (int)B, st);
+    }
+    KKT_HIP_CHECK(hipMemcpyAsync(o.x, S.x_out, sizeof(double) * B * N, hipMemcpyDeviceToHost, st));
+    if (o.s) KKT_HIP_CHECK(hipMemcpyAsync(o.s, S.s_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
+    if (o.z) KKT_HIP_CHECK(hipMemcpyAsync(o.z, S.z_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(o.status, S.status, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(o.iters, S.iters, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+    if (o.pcost) KKT_HIP_CHECK(hipMemcpyAsync(o.pcost, S.pcost, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    if (o.dcost) KKT_HIP_CHECK(hipMemcpyAsync(o.dcost, S.dcost, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    if (o.gap) KKT_HIP_CHECK(hipMemcpyAsync(o.gap, S.gap_out, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipStreamSynchronize(st));
+    if (o.iterations_run) *o.iterations_run = it;
     return 0;
 }
 
+extern "C" {
+
 /* The whole LP-cone coneqp loop (reference coneprog.py:2044-2547 with dims = {'l': ml}, no equalities) for every problem
  * of the batch, iterates and bookkeeping resident in HBM; per iteration only the count of still-active problems returns to
- * the host.  q: [nbatch][n], h: [nbatch][ml] (host).  Outputs (host): x [nbatch][n], s, z [nbatch][ml], status [nbatch]
- * (1 optimal, 2 unknown: iteration limit, 3 unknown: singular KKT matrix), iters, pcost, dcost, gap [nbatch].
- * Returns 0, <0 on error, or 1 when the very first factorisation failed for some problem (Rank([P; G]) < n;
- * coneprog.py:2065-2066 raises ValueError). */
+ * the host.  See include/mi355kkt.h. */
 int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, int maxiters, double abstol, double reltol,
                           double feastol, double* x, double* s, double* z, int* status, int* iters, double* pcost,
                           double* dcost, double* gap, int* iterations_run) {
     if (!b || !q || (!h && b->ml) || !x || !status || !iters) { set_last_error("batch_coneqp: null argument"); return MI355KKT_EINVAL; }
     if (b->ml < 1) { set_last_error("batch_coneqp: needs at least one inequality"); return MI355KKT_EINVAL; }
     KKT_HIP_CHECK(hipSetDevice(b->device));
-    if (int e = ipm_alloc(b)) return e;
-    const size_t B = b->nbatch, N = b->n, M = b->ml;
-    const IpmState& S = b->ipm;
+    if (int e = ipm_alloc(b->ipm, b->nbatch, b->n, b->ml)) return e;
+    const IpmState& S = b->ipm.S;
     struct Guard { mi355kkt_batch* b; ~Guard() { b->defer_sync = false; } } guard{b};
-    hipStream_t st = b->st;
-    KKT_HIP_CHECK(hipMemcpyAsync(S.q, q, sizeof(double) * B * N, hipMemcpyHostToDevice, st));
-    KKT_HIP_CHECK(hipMemcpyAsync(S.h, h, sizeof(double) * B * M, hipMemcpyHostToDevice, st));
-    KKT_HIP_CHECK(hipMemsetAsync(b->ipm_i32, 0, sizeof(int) * (4 * B + 1), st));
     b->defer_sync = true;
-    // ---- starting point: W = I  (coneprog.py:2055-2106)
-    hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((B * M + 255) / 256)), dim3(256), 0, st, S.di, 1.0, (int64_t)(B * M));
-    if (int e = mi355kkt_batch_factor(b, S.di, 1, nullptr)) return e;
-    KKT_HIP_CHECK(hipMemcpyAsync(b->pw.h_info, b->pw.d_info, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st, S.x, S.q, -1.0, (int64_t)(B * N));
-    KKT_HIP_CHECK(hipMemcpyAsync(S.z, S.h, sizeof(double) * B * M, hipMemcpyDeviceToDevice, st));
-    if (int e = mi355kkt_batch_solve(b, S.x, S.z, 1)) return e;
-    ipm_launch_start(S, (int)B, st);
-    KKT_HIP_CHECK(hipStreamSynchronize(st));
-    for (size_t i = 0; i < B; ++i)
-        if (b->pw.h_info[i] > 0) { set_last_error("batch_coneqp: Rank([P; G]) < n for problem %zu", i); return 1; }
-    int it = 0;
-    for (; it <= maxiters; ++it) {
-        if (int e = mi355kkt_batch_products(b, S.x, S.z, S.Gx, S.GTz, S.Px, 1)) return e;
-        KKT_HIP_CHECK(hipMemsetAsync(S.nactive, 0, sizeof(int), st));
-        ipm_launch_residual(S, (int)B, it, maxiters, abstol, reltol, feastol, st);
-        KKT_HIP_CHECK(hipMemcpyAsync(b->h_pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
-        KKT_HIP_CHECK(hipStreamSynchronize(st));
-        if (b->h_pinned[0] == 0) break;
-        if (int e = mi355kkt_batch_factor(b, S.di, 1, nullptr)) return e;
-        ipm_launch_info(S, b->pw.d_info, it, (int)B, st);
-        for (int i01 = 0; i01 < 2; ++i01) {
-            ipm_launch_rhs(S, (int)B, i01, st);
-            if (int e = mi355kkt_batch_solve(b, S.dx, S.dz, 1)) return e;
-            ipm_launch_post(S, (int)B, i01, st);
+    IpmOps ops;
+    ops.products = [&]() { return mi355kkt_batch_products(b, S.x, S.z, S.Gx, S.GTz, S.Px, 1); };
+    ops.factor = [&](const double* di, int* d_info, int* first_bad) -> int {
+        if (int e = mi355kkt_batch_factor(b, di, 1, nullptr)) return e;
+        KKT_HIP_CHECK(hipMemcpyAsync(d_info, b->pw.d_info, sizeof(int) * b->nbatch, hipMemcpyDeviceToDevice, b->st));
+        if (first_bad) {
+            KKT_HIP_CHECK(hipMemcpyAsync(b->pw.h_info, b->pw.d_info, sizeof(int) * b->nbatch, hipMemcpyDeviceToHost, b->st));
+            KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+            for (int i = 0; i < b->nbatch; ++i)
+                if (b->pw.h_info[i] > 0) { *first_bad = i; break; }
         }
-        ipm_launch_update(S, (int)B, st);
+        return 0;
+    };
+    ops.solve = [&](double* dx, double* dz) { return mi355kkt_batch_solve(b, dx, dz, 1); };
+    IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, iterations_run};
+    return run_ipm(b->ipm, b->st, ops, q, h, maxiters, abstol, reltol, feastol, o);
+}
+
+/* Single problem, LP cone, no equality constraints: the coneqp loop of coneprog.py:2044-2547 resident on the device around
+ * this handle's own factor/solve (dense or sparse mode).  G (and H, if any) must have been set.  See include/mi355kkt.h. */
+int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, int maxiters, double abstol, double reltol,
+                       double feastol, double* x, double* s, double* z, int* status, int* iters, double* pcost,
+                       double* dcost, double* gap) {
+    if (!hs || !q || !hv || !x || !status || !iters) { set_last_error("coneqp_lp: null argument"); return MI355KKT_EINVAL; }
+    if (!hs->q.empty() || !hs->s.empty() || hs->p != 0 || hs->ml < 1) {
+        set_last_error("coneqp_lp: needs dims = {'l': m > 0} and no equality constraints");
+        return MI355KKT_ENOTIMPL;
     }
-    b->defer_sync = false;
-    KKT_HIP_CHECK(hipMemcpyAsync(x, S.x_out, sizeof(double) * B * N, hipMemcpyDeviceToHost, st));
-    if (s) KKT_HIP_CHECK(hipMemcpyAsync(s, S.s_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
-    if (z) KKT_HIP_CHECK(hipMemcpyAsync(z, S.z_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
-    KKT_HIP_CHECK(hipMemcpyAsync(status, S.status, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    KKT_HIP_CHECK(hipMemcpyAsync(iters, S.iters, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    if (pcost) KKT_HIP_CHECK(hipMemcpyAsync(pcost, S.pcost, sizeof(double) * B, hipMemcpyDeviceToHost, st));
-    if (dcost) KKT_HIP_CHECK(hipMemcpyAsync(dcost, S.dcost, sizeof(double) * B, hipMemcpyDeviceToHost, st));
-    if (gap) KKT_HIP_CHECK(hipMemcpyAsync(gap, S.gap_out, sizeof(double) * B, hipMemcpyDeviceToHost, st));
-    KKT_HIP_CHECK(hipStreamSynchronize(st));
-    if (iterations_run) *iterations_run = it;
-    return 0;
+    if (hs->sparse) { set_last_error("coneqp_lp: sparse mode not supported yet"); return MI355KKT_ENOTIMPL; }
+    if (int e = bind(hs)) return e;
+    const int n = hs->n, m = hs->ml;
+    if (int e = ipm_alloc(hs->ipm, 1, n, m)) return e;
+    const IpmState& S = hs->ipm.S;
+    hipStream_t st = hs->st;
+    if (hs->dH) {     // only tril(H) is meaningful (coneprog.py:1475-1477): P x needs the mirrored matrix
+        if (!hs->dHsym) KKT_HIP_CHECK(hipMalloc(&hs->dHsym, sizeof(double) * (size_t)n * n));
+        KKT_HIP_CHECK(hipMemcpy2DAsync(hs->dHsym, sizeof(double) * n, hs->dH, sizeof(double) * hs->ldH, sizeof(double) * n, n,
+                                       hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(symmetrize_kernel, dim3((n + 15) / 16, (n + 15) / 16, 1), dim3(16, 16), 0, st, hs->dHsym, n, (int64_t)0);
+    }
+    double* scratch = hs->dzs;       // >= cdim doubles; free between solves
+    if (!hs->dIpmWork)
+        KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n))));
+    double* gwork = hs->dIpmWork;
+    IpmOps ops;
+    ops.products = [&]() -> int {
+        if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, S.x, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
+        KKT_HIP_CHECK(hipMemsetAsync(S.GTz, 0, sizeof(double) * n, st));
+        if (int e = launch_gemv_t_scaled(hs->dG, hs->ldG, m, n, nullptr, S.z, scratch, S.GTz, gwork, st)) return e;
+        if (hs->dH) {
+            if (int e = launch_gemv_n_scaled(hs->dHsym, n, n, n, nullptr, S.x, S.Px, S.Px, 1.0, 0.0, gwork, st)) return e;
+        } else {
+            KKT_HIP_CHECK(hipMemsetAsync(S.Px, 0, sizeof(double) * n, st));
+        }
+        return 0;
+    };
+    ops.factor = [&](const double* di, int* d_info, int* first_bad) -> int {
+        mi355kkt_scaling W = {};
+        W.di = di;
+        const int info = mi355kkt_factor_device(hs, &W);
+        if (info < 0) return info;
+        if (first_bad && info > 0) *first_bad = 0;
+        hs->ipm.pinned[1] = info;
+        KKT_HIP_CHECK(hipMemcpyAsync(d_info, hs->ipm.pinned + 1, sizeof(int), hipMemcpyHostToDevice, st));
+        if (info > 0) hs->factored = true;   // the loop drops the problem before any solve result is used
+        return 0;
+    };
+    ops.solve = [&](double* dx, double* dz) { return mi355kkt_solve_device(hs, dx, nullptr, dz); };
+    IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, nullptr};
+    return run_ipm(hs->ipm, st, ops, q, hv, maxiters, abstol, reltol, feastol, o);
 }
 
 float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b) { return b ? b->t_factor : 0.0f; }

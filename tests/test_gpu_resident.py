@@ -1,0 +1,86 @@
+"""Device-resident coneqp loop (SURVEY.md 8(f) row 1) for a single LP-cone QP: mi355kkt_coneqp_lp vs the reference
+driver (same iterates: status, iteration count, objectives, x/s/z), the committed golden run, and -- at BASELINE
+configs[1]'s full size -- the surveyor's probe values of the unmodified reference."""
+import time
+
+import numpy as np
+import pytest
+
+import cvxopt_amd
+from cvxopt_amd import synth
+from helpers import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_resident_coneqp_matches_golden_reference_run():
+    g = load_golden("coneqp_qp256")
+    pr = synth.dense_qp(int(g['n']), int(g['m']), seed=int(g['seed']))
+    sol = cvxopt_amd.coneqp_lp(pr['P'], pr['q'], pr['G'], pr['h'])
+    assert sol['status'] == 'optimal' and sol['iterations'] == int(g['iterations'])
+    assert abs(sol['primal objective'] - float(g['pobj'])) <= 1e-9 * abs(float(g['pobj']))
+    assert relerr(sol['x'], g['x']) < 1e-7
+
+
+@pytest.mark.parametrize("n,m,kind", [(48, 100, 'chol2'), (200, 333, 'chol'), (130, 61, 'ldl'), (300, 700, 'ldl2')])
+def test_resident_coneqp_matches_reference_driver(ref_cvxopt, n, m, kind):
+    from cvxopt import matrix, solvers
+    pr = synth.dense_qp(n, m, seed=n + m)
+    ref = solvers.coneqp(matrix(pr['P']), matrix(pr['q']), matrix(pr['G']), matrix(pr['h']), kktsolver='chol2')
+    sol = cvxopt_amd.coneqp_lp(matrix(pr['P']), pr['q'], matrix(pr['G']), pr['h'], kktsolver=kind)
+    assert sol['status'] == ref['status'] == 'optimal'
+    assert sol['iterations'] == ref['iterations']
+    for k in ('primal objective', 'dual objective'):
+        assert abs(sol[k] - ref[k]) <= 1e-9 * max(1.0, abs(ref[k])), k
+    assert abs(sol['gap'] - ref['gap']) <= 1e-6 * ref['gap'] + 1e-14
+    assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-7
+    assert relerr(sol['s'], np.array(ref['s']).ravel()) < 1e-6
+    assert relerr(sol['z'], np.array(ref['z']).ravel()) < 1e-6
+
+
+def test_resident_coneqp_only_reads_tril_of_P_and_handles_lp(ref_cvxopt):
+    from cvxopt import matrix, solvers
+    pr = synth.dense_qp(60, 140, seed=5)
+    Pl = np.tril(pr['P']) + np.triu(np.full((60, 60), 7.0), 1)          # garbage above the diagonal
+    a = cvxopt_amd.coneqp_lp(Pl, pr['q'], pr['G'], pr['h'])
+    b = cvxopt_amd.coneqp_lp(pr['P'], pr['q'], pr['G'], pr['h'])
+    assert a['iterations'] == b['iterations'] and relerr(a['x'], b['x']) < 1e-12
+    # P = None: an LP in coneqp form, bounded because G has a box part
+    rng = np.random.default_rng(3)
+    n = 30
+    G = np.vstack([np.eye(n), -np.eye(n), rng.standard_normal((20, n))])
+    h = np.concatenate([np.ones(2 * n), 5.0 + rng.random(20)])
+    q = rng.standard_normal(n)
+    sol = cvxopt_amd.coneqp_lp(None, q, G, h)
+    ref = solvers.coneqp(matrix(np.zeros((n, n))), matrix(q), matrix(G), matrix(h), kktsolver='chol2')
+    assert sol['status'] == ref['status'] and sol['iterations'] == ref['iterations']
+    assert abs(sol['primal objective'] - ref['primal objective']) <= 1e-8 * max(1, abs(ref['primal objective']))
+
+
+def test_resident_coneqp_errors():
+    pr = synth.dense_qp(40, 20, seed=1)
+    with pytest.raises(ValueError):                                     # Rank([P; G]) < n
+        cvxopt_amd.coneqp_lp(None, pr['q'], pr['G'], pr['h'])
+    pr = synth.dense_qp(32, 64, seed=2)
+    sol = cvxopt_amd.coneqp_lp(pr['P'], pr['q'], pr['G'], pr['h'], maxiters=2)
+    assert sol['status'] == 'unknown' and sol['iterations'] == 2
+
+
+def test_resident_coneqp_full_size_config2():
+    """n = 8192, m = 16384: reference probe (SURVEY.md 8(d)): 16 iterations, pobj 3.616388620214e+03,
+    dobj 3.616388571214e+03."""
+    n, m = 8192, 16384
+    pr = synth.dense_qp(n, m, seed=0)
+    t = time.perf_counter()
+    sol = cvxopt_amd.coneqp_lp(pr['P'], pr['q'], pr['G'], pr['h'])
+    t = time.perf_counter() - t
+    print("resident coneqp n=8192: %.2f s wall incl. upload, %d iterations" % (t, sol['iterations']))
+    assert sol['status'] == 'optimal' and sol['iterations'] == 16
+    assert abs(sol['primal objective'] - 3.616388620214e+03) <= 1e-8 * 3.616388620214e+03
+    assert abs(sol['dual objective'] - 3.616388571214e+03) <= 1e-8 * 3.616388571214e+03
+    # size-independent properties: primal/dual feasibility and complementarity of the returned point
+    x, s, z = sol['x'], sol['s'], sol['z']
+    assert np.all(s > 0) and np.all(z > 0)
+    assert np.linalg.norm(pr['G'] @ x + s - pr['h']) <= 1e-7 * max(1.0, np.linalg.norm(pr['h']))
+    assert np.linalg.norm(pr['P'] @ x + pr['q'] + pr['G'].T @ z) <= 1e-7 * max(1.0, np.linalg.norm(pr['q']))
+    assert abs(s @ z - sol['gap']) <= 1e-9 * max(1.0, sol['gap'])
