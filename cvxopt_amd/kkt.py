@@ -278,12 +278,13 @@ class _Engine(object):
     def sync(self):
         _capi.check(self.L.mi355kkt_sync(self.h), "mi355kkt_sync")
 
-    def coneqp(self, q, h, P=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):
+    def coneqp(self, q, h, P=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, keep_H=False):
         """The reference coneqp loop (coneprog.py:2044-2547; LP cone, no equalities) resident on the device around
         this handle (`mi355kkt_coneqp_lp`).  Returns a dict with the reference's keys, vectors as NumPy arrays."""
         if self.dims['q'] or self.dims['s'] or self.p:
             raise NotImplementedError("device-resident coneqp: LP cone without equality constraints only")
-        self._set_H(P)
+        if not keep_H:                    # keep_H: H was placed with set_H_device / a previous call
+            self._set_H(P)
         if self._mode != "dense":
             raise NotImplementedError("device-resident coneqp: dense mode only")
         n, m = self.n, self.cdim
