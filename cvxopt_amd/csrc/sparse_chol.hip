@@ -226,20 +226,27 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
             std::sort(s.begin(), s.end());
         }
     }
-    // ---- supernodes: j+1 joins j's supernode when parent[j] == j+1, j is the only child of j+1 and
-    //      struct(j) == {j+1} U struct(j+1) (fundamental); small chains are also merged when the fill is small.
+    // ---- supernodes: column j joins the supernode that ends at j-1 when parent[j-1] == j (so struct(j-1) \ {j} is
+    //      contained in struct(j)) and the explicit zeros this adds to the stored panel stay a small fraction of it.
+    //      Exact (fundamental) merges add none; relaxed merges trade a little fill for far fewer, denser fronts and a
+    //      much shallower supernodal tree (other subtrees may hang off any column of the supernode).
     std::vector<int> sn_first;   // first column of each supernode
     std::vector<int> sn_of(n, 0);
     const int MAXW = 256;
+    int64_t true_nnz = 0;        // nonzeros of L in the columns of the current supernode
     for (int j = 0; j < n; ++j) {
         bool join = false;
-        if (j > 0 && parent[j - 1] == j && child[j].size() == 1) {
+        const int64_t cj = 1 + (int64_t)st[j].size();
+        if (j > 0 && parent[j - 1] == j) {
             const int first = sn_first.back();
-            const bool exact = st[j - 1].size() == st[j].size() + 1;
-            const bool relaxed = (j - first) < 8 && st[j - 1].size() <= st[j].size() + 3;   // tiny extra fill
-            if ((exact || relaxed) && (j - first) < MAXW) join = true;
+            const int64_t wn = j - first + 1;
+            const int64_t stored = wn * (int64_t)st[j].size() + wn * (wn + 1) / 2;   // trapezoid ending at column j
+            const int64_t zeros = stored - (true_nnz + cj);
+            const double lim = wn <= 4 ? 0.5 : (wn <= 16 ? 0.3 : (wn <= 64 ? 0.2 : 0.1));
+            if (wn <= MAXW && (zeros == 0 || (double)zeros <= lim * (double)stored)) join = true;
         }
-        if (!join) sn_first.push_back(j);
+        if (!join) { sn_first.push_back(j); true_nnz = 0; }
+        true_nnz += cj;
         sn_of[j] = (int)sn_first.size() - 1;
     }
     const int ns = (int)sn_first.size();
@@ -326,6 +333,22 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         std::stable_partition(S.level_sn.begin() + S.level_ptr[l], S.level_sn.begin() + S.level_ptr[l + 1],
                               [&](int sn) { return !S.big[sn]; });
         for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) S.level_nsmall[l] += !S.big[S.level_sn[k]];
+    }
+    if (getenv("MI355KKT_SPARSE_DEBUG")) {
+        fprintf(stderr, "[sparse] n=%d supernodes=%d levels=%d store=%.1f MB\n", n, ns, S.nlevels, off * 8.0 / 1e6);
+        for (int l = 0; l < S.nlevels; ++l) {
+            int nb = 0, nsm = 0, maxh_s = 0, maxh_b = 0, maxw_b = 0;
+            double fs = 0, fb = 0, fmax_s = 0;
+            for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
+                const int sn = S.level_sn[k];
+                const int64_t h = S.sn_rowptr[sn + 1] - S.sn_rowptr[sn], w = S.sn_first[sn + 1] - S.sn_first[sn];
+                const double fl = (double)w * h * h;
+                if (S.big[sn]) { nb++; fb += fl; maxh_b = std::max<int>(maxh_b, (int)h); maxw_b = std::max<int>(maxw_b, (int)w); }
+                else { nsm++; fs += fl; fmax_s = std::max(fmax_s, fl); maxh_s = std::max<int>(maxh_s, (int)h); }
+            }
+            fprintf(stderr, "[sparse] level %3d: small %6d (flops %.2e, max %.2e, max h %4d) big %4d (flops %.2e, max h %5d, max w %3d)\n",
+                    l, nsm, fs, fmax_s, maxh_s, nb, fb, maxh_b, maxw_b);
+        }
     }
     // children lists + extend-add maps: position of each below-row of child c inside the parent's row list
     S.child_ptr.assign(ns + 1, 0);
