@@ -120,6 +120,7 @@ struct SparseSymbolic {
     std::vector<int64_t> panel_off, upd_off, relmap_off;
     std::vector<int> upd_ld, level_nsmall;
     std::vector<char> big;
+    std::vector<int> heavy, heavy_ptr, heavy_maxhu, heavy_maxw;   // per level: supernodes with large off-diagonal panels
     int64_t store_doubles = 0;
     std::vector<int> child_ptr, child_list, relmap;
     std::vector<int64_t> asm_slot, asm_ptr;       // numeric assembly: one entry per structural nonzero of S
@@ -130,7 +131,8 @@ struct SparseEngine {
     int n = 0, m = 0;
     int *d_sn_first = nullptr, *d_sn_rows = nullptr, *d_child_ptr = nullptr, *d_child_list = nullptr, *d_relmap = nullptr,
         *d_level_sn = nullptr, *d_asm_a = nullptr, *d_asm_b = nullptr, *d_asm_r = nullptr, *d_perm = nullptr,
-        *d_gri = nullptr, *d_gci = nullptr, *d_gnzmap = nullptr, *d_info = nullptr, *h_info = nullptr, *d_upd_ld = nullptr;
+        *d_gri = nullptr, *d_gci = nullptr, *d_gnzmap = nullptr, *d_info = nullptr, *h_info = nullptr, *d_upd_ld = nullptr,
+        *d_heavy = nullptr;
     static constexpr int NSTREAMS = 8;
     PotrfWork pws[NSTREAMS];
     hipStream_t streams[NSTREAMS] = {};

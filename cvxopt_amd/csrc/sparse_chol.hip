@@ -334,6 +334,23 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
                               [&](int sn) { return !S.big[sn]; });
         for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) S.level_nsmall[l] += !S.big[S.level_sn[k]];
     }
+    // supernodes whose off-diagonal panel is large: their solve-phase products run as multi-workgroup kernels
+    S.heavy_ptr.assign(S.nlevels + 1, 0);
+    S.heavy_maxhu.assign(S.nlevels, 0);
+    S.heavy_maxw.assign(S.nlevels, 0);
+    S.heavy.clear();
+    for (int l = 0; l < S.nlevels; ++l) {
+        for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
+            const int sn = S.level_sn[k];
+            const int64_t h = S.sn_rowptr[sn + 1] - S.sn_rowptr[sn], w = S.sn_first[sn + 1] - S.sn_first[sn];
+            if ((h - w) * w > 32768) {      // == SP_HEAVY in the kernels
+                S.heavy.push_back(sn);
+                S.heavy_maxhu[l] = std::max<int>(S.heavy_maxhu[l], (int)(h - w));
+                S.heavy_maxw[l] = std::max<int>(S.heavy_maxw[l], (int)w);
+            }
+        }
+        S.heavy_ptr[l + 1] = (int)S.heavy.size();
+    }
     if (getenv("MI355KKT_SPARSE_DEBUG")) {
         fprintf(stderr, "[sparse] n=%d supernodes=%d levels=%d store=%.1f MB\n", n, ns, S.nlevels, off * 8.0 / 1e6);
         for (int l = 0; l < S.nlevels; ++l) {
@@ -578,11 +595,85 @@ __global__ void sp_merge_info_kernel(const int* __restrict__ local, int offset, 
     if (*local > 0) atomicMin(global, offset + *local);
 }
 
+// ---- triangular solves with one supernode's w x w diagonal block (w <= 256), right-hand side in LDS ----------------
+// 32-column blocks: wave 0 solves the 32 x 32 diagonal block with its rows (columns for the transposed solve) in
+// registers and v_readlane-style broadcasts -- no barrier on the 32-step dependency chain -- then all four waves apply
+// the block to the rest of the vector.
+constexpr int SPB = 32;
+constexpr int64_t SP_HEAVY = 32768;     // supernodes with more off-diagonal panel entries get the multi-workgroup kernels
+
+__device__ __forceinline__ void sp_trsv_fwd_lds(const double* __restrict__ P, int h, int w, double* xs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int jb = 0; jb < w; jb += SPB) {
+        const int nbk = min(SPB, w - jb);
+        if (wave == 0) {
+            double Lr[SPB];
+            const int r = min(lane, nbk - 1);
+#pragma unroll
+            for (int k = 0; k < SPB; ++k) Lr[k] = (k < nbk) ? P[(jb + r) + (int64_t)(jb + k) * h] : 1.0;
+            double xi = (lane < nbk) ? xs[jb + lane] : 0.0;
+#pragma unroll
+            for (int k = 0; k < SPB; ++k) {
+                if (lane == k) xi = xi / Lr[k];
+                const double v = __shfl(xi, k, 64);
+                if (lane > k && lane < nbk) xi -= Lr[k] * v;
+            }
+            if (lane < nbk) xs[jb + lane] = xi;
+        }
+        __syncthreads();
+        for (int i = jb + nbk + tid; i < w; i += 256) {
+            double acc = 0.0;
+            for (int k = 0; k < nbk; ++k) acc += P[i + (int64_t)(jb + k) * h] * xs[jb + k];
+            xs[i] -= acc;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void sp_trsv_bwd_lds(const double* __restrict__ P, int h, int w, double* xs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = (w + SPB - 1) / SPB;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int jb = b * SPB;
+        const int nbk = min(SPB, w - jb);
+        if (wave == 0) {
+            double Lc[SPB];      // Lc[k] = L[jb + k][jb + lane]  (column `lane` of the block)
+            const int c = min(lane, nbk - 1);
+#pragma unroll
+            for (int k = 0; k < SPB; ++k) Lc[k] = (k < nbk) ? P[(jb + k) + (int64_t)(jb + c) * h] : 1.0;
+            double xi = (lane < nbk) ? xs[jb + lane] : 0.0;
+#pragma unroll
+            for (int k = SPB - 1; k >= 0; --k) {
+                if (k < nbk) {
+                    if (lane == k) xi = xi / Lc[k];
+                    const double v = __shfl(xi, k, 64);
+                    if (lane < k) xi -= Lc[k] * v;
+                }
+            }
+            if (lane < nbk) xs[jb + lane] = xi;
+        }
+        __syncthreads();
+        {   // columns to the left: xs[i] -= sum_k L[jb + k][i] xs[jb + k]; 32 lanes share one column (contiguous in memory)
+            const int k = tid & 31, g = tid >> 5;
+            const double xk = (k < nbk) ? xs[jb + k] : 0.0;
+            for (int i = g; i < jb; i += 8) {
+                double v = (k < nbk) ? P[(jb + k) + (int64_t)i * h] * xk : 0.0;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (k == 0) xs[i] -= v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // forward substitution, one workgroup per supernode of a level:  y_s = L11^-1 (b_s + children updates),
-// then the front's right-hand-side remainder r_s = (children updates below) - L21 y_s is left for the parent.
+// then the front's right-hand-side remainder r_s = (children updates below) - L21 y_s is left for the parent
+// (by sp_fwd_rem_kernel, many workgroups, when the panel is large).
 __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, const double* __restrict__ panels,
                                                      double* __restrict__ x, double* __restrict__ rem,
                                                      const int64_t* __restrict__ rem_off) {
+    __shared__ double xs[256];
     const int s = d.level_sn[level_begin + blockIdx.x];
     const int tid = threadIdx.x;
     const int f = d.sn_first[s];
@@ -592,6 +683,7 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
     const double* __restrict__ P = panels + d.panel_off[s];
     double* __restrict__ R = rem + rem_off[s];          // hu entries
     for (int i = tid; i < hu; i += 256) R[i] = 0.0;
+    if (tid < w) xs[tid] = x[f + tid];
     __syncthreads();
     for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
         const int c = d.child_list[ci];
@@ -600,59 +692,94 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
         const int* __restrict__ rm = d.relmap + d.relmap_off[c];
         for (int i = tid; i < hc; i += 256) {
             const int p = rm[i];
-            if (p < w) x[f + p] += Rc[i];
+            if (p < w) xs[p] += Rc[i];
             else R[p - w] += Rc[i];
         }
-        __syncthreads();
+        __syncthreads();   // children one after the other: deterministic, no atomics
     }
-    // dense forward substitution on the w x w triangle (column sweep)
-    for (int j = 0; j < w; ++j) {
-        __shared__ double xj;
-        if (tid == 0) {
-            xj = x[f + j] / P[j + (int64_t)j * h];
-            x[f + j] = xj;
-        }
-        __syncthreads();
-        const double v = xj;
-        for (int i = j + 1 + tid; i < w; i += 256) x[f + i] -= P[i + (int64_t)j * h] * v;
-        __syncthreads();
-    }
-    // remainder: R -= L21 y
+    sp_trsv_fwd_lds(P, h, w, xs);
+    if (tid < w) x[f + tid] = xs[tid];
+    if ((int64_t)hu * w > SP_HEAVY) return;             // remainder by sp_fwd_rem_kernel
     for (int i = tid; i < hu; i += 256) {
         double sacc = 0.0;
-        for (int j = 0; j < w; ++j) sacc += P[(w + i) + (int64_t)j * h] * x[f + j];
+        for (int j = 0; j < w; ++j) sacc += P[(w + i) + (int64_t)j * h] * xs[j];
         R[i] -= sacc;
     }
+}
+
+// R_s -= L21 y_s for the heavy supernodes of a level: grid (row chunks of 256, heavy supernodes)
+__global__ __launch_bounds__(256) void sp_fwd_rem_kernel(SpDev d, const int* __restrict__ heavy,
+                                                         const double* __restrict__ panels, const double* __restrict__ x,
+                                                         double* __restrict__ rem, const int64_t* __restrict__ rem_off) {
+    __shared__ double xs[256];
+    const int s = heavy[blockIdx.y];
+    const int f = d.sn_first[s];
+    const int w = d.sn_first[s + 1] - f;
+    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
+    const int hu = h - w;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x * 256 >= hu) return;
+    if (threadIdx.x < w) xs[threadIdx.x] = x[f + threadIdx.x];
+    __syncthreads();
+    if (i >= hu) return;
+    const double* __restrict__ P = panels + d.panel_off[s] + w + i;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int j = 0;
+    for (; j + 4 <= w; j += 4) {
+        a0 += P[(int64_t)j * h] * xs[j];
+        a1 += P[(int64_t)(j + 1) * h] * xs[j + 1];
+        a2 += P[(int64_t)(j + 2) * h] * xs[j + 2];
+        a3 += P[(int64_t)(j + 3) * h] * xs[j + 3];
+    }
+    for (; j < w; ++j) a0 += P[(int64_t)j * h] * xs[j];
+    rem[rem_off[s] + i] -= (a0 + a1) + (a2 + a3);
+}
+
+// y_j -= sum_{i >= w} L[i][j] x[rows[i]] for `ncol` columns starting at j0: one wave per column, lanes along the
+// (contiguous) column
+__device__ __forceinline__ void sp_bwd_cols(const double* __restrict__ P, const int* __restrict__ rows, int h, int w,
+                                            const double* __restrict__ x, int j0, int j1, double* out, int out_off) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = j0 + wave; j < j1; j += 4) {
+        const double* __restrict__ col = P + (int64_t)j * h;
+        double acc = 0.0;
+        for (int i = w + lane; i < h; i += 64) acc += col[i] * x[rows[i]];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) out[j - out_off] -= acc;
+    }
+}
+
+// heavy supernodes of a level, before sp_bwd_kernel: grid (groups of 16 columns, heavy supernodes)
+__global__ __launch_bounds__(256) void sp_bwd_gemv_kernel(SpDev d, const int* __restrict__ heavy,
+                                                          const double* __restrict__ panels, double* __restrict__ x) {
+    const int s = heavy[blockIdx.y];
+    const int f = d.sn_first[s];
+    const int w = d.sn_first[s + 1] - f;
+    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
+    const int j0 = blockIdx.x * 16;
+    if (j0 >= w) return;
+    sp_bwd_cols(panels + d.panel_off[s], d.sn_rows + d.sn_rowptr[s], h, w, x, j0, min(j0 + 16, w), x + f, 0);
 }
 
 // backward substitution (root level first):  x_s = L11^-T (y_s - L21' x[rows below])
 __global__ __launch_bounds__(256) void sp_bwd_kernel(SpDev d, int level_begin, const double* __restrict__ panels,
                                                      double* __restrict__ x) {
+    __shared__ double xs[256];
     const int s = d.level_sn[level_begin + blockIdx.x];
     const int tid = threadIdx.x;
     const int f = d.sn_first[s];
     const int w = d.sn_first[s + 1] - f;
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
     const double* __restrict__ P = panels + d.panel_off[s];
-    const int* __restrict__ rows = d.sn_rows + d.sn_rowptr[s];
-    // y_j -= sum_{i >= w} L[i][j] x[rows[i]]   (one column per thread, columns are contiguous)
-    for (int j = tid; j < w; j += 256) {
-        double sacc = 0.0;
-        for (int i = w; i < h; ++i) sacc += P[i + (int64_t)j * h] * x[rows[i]];
-        x[f + j] -= sacc;
-    }
+    if (tid < w) xs[tid] = x[f + tid];
     __syncthreads();
-    for (int j = w - 1; j >= 0; --j) {
-        __shared__ double xj;
-        if (tid == 0) {
-            xj = x[f + j] / P[j + (int64_t)j * h];
-            x[f + j] = xj;
-        }
-        __syncthreads();
-        const double v = xj;
-        for (int i = tid; i < j; i += 256) x[f + i] -= P[j + (int64_t)i * h] * v;
+    if ((int64_t)(h - w) * w <= SP_HEAVY && h > w) {
+        sp_bwd_cols(P, d.sn_rows + d.sn_rowptr[s], h, w, x, 0, w, xs, 0);
         __syncthreads();
     }
+    sp_trsv_bwd_lds(P, h, w, xs);
+    if (tid < w) x[f + tid] = xs[tid];
 }
 
 __global__ void sp_permute_kernel(const double* __restrict__ in, double* __restrict__ out, const int* __restrict__ map, int n,
@@ -726,6 +853,7 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     if (int e = up(&E.d_asm_b, S.asm_b)) return e;
     if (int e = up(&E.d_asm_r, S.asm_r)) return e;
     if (int e = up(&E.d_perm, S.perm)) return e;
+    if (int e = up(&E.d_heavy, S.heavy)) return e;
     {   // G in CSC (values + int rows) and CSR (for G x)
         std::vector<double> gvals(gv, gv + gnnz), hvals;
         if (hv) hvals.assign(hv, hv + hnnz);
@@ -775,7 +903,7 @@ void sparse_engine_free(SparseEngine& E) {
     void* ptrs[] = {E.d_sn_first, E.d_sn_rowptr, E.d_sn_rows, E.d_panel_off, E.d_upd_off, E.d_child_ptr, E.d_child_list,
                     E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
-                    E.d_panels, E.d_upd, E.d_xp, E.d_info};
+                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
@@ -869,9 +997,17 @@ int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st) {
         if (cnt > 0)
             hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp, E.d_rem,
                                E.d_rem_off);
+        const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
+        if (nh > 0)
+            hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 255) / 256, nh), dim3(256), 0, st, d,
+                               E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp, E.d_rem, E.d_rem_off);
     }
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
+        const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
+        if (nh > 0)
+            hipLaunchKernelGGL(sp_bwd_gemv_kernel, dim3((S.heavy_maxw[l] + 15) / 16, nh), dim3(256), 0, st, d,
+                               E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp);
         if (cnt > 0) hipLaunchKernelGGL(sp_bwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp);
     }
     hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, E.d_xp, d_x, E.d_perm, E.n, 0);
