@@ -419,11 +419,28 @@ template <bool SYM>
 __global__ __launch_bounds__(256, 2) void nt_update_kernel(double* __restrict__ C, int64_t ldc,
                                                            const double* __restrict__ A, int64_t lda,
                                                            const double* __restrict__ B, int64_t ldb,
-                                                           int M, int N, int K, int fast_ok, int64_t bstride) {
+                                                           int M, int N, int K, int fast_ok, int64_t bstride,
+                                                           const VbDesc* __restrict__ vb) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    C += (int64_t)blockIdx.z * bstride;     // batched problems: C, A, B live in the same matrix
-    A += (int64_t)blockIdx.z * bstride;
-    B += (int64_t)blockIdx.z * bstride;
+    if (vb) {      // variable batched fronts (SYM only): K carries the panel offset k0; C = A = B = base
+        const VbDesc dd = vb[blockIdx.z];
+        const int k0 = K;
+        if (k0 >= dd.w) return;
+        const int nb = min(128, dd.w - k0);
+        const int m = dd.h - k0 - nb;
+        const int nt = (m + TILE - 1) / TILE;
+        if ((int)blockIdx.x >= nt * (nt + 1) / 2) return;
+        ldc = lda = ldb = dd.h;
+        A += dd.off + (k0 + nb) + (int64_t)k0 * dd.h;
+        B = A;
+        C += dd.off + (k0 + nb) + (int64_t)(k0 + nb) * dd.h;
+        M = N = m;
+        K = nb;
+    } else {
+        C += (int64_t)blockIdx.z * bstride;     // batched problems: C, A, B live in the same matrix
+        A += (int64_t)blockIdx.z * bstride;
+        B += (int64_t)blockIdx.z * bstride;
+    }
     int ti, tj;
     if (SYM) {
         const int t = blockIdx.x;
@@ -521,7 +538,17 @@ int launch_syrk_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, 
     // to the critical-path kernels of the other stream
     const size_t lds = one_wg_per_cu ? kGemmLdsWide : kGemmLds;
     hipLaunchKernelGGL(nt_update_kernel<true>, dim3(nt * (nt + 1) / 2, 1, nbatch), dim3(256), lds, st, C, ldc, A,
-                       lda, A, lda, nrows, nrows, K, fast_ok, bstride);
+                       lda, A, lda, nrows, nrows, K, fast_ok, bstride, nullptr);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_syrk_nt_update_vb(double* base, const VbDesc* d_desc, int nfronts, int k0, int maxh, hipStream_t st) {
+    if (int e = nt_attr()) return e;
+    const int nt = (maxh - k0 - 1 + TILE - 1) / TILE;
+    if (nt <= 0) return 0;
+    hipLaunchKernelGGL(nt_update_kernel<true>, dim3(nt * (nt + 1) / 2, 1, nfronts), dim3(256), kGemmLds, st, base, (int64_t)0,
+                       base, (int64_t)0, base, (int64_t)0, 0, 0, k0, 1, (int64_t)0, d_desc);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -532,7 +559,7 @@ int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, 
     if (int e = nt_attr()) return e;
     const int fast_ok = (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 7) == 0) ? 1 : 0;
     hipLaunchKernelGGL(nt_update_kernel<false>, dim3((M + TILE - 1) / TILE, (N + TILE - 1) / TILE, nbatch), dim3(256),
-                       kGemmLds, st, C, ldc, A, lda, B, ldb, M, N, K, fast_ok, bstride);
+                       kGemmLds, st, C, ldc, A, lda, B, ldb, M, N, K, fast_ok, bstride, nullptr);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -69,6 +69,10 @@ int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, 
 int run_mfma_f64_peak(int iters, int num_cus, float* tflops);
 
 // ---- dense Cholesky -----------------------------------------------------------------------------
+// One frontal matrix of a level-batched ("variable batched") partial factorisation: h x h, column-major with ld = h,
+// at base + off; only its first w columns are factored, the trailing block receives the Schur update.
+struct VbDesc { int64_t off; int h, w, col0, pad; };
+
 struct PotrfWork {
     int* d_info = nullptr;   // device int: 0 ok, >0 first failing pivot (1-based, LAPACK convention)
     int* h_info = nullptr;   // pinned host mirror
@@ -85,6 +89,10 @@ void potrf_work_free(PotrfWork& w);
 // Asynchronous on `st`; *w.d_info is updated on device.  Returns 0 or a negative error code.
 int launch_potrf(double* A, int64_t lda, int n, PotrfWork& w, hipStream_t st);
 int launch_potrf_partial(double* F, int64_t ld, int h, int ncols, PotrfWork& w, hipStream_t st);
+// the same for `nfronts` fronts of different sizes in one set of launches (blockIdx.z = front; grids sized for maxh/maxw);
+// w.d_info / w.d_dinv must hold nfronts ints / nfronts*2048 doubles; info[z] = global column + 1 of a failing pivot
+int launch_potrf_partial_vb(double* base, const VbDesc* d_desc, int nfronts, int maxh, int maxw, PotrfWork& w, hipStream_t st);
+int launch_syrk_nt_update_vb(double* base, const VbDesc* d_desc, int nfronts, int k0, int maxh, hipStream_t st);
 // nbatch matrices `bstride` doubles apart; w.d_info / w.d_dinv must hold nbatch ints / nbatch*2048 doubles
 int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st);
 int potrf_work_init_batched(PotrfWork& w, int nbatch);
@@ -120,6 +128,9 @@ struct SparseSymbolic {
     std::vector<int64_t> panel_off, upd_off, relmap_off;
     std::vector<int> upd_ld, level_nsmall;
     std::vector<char> big;
+    std::vector<VbDesc> vb;                       // big fronts, level by level (same order as level_sn's big part)
+    std::vector<int> vb_ptr, vb_maxh, vb_maxw;    // per level
+    int vb_maxcount = 0;
     std::vector<int> heavy, heavy_ptr, heavy_maxhu, heavy_maxw;   // per level: supernodes with large off-diagonal panels
     int64_t store_doubles = 0;
     std::vector<int> child_ptr, child_list, relmap;
@@ -133,11 +144,8 @@ struct SparseEngine {
         *d_level_sn = nullptr, *d_asm_a = nullptr, *d_asm_b = nullptr, *d_asm_r = nullptr, *d_perm = nullptr,
         *d_gri = nullptr, *d_gci = nullptr, *d_gnzmap = nullptr, *d_info = nullptr, *h_info = nullptr, *d_upd_ld = nullptr,
         *d_heavy = nullptr;
-    static constexpr int NSTREAMS = 8;
-    PotrfWork pws[NSTREAMS];
-    hipStream_t streams[NSTREAMS] = {};
-    hipEvent_t ev_done[NSTREAMS] = {};
-    hipEvent_t ev_level = nullptr;
+    VbDesc* d_vb = nullptr;
+    PotrfWork pw_vb;
     int64_t *d_sn_rowptr = nullptr, *d_panel_off = nullptr, *d_upd_off = nullptr, *d_relmap_off = nullptr,
             *d_asm_slot = nullptr, *d_asm_ptr = nullptr, *d_gcp = nullptr, *d_grp = nullptr, *d_rem_off = nullptr;
     double *d_gv = nullptr, *d_hv = nullptr, *d_rem = nullptr, *d_panels = nullptr, *d_upd = nullptr, *d_xp = nullptr;

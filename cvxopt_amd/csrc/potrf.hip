@@ -53,9 +53,19 @@ __device__ __forceinline__ void sqrt_rsqrt(double p, double& d, double& inv) {
 // linv_out[blk][k][g] = inv(L_d)[g][k] (16x16 diagonal blocks, zero upper) is exported for trsm_panel_kernel.
 __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int64_t lda, int nb, int col0,
                                                     int* __restrict__ info, double* __restrict__ linv_out,
-                                                    int64_t bstride) {
+                                                    int64_t bstride, const VbDesc* __restrict__ vb) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    A += (int64_t)blockIdx.z * bstride;          // batched problems along blockIdx.z
+    if (vb) {                                    // variable batched fronts: col0 carries the panel offset k0
+        const VbDesc dd = vb[blockIdx.z];
+        const int k0 = col0;
+        if (k0 >= dd.w) return;
+        nb = min(NB, dd.w - k0);
+        lda = dd.h;
+        A += dd.off + k0 + (int64_t)k0 * lda;
+        col0 = dd.col0 + k0;
+    } else {
+        A += (int64_t)blockIdx.z * bstride;      // batched problems along blockIdx.z
+    }
     info += blockIdx.z;
     if (linv_out) linv_out += (int64_t)blockIdx.z * 2048;
     double* As = smem;                       // NB x PLD, column-major, lower triangle valid
@@ -237,9 +247,21 @@ template <bool full>     // full: nb == 128 (every panel of a dense potrf); ragg
 __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restrict__ L,
                                                          const double* __restrict__ linv,
                                                          double* __restrict__ B, int64_t lda, int mrows,
-                                                         const int* __restrict__ info, int64_t bstride, int nb) {
-    L += (int64_t)blockIdx.z * bstride;
-    B += (int64_t)blockIdx.z * bstride;
+                                                         const int* __restrict__ info, int64_t bstride, int nb,
+                                                         const VbDesc* __restrict__ vb) {
+    if (vb) {                                    // variable batched fronts: mrows carries the panel offset k0; L = B = base
+        const VbDesc dd = vb[blockIdx.z];
+        const int k0 = mrows;
+        if (k0 >= dd.w) return;
+        nb = min(128, dd.w - k0);
+        lda = dd.h;
+        L += dd.off + k0 + (int64_t)k0 * lda;
+        B += dd.off + k0 + nb + (int64_t)k0 * lda;
+        mrows = dd.h - k0 - nb;
+    } else {
+        L += (int64_t)blockIdx.z * bstride;
+        B += (int64_t)blockIdx.z * bstride;
+    }
     linv += (int64_t)blockIdx.z * 2048;
     info += blockIdx.z;
     if (*info != 0) return;
@@ -341,16 +363,16 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
     auto panel = [&](int k0, int nb) -> int {   // factor diagonal block at k0 and solve the rows below it
         double* Akk = A + k0 + (int64_t)k0 * lda;
         hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, nbatch), dim3(256), lds, st, Akk, lda, nb, k0, w.d_info, w.d_dinv,
-                           bstride);
+                           bstride, nullptr);
         KKT_HIP_CHECK(hipGetLastError());
         const int m = n - k0 - nb;
         if (m > 0) {
             if (nb == NB)
                 hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS, 1, nbatch), dim3(256), 0, st,
-                                   Akk, w.d_dinv, Akk + nb, lda, m, w.d_info, bstride, nb);
+                                   Akk, w.d_dinv, Akk + nb, lda, m, w.d_info, bstride, nb, nullptr);
             else
                 hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS, 1, nbatch), dim3(256), 0, st,
-                                   Akk, w.d_dinv, Akk + nb, lda, m, w.d_info, bstride, nb);
+                                   Akk, w.d_dinv, Akk + nb, lda, m, w.d_info, bstride, nb, nullptr);
             KKT_HIP_CHECK(hipGetLastError());
         }
         return 0;
@@ -380,7 +402,7 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
         if (int e = grow(w.ev_ir)) return e;
         auto potf2 = [&](int k0, int nb) {
             hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), lds, st, A + k0 + (int64_t)k0 * lda, lda, nb, k0, w.d_info,
-                               w.d_dinv, (int64_t)0);
+                               w.d_dinv, (int64_t)0, nullptr);
         };
         auto trsm = [&](int k0, int nb) {
             const int m = n - k0 - nb;
@@ -388,10 +410,10 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
             double* Akk = A + k0 + (int64_t)k0 * lda;
             if (nb == NB)
                 hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Akk, w.d_dinv,
-                                   Akk + nb, lda, m, w.d_info, (int64_t)0, nb);
+                                   Akk + nb, lda, m, w.d_info, (int64_t)0, nb, nullptr);
             else
                 hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Akk, w.d_dinv,
-                                   Akk + nb, lda, m, w.d_info, (int64_t)0, nb);
+                                   Akk + nb, lda, m, w.d_info, (int64_t)0, nb, nullptr);
         };
         // C[r0:r0+M, c0:c0+N] -= L[r0:.., kp:kp+K] L[c0:.., kp:kp+K]'
         auto upd = [&](int r0, int M, int c0, int N, int kp, int K, hipStream_t s_) -> int {
@@ -539,16 +561,37 @@ int launch_potrf_partial(double* F, int64_t ld, int h, int ncols, PotrfWork& w, 
     for (int k0 = 0; k0 < ncols; k0 += NB) {
         const int nb = (ncols - k0 < NB) ? (ncols - k0) : NB;
         double* Fkk = F + k0 + (int64_t)k0 * ld;
-        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), lds, st, Fkk, ld, nb, k0, w.d_info, w.d_dinv, (int64_t)0);
+        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), lds, st, Fkk, ld, nb, k0, w.d_info, w.d_dinv, (int64_t)0, nullptr);
         const int m = h - k0 - nb;
         if (m > 0) {
             if (nb == NB)
                 hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Fkk,
-                                   w.d_dinv, Fkk + nb, ld, m, w.d_info, (int64_t)0, nb);
+                                   w.d_dinv, Fkk + nb, ld, m, w.d_info, (int64_t)0, nb, nullptr);
             else
                 hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Fkk,
-                                   w.d_dinv, Fkk + nb, ld, m, w.d_info, (int64_t)0, nb);
+                                   w.d_dinv, Fkk + nb, ld, m, w.d_info, (int64_t)0, nb, nullptr);
             if (int e = launch_syrk_nt_update(Fkk + nb + (int64_t)nb * ld, ld, Fkk + nb, ld, m, nb, st)) return e;
+        }
+    }
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int launch_potrf_partial_vb(double* base, const VbDesc* d_desc, int nfronts, int maxh, int maxw, PotrfWork& w,
+                            hipStream_t st) {
+    if (nfronts <= 0) return 0;
+    constexpr size_t lds = sizeof(double) * (NB * PLD + 256 + 16) + 16;
+    KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    KKT_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int) * nfronts, st));
+    for (int k0 = 0; k0 < maxw; k0 += NB) {
+        hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, nfronts), dim3(256), lds, st, base, (int64_t)0, 0, k0, w.d_info, w.d_dinv,
+                           (int64_t)0, d_desc);
+        const int mmax = maxh - k0 - 1;           // a front's panel may be as narrow as one column
+        if (mmax > 0) {
+            hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((mmax + TRSM_ROWS - 1) / TRSM_ROWS, 1, nfronts), dim3(256), 0, st,
+                               base, w.d_dinv, base, (int64_t)0, k0, w.d_info, (int64_t)0, 0, d_desc);
+            if (int e = launch_syrk_nt_update_vb(base, d_desc, nfronts, k0, maxh, st)) return e;
         }
     }
     KKT_HIP_CHECK(hipGetLastError());

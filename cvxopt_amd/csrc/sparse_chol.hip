@@ -334,6 +334,23 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
                               [&](int sn) { return !S.big[sn]; });
         for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) S.level_nsmall[l] += !S.big[S.level_sn[k]];
     }
+    // big fronts of every level as one descriptor list for the level-batched dense kernels
+    S.vb.clear();
+    S.vb_ptr.assign(S.nlevels + 1, 0);
+    S.vb_maxh.assign(S.nlevels, 0);
+    S.vb_maxw.assign(S.nlevels, 0);
+    S.vb_maxcount = 0;
+    for (int l = 0; l < S.nlevels; ++l) {
+        for (int k = S.level_ptr[l] + S.level_nsmall[l]; k < S.level_ptr[l + 1]; ++k) {
+            const int sn = S.level_sn[k];
+            const int h = (int)(S.sn_rowptr[sn + 1] - S.sn_rowptr[sn]), w = S.sn_first[sn + 1] - S.sn_first[sn];
+            S.vb.push_back(VbDesc{S.panel_off[sn], h, w, S.sn_first[sn], sn});
+            S.vb_maxh[l] = std::max(S.vb_maxh[l], h);
+            S.vb_maxw[l] = std::max(S.vb_maxw[l], w);
+        }
+        S.vb_ptr[l + 1] = (int)S.vb.size();
+        S.vb_maxcount = std::max(S.vb_maxcount, S.vb_ptr[l + 1] - S.vb_ptr[l]);
+    }
     // supernodes whose off-diagonal panel is large: their solve-phase products run as multi-workgroup kernels
     S.heavy_ptr.assign(S.nlevels + 1, 0);
     S.heavy_maxhu.assign(S.nlevels, 0);
@@ -574,21 +591,50 @@ __global__ __launch_bounds__(256) void sp_front_kernel(SpDev d, int level_begin,
     if (tid == 0 && bad) atomicMin(info, bad);      // smallest failing column (info starts at INT_MAX)
 }
 
-// extend-add of ONE child's update matrix into a big parent front (F is h x h, ld h); launched child by child
-__global__ __launch_bounds__(256) void sp_extend_add_kernel(SpDev d, int s, int c, double* store) {
-    const int w = d.sn_first[s + 1] - d.sn_first[s];
-    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
-    const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
-    double* __restrict__ F = store + d.panel_off[s];
-    const double* __restrict__ Uc = store + d.upd_off[c];
-    const int ldc = d.upd_ld[c];
-    const int* __restrict__ rm = d.relmap + d.relmap_off[c];
-    (void)w;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < (int64_t)hc * hc; e += (int64_t)gridDim.x * 256) {
-        const int i = (int)(e % hc), j = (int)(e / hc);
-        if (i < j) continue;
-        F[rm[i] + (int64_t)rm[j] * h] += Uc[i + (int64_t)j * ldc];
+// extend-add of the children's update matrices into the big fronts of one level: grid (64-column blocks of the
+// front, fronts).  One workgroup owns its target columns, so the children can be added one after the other
+// (deterministic, no atomics); the child columns that land in the block are a contiguous range of its sorted map.
+__global__ __launch_bounds__(256) void sp_extend_add_vb_kernel(SpDev d, const VbDesc* __restrict__ vb, double* store) {
+    const VbDesc dd = vb[blockIdx.y];
+    const int s = dd.pad;                      // supernode id
+    const int h = dd.h;
+    const int c0 = blockIdx.x * 64, c1 = min(c0 + 64, h);
+    if (c0 >= h) return;
+    double* __restrict__ F = store + dd.off;
+    __shared__ int range[2];
+    for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
+        const int c = d.child_list[ci];
+        const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
+        if (hc <= 0) continue;
+        const int* __restrict__ rm = d.relmap + d.relmap_off[c];
+        if (threadIdx.x < 2) {                 // first child column with rm >= c0 / >= c1
+            const int target = threadIdx.x == 0 ? c0 : c1;
+            int lo = 0, hi = hc;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (rm[mid] < target) lo = mid + 1; else hi = mid;
+            }
+            range[threadIdx.x] = lo;
+        }
+        __syncthreads();
+        const int ja = range[0], jb = range[1];
+        if (jb > ja) {
+            const double* __restrict__ Uc = store + d.upd_off[c];
+            const int ldc = d.upd_ld[c];
+            const int rows = hc - ja;          // rows i >= ja can be in the lower triangle of these columns
+            for (int64_t e = threadIdx.x; e < (int64_t)(jb - ja) * rows; e += 256) {
+                const int j = ja + (int)(e / rows), i = ja + (int)(e % rows);
+                if (i < j) continue;
+                F[rm[i] + (int64_t)rm[j] * h] += Uc[i + (int64_t)j * ldc];
+            }
+        }
+        __syncthreads();
     }
+}
+
+__global__ void sp_merge_info_vb_kernel(const int* __restrict__ local, int n, int* __restrict__ global) {
+    const int z = blockIdx.x * 256 + threadIdx.x;
+    if (z < n && local[z] > 0) atomicMin(global, local[z]);
 }
 
 __global__ void sp_merge_info_kernel(const int* __restrict__ local, int offset, int* __restrict__ global) {
@@ -854,6 +900,8 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     if (int e = up(&E.d_asm_r, S.asm_r)) return e;
     if (int e = up(&E.d_perm, S.perm)) return e;
     if (int e = up(&E.d_heavy, S.heavy)) return e;
+    if (int e = up(&E.d_vb, S.vb)) return e;
+    if (int e = potrf_work_init_batched(E.pw_vb, std::max(1, S.vb_maxcount))) return e;
     {   // G in CSC (values + int rows) and CSR (for G x)
         std::vector<double> gvals(gv, gv + gnnz), hvals;
         if (hv) hvals.assign(hv, hv + hnnz);
@@ -887,12 +935,6 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     KKT_HIP_CHECK(hipMalloc(&E.d_rem, sizeof(double) * (rem_off[S.ns] ? rem_off[S.ns] : 1)));
     KKT_HIP_CHECK(hipMalloc(&E.d_panels, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
     E.d_upd = nullptr;          // update matrices live in the same buffer (offsets are absolute)
-    for (int k = 0; k < SparseEngine::NSTREAMS; ++k) {
-        if (int e = potrf_work_init(E.pws[k])) return e;
-        KKT_HIP_CHECK(hipStreamCreateWithFlags(&E.streams[k], hipStreamNonBlocking));
-        KKT_HIP_CHECK(hipEventCreateWithFlags(&E.ev_done[k], hipEventDisableTiming));
-    }
-    KKT_HIP_CHECK(hipEventCreateWithFlags(&E.ev_level, hipEventDisableTiming));
     KKT_HIP_CHECK(hipMalloc(&E.d_xp, sizeof(double) * (n ? n : 1)));
     KKT_HIP_CHECK(hipMalloc(&E.d_info, sizeof(int)));
     KKT_HIP_CHECK(hipHostMalloc(&E.h_info, sizeof(int)));
@@ -903,16 +945,11 @@ void sparse_engine_free(SparseEngine& E) {
     void* ptrs[] = {E.d_sn_first, E.d_sn_rowptr, E.d_sn_rows, E.d_panel_off, E.d_upd_off, E.d_child_ptr, E.d_child_list,
                     E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
-                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy};
+                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
-    for (int k = 0; k < SparseEngine::NSTREAMS; ++k) {
-        potrf_work_free(E.pws[k]);
-        if (E.streams[k]) (void)hipStreamDestroy(E.streams[k]);
-        if (E.ev_done[k]) (void)hipEventDestroy(E.ev_done[k]);
-    }
-    if (E.ev_level) (void)hipEventDestroy(E.ev_level);
+    potrf_work_free(E.pw_vb);
     E = SparseEngine();
 }
 
@@ -949,33 +986,13 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
         if (nsmall > 0)
             hipLaunchKernelGGL(sp_front_kernel, dim3(nsmall), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_panels,
                                E.d_info);
-        const int nbig = S.level_ptr[l + 1] - S.level_ptr[l] - nsmall;
+        const int nbig = S.vb_ptr[l + 1] - S.vb_ptr[l];
         if (nbig > 0) {
-            // big fronts of one level are independent: spread them over a few streams (each with its own potrf
-            // workspace); they start after everything issued so far and the level ends when all of them are done
-            KKT_HIP_CHECK(hipEventRecord(E.ev_level, st));
-            const int nuse = std::min(nbig, (int)SparseEngine::NSTREAMS);
-            for (int q = 0; q < nuse; ++q) KKT_HIP_CHECK(hipStreamWaitEvent(E.streams[q], E.ev_level, 0));
-            for (int k = S.level_ptr[l] + nsmall, q = 0; k < S.level_ptr[l + 1]; ++k, q = (q + 1) % nuse) {
-                hipStream_t sq = E.streams[q];
-                const int sn = S.level_sn[k];
-                const int w = S.sn_first[sn + 1] - S.sn_first[sn];
-                const int h = (int)(S.sn_rowptr[sn + 1] - S.sn_rowptr[sn]);
-                for (int ci = S.child_ptr[sn]; ci < S.child_ptr[sn + 1]; ++ci) {   // child by child: deterministic
-                    const int c = S.child_list[ci];
-                    const int64_t hc = (S.sn_rowptr[c + 1] - S.sn_rowptr[c]) - (S.sn_first[c + 1] - S.sn_first[c]);
-                    if (hc <= 0) continue;
-                    const int64_t blocks = std::min<int64_t>((hc * hc + 255) / 256, 4096);
-                    hipLaunchKernelGGL(sp_extend_add_kernel, dim3((unsigned)blocks), dim3(256), 0, sq, d, sn, c, E.d_panels);
-                }
-                KKT_HIP_CHECK(hipMemsetAsync(E.pws[q].d_info, 0, sizeof(int), sq));
-                if (int e = launch_potrf_partial(E.d_panels + S.panel_off[sn], h, h, w, E.pws[q], sq)) return e;
-                hipLaunchKernelGGL(sp_merge_info_kernel, dim3(1), dim3(1), 0, sq, E.pws[q].d_info, S.sn_first[sn], E.d_info);
-            }
-            for (int q = 0; q < nuse; ++q) {
-                KKT_HIP_CHECK(hipEventRecord(E.ev_done[q], E.streams[q]));
-                KKT_HIP_CHECK(hipStreamWaitEvent(st, E.ev_done[q], 0));
-            }
+            // the big fronts of a level go through the dense MFMA kernels together (blockIdx.z = front)
+            const VbDesc* dv = E.d_vb + S.vb_ptr[l];
+            hipLaunchKernelGGL(sp_extend_add_vb_kernel, dim3((S.vb_maxh[l] + 63) / 64, nbig), dim3(256), 0, st, d, dv, E.d_panels);
+            if (int e = launch_potrf_partial_vb(E.d_panels, dv, nbig, S.vb_maxh[l], S.vb_maxw[l], E.pw_vb, st)) return e;
+            hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3((nbig + 255) / 256), dim3(256), 0, st, E.pw_vb.d_info, nbig, E.d_info);
         }
     }
     KKT_HIP_CHECK(hipGetLastError());
