@@ -307,13 +307,15 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     S.upd_ld.assign(ns, 0);
     S.big.assign(ns, 0);
     int64_t off = 0;
+    const double big_flops = getenv("MI355KKT_SPARSE_BIG_FLOPS") ? atof(getenv("MI355KKT_SPARSE_BIG_FLOPS")) : 5.0e4;
+    const int64_t big_h = getenv("MI355KKT_SPARSE_BIG_H") ? atoi(getenv("MI355KKT_SPARSE_BIG_H")) : 48;
     for (int s = 0; s < ns; ++s) {
         const int64_t h = S.sn_rowptr[s + 1] - S.sn_rowptr[s], w = S.sn_first[s + 1] - S.sn_first[s];
         const double fl = (double)w * h * h;
         S.flops += fl;   // rough
         S.nnzL += h * w;
         S.panel_off[s] = off;
-        if (fl >= 1.0e6 && h >= 96) {
+        if (fl >= big_flops && h >= big_h) {
             S.big[s] = 1;
             S.upd_off[s] = off + w + w * h;
             S.upd_ld[s] = (int)h;
@@ -591,24 +593,27 @@ __global__ __launch_bounds__(256) void sp_front_kernel(SpDev d, int level_begin,
     if (tid == 0 && bad) atomicMin(info, bad);      // smallest failing column (info starts at INT_MAX)
 }
 
-// extend-add of the children's update matrices into the big fronts of one level: grid (64-column blocks of the
-// front, fronts).  One workgroup owns its target columns, so the children can be added one after the other
-// (deterministic, no atomics); the child columns that land in the block are a contiguous range of its sorted map.
+// extend-add of the children's update matrices into the big fronts of one level: grid (64-column blocks, 256-row
+// blocks, fronts).  One workgroup owns its block of the target front, so the children can be added one after the
+// other (deterministic, no atomics); the child rows / columns that land in the block are contiguous ranges of its
+// sorted map.
+constexpr int EA_COLS = 64, EA_ROWS = 256;
 __global__ __launch_bounds__(256) void sp_extend_add_vb_kernel(SpDev d, const VbDesc* __restrict__ vb, double* store) {
-    const VbDesc dd = vb[blockIdx.y];
+    const VbDesc dd = vb[blockIdx.z];
     const int s = dd.pad;                      // supernode id
     const int h = dd.h;
-    const int c0 = blockIdx.x * 64, c1 = min(c0 + 64, h);
-    if (c0 >= h) return;
+    const int c0 = blockIdx.x * EA_COLS, c1 = min(c0 + EA_COLS, h);
+    const int r0 = blockIdx.y * EA_ROWS, r1 = min(r0 + EA_ROWS, h);
+    if (c0 >= h || r0 >= h || r1 <= c0) return;            // outside the front / strictly above the diagonal
     double* __restrict__ F = store + dd.off;
-    __shared__ int range[2];
+    __shared__ int range[4];
     for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
         const int c = d.child_list[ci];
         const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
         if (hc <= 0) continue;
         const int* __restrict__ rm = d.relmap + d.relmap_off[c];
-        if (threadIdx.x < 2) {                 // first child column with rm >= c0 / >= c1
-            const int target = threadIdx.x == 0 ? c0 : c1;
+        if (threadIdx.x < 4) {                 // first child index with rm >= c0, c1, r0, r1
+            const int target = threadIdx.x == 0 ? c0 : (threadIdx.x == 1 ? c1 : (threadIdx.x == 2 ? r0 : r1));
             int lo = 0, hi = hc;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
@@ -617,13 +622,13 @@ __global__ __launch_bounds__(256) void sp_extend_add_vb_kernel(SpDev d, const Vb
             range[threadIdx.x] = lo;
         }
         __syncthreads();
-        const int ja = range[0], jb = range[1];
-        if (jb > ja) {
+        const int ja = range[0], jb = range[1], ia = max(range[2], ja), ib = range[3];
+        if (jb > ja && ib > ia) {
             const double* __restrict__ Uc = store + d.upd_off[c];
             const int ldc = d.upd_ld[c];
-            const int rows = hc - ja;          // rows i >= ja can be in the lower triangle of these columns
+            const int rows = ib - ia;
             for (int64_t e = threadIdx.x; e < (int64_t)(jb - ja) * rows; e += 256) {
-                const int j = ja + (int)(e / rows), i = ja + (int)(e % rows);
+                const int j = ja + (int)(e / rows), i = ia + (int)(e % rows);
                 if (i < j) continue;
                 F[rm[i] + (int64_t)rm[j] * h] += Uc[i + (int64_t)j * ldc];
             }
@@ -668,9 +673,17 @@ __device__ __forceinline__ void sp_trsv_fwd_lds(const double* __restrict__ P, in
         }
         __syncthreads();
         for (int i = jb + nbk + tid; i < w; i += 256) {
-            double acc = 0.0;
-            for (int k = 0; k < nbk; ++k) acc += P[i + (int64_t)(jb + k) * h] * xs[jb + k];
-            xs[i] -= acc;
+            const double* __restrict__ Pi = P + i + (int64_t)jb * h;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            int k = 0;
+            for (; k + 4 <= nbk; k += 4) {           // four loads in flight per thread
+                a0 += Pi[(int64_t)k * h] * xs[jb + k];
+                a1 += Pi[(int64_t)(k + 1) * h] * xs[jb + k + 1];
+                a2 += Pi[(int64_t)(k + 2) * h] * xs[jb + k + 2];
+                a3 += Pi[(int64_t)(k + 3) * h] * xs[jb + k + 3];
+            }
+            for (; k < nbk; ++k) a0 += Pi[(int64_t)k * h] * xs[jb + k];
+            xs[i] -= (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
     }
@@ -702,8 +715,22 @@ __device__ __forceinline__ void sp_trsv_bwd_lds(const double* __restrict__ P, in
         {   // columns to the left: xs[i] -= sum_k L[jb + k][i] xs[jb + k]; 32 lanes share one column (contiguous in memory)
             const int k = tid & 31, g = tid >> 5;
             const double xk = (k < nbk) ? xs[jb + k] : 0.0;
-            for (int i = g; i < jb; i += 8) {
-                double v = (k < nbk) ? P[(jb + k) + (int64_t)i * h] * xk : 0.0;
+            const double* __restrict__ Pk = P + jb + min(k, nbk - 1);
+            int i = g;
+            for (; i + 24 < jb; i += 32) {            // four columns (loads) in flight per thread
+                double v0 = Pk[(int64_t)i * h] * xk, v1 = Pk[(int64_t)(i + 8) * h] * xk;
+                double v2 = Pk[(int64_t)(i + 16) * h] * xk, v3 = Pk[(int64_t)(i + 24) * h] * xk;
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    v0 += __shfl_xor(v0, o, 64);
+                    v1 += __shfl_xor(v1, o, 64);
+                    v2 += __shfl_xor(v2, o, 64);
+                    v3 += __shfl_xor(v3, o, 64);
+                }
+                if (k == 0) { xs[i] -= v0; xs[i + 8] -= v1; xs[i + 16] -= v2; xs[i + 24] -= v3; }
+            }
+            for (; i < jb; i += 8) {
+                double v = Pk[(int64_t)i * h] * xk;
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
                 if (k == 0) xs[i] -= v;
@@ -747,9 +774,17 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
     if (tid < w) x[f + tid] = xs[tid];
     if ((int64_t)hu * w > SP_HEAVY) return;             // remainder by sp_fwd_rem_kernel
     for (int i = tid; i < hu; i += 256) {
-        double sacc = 0.0;
-        for (int j = 0; j < w; ++j) sacc += P[(w + i) + (int64_t)j * h] * xs[j];
-        R[i] -= sacc;
+        const double* __restrict__ Pi = P + w + i;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int j = 0;
+        for (; j + 4 <= w; j += 4) {
+            a0 += Pi[(int64_t)j * h] * xs[j];
+            a1 += Pi[(int64_t)(j + 1) * h] * xs[j + 1];
+            a2 += Pi[(int64_t)(j + 2) * h] * xs[j + 2];
+            a3 += Pi[(int64_t)(j + 3) * h] * xs[j + 3];
+        }
+        for (; j < w; ++j) a0 += Pi[(int64_t)j * h] * xs[j];
+        R[i] -= (a0 + a1) + (a2 + a3);
     }
 }
 
@@ -788,8 +823,16 @@ __device__ __forceinline__ void sp_bwd_cols(const double* __restrict__ P, const 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int j = j0 + wave; j < j1; j += 4) {
         const double* __restrict__ col = P + (int64_t)j * h;
-        double acc = 0.0;
-        for (int i = w + lane; i < h; i += 64) acc += col[i] * x[rows[i]];
+        double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        int i = w + lane;
+        for (; i + 192 < h; i += 256) {
+            acc += col[i] * x[rows[i]];
+            acc1 += col[i + 64] * x[rows[i + 64]];
+            acc2 += col[i + 128] * x[rows[i + 128]];
+            acc3 += col[i + 192] * x[rows[i + 192]];
+        }
+        for (; i < h; i += 64) acc += col[i] * x[rows[i]];
+        acc = (acc + acc1) + (acc2 + acc3);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (lane == 0) out[j - out_off] -= acc;
@@ -990,7 +1033,8 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
         if (nbig > 0) {
             // the big fronts of a level go through the dense MFMA kernels together (blockIdx.z = front)
             const VbDesc* dv = E.d_vb + S.vb_ptr[l];
-            hipLaunchKernelGGL(sp_extend_add_vb_kernel, dim3((S.vb_maxh[l] + 63) / 64, nbig), dim3(256), 0, st, d, dv, E.d_panels);
+            hipLaunchKernelGGL(sp_extend_add_vb_kernel, dim3((S.vb_maxh[l] + EA_COLS - 1) / EA_COLS, (S.vb_maxh[l] + EA_ROWS - 1) / EA_ROWS, nbig),
+                               dim3(256), 0, st, d, dv, E.d_panels);
             if (int e = launch_potrf_partial_vb(E.d_panels, dv, nbig, S.vb_maxh[l], S.vb_maxw[l], E.pw_vb, st)) return e;
             hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3((nbig + 255) / 256), dim3(256), 0, st, E.pw_vb.d_info, nbig, E.d_info);
         }
