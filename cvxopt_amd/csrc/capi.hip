@@ -988,24 +988,24 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, i
         set_last_error("coneqp_lp: needs dims = {'l': m > 0} and no equality constraints");
         return MI355KKT_ENOTIMPL;
     }
-    if (hs->sparse) { set_last_error("coneqp_lp: sparse mode not supported yet"); return MI355KKT_ENOTIMPL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->ml;
     if (int e = ipm_alloc(hs->ipm, 1, n, m)) return e;
     const IpmState& S = hs->ipm.S;
     hipStream_t st = hs->st;
-    if (hs->dH) {     // only tril(H) is meaningful (coneprog.py:1475-1477): P x needs the mirrored matrix
+    if (hs->dH && !hs->sparse) {     // only tril(H) is meaningful (coneprog.py:1475-1477): P x needs the mirrored matrix
         if (!hs->dHsym) KKT_HIP_CHECK(hipMalloc(&hs->dHsym, sizeof(double) * (size_t)n * n));
         KKT_HIP_CHECK(hipMemcpy2DAsync(hs->dHsym, sizeof(double) * n, hs->dH, sizeof(double) * hs->ldH, sizeof(double) * n, n,
                                        hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(symmetrize_kernel, dim3((n + 15) / 16, (n + 15) / 16, 1), dim3(16, 16), 0, st, hs->dHsym, n, (int64_t)0);
     }
     double* scratch = hs->dzs;       // >= cdim doubles; free between solves
-    if (!hs->dIpmWork)
+    if (!hs->dIpmWork && !hs->sparse)
         KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n))));
     double* gwork = hs->dIpmWork;
     IpmOps ops;
     ops.products = [&]() -> int {
+        if (hs->sparse) return sparse_engine_products(hs->sp, S.x, S.z, S.Gx, S.GTz, S.Px, st);
         if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, S.x, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
         KKT_HIP_CHECK(hipMemsetAsync(S.GTz, 0, sizeof(double) * n, st));
         if (int e = launch_gemv_t_scaled(hs->dG, hs->ldG, m, n, nullptr, S.z, scratch, S.GTz, gwork, st)) return e;

@@ -143,11 +143,12 @@ struct SparseEngine {
     int *d_sn_first = nullptr, *d_sn_rows = nullptr, *d_child_ptr = nullptr, *d_child_list = nullptr, *d_relmap = nullptr,
         *d_level_sn = nullptr, *d_asm_a = nullptr, *d_asm_b = nullptr, *d_asm_r = nullptr, *d_perm = nullptr,
         *d_gri = nullptr, *d_gci = nullptr, *d_gnzmap = nullptr, *d_info = nullptr, *h_info = nullptr, *d_upd_ld = nullptr,
-        *d_heavy = nullptr;
+        *d_heavy = nullptr, *d_hci = nullptr, *d_hmap = nullptr;
     VbDesc* d_vb = nullptr;
     PotrfWork pw_vb;
     int64_t *d_sn_rowptr = nullptr, *d_panel_off = nullptr, *d_upd_off = nullptr, *d_relmap_off = nullptr,
-            *d_asm_slot = nullptr, *d_asm_ptr = nullptr, *d_gcp = nullptr, *d_grp = nullptr, *d_rem_off = nullptr;
+            *d_asm_slot = nullptr, *d_asm_ptr = nullptr, *d_gcp = nullptr, *d_grp = nullptr, *d_rem_off = nullptr,
+            *d_hrp = nullptr;
     double *d_gv = nullptr, *d_hv = nullptr, *d_rem = nullptr, *d_panels = nullptr, *d_upd = nullptr, *d_xp = nullptr;
 };
 int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const int64_t* gri, const int64_t* hcp,
@@ -157,6 +158,8 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
 void sparse_engine_free(SparseEngine& E);
 int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, int* info);
 int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st);
+int sparse_engine_products(SparseEngine& E, const double* d_x, const double* d_z, double* d_Gx, double* d_GTz, double* d_Px,
+                           hipStream_t st);
 int sparse_engine_gemv_t(SparseEngine& E, const double* d_w, const double* d_z, double* d_zs, double* d_zss, double* d_x,
                          hipStream_t st);
 int sparse_engine_gemv_n(SparseEngine& E, const double* d_w, const double* d_x, const double* d_zs, double* d_z,

@@ -899,6 +899,16 @@ __global__ __launch_bounds__(256) void sp_gemv_n_kernel(int m, const int64_t* __
     for (int64_t k = rp[r]; k < rp[r + 1]; ++k) s += gv[nzmap[k]] * x[ci[k]];
     z[r] = w[r] * s - zs[r];
 }
+// y = A x for a CSR pattern whose values are looked up through nzmap (G by rows; H mirrored to a full symmetric CSR)
+__global__ __launch_bounds__(256) void sp_spmv_kernel(int m, const int64_t* __restrict__ rp, const int* __restrict__ ci,
+                                                      const int* __restrict__ nzmap, const double* __restrict__ vals,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    double s = 0.0;
+    for (int64_t k = rp[r]; k < rp[r + 1]; ++k) s += vals[nzmap[k]] * x[ci[k]];
+    y[r] = s;
+}
 __global__ void sp_scale2_kernel(const double* __restrict__ w, const double* __restrict__ z, double* __restrict__ zs,
                                  double* __restrict__ zss, int m) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -962,6 +972,30 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
                 ci[p] = j;
                 nzmap[p] = (int)k;
             }
+        if (hcp) {   // H mirrored to a full symmetric CSR (values by reference to the lower-triangular CSC) for P x
+            std::vector<int64_t> hrp(n + 1, 0);
+            for (int j = 0; j < n; ++j)
+                for (int64_t k = hcp[j]; k < hcp[j + 1]; ++k) {
+                    const int i = (int)hri[k];
+                    if (i < j) continue;
+                    hrp[i + 1]++;
+                    if (i != j) hrp[j + 1]++;
+                }
+            for (int r = 0; r < n; ++r) hrp[r + 1] += hrp[r];
+            std::vector<int> hci(hrp[n]), hmap(hrp[n]);
+            std::vector<int64_t> hpos(hrp.begin(), hrp.end() - 1);
+            for (int j = 0; j < n; ++j)
+                for (int64_t k = hcp[j]; k < hcp[j + 1]; ++k) {
+                    const int i = (int)hri[k];
+                    if (i < j) continue;
+                    int64_t q = hpos[i]++;
+                    hci[q] = j; hmap[q] = (int)k;
+                    if (i != j) { q = hpos[j]++; hci[q] = i; hmap[q] = (int)k; }
+                }
+            if (int e = up(&E.d_hrp, hrp)) return e;
+            if (int e = up(&E.d_hci, hci)) return e;
+            if (int e = up(&E.d_hmap, hmap)) return e;
+        }
         if (int e = up(&E.d_gv, gvals)) return e;
         if (int e = up(&E.d_hv, hvals)) return e;
         if (int e = up(&E.d_gcp, cpv)) return e;
@@ -988,7 +1022,7 @@ void sparse_engine_free(SparseEngine& E) {
     void* ptrs[] = {E.d_sn_first, E.d_sn_rowptr, E.d_sn_rows, E.d_panel_off, E.d_upd_off, E.d_child_ptr, E.d_child_list,
                     E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
-                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb};
+                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
@@ -1091,6 +1125,22 @@ int sparse_engine_gemv_n(SparseEngine& E, const double* d_w, const double* d_x, 
     if (E.m > 0)
         hipLaunchKernelGGL(sp_gemv_n_kernel, dim3((E.m + 255) / 256), dim3(256), 0, st, E.m, E.d_grp, E.d_gci, E.d_gnzmap,
                            E.d_gv, d_x, d_w, d_zs, d_z);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// residual products of the interior-point loop (coneprog.py:2170-2186): Gx = G x, GTz = G' z, Px = H x
+int sparse_engine_products(SparseEngine& E, const double* d_x, const double* d_z, double* d_Gx, double* d_GTz, double* d_Px,
+                           hipStream_t st) {
+    const dim3 gn((E.n + 255) / 256), gm((E.m + 255) / 256);
+    if (E.m > 0)
+        hipLaunchKernelGGL(sp_spmv_kernel, gm, dim3(256), 0, st, E.m, E.d_grp, E.d_gci, E.d_gnzmap, E.d_gv, d_x, d_Gx);
+    KKT_HIP_CHECK(hipMemsetAsync(d_GTz, 0, sizeof(double) * E.n, st));
+    if (E.m > 0) hipLaunchKernelGGL(sp_gemv_t_kernel, gn, dim3(256), 0, st, E.n, E.d_gcp, E.d_gri, E.d_gv, d_z, d_GTz);
+    if (E.d_hrp)
+        hipLaunchKernelGGL(sp_spmv_kernel, gn, dim3(256), 0, st, E.n, E.d_hrp, E.d_hci, E.d_hmap, E.d_hv, d_x, d_Px);
+    else
+        KKT_HIP_CHECK(hipMemsetAsync(d_Px, 0, sizeof(double) * E.n, st));
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

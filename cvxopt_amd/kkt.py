@@ -285,8 +285,8 @@ class _Engine(object):
             raise NotImplementedError("device-resident coneqp: LP cone without equality constraints only")
         if not keep_H:                    # keep_H: H was placed with set_H_device / a previous call
             self._set_H(P)
-        if self._mode != "dense":
-            raise NotImplementedError("device-resident coneqp: dense mode only")
+        if self._mode == "undecided":
+            raise ValueError("device-resident coneqp: G / P not placed on the device yet")
         n, m = self.n, self.cdim
         qv = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1))
         hv = np.ascontiguousarray(np.asarray(h, dtype=np.float64).reshape(-1))

@@ -130,7 +130,7 @@ int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL);
  * The coneqp loop of coneprog.py:2044-2547 for dims = {'l': ml}, p = 0, run around this handle's factor/solve with the
  * iterates, the Nesterov-Todd scaling (misc.py:284-287, :444-464) and the step bookkeeping (coneprog.py:2376-2456)
  * resident in HBM: per iteration one word ("still active?") and the factorisation info cross PCIe.  G (set_G_*) and
- * optionally H = P (set_H_*) must be set; dense mode only.  q: n, hv: ml (host).  Outputs (host): x (n), s, z (ml),
+ * optionally H = P (set_H_*), or the sparse problem (set_sparse_problem), must be set.  q: n, hv: ml (host).  Outputs (host): x (n), s, z (ml),
  * *status (1 optimal, 2 unknown: iteration limit, 3 unknown: singular KKT matrix), *iters, *pcost, *dcost, *gap.
  * Returns 0; <0 on error; 1 if the initial factorisation failed (the ValueError of coneprog.py:2065-2066). */
 int mi355kkt_coneqp_lp(mi355kkt_solver* h, const double* q, const double* hv, int maxiters, double abstol, double reltol,

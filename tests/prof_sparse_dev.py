@@ -24,3 +24,8 @@ for r in range(3):
     x, z = rng.standard_normal(n), rng.standard_normal(2 * n)
     t = time.perf_counter(); s(x, np.zeros(0), z); ts = time.perf_counter() - t
     print("factor %.2f ms solve %.2f ms" % (tf * 1e3, ts * 1e3))
+import cvxopt_amd
+q, h = -np.ones(n), np.ones(2 * n)
+for r in range(2):
+    t = time.perf_counter(); sol = cvxopt_amd.coneqp_lp(Pl, q, FakeSp(G), h); t = time.perf_counter() - t
+    print("resident coneqp: %.3f s wall (incl. symbolic analysis), %s, %d iterations, pobj %.9e" % (t, sol['status'], sol['iterations'], sol['primal objective']))

@@ -131,3 +131,46 @@ def test_sparse_coneqp_drop_in_matches_reference_sparse_branch(ref_cvxopt):
     assert abs(got['primal objective'] - ref['primal objective']) <= 1e-9 * abs(ref['primal objective'])
     assert relerr(np.array(got['x']).ravel(), np.array(ref['x']).ravel()) < 1e-7
     ks.engine.close()
+
+
+def test_sparse_resident_coneqp_matches_reference_sparse_branch(ref_cvxopt):
+    """Device-resident loop in sparse mode (sparse residual products + supernodal factor/solve) vs the unmodified
+    reference's sparse kkt_chol2 run of the same box-QP."""
+    import cvxopt_amd
+    from cvxopt import matrix, spmatrix, solvers
+    nx = 20
+    P = laplace2d(nx, nx)
+    n = nx * nx
+    Pc = sp.tril(P).tocoo()
+    Pcv = spmatrix(list(Pc.data), list(map(int, Pc.row)), list(map(int, Pc.col)), (n, n))
+    Gc = box(n).tocoo()
+    Gcv = spmatrix(list(Gc.data), list(map(int, Gc.row)), list(map(int, Gc.col)), (2 * n, n))
+    q, h = -np.ones(n), np.ones(2 * n)
+    ref = solvers.coneqp(Pcv, matrix(q), Gcv, matrix(h), kktsolver='chol2')
+    got = cvxopt_amd.coneqp_lp(Pcv, q, Gcv, h)
+    assert got['status'] == ref['status'] == 'optimal'
+    assert got['iterations'] == ref['iterations']
+    assert abs(got['primal objective'] - ref['primal objective']) <= 1e-9 * abs(ref['primal objective'])
+    assert abs(got['dual objective'] - ref['dual objective']) <= 1e-9 * abs(ref['dual objective'])
+    assert relerr(got['x'], np.array(ref['x']).ravel()) < 1e-7
+    assert relerr(got['z'], np.array(ref['z']).ravel()) < 1e-6
+
+
+@pytest.mark.parametrize("maker,arg", [(laplace2d, (60, 45)), (laplace3d, (14,))])
+def test_sparse_resident_coneqp_matches_dense_resident(maker, arg):
+    """Same problem through the sparse engine and (densified) through the dense engine: same iterates."""
+    import time
+    import cvxopt_amd
+    P = maker(*arg)
+    n = P.shape[0]
+    G = box(n)
+    rng = np.random.default_rng(n)
+    q, h = rng.standard_normal(n), 0.5 + rng.random(2 * n)
+    t = time.perf_counter()
+    a = cvxopt_amd.coneqp_lp(FakeSp(sp.tril(P)), q, FakeSp(G), h)
+    ta = time.perf_counter() - t
+    b = cvxopt_amd.coneqp_lp(np.asfortranarray(P.toarray()), q, np.asfortranarray(G.toarray()), h)
+    print("sparse resident coneqp n=%d: %.3f s, %d iterations" % (n, ta, a['iterations']))
+    assert a['status'] == b['status'] == 'optimal' and a['iterations'] == b['iterations']
+    assert abs(a['primal objective'] - b['primal objective']) <= 1e-9 * max(1.0, abs(b['primal objective']))
+    assert relerr(a['x'], b['x']) < 1e-7 and relerr(a['z'], b['z']) < 1e-6
