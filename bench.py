@@ -195,7 +195,7 @@ def main():
                          "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel_ms": round(kernel_ms, 3), "flops_per_launch": flops},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (rank 0, host cores)
             try:
                 out["cpu_baseline"] = cpu_baseline(pr, W_np, n, m, args.cpu_iters)
                 out["speedup_vs_cpu"] = round(out["cpu_baseline"]["value"] / ms_per_step, 2)

@@ -44,7 +44,11 @@ __global__ __launch_bounds__(256) void ipm_start_kernel(IpmState S) {
     for (int i = tid; i < m; i += 256) c += h[i] * h[i];
     a = block_sum(a, sh);
     c = block_sum(c, sh);
+    double e = 0.0;
+    for (int i = tid; i < S.p; i += 256) e += S.b[(int64_t)b * S.p + i] * S.b[(int64_t)b * S.p + i];
+    e = block_sum(e, sh);
     if (tid == 0) {
+        if (S.p > 0) S.resy0[b] = fmax(1.0, sqrt(e));
         S.resx0[b] = fmax(1.0, sqrt(a));
         S.resz0[b] = fmax(1.0, sqrt(c));
         S.active[b] = 1;
@@ -91,14 +95,34 @@ __global__ __launch_bounds__(256) void ipm_residual_kernel(IpmState S, int it, i
     const double* gx = S.Gx + (int64_t)b * m;
     const double* h = S.h + (int64_t)b * m;
     double* rz = S.rz + (int64_t)b * m;
+    const int p = S.p;
+    const double* aty = p > 0 ? S.ATy + (int64_t)b * n : nullptr;
     double f0a = 0.0, f0b = 0.0, r2 = 0.0;
     for (int i = tid; i < n; i += 256) {
         const double t = q[i] + px[i];
         f0a += x[i] * t;
         f0b += x[i] * q[i];
-        const double r = t + gtz[i];
+        double r = t;
+        if (p > 0) r += aty[i];                 // rx = P x + q + A'y + G'z in the reference's order (coneprog.py:2170-2178)
+        r += gtz[i];
         rx[i] = r;
         r2 += r * r;
+    }
+    double resy = 0.0, yry = 0.0;
+    if (p > 0) {                                // ry = A x - b (coneprog.py:2181-2183)
+        const double* y = S.y + (int64_t)b * p;
+        const double* ax = S.Ax + (int64_t)b * p;
+        const double* bb = S.b + (int64_t)b * p;
+        double* ry = S.ry + (int64_t)b * p;
+        double e2 = 0.0, d2 = 0.0;
+        for (int i = tid; i < p; i += 256) {
+            const double r = ax[i] - bb[i];
+            ry[i] = r;
+            e2 += r * r;
+            d2 += y[i] * r;
+        }
+        resy = sqrt(block_sum(e2, sh));
+        yry = block_sum(d2, sh);
     }
     f0a = block_sum(f0a, sh);
     f0b = block_sum(f0b, sh);
@@ -114,11 +138,13 @@ __global__ __launch_bounds__(256) void ipm_residual_kernel(IpmState S, int it, i
     zr = block_sum(zr, sh);
     const double gap = S.gap[b];
     const double f0 = 0.5 * (f0a + f0b);
-    const double pcost = f0, dcost = f0 + zr - gap;
+    const double pcost = f0, dcost = f0 + yry + zr - gap;
     double relgap = 1e300;
     if (pcost < 0.0) relgap = gap / -pcost;
     else if (dcost > 0.0) relgap = gap / dcost;
-    const double pres = resz / S.resz0[b], dres = resx / S.resx0[b];
+    double pres = resz / S.resz0[b];
+    if (p > 0) pres = fmax(resy / S.resy0[b], pres);
+    const double dres = resx / S.resx0[b];
     const bool conv = (pres <= feastol) && (dres <= feastol) && ((gap <= abstol) || (relgap <= reltol));
     const bool act = S.active[b] != 0;
     const bool stop = act && (conv || it == maxiters);
@@ -128,6 +154,7 @@ __global__ __launch_bounds__(256) void ipm_residual_kernel(IpmState S, int it, i
         double* zo = S.z_out + (int64_t)b * m;
         for (int i = tid; i < n; i += 256) xo[i] = x[i];
         for (int i = tid; i < m; i += 256) { so[i] = s[i]; zo[i] = z[i]; }
+        for (int i = tid; i < p; i += 256) S.y_out[(int64_t)b * p + i] = S.y[(int64_t)b * p + i];
     }
     if (it == 0) {                                // misc.compute_scaling, 'l' block (misc.py:284-287)
         double* d = S.d + (int64_t)b * m;
@@ -174,6 +201,7 @@ __global__ __launch_bounds__(256) void ipm_freeze_kernel(IpmState S) {
         S.s_out[(int64_t)b * S.m + i] = S.s[(int64_t)b * S.m + i];
         S.z_out[(int64_t)b * S.m + i] = S.z[(int64_t)b * S.m + i];
     }
+    for (int i = tid; i < S.p; i += 256) S.y_out[(int64_t)b * S.p + i] = S.y[(int64_t)b * S.p + i];
     __syncthreads();
     if (tid == 0) S.freeze[b] = 0;
 }
@@ -198,6 +226,7 @@ __global__ __launch_bounds__(256) void ipm_rhs_kernel(IpmState S, int i01) {
     const double* rx = S.rx + (int64_t)b * n;
     double* dx = S.dx + (int64_t)b * n;
     for (int i = tid; i < n; i += 256) dx[i] = -rx[i];
+    for (int i = tid; i < S.p; i += 256) S.dy[(int64_t)b * S.p + i] = -S.ry[(int64_t)b * S.p + i];
 }
 
 __global__ __launch_bounds__(256) void ipm_post_kernel(IpmState S, int i01) {
@@ -240,6 +269,7 @@ __global__ __launch_bounds__(256) void ipm_update_kernel(IpmState S) {
     double* x = S.x + (int64_t)b * n;
     const double* dx = S.dx + (int64_t)b * n;
     for (int i = tid; i < n; i += 256) x[i] += step * dx[i];
+    for (int i = tid; i < S.p; i += 256) S.y[(int64_t)b * S.p + i] += step * S.dy[(int64_t)b * S.p + i];
     double* lm = S.lmbda + (int64_t)b * m;
     double* d = S.d + (int64_t)b * m;
     double* s = S.s + (int64_t)b * m;

@@ -91,16 +91,16 @@ static void ipm_free(IpmWork& w) {
     if (w.pinned) (void)hipHostFree(w.pinned);
     w = IpmWork();
 }
-static int ipm_alloc(IpmWork& w, int nbatch, int n, int m) {
+static int ipm_alloc(IpmWork& w, int nbatch, int n, int m, int np = 0) {
     if (w.f64) return 0;
-    const size_t B = nbatch, N = n, M = m ? m : 1;
-    const size_t nd = B * (7 * N + 13 * M + 8);
+    const size_t B = nbatch, N = n, M = m ? m : 1, Pq = np;
+    const size_t nd = B * (8 * N + 13 * M + 6 * Pq + 9);
     if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
     if (hipMalloc(&w.i32, sizeof(int) * (5 * B + 1)) != hipSuccess) return MI355KKT_ENOMEM;
     if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
     w.B = nbatch;
     IpmState& S = w.S;
-    S.n = n; S.m = m;
+    S.n = n; S.m = m; S.p = np;
     double* p = w.f64;
     auto take = [&](size_t k) { double* r = p; p += k; return r; };
     S.q = take(B * N); S.x = take(B * N); S.rx = take(B * N); S.dx = take(B * N);
@@ -109,7 +109,12 @@ static int ipm_alloc(IpmWork& w, int nbatch, int n, int m) {
     S.lmbda = take(B * M); S.d = take(B * M); S.di = take(B * M); S.ws3 = take(B * M); S.Gx = take(B * M);
     S.s_out = take(B * M); S.z_out = take(B * M);
     S.gap = take(B); S.resx0 = take(B); S.resz0 = take(B); S.step = take(B); S.sigma = take(B);
-    S.pcost = take(B); S.dcost = take(B); S.gap_out = take(B);
+    S.pcost = take(B); S.dcost = take(B); S.gap_out = take(B); S.resy0 = take(B);
+    S.ATy = take(B * N);
+    if (np > 0) {
+        S.b = take(B * Pq); S.y = take(B * Pq); S.ry = take(B * Pq); S.dy = take(B * Pq); S.Ax = take(B * Pq);
+        S.y_out = take(B * Pq);
+    }
     int* q = w.i32;
     S.active = q; S.status = q + B; S.iters = q + 2 * B; S.freeze = q + 3 * B; S.nactive = q + 4 * B;
     return 0;
@@ -893,15 +898,16 @@ int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device)
 struct IpmOps {
     std::function<int()> products;
     std::function<int(const double* di, int* d_info, int* h_info_first)> factor;
-    std::function<int(double* dx, double* dz)> solve;
+    std::function<int(double* dx, double* dy, double* dz)> solve;
 };
 struct IpmHostOut {
-    double *x, *s, *z; int *status, *iters; double *pcost, *dcost, *gap; int* iterations_run;
+    double *x, *s, *z; int *status, *iters; double *pcost, *dcost, *gap; int* iterations_run; double* y;
 };
-static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, const double* h, int maxiters, double abstol,
-                   double reltol, double feastol, const IpmHostOut& o) {
+static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, const double* h, const double* bvec,
+                   int maxiters, double abstol, double reltol, double feastol, const IpmHostOut& o) {
     const IpmState& S = w.S;
-    const size_t B = w.B, N = S.n, M = S.m;
+    const size_t B = w.B, N = S.n, M = S.m, Pq = S.p;
+    if (Pq > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bvec, sizeof(double) * B * Pq, hipMemcpyHostToDevice, st));
     int* d_info = ipm_info_words(w);
     KKT_HIP_CHECK(hipMemcpyAsync(S.q, q, sizeof(double) * B * N, hipMemcpyHostToDevice, st));
     KKT_HIP_CHECK(hipMemcpyAsync(S.h, h, sizeof(double) * B * M, hipMemcpyHostToDevice, st));
@@ -913,7 +919,8 @@ static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, con
     if (first_bad >= 0) { set_last_error("coneqp: Rank([P; G]) < n (problem %d)", first_bad); return 1; }
     hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st, S.x, S.q, -1.0, (int64_t)(B * N));
     KKT_HIP_CHECK(hipMemcpyAsync(S.z, S.h, sizeof(double) * B * M, hipMemcpyDeviceToDevice, st));
-    if (int e = ops.solve(S.x, S.z)) return e;
+    if (Pq > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.y, S.b, sizeof(double) * B * Pq, hipMemcpyDeviceToDevice, st));
+    if (int e = ops.solve(S.x, S.y, S.z)) return e;
     ipm_launch_start(S, (int)B, st);
     int it = 0;
     for (; it <= maxiters; ++it) {
@@ -927,7 +934,7 @@ static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, con
         ipm_launch_info(S, d_info, it, (int)B, st);
         for (int i01 = 0; i01 < 2; ++i01) {
             ipm_launch_rhs(S, (int)B, i01, st);
-            if (int e = ops.solve(S.dx, S.dz)) return e;
+            if (int e = ops.solve(S.dx, S.dy, S.dz)) return e;
             ipm_launch_post(S, (int)B, i01, st);
         }
         ipm_launch_update(S, (int)B, st);
@@ -935,6 +942,7 @@ static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, con
     KKT_HIP_CHECK(hipMemcpyAsync(o.x, S.x_out, sizeof(double) * B * N, hipMemcpyDeviceToHost, st));
     if (o.s) KKT_HIP_CHECK(hipMemcpyAsync(o.s, S.s_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
     if (o.z) KKT_HIP_CHECK(hipMemcpyAsync(o.z, S.z_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
+    if (o.y && Pq > 0) KKT_HIP_CHECK(hipMemcpyAsync(o.y, S.y_out, sizeof(double) * B * Pq, hipMemcpyDeviceToHost, st));
     KKT_HIP_CHECK(hipMemcpyAsync(o.status, S.status, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     KKT_HIP_CHECK(hipMemcpyAsync(o.iters, S.iters, sizeof(int) * B, hipMemcpyDeviceToHost, st));
     if (o.pcost) KKT_HIP_CHECK(hipMemcpyAsync(o.pcost, S.pcost, sizeof(double) * B, hipMemcpyDeviceToHost, st));
@@ -956,7 +964,7 @@ int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, i
     if (!b || !q || (!h && b->ml) || !x || !status || !iters) { set_last_error("batch_coneqp: null argument"); return MI355KKT_EINVAL; }
     if (b->ml < 1) { set_last_error("batch_coneqp: needs at least one inequality"); return MI355KKT_EINVAL; }
     KKT_HIP_CHECK(hipSetDevice(b->device));
-    if (int e = ipm_alloc(b->ipm, b->nbatch, b->n, b->ml)) return e;
+    if (int e = ipm_alloc(b->ipm, b->nbatch, b->n, b->ml, 0)) return e;
     const IpmState& S = b->ipm.S;
     struct Guard { mi355kkt_batch* b; ~Guard() { b->defer_sync = false; } } guard{b};
     b->defer_sync = true;
@@ -973,24 +981,30 @@ int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, i
         }
         return 0;
     };
-    ops.solve = [&](double* dx, double* dz) { return mi355kkt_batch_solve(b, dx, dz, 1); };
-    IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, iterations_run};
-    return run_ipm(b->ipm, b->st, ops, q, h, maxiters, abstol, reltol, feastol, o);
+    ops.solve = [&](double* dx, double*, double* dz) { return mi355kkt_batch_solve(b, dx, dz, 1); };
+    IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, iterations_run, nullptr};
+    return run_ipm(b->ipm, b->st, ops, q, h, nullptr, maxiters, abstol, reltol, feastol, o);
 }
 
 /* Single problem, LP cone, no equality constraints: the coneqp loop of coneprog.py:2044-2547 resident on the device around
  * this handle's own factor/solve (dense or sparse mode).  G (and H, if any) must have been set.  See include/mi355kkt.h. */
-int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, int maxiters, double abstol, double reltol,
-                       double feastol, double* x, double* s, double* z, int* status, int* iters, double* pcost,
-                       double* dcost, double* gap) {
-    if (!hs || !q || !hv || !x || !status || !iters) { set_last_error("coneqp_lp: null argument"); return MI355KKT_EINVAL; }
-    if (!hs->q.empty() || !hs->s.empty() || hs->p != 0 || hs->ml < 1) {
-        set_last_error("coneqp_lp: needs dims = {'l': m > 0} and no equality constraints");
+int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, const double* bv, int maxiters,
+                       double abstol, double reltol, double feastol, double* x, double* y, double* s, double* z, int* status,
+                       int* iters, double* pcost, double* dcost, double* gap) {
+    if (!hs || !q || !hv || !x || !status || !iters || (hs->p > 0 && (!bv || !y))) {
+        set_last_error("coneqp_lp: null argument");
+        return MI355KKT_EINVAL;
+    }
+    if (!hs->q.empty() || !hs->s.empty() || hs->ml < 1) {
+        set_last_error("coneqp_lp: needs dims = {'l': m > 0}");
         return MI355KKT_ENOTIMPL;
     }
+    if (hs->sparse && hs->p > 0) { set_last_error("coneqp_lp: equality constraints need the dense engine"); return MI355KKT_ENOTIMPL; }
+    if (hs->p > 0 && !hs->dA) { set_last_error("coneqp_lp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->ml;
-    if (int e = ipm_alloc(hs->ipm, 1, n, m)) return e;
+    const int np = hs->p;
+    if (int e = ipm_alloc(hs->ipm, 1, n, m, np)) return e;
     const IpmState& S = hs->ipm.S;
     hipStream_t st = hs->st;
     if (hs->dH && !hs->sparse) {     // only tril(H) is meaningful (coneprog.py:1475-1477): P x needs the mirrored matrix
@@ -1001,7 +1015,8 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, i
     }
     double* scratch = hs->dzs;       // >= cdim doubles; free between solves
     if (!hs->dIpmWork && !hs->sparse)
-        KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n))));
+        KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n)),
+                                                                    gemv_work_doubles(np, n))));
     double* gwork = hs->dIpmWork;
     IpmOps ops;
     ops.products = [&]() -> int {
@@ -1013,6 +1028,11 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, i
             if (int e = launch_gemv_n_scaled(hs->dHsym, n, n, n, nullptr, S.x, S.Px, S.Px, 1.0, 0.0, gwork, st)) return e;
         } else {
             KKT_HIP_CHECK(hipMemsetAsync(S.Px, 0, sizeof(double) * n, st));
+        }
+        if (np > 0) {                                  // A x and A' y (coneprog.py:2176, :2181)
+            if (int e = launch_gemv_n_scaled(hs->dA, hs->ldA, np, n, nullptr, S.x, S.Ax, S.Ax, 1.0, 0.0, gwork, st)) return e;
+            KKT_HIP_CHECK(hipMemsetAsync(S.ATy, 0, sizeof(double) * n, st));
+            if (int e = launch_gemv_t_scaled(hs->dA, hs->ldA, np, n, nullptr, S.y, hs->dtp, S.ATy, gwork, st)) return e;
         }
         return 0;
     };
@@ -1027,9 +1047,9 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, i
         if (info > 0) hs->factored = true;   // the loop drops the problem before any solve result is used
         return 0;
     };
-    ops.solve = [&](double* dx, double* dz) { return mi355kkt_solve_device(hs, dx, nullptr, dz); };
-    IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, nullptr};
-    return run_ipm(hs->ipm, st, ops, q, hv, maxiters, abstol, reltol, feastol, o);
+    ops.solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_solve_device(hs, dx, dy, dz); };
+    IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, nullptr, y};
+    return run_ipm(hs->ipm, st, ops, q, hv, bv, maxiters, abstol, reltol, feastol, o);
 }
 
 float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b) { return b ? b->t_factor : 0.0f; }

@@ -190,7 +190,10 @@ int launch_cone_scale(const ConeLayout& cl, const double* in, int64_t ldi, doubl
 
 // ---- device-resident LP-cone coneqp loop for a batch (batch_ipm.hip) --------------------------------
 struct IpmState {
-    int n = 0, m = 0;
+    int n = 0, m = 0, p = 0;
+    // equality constraints A x = b (single-problem entry point only; p = 0 in the batched mode), [B][p]
+    double *b = nullptr, *y = nullptr, *ry = nullptr, *dy = nullptr, *Ax = nullptr, *y_out = nullptr, *resy0 = nullptr;
+    double* ATy = nullptr;     // [B][n]
     // problem data and iterates, [B][n] / [B][m]
     double *q = nullptr, *h = nullptr, *x = nullptr, *s = nullptr, *z = nullptr;
     double *rx = nullptr, *rz = nullptr, *dx = nullptr, *dz = nullptr, *ds = nullptr;

@@ -278,11 +278,11 @@ class _Engine(object):
     def sync(self):
         _capi.check(self.L.mi355kkt_sync(self.h), "mi355kkt_sync")
 
-    def coneqp(self, q, h, P=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, keep_H=False):
+    def coneqp(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, keep_H=False):
         """The reference coneqp loop (coneprog.py:2044-2547; LP cone, no equalities) resident on the device around
         this handle (`mi355kkt_coneqp_lp`).  Returns a dict with the reference's keys, vectors as NumPy arrays."""
-        if self.dims['q'] or self.dims['s'] or self.p:
-            raise NotImplementedError("device-resident coneqp: LP cone without equality constraints only")
+        if self.dims['q'] or self.dims['s']:
+            raise NotImplementedError("device-resident coneqp: LP cone only")
         if not keep_H:                    # keep_H: H was placed with set_H_device / a previous call
             self._set_H(P)
         if self._mode == "undecided":
@@ -290,20 +290,21 @@ class _Engine(object):
         n, m = self.n, self.cdim
         qv = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1))
         hv = np.ascontiguousarray(np.asarray(h, dtype=np.float64).reshape(-1))
-        if qv.size != n or hv.size != m:
-            raise TypeError("q / h have the wrong length")
-        x, s, z = np.zeros(n), np.zeros(m), np.zeros(m)
+        bv = np.ascontiguousarray(np.asarray(b if b is not None else [], dtype=np.float64).reshape(-1))
+        if qv.size != n or hv.size != m or bv.size != self.p:
+            raise TypeError("q / h / b have the wrong length")
+        x, y, s, z = np.zeros(n), np.zeros(self.p), np.zeros(m), np.zeros(m)
         status, iters = C.c_int(0), C.c_int(0)
         pc, dc, gap = C.c_double(0), C.c_double(0), C.c_double(0)
-        rc = self.L.mi355kkt_coneqp_lp(self.h, _ptr(qv), _ptr(hv), int(maxiters), float(abstol), float(reltol),
-                                       float(feastol), _ptr(x), _ptr(s), _ptr(z), C.byref(status), C.byref(iters),
-                                       C.byref(pc), C.byref(dc), C.byref(gap))
+        rc = self.L.mi355kkt_coneqp_lp(self.h, _ptr(qv), _ptr(hv), _ptr(bv), int(maxiters), float(abstol), float(reltol),
+                                       float(feastol), _ptr(x), _ptr(y), _ptr(s), _ptr(z), C.byref(status),
+                                       C.byref(iters), C.byref(pc), C.byref(dc), C.byref(gap))
         if rc == 1:
             raise ValueError("Rank([P; A; G]) < n")                       # coneprog.py:2065-2066
         _capi.check(rc, "mi355kkt_coneqp_lp")
         pcost, dcost, g = pc.value, dc.value, gap.value
         relgap = g / -pcost if pcost < 0.0 else (g / dcost if dcost > 0.0 else None)
-        return {'x': x, 'y': np.zeros(0), 's': s, 'z': z, 'status': 'optimal' if status.value == 1 else 'unknown',
+        return {'x': x, 'y': y, 's': s, 'z': z, 'status': 'optimal' if status.value == 1 else 'unknown',
                 'gap': g, 'relative gap': relgap, 'primal objective': pcost, 'dual objective': dcost,
                 'iterations': iters.value}
 
@@ -323,15 +324,15 @@ def _factory(kind, G, dims, A, mnl=0, kktreg=None):
     return factor
 
 
-def coneqp_lp(P, q, G, h, kktsolver='chol2', maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):
-    """min 1/2 x'Px + q'x  s.t.  Gx <= h  with the whole interior-point loop on the MI355X (no host round trips
+def coneqp_lp(P, q, G, h, A=None, b=None, kktsolver='chol2', maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):
+    """min 1/2 x'Px + q'x  s.t.  Gx <= h, Ax = b  with the whole interior-point loop on the MI355X (no host round trips
     for the residual products or the cone-vector bookkeeping).  P, G: cvxopt 'd' matrices or NumPy arrays
     (only tril(P) is read, like the reference).  Iterates match `solvers.coneqp(P, q, G, h)`."""
     kind = {'chol2': _capi.CHOL2, 'chol': _capi.CHOL, 'ldl': _capi.LDL, 'ldl2': _capi.LDL2}[kktsolver]
     m, n = _size(G)
-    eng = _Engine(kind, G, {'l': m, 'q': [], 's': []}, _EmptyA(n))
+    eng = _Engine(kind, G, {'l': m, 'q': [], 's': []}, A if A is not None else _EmptyA(n))
     try:
-        return eng.coneqp(q, h, P, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol)
+        return eng.coneqp(q, h, P, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol)
     finally:
         eng.close()
 

@@ -127,15 +127,16 @@ int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n);
 int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL);
 
 /* ---- device-resident interior-point loop -----------------------------------------
- * The coneqp loop of coneprog.py:2044-2547 for dims = {'l': ml}, p = 0, run around this handle's factor/solve with the
+ * The coneqp loop of coneprog.py:2044-2547 for dims = {'l': ml} (equality constraints A x = b allowed with the dense
+ * engine: bv, y of length p; NULL when p = 0), run around this handle's factor/solve with the
  * iterates, the Nesterov-Todd scaling (misc.py:284-287, :444-464) and the step bookkeeping (coneprog.py:2376-2456)
  * resident in HBM: per iteration one word ("still active?") and the factorisation info cross PCIe.  G (set_G_*) and
  * optionally H = P (set_H_*), or the sparse problem (set_sparse_problem), must be set.  q: n, hv: ml (host).  Outputs (host): x (n), s, z (ml),
  * *status (1 optimal, 2 unknown: iteration limit, 3 unknown: singular KKT matrix), *iters, *pcost, *dcost, *gap.
  * Returns 0; <0 on error; 1 if the initial factorisation failed (the ValueError of coneprog.py:2065-2066). */
-int mi355kkt_coneqp_lp(mi355kkt_solver* h, const double* q, const double* hv, int maxiters, double abstol, double reltol,
-                       double feastol, double* x, double* s, double* z, int* status, int* iters, double* pcost,
-                       double* dcost, double* gap);
+int mi355kkt_coneqp_lp(mi355kkt_solver* h, const double* q, const double* hv, const double* bv, int maxiters,
+                       double abstol, double reltol, double feastol, double* x, double* y, double* s, double* z, int* status,
+                       int* iters, double* pcost, double* dcost, double* gap);
 
 /* ---- batched mode: nbatch independent dense LP-cone problems of one shape (BASELINE configs[4]) ---------
  * No reference API exists for this; per problem it is exactly factor()/solve() of the

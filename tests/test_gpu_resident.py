@@ -84,3 +84,41 @@ def test_resident_coneqp_full_size_config2():
     assert np.linalg.norm(pr['G'] @ x + s - pr['h']) <= 1e-7 * max(1.0, np.linalg.norm(pr['h']))
     assert np.linalg.norm(pr['P'] @ x + pr['q'] + pr['G'].T @ z) <= 1e-7 * max(1.0, np.linalg.norm(pr['q']))
     assert abs(s @ z - sol['gap']) <= 1e-9 * max(1.0, sol['gap'])
+
+
+@pytest.mark.parametrize("n,m,p,kind", [(64, 150, 9, 'chol2'), (200, 310, 40, 'chol'), (120, 100, 33, 'ldl')])
+def test_resident_coneqp_with_equality_constraints(ref_cvxopt, n, m, p, kind):
+    """A x = b in the device-resident loop: y, ry, dy bookkeeping of coneprog.py:2170-2190, :2459-2463."""
+    from cvxopt import matrix, solvers
+    pr = synth.dense_qp(n, m, seed=7 + n, p=p)
+    ref = solvers.coneqp(matrix(pr['P']), matrix(pr['q']), matrix(pr['G']), matrix(pr['h']), A=matrix(pr['A']),
+                         b=matrix(pr['b']), kktsolver='chol2')
+    sol = cvxopt_amd.coneqp_lp(pr['P'], pr['q'], pr['G'], pr['h'], A=pr['A'], b=pr['b'], kktsolver=kind)
+    assert sol['status'] == ref['status'] == 'optimal'
+    assert sol['iterations'] == ref['iterations']
+    for k in ('primal objective', 'dual objective'):
+        assert abs(sol[k] - ref[k]) <= 1e-9 * max(1.0, abs(ref[k])), k
+    assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-7
+    assert relerr(sol['y'], np.array(ref['y']).ravel()) < 1e-6
+    assert relerr(sol['z'], np.array(ref['z']).ravel()) < 1e-6
+    assert np.linalg.norm(pr['A'] @ sol['x'] - pr['b']) <= 1e-8 * max(1.0, np.linalg.norm(pr['b']))
+
+
+def test_resident_coneqp_equalities_singular_P_uses_S_plus_AtA(ref_cvxopt):
+    """P + G'G singular on the first call (few inequalities, P = 0 on half of the space; the objective is still
+    strictly convex on {A x = b}): the engine's S += A'A fallback
+    (misc.py:1433-1447) inside the resident loop."""
+    from cvxopt import matrix, solvers
+    rng = np.random.default_rng(11)
+    n, m, p = 30, 12, 20
+    G = rng.standard_normal((m, n))
+    A = rng.standard_normal((p, n))
+    x0 = rng.standard_normal(n)
+    h, b = G @ x0 + 0.5 + rng.random(m), A @ x0
+    q = rng.standard_normal(n)
+    P = np.diag(np.concatenate([np.ones(15), np.zeros(15)]))
+    ref = solvers.coneqp(matrix(P), matrix(q), matrix(G), matrix(h), A=matrix(A), b=matrix(b), kktsolver='chol2')
+    sol = cvxopt_amd.coneqp_lp(P, q, G, h, A=A, b=b)
+    assert sol['status'] == ref['status'] == 'optimal' and sol['iterations'] == ref['iterations']
+    assert abs(sol['primal objective'] - ref['primal objective']) <= 1e-8 * max(1.0, abs(ref['primal objective']))
+    assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-6
