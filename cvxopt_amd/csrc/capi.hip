@@ -1132,6 +1132,24 @@ int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX
     return rc;
 }
 
+}  // extern "C"
+__global__ void hwid_probe_kernel(unsigned* out) {
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_REG_HW_ID, all 32 bits
+        out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+    }
+    __builtin_amdgcn_s_sleep(127);
+}
+extern "C" {
+/* developer probe: HW_ID / XCC_ID of nblocks one-wave workgroups (out: 2 * nblocks words, host) */
+int mi355kkt_debug_hwid(unsigned* out, int nblocks) {
+    unsigned* d = nullptr;
+    KKT_HIP_CHECK(hipMalloc(&d, sizeof(unsigned) * 2 * nblocks));
+    hipLaunchKernelGGL(hwid_probe_kernel, dim3(nblocks), dim3(64), 0, nullptr, d);
+    KKT_HIP_CHECK(hipMemcpy(out, d, sizeof(unsigned) * 2 * nblocks, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return 0;
+}
 int mi355kkt_debug_potf2_skip(int mask) { return mi355kkt::set_potf2_skip(mask); }
 int mi355kkt_debug_syrk_skip(int mask) { return mi355kkt::set_syrk_skip(mask); }
 

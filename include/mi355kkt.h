@@ -174,6 +174,7 @@ int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* gr
 int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
                            const double* dv, const double* dbeta, float* ms);
 /* developer ablation switch for potf2_kernel phases (timing experiments only; results are wrong when != 0) */
+int mi355kkt_debug_hwid(unsigned* out, int nblocks);
 int mi355kkt_debug_potf2_skip(int mask);
 int mi355kkt_debug_syrk_skip(int mask);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
