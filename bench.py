@@ -34,6 +34,11 @@ def parse():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--m", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="dense", choices=["dense", "batch", "sparse"],
+                    help="dense = BASELINE configs[1] (the headline line, default); batch = configs[4] class "
+                         "(independent n=512 problems, sharded over ranks); sparse = configs[3] class (3-D Laplacian box-QP)")
+    ap.add_argument("--batch", type=int, default=512, help="problems per GPU for --workload batch")
+    ap.add_argument("--grid", type=int, default=46, help="k for the k^3 Laplacian of --workload sparse")
     ap.add_argument("--cpu-iters", type=int, default=2, help="reference CPU iterations timed (bounded sample)")
     return ap.parse_args()
 
@@ -85,8 +90,140 @@ def cpu_baseline(pr, W_np, n, m, iters):
             "iters_per_s": round(1e3 / ms, 4)}
 
 
+def _dist_setup():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    dist = None
+    if world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ):
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    return rank, world, local_rank, torch, dist
+
+
+def _timed(step, args, torch, dist):
+    from cvxopt_amd import _capi
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        _capi.lib().mi355kkt_device_synchronize()
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def main_batch(args):
+    """configs[4] class: every rank owns `--batch` independent dense QPs (n=512, m=1024); a step = the whole
+    device-resident coneqp solve of the rank's shard (no collective in the data path); value = problem-IPM-iterations/s."""
+    rank, world, local_rank, torch, dist = _dist_setup()
+    import numpy as np
+    from cvxopt_amd import synth
+    from cvxopt_amd.batch import BatchKkt, pack_problems
+    B, n, m = args.batch, 512, 1024
+    probs = [synth.dense_qp(n, m, seed=rank * B + i) for i in range(B)]
+    P, q, Gt, h = pack_problems(probs)
+    k = BatchKkt(Gt, P, device=local_rank)
+    res = {}
+
+    def step():
+        res['r'] = k.coneqp(q, h)
+    elapsed = _timed(step, args, torch, dist)
+    its = int(res['r']['iterations'].sum())
+    if dist is not None:
+        t = torch.tensor([its], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t)
+        its = int(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "batched coneqp: problem-IPM-iterations/s (BASELINE configs[4] class)", "value": round(its * args.steps / elapsed, 1),
+            "unit": "problem-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d independent dense QPs per GPU, n=%d, m=%d, whole coneqp solve resident on the device"
+                                   % (B, n, m), "all_optimal": bool(np.all(res['r']['status'] == 'optimal'))}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_sparse(args):
+    """configs[3] class stand-in: P = 3-D 7-point Laplacian + 1e-2 I, box constraints; a step = 1 sparse
+    factor + 2 solves through the hook-level engine with inputs resident; replicas over ranks."""
+    rank, world, local_rank, torch, dist = _dist_setup()
+    import numpy as np
+    import scipy.sparse as sp
+    from cvxopt_amd import kkt, synth, _capi
+    kkt.options["device"] = local_rank
+    k = args.grid
+    e = np.ones(k)
+    T = sp.diags([-e[:-1], 2 * e, -e[:-1]], [-1, 0, 1])
+    I = sp.eye(k)
+    P = (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T) + 1e-2 * sp.eye(k ** 3)).tocsc()
+    n = k ** 3
+    G = sp.vstack([sp.eye(n), -sp.eye(n)]).tocsc()
+
+    class Sp(object):                      # the minimal spmatrix surface cvxopt_amd reads (.size, .CCS)
+        def __init__(self, A):
+            A = sp.csc_matrix(A)
+            A.sort_indices()
+            self.size = A.shape
+            self.CCS = (A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64))
+    dims = {'l': 2 * n, 'q': [], 's': []}
+    t = time.perf_counter()
+    f = kkt.kkt_chol2(Sp(G), dims, np.zeros((0, n)))
+    W = synth.random_scaling(dims, seed=rank, spread=1.0)
+    f(W, Sp(sp.tril(P)))
+    t_sym = time.perf_counter() - t
+    eng = f.engine
+    d_di = _capi.DeviceBuffer.from_array(W['di'])
+    rng = np.random.default_rng(rank)
+    rhs = [(_capi.DeviceBuffer.from_array(rng.standard_normal(n)), _capi.DeviceBuffer.from_array(rng.standard_normal(2 * n)))
+           for _ in range(2)]
+    d_y = _capi.DeviceBuffer(8)
+
+    def step():
+        eng.factor_device(di_ptr=d_di.ptr)
+        for dx, dz in rhs:
+            eng.solve_device(dx.ptr, d_y.ptr, dz.ptr)
+        eng.sync()
+    elapsed = _timed(step, args, torch, dist)
+    if rank == 0:
+        st = eng.sparse_stats()
+        print(json.dumps({
+            "metric": "sparse KKT factor+solve ms/iter (BASELINE configs[3] class)", "value": round(world * args.steps / elapsed, 3),
+            "unit": "KKT iterations/s (1 factor + 2 solves each)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "box-QP on the %d^3 7-point Laplacian (n=%d, m=%d), supernodal multifrontal engine; stand-in for "
+                                   "the ssget-1288 class (no network)" % (k, n, 2 * n), "replicas": world,
+                       "nnzL": st["nnzL"], "supernodes": st["supernodes"], "levels": st["levels"], "flops_estimate": st["flops"],
+                       "symbolic_plus_first_factor_s": round(t_sym, 3)}}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.workload == "batch":
+        return main_batch(args)
+    if args.workload == "sparse":
+        return main_sparse(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
