@@ -121,6 +121,39 @@ static int ipm_alloc(IpmWork& w, int nbatch, int n, int m, int np = 0) {
 }
 static int* ipm_info_words(IpmWork& w) { return w.i32 + 4 * (size_t)w.B + 1; }
 
+struct LpWork {
+    LpState S;
+    double* f64 = nullptr;
+    int* i32 = nullptr;       // active | status | iters | init_optimal | nactive | info
+    int* pinned = nullptr;
+};
+static void lp_free(LpWork& w) {
+    if (w.f64) (void)hipFree(w.f64);
+    if (w.i32) (void)hipFree(w.i32);
+    if (w.pinned) (void)hipHostFree(w.pinned);
+    w = LpWork();
+}
+static int lp_alloc(LpWork& w, int n, int m, int np) {
+    if (w.f64) return 0;
+    const size_t N = n, M = m ? m : 1, Pq = np ? np : 1;
+    const size_t nd = 8 * N + 7 * Pq + 15 * M + LP_NSC;
+    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
+    if (hipMalloc(&w.i32, sizeof(int) * 8) != hipSuccess) return MI355KKT_ENOMEM;
+    if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
+    LpState& S = w.S;
+    S.n = n; S.m = m; S.p = np;
+    double* p = w.f64;
+    auto take = [&](size_t k) { double* r = p; p += k; return r; };
+    S.c = take(N); S.x = take(N); S.dx = take(N); S.rx = take(N); S.x1 = take(N); S.GTz = take(N); S.ATy = take(N); S.x_out = take(N);
+    S.b = take(Pq); S.y = take(Pq); S.dy = take(Pq); S.ry = take(Pq); S.y1 = take(Pq); S.Ax = take(Pq); S.y_out = take(Pq);
+    S.h = take(M); S.s = take(M); S.z = take(M); S.ds = take(M); S.dz = take(M); S.rz = take(M); S.z1 = take(M); S.th = take(M);
+    S.lmbda = take(M); S.d = take(M); S.di = take(M); S.ws3 = take(M); S.Gx = take(M); S.s_out = take(M); S.z_out = take(M);
+    S.sc = take(LP_NSC);
+    int* q = w.i32;
+    S.active = q; S.status = q + 1; S.iters = q + 2; S.init_optimal = q + 3; S.nactive = q + 4;
+    return 0;
+}
+
 struct mi355kkt_solver {
     int device = 0, kind = 0;
     int n = 0, p = 0, ml = 0, cdim = 0;
@@ -163,6 +196,7 @@ struct mi355kkt_solver {
     PotrfWork pw;
     float t_syrk = 0, t_potrf = 0, t_schur = 0, t_factor = 0, t_solve = 0, t_syrk_kernel = 0;
     IpmWork ipm;               // device-resident coneqp loop (mi355kkt_coneqp_lp), allocated on first use
+    LpWork lp;                 // device-resident conelp loop (mi355kkt_conelp_lp)
     double* dHsym = nullptr;   // full symmetric copy of H for the residual product P x
     double* dIpmWork = nullptr;
 };
@@ -325,6 +359,7 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     cone_layout_free(h->cl);
     sparse_engine_free(h->sp);
     ipm_free(h->ipm);
+    lp_free(h->lp);
     if (h->dHsym) (void)hipFree(h->dHsym);
     if (h->dIpmWork) (void)hipFree(h->dIpmWork);
     if (h->dflags) (void)hipFree(h->dflags);
@@ -1050,6 +1085,119 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
     ops.solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_solve_device(hs, dx, dy, dz); };
     IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, nullptr, y};
     return run_ipm(hs->ipm, st, ops, q, hv, bv, maxiters, abstol, reltol, feastol, o);
+}
+
+/* Single problem, LP cone: the conelp loop of coneprog.py:586-1436 (self-dual embedding, default starting point, no
+ * refinement) resident on the device around this handle's factor/solve (H must be absent).  See include/mi355kkt.h. */
+int mi355kkt_conelp_lp(mi355kkt_solver* hs, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
+                       double reltol, double feastol, double* x, double* y, double* s, double* z, int* status, int* iters,
+                       double* stats) {
+    if (!hs || !c || !hv || !x || !s || !z || !status || !iters || (hs->p > 0 && (!bv || !y))) {
+        set_last_error("conelp_lp: null argument");
+        return MI355KKT_EINVAL;
+    }
+    if (!hs->q.empty() || !hs->s.empty() || hs->ml < 1) { set_last_error("conelp_lp: needs dims = {'l': m > 0}"); return MI355KKT_ENOTIMPL; }
+    if (hs->dH) { set_last_error("conelp_lp: the handle carries a quadratic term (H)"); return MI355KKT_EINVAL; }
+    if (hs->sparse && hs->p > 0) { set_last_error("conelp_lp: equality constraints need the dense engine"); return MI355KKT_ENOTIMPL; }
+    if (hs->p > 0 && !hs->dA) { set_last_error("conelp_lp: A not set"); return MI355KKT_EINVAL; }
+    if (int e = bind(hs)) return e;
+    const int n = hs->n, m = hs->ml, np = hs->p;
+    if (int e = lp_alloc(hs->lp, n, m, np)) return e;
+    LpWork& w = hs->lp;
+    const LpState& S = w.S;
+    hipStream_t st = hs->st;
+    if (!hs->dIpmWork && !hs->sparse)
+        KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n)),
+                                                                    gemv_work_doubles(np, n))));
+    double* gwork = hs->dIpmWork;
+    int* d_info = w.i32 + 5;
+    auto products = [&]() -> int {                 // G x, G'z, A x, A'y
+        if (hs->sparse) {
+            if (int e = sparse_engine_products(hs->sp, S.x, S.z, S.Gx, S.GTz, S.ATy /* P x = 0: scratch */, st)) return e;
+            return 0;
+        }
+        if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, S.x, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
+        KKT_HIP_CHECK(hipMemsetAsync(S.GTz, 0, sizeof(double) * n, st));
+        if (int e = launch_gemv_t_scaled(hs->dG, hs->ldG, m, n, nullptr, S.z, hs->dzs, S.GTz, gwork, st)) return e;
+        if (np > 0) {
+            if (int e = launch_gemv_n_scaled(hs->dA, hs->ldA, np, n, nullptr, S.x, S.Ax, S.Ax, 1.0, 0.0, gwork, st)) return e;
+            KKT_HIP_CHECK(hipMemsetAsync(S.ATy, 0, sizeof(double) * n, st));
+            if (int e = launch_gemv_t_scaled(hs->dA, hs->ldA, np, n, nullptr, S.y, hs->dtp, S.ATy, gwork, st)) return e;
+        }
+        return 0;
+    };
+    auto factor = [&](int* info_out) -> int {
+        mi355kkt_scaling W = {};
+        W.di = S.di;
+        const int info = mi355kkt_factor_device(hs, &W);
+        if (info < 0) return info;
+        *info_out = info;
+        w.pinned[1] = info;
+        KKT_HIP_CHECK(hipMemcpyAsync(d_info, w.pinned + 1, sizeof(int), hipMemcpyHostToDevice, st));
+        if (info > 0) hs->factored = true;   // the loop drops the problem before any solve result is used
+        return 0;
+    };
+    auto solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_solve_device(hs, dx, dy, dz); };
+    auto dcopy = [&](double* dst, const double* src, size_t k) -> int {
+        if (k) KKT_HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(double) * k, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    KKT_HIP_CHECK(hipMemcpyAsync(S.c, c, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.h, hv, sizeof(double) * m, hipMemcpyHostToDevice, st));
+    if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bv, sizeof(double) * np, hipMemcpyHostToDevice, st));
+    KKT_HIP_CHECK(hipMemsetAsync(w.i32, 0, sizeof(int) * 8, st));
+    KKT_HIP_CHECK(hipMemsetAsync(S.sc, 0, sizeof(double) * LP_NSC, st));
+    // ---- starting points with W = I (coneprog.py:664-748)
+    hipLaunchKernelGGL(fill_kernel, dim3((m + 255) / 256), dim3(256), 0, st, S.di, 1.0, (int64_t)m);
+    int info = 0;
+    if (int e = factor(&info)) return e;
+    if (info > 0) { set_last_error("conelp_lp: Rank(A) < p or Rank([G; A]) < n"); return 1; }
+    KKT_HIP_CHECK(hipMemsetAsync(S.x, 0, sizeof(double) * n, st));
+    if (int e = dcopy(S.dy, S.b, np)) return e;
+    if (int e = dcopy(S.s, S.h, m)) return e;
+    if (int e = solve(S.x, S.dy, S.s)) return e;
+    lp_launch_init_primal(S, 1, st);
+    hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S.dx, S.c, -1.0, (int64_t)n);
+    if (np > 0) KKT_HIP_CHECK(hipMemsetAsync(S.y, 0, sizeof(double) * np, st));
+    KKT_HIP_CHECK(hipMemsetAsync(S.z, 0, sizeof(double) * m, st));
+    if (int e = solve(S.dx, S.y, S.z)) return e;
+    lp_launch_init_dual(S, 1, abstol, reltol, st);
+    int it = 0;
+    for (; it <= maxiters; ++it) {
+        if (int e = products()) return e;
+        KKT_HIP_CHECK(hipMemsetAsync(S.nactive, 0, sizeof(int), st));
+        lp_launch_residual(S, 1, it, maxiters, abstol, reltol, feastol, st);
+        KKT_HIP_CHECK(hipMemcpyAsync(w.pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
+        KKT_HIP_CHECK(hipStreamSynchronize(st));
+        if (w.pinned[0] == 0) break;
+        if (int e = factor(&info)) return e;
+        lp_launch_singular(S, 1, d_info, it, st);
+        if (info > 0) break;
+        if (int e = solve(S.x1, S.y1, S.z1)) return e;
+        lp_launch_scale1(S, 1, st);
+        for (int i01 = 0; i01 < 2; ++i01) {
+            lp_launch_rhs(S, 1, i01, st);
+            if (int e = solve(S.dx, S.dy, S.dz)) return e;
+            lp_launch_post(S, 1, i01, st);
+        }
+        lp_launch_update(S, 1, st);
+    }
+    KKT_HIP_CHECK(hipMemcpyAsync(x, S.x_out, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(y, S.y_out, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(s, S.s_out, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(z, S.z_out, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(status, S.status, sizeof(int), hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(iters, S.iters, sizeof(int), hipMemcpyDeviceToHost, st));
+    double hsc[LP_NSC];
+    KKT_HIP_CHECK(hipMemcpyAsync(hsc, S.sc, sizeof(double) * LP_NSC, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipStreamSynchronize(st));
+    if (stats) {   // gap, relative gap, pcost, dcost, pres, dres, pinfres, dinfres, ts, tz (1e300 = "None")
+        stats[0] = hsc[LP_GAP_OUT]; stats[1] = hsc[LP_RELGAP]; stats[2] = hsc[LP_PCOST]; stats[3] = hsc[LP_DCOST];
+        stats[4] = hsc[LP_PRES]; stats[5] = hsc[LP_DRES]; stats[6] = hsc[LP_PINFRES]; stats[7] = hsc[LP_DINFRES];
+        stats[8] = hsc[LP_TS]; stats[9] = hsc[LP_TZ];
+        if (*iters == 0 && *status == 1 && hsc[LP_GAP_OUT] == 0.0) stats[0] = hsc[LP_GAP];   // optimal starting point
+    }
+    return 0;
 }
 
 float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b) { return b ? b->t_factor : 0.0f; }

@@ -214,4 +214,31 @@ void ipm_launch_rhs(const IpmState& S, int B, int i01, hipStream_t st);
 void ipm_launch_post(const IpmState& S, int B, int i01, hipStream_t st);
 void ipm_launch_update(const IpmState& S, int B, hipStream_t st);
 
+// ---- device-resident conelp loop, LP cone (conelp_ipm.hip) --------------------------------------------
+enum LpScalar {
+    LP_TAU = 0, LP_KAPPA, LP_DG, LP_DGI, LP_LG, LP_RT, LP_GAP, LP_SIGMA, LP_STEP, LP_MU, LP_DTAU, LP_DKAPPA, LP_WKAPPA3,
+    LP_TT, LP_TK, LP_TS, LP_TZ, LP_RESX0, LP_RESY0, LP_RESZ0, LP_Z1Z1, LP_PCOST, LP_DCOST, LP_RELGAP, LP_PRES, LP_DRES,
+    LP_PINFRES, LP_DINFRES, LP_GAP_OUT, LP_NSC
+};
+struct LpState {
+    int n = 0, m = 0, p = 0;
+    double *c = nullptr, *x = nullptr, *dx = nullptr, *rx = nullptr, *x1 = nullptr, *GTz = nullptr, *ATy = nullptr,
+           *x_out = nullptr;                                                         // [B][n]
+    double *b = nullptr, *y = nullptr, *dy = nullptr, *ry = nullptr, *y1 = nullptr, *Ax = nullptr, *y_out = nullptr;   // [B][p]
+    double *h = nullptr, *s = nullptr, *z = nullptr, *ds = nullptr, *dz = nullptr, *rz = nullptr, *z1 = nullptr, *th = nullptr,
+           *lmbda = nullptr, *d = nullptr, *di = nullptr, *ws3 = nullptr, *Gx = nullptr, *s_out = nullptr,
+           *z_out = nullptr;                                                         // [B][m]
+    double* sc = nullptr;                                                            // [B][LP_NSC]
+    int *active = nullptr, *status = nullptr, *iters = nullptr, *init_optimal = nullptr, *nactive = nullptr;
+};
+void lp_launch_init_primal(const LpState& S, int B, hipStream_t st);
+void lp_launch_init_dual(const LpState& S, int B, double abstol, double reltol, hipStream_t st);
+void lp_launch_residual(const LpState& S, int B, int it, int maxiters, double abstol, double reltol, double feastol,
+                        hipStream_t st);
+void lp_launch_singular(const LpState& S, int B, const int* d_info, int it, hipStream_t st);
+void lp_launch_scale1(const LpState& S, int B, hipStream_t st);
+void lp_launch_rhs(const LpState& S, int B, int i01, hipStream_t st);
+void lp_launch_post(const LpState& S, int B, int i01, hipStream_t st);
+void lp_launch_update(const LpState& S, int B, hipStream_t st);
+
 }  // namespace mi355kkt

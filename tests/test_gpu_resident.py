@@ -122,3 +122,90 @@ def test_resident_coneqp_equalities_singular_P_uses_S_plus_AtA(ref_cvxopt):
     assert sol['status'] == ref['status'] == 'optimal' and sol['iterations'] == ref['iterations']
     assert abs(sol['primal objective'] - ref['primal objective']) <= 1e-8 * max(1.0, abs(ref['primal objective']))
     assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-6
+
+
+# ---- conelp (self-dual loop) resident on the device, LP cone ------------------------------------------------
+def _lp(n, m, p=0, seed=0):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((m, n))
+    x0 = rng.standard_normal(n)
+    h = G @ x0 + rng.uniform(0.1, 1.0, m)
+    z0 = rng.uniform(0.1, 1.0, m)
+    A = rng.standard_normal((p, n))
+    b = A @ x0
+    c = -G.T @ z0 - A.T @ rng.standard_normal(p)          # dual feasible => bounded
+    return c, G, h, A, b
+
+
+@pytest.mark.parametrize("n,m,p,kind", [(40, 100, 0, 'chol'), (150, 400, 0, 'chol2'), (80, 200, 20, 'chol'),
+                                        (60, 61, 30, 'ldl'), (300, 900, 0, 'qr')])
+def test_resident_conelp_matches_reference_driver(ref_cvxopt, n, m, p, kind):
+    from cvxopt import matrix, solvers
+    c, G, h, A, b = _lp(n, m, p, seed=n + m + p)
+    kw = dict(A=matrix(A), b=matrix(b)) if p else {}
+    ref = solvers.conelp(matrix(c), matrix(G), matrix(h), **kw)
+    sol = cvxopt_amd.conelp_lp(c, G, h, A=A if p else None, b=b if p else None, kktsolver=kind)
+    assert sol['status'] == ref['status'] == 'optimal'
+    assert sol['iterations'] == ref['iterations']
+    for k in ('primal objective', 'dual objective'):
+        assert abs(sol[k] - ref[k]) <= 1e-9 * max(1.0, abs(ref[k])), k
+    assert abs(sol['gap'] - ref['gap']) <= 1e-4 * ref['gap'] + 1e-14      # the final gap is itself O(1e-6): rounding shows
+    assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-7
+    assert relerr(sol['s'], np.array(ref['s']).ravel()) < 1e-6
+    assert relerr(sol['z'], np.array(ref['z']).ravel()) < 1e-6
+    if p:
+        assert relerr(sol['y'], np.array(ref['y']).ravel()) < 1e-6
+    for k in ('primal infeasibility', 'dual infeasibility'):
+        assert abs(sol[k] - ref[k]) <= 1e-4 * abs(ref[k]) + 1e-12, k
+    assert abs(sol['primal slack'] - ref['primal slack']) <= 1e-6 * abs(ref['primal slack']) + 1e-12
+
+
+def test_resident_conelp_reference_doc_example(ref_cvxopt):
+    """reference tests/test_examples.py:31-34 / doc/source/coneprog.rst LP: x = [1, 1]."""
+    from cvxopt import matrix, solvers
+    c = np.array([-4.0, -5.0])
+    G = np.array([[2.0, 1.0], [1.0, 2.0], [-1.0, 0.0], [0.0, -1.0]])
+    h = np.array([3.0, 3.0, 0.0, 0.0])
+    sol = cvxopt_amd.conelp_lp(c, G, h)
+    ref = solvers.lp(matrix(c), matrix(G), matrix(h))
+    assert sol['status'] == 'optimal' and sol['iterations'] == ref['iterations']
+    assert np.allclose(sol['x'], [1.0, 1.0], atol=1e-6)
+    assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-8
+
+
+def test_resident_conelp_infeasibility_certificates(ref_cvxopt):
+    from cvxopt import matrix, solvers
+    rng = np.random.default_rng(4)
+    n, m = 12, 30
+    # primal infeasible: x_0 <= -1 and -x_0 <= -1 among random rows
+    G = rng.standard_normal((m, n))
+    G[0, :] = 0.0; G[0, 0] = 1.0
+    G[1, :] = 0.0; G[1, 0] = -1.0
+    h = rng.uniform(0.5, 1.0, m); h[0] = -1.0; h[1] = -1.0
+    c = rng.standard_normal(n)
+    ref = solvers.conelp(matrix(c), matrix(G), matrix(h))
+    sol = cvxopt_amd.conelp_lp(c, G, h)
+    assert sol['status'] == ref['status'] == 'primal infeasible' and sol['iterations'] == ref['iterations']
+    assert sol['x'] is None and sol['s'] is None
+    assert relerr(sol['z'], np.array(ref['z']).ravel()) < 1e-6
+    assert abs(sol['residual as primal infeasibility certificate'] - ref['residual as primal infeasibility certificate']) \
+        <= 1e-6 * ref['residual as primal infeasibility certificate'] + 1e-14
+    # dual infeasible (unbounded): minimise -x_0 with only x_0 >= 0 and box constraints on the other variables
+    G2 = np.vstack([-np.eye(n), np.eye(n)[1:]])
+    h2 = np.concatenate([np.zeros(n), np.ones(n - 1)])
+    c2 = np.zeros(n); c2[0] = -1.0
+    ref = solvers.conelp(matrix(c2), matrix(G2), matrix(h2))
+    sol = cvxopt_amd.conelp_lp(c2, G2, h2)
+    assert sol['status'] == ref['status'] == 'dual infeasible' and sol['iterations'] == ref['iterations']
+    assert sol['z'] is None and relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-6
+
+
+def test_resident_conelp_limits_and_errors():
+    c, G, h, A, b = _lp(30, 70, 0, seed=1)
+    sol = cvxopt_amd.conelp_lp(c, G, h, maxiters=2)
+    assert sol['status'] == 'unknown' and sol['iterations'] == 2
+    with pytest.raises(ValueError):                        # p + m < n: Rank([G; A]) < n
+        cvxopt_amd.conelp_lp(np.ones(10), np.ones((4, 10)), np.ones(4))
+    with pytest.raises(ValueError):                        # rank deficient G at the start
+        Gd = np.ones((20, 10))
+        cvxopt_amd.conelp_lp(np.ones(10), Gd, np.ones(20))
