@@ -209,3 +209,23 @@ def test_resident_conelp_limits_and_errors():
     with pytest.raises(ValueError):                        # rank deficient G at the start
         Gd = np.ones((20, 10))
         cvxopt_amd.conelp_lp(np.ones(10), Gd, np.ones(20))
+
+
+def test_resident_conelp_large_lp_optimality_conditions():
+    """n = 4096, m = 12288 (no CPU reference at this size in the suite): size-independent properties of the returned
+    point -- primal / dual feasibility, complementarity, zero duality gap."""
+    n, m = 4096, 12288
+    c, G, h, A, b = _lp(n, m, 0, seed=3)
+    t = time.perf_counter()
+    sol = cvxopt_amd.conelp_lp(c, G, h)
+    t = time.perf_counter() - t
+    print("resident conelp n=%d m=%d: %.2f s wall incl. upload, %d iterations" % (n, m, t, sol['iterations']))
+    assert sol['status'] == 'optimal'
+    x, s, z = sol['x'], sol['s'], sol['z']
+    assert np.all(s > 0) and np.all(z > 0)
+    assert np.linalg.norm(G @ x + s - h) <= 1e-7 * max(1.0, np.linalg.norm(h))
+    assert np.linalg.norm(G.T @ z + c) <= 1e-7 * max(1.0, np.linalg.norm(c))
+    assert abs(s @ z - sol['gap']) <= 1e-6 * max(1e-6, sol['gap'])
+    assert abs(c @ x - sol['primal objective']) <= 1e-9 * max(1.0, abs(c @ x))
+    assert abs(-(h @ z) - sol['dual objective']) <= 1e-9 * max(1.0, abs(h @ z))
+    assert abs(sol['primal objective'] - sol['dual objective']) <= 1e-6 * max(1.0, abs(sol['primal objective']))
