@@ -198,6 +198,7 @@ struct mi355kkt_solver {
     IpmWork ipm;               // device-resident coneqp loop (mi355kkt_coneqp_lp), allocated on first use
     LpWork lp;                 // device-resident conelp loop (mi355kkt_conelp_lp)
     double* dHsym = nullptr;   // full symmetric copy of H for the residual product P x
+    bool hsym_valid = false;
     double* dIpmWork = nullptr;
 };
 
@@ -465,6 +466,7 @@ int mi355kkt_set_A_device(mi355kkt_solver* h, const double* dA, int64_t ldA) {
 int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) {
     if (!h) return MI355KKT_EINVAL;
     if (int e = bind(h)) return e;
+    h->hsym_valid = false;
     if (!H) {
         h->dH = nullptr;
         return 0;
@@ -482,6 +484,7 @@ int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH) {
     if (!h) return MI355KKT_EINVAL;
     h->dH = dH;
     h->ldH = ldH;
+    h->hsym_valid = false;
     return 0;
 }
 int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg) {
@@ -1021,6 +1024,72 @@ int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, i
     return run_ipm(b->ipm, b->st, ops, q, h, nullptr, maxiters, abstol, reltol, feastol, o);
 }
 
+// the mirrored copy of H (only tril(H) is meaningful on input, coneprog.py:1475-1477) for plain products H x
+static int ensure_hsym(mi355kkt_solver* hs) {
+    if (!hs->dH || hs->sparse || hs->hsym_valid) return 0;
+    const int n = hs->n;
+    if (!hs->dHsym) KKT_HIP_CHECK(hipMalloc(&hs->dHsym, sizeof(double) * dmax((size_t)n * n, 1)));
+    if (n > 0) {
+        KKT_HIP_CHECK(hipMemcpy2DAsync(hs->dHsym, sizeof(double) * n, hs->dH, sizeof(double) * hs->ldH, sizeof(double) * n, n,
+                                       hipMemcpyDeviceToDevice, hs->st));
+        hipLaunchKernelGGL(symmetrize_kernel, dim3((n + 15) / 16, (n + 15) / 16, 1), dim3(16, 16), 0, hs->st, hs->dHsym, n, (int64_t)0);
+    }
+    hs->hsym_valid = true;
+    return 0;
+}
+static int ensure_gemv_work(mi355kkt_solver* hs) {
+    if (hs->dIpmWork || hs->sparse) return 0;
+    const int n = hs->n, m = hs->cdim, np = hs->p;
+    KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n)),
+                                                                gemv_work_doubles(np, n))));
+    return 0;
+}
+
+/* out = op(M) x on the device, host vectors in and out: which = 0: G (cdim x n), 1: A (p x n), 2: H (n x n, symmetric,
+ * tril(H) as set); trans != 0: op = transpose.  The operator form of the reference's fG / fA / fP closures
+ * (coneprog.py:531-550, :1843-1844, :1896-1916) for callers that hand conelp / coneqp callables instead of matrices. */
+int mi355kkt_product(mi355kkt_solver* hs, int which, int trans, const double* x, double* out) {
+    if (!hs || !x || !out || which < 0 || which > 2) { set_last_error("product: invalid argument"); return MI355KKT_EINVAL; }
+    if (int e = bind(hs)) return e;
+    const int n = hs->n, m = hs->cdim, np = hs->p;
+    hipStream_t st = hs->st;
+    const int rows = which == 0 ? m : (which == 1 ? np : n);
+    const int nin = (which == 2) ? n : (trans ? rows : n), nout = (which == 2) ? n : (trans ? n : rows);
+    if (nout == 0) return 0;
+    double* din = (nin == n) ? hs->dx : (which == 0 ? hs->dz : hs->dy);
+    double* dout = (nout == n) ? hs->dtn : (which == 0 ? hs->dzs : hs->dtp);
+    if (which == 2 && !hs->sparse && !hs->dH) { memset(out, 0, sizeof(double) * n); return 0; }
+    if (nin > 0) {
+        memcpy(hs->hbuf, x, sizeof(double) * nin);
+        KKT_HIP_CHECK(hipMemcpyAsync(din, hs->hbuf, sizeof(double) * nin, hipMemcpyHostToDevice, st));
+    }
+    if (hs->sparse) {
+        if (which == 1) { set_last_error("product: A is not held by the sparse engine"); return MI355KKT_ENOTIMPL; }
+        if (int e = sparse_engine_product(hs->sp, which, trans, din, dout, st)) return e;
+    } else {
+        if ((which == 0 && !hs->dG) || (which == 1 && np > 0 && !hs->dA)) { set_last_error("product: matrix not set"); return MI355KKT_EINVAL; }
+        if (int e = ensure_gemv_work(hs)) return e;
+        const double* M = which == 0 ? hs->dG : (which == 1 ? hs->dA : nullptr);
+        const int64_t ld = which == 0 ? hs->ldG : hs->ldA;
+        if (which == 2) {
+            if (int e = ensure_hsym(hs)) return e;
+            if (int e = launch_gemv_n_scaled(hs->dHsym, n, n, n, nullptr, din, dout, dout, 1.0, 0.0, hs->dIpmWork, st)) return e;
+        } else if (nin == 0) {
+            KKT_HIP_CHECK(hipMemsetAsync(dout, 0, sizeof(double) * nout, st));
+        } else if (!trans) {
+            if (int e = launch_gemv_n_scaled(M, ld, rows, n, nullptr, din, dout, dout, 1.0, 0.0, hs->dIpmWork, st)) return e;
+        } else {
+            KKT_HIP_CHECK(hipMemsetAsync(dout, 0, sizeof(double) * n, st));
+            double* scratch = which == 0 ? hs->dzs : hs->dtp;
+            if (int e = launch_gemv_t_scaled(M, ld, rows, n, nullptr, din, scratch, dout, hs->dIpmWork, st)) return e;
+        }
+    }
+    KKT_HIP_CHECK(hipMemcpyAsync(hs->hbuf, dout, sizeof(double) * nout, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipStreamSynchronize(st));
+    memcpy(out, hs->hbuf, sizeof(double) * nout);
+    return 0;
+}
+
 /* Single problem, LP cone, no equality constraints: the coneqp loop of coneprog.py:2044-2547 resident on the device around
  * this handle's own factor/solve (dense or sparse mode).  G (and H, if any) must have been set.  See include/mi355kkt.h. */
 int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, const double* bv, int maxiters,
@@ -1042,12 +1111,7 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
     if (int e = ipm_alloc(hs->ipm, 1, n, m, np)) return e;
     const IpmState& S = hs->ipm.S;
     hipStream_t st = hs->st;
-    if (hs->dH && !hs->sparse) {     // only tril(H) is meaningful (coneprog.py:1475-1477): P x needs the mirrored matrix
-        if (!hs->dHsym) KKT_HIP_CHECK(hipMalloc(&hs->dHsym, sizeof(double) * (size_t)n * n));
-        KKT_HIP_CHECK(hipMemcpy2DAsync(hs->dHsym, sizeof(double) * n, hs->dH, sizeof(double) * hs->ldH, sizeof(double) * n, n,
-                                       hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(symmetrize_kernel, dim3((n + 15) / 16, (n + 15) / 16, 1), dim3(16, 16), 0, st, hs->dHsym, n, (int64_t)0);
-    }
+    if (int e = ensure_hsym(hs)) return e;
     double* scratch = hs->dzs;       // >= cdim doubles; free between solves
     if (!hs->dIpmWork && !hs->sparse)
         KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n)),

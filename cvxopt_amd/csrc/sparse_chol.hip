@@ -1129,6 +1129,23 @@ int sparse_engine_gemv_n(SparseEngine& E, const double* d_w, const double* d_x, 
     return 0;
 }
 
+// one product with the CSC / CSR copies: which = 0: G (trans: G'), 2: H (symmetric)
+int sparse_engine_product(SparseEngine& E, int which, int trans, const double* d_in, double* d_out, hipStream_t st) {
+    const dim3 gn((E.n + 255) / 256), gm((E.m + 255) / 256);
+    if (which == 0 && !trans) {
+        if (E.m > 0) hipLaunchKernelGGL(sp_spmv_kernel, gm, dim3(256), 0, st, E.m, E.d_grp, E.d_gci, E.d_gnzmap, E.d_gv, d_in, d_out);
+    } else if (which == 0) {
+        KKT_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(double) * E.n, st));
+        if (E.m > 0) hipLaunchKernelGGL(sp_gemv_t_kernel, gn, dim3(256), 0, st, E.n, E.d_gcp, E.d_gri, E.d_gv, d_in, d_out);
+    } else if (E.d_hrp) {
+        hipLaunchKernelGGL(sp_spmv_kernel, gn, dim3(256), 0, st, E.n, E.d_hrp, E.d_hci, E.d_hmap, E.d_hv, d_in, d_out);
+    } else {
+        KKT_HIP_CHECK(hipMemsetAsync(d_out, 0, sizeof(double) * E.n, st));
+    }
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // residual products of the interior-point loop (coneprog.py:2170-2186): Gx = G x, GTz = G' z, Px = H x
 int sparse_engine_products(SparseEngine& E, const double* d_x, const double* d_z, double* d_Gx, double* d_GTz, double* d_Px,
                            hipStream_t st) {

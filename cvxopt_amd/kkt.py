@@ -278,6 +278,16 @@ class _Engine(object):
     def sync(self):
         _capi.check(self.L.mi355kkt_sync(self.h), "mi355kkt_sync")
 
+    def product(self, which, trans, x):
+        """op(M) x on the device: which = 0: G, 1: A, 2: H (symmetric from tril).  x, result: 1-D float64 arrays."""
+        if self._mode == "undecided":
+            raise ValueError("cvxopt_amd: G is not on the device yet (call factor / _set_H first)")
+        nout = self.n if (which == 2 or trans) else (self.cdim if which == 0 else self.p)
+        out = np.zeros(nout)
+        xv = np.ascontiguousarray(x, dtype=np.float64)
+        _capi.check(self.L.mi355kkt_product(self.h, int(which), 1 if trans else 0, _ptr(xv), _ptr(out)), "mi355kkt_product")
+        return out
+
     def coneqp(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, keep_H=False):
         """The reference coneqp loop (coneprog.py:2044-2547; LP cone, no equalities) resident on the device around
         this handle (`mi355kkt_coneqp_lp`).  Returns a dict with the reference's keys, vectors as NumPy arrays."""

@@ -1,0 +1,142 @@
+"""`conelp` / `coneqp` with every heavy product on the MI355X, for all cone types, through the reference's own
+operator + kktsolver plug-in API.
+
+The reference drivers accept G, A (and P) as Python callables instead of matrices (`conelp`: coneprog.py:521-550,
+`coneqp`: :1838-1917) as long as `kktsolver` is a callable too.  Here both are device backed:
+
+    * `kktsolver`     = the GPU KKT engine of `cvxopt_amd.kkt` (factor + solves in HBM),
+    * `G`, `A`, `P`   = closures around `mi355kkt_product`: y := alpha op(M) x + beta y with M resident in HBM
+                        (for 's' cones with the trisc/triusc convention of misc.sgemv, misc.py:801-832),
+
+so the host loop only does the O(n + cdim) cone-vector bookkeeping of the unmodified reference, and the iterates are
+the reference's.  (For LP-cone problems `cvxopt_amd.coneqp_lp` / `conelp_lp` move that bookkeeping to the device too.)
+
+    import cvxopt_amd.solvers as gsolvers
+    sol = gsolvers.conelp(c, G, h, dims)            # same signature and result dict as cvxopt.solvers.conelp
+    sol = gsolvers.coneqp(P, q, G, h, dims, A, b)
+    sol = gsolvers.socp(c, Gl, hl, Gq, hq)          # via the reference's own argument packing
+"""
+import numpy as np
+
+from . import kkt as _kkt
+
+
+def _dims_of(h, dims):
+    if dims is None:
+        return {'l': h.size[0], 'q': [], 's': []}
+    return {'l': int(dims['l']), 'q': [int(k) for k in dims['q']], 's': [int(k) for k in dims['s']]}
+
+
+def _trisc(x, dims):
+    """copy of x with the strictly lower triangles of the 's' blocks doubled and the upper triangles zeroed
+    (misc_solvers.c:887-938, what misc.sgemv applies before a product with G')."""
+    if not dims['s']:
+        return x
+    x = x.copy()
+    ind = dims['l'] + sum(dims['q'])
+    for m in dims['s']:
+        X = x[ind:ind + m * m].reshape(m, m, order='F')
+        x[ind:ind + m * m] = (2.0 * np.tril(X, -1) + np.diag(np.diag(X))).reshape(-1, order='F')
+        ind += m * m
+    return x
+
+
+def _operators(eng, dims):
+    def view(v):
+        a = np.asarray(v)
+        return a.reshape(-1, order='F')
+
+    def combine(y, t, alpha, beta):
+        yv = view(y)
+        if beta == 0.0:
+            yv[:] = alpha * t
+        else:
+            yv[:] = alpha * t + beta * yv
+
+    def Gop(x, y, alpha=1.0, beta=0.0, trans='N'):
+        xv = view(x)
+        if trans == 'T':
+            xv = _trisc(xv, dims)
+        combine(y, eng.product(0, trans == 'T', xv), alpha, beta)
+
+    def Aop(x, y, alpha=1.0, beta=0.0, trans='N'):
+        combine(y, eng.product(1, trans == 'T', view(x)), alpha, beta)
+
+    def Pop(x, y, alpha=1.0, beta=0.0):
+        combine(y, eng.product(2, False, view(x)), alpha, beta)
+    return Gop, Aop, Pop
+
+
+def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None, kktsolver='chol', **kwargs):
+    """cvxopt.solvers.conelp with G, A as device operators and the GPU kktsolver ('chol' | 'chol2' | 'ldl' | 'ldl2')."""
+    from cvxopt import solvers, spmatrix
+    dims = _dims_of(h, dims)
+    n = c.size[0]
+    Am = A if A is not None else spmatrix([], [], [], (0, n))
+    ks = _kkt.kktsolver_lp(G, dims, Am, kind={'qr': 'chol'}.get(kktsolver, kktsolver))
+    eng = ks.engine
+    try:
+        eng._set_H(None)                       # decides dense / sparse mode and places G in HBM
+        Gop, Aop, _ = _operators(eng, dims)
+        kw = {}
+        if A is not None:
+            kw = {'A': Aop, 'b': b}
+        return solvers.conelp(c, Gop, h, dims, primalstart=primalstart, dualstart=dualstart, kktsolver=ks, **kw, **kwargs)
+    finally:
+        eng.close()
+
+
+def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktsolver='chol2', **kwargs):
+    """cvxopt.solvers.coneqp with P, G, A as device operators and the GPU kktsolver."""
+    from cvxopt import solvers, spmatrix, matrix
+    n = q.size[0]
+    if G is None:
+        G, h = spmatrix([], [], [], (0, n)), matrix(0.0, (0, 1))
+    dims = _dims_of(h, dims)
+    if (dims['q'] or dims['s']) and kktsolver == 'chol2':
+        kktsolver = 'chol'                      # like the reference's default for non-LP cones (coneprog.py:1775-1781)
+    Am = A if A is not None else spmatrix([], [], [], (0, n))
+    ks = _kkt.kktsolver_qp(G, dims, Am, P, kind=kktsolver)
+    eng = ks.engine
+    try:
+        eng._set_H(P)
+        Gop, Aop, Pop = _operators(eng, dims)
+        kw = {}
+        if A is not None:
+            kw = {'A': Aop, 'b': b}
+        return solvers.coneqp(Pop, q, Gop, h, dims, initvals=initvals, kktsolver=ks, **kw, **kwargs)
+    finally:
+        eng.close()
+
+
+def socp(c, Gl=None, hl=None, Gq=None, hq=None, A=None, b=None, **kwargs):
+    """cvxopt.solvers.socp's argument convention (coneprog.py:2862-3100: stacks Gl, Gq[k] and calls conelp)."""
+    from cvxopt import matrix, sparse, spmatrix
+    n = c.size[0]
+    blocks, hs = [], []
+    ml = 0
+    if Gl is not None:
+        blocks.append(Gl)
+        hs.append(hl)
+        ml = Gl.size[0]
+    q = []
+    for Gk, hk in zip(Gq or [], hq or []):
+        blocks.append(Gk)
+        hs.append(hk)
+        q.append(Gk.size[0])
+    G = sparse(blocks) if all(isinstance(B, spmatrix) for B in blocks) \
+        else matrix([matrix(B) for B in blocks])
+    h = matrix([matrix(v) for v in hs])
+    sol = conelp(c, G, h, {'l': ml, 'q': q, 's': []}, A, b, **kwargs)
+    for key in ('s', 'z'):                      # the reference returns the blocks separately ('sl', 'sq', 'zl', 'zq')
+        v = sol.pop(key)
+        if v is None:
+            sol[key + 'l'], sol[key + 'q'] = None, None
+            continue
+        sol[key + 'l'] = v[:ml]
+        parts, ind = [], ml
+        for mk in q:
+            parts.append(v[ind:ind + mk])
+            ind += mk
+        sol[key + 'q'] = parts
+    return sol

@@ -126,6 +126,13 @@ int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n);
 /* copies the factored S (lower Cholesky factor L in tril) to a host n x n buffer -- tests only */
 int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL);
 
+/* ---- operator form of the matrices held by a handle ---------------------------------------------------------
+ * out = op(M) x with host vectors: which = 0: G (cdim x n; 's' rows unpacked), 1: A (p x n), 2: H (n x n, symmetric from
+ * tril(H)); trans != 0: the transpose.  These are the products behind the reference's Gf / Af / fP closures
+ * (coneprog.py:531-550, :1843-1844, :1896-1916): handing conelp / coneqp callables built on them keeps G, A, P in HBM
+ * and off the host's GEMV path for every cone type (cvxopt_amd.solvers). */
+int mi355kkt_product(mi355kkt_solver* h, int which, int trans, const double* x, double* out);
+
 /* ---- device-resident interior-point loop -----------------------------------------
  * The coneqp loop of coneprog.py:2044-2547 for dims = {'l': ml} (equality constraints A x = b allowed with the dense
  * engine: bv, y of length p; NULL when p = 0), run around this handle's factor/solve with the

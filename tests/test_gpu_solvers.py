@@ -1,0 +1,128 @@
+"""cvxopt_amd.solvers: the unmodified reference drivers fed with device operators (G, A, P as callables around
+mi355kkt_product) and the GPU kktsolver -- same iterates as the reference on its own data path, for every cone type."""
+import time
+
+import numpy as np
+import pytest
+
+from cvxopt_amd import synth
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(sol, ref, xt=1e-7):
+    assert sol['status'] == ref['status']
+    assert sol['iterations'] == ref['iterations']
+    for k in ('primal objective', 'dual objective'):
+        assert abs(sol[k] - ref[k]) <= 1e-9 * max(1.0, abs(ref[k])), k
+    assert relerr(np.array(sol['x']).ravel(), np.array(ref['x']).ravel()) < xt
+
+
+def test_products_match_numpy():
+    from cvxopt_amd import kkt
+    rng = np.random.default_rng(0)
+    n, m, p = 50, 120, 7
+    G, A = np.asfortranarray(rng.standard_normal((m, n))), np.asfortranarray(rng.standard_normal((p, n)))
+    P = rng.standard_normal((n, n)); P = P @ P.T
+    f = kkt.kkt_chol2(G, {'l': m, 'q': [], 's': []}, A)
+    e = f.engine
+    e._set_H(np.asfortranarray(np.tril(P) + np.triu(np.full((n, n), 3.0), 1)))      # garbage above the diagonal
+    x, z, y = rng.standard_normal(n), rng.standard_normal(m), rng.standard_normal(p)
+    assert relerr(e.product(0, False, x), G @ x) < 1e-13 and relerr(e.product(0, True, z), G.T @ z) < 1e-13
+    assert relerr(e.product(1, False, x), A @ x) < 1e-13 and relerr(e.product(1, True, y), A.T @ y) < 1e-13
+    assert relerr(e.product(2, False, x), P @ x) < 1e-13
+    e.close()
+
+
+def test_socp_config3_class_matches_reference(ref_cvxopt):
+    """BASELINE configs[2] class scaled down: many small second-order cones through solvers.socp's path (conelp)."""
+    from cvxopt import matrix, solvers
+    import cvxopt_amd.solvers as gs
+    pr = synth.socp(n=96, ncones=48, r=8, seed=3, ml=10)
+    c, G, h, dims = matrix(pr['c']), matrix(pr['G']), matrix(pr['h']), pr['dims']
+    ref = solvers.conelp(c, G, h, dims)
+    sol = gs.conelp(c, G, h, dims)
+    _same(sol, ref)
+    assert relerr(np.array(sol['z']).ravel(), np.array(ref['z']).ravel()) < 1e-6
+
+
+def test_socp_wrapper_returns_reference_layout(ref_cvxopt):
+    from cvxopt import matrix, solvers
+    import cvxopt_amd.solvers as gs
+    pr = synth.socp(n=30, ncones=5, r=6, seed=1, ml=4)
+    G, h = pr['G'], pr['h']
+    Gl, hl = matrix(G[:4]), matrix(h[:4])
+    Gq = [matrix(G[4 + 6 * k:4 + 6 * (k + 1)]) for k in range(5)]
+    hq = [matrix(h[4 + 6 * k:4 + 6 * (k + 1)]) for k in range(5)]
+    ref = solvers.socp(matrix(pr['c']), Gl, hl, Gq, hq)
+    sol = gs.socp(matrix(pr['c']), Gl, hl, Gq, hq)
+    _same(sol, ref)
+    assert len(sol['sq']) == 5 and relerr(np.array(sol['sq'][2]).ravel(), np.array(ref['sq'][2]).ravel()) < 1e-6
+    assert relerr(np.array(sol['zl']).ravel(), np.array(ref['zl']).ravel()) < 1e-6
+
+
+def test_sdp_and_mixed_cones_through_operators(ref_cvxopt):
+    """'s' cones: the operator applies misc.sgemv's trisc convention before G'."""
+    from cvxopt import matrix, solvers
+    import cvxopt_amd.solvers as gs
+    # reference doc example (doc/source/coneprog.rst, conelp with l, q and s blocks)
+    c = matrix([-6., -4., -5.])
+    G = matrix([[16., 7., 24., -8., 8., -1., 0., -1., 0., 0., 7., -5., 1., -5., 1., -7., 1., -7., -4.],
+                [-14., 2., 7., -13., -18., 3., 0., 0., -1., 0., 3., 13., -6., 13., 12., -10., -6., -10., -28.],
+                [5., 0., -15., 12., -6., 17., 0., 0., 0., -1., 9., 6., -6., 6., -7., -7., -6., -7., -11.]])
+    h = matrix([-3., 5., 12., -2., -14., -13., 10., 0., 0., 0., 68., -30., -19., -30., 99., 23., -19., 23., 10.])
+    dims = {'l': 2, 'q': [4, 4], 's': [3]}
+    ref = solvers.conelp(c, G, h, dims)
+    sol = gs.conelp(c, G, h, dims)
+    _same(sol, ref, xt=1e-6)
+    assert np.allclose(np.array(sol['x']).ravel(), [-1.22, 9.66e-02, 3.58], rtol=5e-3)     # doc transcript (coneprog.rst:332-335)
+
+
+def test_coneqp_with_soc_and_equalities_through_operators(ref_cvxopt):
+    from cvxopt import matrix, solvers
+    import cvxopt_amd.solvers as gs
+    rng = np.random.default_rng(5)
+    n, p = 40, 6
+    pr = synth.socp(n=n, ncones=6, r=5, seed=2, ml=12)
+    B = rng.standard_normal((n, n)) / np.sqrt(n)
+    P = matrix(B.T @ B + 1e-2 * np.eye(n))
+    A = matrix(rng.standard_normal((p, n)))
+    b = matrix(np.array(A) @ pr['x0']) if 'x0' in pr else matrix(np.zeros(p))
+    q, G, h, dims = matrix(pr['c']), matrix(pr['G']), matrix(pr['h']), pr['dims']
+    ref = solvers.coneqp(P, q, G, h, dims, A, b)
+    sol = gs.coneqp(P, q, G, h, dims, A, b)
+    _same(sol, ref, xt=1e-6)
+
+
+def test_sparse_lp_through_operators(ref_cvxopt):
+    from cvxopt import matrix, spmatrix, solvers
+    import cvxopt_amd.solvers as gs
+    import scipy.sparse as sp
+    rng = np.random.default_rng(9)
+    n = 120
+    Gs = sp.vstack([sp.eye(n), -sp.eye(n), sp.random(60, n, density=0.05, random_state=3)]).tocoo()
+    G = spmatrix(list(Gs.data), list(map(int, Gs.row)), list(map(int, Gs.col)), Gs.shape)
+    h = matrix(np.concatenate([np.ones(2 * n), 5.0 + rng.random(60)]))
+    c = matrix(rng.standard_normal(n))
+    ref = solvers.conelp(c, G, h)
+    sol = gs.conelp(c, G, h)
+    _same(sol, ref)
+
+
+def test_socp_config3_full_size_timing(ref_cvxopt):
+    """BASELINE configs[2]: n=2048, 1024 cones of dimension 8 -- operators + GPU kktsolver vs the host products with the
+    GPU kktsolver hook (both through the unmodified reference driver): same iterates, timing printed."""
+    from cvxopt import matrix, solvers, spmatrix
+    import cvxopt_amd.solvers as gs
+    from cvxopt_amd import kkt
+    pr = synth.socp(n=2048, ncones=1024, r=8, seed=0)
+    c, G, h, dims = matrix(pr['c']), matrix(pr['G']), matrix(pr['h']), pr['dims']
+    t = time.perf_counter(); sol = gs.conelp(c, G, h, dims); t_ops = time.perf_counter() - t
+    ks = kkt.kktsolver_lp(G, dims, spmatrix([], [], [], (0, 2048)))
+    t = time.perf_counter(); hook = solvers.conelp(c, G, h, dims, kktsolver=ks); t_hook = time.perf_counter() - t
+    ks.engine.close()
+    print("config 3 (n=2048, cdim=8192): operators+kktsolver %.2f s, kktsolver hook only %.2f s, %d iterations"
+          % (t_ops, t_hook, sol['iterations']))
+    _same(sol, hook)
+    assert sol['status'] == 'optimal'
