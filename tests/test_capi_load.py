@@ -87,4 +87,6 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".sh")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), f
-                assert "import cvxopt\n" not in txt and "from cvxopt " not in txt or f == "kkt.py", f
+                # cvxopt (the reference, installed by the user) is only ever the CALLER: kkt.install() rebinds its factories,
+                # solvers.py hands its own drivers device operators; nothing else may import it
+                assert "import cvxopt\n" not in txt and "from cvxopt " not in txt or f in ("kkt.py", "solvers.py"), f
