@@ -378,18 +378,23 @@ __device__ __forceinline__ void publish_flag(u32* flag, u32 epoch) {
 }
 
 template <bool TRANS>
-__global__ __launch_bounds__(128) void trsv_persistent_kernel(const double* __restrict__ L, int64_t ldl, int n,
+__global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __restrict__ L, int64_t ldl, int n,
                                                               double* x, u32* flags, u32 epoch, int* err) {
+    // 256 threads: two per row (forward) / column (backward) of the block row; each holds one 64-wide half of the strip
+    // of every off-diagonal block in registers BEFORE waiting for that block's x, so that nothing but 64 FMAs, one
+    // partial-sum exchange and the diagonal solve sits between "x_j published" and "x_k published".
     __shared__ double xs[TB];
+    __shared__ double ps[TB];
     __shared__ int ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = tid >> 7, r = tid & (TB - 1);
     const int nblk = (n + TB - 1) / TB;
     const int k = TRANS ? (nblk - 1 - (int)blockIdx.x) : (int)blockIdx.x;   // dispatch order ~ dependency order
     const int k0 = k * TB;
     const int nb = min(TB, n - k0);
-    const int idx = k0 + tid;                         // my row (forward) / my column (backward)
-    const bool mine = tid < nb;
-    double acc = mine ? x[idx] : 0.0;
+    const int idx = k0 + r;                           // my row (forward) / my column (backward)
+    const bool mine = r < nb;
+    double acc = (mine && half == 0) ? x[idx] : 0.0;
     // ---- diagonal block operands: issue their loads now (independent of everything), use them at the end
     const double* Lkk = L + k0 + (int64_t)k0 * ldl;
     const int n0 = min(nb, 64), n1 = nb - n0;
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(128) void trsv_persistent_kernel(const double* __re
         if (wave == 0) {   // rows 0..63: row of L11
 #pragma unroll
             for (int j = 0; j < 64; ++j) ra[j] = (j < lane && lane < n0) ? Lkk[lane + (int64_t)j * ldl] : 0.0;
-        } else {           // rows 64..127: row of L21 (ra) and of L22 (rb)
+        } else if (wave == 1) {   // rows 64..127: row of L21 (ra) and of L22 (rb)
 #pragma unroll
             for (int j = 0; j < 64; ++j) ra[j] = (lane < n1) ? Lkk[64 + lane + (int64_t)j * ldl] : 0.0;
 #pragma unroll
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(128) void trsv_persistent_kernel(const double* __re
         if (wave == 1) {   // columns 64..127: column of L22 (solved first)
 #pragma unroll
             for (int j = 0; j < 64; ++j) ra[j] = (j > lane && j < n1) ? Lkk[64 + j + (int64_t)(64 + lane) * ldl] : 0.0;
-        } else {           // columns 0..63: column of L21 (ra) and of L11 (rb)
+        } else if (wave == 0) {   // columns 0..63: column of L21 (ra) and of L11 (rb)
 #pragma unroll
             for (int j = 0; j < 64; ++j) ra[j] = (j < n1 && lane < n0) ? Lkk[64 + j + (int64_t)lane * ldl] : 0.0;
 #pragma unroll
@@ -423,42 +428,32 @@ __global__ __launch_bounds__(128) void trsv_persistent_kernel(const double* __re
         const int j = TRANS ? (nblk - 1 - s) : s;      // block whose solution we consume
         const int j0 = j * TB;
         const int jb = min(TB, n - j0);
-        // prefetch the first half of my strip of block (k,j) before waiting
+        // prefetch my half of my strip of block (k,j) before waiting
         double l0[64];
+        const int ch = 64 * half;
         if (!TRANS) {
 #pragma unroll
-            for (int c = 0; c < 64; ++c) l0[c] = (mine && c < jb) ? L[idx + (int64_t)(j0 + c) * ldl] : 0.0;
+            for (int c = 0; c < 64; ++c) l0[c] = (mine && ch + c < jb) ? L[idx + (int64_t)(j0 + ch + c) * ldl] : 0.0;
         } else {
 #pragma unroll
-            for (int c = 0; c < 64; ++c) l0[c] = (mine && c < jb) ? L[j0 + c + (int64_t)idx * ldl] : 0.0;
+            for (int c = 0; c < 64; ++c) l0[c] = (mine && ch + c < jb) ? L[j0 + ch + c + (int64_t)idx * ldl] : 0.0;
         }
         if (tid == 0) ok = wait_flag(flags + j, epoch, err) ? 1 : 0;
         __syncthreads();
         if (!ok) return;                                // timeout: give up (err is set)
         if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         __syncthreads();
-        xs[tid] = (tid < jb) ? x[j0 + tid] : 0.0;
+        if (tid < TB) xs[tid] = (tid < jb) ? x[j0 + tid] : 0.0;
         __syncthreads();
 #pragma unroll
-        for (int c = 0; c < 64; ++c) acc = fma(-l0[c], xs[c], acc);
-        if (jb > 64) {
-            if (!TRANS) {
-#pragma unroll 16
-                for (int c = 64; c < TB; ++c) {
-                    const double l = (mine && c < jb) ? L[idx + (int64_t)(j0 + c) * ldl] : 0.0;
-                    acc = fma(-l, xs[c], acc);
-                }
-            } else {
-#pragma unroll 16
-                for (int c = 64; c < TB; ++c) {
-                    const double l = (mine && c < jb) ? L[j0 + c + (int64_t)idx * ldl] : 0.0;
-                    acc = fma(-l, xs[c], acc);
-                }
-            }
-        }
+        for (int c = 0; c < 64; ++c) acc = fma(-l0[c], xs[ch + c], acc);
         __syncthreads();                               // xs is reused by the next step
     }
-    // ---- diagonal block: two 64-wide halves, the first half's solution goes through LDS to the second
+    // ---- combine the two partial sums of every row / column
+    if (half == 1) ps[r] = acc;
+    __syncthreads();
+    if (half == 0) acc += ps[r];
+    // ---- diagonal block (threads 0..127): two 64-wide halves, the first half's solution goes through LDS to the second
     const double dinv = 1.0 / dg;
     if (!TRANS) {
         if (wave == 0) {
@@ -503,7 +498,7 @@ __global__ __launch_bounds__(128) void trsv_persistent_kernel(const double* __re
             }
         }
     }
-    if (mine) x[idx] = acc;
+    if (mine && half == 0) x[idx] = acc;
     __syncthreads();
     if (tid == 0) publish_flag(flags + k, epoch);
 }
@@ -513,9 +508,9 @@ int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int t
     const int nblk = (n + TB - 1) / TB;
     if (nblk <= 0) return 0;
     if (trans)
-        hipLaunchKernelGGL(trsv_persistent_kernel<true>, dim3(nblk), dim3(128), 0, st, L, ldl, n, x, flags, epoch, err);
+        hipLaunchKernelGGL(trsv_persistent_kernel<true>, dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err);
     else
-        hipLaunchKernelGGL(trsv_persistent_kernel<false>, dim3(nblk), dim3(128), 0, st, L, ldl, n, x, flags, epoch, err);
+        hipLaunchKernelGGL(trsv_persistent_kernel<false>, dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

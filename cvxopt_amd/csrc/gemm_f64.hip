@@ -258,12 +258,22 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkItem* __rest
                                                           const double* __restrict__ P, int64_t ldp) {
     const SyrkItem it = tiles[blockIdx.x];
     const int i0 = it.ti * TILE, j0 = it.tj * TILE;
-    for (int e = threadIdx.x; e < TILE * TILE; e += 256) {
+    // grid.y = 16 slices of 8 tile columns: enough workgroups to stream the slabs at HBM speed
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = blockIdx.y * 1024 + r * 256 + threadIdx.x;
         const int il = e & (TILE - 1), jl = e >> 7;
         const int i = i0 + il, j = j0 + jl;
         if (i < n && j < n && i >= j) {
             double v = P ? P[i + (int64_t)j * ldp] : 0.0;
-            for (int s = 0; s < it.nparts; ++s) v += slabs[(int64_t)(it.first + s) * TILE * TILE + e];
+            const double* __restrict__ sl = slabs + (int64_t)it.first * TILE * TILE + e;
+            int s2 = 0;
+            for (; s2 + 4 <= it.nparts; s2 += 4) {            // fixed summation order, four loads in flight
+                const double a0 = sl[(int64_t)s2 * TILE * TILE], a1 = sl[(int64_t)(s2 + 1) * TILE * TILE];
+                const double a2 = sl[(int64_t)(s2 + 2) * TILE * TILE], a3 = sl[(int64_t)(s2 + 3) * TILE * TILE];
+                v += a0; v += a1; v += a2; v += a3;
+            }
+            for (; s2 < it.nparts; ++s2) v += sl[(int64_t)s2 * TILE * TILE];
             C[i + (int64_t)j * ldc] = v;
         }
     }
@@ -373,7 +383,7 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
     KKT_HIP_CHECK(hipGetLastError());
     if (kernel_events) KKT_HIP_CHECK(hipEventRecord(kernel_events[1], st));
     if (plan.nsplit_tiles) {
-        hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.nsplit_tiles), dim3(256), 0, st, plan.d_split_tiles,
+        hipLaunchKernelGGL(syrk_reduce_kernel, dim3(plan.nsplit_tiles, 16), dim3(256), 0, st, plan.d_split_tiles,
                            plan.n, plan.d_slabs, C, ldc, P, ldp);
         KKT_HIP_CHECK(hipGetLastError());
     }
