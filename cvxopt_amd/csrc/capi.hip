@@ -124,7 +124,7 @@ static int* ipm_info_words(IpmWork& w) { return w.i32 + 4 * (size_t)w.B + 1; }
 struct LpWork {
     LpState S;
     double* f64 = nullptr;
-    int* i32 = nullptr;       // active | status | iters | init_optimal | nactive | info
+    int* i32 = nullptr;       // active | status | iters | init_optimal | nactive | info | qoff[nq] | qdim[nq]
     int* pinned = nullptr;
 };
 static void lp_free(LpWork& w) {
@@ -133,24 +133,39 @@ static void lp_free(LpWork& w) {
     if (w.pinned) (void)hipHostFree(w.pinned);
     w = LpWork();
 }
-static int lp_alloc(LpWork& w, int n, int m, int np) {
+static int lp_alloc(LpWork& w, int n, int ml, const std::vector<int>& q, int np) {
     if (w.f64) return 0;
-    const size_t N = n, M = m ? m : 1, Pq = np ? np : 1;
-    const size_t nd = 8 * N + 7 * Pq + 15 * M + LP_NSC;
+    int sumq = 0;
+    for (int k : q) sumq += k;
+    const int m = ml + sumq, nq = (int)q.size();
+    const size_t N = n ? n : 1, M = m ? m : 1, Pq = np ? np : 1;
+    const size_t nd = 10 * N + 9 * Pq + 23 * M + (size_t)sumq + nq + LP_NSC + 8;
     if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
-    if (hipMalloc(&w.i32, sizeof(int) * 8) != hipSuccess) return MI355KKT_ENOMEM;
+    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq)) != hipSuccess) return MI355KKT_ENOMEM;
     if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
     LpState& S = w.S;
-    S.n = n; S.m = m; S.p = np;
+    S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq;
     double* p = w.f64;
     auto take = [&](size_t k) { double* r = p; p += k; return r; };
     S.c = take(N); S.x = take(N); S.dx = take(N); S.rx = take(N); S.x1 = take(N); S.GTz = take(N); S.ATy = take(N); S.x_out = take(N);
+    S.wx = take(N); S.wx2 = take(N);
     S.b = take(Pq); S.y = take(Pq); S.dy = take(Pq); S.ry = take(Pq); S.y1 = take(Pq); S.Ax = take(Pq); S.y_out = take(Pq);
+    S.wy = take(Pq); S.wy2 = take(Pq);
     S.h = take(M); S.s = take(M); S.z = take(M); S.ds = take(M); S.dz = take(M); S.rz = take(M); S.z1 = take(M); S.th = take(M);
-    S.lmbda = take(M); S.d = take(M); S.di = take(M); S.ws3 = take(M); S.Gx = take(M); S.s_out = take(M); S.z_out = take(M);
+    S.lmbda = take(M); S.lmbdasq = take(M); S.d = take(M); S.di = take(M); S.ws3 = take(M); S.Gx = take(M); S.s_out = take(M);
+    S.z_out = take(M); S.t1 = take(M); S.t2 = take(M); S.wz3 = take(M); S.ws = take(M); S.wz = take(M); S.ws2 = take(M);
+    S.wz2 = take(M);
+    S.v = take(sumq ? sumq : 1); S.beta = take(nq ? nq : 1);
     S.sc = take(LP_NSC);
-    int* q = w.i32;
-    S.active = q; S.status = q + 1; S.iters = q + 2; S.init_optimal = q + 3; S.nactive = q + 4;
+    int* qi = w.i32;
+    S.active = qi; S.status = qi + 1; S.iters = qi + 2; S.init_optimal = qi + 3; S.nactive = qi + 4;
+    if (nq) {
+        std::vector<int> hq(2 * (size_t)nq);
+        int off = ml;
+        for (int k = 0; k < nq; ++k) { hq[k] = off; hq[nq + k] = q[k]; off += q[k]; }
+        if (hipMemcpy(qi + 8, hq.data(), sizeof(int) * 2 * nq, hipMemcpyHostToDevice) != hipSuccess) return MI355KKT_EHIP;
+    }
+    S.qoff = qi + 8; S.qdim = qi + 8 + nq;
     return 0;
 }
 
@@ -1151,54 +1166,52 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
     return run_ipm(hs->ipm, st, ops, q, hv, bv, maxiters, abstol, reltol, feastol, o);
 }
 
-/* Single problem, LP cone: the conelp loop of coneprog.py:586-1436 (self-dual embedding, default starting point, no
- * refinement) resident on the device around this handle's factor/solve (H must be absent).  See include/mi355kkt.h. */
-int mi355kkt_conelp_lp(mi355kkt_solver* hs, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
-                       double reltol, double feastol, double* x, double* y, double* s, double* z, int* status, int* iters,
-                       double* stats) {
+/* Single problem, 'l' + 'q' cones: the conelp loop of coneprog.py:586-1436 (self-dual embedding, default starting point,
+ * refinement 0 for the LP cone and 1 with second-order cones, :502-507) resident on the device around this handle's
+ * factor/solve (H must be absent).  See include/mi355kkt.h. */
+int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
+                    double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
+                    int* iters, double* stats) {
     if (!hs || !c || !hv || !x || !s || !z || !status || !iters || (hs->p > 0 && (!bv || !y))) {
-        set_last_error("conelp_lp: null argument");
+        set_last_error("conelp: null argument");
         return MI355KKT_EINVAL;
     }
-    if (!hs->q.empty() || !hs->s.empty() || hs->ml < 1) { set_last_error("conelp_lp: needs dims = {'l': m > 0}"); return MI355KKT_ENOTIMPL; }
-    if (hs->dH) { set_last_error("conelp_lp: the handle carries a quadratic term (H)"); return MI355KKT_EINVAL; }
-    if (hs->sparse && hs->p > 0) { set_last_error("conelp_lp: equality constraints need the dense engine"); return MI355KKT_ENOTIMPL; }
-    if (hs->p > 0 && !hs->dA) { set_last_error("conelp_lp: A not set"); return MI355KKT_EINVAL; }
+    if (!hs->s.empty() || hs->cdim < 1) { set_last_error("conelp: needs dims = {'l': ml, 'q': [...]} with at least one row"); return MI355KKT_ENOTIMPL; }
+    if (hs->dH) { set_last_error("conelp: the handle carries a quadratic term (H)"); return MI355KKT_EINVAL; }
+    if (hs->sparse && hs->p > 0) { set_last_error("conelp: equality constraints need the dense engine"); return MI355KKT_ENOTIMPL; }
+    if (hs->p > 0 && !hs->dA) { set_last_error("conelp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
-    const int n = hs->n, m = hs->ml, np = hs->p;
-    if (int e = lp_alloc(hs->lp, n, m, np)) return e;
+    const int n = hs->n, m = hs->cdim, np = hs->p;
+    if (refinement < 0) refinement = hs->q.empty() ? 0 : 1;
+    if (int e = lp_alloc(hs->lp, n, hs->ml, hs->q, np)) return e;
     LpWork& w = hs->lp;
     const LpState& S = w.S;
     hipStream_t st = hs->st;
-    if (!hs->dIpmWork && !hs->sparse)
-        KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n)),
-                                                                    gemv_work_doubles(np, n))));
+    if (int e = ensure_gemv_work(hs)) return e;
     double* gwork = hs->dIpmWork;
     int* d_info = w.i32 + 5;
-    auto products = [&]() -> int {                 // G x, G'z, A x, A'y
-        if (hs->sparse) {
-            if (int e = sparse_engine_products(hs->sp, S.x, S.z, S.Gx, S.GTz, S.ATy /* P x = 0: scratch */, st)) return e;
-            return 0;
-        }
-        if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, S.x, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
+    // G xin -> Gx, A xin -> Ax, G' zin -> GTz, A' yin -> ATy
+    auto products = [&](const double* xin, const double* yin, const double* zin) -> int {
+        if (hs->sparse) return sparse_engine_products(hs->sp, xin, zin, S.Gx, S.GTz, S.ATy /* P x = 0: scratch */, st);
+        if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, xin, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
         KKT_HIP_CHECK(hipMemsetAsync(S.GTz, 0, sizeof(double) * n, st));
-        if (int e = launch_gemv_t_scaled(hs->dG, hs->ldG, m, n, nullptr, S.z, hs->dzs, S.GTz, gwork, st)) return e;
+        if (int e = launch_gemv_t_scaled(hs->dG, hs->ldG, m, n, nullptr, zin, hs->dzs, S.GTz, gwork, st)) return e;
         if (np > 0) {
-            if (int e = launch_gemv_n_scaled(hs->dA, hs->ldA, np, n, nullptr, S.x, S.Ax, S.Ax, 1.0, 0.0, gwork, st)) return e;
+            if (int e = launch_gemv_n_scaled(hs->dA, hs->ldA, np, n, nullptr, xin, S.Ax, S.Ax, 1.0, 0.0, gwork, st)) return e;
             KKT_HIP_CHECK(hipMemsetAsync(S.ATy, 0, sizeof(double) * n, st));
-            if (int e = launch_gemv_t_scaled(hs->dA, hs->ldA, np, n, nullptr, S.y, hs->dtp, S.ATy, gwork, st)) return e;
+            if (int e = launch_gemv_t_scaled(hs->dA, hs->ldA, np, n, nullptr, yin, hs->dtp, S.ATy, gwork, st)) return e;
         }
         return 0;
     };
     auto factor = [&](int* info_out) -> int {
         mi355kkt_scaling W = {};
-        W.di = S.di;
+        W.di = S.di; W.d = S.d; W.v = S.v; W.beta = S.beta;
         const int info = mi355kkt_factor_device(hs, &W);
         if (info < 0) return info;
         *info_out = info;
         w.pinned[1] = info;
         KKT_HIP_CHECK(hipMemcpyAsync(d_info, w.pinned + 1, sizeof(int), hipMemcpyHostToDevice, st));
-        if (info > 0) hs->factored = true;   // the loop drops the problem before any solve result is used
+        if (info > 0) hs->factored = true;   // the loop leaves before any solve result is used
         return 0;
     };
     auto solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_solve_device(hs, dx, dy, dz); };
@@ -1206,45 +1219,60 @@ int mi355kkt_conelp_lp(mi355kkt_solver* hs, const double* c, const double* hv, c
         if (k) KKT_HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(double) * k, hipMemcpyDeviceToDevice, st));
         return 0;
     };
+    const LpBuf D{S.dx, S.dy, S.dz, S.ds, LP_DTAU, LP_DKAPPA};
+    const LpBuf Wsave{S.wx, S.wy, S.wz, S.ws, LP_WTAU, LP_WKAPPA};
+    const LpBuf W2{S.wx2, S.wy2, S.wz2, S.ws2, LP_WTAU2, LP_WKAPPA2};
     KKT_HIP_CHECK(hipMemcpyAsync(S.c, c, sizeof(double) * n, hipMemcpyHostToDevice, st));
     KKT_HIP_CHECK(hipMemcpyAsync(S.h, hv, sizeof(double) * m, hipMemcpyHostToDevice, st));
     if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bv, sizeof(double) * np, hipMemcpyHostToDevice, st));
     KKT_HIP_CHECK(hipMemsetAsync(w.i32, 0, sizeof(int) * 8, st));
     KKT_HIP_CHECK(hipMemsetAsync(S.sc, 0, sizeof(double) * LP_NSC, st));
     // ---- starting points with W = I (coneprog.py:664-748)
-    hipLaunchKernelGGL(fill_kernel, dim3((m + 255) / 256), dim3(256), 0, st, S.di, 1.0, (int64_t)m);
+    lp_launch_unit_scaling(S, st);
     int info = 0;
     if (int e = factor(&info)) return e;
-    if (info > 0) { set_last_error("conelp_lp: Rank(A) < p or Rank([G; A]) < n"); return 1; }
+    if (info > 0) { set_last_error("conelp: Rank(A) < p or Rank([G; A]) < n"); return 1; }
     KKT_HIP_CHECK(hipMemsetAsync(S.x, 0, sizeof(double) * n, st));
     if (int e = dcopy(S.dy, S.b, np)) return e;
     if (int e = dcopy(S.s, S.h, m)) return e;
     if (int e = solve(S.x, S.dy, S.s)) return e;
-    lp_launch_init_primal(S, 1, st);
+    lp_launch_init_primal(S, st);
     hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S.dx, S.c, -1.0, (int64_t)n);
     if (np > 0) KKT_HIP_CHECK(hipMemsetAsync(S.y, 0, sizeof(double) * np, st));
     KKT_HIP_CHECK(hipMemsetAsync(S.z, 0, sizeof(double) * m, st));
     if (int e = solve(S.dx, S.y, S.z)) return e;
-    lp_launch_init_dual(S, 1, abstol, reltol, st);
+    lp_launch_init_dual(S, abstol, reltol, st);
     int it = 0;
     for (; it <= maxiters; ++it) {
-        if (int e = products()) return e;
+        if (int e = products(S.x, S.y, S.z)) return e;
         KKT_HIP_CHECK(hipMemsetAsync(S.nactive, 0, sizeof(int), st));
-        lp_launch_residual(S, 1, it, maxiters, abstol, reltol, feastol, st);
+        lp_launch_residual(S, it, maxiters, abstol, reltol, feastol, st);
         KKT_HIP_CHECK(hipMemcpyAsync(w.pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
         KKT_HIP_CHECK(hipStreamSynchronize(st));
         if (w.pinned[0] == 0) break;
         if (int e = factor(&info)) return e;
-        lp_launch_singular(S, 1, d_info, it, st);
+        lp_launch_singular(S, d_info, it, st);
         if (info > 0) break;
         if (int e = solve(S.x1, S.y1, S.z1)) return e;
-        lp_launch_scale1(S, 1, st);
+        lp_launch_scale1(S, st);
         for (int i01 = 0; i01 < 2; ++i01) {
-            lp_launch_rhs(S, 1, i01, st);
-            if (int e = solve(S.dx, S.dy, S.dz)) return e;
-            lp_launch_post(S, 1, i01, st);
+            lp_launch_build(S, D, Wsave, i01, refinement > 0 ? 1 : 0, st);
+            lp_launch_f6pre(S, D, st);                                   // f6 = f6_no_ir + `refinement` correction steps
+            if (int e = solve(D.x, D.y, D.z)) return e;
+            lp_launch_f6post(S, D, st);
+            for (int r = 0; r < refinement; ++r) {                       // coneprog.py:1220-1235
+                lp_launch_copy(S, W2, Wsave, st);
+                lp_launch_res_a(S, D, st);
+                if (int e = products(D.x, D.y, S.wz3)) return e;
+                lp_launch_res_b(S, D, W2, st);
+                lp_launch_f6pre(S, W2, st);
+                if (int e = solve(W2.x, W2.y, W2.z)) return e;
+                lp_launch_f6post(S, W2, st);
+                lp_launch_add(S, D, W2, st);
+            }
+            lp_launch_step(S, D, i01, st);
         }
-        lp_launch_update(S, 1, st);
+        lp_launch_update(S, D, st);
     }
     KKT_HIP_CHECK(hipMemcpyAsync(x, S.x_out, sizeof(double) * n, hipMemcpyDeviceToHost, st));
     if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(y, S.y_out, sizeof(double) * np, hipMemcpyDeviceToHost, st));

@@ -1,15 +1,19 @@
 // Device-resident bookkeeping of the reference conelp loop (self-dual embedding) for
-// dims = {'l': m}: one workgroup per problem, fixed-order block reductions.  Each kernel restates a stretch of
+// dims = {'l': ml, 'q': [...]}: one 256-thread workgroup, fixed-order block reductions; second-order cones are walked
+// one cone per thread (the BASELINE SOCP class has ~1e3 cones of dimension ~1e1).  Each kernel restates a stretch of
 // src/python/coneprog.py, operation for operation:
 //     lp_init_primal_kernel   :699-713    s = -s after the first KKT solve, ts
 //     lp_init_dual_kernel     :735-836    tz, the "initial point is optimal" test, shifts, tau = kappa = 1, gap
-//     lp_residual_kernel      :860-1041   residuals, statistics, the four stopping tests, compute_scaling (misc.py:284-287),
-//                                         right-hand side of the extra solve (:1064-1071), th (:1133-1135), mu
+//     lp_residual_kernel      :860-1041   residuals, statistics, the four stopping tests, compute_scaling (misc.py:284-354),
+//                                         right-hand side of the extra solve (:1064-1071), th (:1133-1135), lmbdasq, mu
 //     lp_scale1_kernel        :1072-1074  (x1, y1, z1) *= dgi
-//     lp_rhs_kernel           :1259-1296 + f6_no_ir :1158-1174   right-hand sides
-//     lp_post_kernel          f6_no_ir :1187-1203, :1299-1331    combination with (x1, y1, z1), step length, sigma
-//     lp_update_kernel        :1335-1432 + misc.py:444-464       iterate, scaling, tau / kappa update
-// Refinement is 0 for the LP cone (coneprog.py:551-554), so f6 == f6_no_ir.
+//     lp_build_kernel         :1259-1296  right-hand side (dx, dy, dz, dtau, ds, dkappa), saved for the refinement
+//     lp_f6pre_kernel         f6_no_ir :1158-1174      lp_f6post_kernel   f6_no_ir :1187-1203
+//     lp_res_a/_b_kernel      res() :596-634 (5x5 residual of the refinement step, :1220-1235);  lp_add_kernel
+//     lp_step_kernel          :1299-1331  Mehrotra products, scale2, step to the boundary, sigma
+//     lp_update_kernel        :1335-1432 + misc.py:444-464, :503-573   iterate, scaling, tau / kappa update
+// and the cone-vector operations sprod, sinv, ssqr, scale2, max_step, scale (src/C/misc_solvers.c:634, :775, :256, :1052,
+// :85; misc.py:945) for the 'l' and 'q' blocks.
 #include "kkt_common.h"
 
 namespace mi355kkt {
@@ -38,64 +42,153 @@ __device__ __forceinline__ double lp_dot(const double* a, const double* b, int n
     return lp_block_sum(v, sh);
 }
 
+// ---- second-order-cone pieces, one cone (x: the cone's own entries, mk of them) -----------------------------
+__device__ __forceinline__ double q_nrm1(const double* x, int mk) {      // ||x[1:]||
+    double a = 0.0;
+    for (int i = 1; i < mk; ++i) a += x[i] * x[i];
+    return sqrt(a);
+}
+__device__ __forceinline__ double q_jnrm2(const double* x, int mk) {     // misc.py:848-857
+    const double a = q_nrm1(x, mk);
+    return sqrt(x[0] - a) * sqrt(x[0] + a);
+}
+__device__ __forceinline__ void q_sprod(double* x, const double* y, int mk) {           // x := x o y
+    double a = 0.0;
+    for (int i = 0; i < mk; ++i) a += y[i] * x[i];
+    const double x0 = x[0], y0 = y[0];
+    for (int i = 1; i < mk; ++i) x[i] = y0 * x[i] + x0 * y[i];
+    x[0] = a;
+}
+__device__ __forceinline__ void q_sinv(double* x, const double* y, int mk) {            // x := y o\ x
+    double a = q_nrm1(y, mk);
+    a = (y[0] + a) * (y[0] - a);
+    const double c = x[0];
+    double d = 0.0;
+    for (int i = 1; i < mk; ++i) d += x[i] * y[i];
+    const double x0 = c * y[0] - d;
+    const double al = a / y[0], be = d / y[0] - c, ia = 1.0 / a;
+    for (int i = 1; i < mk; ++i) x[i] = (al * x[i] + be * y[i]) * ia;
+    x[0] = x0 * ia;
+}
+__device__ __forceinline__ void q_ssqr(double* x, const double* y, int mk) {            // x := y o y
+    double a = 0.0;
+    for (int i = 0; i < mk; ++i) a += y[i] * y[i];
+    const double y0 = y[0];
+    for (int i = 1; i < mk; ++i) x[i] = 2.0 * y0 * y[i];
+    x[0] = a;
+}
+__device__ __forceinline__ void q_scale2(const double* l, double* x, int mk, bool inverse) {
+    double a = q_nrm1(l, mk);
+    a = sqrt(l[0] + a) * sqrt(l[0] - a);
+    double lx = 0.0;
+    if (!inverse) {
+        for (int i = 1; i < mk; ++i) lx += l[i] * x[i];
+        lx = (l[0] * x[0] - lx) / a;
+    } else {
+        for (int i = 0; i < mk; ++i) lx += l[i] * x[i];
+        lx = lx / a;
+    }
+    const double x0 = x[0];
+    double b = (x0 + lx) / (l[0] / a + 1.0) / a;
+    if (!inverse) b = -b;
+    const double sc = inverse ? a : 1.0 / a;
+    for (int i = 1; i < mk; ++i) x[i] = (x[i] + b * l[i]) * sc;
+    x[0] = lx * sc;
+}
+__device__ __forceinline__ void q_scale(double* x, const double* v, double beta, int mk, bool inverse) {   // W x / W^-1 x
+    double w = 0.0;
+    if (!inverse) {
+        for (int i = 0; i < mk; ++i) w += v[i] * x[i];
+        x[0] = beta * (2.0 * v[0] * w - x[0]);
+        for (int i = 1; i < mk; ++i) x[i] = beta * (x[i] + 2.0 * v[i] * w);
+    } else {
+        for (int i = 1; i < mk; ++i) w += v[i] * x[i];
+        w = v[0] * x[0] - w;
+        const double ib = 1.0 / beta;
+        x[0] = (2.0 * v[0] * w - x[0]) * ib;
+        for (int i = 1; i < mk; ++i) x[i] = (x[i] - 2.0 * v[i] * w) * ib;
+    }
+}
+
+// ---- whole cone vectors (l part strided over the workgroup, q part one cone per thread) -----------------------
+__device__ __forceinline__ double cv_maxstep(const LpState& S, const double* x, double* sh) {
+    double t = -1e300;
+    for (int i = threadIdx.x; i < S.ml; i += 256) t = fmax(t, -x[i]);
+    for (int k = threadIdx.x; k < S.nq; k += 256) t = fmax(t, q_nrm1(x + S.qoff[k], S.qdim[k]) - x[S.qoff[k]]);
+    return lp_block_max(t, sh);
+}
+__device__ __forceinline__ void cv_add_e(const LpState& S, double* x, double a) {
+    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] += a;
+    for (int k = threadIdx.x; k < S.nq; k += 256) x[S.qoff[k]] += a;
+}
+__device__ __forceinline__ void cv_sprod(const LpState& S, double* x, const double* y) {
+    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] *= y[i];
+    for (int k = threadIdx.x; k < S.nq; k += 256) q_sprod(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
+}
+__device__ __forceinline__ void cv_sinv(const LpState& S, double* x, const double* y) {
+    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] /= y[i];
+    for (int k = threadIdx.x; k < S.nq; k += 256) q_sinv(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
+}
+__device__ __forceinline__ void cv_ssqr(const LpState& S, double* x, const double* y) {
+    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] = y[i] * y[i];
+    for (int k = threadIdx.x; k < S.nq; k += 256) q_ssqr(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
+}
+__device__ __forceinline__ void cv_scale2(const LpState& S, const double* l, double* x, bool inverse) {
+    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] = inverse ? x[i] * l[i] : x[i] / l[i];
+    for (int k = threadIdx.x; k < S.nq; k += 256) q_scale2(l + S.qoff[k], x + S.qoff[k], S.qdim[k], inverse);
+}
+// x := W x (== W' x) or W^-1 x (== W^-T x): both symmetric for 'l' and 'q' blocks
+__device__ __forceinline__ void cv_scale(const LpState& S, double* x, bool inverse) {
+    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] = inverse ? x[i] / S.d[i] : x[i] * S.d[i];
+    for (int k = threadIdx.x; k < S.nq; k += 256)
+        q_scale(x + S.qoff[k], S.v + (S.qoff[k] - S.ml), S.beta[k], S.qdim[k], inverse);
+}
+
 // status codes: 1 optimal, 2 unknown (iteration limit), 3 unknown (singular KKT matrix), 4 primal infeasible,
 // 5 dual infeasible
-__device__ __forceinline__ void lp_store_result(const LpState& S, int b, int status, int it, double xs, double ys, double ss,
-                                                double zs) {
+__device__ __forceinline__ void lp_store_result(const LpState& S, int status, int it, double xs, double ys, double ss, double zs) {
     const int tid = threadIdx.x, n = S.n, m = S.m, p = S.p;
-    for (int i = tid; i < n; i += 256) S.x_out[(int64_t)b * n + i] = S.x[(int64_t)b * n + i] * xs;
-    for (int i = tid; i < p; i += 256) S.y_out[(int64_t)b * p + i] = S.y[(int64_t)b * p + i] * ys;
+    for (int i = tid; i < n; i += 256) S.x_out[i] = S.x[i] * xs;
+    for (int i = tid; i < p; i += 256) S.y_out[i] = S.y[i] * ys;
     for (int i = tid; i < m; i += 256) {
-        S.s_out[(int64_t)b * m + i] = S.s[(int64_t)b * m + i] * ss;
-        S.z_out[(int64_t)b * m + i] = S.z[(int64_t)b * m + i] * zs;
+        S.s_out[i] = S.s[i] * ss;
+        S.z_out[i] = S.z[i] * zs;
     }
     if (tid == 0) {
-        S.status[b] = status;
-        S.iters[b] = it;
-        S.active[b] = 0;
+        S.status[0] = status;
+        S.iters[0] = it;
+        S.active[0] = 0;
     }
+}
+
+// W = I: d = di = 1, v_k = e, beta_k = 1 (coneprog.py:676-688)
+__global__ __launch_bounds__(256) void lp_unit_scaling_kernel(LpState S) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < S.ml; i += 256) { S.d[i] = 1.0; S.di[i] = 1.0; }
+    for (int i = tid; i < S.m - S.ml; i += 256) S.v[i] = 0.0;
+    __syncthreads();
+    for (int k = tid; k < S.nq; k += 256) { S.v[S.qoff[k] - S.ml] = 1.0; S.beta[k] = 1.0; }
 }
 
 __global__ __launch_bounds__(256) void lp_init_primal_kernel(LpState S) {
     __shared__ double sh[4];
-    const int b = blockIdx.x, tid = threadIdx.x, m = S.m;
-    double* s = S.s + (int64_t)b * m;
-    double ts = -1e300;
-    for (int i = tid; i < m; i += 256) {
-        const double v = -s[i];
-        s[i] = v;
-        ts = fmax(ts, -v);
-    }
-    ts = lp_block_max(ts, sh);
-    if (tid == 0) S.sc[b * LP_NSC + LP_TS] = ts;
+    for (int i = threadIdx.x; i < S.m; i += 256) S.s[i] = -S.s[i];
+    __syncthreads();
+    const double ts = cv_maxstep(S, S.s, sh);
+    if (threadIdx.x == 0) S.sc[LP_TS] = ts;
 }
 
 __global__ __launch_bounds__(256) void lp_init_dual_kernel(LpState S, double abstol, double reltol) {
     __shared__ double sh[4];
-    const int b = blockIdx.x, tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
-    double* sc = S.sc + b * LP_NSC;
-    double* s = S.s + (int64_t)b * m;
-    double* z = S.z + (int64_t)b * m;
-    const double* h = S.h + (int64_t)b * m;
-    const double* c = S.c + (int64_t)b * n;
-    const double* x = S.x + (int64_t)b * n;
-    double tz = -1e300, ns = 0.0, nz = 0.0, g = 0.0, hz = 0.0;
-    for (int i = tid; i < m; i += 256) {
-        tz = fmax(tz, -z[i]);
-        ns += s[i] * s[i];
-        nz += z[i] * z[i];
-        g += s[i] * z[i];
-        hz += h[i] * z[i];
-    }
-    tz = lp_block_max(tz, sh);
-    ns = sqrt(lp_block_sum(ns, sh));
-    nz = sqrt(lp_block_sum(nz, sh));
-    g = lp_block_sum(g, sh);
-    hz = lp_block_sum(hz, sh);
-    const double cx = lp_dot(c, x, n, sh);
-    const double by = p > 0 ? lp_dot(S.b + (int64_t)b * p, S.y + (int64_t)b * p, p, sh) : 0.0;
-    const double c2 = lp_dot(c, c, n, sh), h2 = lp_dot(h, h, m, sh);
-    const double b2 = p > 0 ? lp_dot(S.b + (int64_t)b * p, S.b + (int64_t)b * p, p, sh) : 0.0;
+    const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
+    double* sc = S.sc;
+    const double tz = cv_maxstep(S, S.z, sh);
+    const double ns = sqrt(lp_dot(S.s, S.s, m, sh)), nz = sqrt(lp_dot(S.z, S.z, m, sh));
+    const double g = lp_dot(S.s, S.z, m, sh), hz = lp_dot(S.h, S.z, m, sh);
+    const double cx = lp_dot(S.c, S.x, n, sh);
+    const double by = p > 0 ? lp_dot(S.b, S.y, p, sh) : 0.0;
+    const double c2 = lp_dot(S.c, S.c, n, sh), h2 = lp_dot(S.h, S.h, m, sh);
+    const double b2 = p > 0 ? lp_dot(S.b, S.b, p, sh) : 0.0;
     const double ts = sc[LP_TS];
     const double pcost = cx, dcost = -by - hz;
     double relgap = 1e300;
@@ -113,88 +206,68 @@ __global__ __launch_bounds__(256) void lp_init_dual_kernel(LpState S, double abs
         sc[LP_RELGAP] = relgap;
         sc[LP_TAU] = 1.0;
         sc[LP_KAPPA] = 1.0;
-        S.active[b] = 1;
-        S.status[b] = 0;
-        S.iters[b] = 0;
-        S.init_optimal[b] = init_opt ? 1 : 0;
+        S.active[0] = 1;
+        S.status[0] = 0;
+        S.iters[0] = 0;
+        S.init_optimal[0] = init_opt ? 1 : 0;
     }
     if (init_opt) {                                 // coneprog.py:761-806: the constructed point is already optimal
         __syncthreads();
-        lp_store_result(S, b, 1, 0, 1.0, 1.0, 1.0, 1.0);
+        lp_store_result(S, 1, 0, 1.0, 1.0, 1.0, 1.0);
         return;
     }
-    const double as = (ts >= -1e-8 * fmax(ns, 1.0)) ? 1.0 + ts : 0.0;
-    const double az = (tz >= -1e-8 * fmax(nz, 1.0)) ? 1.0 + tz : 0.0;
-    double g2 = 0.0;
-    for (int i = tid; i < m; i += 256) {
-        const double si = s[i] + as, zi = z[i] + az;
-        s[i] = si;
-        z[i] = zi;
-        g2 += si * zi;
-    }
-    g2 = lp_block_sum(g2, sh);
+    if (ts >= -1e-8 * fmax(ns, 1.0)) cv_add_e(S, S.s, 1.0 + ts);
+    if (tz >= -1e-8 * fmax(nz, 1.0)) cv_add_e(S, S.z, 1.0 + tz);
+    __syncthreads();
+    const double g2 = lp_dot(S.s, S.z, m, sh);
     if (tid == 0) sc[LP_GAP] = g2;
 }
 
 __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int maxiters, double abstol, double reltol,
                                                           double feastol) {
     __shared__ double sh[4];
-    const int b = blockIdx.x, tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
-    double* sc = S.sc + b * LP_NSC;
-    const bool act = S.active[b] != 0;
+    const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
+    double* sc = S.sc;
+    if (S.active[0] == 0) return;
     const double tau = sc[LP_TAU], kappa = sc[LP_KAPPA], gap = sc[LP_GAP];
-    const double* c = S.c + (int64_t)b * n;
-    const double* x = S.x + (int64_t)b * n;
-    const double* gtz = S.GTz + (int64_t)b * n;
-    const double* aty = S.ATy + (int64_t)b * n;
-    double* rx = S.rx + (int64_t)b * n;
     // hrx = -A'y - G'z ; rx = hrx - c tau
     double hx2 = 0.0, rx2 = 0.0, cx = 0.0;
     for (int i = tid; i < n; i += 256) {
         double hr = 0.0;
-        if (p > 0) hr = -aty[i];
-        hr -= gtz[i];
-        const double r = hr - c[i] * tau;
-        rx[i] = r;
+        if (p > 0) hr = -S.ATy[i];
+        hr -= S.GTz[i];
+        const double r = hr - S.c[i] * tau;
+        S.rx[i] = r;
         hx2 += hr * hr;
         rx2 += r * r;
-        cx += c[i] * x[i];
+        cx += S.c[i] * S.x[i];
     }
     const double hresx = sqrt(lp_block_sum(hx2, sh));
     const double resx = sqrt(lp_block_sum(rx2, sh)) / tau;
     cx = lp_block_sum(cx, sh);
     double hresy = 0.0, resy = 0.0, by = 0.0;
     if (p > 0) {
-        const double* bb = S.b + (int64_t)b * p;
-        const double* y = S.y + (int64_t)b * p;
-        const double* ax = S.Ax + (int64_t)b * p;
-        double* ry = S.ry + (int64_t)b * p;
         double a2 = 0.0, r2 = 0.0, d = 0.0;
         for (int i = tid; i < p; i += 256) {
-            const double hr = ax[i];
-            const double r = hr - bb[i] * tau;
-            ry[i] = r;
+            const double hr = S.Ax[i];
+            const double r = hr - S.b[i] * tau;
+            S.ry[i] = r;
             a2 += hr * hr;
             r2 += r * r;
-            d += bb[i] * y[i];
+            d += S.b[i] * S.y[i];
         }
         hresy = sqrt(lp_block_sum(a2, sh));
         resy = sqrt(lp_block_sum(r2, sh)) / tau;
         by = lp_block_sum(d, sh);
     }
-    const double* h = S.h + (int64_t)b * m;
-    double* s = S.s + (int64_t)b * m;
-    double* z = S.z + (int64_t)b * m;
-    const double* gx = S.Gx + (int64_t)b * m;
-    double* rz = S.rz + (int64_t)b * m;
     double hz2 = 0.0, rz2 = 0.0, hz = 0.0;
     for (int i = tid; i < m; i += 256) {
-        const double hr = s[i] + gx[i];
-        const double r = hr - h[i] * tau;
-        rz[i] = r;
+        const double hr = S.s[i] + S.Gx[i];
+        const double r = hr - S.h[i] * tau;
+        S.rz[i] = r;
         hz2 += hr * hr;
         rz2 += r * r;
-        hz += h[i] * z[i];
+        hz += S.h[i] * S.z[i];
     }
     const double hresz = sqrt(lp_block_sum(hz2, sh));
     const double resz = sqrt(lp_block_sum(rz2, sh)) / tau;
@@ -209,7 +282,7 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
     const bool has_pinf = (hz + by < 0.0), has_dinf = (cx < 0.0);
     const double pinfres = has_pinf ? hresx / resx0 / (-hz - by) : 1e300;
     const double dinfres = has_dinf ? fmax(hresy / resy0, hresz / resz0) / (-cx) : 1e300;
-    if (act && tid == 0) {
+    if (tid == 0) {
         sc[LP_RT] = rt;
         sc[LP_PCOST] = pcost;
         sc[LP_DCOST] = dcost;
@@ -220,35 +293,52 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
         sc[LP_DINFRES] = dinfres;
         sc[LP_GAP_OUT] = gap;
     }
-    if (!act) {
-        for (int i = tid; i < m; i += 256) S.di[(int64_t)b * m + i] = 1.0;
-        return;
-    }
     const bool conv = pres <= feastol && dres <= feastol && (gap <= abstol || relgap <= reltol);
     const bool stop_opt = conv || it == maxiters;
     const bool stop_pinf = !stop_opt && has_pinf && pinfres <= feastol;
     const bool stop_dinf = !stop_opt && !stop_pinf && has_dinf && dinfres <= feastol;
     __syncthreads();
     if (stop_opt) {                                // coneprog.py:920-971
-        lp_store_result(S, b, conv ? 1 : 2, it, 1.0 / tau, 1.0 / tau, 1.0 / tau, 1.0 / tau);
+        lp_store_result(S, conv ? 1 : 2, it, 1.0 / tau, 1.0 / tau, 1.0 / tau, 1.0 / tau);
+        return;
     } else if (stop_pinf) {                        // :973-995
-        lp_store_result(S, b, 4, it, 0.0, 1.0 / (-hz - by), 0.0, 1.0 / (-hz - by));
+        lp_store_result(S, 4, it, 0.0, 1.0 / (-hz - by), 0.0, 1.0 / (-hz - by));
+        return;
     } else if (stop_dinf) {                        // :997-1020
-        lp_store_result(S, b, 5, it, 1.0 / (-cx), 0.0, 1.0 / (-cx), 0.0);
-    } else if (tid == 0) {
-        atomicAdd(S.nactive, 1);
-    }
-    double* d = S.d + (int64_t)b * m;
-    double* lm = S.lmbda + (int64_t)b * m;
-    double* di = S.di + (int64_t)b * m;
-    if (stop_opt || stop_pinf || stop_dinf) {
-        for (int i = tid; i < m; i += 256) di[i] = 1.0;
+        lp_store_result(S, 5, it, 1.0 / (-cx), 0.0, 1.0 / (-cx), 0.0);
         return;
     }
-    if (it == 0) {                                 // compute_scaling, 'l' block; dg, lambda_g (:1026-1041)
-        for (int i = tid; i < m; i += 256) {
-            d[i] = sqrt(s[i] / z[i]);
-            lm[i] = sqrt(s[i] * z[i]);
+    if (tid == 0) atomicAdd(S.nactive, 1);
+    if (it == 0) {                                 // compute_scaling (misc.py:284-354); dg, lambda_g (:1026-1041)
+        for (int i = tid; i < S.ml; i += 256) {
+            S.d[i] = sqrt(S.s[i] / S.z[i]);
+            S.lmbda[i] = sqrt(S.s[i] * S.z[i]);
+        }
+        for (int k = tid; k < S.nq; k += 256) {
+            const int o = S.qoff[k], mk = S.qdim[k];
+            const double* sk = S.s + o;
+            const double* zk = S.z + o;
+            double* v = S.v + (o - S.ml);
+            double* lk = S.lmbda + o;
+            const double aa = q_jnrm2(sk, mk), bb = q_jnrm2(zk, mk);
+            S.beta[k] = sqrt(aa / bb);
+            double dsz = 0.0;
+            for (int i = 0; i < mk; ++i) dsz += sk[i] * zk[i];
+            const double cc = sqrt((dsz / aa / bb + 1.0) / 2.0);
+            // vk = 1/(2c) (sk/a + J zk/b);  then v = (vk + e) / sqrt(2 (vk0 + 1))
+            for (int i = 0; i < mk; ++i) {
+                double t = zk[i] * (-1.0 / bb);
+                if (i == 0) t = -t;
+                t += sk[i] * (1.0 / aa);
+                v[i] = t * (1.0 / 2.0 / cc);
+            }
+            v[0] += 1.0;
+            const double f = 1.0 / sqrt(2.0 * v[0]);
+            for (int i = 0; i < mk; ++i) v[i] *= f;
+            const double dd = 2.0 * cc + sk[0] / aa + zk[0] / bb;
+            const double fs = (cc + zk[0] / bb) / dd / aa, fz = (cc + sk[0] / aa) / dd / bb, sq = sqrt(aa * bb);
+            lk[0] = cc * sq;
+            for (int i = 1; i < mk; ++i) lk[i] = (sk[i] * fs + zk[i] * fz) * sq;
         }
         if (tid == 0) {
             sc[LP_DG] = sqrt(kappa / tau);
@@ -257,19 +347,18 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
         }
         __syncthreads();
     }
-    // right-hand side of the extra solve (x1, y1, z1) = (-c, b, h); th = W^-T h; mu
-    double* x1 = S.x1 + (int64_t)b * n;
-    for (int i = tid; i < n; i += 256) x1[i] = -c[i];
-    for (int i = tid; i < p; i += 256) S.y1[(int64_t)b * p + i] = S.b[(int64_t)b * p + i];
-    double l2 = 0.0;
+    // scaling for the factorisation; right-hand side of the extra solve (x1, y1, z1) = (-c, b, h); th = W^-T h
+    for (int i = tid; i < S.ml; i += 256) S.di[i] = 1.0 / S.d[i];
+    for (int i = tid; i < n; i += 256) S.x1[i] = -S.c[i];
+    for (int i = tid; i < p; i += 256) S.y1[i] = S.b[i];
     for (int i = tid; i < m; i += 256) {
-        const double dii = 1.0 / d[i];
-        di[i] = dii;
-        S.z1[(int64_t)b * m + i] = h[i];
-        S.th[(int64_t)b * m + i] = h[i] * dii;
-        l2 += lm[i] * lm[i];
+        S.z1[i] = S.h[i];
+        S.th[i] = S.h[i];
     }
-    l2 = lp_block_sum(l2, sh);
+    __syncthreads();
+    cv_scale(S, S.th, true);
+    cv_ssqr(S, S.lmbdasq, S.lmbda);
+    const double l2 = lp_dot(S.lmbda, S.lmbda, m, sh);
     if (tid == 0) {
         const double lg = sc[LP_LG];
         const double nr = sqrt(l2 + lg * lg);       // blas.nrm2(lmbda)**2 / (1 + cdim_diag)
@@ -278,104 +367,185 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
     }
 }
 
-// problems whose factorisation failed: "Terminated (singular KKT matrix)" (:1076-1109)
+// "Terminated (singular KKT matrix)" (:1076-1109)
 __global__ __launch_bounds__(256) void lp_singular_kernel(LpState S, const int* info, int it) {
-    const int b = blockIdx.x;
-    if (!S.active[b] || info[b] <= 0) return;
-    const double tau = S.sc[b * LP_NSC + LP_TAU];
+    if (!S.active[0] || info[0] <= 0) return;
+    const double tau = S.sc[LP_TAU];
     __syncthreads();
-    lp_store_result(S, b, 3, it, 1.0 / tau, 1.0 / tau, 1.0 / tau, 1.0 / tau);
+    lp_store_result(S, 3, it, 1.0 / tau, 1.0 / tau, 1.0 / tau, 1.0 / tau);
     if (threadIdx.x == 0) atomicAdd(S.nactive, -1);
 }
 
 __global__ __launch_bounds__(256) void lp_scale1_kernel(LpState S) {
     __shared__ double sh[4];
-    const int b = blockIdx.x, tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
-    double* sc = S.sc + b * LP_NSC;
-    const double dgi = sc[LP_DGI];
-    for (int i = tid; i < n; i += 256) S.x1[(int64_t)b * n + i] *= dgi;
-    for (int i = tid; i < p; i += 256) S.y1[(int64_t)b * p + i] *= dgi;
-    double zz = 0.0;
-    for (int i = tid; i < m; i += 256) {
-        const double v = S.z1[(int64_t)b * m + i] * dgi;
-        S.z1[(int64_t)b * m + i] = v;
-        zz += v * v;
-    }
-    zz = lp_block_sum(zz, sh);
-    if (tid == 0) sc[LP_Z1Z1] = zz;
+    const int tid = threadIdx.x;
+    const double dgi = S.sc[LP_DGI];
+    for (int i = tid; i < S.n; i += 256) S.x1[i] *= dgi;
+    for (int i = tid; i < S.p; i += 256) S.y1[i] *= dgi;
+    for (int i = tid; i < S.m; i += 256) S.z1[i] *= dgi;
+    __syncthreads();
+    const double zz = lp_dot(S.z1, S.z1, S.m, sh);
+    if (tid == 0) S.sc[LP_Z1Z1] = zz;
 }
 
-__global__ __launch_bounds__(256) void lp_rhs_kernel(LpState S, int i01) {
-    const int b = blockIdx.x, tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
-    double* sc = S.sc + b * LP_NSC;
+// right-hand side of the Newton system (:1259-1296), also saved in W for the refinement step
+__global__ __launch_bounds__(256) void lp_build_kernel(LpState S, LpBuf D, LpBuf W, int i01, int save) {
+    const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
+    double* sc = S.sc;
     const double sigma = (i01 == 0) ? 0.0 : sc[LP_SIGMA];
     const double mu = sc[LP_MU], lg = sc[LP_LG];
-    const double* lm = S.lmbda + (int64_t)b * m;
-    const double* d = S.d + (int64_t)b * m;
-    const double* rz = S.rz + (int64_t)b * m;
-    const double* ws3 = S.ws3 + (int64_t)b * m;
-    double* ds = S.ds + (int64_t)b * m;
-    double* dz = S.dz + (int64_t)b * m;
     for (int i = tid; i < m; i += 256) {
-        double v = lm[i] * lm[i];                   // ds = lmbdasq (+ ws3 - sigma mu)
-        if (i01 == 1) v += ws3[i] - sigma * mu;
-        v = -(v / lm[i]);                           // f6_no_ir: s := -lmbda o\ s
-        ds[i] = v;
-        dz[i] = -((1.0 - sigma) * rz[i] + d[i] * v);   // z := -(z + W's)
+        double v = S.lmbdasq[i];
+        if (i01 == 1) v += S.ws3[i];
+        D.s[i] = v;
+        D.z[i] = (1.0 - sigma) * S.rz[i];
     }
-    for (int i = tid; i < n; i += 256) S.dx[(int64_t)b * n + i] = (1.0 - sigma) * S.rx[(int64_t)b * n + i];
-    for (int i = tid; i < p; i += 256) S.dy[(int64_t)b * p + i] = -((1.0 - sigma) * S.ry[(int64_t)b * p + i]);
+    for (int i = tid; i < n; i += 256) D.x[i] = (1.0 - sigma) * S.rx[i];
+    for (int i = tid; i < p; i += 256) D.y[i] = (1.0 - sigma) * S.ry[i];
+    __syncthreads();
+    if (i01 == 1) cv_add_e(S, D.s, -sigma * mu);
     if (tid == 0) {
         double dk = lg * lg;
         if (i01 == 1) dk += sc[LP_WKAPPA3] - sigma * mu;
-        sc[LP_DKAPPA] = dk;
-        sc[LP_DTAU] = (1.0 - sigma) * sc[LP_RT];
+        sc[D.ikappa] = dk;
+        sc[D.itau] = (1.0 - sigma) * sc[LP_RT];
+    }
+    if (save) {
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) { W.s[i] = D.s[i]; W.z[i] = D.z[i]; }
+        for (int i = tid; i < n; i += 256) W.x[i] = D.x[i];
+        for (int i = tid; i < p; i += 256) W.y[i] = D.y[i];
+        if (tid == 0) { sc[W.itau] = sc[D.itau]; sc[W.ikappa] = sc[D.ikappa]; }
     }
 }
 
-__global__ __launch_bounds__(256) void lp_post_kernel(LpState S, int i01) {
+// dst := src (all six components)
+__global__ __launch_bounds__(256) void lp_copy_kernel(LpState S, LpBuf dst, LpBuf src) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < S.m; i += 256) { dst.s[i] = src.s[i]; dst.z[i] = src.z[i]; }
+    for (int i = tid; i < S.n; i += 256) dst.x[i] = src.x[i];
+    for (int i = tid; i < S.p; i += 256) dst.y[i] = src.y[i];
+    if (tid == 0) { S.sc[dst.itau] = S.sc[src.itau]; S.sc[dst.ikappa] = S.sc[src.ikappa]; }
+}
+// dst += src
+__global__ __launch_bounds__(256) void lp_add_kernel(LpState S, LpBuf dst, LpBuf src) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < S.m; i += 256) { dst.s[i] += src.s[i]; dst.z[i] += src.z[i]; }
+    for (int i = tid; i < S.n; i += 256) dst.x[i] += src.x[i];
+    for (int i = tid; i < S.p; i += 256) dst.y[i] += src.y[i];
+    if (tid == 0) { S.sc[dst.itau] += S.sc[src.itau]; S.sc[dst.ikappa] += S.sc[src.ikappa]; }
+}
+
+// f6_no_ir, part before the KKT solve (:1158-1174): y := -y; s := -lmbda o\ s; z := -(z + W's)
+__global__ __launch_bounds__(256) void lp_f6pre_kernel(LpState S, LpBuf X) {
+    const int tid = threadIdx.x, m = S.m;
+    for (int i = tid; i < S.p; i += 256) X.y[i] = -X.y[i];
+    cv_sinv(S, X.s, S.lmbda);
+    __syncthreads();
+    for (int i = tid; i < m; i += 256) {
+        const double v = -X.s[i];
+        X.s[i] = v;
+        S.t1[i] = v;
+    }
+    __syncthreads();
+    cv_scale(S, S.t1, false);
+    __syncthreads();
+    for (int i = tid; i < m; i += 256) X.z[i] = -(X.z[i] + S.t1[i]);
+}
+
+// f6_no_ir, part after the KKT solve (:1187-1203)
+__global__ __launch_bounds__(256) void lp_f6post_kernel(LpState S, LpBuf X) {
     __shared__ double sh[4];
     __shared__ double tsh;
-    const int b = blockIdx.x, tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
-    double* sc = S.sc + b * LP_NSC;
-    double* dx = S.dx + (int64_t)b * n;
-    double* dz = S.dz + (int64_t)b * m;
-    double* ds = S.ds + (int64_t)b * m;
-    const double cdx = lp_dot(S.c + (int64_t)b * n, dx, n, sh);
-    const double bdy = p > 0 ? lp_dot(S.b + (int64_t)b * p, S.dy + (int64_t)b * p, p, sh) : 0.0;
-    const double thz = lp_dot(S.th + (int64_t)b * m, dz, m, sh);
+    const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
+    double* sc = S.sc;
+    const double cdx = lp_dot(S.c, X.x, n, sh);
+    const double bdy = p > 0 ? lp_dot(S.b, X.y, p, sh) : 0.0;
+    const double thz = lp_dot(S.th, X.z, m, sh);
     if (tid == 0) {
         const double lg = sc[LP_LG], dgi = sc[LP_DGI];
-        const double kap = -sc[LP_DKAPPA] / lg;     // kappa[0] := -bkappa / lmbdag
-        double t = sc[LP_DTAU] + kap / dgi;
+        const double kap = -sc[X.ikappa] / lg;      // kappa[0] := -bkappa / lmbdag
+        double t = sc[X.itau] + kap / dgi;
         t = dgi * (t + cdx + bdy + thz) / (1.0 + sc[LP_Z1Z1]);
-        sc[LP_DTAU] = t;
-        sc[LP_DKAPPA] = kap - t;
+        sc[X.itau] = t;
+        sc[X.ikappa] = kap - t;
         tsh = t;
     }
     __syncthreads();
     const double t = tsh;
-    for (int i = tid; i < n; i += 256) dx[i] += t * S.x1[(int64_t)b * n + i];
-    for (int i = tid; i < p; i += 256) S.dy[(int64_t)b * p + i] += t * S.y1[(int64_t)b * p + i];
-    const double* lm = S.lmbda + (int64_t)b * m;
-    double* ws3 = S.ws3 + (int64_t)b * m;
-    double tm = 0.0;
+    for (int i = tid; i < n; i += 256) X.x[i] += t * S.x1[i];
+    for (int i = tid; i < p; i += 256) X.y[i] += t * S.y1[i];
     for (int i = tid; i < m; i += 256) {
-        const double zz = dz[i] + t * S.z1[(int64_t)b * m + i];
-        const double ss = ds[i] - zz;               // s := s - z
-        if (i01 == 0) ws3[i] = ss * zz;             // ds o dz for the Mehrotra correction
-        const double sl = ss / lm[i], zl = zz / lm[i];   // scale2
-        ds[i] = sl;
-        dz[i] = zl;
-        tm = fmax(tm, fmax(-sl, -zl));
+        const double zz = X.z[i] + t * S.z1[i];
+        X.z[i] = zz;
+        X.s[i] -= zz;                               // s := s - z
     }
-    tm = lp_block_max(tm, sh);
+}
+
+// res() (:596-634), first half: wz3 = W^-1 uz (the products with G', A', G, A are launched by the host in between)
+__global__ __launch_bounds__(256) void lp_res_a_kernel(LpState S, LpBuf U) {
+    for (int i = threadIdx.x; i < S.m; i += 256) S.wz3[i] = U.z[i];
+    __syncthreads();
+    cv_scale(S, S.wz3, true);
+}
+// second half: S.GTz = G' wz3, S.ATy = A' uy, S.Gx = G ux, S.Ax = A ux are in place
+__global__ __launch_bounds__(256) void lp_res_b_kernel(LpState S, LpBuf U, LpBuf V) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
+    double* sc = S.sc;
+    const double dg = sc[LP_DG], lg = sc[LP_LG];
+    const double utau = sc[U.itau], ukappa = sc[U.ikappa];
+    const double cux = lp_dot(S.c, U.x, n, sh);
+    const double buy = p > 0 ? lp_dot(S.b, U.y, p, sh) : 0.0;
+    const double hw = lp_dot(S.h, S.wz3, m, sh);
+    for (int i = tid; i < n; i += 256) {
+        double v = V.x[i];
+        if (p > 0) v -= S.ATy[i];
+        v -= S.GTz[i];
+        v -= S.c[i] * (utau / dg);
+        V.x[i] = v;
+    }
+    for (int i = tid; i < p; i += 256) V.y[i] = V.y[i] + S.Ax[i] - S.b[i] * (utau / dg);
+    for (int i = tid; i < m; i += 256) {
+        S.t1[i] = U.s[i];                           // W' us
+        S.t2[i] = U.s[i] + U.z[i];                  // lmbda o (uz + us)
+    }
+    __syncthreads();
+    cv_scale(S, S.t1, false);
+    cv_sprod(S, S.t2, S.lmbda);
+    __syncthreads();
+    for (int i = tid; i < m; i += 256) {
+        V.z[i] = V.z[i] + S.Gx[i] - S.h[i] * (utau / dg) + S.t1[i];
+        V.s[i] += S.t2[i];
+    }
+    if (tid == 0) {
+        sc[V.itau] += dg * ukappa + cux + buy + hw;
+        sc[V.ikappa] += lg * (utau + ukappa);
+    }
+}
+
+// Mehrotra products, scale2, step to the boundary, sigma (:1299-1331)
+__global__ __launch_bounds__(256) void lp_step_kernel(LpState S, LpBuf D, int i01) {
+    __shared__ double sh[4];
+    const int tid = threadIdx.x, m = S.m;
+    double* sc = S.sc;
+    if (i01 == 0) {
+        for (int i = tid; i < m; i += 256) S.ws3[i] = D.s[i];
+        __syncthreads();
+        cv_sprod(S, S.ws3, D.z);
+    }
+    __syncthreads();
+    cv_scale2(S, S.lmbda, D.s, false);
+    cv_scale2(S, S.lmbda, D.z, false);
+    __syncthreads();
+    const double ts = cv_maxstep(S, D.s, sh);
+    const double tz = cv_maxstep(S, D.z, sh);
     if (tid == 0) {
         const double lg = sc[LP_LG];
-        const double dtau = sc[LP_DTAU], dkappa = sc[LP_DKAPPA];
+        const double dtau = sc[D.itau], dkappa = sc[D.ikappa];
         if (i01 == 0) sc[LP_WKAPPA3] = dtau * dkappa;
         const double tt = -dtau / lg, tk = -dkappa / lg;
-        const double tmax = fmax(fmax(0.0, tm), fmax(tt, tk));
+        const double tmax = fmax(fmax(0.0, fmax(ts, tz)), fmax(tt, tk));
         const double step = (tmax == 0.0) ? 1.0 : fmin(1.0, (i01 == 0 ? 1.0 : 0.99) / tmax);
         sc[LP_TT] = tt;
         sc[LP_TK] = tk;
@@ -387,34 +557,73 @@ __global__ __launch_bounds__(256) void lp_post_kernel(LpState S, int i01) {
     }
 }
 
-__global__ __launch_bounds__(256) void lp_update_kernel(LpState S) {
+__global__ __launch_bounds__(256) void lp_update_kernel(LpState S, LpBuf D) {
     __shared__ double sh[4];
-    const int b = blockIdx.x, tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
-    if (!S.active[b]) return;
-    double* sc = S.sc + b * LP_NSC;
+    const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
+    if (!S.active[0]) return;
+    double* sc = S.sc;
     const double step = sc[LP_STEP];
-    for (int i = tid; i < n; i += 256) S.x[(int64_t)b * n + i] += step * S.dx[(int64_t)b * n + i];
-    for (int i = tid; i < p; i += 256) S.y[(int64_t)b * p + i] += step * S.dy[(int64_t)b * p + i];
-    double* lm = S.lmbda + (int64_t)b * m;
-    double* d = S.d + (int64_t)b * m;
-    double* s = S.s + (int64_t)b * m;
-    double* z = S.z + (int64_t)b * m;
-    const double* ds = S.ds + (int64_t)b * m;
-    const double* dz = S.dz + (int64_t)b * m;
-    double g = 0.0;
+    for (int i = tid; i < n; i += 256) S.x[i] += step * D.x[i];
+    for (int i = tid; i < p; i += 256) S.y[i] += step * D.y[i];
+    // ds := e + step ds, dz := e + step dz; then H(lambda)^{-1/2}: the updated variables in the current scaling
     for (int i = tid; i < m; i += 256) {
-        const double l = lm[i];
-        const double a = sqrt((1.0 + step * ds[i]) * l);
-        const double c = sqrt((1.0 + step * dz[i]) * l);
-        const double dn = d[i] * a / c;
-        const double ln = a * c;
-        d[i] = dn;
-        lm[i] = ln;
-        s[i] = dn * ln;
-        z[i] = ln / dn;
-        g += ln * ln;
+        D.s[i] *= step;
+        D.z[i] *= step;
     }
-    g = lp_block_sum(g, sh);
+    __syncthreads();
+    cv_add_e(S, D.s, 1.0);
+    cv_add_e(S, D.z, 1.0);
+    __syncthreads();
+    cv_scale2(S, S.lmbda, D.s, true);
+    cv_scale2(S, S.lmbda, D.z, true);
+    __syncthreads();
+    // update_scaling: 'l' (misc.py:444-464) and 'q' (misc.py:503-573)
+    for (int i = tid; i < S.ml; i += 256) {
+        const double a = sqrt(D.s[i]), c = sqrt(D.z[i]);
+        S.d[i] = S.d[i] * a / c;
+        S.lmbda[i] = a * c;
+    }
+    for (int k = tid; k < S.nq; k += 256) {
+        const int o = S.qoff[k], mk = S.qdim[k];
+        double* sk = D.s + o;
+        double* zk = D.z + o;
+        double* v = S.v + (o - S.ml);
+        double* lk = S.lmbda + o;
+        const double aa = q_jnrm2(sk, mk);
+        for (int i = 0; i < mk; ++i) sk[i] *= 1.0 / aa;
+        const double bb = q_jnrm2(zk, mk);
+        for (int i = 0; i < mk; ++i) zk[i] *= 1.0 / bb;
+        double dsz = 0.0, vs = 0.0, vz1 = 0.0;
+        for (int i = 0; i < mk; ++i) {
+            dsz += sk[i] * zk[i];
+            vs += v[i] * sk[i];
+            if (i > 0) vz1 += v[i] * zk[i];
+        }
+        const double cc = sqrt((1.0 + dsz) / 2.0);
+        const double vz = v[0] * zk[0] - vz1;                       // v' J z
+        const double vq = (vs + vz) / 2.0 / cc;
+        const double vu = vs - vz;
+        const double wk0 = 2.0 * v[0] * vq - (sk[0] + zk[0]) / 2.0 / cc;
+        const double dd = (v[0] * vu - sk[0] / 2.0 + zk[0] / 2.0) / (wk0 + 1.0);
+        const double fv = 2.0 * (-dd * vq + 0.5 * vu), fs = 0.5 * (1.0 - dd / cc), fz = 0.5 * (1.0 + dd / cc);
+        const double sq = sqrt(aa * bb);
+        lk[0] = cc * sq;
+        for (int i = 1; i < mk; ++i) lk[i] = (v[i] * fv + sk[i] * fs + zk[i] * fz) * sq;
+        // v := (2 v v' - J) q, then v := v^{1/2}
+        const double s0 = sk[0];
+        for (int i = 0; i < mk; ++i) {
+            double t = 2.0 * vq * v[i];
+            if (i == 0) t -= s0 / 2.0 / cc;
+            else t += sk[i] * (0.5 / cc);
+            t += zk[i] * (-0.5 / cc);
+            v[i] = t;
+        }
+        v[0] += 1.0;
+        const double f = 1.0 / sqrt(2.0 * v[0]);
+        for (int i = 0; i < mk; ++i) v[i] *= f;
+        S.beta[k] *= sqrt(aa / bb);
+    }
+    __syncthreads();
     if (tid == 0) {
         const double tt = sc[LP_TT], tk = sc[LP_TK];
         const double dg = sc[LP_DG] * (sqrt(1.0 - step * tk) / sqrt(1.0 - step * tt));
@@ -423,28 +632,41 @@ __global__ __launch_bounds__(256) void lp_update_kernel(LpState S) {
         sc[LP_DG] = dg;
         sc[LP_DGI] = dgi;
         sc[LP_LG] = lg;
-        const double kappa = lg / dgi, tau = lg * dgi;
-        sc[LP_KAPPA] = kappa;
-        sc[LP_TAU] = tau;
-        const double r = sqrt(g) / tau;
+        sc[LP_KAPPA] = lg / dgi;
+        sc[LP_TAU] = lg * dgi;
+    }
+    // unscale: s = W' lmbda, z = W^-1 lmbda
+    for (int i = tid; i < m; i += 256) {
+        S.s[i] = S.lmbda[i];
+        S.z[i] = S.lmbda[i];
+    }
+    __syncthreads();
+    cv_scale(S, S.s, false);
+    cv_scale(S, S.z, true);
+    const double g = lp_dot(S.lmbda, S.lmbda, m, sh);
+    if (tid == 0) {
+        const double r = sqrt(g) / sc[LP_TAU];
         sc[LP_GAP] = r * r;
     }
 }
 
-void lp_launch_init_primal(const LpState& S, int B, hipStream_t st) { hipLaunchKernelGGL(lp_init_primal_kernel, dim3(B), dim3(256), 0, st, S); }
-void lp_launch_init_dual(const LpState& S, int B, double abstol, double reltol, hipStream_t st) {
-    hipLaunchKernelGGL(lp_init_dual_kernel, dim3(B), dim3(256), 0, st, S, abstol, reltol);
+#define LP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(256), 0, st, __VA_ARGS__)
+void lp_launch_unit_scaling(const LpState& S, hipStream_t st) { LP1(lp_unit_scaling_kernel, S); }
+void lp_launch_init_primal(const LpState& S, hipStream_t st) { LP1(lp_init_primal_kernel, S); }
+void lp_launch_init_dual(const LpState& S, double abstol, double reltol, hipStream_t st) { LP1(lp_init_dual_kernel, S, abstol, reltol); }
+void lp_launch_residual(const LpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st) {
+    LP1(lp_residual_kernel, S, it, maxiters, abstol, reltol, feastol);
 }
-void lp_launch_residual(const LpState& S, int B, int it, int maxiters, double abstol, double reltol, double feastol,
-                        hipStream_t st) {
-    hipLaunchKernelGGL(lp_residual_kernel, dim3(B), dim3(256), 0, st, S, it, maxiters, abstol, reltol, feastol);
-}
-void lp_launch_singular(const LpState& S, int B, const int* d_info, int it, hipStream_t st) {
-    hipLaunchKernelGGL(lp_singular_kernel, dim3(B), dim3(256), 0, st, S, d_info, it);
-}
-void lp_launch_scale1(const LpState& S, int B, hipStream_t st) { hipLaunchKernelGGL(lp_scale1_kernel, dim3(B), dim3(256), 0, st, S); }
-void lp_launch_rhs(const LpState& S, int B, int i01, hipStream_t st) { hipLaunchKernelGGL(lp_rhs_kernel, dim3(B), dim3(256), 0, st, S, i01); }
-void lp_launch_post(const LpState& S, int B, int i01, hipStream_t st) { hipLaunchKernelGGL(lp_post_kernel, dim3(B), dim3(256), 0, st, S, i01); }
-void lp_launch_update(const LpState& S, int B, hipStream_t st) { hipLaunchKernelGGL(lp_update_kernel, dim3(B), dim3(256), 0, st, S); }
+void lp_launch_singular(const LpState& S, const int* d_info, int it, hipStream_t st) { LP1(lp_singular_kernel, S, d_info, it); }
+void lp_launch_scale1(const LpState& S, hipStream_t st) { LP1(lp_scale1_kernel, S); }
+void lp_launch_build(const LpState& S, const LpBuf& D, const LpBuf& W, int i01, int save, hipStream_t st) { LP1(lp_build_kernel, S, D, W, i01, save); }
+void lp_launch_copy(const LpState& S, const LpBuf& dst, const LpBuf& src, hipStream_t st) { LP1(lp_copy_kernel, S, dst, src); }
+void lp_launch_add(const LpState& S, const LpBuf& dst, const LpBuf& src, hipStream_t st) { LP1(lp_add_kernel, S, dst, src); }
+void lp_launch_f6pre(const LpState& S, const LpBuf& X, hipStream_t st) { LP1(lp_f6pre_kernel, S, X); }
+void lp_launch_f6post(const LpState& S, const LpBuf& X, hipStream_t st) { LP1(lp_f6post_kernel, S, X); }
+void lp_launch_res_a(const LpState& S, const LpBuf& U, hipStream_t st) { LP1(lp_res_a_kernel, S, U); }
+void lp_launch_res_b(const LpState& S, const LpBuf& U, const LpBuf& V, hipStream_t st) { LP1(lp_res_b_kernel, S, U, V); }
+void lp_launch_step(const LpState& S, const LpBuf& D, int i01, hipStream_t st) { LP1(lp_step_kernel, S, D, i01); }
+void lp_launch_update(const LpState& S, const LpBuf& D, hipStream_t st) { LP1(lp_update_kernel, S, D); }
 
 }  // namespace mi355kkt

@@ -215,31 +215,42 @@ void ipm_launch_rhs(const IpmState& S, int B, int i01, hipStream_t st);
 void ipm_launch_post(const IpmState& S, int B, int i01, hipStream_t st);
 void ipm_launch_update(const IpmState& S, int B, hipStream_t st);
 
-// ---- device-resident conelp loop, LP cone (conelp_ipm.hip) --------------------------------------------
+// ---- device-resident conelp loop, 'l' + 'q' cones (conelp_ipm.hip) ---------------------------------------
 enum LpScalar {
     LP_TAU = 0, LP_KAPPA, LP_DG, LP_DGI, LP_LG, LP_RT, LP_GAP, LP_SIGMA, LP_STEP, LP_MU, LP_DTAU, LP_DKAPPA, LP_WKAPPA3,
     LP_TT, LP_TK, LP_TS, LP_TZ, LP_RESX0, LP_RESY0, LP_RESZ0, LP_Z1Z1, LP_PCOST, LP_DCOST, LP_RELGAP, LP_PRES, LP_DRES,
-    LP_PINFRES, LP_DINFRES, LP_GAP_OUT, LP_NSC
+    LP_PINFRES, LP_DINFRES, LP_GAP_OUT, LP_WTAU, LP_WKAPPA, LP_WTAU2, LP_WKAPPA2, LP_NSC
 };
+struct LpBuf { double *x, *y, *z, *s; int itau, ikappa; };   // one (x, y, z, tau, s, kappa) sextuple of f6 / res
 struct LpState {
-    int n = 0, m = 0, p = 0;
+    int n = 0, m = 0, p = 0, ml = 0, nq = 0;          // m = ml + sum(q)
+    const int *qoff = nullptr, *qdim = nullptr;       // per cone: offset into the cone vectors, dimension
     double *c = nullptr, *x = nullptr, *dx = nullptr, *rx = nullptr, *x1 = nullptr, *GTz = nullptr, *ATy = nullptr,
-           *x_out = nullptr;                                                         // [B][n]
-    double *b = nullptr, *y = nullptr, *dy = nullptr, *ry = nullptr, *y1 = nullptr, *Ax = nullptr, *y_out = nullptr;   // [B][p]
+           *x_out = nullptr, *wx = nullptr, *wx2 = nullptr;                          // [n]
+    double *b = nullptr, *y = nullptr, *dy = nullptr, *ry = nullptr, *y1 = nullptr, *Ax = nullptr, *y_out = nullptr,
+           *wy = nullptr, *wy2 = nullptr;                                            // [p]
     double *h = nullptr, *s = nullptr, *z = nullptr, *ds = nullptr, *dz = nullptr, *rz = nullptr, *z1 = nullptr, *th = nullptr,
-           *lmbda = nullptr, *d = nullptr, *di = nullptr, *ws3 = nullptr, *Gx = nullptr, *s_out = nullptr,
-           *z_out = nullptr;                                                         // [B][m]
-    double* sc = nullptr;                                                            // [B][LP_NSC]
+           *lmbda = nullptr, *lmbdasq = nullptr, *d = nullptr, *di = nullptr, *ws3 = nullptr, *Gx = nullptr, *s_out = nullptr,
+           *z_out = nullptr, *t1 = nullptr, *t2 = nullptr, *wz3 = nullptr, *ws = nullptr, *wz = nullptr, *ws2 = nullptr,
+           *wz2 = nullptr;                                                           // [m]
+    double *v = nullptr, *beta = nullptr;             // W['v'] concatenated [sum(q)], W['beta'] [nq]
+    double* sc = nullptr;                             // [LP_NSC]
     int *active = nullptr, *status = nullptr, *iters = nullptr, *init_optimal = nullptr, *nactive = nullptr;
 };
-void lp_launch_init_primal(const LpState& S, int B, hipStream_t st);
-void lp_launch_init_dual(const LpState& S, int B, double abstol, double reltol, hipStream_t st);
-void lp_launch_residual(const LpState& S, int B, int it, int maxiters, double abstol, double reltol, double feastol,
-                        hipStream_t st);
-void lp_launch_singular(const LpState& S, int B, const int* d_info, int it, hipStream_t st);
-void lp_launch_scale1(const LpState& S, int B, hipStream_t st);
-void lp_launch_rhs(const LpState& S, int B, int i01, hipStream_t st);
-void lp_launch_post(const LpState& S, int B, int i01, hipStream_t st);
-void lp_launch_update(const LpState& S, int B, hipStream_t st);
+void lp_launch_unit_scaling(const LpState& S, hipStream_t st);
+void lp_launch_init_primal(const LpState& S, hipStream_t st);
+void lp_launch_init_dual(const LpState& S, double abstol, double reltol, hipStream_t st);
+void lp_launch_residual(const LpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st);
+void lp_launch_singular(const LpState& S, const int* d_info, int it, hipStream_t st);
+void lp_launch_scale1(const LpState& S, hipStream_t st);
+void lp_launch_build(const LpState& S, const LpBuf& D, const LpBuf& W, int i01, int save, hipStream_t st);
+void lp_launch_copy(const LpState& S, const LpBuf& dst, const LpBuf& src, hipStream_t st);
+void lp_launch_add(const LpState& S, const LpBuf& dst, const LpBuf& src, hipStream_t st);
+void lp_launch_f6pre(const LpState& S, const LpBuf& X, hipStream_t st);
+void lp_launch_f6post(const LpState& S, const LpBuf& X, hipStream_t st);
+void lp_launch_res_a(const LpState& S, const LpBuf& U, hipStream_t st);
+void lp_launch_res_b(const LpState& S, const LpBuf& U, const LpBuf& V, hipStream_t st);
+void lp_launch_step(const LpState& S, const LpBuf& D, int i01, hipStream_t st);
+void lp_launch_update(const LpState& S, const LpBuf& D, hipStream_t st);
 
 }  // namespace mi355kkt

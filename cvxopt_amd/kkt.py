@@ -318,12 +318,12 @@ class _Engine(object):
                 'gap': g, 'relative gap': relgap, 'primal objective': pcost, 'dual objective': dcost,
                 'iterations': iters.value}
 
-    def conelp(self, c, h, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):
-        """The reference conelp loop (coneprog.py:586-1436; LP cone, default starting point) resident on the device
-        around this handle (`mi355kkt_conelp_lp`).  Returns a dict with the reference's keys and conventions
+    def conelp(self, c, h, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None):
+        """The reference conelp loop (coneprog.py:586-1436; 'l' and 'q' cones, default starting point) resident on the
+        device around this handle (`mi355kkt_conelp`).  Returns a dict with the reference's keys and conventions
         (None entries for the infeasibility-certificate cases), vectors as NumPy arrays."""
-        if self.dims['q'] or self.dims['s']:
-            raise NotImplementedError("device-resident conelp: LP cone only")
+        if self.dims['s']:
+            raise NotImplementedError("device-resident conelp: 'l' and 'q' cones only (use cvxopt_amd.solvers.conelp)")
         self._set_H(None)
         n, m, p = self.n, self.cdim, self.p
         if p > n or p + m < n:
@@ -336,13 +336,21 @@ class _Engine(object):
         x, y, s, z = np.zeros(n), np.zeros(p), np.zeros(m), np.zeros(m)
         status, iters = C.c_int(0), C.c_int(0)
         st = (C.c_double * 10)()
-        rc = self.L.mi355kkt_conelp_lp(self.h, _ptr(cv), _ptr(hv), _ptr(bv), int(maxiters), float(abstol), float(reltol),
-                                       float(feastol), _ptr(x), _ptr(y), _ptr(s), _ptr(z), C.byref(status),
-                                       C.byref(iters), st)
+        rc = self.L.mi355kkt_conelp(self.h, _ptr(cv), _ptr(hv), _ptr(bv), int(maxiters), float(abstol), float(reltol),
+                                    float(feastol), -1 if refinement is None else int(refinement), _ptr(x), _ptr(y),
+                                    _ptr(s), _ptr(z), C.byref(status), C.byref(iters), st)
         if rc == 1:
             raise ValueError("Rank(A) < p or Rank([G; A]) < n")           # coneprog.py:690-691
-        _capi.check(rc, "mi355kkt_conelp_lp")
+        _capi.check(rc, "mi355kkt_conelp")
         none = lambda v: None if v >= 1e299 else v
+
+        def slack(v):                               # -max_step(v): min over the 'l' entries and v0 - ||v1|| per cone
+            t = [float(np.min(v[:self.dims['l']]))] if self.dims['l'] else []
+            ind = self.dims['l']
+            for mk in self.dims['q']:
+                t.append(float(v[ind] - np.linalg.norm(v[ind + 1:ind + mk])))
+                ind += mk
+            return min(t) if t else 0.0
         gap, relgap, pcost, dcost, pres, dres, pinf, dinf, ts, tz = [float(v) for v in st]
         code = status.value
         out = {'iterations': iters.value}
@@ -350,21 +358,21 @@ class _Engine(object):
             out.update({'x': x, 'y': y, 's': s, 'z': z, 'status': 'optimal' if code == 1 else 'unknown', 'gap': gap,
                         'relative gap': none(relgap), 'primal objective': pcost, 'dual objective': dcost,
                         'primal infeasibility': pres, 'dual infeasibility': dres,
-                        'primal slack': float(np.min(s)) if m else 0.0, 'dual slack': float(np.min(z)) if m else 0.0,
+                        'primal slack': slack(s), 'dual slack': slack(z),
                         'residual as primal infeasibility certificate': None if code == 1 else none(pinf),
                         'residual as dual infeasibility certificate': None if code == 1 else none(dinf)})
         elif code == 4:
             out.update({'x': None, 'y': y, 's': None, 'z': z, 'status': 'primal infeasible', 'gap': None,
                         'relative gap': None, 'primal objective': None, 'dual objective': 1.0,
                         'primal infeasibility': None, 'dual infeasibility': None, 'primal slack': None,
-                        'dual slack': float(np.min(z)) if m else 0.0,
+                        'dual slack': slack(z),
                         'residual as primal infeasibility certificate': pinf,
                         'residual as dual infeasibility certificate': None})
         else:
             out.update({'x': x, 'y': None, 's': s, 'z': None, 'status': 'dual infeasible', 'gap': None,
                         'relative gap': None, 'primal objective': -1.0, 'dual objective': None,
                         'primal infeasibility': None, 'dual infeasibility': None,
-                        'primal slack': float(np.min(s)) if m else 0.0, 'dual slack': None,
+                        'primal slack': slack(s), 'dual slack': None,
                         'residual as primal infeasibility certificate': None,
                         'residual as dual infeasibility certificate': dinf})
         return out
@@ -385,16 +393,28 @@ def _factory(kind, G, dims, A, mnl=0, kktreg=None):
     return factor
 
 
-def conelp_lp(c, G, h, A=None, b=None, kktsolver='chol', maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):
-    """min c'x  s.t.  Gx <= h, Ax = b  (`solvers.lp` / `solvers.conelp` with dims = {'l': m}) with the whole
-    self-dual interior-point loop on the MI355X.  Iterates match `solvers.conelp(c, G, h[, A=A, b=b])`."""
+def conelp_device(c, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters=100, abstol=1e-7, reltol=1e-6,
+                  feastol=1e-7, refinement=None):
+    """min c'x  s.t.  Gx <=_K h, Ax = b,  K = R^l_+ x second-order cones (`solvers.conelp` / `lp` / `socp`) with the whole
+    self-dual interior-point loop on the MI355X.  Iterates match `solvers.conelp(c, G, h, dims[, A=A, b=b])`."""
     kind = {'chol2': _capi.CHOL2, 'chol': _capi.CHOL, 'ldl': _capi.LDL, 'ldl2': _capi.LDL2, 'qr': _capi.CHOL}[kktsolver]
     m, n = _size(G)
-    eng = _Engine(kind, G, {'l': m, 'q': [], 's': []}, A if A is not None else _EmptyA(n))
+    if dims is None:
+        dims = {'l': m, 'q': [], 's': []}
+    dims = {'l': int(dims['l']), 'q': [int(k) for k in dims['q']], 's': [int(k) for k in dims['s']]}
+    if kind == _capi.CHOL2 and dims['q']:
+        kind = _capi.CHOL
+    eng = _Engine(kind, G, dims, A if A is not None else _EmptyA(n))
     try:
-        return eng.conelp(c, h, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol)
+        return eng.conelp(c, h, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol,
+                          refinement=refinement)
     finally:
         eng.close()
+
+
+def conelp_lp(c, G, h, A=None, b=None, **kw):
+    """LP-cone form of `conelp_device` (`solvers.lp`)."""
+    return conelp_device(c, G, h, None, A, b, **kw)
 
 
 def coneqp_lp(P, q, G, h, A=None, b=None, kktsolver='chol2', maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):

@@ -145,16 +145,17 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* h, const double* q, const double* hv, co
                        double abstol, double reltol, double feastol, double* x, double* y, double* s, double* z, int* status,
                        int* iters, double* pcost, double* dcost, double* gap);
 
-/* The conelp loop (coneprog.py:586-1436: self-dual embedding, default starting point, LP cone => no refinement) for
- * dims = {'l': ml} around this handle (no H; equality constraints with the dense engine).  c: n, hv: ml, bv: p (host).
+/* The conelp loop (coneprog.py:586-1436: self-dual embedding, default starting point) for dims = {'l': ml, 'q': [...]}
+ * around this handle (no H; equality constraints with the dense engine).  refinement < 0: the reference's default
+ * (0 for the LP cone, 1 with second-order cones, :502-507).  c: n, hv: cdim, bv: p (host).
  * Outputs (host): x, y, s, z scaled like the reference's return values; *status: 1 optimal, 2 unknown (iteration limit),
  * 3 unknown (singular KKT matrix), 4 primal infeasible (y, z = certificate), 5 dual infeasible (x, s = certificate);
  * stats[10] = gap, relative gap, primal objective, dual objective, primal / dual infeasibility, residual as primal /
  * dual infeasibility certificate, ts, tz of the starting point (1e300 stands for the reference's None).
  * Returns 0; <0 on error; 1 if the initial factorisation failed (the ValueError of coneprog.py:690-691). */
-int mi355kkt_conelp_lp(mi355kkt_solver* h, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
-                       double reltol, double feastol, double* x, double* y, double* s, double* z, int* status, int* iters,
-                       double* stats);
+int mi355kkt_conelp(mi355kkt_solver* h, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
+                    double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
+                    int* iters, double* stats);
 
 /* ---- batched mode: nbatch independent dense LP-cone problems of one shape (BASELINE configs[4]) ---------
  * No reference API exists for this; per problem it is exactly factor()/solve() of the

@@ -229,3 +229,44 @@ def test_resident_conelp_large_lp_optimality_conditions():
     assert abs(c @ x - sol['primal objective']) <= 1e-9 * max(1.0, abs(c @ x))
     assert abs(-(h @ z) - sol['dual objective']) <= 1e-9 * max(1.0, abs(h @ z))
     assert abs(sol['primal objective'] - sol['dual objective']) <= 1e-6 * max(1.0, abs(sol['primal objective']))
+
+
+# ---- conelp resident on the device with second-order cones (refinement 1, hyperbolic Householder scalings) ------
+@pytest.mark.parametrize("n,ncones,r,ml,p", [(24, 6, 5, 0, 0), (60, 20, 4, 15, 0), (96, 48, 8, 10, 7), (50, 3, 30, 0, 0)])
+def test_resident_conelp_socp_matches_reference_driver(ref_cvxopt, n, ncones, r, ml, p):
+    from cvxopt import matrix, solvers
+    pr = synth.socp(n=n, ncones=ncones, r=r, seed=n + ncones, ml=ml)
+    rng = np.random.default_rng(p + 1)
+    kw, kwd = {}, {}
+    if p:
+        A = rng.standard_normal((p, n))
+        xf = np.linalg.lstsq(pr['G'], pr['h'], rcond=None)[0] * 0.0
+        b = A @ xf                                  # x = 0 direction: h = G x0 + s0 with interior s0, keep it simple
+        kw, kwd = dict(A=matrix(A), b=matrix(b)), dict(A=A, b=b)
+    ref = solvers.conelp(matrix(pr['c']), matrix(pr['G']), matrix(pr['h']), pr['dims'], **kw)
+    sol = cvxopt_amd.conelp_device(pr['c'], pr['G'], pr['h'], pr['dims'], **kwd)
+    assert sol['status'] == ref['status']
+    assert sol['iterations'] == ref['iterations']
+    if ref['status'] == 'optimal':
+        for k in ('primal objective', 'dual objective'):
+            assert abs(sol[k] - ref[k]) <= 1e-8 * max(1.0, abs(ref[k])), k
+        assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-6
+        assert relerr(sol['s'], np.array(ref['s']).ravel()) < 1e-5
+        assert relerr(sol['z'], np.array(ref['z']).ravel()) < 1e-5
+        assert abs(sol['primal slack'] - ref['primal slack']) <= 1e-4 * abs(ref['primal slack']) + 1e-9
+
+
+def test_resident_conelp_socp_config3_full_size(ref_cvxopt):
+    """BASELINE configs[2]: n=2048, 1024 cones of dimension 8; vs the reference driver with the GPU kktsolver + device
+    operators (same iterates as the CPU reference, tests/test_gpu_solvers.py)."""
+    from cvxopt import matrix
+    import cvxopt_amd.solvers as gs
+    pr = synth.socp(n=2048, ncones=1024, r=8, seed=0)
+    t = time.perf_counter()
+    sol = cvxopt_amd.conelp_device(pr['c'], pr['G'], pr['h'], pr['dims'])
+    t = time.perf_counter() - t
+    ref = gs.conelp(matrix(pr['c']), matrix(pr['G']), matrix(pr['h']), pr['dims'])
+    print("resident conelp, config 3: %.3f s wall incl. upload, %d iterations" % (t, sol['iterations']))
+    assert sol['status'] == ref['status'] == 'optimal' and sol['iterations'] == ref['iterations']
+    assert abs(sol['primal objective'] - ref['primal objective']) <= 1e-8 * max(1.0, abs(ref['primal objective']))
+    assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-6
