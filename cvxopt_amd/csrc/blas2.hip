@@ -348,6 +348,35 @@ __global__ __launch_bounds__(64) void trsv_diag_bwd_kernel(const double* __restr
 }
 
 // ===================================================================================================
+// A(upper) := A(lower)': the backward solve then streams L' with the same coalesced row-of-a-block-row pattern as the
+// forward solve streams L (32 x 32 tiles through LDS; diagonal tiles mirror themselves).
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ A, int64_t lda, int n) {
+    __shared__ double t[32][33];
+    const int bi = blockIdx.x, bj = blockIdx.y;
+    if (bj > bi) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int i0 = bi * 32, j0 = bj * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = i0 + tx, j = j0 + ty + 8 * r;
+        t[ty + 8 * r][tx] = (i < n && j < n) ? A[i + (int64_t)j * lda] : 0.0;     // t[jl][il] = A[i][j]
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // write A[j0 + tx][i0 + ty + 8r] = A_lower[i0 + ty + 8r][j0 + tx] = t[tx][ty + 8r]
+        const int jr = j0 + tx, ic = i0 + ty + 8 * r;
+        if (jr < n && ic < n && ic > jr) A[jr + (int64_t)ic * lda] = t[tx][ty + 8 * r];
+    }
+}
+int launch_mirror_lower(double* A, int64_t lda, int n, hipStream_t st) {
+    if (n <= 1) return 0;
+    const int nb = (n + 31) / 32;
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb, nb), dim3(256), 0, st, A, lda, n);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // Persistent single-launch triangular solve (one right-hand side): workgroup k owns block row k (forward)
 // or block column k (backward) of the 128-blocked factor, streams its off-diagonal blocks while it waits
 // for the x blocks it depends on, solves its diagonal block inside the workgroup and publishes x_k.
@@ -412,12 +441,12 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
     } else {
         if (wave == 1) {   // columns 64..127: column of L22 (solved first)
 #pragma unroll
-            for (int j = 0; j < 64; ++j) ra[j] = (j > lane && j < n1) ? Lkk[64 + j + (int64_t)(64 + lane) * ldl] : 0.0;
+            for (int j = 0; j < 64; ++j) ra[j] = (j > lane && j < n1) ? Lkk[64 + lane + (int64_t)(64 + j) * ldl] : 0.0;
         } else if (wave == 0) {   // columns 0..63: column of L21 (ra) and of L11 (rb)
 #pragma unroll
-            for (int j = 0; j < 64; ++j) ra[j] = (j < n1 && lane < n0) ? Lkk[64 + j + (int64_t)lane * ldl] : 0.0;
+            for (int j = 0; j < 64; ++j) ra[j] = (j < n1 && lane < n0) ? Lkk[lane + (int64_t)(64 + j) * ldl] : 0.0;
 #pragma unroll
-            for (int j = 0; j < 64; ++j) rb[j] = (j > lane && j < n0) ? Lkk[j + (int64_t)lane * ldl] : 0.0;
+            for (int j = 0; j < 64; ++j) rb[j] = (j > lane && j < n0) ? Lkk[lane + (int64_t)j * ldl] : 0.0;
         }
     }
     const int dpos = (wave == 0) ? lane : 64 + lane;
@@ -436,7 +465,8 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
             for (int c = 0; c < 64; ++c) l0[c] = (mine && ch + c < jb) ? L[idx + (int64_t)(j0 + ch + c) * ldl] : 0.0;
         } else {
 #pragma unroll
-            for (int c = 0; c < 64; ++c) l0[c] = (mine && ch + c < jb) ? L[j0 + ch + c + (int64_t)idx * ldl] : 0.0;
+            for (int c = 0; c < 64; ++c) l0[c] = (mine && ch + c < jb) ? L[idx + (int64_t)(j0 + ch + c) * ldl] : 0.0;   // mirrored L'
+
         }
         if (tid == 0) ok = wait_flag(flags + j, epoch, err) ? 1 : 0;
         __syncthreads();

@@ -611,6 +611,9 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
         if (h->kktreg != 0.0) hipLaunchKernelGGL(diag_add_kernel, g1(h->p), dim3(256), 0, h->st, h->dK, (int64_t)h->p, h->p, h->kktreg);
         if (int e = launch_potrf(h->dK, h->p, h->p, h->pw, h->st)) return e;
     }
+    // L' into the (otherwise unused) upper triangle of S: the transposed persistent solve streams it coalesced
+    if ((h->n + 127) / 128 <= h->num_cus && !getenv("MI355KKT_NO_PERSISTENT_TRSV"))
+        if (int e = launch_mirror_lower(h->dS, h->n, h->n, h->st)) return e;
     KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
     if (int e = fetch_info(h, &info)) return e;
     (void)hipEventElapsedTime(&h->t_syrk, h->ev[0], h->ev[1]);

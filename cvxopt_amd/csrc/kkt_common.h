@@ -109,6 +109,9 @@ int launch_gemv_n_scaled(const double* G, int64_t ldg, int m, int n, const doubl
 size_t gemv_work_doubles(int m, int n);
 // single right-hand side, single launch (needs ceil(n/128) co-resident workgroups: callers check against #CUs);
 // flags: ceil(n/128) words zeroed once at allocation, epoch: a fresh non-zero value per launch, err: device int
+// copies the strictly lower triangle, transposed, into the strictly upper triangle (needed by the transposed persistent solve)
+int launch_mirror_lower(double* A, int64_t lda, int n, hipStream_t st);
+// trans != 0 solves L' x = b and REQUIRES the mirrored upper triangle (launch_mirror_lower after the factorisation)
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
                            unsigned int epoch, int* err, hipStream_t st);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
