@@ -14,7 +14,7 @@ include/mi355kkt.h).  There is no CPU fallback: importing works everywhere, but 
 without the library or without a GPU raises.
 """
 from .kkt import (kkt_chol, kkt_chol2, kkt_ldl, kkt_ldl2, kkt_qr, install, uninstall,   # noqa: F401
-                  kktsolver_qp, kktsolver_lp, coneqp_lp, conelp_lp, conelp_device)
+                  kktsolver_qp, kktsolver_lp, coneqp_lp, conelp_lp, conelp_device, coneqp_device)
 from . import synth   # noqa: F401
 
 __version__ = "0.1.0"

@@ -169,6 +169,53 @@ static int lp_alloc(LpWork& w, int n, int ml, const std::vector<int>& q, int np)
     return 0;
 }
 
+struct QpWork {
+    QpState S;
+    double* f64 = nullptr;
+    int* i32 = nullptr;       // active | status | iters | nactive | info | - | - | - | qoff[nq] | qdim[nq]
+    int* pinned = nullptr;
+};
+static void qp_free(QpWork& w) {
+    if (w.f64) (void)hipFree(w.f64);
+    if (w.i32) (void)hipFree(w.i32);
+    if (w.pinned) (void)hipHostFree(w.pinned);
+    w = QpWork();
+}
+static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, int np) {
+    if (w.f64) return 0;
+    int sumq = 0;
+    for (int k : q) sumq += k;
+    const int m = ml + sumq, nq = (int)q.size();
+    const size_t N = n ? n : 1, M = m ? m : 1, Pq = np ? np : 1;
+    const size_t nd = 10 * N + 8 * Pq + 21 * M + (size_t)sumq + nq + QP_NSC + 8;
+    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
+    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq)) != hipSuccess) return MI355KKT_ENOMEM;
+    if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
+    QpState& S = w.S;
+    S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq;
+    double* p = w.f64;
+    auto take = [&](size_t k) { double* r = p; p += k; return r; };
+    S.q = take(N); S.x = take(N); S.dx = take(N); S.rx = take(N); S.Px = take(N); S.GTz = take(N); S.ATy = take(N); S.x_out = take(N);
+    S.wx = take(N); S.wx2 = take(N);
+    S.b = take(Pq); S.y = take(Pq); S.dy = take(Pq); S.ry = take(Pq); S.Ax = take(Pq); S.y_out = take(Pq); S.wy = take(Pq);
+    S.wy2 = take(Pq);
+    S.h = take(M); S.s = take(M); S.z = take(M); S.ds = take(M); S.dz = take(M); S.rz = take(M); S.lmbda = take(M);
+    S.lmbdasq = take(M); S.d = take(M); S.di = take(M); S.ws3 = take(M); S.Gx = take(M); S.s_out = take(M); S.z_out = take(M);
+    S.t1 = take(M); S.t2 = take(M); S.wz3 = take(M); S.ws = take(M); S.wz = take(M); S.ws2 = take(M); S.wz2 = take(M);
+    S.v = take(sumq ? sumq : 1); S.beta = take(nq ? nq : 1);
+    S.sc = take(QP_NSC);
+    int* qi = w.i32;
+    S.active = qi; S.status = qi + 1; S.iters = qi + 2; S.nactive = qi + 3;
+    if (nq) {
+        std::vector<int> hq(2 * (size_t)nq);
+        int off = ml;
+        for (int k = 0; k < nq; ++k) { hq[k] = off; hq[nq + k] = q[k]; off += q[k]; }
+        if (hipMemcpy(qi + 8, hq.data(), sizeof(int) * 2 * nq, hipMemcpyHostToDevice) != hipSuccess) return MI355KKT_EHIP;
+    }
+    S.qoff = qi + 8; S.qdim = qi + 8 + nq;
+    return 0;
+}
+
 struct mi355kkt_solver {
     int device = 0, kind = 0;
     int n = 0, p = 0, ml = 0, cdim = 0;
@@ -211,7 +258,8 @@ struct mi355kkt_solver {
     PotrfWork pw;
     float t_syrk = 0, t_potrf = 0, t_schur = 0, t_factor = 0, t_solve = 0, t_syrk_kernel = 0;
     IpmWork ipm;               // device-resident coneqp loop (mi355kkt_coneqp_lp), allocated on first use
-    LpWork lp;                 // device-resident conelp loop (mi355kkt_conelp_lp)
+    LpWork lp;                 // device-resident conelp loop (mi355kkt_conelp)
+    QpWork qp;                 // device-resident coneqp loop with second-order cones (mi355kkt_coneqp)
     double* dHsym = nullptr;   // full symmetric copy of H for the residual product P x
     bool hsym_valid = false;
     double* dIpmWork = nullptr;
@@ -376,6 +424,7 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     sparse_engine_free(h->sp);
     ipm_free(h->ipm);
     lp_free(h->lp);
+    qp_free(h->qp);
     if (h->dHsym) (void)hipFree(h->dHsym);
     if (h->dIpmWork) (void)hipFree(h->dIpmWork);
     if (h->dflags) (void)hipFree(h->dflags);
@@ -1291,6 +1340,124 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
         stats[4] = hsc[LP_PRES]; stats[5] = hsc[LP_DRES]; stats[6] = hsc[LP_PINFRES]; stats[7] = hsc[LP_DINFRES];
         stats[8] = hsc[LP_TS]; stats[9] = hsc[LP_TZ];
         if (*iters == 0 && *status == 1 && hsc[LP_GAP_OUT] == 0.0) stats[0] = hsc[LP_GAP];   // optimal starting point
+    }
+    return 0;
+}
+
+/* Single problem, 'l' + 'q' cones: the coneqp loop of coneprog.py:2044-2547 (refinement 0 for the LP cone, 1 with
+ * second-order cones, :1862-1865) resident on the device around this handle's factor/solve.  See include/mi355kkt.h. */
+int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, const double* bv, int maxiters, double abstol,
+                    double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
+                    int* iters, double* stats) {
+    if (!hs || !q || !hv || !x || !s || !z || !status || !iters || (hs->p > 0 && (!bv || !y))) {
+        set_last_error("coneqp: null argument");
+        return MI355KKT_EINVAL;
+    }
+    if (!hs->s.empty() || hs->cdim < 1) { set_last_error("coneqp: needs dims = {'l': ml, 'q': [...]} with at least one row"); return MI355KKT_ENOTIMPL; }
+    if (hs->sparse && hs->p > 0) { set_last_error("coneqp: equality constraints need the dense engine"); return MI355KKT_ENOTIMPL; }
+    if (hs->p > 0 && !hs->dA) { set_last_error("coneqp: A not set"); return MI355KKT_EINVAL; }
+    if (int e = bind(hs)) return e;
+    const int n = hs->n, m = hs->cdim, np = hs->p;
+    if (refinement < 0) refinement = hs->q.empty() ? 0 : 1;
+    if (int e = qp_alloc(hs->qp, n, hs->ml, hs->q, np)) return e;
+    QpWork& w = hs->qp;
+    const QpState& S = w.S;
+    hipStream_t st = hs->st;
+    if (int e = ensure_gemv_work(hs)) return e;
+    if (int e = ensure_hsym(hs)) return e;
+    double* gwork = hs->dIpmWork;
+    int* d_info = w.i32 + 4;
+    // P xin -> Px, G xin -> Gx, A xin -> Ax, G' zin -> GTz, A' yin -> ATy
+    auto products = [&](const double* xin, const double* yin, const double* zin) -> int {
+        if (hs->sparse) return sparse_engine_products(hs->sp, xin, zin, S.Gx, S.GTz, S.Px, st);
+        if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, xin, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
+        KKT_HIP_CHECK(hipMemsetAsync(S.GTz, 0, sizeof(double) * n, st));
+        if (int e = launch_gemv_t_scaled(hs->dG, hs->ldG, m, n, nullptr, zin, hs->dzs, S.GTz, gwork, st)) return e;
+        if (hs->dH) {
+            if (int e = launch_gemv_n_scaled(hs->dHsym, n, n, n, nullptr, xin, S.Px, S.Px, 1.0, 0.0, gwork, st)) return e;
+        } else {
+            KKT_HIP_CHECK(hipMemsetAsync(S.Px, 0, sizeof(double) * n, st));
+        }
+        if (np > 0) {
+            if (int e = launch_gemv_n_scaled(hs->dA, hs->ldA, np, n, nullptr, xin, S.Ax, S.Ax, 1.0, 0.0, gwork, st)) return e;
+            KKT_HIP_CHECK(hipMemsetAsync(S.ATy, 0, sizeof(double) * n, st));
+            if (int e = launch_gemv_t_scaled(hs->dA, hs->ldA, np, n, nullptr, yin, hs->dtp, S.ATy, gwork, st)) return e;
+        }
+        return 0;
+    };
+    auto factor = [&](int* info_out) -> int {
+        mi355kkt_scaling W = {};
+        W.di = S.di; W.d = S.d; W.v = S.v; W.beta = S.beta;
+        const int info = mi355kkt_factor_device(hs, &W);
+        if (info < 0) return info;
+        *info_out = info;
+        w.pinned[1] = info;
+        KKT_HIP_CHECK(hipMemcpyAsync(d_info, w.pinned + 1, sizeof(int), hipMemcpyHostToDevice, st));
+        if (info > 0) hs->factored = true;
+        return 0;
+    };
+    auto solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_solve_device(hs, dx, dy, dz); };
+    const QpBuf D{S.dx, S.dy, S.dz, S.ds};
+    const QpBuf Wsave{S.wx, S.wy, S.wz, S.ws};
+    const QpBuf W2{S.wx2, S.wy2, S.wz2, S.ws2};
+    KKT_HIP_CHECK(hipMemcpyAsync(S.q, q, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.h, hv, sizeof(double) * m, hipMemcpyHostToDevice, st));
+    if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bv, sizeof(double) * np, hipMemcpyHostToDevice, st));
+    KKT_HIP_CHECK(hipMemsetAsync(w.i32, 0, sizeof(int) * 8, st));
+    KKT_HIP_CHECK(hipMemsetAsync(S.sc, 0, sizeof(double) * QP_NSC, st));
+    // ---- starting point with W = I (coneprog.py:2054-2106)
+    qp_launch_unit_scaling(S, st);
+    int info = 0;
+    if (int e = factor(&info)) return e;
+    if (info > 0) { set_last_error("coneqp: Rank(A) < p or Rank([P; A; G]) < n"); return 1; }
+    hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S.x, S.q, -1.0, (int64_t)n);
+    if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.y, S.b, sizeof(double) * np, hipMemcpyDeviceToDevice, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.z, S.h, sizeof(double) * m, hipMemcpyDeviceToDevice, st));
+    if (int e = solve(S.x, S.y, S.z)) return e;
+    qp_launch_start(S, st);
+    int it = 0;
+    for (; it <= maxiters; ++it) {
+        if (int e = products(S.x, S.y, S.z)) return e;
+        KKT_HIP_CHECK(hipMemsetAsync(S.nactive, 0, sizeof(int), st));
+        qp_launch_residual(S, it, maxiters, abstol, reltol, feastol, st);
+        KKT_HIP_CHECK(hipMemcpyAsync(w.pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
+        KKT_HIP_CHECK(hipStreamSynchronize(st));
+        if (w.pinned[0] == 0) break;
+        if (int e = factor(&info)) return e;
+        if (info > 0 && it == 0) { set_last_error("coneqp: Rank(A) < p or Rank([P; A; G]) < n"); return 1; }
+        qp_launch_singular(S, d_info, it, st);
+        if (info > 0) break;
+        for (int i01 = 0; i01 < 2; ++i01) {
+            qp_launch_build(S, D, Wsave, i01, refinement > 0 ? 1 : 0, st);
+            qp_launch_f4pre(S, D, st);
+            if (int e = solve(D.x, D.y, D.z)) return e;
+            qp_launch_f4post(S, D, st);
+            for (int r = 0; r < refinement; ++r) {                       // coneprog.py:2330-2345
+                qp_launch_copy(S, W2, Wsave, st);
+                qp_launch_res_a(S, D, st);
+                if (int e = products(D.x, D.y, S.wz3)) return e;
+                qp_launch_res_b(S, D, W2, st);
+                qp_launch_f4pre(S, W2, st);
+                if (int e = solve(W2.x, W2.y, W2.z)) return e;
+                qp_launch_f4post(S, W2, st);
+                qp_launch_add(S, D, W2, st);
+            }
+            qp_launch_step(S, D, i01, st);
+        }
+        qp_launch_update(S, D, st);
+    }
+    KKT_HIP_CHECK(hipMemcpyAsync(x, S.x_out, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(y, S.y_out, sizeof(double) * np, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(s, S.s_out, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(z, S.z_out, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(status, S.status, sizeof(int), hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(iters, S.iters, sizeof(int), hipMemcpyDeviceToHost, st));
+    double hsc[QP_NSC];
+    KKT_HIP_CHECK(hipMemcpyAsync(hsc, S.sc, sizeof(double) * QP_NSC, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipStreamSynchronize(st));
+    if (stats) {   // gap, relative gap (1e300 = None), pcost, dcost, pres, dres
+        stats[0] = hsc[QP_GAP_OUT]; stats[1] = hsc[QP_RELGAP]; stats[2] = hsc[QP_PCOST]; stats[3] = hsc[QP_DCOST];
+        stats[4] = hsc[QP_PRES]; stats[5] = hsc[QP_DRES];
     }
     return 0;
 }

@@ -14,135 +14,9 @@
 //     lp_update_kernel        :1335-1432 + misc.py:444-464, :503-573   iterate, scaling, tau / kappa update
 // and the cone-vector operations sprod, sinv, ssqr, scale2, max_step, scale (src/C/misc_solvers.c:634, :775, :256, :1052,
 // :85; misc.py:945) for the 'l' and 'q' blocks.
-#include "kkt_common.h"
+#include "cone_ops.h"
 
 namespace mi355kkt {
-
-__device__ __forceinline__ double lp_block_sum(double v, double* sh) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) sh[w] = v;
-    __syncthreads();
-    return sh[0] + sh[1] + sh[2] + sh[3];
-}
-__device__ __forceinline__ double lp_block_max(double v, double* sh) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) sh[w] = v;
-    __syncthreads();
-    return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
-}
-__device__ __forceinline__ double lp_dot(const double* a, const double* b, int n, double* sh) {
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) v += a[i] * b[i];
-    return lp_block_sum(v, sh);
-}
-
-// ---- second-order-cone pieces, one cone (x: the cone's own entries, mk of them) -----------------------------
-__device__ __forceinline__ double q_nrm1(const double* x, int mk) {      // ||x[1:]||
-    double a = 0.0;
-    for (int i = 1; i < mk; ++i) a += x[i] * x[i];
-    return sqrt(a);
-}
-__device__ __forceinline__ double q_jnrm2(const double* x, int mk) {     // misc.py:848-857
-    const double a = q_nrm1(x, mk);
-    return sqrt(x[0] - a) * sqrt(x[0] + a);
-}
-__device__ __forceinline__ void q_sprod(double* x, const double* y, int mk) {           // x := x o y
-    double a = 0.0;
-    for (int i = 0; i < mk; ++i) a += y[i] * x[i];
-    const double x0 = x[0], y0 = y[0];
-    for (int i = 1; i < mk; ++i) x[i] = y0 * x[i] + x0 * y[i];
-    x[0] = a;
-}
-__device__ __forceinline__ void q_sinv(double* x, const double* y, int mk) {            // x := y o\ x
-    double a = q_nrm1(y, mk);
-    a = (y[0] + a) * (y[0] - a);
-    const double c = x[0];
-    double d = 0.0;
-    for (int i = 1; i < mk; ++i) d += x[i] * y[i];
-    const double x0 = c * y[0] - d;
-    const double al = a / y[0], be = d / y[0] - c, ia = 1.0 / a;
-    for (int i = 1; i < mk; ++i) x[i] = (al * x[i] + be * y[i]) * ia;
-    x[0] = x0 * ia;
-}
-__device__ __forceinline__ void q_ssqr(double* x, const double* y, int mk) {            // x := y o y
-    double a = 0.0;
-    for (int i = 0; i < mk; ++i) a += y[i] * y[i];
-    const double y0 = y[0];
-    for (int i = 1; i < mk; ++i) x[i] = 2.0 * y0 * y[i];
-    x[0] = a;
-}
-__device__ __forceinline__ void q_scale2(const double* l, double* x, int mk, bool inverse) {
-    double a = q_nrm1(l, mk);
-    a = sqrt(l[0] + a) * sqrt(l[0] - a);
-    double lx = 0.0;
-    if (!inverse) {
-        for (int i = 1; i < mk; ++i) lx += l[i] * x[i];
-        lx = (l[0] * x[0] - lx) / a;
-    } else {
-        for (int i = 0; i < mk; ++i) lx += l[i] * x[i];
-        lx = lx / a;
-    }
-    const double x0 = x[0];
-    double b = (x0 + lx) / (l[0] / a + 1.0) / a;
-    if (!inverse) b = -b;
-    const double sc = inverse ? a : 1.0 / a;
-    for (int i = 1; i < mk; ++i) x[i] = (x[i] + b * l[i]) * sc;
-    x[0] = lx * sc;
-}
-__device__ __forceinline__ void q_scale(double* x, const double* v, double beta, int mk, bool inverse) {   // W x / W^-1 x
-    double w = 0.0;
-    if (!inverse) {
-        for (int i = 0; i < mk; ++i) w += v[i] * x[i];
-        x[0] = beta * (2.0 * v[0] * w - x[0]);
-        for (int i = 1; i < mk; ++i) x[i] = beta * (x[i] + 2.0 * v[i] * w);
-    } else {
-        for (int i = 1; i < mk; ++i) w += v[i] * x[i];
-        w = v[0] * x[0] - w;
-        const double ib = 1.0 / beta;
-        x[0] = (2.0 * v[0] * w - x[0]) * ib;
-        for (int i = 1; i < mk; ++i) x[i] = (x[i] - 2.0 * v[i] * w) * ib;
-    }
-}
-
-// ---- whole cone vectors (l part strided over the workgroup, q part one cone per thread) -----------------------
-__device__ __forceinline__ double cv_maxstep(const LpState& S, const double* x, double* sh) {
-    double t = -1e300;
-    for (int i = threadIdx.x; i < S.ml; i += 256) t = fmax(t, -x[i]);
-    for (int k = threadIdx.x; k < S.nq; k += 256) t = fmax(t, q_nrm1(x + S.qoff[k], S.qdim[k]) - x[S.qoff[k]]);
-    return lp_block_max(t, sh);
-}
-__device__ __forceinline__ void cv_add_e(const LpState& S, double* x, double a) {
-    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] += a;
-    for (int k = threadIdx.x; k < S.nq; k += 256) x[S.qoff[k]] += a;
-}
-__device__ __forceinline__ void cv_sprod(const LpState& S, double* x, const double* y) {
-    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] *= y[i];
-    for (int k = threadIdx.x; k < S.nq; k += 256) q_sprod(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
-}
-__device__ __forceinline__ void cv_sinv(const LpState& S, double* x, const double* y) {
-    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] /= y[i];
-    for (int k = threadIdx.x; k < S.nq; k += 256) q_sinv(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
-}
-__device__ __forceinline__ void cv_ssqr(const LpState& S, double* x, const double* y) {
-    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] = y[i] * y[i];
-    for (int k = threadIdx.x; k < S.nq; k += 256) q_ssqr(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
-}
-__device__ __forceinline__ void cv_scale2(const LpState& S, const double* l, double* x, bool inverse) {
-    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] = inverse ? x[i] * l[i] : x[i] / l[i];
-    for (int k = threadIdx.x; k < S.nq; k += 256) q_scale2(l + S.qoff[k], x + S.qoff[k], S.qdim[k], inverse);
-}
-// x := W x (== W' x) or W^-1 x (== W^-T x): both symmetric for 'l' and 'q' blocks
-__device__ __forceinline__ void cv_scale(const LpState& S, double* x, bool inverse) {
-    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] = inverse ? x[i] / S.d[i] : x[i] * S.d[i];
-    for (int k = threadIdx.x; k < S.nq; k += 256)
-        q_scale(x + S.qoff[k], S.v + (S.qoff[k] - S.ml), S.beta[k], S.qdim[k], inverse);
-}
 
 // status codes: 1 optimal, 2 unknown (iteration limit), 3 unknown (singular KKT matrix), 4 primal infeasible,
 // 5 dual infeasible
@@ -310,36 +184,7 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
     }
     if (tid == 0) atomicAdd(S.nactive, 1);
     if (it == 0) {                                 // compute_scaling (misc.py:284-354); dg, lambda_g (:1026-1041)
-        for (int i = tid; i < S.ml; i += 256) {
-            S.d[i] = sqrt(S.s[i] / S.z[i]);
-            S.lmbda[i] = sqrt(S.s[i] * S.z[i]);
-        }
-        for (int k = tid; k < S.nq; k += 256) {
-            const int o = S.qoff[k], mk = S.qdim[k];
-            const double* sk = S.s + o;
-            const double* zk = S.z + o;
-            double* v = S.v + (o - S.ml);
-            double* lk = S.lmbda + o;
-            const double aa = q_jnrm2(sk, mk), bb = q_jnrm2(zk, mk);
-            S.beta[k] = sqrt(aa / bb);
-            double dsz = 0.0;
-            for (int i = 0; i < mk; ++i) dsz += sk[i] * zk[i];
-            const double cc = sqrt((dsz / aa / bb + 1.0) / 2.0);
-            // vk = 1/(2c) (sk/a + J zk/b);  then v = (vk + e) / sqrt(2 (vk0 + 1))
-            for (int i = 0; i < mk; ++i) {
-                double t = zk[i] * (-1.0 / bb);
-                if (i == 0) t = -t;
-                t += sk[i] * (1.0 / aa);
-                v[i] = t * (1.0 / 2.0 / cc);
-            }
-            v[0] += 1.0;
-            const double f = 1.0 / sqrt(2.0 * v[0]);
-            for (int i = 0; i < mk; ++i) v[i] *= f;
-            const double dd = 2.0 * cc + sk[0] / aa + zk[0] / bb;
-            const double fs = (cc + zk[0] / bb) / dd / aa, fz = (cc + sk[0] / aa) / dd / bb, sq = sqrt(aa * bb);
-            lk[0] = cc * sq;
-            for (int i = 1; i < mk; ++i) lk[i] = (sk[i] * fs + zk[i] * fz) * sq;
-        }
+        cv_compute_scaling(S, S.s, S.z, S.lmbda);
         if (tid == 0) {
             sc[LP_DG] = sqrt(kappa / tau);
             sc[LP_DGI] = sqrt(tau / kappa);
@@ -577,52 +422,7 @@ __global__ __launch_bounds__(256) void lp_update_kernel(LpState S, LpBuf D) {
     cv_scale2(S, S.lmbda, D.s, true);
     cv_scale2(S, S.lmbda, D.z, true);
     __syncthreads();
-    // update_scaling: 'l' (misc.py:444-464) and 'q' (misc.py:503-573)
-    for (int i = tid; i < S.ml; i += 256) {
-        const double a = sqrt(D.s[i]), c = sqrt(D.z[i]);
-        S.d[i] = S.d[i] * a / c;
-        S.lmbda[i] = a * c;
-    }
-    for (int k = tid; k < S.nq; k += 256) {
-        const int o = S.qoff[k], mk = S.qdim[k];
-        double* sk = D.s + o;
-        double* zk = D.z + o;
-        double* v = S.v + (o - S.ml);
-        double* lk = S.lmbda + o;
-        const double aa = q_jnrm2(sk, mk);
-        for (int i = 0; i < mk; ++i) sk[i] *= 1.0 / aa;
-        const double bb = q_jnrm2(zk, mk);
-        for (int i = 0; i < mk; ++i) zk[i] *= 1.0 / bb;
-        double dsz = 0.0, vs = 0.0, vz1 = 0.0;
-        for (int i = 0; i < mk; ++i) {
-            dsz += sk[i] * zk[i];
-            vs += v[i] * sk[i];
-            if (i > 0) vz1 += v[i] * zk[i];
-        }
-        const double cc = sqrt((1.0 + dsz) / 2.0);
-        const double vz = v[0] * zk[0] - vz1;                       // v' J z
-        const double vq = (vs + vz) / 2.0 / cc;
-        const double vu = vs - vz;
-        const double wk0 = 2.0 * v[0] * vq - (sk[0] + zk[0]) / 2.0 / cc;
-        const double dd = (v[0] * vu - sk[0] / 2.0 + zk[0] / 2.0) / (wk0 + 1.0);
-        const double fv = 2.0 * (-dd * vq + 0.5 * vu), fs = 0.5 * (1.0 - dd / cc), fz = 0.5 * (1.0 + dd / cc);
-        const double sq = sqrt(aa * bb);
-        lk[0] = cc * sq;
-        for (int i = 1; i < mk; ++i) lk[i] = (v[i] * fv + sk[i] * fs + zk[i] * fz) * sq;
-        // v := (2 v v' - J) q, then v := v^{1/2}
-        const double s0 = sk[0];
-        for (int i = 0; i < mk; ++i) {
-            double t = 2.0 * vq * v[i];
-            if (i == 0) t -= s0 / 2.0 / cc;
-            else t += sk[i] * (0.5 / cc);
-            t += zk[i] * (-0.5 / cc);
-            v[i] = t;
-        }
-        v[0] += 1.0;
-        const double f = 1.0 / sqrt(2.0 * v[0]);
-        for (int i = 0; i < mk; ++i) v[i] *= f;
-        S.beta[k] *= sqrt(aa / bb);
-    }
+    cv_update_scaling(S, S.lmbda, D.s, D.z);
     __syncthreads();
     if (tid == 0) {
         const double tt = sc[LP_TT], tk = sc[LP_TK];

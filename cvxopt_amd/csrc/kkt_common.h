@@ -256,4 +256,38 @@ void lp_launch_res_b(const LpState& S, const LpBuf& U, const LpBuf& V, hipStream
 void lp_launch_step(const LpState& S, const LpBuf& D, int i01, hipStream_t st);
 void lp_launch_update(const LpState& S, const LpBuf& D, hipStream_t st);
 
+// ---- device-resident coneqp loop for one problem, 'l' + 'q' cones (coneqp_ipm.hip) ------------------------
+enum QpScalar {
+    QP_GAP = 0, QP_SIGMA, QP_STEP, QP_MU, QP_RESX0, QP_RESY0, QP_RESZ0, QP_PCOST, QP_DCOST, QP_RELGAP, QP_PRES, QP_DRES,
+    QP_GAP_OUT, QP_NSC
+};
+struct QpBuf { double *x, *y, *z, *s; };            // one (x, y, z, s) quadruple of f4 / res
+struct QpState {
+    int n = 0, m = 0, p = 0, ml = 0, nq = 0;          // m = ml + sum(q)
+    const int *qoff = nullptr, *qdim = nullptr;
+    double *q = nullptr, *x = nullptr, *dx = nullptr, *rx = nullptr, *Px = nullptr, *GTz = nullptr, *ATy = nullptr,
+           *x_out = nullptr, *wx = nullptr, *wx2 = nullptr;                          // [n]
+    double *b = nullptr, *y = nullptr, *dy = nullptr, *ry = nullptr, *Ax = nullptr, *y_out = nullptr, *wy = nullptr,
+           *wy2 = nullptr;                                                           // [p]
+    double *h = nullptr, *s = nullptr, *z = nullptr, *ds = nullptr, *dz = nullptr, *rz = nullptr, *lmbda = nullptr,
+           *lmbdasq = nullptr, *d = nullptr, *di = nullptr, *ws3 = nullptr, *Gx = nullptr, *s_out = nullptr, *z_out = nullptr,
+           *t1 = nullptr, *t2 = nullptr, *wz3 = nullptr, *ws = nullptr, *wz = nullptr, *ws2 = nullptr, *wz2 = nullptr;   // [m]
+    double *v = nullptr, *beta = nullptr;
+    double* sc = nullptr;                             // [QP_NSC]
+    int *active = nullptr, *status = nullptr, *iters = nullptr, *nactive = nullptr;
+};
+void qp_launch_unit_scaling(const QpState& S, hipStream_t st);
+void qp_launch_start(const QpState& S, hipStream_t st);
+void qp_launch_residual(const QpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st);
+void qp_launch_singular(const QpState& S, const int* d_info, int it, hipStream_t st);
+void qp_launch_build(const QpState& S, const QpBuf& D, const QpBuf& W, int i01, int save, hipStream_t st);
+void qp_launch_copy(const QpState& S, const QpBuf& dst, const QpBuf& src, hipStream_t st);
+void qp_launch_add(const QpState& S, const QpBuf& dst, const QpBuf& src, hipStream_t st);
+void qp_launch_f4pre(const QpState& S, const QpBuf& X, hipStream_t st);
+void qp_launch_f4post(const QpState& S, const QpBuf& X, hipStream_t st);
+void qp_launch_res_a(const QpState& S, const QpBuf& U, hipStream_t st);
+void qp_launch_res_b(const QpState& S, const QpBuf& U, const QpBuf& V, hipStream_t st);
+void qp_launch_step(const QpState& S, const QpBuf& D, int i01, hipStream_t st);
+void qp_launch_update(const QpState& S, const QpBuf& D, hipStream_t st);
+
 }  // namespace mi355kkt

@@ -318,6 +318,32 @@ class _Engine(object):
                 'gap': g, 'relative gap': relgap, 'primal objective': pcost, 'dual objective': dcost,
                 'iterations': iters.value}
 
+    def coneqp_cones(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None):
+        """The reference coneqp loop (coneprog.py:2044-2547) for 'l' and 'q' cones resident on the device around this
+        handle (`mi355kkt_coneqp`; refinement 1 with second-order cones like the reference)."""
+        if self.dims['s']:
+            raise NotImplementedError("device-resident coneqp: 'l' and 'q' cones only (use cvxopt_amd.solvers.coneqp)")
+        self._set_H(P)
+        n, m, p = self.n, self.cdim, self.p
+        qv = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1))
+        hv = np.ascontiguousarray(np.asarray(h, dtype=np.float64).reshape(-1))
+        bv = np.ascontiguousarray(np.asarray(b if b is not None else [], dtype=np.float64).reshape(-1))
+        if qv.size != n or hv.size != m or bv.size != p:
+            raise TypeError("q / h / b have the wrong length")
+        x, y, s, z = np.zeros(n), np.zeros(p), np.zeros(m), np.zeros(m)
+        status, iters = C.c_int(0), C.c_int(0)
+        st = (C.c_double * 6)()
+        rc = self.L.mi355kkt_coneqp(self.h, _ptr(qv), _ptr(hv), _ptr(bv), int(maxiters), float(abstol), float(reltol),
+                                    float(feastol), -1 if refinement is None else int(refinement), _ptr(x), _ptr(y),
+                                    _ptr(s), _ptr(z), C.byref(status), C.byref(iters), st)
+        if rc == 1:
+            raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")        # coneprog.py:2065-2066
+        _capi.check(rc, "mi355kkt_coneqp")
+        gap, relgap, pcost, dcost, pres, dres = [float(v) for v in st]
+        return {'x': x, 'y': y, 's': s, 'z': z, 'status': 'optimal' if status.value == 1 else 'unknown', 'gap': gap,
+                'relative gap': None if relgap >= 1e299 else relgap, 'primal objective': pcost, 'dual objective': dcost,
+                'primal infeasibility': pres, 'dual infeasibility': dres, 'iterations': iters.value}
+
     def conelp(self, c, h, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None):
         """The reference conelp loop (coneprog.py:586-1436; 'l' and 'q' cones, default starting point) resident on the
         device around this handle (`mi355kkt_conelp`).  Returns a dict with the reference's keys and conventions
@@ -408,6 +434,25 @@ def conelp_device(c, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters
     try:
         return eng.conelp(c, h, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol,
                           refinement=refinement)
+    finally:
+        eng.close()
+
+
+def coneqp_device(P, q, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters=100, abstol=1e-7, reltol=1e-6,
+                  feastol=1e-7, refinement=None):
+    """min 1/2 x'Px + q'x  s.t.  Gx <=_K h, Ax = b,  K = R^l_+ x second-order cones, with the whole interior-point loop
+    on the MI355X.  Iterates match `solvers.coneqp(P, q, G, h, dims[, A, b])`."""
+    kind = {'chol2': _capi.CHOL2, 'chol': _capi.CHOL, 'ldl': _capi.LDL, 'ldl2': _capi.LDL2}[kktsolver]
+    m, n = _size(G)
+    if dims is None:
+        dims = {'l': m, 'q': [], 's': []}
+    dims = {'l': int(dims['l']), 'q': [int(k) for k in dims['q']], 's': [int(k) for k in dims['s']]}
+    if kind == _capi.CHOL2 and dims['q']:
+        kind = _capi.CHOL
+    eng = _Engine(kind, G, dims, A if A is not None else _EmptyA(n))
+    try:
+        return eng.coneqp_cones(q, h, P, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol,
+                                refinement=refinement)
     finally:
         eng.close()
 

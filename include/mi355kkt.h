@@ -157,6 +157,16 @@ int mi355kkt_conelp(mi355kkt_solver* h, const double* c, const double* hv, const
                     double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
                     int* iters, double* stats);
 
+/* The coneqp loop (coneprog.py:2044-2547) for dims = {'l': ml, 'q': [...]} around this handle (H = P optional; equality
+ * constraints with the dense engine); refinement < 0: the reference's default (0 for the LP cone, 1 with second-order
+ * cones, :1862-1865).  q: n, hv: cdim, bv: p (host).  Outputs (host): x, y, s, z; *status: 1 optimal, 2 unknown
+ * (iteration limit), 3 unknown (singular KKT matrix); stats[6] = gap, relative gap (1e300 = None), primal objective,
+ * dual objective, primal infeasibility, dual infeasibility.  Returns 0; <0 on error; 1 if the KKT matrix of the starting
+ * point is singular (the ValueError of coneprog.py:2065-2066). */
+int mi355kkt_coneqp(mi355kkt_solver* h, const double* q, const double* hv, const double* bv, int maxiters, double abstol,
+                    double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
+                    int* iters, double* stats);
+
 /* ---- batched mode: nbatch independent dense LP-cone problems of one shape (BASELINE configs[4]) ---------
  * No reference API exists for this; per problem it is exactly factor()/solve() of the
  * kkt_chol2 hook with p = 0: S_b = H_b + G_b' diag(di_b)^2 G_b = L_b L_b', launched as batched kernels

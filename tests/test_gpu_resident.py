@@ -270,3 +270,36 @@ def test_resident_conelp_socp_config3_full_size(ref_cvxopt):
     assert sol['status'] == ref['status'] == 'optimal' and sol['iterations'] == ref['iterations']
     assert abs(sol['primal objective'] - ref['primal objective']) <= 1e-8 * max(1.0, abs(ref['primal objective']))
     assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-6
+
+
+# ---- coneqp resident on the device with second-order cones -------------------------------------------------------
+@pytest.mark.parametrize("n,ncones,r,ml,p", [(30, 6, 5, 0, 0), (64, 16, 4, 20, 0), (80, 10, 9, 12, 6), (40, 0, 0, 90, 5)])
+def test_resident_coneqp_with_cones_matches_reference_driver(ref_cvxopt, n, ncones, r, ml, p):
+    from cvxopt import matrix, solvers
+    rng = np.random.default_rng(n + ncones)
+    if ncones:
+        pr = synth.socp(n=n, ncones=ncones, r=r, seed=n, ml=ml)
+        G, h, dims = pr['G'], pr['h'], pr['dims']
+    else:
+        pr = synth.dense_qp(n, ml, seed=n)
+        G, h, dims = pr['G'], pr['h'], pr['dims']
+    B = rng.standard_normal((n, n)) / np.sqrt(n)
+    P = B.T @ B + 1e-2 * np.eye(n)
+    q = rng.standard_normal(n)
+    kw, kwd = {}, {}
+    if p:
+        A = rng.standard_normal((p, n))
+        b = np.zeros(p)                               # x = 0 satisfies A x = b; the cone part is strictly feasible nearby
+        kw, kwd = dict(A=matrix(A), b=matrix(b)), dict(A=A, b=b)
+    ref = solvers.coneqp(matrix(P), matrix(q), matrix(G), matrix(h), dims, **kw)
+    sol = cvxopt_amd.coneqp_device(P, q, G, h, dims, **kwd)
+    assert sol['status'] == ref['status']
+    assert sol['iterations'] == ref['iterations']
+    if ref['status'] == 'optimal':
+        for k in ('primal objective', 'dual objective'):
+            assert abs(sol[k] - ref[k]) <= 1e-8 * max(1.0, abs(ref[k])), k
+        assert relerr(sol['x'], np.array(ref['x']).ravel()) < 1e-6
+        assert relerr(sol['s'], np.array(ref['s']).ravel()) < 1e-5
+        assert relerr(sol['z'], np.array(ref['z']).ravel()) < 1e-5
+        if p:
+            assert relerr(sol['y'], np.array(ref['y']).ravel()) < 1e-5
