@@ -58,6 +58,7 @@ SIGNATURES = {
     "mi355kkt_is_singular_mode": (C.c_int, [C.c_void_p]),
     "mi355kkt_get_timings": (C.c_int, [C.c_void_p, c_float_p, C.c_int]),
     "mi355kkt_get_factor": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_set_G_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64]),
     "mi355kkt_product": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mi355kkt_coneqp_lp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_int_p,

@@ -465,6 +465,22 @@ int mi355kkt_set_G_dense(mi355kkt_solver* h, const double* G, int64_t ldG) {
     return 0;
 }
 
+/* Overwrites rows [row0, row0 + nrows) of the dense G held by the handle (host source, column-major, ld = ldsrc): the
+ * Jacobian block Df of the nonlinear constraints that cvxprog.cp / cpl prepend to G at every iteration
+ * (misc.py:1265-1266 `Gs[:mnl,:] = Df`). */
+int mi355kkt_set_G_rows(mi355kkt_solver* h, int row0, int nrows, const double* src, int64_t ldsrc) {
+    if (!h || nrows < 0 || row0 < 0 || row0 + nrows > h->cdim || (nrows > 0 && (!src || ldsrc < nrows))) {
+        set_last_error("set_G_rows: invalid argument");
+        return MI355KKT_EINVAL;
+    }
+    if (!h->G_owned || h->dG != h->G_owned) { set_last_error("set_G_rows: G must have been set with set_G_dense / set_G_csc"); return MI355KKT_EINVAL; }
+    if (int e = bind(h)) return e;
+    if (nrows > 0 && h->n > 0)
+        KKT_HIP_CHECK(hipMemcpy2D(h->G_owned + row0, sizeof(double) * h->ldG, src, sizeof(double) * ldsrc, sizeof(double) * nrows,
+                                  h->n, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t* rowind, const double* values) {
     if (!h || !colptr) { set_last_error("set_G_csc: invalid argument"); return MI355KKT_EINVAL; }
     std::vector<double> dense((size_t)h->cdim * h->n, 0.0);

@@ -95,16 +95,22 @@ class _Engine(object):
     """One device solver handle = one reference factory closure (misc.py:1080-1083 'allocate once')."""
 
     def __init__(self, kind, G, dims, A, mnl=0, kktreg=None):
-        if mnl:
-            raise NotImplementedError("cvxopt_amd: nonlinear blocks (mnl > 0, cvxprog.cp/cpl) are outside "
-                                      "the accelerated path; use the reference CPU kktsolver")
         self.L = _capi.lib()
+        self.mnl = int(mnl)
         self.dims = {'l': int(dims['l']), 'q': [int(k) for k in dims['q']], 's': [int(k) for k in dims['s']]}
         p, n = _size(A)
         cdim = self.dims['l'] + sum(self.dims['q']) + sum(k * k for k in self.dims['s'])
         gm, gn = _size(G)
         if gn != n or gm != cdim:
             raise TypeError("G must be a 'd' matrix of size (%d, %d)" % (cdim, n))
+        if self.mnl:
+            # cvxprog.cp / cpl: mnl rows of Df are stacked on top of G and scaled by W['dnli'] (misc.py:1265-1271, :50-56):
+            # on the device they are simply mnl more 'l' rows whose values are refreshed at every factor(W, H, Df)
+            Gd = np.zeros((self.mnl + cdim, n), order='F')
+            Gd[self.mnl:, :] = self._densify(G, "G")
+            G = Gd
+            self.dims['l'] += self.mnl
+            cdim += self.mnl
         self.n, self.p, self.cdim, self.kind = n, p, cdim, kind
         q = (C.c_int * max(1, len(self.dims['q'])))(*self.dims['q'])
         s = (C.c_int * max(1, len(self.dims['s'])))(*self.dims['s'])
@@ -233,7 +239,11 @@ class _Engine(object):
             keep.append(a)
             return _dptr(a)
         ml = self.dims['l']
-        if ml:
+        if ml and self.mnl:
+            one = lambda v: np.asarray(v, dtype=np.float64).reshape(-1, order='F')
+            sc.di = flat(np.concatenate([one(W['dnli']), one(W['di'])]), ml)
+            sc.d = flat(np.concatenate([one(W['dnl']), one(W['d'])]), ml)
+        elif ml:
             sc.di = flat(W['di'], ml)
             sc.d = flat(W['d'], ml)
         if self.dims['q']:
@@ -247,8 +257,15 @@ class _Engine(object):
         return sc, keep
 
     def factor(self, W, H=None, Df=None):
-        if Df is not None:
-            raise NotImplementedError("cvxopt_amd: Df (nonlinear constraints) is outside the accelerated path")
+        if self.mnl:
+            if Df is None:
+                raise ValueError("factor(W, H, Df): Df is required when mnl > 0")
+            d = self._densify(Df, "Df")
+            if d.shape != (self.mnl, self.n):
+                raise TypeError("Df must be a 'd' matrix of size (%d, %d)" % (self.mnl, self.n))
+            _capi.check(self.L.mi355kkt_set_G_rows(self.h, 0, self.mnl, _ptr(d), max(1, d.shape[0])), "set_G_rows")
+        elif Df is not None and _size(Df)[0] != 0:
+            raise ValueError("factor(W, H, Df): Df given but the factory was created with mnl = 0")
         self._set_H(H)
         sc, keep = self._scaling(W)
         _capi.check(self.L.mi355kkt_factor(self.h, C.byref(sc)), "mi355kkt_factor")

@@ -83,6 +83,9 @@ void mi355kkt_destroy(mi355kkt_solver* h);
 int mi355kkt_set_G_dense(mi355kkt_solver* h, const double* G, int64_t ldG);         /* cdim x n  */
 int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t* rowind,
                        const double* values);                                        /* CCS, cdim x n */
+/* rows [row0, row0 + nrows) of the dense G := src (host, column-major): the Jacobian rows Df that cvxprog.cp / cpl stack on
+ * top of G in every iteration (misc.py:1265-1266, :1412-1416); the handle is then created with dims['l'] = mnl + l. */
+int mi355kkt_set_G_rows(mi355kkt_solver* h, int row0, int nrows, const double* src, int64_t ldsrc);
 int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA);         /* p x n     */
 /* Sparse mode (reference misc.py:1405-1462 sparse branch of kkt_chol2 -> cholmod.symbolic/numeric/solve,
  * src/C/cholmod.c:273-558): G (cdim x n) and H (n x n, lower triangle used; NULL = 0) in CCS.  Runs the symbolic

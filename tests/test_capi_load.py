@@ -58,7 +58,7 @@ def test_argument_errors_mirror_the_reference():
     from cvxopt_amd import kkt
     with pytest.raises(ValueError):                      # misc.py:1381-1384
         kkt.kkt_chol2(np.zeros((5, 3), order='F'), {'l': 2, 'q': [3], 's': []}, np.zeros((0, 3)))
-    with pytest.raises(NotImplementedError):             # mnl > 0 is cvxprog territory
+    with pytest.raises(RuntimeError):                    # mnl > 0 (cvxprog.cp / cpl) is accepted; no GPU here -> fails loudly
         kkt.kkt_chol(np.zeros((5, 3), order='F'), {'l': 5, 'q': [], 's': []}, np.zeros((0, 3)), mnl=2)
     with pytest.raises(ValueError):
         kkt._vec(np.zeros(4), 5, "x")
