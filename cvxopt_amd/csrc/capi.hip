@@ -51,6 +51,10 @@ __global__ void axpby_kernel(double* y, const double* x, double a, int64_t n) { 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = a * x[i];
 }
+__global__ void row_gather_kernel(const double* __restrict__ row, int64_t ld, int n, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // out[i] = A[j][i] for the row whose first entry is `row`
+    if (i < n) out[i] = row[(int64_t)i * ld];
+}
 __global__ void symmetrize_kernel(double* A, int n, int64_t bstride) {
     A += (int64_t)blockIdx.z * bstride;
     const int i = blockIdx.x * 16 + threadIdx.x, j = blockIdx.y * 16 + threadIdx.y;
@@ -263,6 +267,7 @@ struct mi355kkt_solver {
     double* dHsym = nullptr;   // full symmetric copy of H for the residual product P x
     bool hsym_valid = false;
     double* dIpmWork = nullptr;
+    double* dSpWork = nullptr;  // GEMV workspace of the sparse engine's Schur-complement step (p > 0)
 };
 
 static int bind(const mi355kkt_solver* h) {
@@ -427,6 +432,7 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     qp_free(h->qp);
     if (h->dHsym) (void)hipFree(h->dHsym);
     if (h->dIpmWork) (void)hipFree(h->dIpmWork);
+    if (h->dSpWork) (void)hipFree(h->dSpWork);
     if (h->dflags) (void)hipFree(h->dflags);
     if (h->derr) (void)hipFree(h->derr);
     if (h->herr) (void)hipHostFree(h->herr);
@@ -495,8 +501,8 @@ int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t*
 int mi355kkt_set_sparse_problem(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
                                 const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues) {
     if (!h || !gcolptr) { set_last_error("set_sparse_problem: null argument"); return MI355KKT_EINVAL; }
-    if (h->p != 0 || !h->q.empty() || !h->s.empty()) {
-        set_last_error("set_sparse_problem: the sparse engine handles LP cones without equality constraints");
+    if (!h->q.empty() || !h->s.empty()) {
+        set_last_error("set_sparse_problem: the sparse engine handles LP cones");
         return MI355KKT_ENOTIMPL;
     }
     if (int e = bind(h)) return e;
@@ -616,7 +622,24 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
         (void)hipEventElapsedTime(&h->t_factor, h->ev[0], h->ev[3]);
         h->t_syrk = h->t_potrf = h->t_schur = h->t_syrk_kernel = 0;
         h->firstcall = false;
-        if (sinfo > 0) return sinfo;
+        if (sinfo > 0) return sinfo;     // (the S + A'A fallback of misc.py:1433-1447 would change the sparsity pattern: not done)
+        if (h->p > 0) {
+            // equality constraints (misc.py:1464-1487, sparse branch): Asct = L^-1 P A' column by column through the
+            // supernodal forward solve (kept in the permuted ordering), K = Asct' Asct, dense Cholesky of K
+            if (!h->dA) { set_last_error("factor: A not set"); return MI355KKT_EINVAL; }
+            if (!h->dSpWork) KKT_HIP_CHECK(hipMalloc(&h->dSpWork, sizeof(double) * gemv_work_doubles(h->n, h->p)));
+            for (int j = 0; j < h->p; ++j) {
+                hipLaunchKernelGGL(row_gather_kernel, g1(h->n), dim3(256), 0, h->st, h->dA + j, h->ldA, h->n, h->dtn);
+                if (int e = sparse_engine_forward(h->sp, h->dtn, h->dAsct + (size_t)j * h->n, h->st)) return e;
+            }
+            KKT_HIP_CHECK(hipMemsetAsync(h->pw.d_info, 0, sizeof(int), h->st));
+            if (int e = launch_syrk_scaled(h->planK, h->dAsct, h->n, nullptr, h->dK, h->p, nullptr, 0, h->st)) return e;
+            if (h->kktreg != 0.0) hipLaunchKernelGGL(diag_add_kernel, g1(h->p), dim3(256), 0, h->st, h->dK, (int64_t)h->p, h->p, h->kktreg);
+            if (int e = launch_potrf(h->dK, h->p, h->p, h->pw, h->st)) return e;
+            int kinfo = 0;
+            if (int e = fetch_info(h, &kinfo)) return e;
+            if (kinfo > 0) return h->n + kinfo;
+        }
         h->factored = true;
         return 0;
     }
@@ -725,7 +748,19 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     KKT_HIP_CHECK(hipEventRecord(h->ev[4], st));
     if (h->sparse) {                                                // misc.py:1513-1563, sparse branch
         if (int e = sparse_engine_gemv_t(h->sp, h->dW, dz, h->dzs, h->dwork, dx, st)) return e;
-        if (int e = sparse_engine_solve(h->sp, dx, st)) return e;
+        if (p == 0) {
+            if (int e = sparse_engine_solve(h->sp, dx, st)) return e;
+        } else {
+            // x_p := L^-1 P x;  y := K^-1 (Asct' x_p - y);  x_p -= Asct y;  x := P' L^-T x_p       (misc.py:1528-1558)
+            if (int e = sparse_engine_forward(h->sp, dx, nullptr, st)) return e;
+            double* xp = h->sp.d_xp;
+            hipLaunchKernelGGL(scal_kernel, g1(p), dim3(256), 0, st, dy, p, -1.0);
+            if (int e = launch_gemv_t_scaled(h->dAsct, n, n, p, nullptr, xp, h->dtn, dy, nullptr, st)) return e;
+            if (int e = launch_trsm_lower(h->dK, p, p, dy, p, 1, 0, st)) return e;
+            if (int e = launch_trsm_lower(h->dK, p, p, dy, p, 1, 1, st)) return e;
+            if (int e = launch_gemv_n_scaled(h->dAsct, n, n, p, nullptr, dy, xp, xp, -1.0, 1.0, h->dSpWork, st)) return e;
+            if (int e = sparse_engine_backward(h->sp, dx, st)) return e;
+        }
         if (int e = sparse_engine_gemv_n(h->sp, h->dW, dx, h->dzs, dz, st)) return e;
         KKT_HIP_CHECK(hipEventRecord(h->ev[5], st));
         return 0;
@@ -1120,9 +1155,21 @@ static int ensure_hsym(mi355kkt_solver* hs) {
     hs->hsym_valid = true;
     return 0;
 }
+// A xin -> Ax, A' yin -> ATy with the dense A of the handle (both engines keep A dense)
+static int a_products(mi355kkt_solver* hs, const double* xin, const double* yin, double* Ax, double* ATy, double* gwork, hipStream_t st) {
+    const int n = hs->n, np = hs->p;
+    if (np <= 0) return 0;
+    if (int e = launch_gemv_n_scaled(hs->dA, hs->ldA, np, n, nullptr, xin, Ax, Ax, 1.0, 0.0, gwork, st)) return e;
+    KKT_HIP_CHECK(hipMemsetAsync(ATy, 0, sizeof(double) * n, st));
+    return launch_gemv_t_scaled(hs->dA, hs->ldA, np, n, nullptr, yin, hs->dtp, ATy, gwork, st);
+}
 static int ensure_gemv_work(mi355kkt_solver* hs) {
-    if (hs->dIpmWork || hs->sparse) return 0;
+    if (hs->dIpmWork) return 0;
     const int n = hs->n, m = hs->cdim, np = hs->p;
+    if (hs->sparse) {          // only the (dense) A products need it
+        if (np > 0) KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * gemv_work_doubles(np, n)));
+        return 0;
+    }
     KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n)),
                                                                 gemv_work_doubles(np, n))));
     return 0;
@@ -1146,10 +1193,9 @@ int mi355kkt_product(mi355kkt_solver* hs, int which, int trans, const double* x,
         memcpy(hs->hbuf, x, sizeof(double) * nin);
         KKT_HIP_CHECK(hipMemcpyAsync(din, hs->hbuf, sizeof(double) * nin, hipMemcpyHostToDevice, st));
     }
-    if (hs->sparse) {
-        if (which == 1) { set_last_error("product: A is not held by the sparse engine"); return MI355KKT_ENOTIMPL; }
+    if (hs->sparse && which != 1) {
         if (int e = sparse_engine_product(hs->sp, which, trans, din, dout, st)) return e;
-    } else {
+    } else {                                       // A is kept dense by both engines
         if ((which == 0 && !hs->dG) || (which == 1 && np > 0 && !hs->dA)) { set_last_error("product: matrix not set"); return MI355KKT_EINVAL; }
         if (int e = ensure_gemv_work(hs)) return e;
         const double* M = which == 0 ? hs->dG : (which == 1 ? hs->dA : nullptr);
@@ -1186,7 +1232,6 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
         set_last_error("coneqp_lp: needs dims = {'l': m > 0}");
         return MI355KKT_ENOTIMPL;
     }
-    if (hs->sparse && hs->p > 0) { set_last_error("coneqp_lp: equality constraints need the dense engine"); return MI355KKT_ENOTIMPL; }
     if (hs->p > 0 && !hs->dA) { set_last_error("coneqp_lp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->ml;
@@ -1196,13 +1241,14 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
     hipStream_t st = hs->st;
     if (int e = ensure_hsym(hs)) return e;
     double* scratch = hs->dzs;       // >= cdim doubles; free between solves
-    if (!hs->dIpmWork && !hs->sparse)
-        KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n)),
-                                                                    gemv_work_doubles(np, n))));
+    if (int e = ensure_gemv_work(hs)) return e;
     double* gwork = hs->dIpmWork;
     IpmOps ops;
     ops.products = [&]() -> int {
-        if (hs->sparse) return sparse_engine_products(hs->sp, S.x, S.z, S.Gx, S.GTz, S.Px, st);
+        if (hs->sparse) {
+            if (int e = sparse_engine_products(hs->sp, S.x, S.z, S.Gx, S.GTz, S.Px, st)) return e;
+            return a_products(hs, S.x, S.y, S.Ax, S.ATy, gwork, st);
+        }
         if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, S.x, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
         KKT_HIP_CHECK(hipMemsetAsync(S.GTz, 0, sizeof(double) * n, st));
         if (int e = launch_gemv_t_scaled(hs->dG, hs->ldG, m, n, nullptr, S.z, scratch, S.GTz, gwork, st)) return e;
@@ -1246,7 +1292,6 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
     }
     if (!hs->s.empty() || hs->cdim < 1) { set_last_error("conelp: needs dims = {'l': ml, 'q': [...]} with at least one row"); return MI355KKT_ENOTIMPL; }
     if (hs->dH) { set_last_error("conelp: the handle carries a quadratic term (H)"); return MI355KKT_EINVAL; }
-    if (hs->sparse && hs->p > 0) { set_last_error("conelp: equality constraints need the dense engine"); return MI355KKT_ENOTIMPL; }
     if (hs->p > 0 && !hs->dA) { set_last_error("conelp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->cdim, np = hs->p;
@@ -1260,7 +1305,10 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
     int* d_info = w.i32 + 5;
     // G xin -> Gx, A xin -> Ax, G' zin -> GTz, A' yin -> ATy
     auto products = [&](const double* xin, const double* yin, const double* zin) -> int {
-        if (hs->sparse) return sparse_engine_products(hs->sp, xin, zin, S.Gx, S.GTz, S.ATy /* P x = 0: scratch */, st);
+        if (hs->sparse) {
+            if (int e = sparse_engine_products(hs->sp, xin, zin, S.Gx, S.GTz, S.x_out /* P x = 0 lands in a scratch n-vector */, st)) return e;
+            return a_products(hs, xin, yin, S.Ax, S.ATy, gwork, st);
+        }
         if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, xin, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
         KKT_HIP_CHECK(hipMemsetAsync(S.GTz, 0, sizeof(double) * n, st));
         if (int e = launch_gemv_t_scaled(hs->dG, hs->ldG, m, n, nullptr, zin, hs->dzs, S.GTz, gwork, st)) return e;
@@ -1370,7 +1418,6 @@ int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, cons
         return MI355KKT_EINVAL;
     }
     if (!hs->s.empty() || hs->cdim < 1) { set_last_error("coneqp: needs dims = {'l': ml, 'q': [...]} with at least one row"); return MI355KKT_ENOTIMPL; }
-    if (hs->sparse && hs->p > 0) { set_last_error("coneqp: equality constraints need the dense engine"); return MI355KKT_ENOTIMPL; }
     if (hs->p > 0 && !hs->dA) { set_last_error("coneqp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->cdim, np = hs->p;
@@ -1385,7 +1432,10 @@ int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, cons
     int* d_info = w.i32 + 4;
     // P xin -> Px, G xin -> Gx, A xin -> Ax, G' zin -> GTz, A' yin -> ATy
     auto products = [&](const double* xin, const double* yin, const double* zin) -> int {
-        if (hs->sparse) return sparse_engine_products(hs->sp, xin, zin, S.Gx, S.GTz, S.Px, st);
+        if (hs->sparse) {
+            if (int e = sparse_engine_products(hs->sp, xin, zin, S.Gx, S.GTz, S.Px, st)) return e;
+            return a_products(hs, xin, yin, S.Ax, S.ATy, gwork, st);
+        }
         if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, xin, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
         KKT_HIP_CHECK(hipMemsetAsync(S.GTz, 0, sizeof(double) * n, st));
         if (int e = launch_gemv_t_scaled(hs->dG, hs->ldG, m, n, nullptr, zin, hs->dzs, S.GTz, gwork, st)) return e;

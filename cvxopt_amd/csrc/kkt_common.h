@@ -161,6 +161,8 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
 void sparse_engine_free(SparseEngine& E);
 int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, int* info);
 int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st);
+int sparse_engine_forward(SparseEngine& E, const double* d_in, double* d_out_perm, hipStream_t st);   // E.d_xp = L^-1 P b
+int sparse_engine_backward(SparseEngine& E, double* d_out, hipStream_t st);                           // d_out = P' L^-T E.d_xp
 int sparse_engine_product(SparseEngine& E, int which, int trans, const double* d_in, double* d_out, hipStream_t st);
 int sparse_engine_products(SparseEngine& E, const double* d_x, const double* d_z, double* d_Gx, double* d_GTz, double* d_Px,
                            hipStream_t st);

@@ -1080,13 +1080,13 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
     return 0;
 }
 
-// x := S^-1 x  (x: device vector of length n, original ordering)
-int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st) {
+// forward half: E.d_xp := L^-1 P b (b = d_in, original ordering); optionally copied to d_out_perm (permuted ordering)
+int sparse_engine_forward(SparseEngine& E, const double* d_in, double* d_out_perm, hipStream_t st) {
     const SparseSymbolic& S = E.sym;
     if (E.n == 0) return 0;
     const SpDev d = devview(E);
     const dim3 g((E.n + 255) / 256);
-    hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, d_x, E.d_xp, E.d_perm, E.n, 1);
+    hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, d_in, E.d_xp, E.d_perm, E.n, 1);
     for (int l = 0; l < S.nlevels; ++l) {
         const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
         if (cnt > 0)
@@ -1097,6 +1097,16 @@ int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st) {
             hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 255) / 256, nh), dim3(256), 0, st, d,
                                E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp, E.d_rem, E.d_rem_off);
     }
+    if (d_out_perm) KKT_HIP_CHECK(hipMemcpyAsync(d_out_perm, E.d_xp, sizeof(double) * E.n, hipMemcpyDeviceToDevice, st));
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// backward half: d_out := P' L^-T E.d_xp
+int sparse_engine_backward(SparseEngine& E, double* d_out, hipStream_t st) {
+    const SparseSymbolic& S = E.sym;
+    if (E.n == 0) return 0;
+    const SpDev d = devview(E);
+    const dim3 g((E.n + 255) / 256);
     for (int l = S.nlevels - 1; l >= 0; --l) {
         const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
         const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
@@ -1105,9 +1115,14 @@ int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st) {
                                E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp);
         if (cnt > 0) hipLaunchKernelGGL(sp_bwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp);
     }
-    hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, E.d_xp, d_x, E.d_perm, E.n, 0);
+    hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, E.d_xp, d_out, E.d_perm, E.n, 0);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
+}
+// x := S^-1 x  (x: device vector of length n, original ordering)
+int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st) {
+    if (int e = sparse_engine_forward(E, d_x, nullptr, st)) return e;
+    return sparse_engine_backward(E, d_x, st);
 }
 
 // the two sparse products of solve():  zs = w.*z, x += G'(w.*zs)   and   z = w.*(G x) - zs

@@ -173,10 +173,11 @@ class _Engine(object):
                                               v.ctypes.data_as(_capi.c_double_p)), "set_G_csc")
 
     def _decide_mode(self, H):
-        """First factor() with a sparse G: sparse engine iff H is sparse or absent, LP cone only, p = 0
-        (reference: S is an spmatrix exactly when neither G nor H is dense, misc.py:1401-1411)."""
-        sparse_ok = (H is None or _is_sparse(H)) and self.p == 0 and not self.dims['q'] and not self.dims['s'] \
-            and self.kind in (_capi.CHOL2, _capi.CHOL)
+        """First factor() with a sparse G: sparse engine iff H is sparse or absent, LP cone only
+        (reference: S is an spmatrix exactly when neither G nor H is dense, misc.py:1401-1411); equality constraints
+        go through the sparse forward solves (Asct = L^-1 P A' column by column), so p should stay moderate."""
+        sparse_ok = (H is None or _is_sparse(H)) and not self.dims['q'] and not self.dims['s'] and not self.mnl \
+            and self.kind in (_capi.CHOL2, _capi.CHOL) and self.p <= 512
         if sparse_ok:
             gcp, gri, gv = self._G_csc
             hp = (None, None, None)

@@ -174,3 +174,71 @@ def test_sparse_resident_coneqp_matches_dense_resident(maker, arg):
     assert a['status'] == b['status'] == 'optimal' and a['iterations'] == b['iterations']
     assert abs(a['primal objective'] - b['primal objective']) <= 1e-9 * max(1.0, abs(b['primal objective']))
     assert relerr(a['x'], b['x']) < 1e-7 and relerr(a['z'], b['z']) < 1e-6
+
+
+@pytest.mark.parametrize("maker,arg,p", [(laplace2d, (30, 24), 5), (laplace3d, (10,), 12)])
+def test_sparse_factor_solve_with_equalities_matches_dense_oracle(maker, arg, p):
+    """p > 0 on the sparse engine: Asct = L^-1 P A' through the supernodal forward solve, K = Asct'Asct dense
+    (reference misc.py:1464-1487 / :1528-1558, sparse branch) vs the dense NumPy oracle of the same KKT system."""
+    P = maker(*arg)
+    n = P.shape[0]
+    G = box(n)
+    rng = np.random.default_rng(p)
+    A = rng.standard_normal((p, n))
+    dims = {'l': 2 * n, 'q': [], 's': []}
+    W = synth.random_scaling(dims, seed=1, spread=1.0)
+    f = kkt.kkt_chol2(FakeSp(G), dims, A)
+    solve = f(W, FakeSp(sp.tril(P)))
+    assert f.engine._mode == "sparse"
+    bx, by, bz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(2 * n)
+    x, y, z = bx.copy(), by.copy(), bz.copy()
+    solve(x, y, z)
+    xo, yo, zo = bx.copy(), by.copy(), bz.copy()
+    ko.KktChol2(G.toarray(), dims, A).factor(W, P.toarray())(xo, yo, zo)
+    assert relerr(x, xo) < 1e-9 and relerr(y, yo) < 1e-8 and relerr(z, zo) < 1e-9
+    f.engine.close()
+
+
+def test_sparse_coneqp_with_equalities_drop_in(ref_cvxopt):
+    from cvxopt import matrix, spmatrix, solvers
+    nx = 16
+    P = laplace2d(nx, nx)
+    n = nx * nx
+    Pc = sp.tril(P).tocoo()
+    Pcv = spmatrix(list(Pc.data), list(map(int, Pc.row)), list(map(int, Pc.col)), (n, n))
+    Gc = box(n).tocoo()
+    Gcv = spmatrix(list(Gc.data), list(map(int, Gc.row)), list(map(int, Gc.col)), (2 * n, n))
+    rng = np.random.default_rng(0)
+    A = matrix(rng.standard_normal((3, n)) / np.sqrt(n))
+    b = matrix(np.zeros(3))
+    q, h = matrix(-np.ones(n)), matrix(np.ones(2 * n))
+    ref = solvers.coneqp(Pcv, q, Gcv, h, A=A, b=b, kktsolver='chol2')
+    ks = kkt.kktsolver_qp(Gcv, {'l': 2 * n, 'q': [], 's': []}, A, Pcv)
+    got = solvers.coneqp(Pcv, q, Gcv, h, A=A, b=b, kktsolver=ks)
+    assert ks.engine._mode == "sparse"
+    assert got['status'] == ref['status'] == 'optimal' and got['iterations'] == ref['iterations']
+    assert abs(got['primal objective'] - ref['primal objective']) <= 1e-9 * abs(ref['primal objective'])
+    assert relerr(np.array(got['x']).ravel(), np.array(ref['x']).ravel()) < 1e-7
+    assert relerr(np.array(got['y']).ravel(), np.array(ref['y']).ravel()) < 1e-6
+    ks.engine.close()
+
+
+def test_sparse_resident_loops_with_equalities(ref_cvxopt):
+    """Device-resident coneqp / conelp on the sparse engine with a few equality constraints vs the dense engine."""
+    import cvxopt_amd
+    P = laplace2d(18, 14)
+    n = P.shape[0]
+    G = box(n)
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((4, n)) / np.sqrt(n)
+    b = np.zeros(4)
+    q, h = rng.standard_normal(n), 0.5 + rng.random(2 * n)
+    a = cvxopt_amd.coneqp_lp(FakeSp(sp.tril(P)), q, FakeSp(G), h, A=A, b=b)
+    d = cvxopt_amd.coneqp_lp(np.asfortranarray(P.toarray()), q, np.asfortranarray(G.toarray()), h, A=A, b=b)
+    assert a['status'] == d['status'] == 'optimal' and a['iterations'] == d['iterations']
+    assert relerr(a['x'], d['x']) < 1e-7 and relerr(a['y'], d['y']) < 1e-6
+    c = rng.standard_normal(n)
+    a = cvxopt_amd.conelp_device(c, FakeSp(G), np.ones(2 * n), A=A, b=b)
+    d = cvxopt_amd.conelp_device(c, np.asfortranarray(G.toarray()), np.ones(2 * n), A=A, b=b)
+    assert a['status'] == d['status'] == 'optimal' and a['iterations'] == d['iterations']
+    assert relerr(a['x'], d['x']) < 1e-7 and abs(a['primal objective'] - d['primal objective']) <= 1e-9 * max(1, abs(d['primal objective']))
