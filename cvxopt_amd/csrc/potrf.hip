@@ -459,9 +459,10 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
             // everything to the right of the next panel: bulk, low priority, one workgroup per CU
             const int k3 = k2 + wnext;
             if (k3 < n) {
-                KKT_HIP_CHECK(hipStreamWaitEvent(w.side, w.ev_panel[step], 0));
+                // released after the skinny next-panel update on aux (which then shares the machine only with potf2)
+                KKT_HIP_CHECK(hipStreamWaitEvent(w.side, getenv("MI355KKT_BULK_EARLY") ? w.ev_panel[step] : w.ev_ir[step], 0));
                 if (int e = launch_syrk_nt_update(A + k3 + (int64_t)k3 * lda, lda, A + k3 + (int64_t)k0 * lda, lda, n - k3, K,
-                                                  w.side, 1, 0, getenv("MI355KKT_BULK_2WG") == nullptr))
+                                                  w.side, 1, 0, getenv("MI355KKT_BULK_1WG") != nullptr))
                     return e;
                 KKT_HIP_CHECK(hipEventRecord(w.ev_bulk[step], w.side));
                 bulk_pending = true;

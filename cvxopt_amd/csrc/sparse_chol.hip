@@ -18,6 +18,7 @@
 #include <queue>
 
 #include "kkt_common.h"
+#include <chrono>
 
 namespace mi355kkt {
 
@@ -160,8 +161,17 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     S.n = n;
     S.m = m;
     if (n == 0) return 0;
+    const bool dbg = getenv("MI355KKT_SPARSE_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sparse] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     std::vector<std::vector<int>> adj;
     build_graph(n, m, gcp, gri, hcp, hri, adj);
+    lap("pattern of S");
     // ---- ordering
     std::vector<int> nodes(n), order;
     std::iota(nodes.begin(), nodes.end(), 0);
@@ -174,6 +184,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         set_last_error("symbolic_analyze: ordering produced %zu of %d nodes", order.size(), n);
         return -1;
     }
+    lap("nested dissection");
     S.perm = order;                 // perm[new] = old
     S.iperm.assign(n, 0);
     for (int k = 0; k < n; ++k) S.iperm[order[k]] = k;
@@ -208,6 +219,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
                 }
             }
     }
+    lap("elimination tree");
     // ---- column structures struct(j) = rows > j of L(:, j): own pattern U children's structures
     std::vector<std::vector<int>> child(n);
     for (int j = 0; j < n; ++j)
@@ -226,6 +238,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
             std::sort(s.begin(), s.end());
         }
     }
+    lap("column structures");
     // ---- supernodes: column j joins the supernode that ends at j-1 when parent[j-1] == j (so struct(j-1) \ {j} is
     //      contained in struct(j)) and the explicit zeros this adds to the stored panel stay a small fraction of it.
     //      Exact (fundamental) merges add none; relaxed merges trade a little fill for far fewer, denser fronts and a
@@ -273,6 +286,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     }
     S.sn_rows.resize(S.sn_rowptr[ns]);
     for (int s = 0; s < ns; ++s) std::copy(snrows[s].begin(), snrows[s].end(), S.sn_rows.begin() + S.sn_rowptr[s]);
+    lap("supernodes + row lists");
     // supernodal tree: parent = supernode of the first row below the supernode
     S.sn_parent.assign(ns, -1);
     std::vector<std::vector<int>> snchild(ns);
@@ -415,6 +429,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
             for (int r : snrows[p]) where[r] = -1;
         }
     }
+    lap("tree, levels, maps");
     // ---- numeric assembly lists: every structural nonzero of S in (permuted) column j, row i >= j, gets a slot in
     //      its supernode's panel; contributions: H entries and products G_ra G_rb di_r^2.
     //      Sorted by target slot (CSR over targets) so that one thread sums one entry in a fixed order.
@@ -468,6 +483,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         S.asm_ptr.push_back((int64_t)k);
         k = e;
     }
+    lap("assembly lists (build + sort)");
     S.asm_ptr.push_back((int64_t)cs.size());
     S.asm_a.resize(cs.size());
     S.asm_b.resize(cs.size());
