@@ -220,25 +220,25 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
             }
     }
     lap("elimination tree");
-    // ---- column structures struct(j) = rows > j of L(:, j): own pattern U children's structures
-    std::vector<std::vector<int>> child(n);
-    for (int j = 0; j < n; ++j)
-        if (parent[j] >= 0) child[parent[j]].push_back(j);
-    std::vector<std::vector<int>> st(n);
+    // ---- column counts cc[j] = |struct(j)| (rows > j of L(:, j)) without forming the structures: row i belongs to
+    //      struct(j) for every j on the etree paths from the columns k < i of row i's pattern up to i ("row subtrees");
+    //      each entry of L is visited once, nothing is stored or sorted
+    std::vector<int64_t> cc(n, 0);
     {
-        std::vector<int> flag(n, -1);
-        for (int j = 0; j < n; ++j) {   // parents have larger indices: natural order is a valid topological order
-            std::vector<int>& s = st[j];
-            flag[j] = j;
-            for (int i : low[j])
-                if (flag[i] != j) { flag[i] = j; s.push_back(i); }
-            for (int c : child[j])
-                for (int i : st[c])
-                    if (i != j && flag[i] != j) { flag[i] = j; s.push_back(i); }
-            std::sort(s.begin(), s.end());
+        std::vector<std::vector<int>> rowcols(n);
+        for (int j = 0; j < n; ++j)
+            for (int i : low[j]) rowcols[i].push_back(j);
+        std::vector<int> mark(n, -1);
+        for (int i = 0; i < n; ++i) {
+            mark[i] = i;
+            for (int k : rowcols[i])
+                for (int j = k; j != -1 && j < i && mark[j] != i; j = parent[j]) {
+                    mark[j] = i;
+                    cc[j]++;
+                }
         }
     }
-    lap("column structures");
+    lap("column counts");
     // ---- supernodes: column j joins the supernode that ends at j-1 when parent[j-1] == j (so struct(j-1) \ {j} is
     //      contained in struct(j)) and the explicit zeros this adds to the stored panel stay a small fraction of it.
     //      Exact (fundamental) merges add none; relaxed merges trade a little fill for far fewer, denser fronts and a
@@ -249,11 +249,11 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     int64_t true_nnz = 0;        // nonzeros of L in the columns of the current supernode
     for (int j = 0; j < n; ++j) {
         bool join = false;
-        const int64_t cj = 1 + (int64_t)st[j].size();
+        const int64_t cj = 1 + cc[j];
         if (j > 0 && parent[j - 1] == j) {
             const int first = sn_first.back();
             const int64_t wn = j - first + 1;
-            const int64_t stored = wn * (int64_t)st[j].size() + wn * (wn + 1) / 2;   // trapezoid ending at column j
+            const int64_t stored = wn * cc[j] + wn * (wn + 1) / 2;   // trapezoid ending at column j
             const int64_t zeros = stored - (true_nnz + cj);
             const double lim = wn <= 4 ? 0.5 : (wn <= 16 ? 0.3 : (wn <= 64 ? 0.2 : 0.1));
             if (wn <= MAXW && (zeros == 0 || (double)zeros <= lim * (double)stored)) join = true;
@@ -266,22 +266,34 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     S.ns = ns;
     S.sn_first = sn_first;
     S.sn_first.push_back(n);
-    // rows of supernode s: its own columns followed by the union of its columns' structures outside the supernode
+    // rows of supernode s: its own columns, then the union of its columns' structures outside the supernode, by a
+    // supernodal symbolic factorisation: own pattern entries below the supernode U below-rows of the child supernodes
+    // (a supernode's parent is the supernode of its first below-row, so children are complete before their parent)
     S.sn_rowptr.assign(ns + 1, 0);
     std::vector<std::vector<int>> snrows(ns);
     {
         std::vector<int> flag(n, -1);
+        std::vector<std::vector<int>> kids(ns);
         for (int s = 0; s < ns; ++s) {
             const int f = S.sn_first[s], l = S.sn_first[s + 1];
             std::vector<int>& r = snrows[s];
             for (int j = f; j < l; ++j) r.push_back(j);
             std::vector<int> below;
             for (int j = f; j < l; ++j)
-                for (int i : st[j])
+                for (int i : low[j])
                     if (i >= l && flag[i] != s) { flag[i] = s; below.push_back(i); }
+            for (int c : kids[s]) {
+                const std::vector<int>& rc = snrows[c];
+                const int wc = S.sn_first[c + 1] - S.sn_first[c];
+                for (size_t k = wc; k < rc.size(); ++k) {
+                    const int i = rc[k];
+                    if (i >= l && flag[i] != s) { flag[i] = s; below.push_back(i); }
+                }
+            }
             std::sort(below.begin(), below.end());
             r.insert(r.end(), below.begin(), below.end());
             S.sn_rowptr[s + 1] = S.sn_rowptr[s] + (int64_t)r.size();
+            if (!below.empty()) kids[sn_of[below[0]]].push_back(s);
         }
     }
     S.sn_rows.resize(S.sn_rowptr[ns]);
