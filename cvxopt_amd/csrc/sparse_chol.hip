@@ -19,6 +19,9 @@
 
 #include "kkt_common.h"
 #include <chrono>
+#include <memory>
+#include <future>
+#include <atomic>
 
 namespace mi355kkt {
 
@@ -61,10 +64,14 @@ void build_graph(int n, int m, const int64_t* gcp, const int64_t* gri, const int
 // last.  Parts of <= 48 nodes are ordered in BFS order.
 struct Dissector {
     const std::vector<std::vector<int>>& adj;
-    std::vector<int> part, level;
-    std::vector<int>& order;
-    int next_id = 1;
-    Dissector(const std::vector<std::vector<int>>& a, std::vector<int>& o) : adj(a), part(a.size(), 0), level(a.size(), -1), order(o) {}
+    std::unique_ptr<std::atomic<int>[]> part;     // relaxed atomics: sibling subproblems relabel their own nodes concurrently
+    std::vector<int> level;
+    std::vector<int>& order;                      // preallocated, every call fills its own range [off, off + |nodes|)
+    std::atomic<int> next_id{1};
+    Dissector(const std::vector<std::vector<int>>& a, std::vector<int>& o)
+        : adj(a), part(new std::atomic<int>[a.size() ? a.size() : 1]), level(a.size(), -1), order(o) {
+        for (size_t i = 0; i < a.size(); ++i) part[i].store(0, std::memory_order_relaxed);
+    }
 
     // BFS inside part `id` from root; fills levels, leaves level[] set for the visited nodes
     void bfs(int root, int id, std::vector<std::vector<int>>& levels) {
@@ -76,7 +83,7 @@ struct Dissector {
             std::vector<int> nxt;
             for (int v : cur)
                 for (int u : adj[v])
-                    if (part[u] == id && level[u] < 0) {
+                    if (part[u].load(std::memory_order_relaxed) == id && level[u] < 0) {
                         level[u] = (int)levels.size();
                         nxt.push_back(u);
                     }
@@ -87,47 +94,59 @@ struct Dissector {
         for (auto& L : levels)
             for (int v : L) level[v] = -1;
     }
-    void run(std::vector<int>& nodes, int depth) {
+    void emit(const std::vector<std::vector<int>>& levels, size_t off) {
+        for (auto& L : levels)
+            for (int v : L) order[off++] = v;
+    }
+    void run(std::vector<int>& nodes, int depth, size_t off) {
         if (nodes.empty()) return;
-        const int id = next_id++;
-        for (int v : nodes) part[v] = id;
+        const int id = next_id.fetch_add(1);
+        for (int v : nodes) part[v].store(id, std::memory_order_relaxed);
         std::vector<std::vector<int>> levels;
-        // connected components
-        std::vector<std::vector<int>> comps;
-        for (int v : nodes)
-            if (level[v] < 0) {
-                bfs(v, id, levels);
+        // first sweep from nodes[0]: if it does not reach every node the part is disconnected -> one call per component
+        bfs(nodes[0], id, levels);
+        size_t reached = 0;
+        for (auto& L : levels) reached += L.size();
+        if (reached != nodes.size()) {
+            std::vector<std::vector<int>> comps;
+            {
                 std::vector<int> c;
                 for (auto& L : levels) c.insert(c.end(), L.begin(), L.end());
                 comps.push_back(std::move(c));
             }
-        for (int v : nodes) level[v] = -1;
-        if (comps.size() > 1) {
-            for (auto& c : comps) run(c, depth);
+            for (int v : nodes)
+                if (level[v] < 0) {
+                    bfs(v, id, levels);
+                    std::vector<int> c;
+                    for (auto& L : levels) c.insert(c.end(), L.begin(), L.end());
+                    comps.push_back(std::move(c));
+                }
+            for (int v : nodes) level[v] = -1;
+            for (auto& c : comps) {
+                run(c, depth, off);
+                off += c.size();
+            }
             return;
         }
         if ((int)nodes.size() <= 48 || depth > 60) {
-            bfs(nodes[0], id, levels);
-            for (auto& L : levels)
-                for (int v : L) order.push_back(v);
+            emit(levels, off);
             clear(levels);
             return;
         }
+        // pseudo-peripheral root: restart from a minimum-degree node of the last level, at most twice more; the level
+        // structure of the last sweep is the one that is cut
         int root = nodes[0];
         for (int sweep = 0; sweep < 3; ++sweep) {
-            bfs(root, id, levels);
             int best = levels.back()[0];
             for (int v : levels.back())
                 if (adj[v].size() < adj[best].size()) best = v;
             clear(levels);
-            if (best == root) break;
+            if (best == root || sweep == 2) break;
             root = best;
+            bfs(root, id, levels);
         }
-        bfs(root, id, levels);
-        clear(levels);
         if (levels.size() < 3) {   // (nearly) complete graph: no useful separator
-            for (auto& L : levels)
-                for (int v : L) order.push_back(v);
+            emit(levels, off);
             return;
         }
         const size_t total = nodes.size();
@@ -147,9 +166,18 @@ struct Dissector {
         std::vector<int> left, right, sep = levels[best_l];
         for (size_t l = 0; l < best_l; ++l) left.insert(left.end(), levels[l].begin(), levels[l].end());
         for (size_t l = best_l + 1; l < levels.size(); ++l) right.insert(right.end(), levels[l].begin(), levels[l].end());
-        run(left, depth + 1);
-        run(right, depth + 1);
-        for (int v : sep) order.push_back(v);
+        const size_t off_r = off + left.size(), off_s = off_r + right.size();
+        // the two sides are independent subproblems (disjoint nodes, disjoint output ranges): the first few levels of
+        // the recursion run them on separate host threads
+        if (depth < 5 && left.size() > 2048 && right.size() > 2048) {
+            auto fut = std::async(std::launch::async, [&]() { run(left, depth + 1, off); });
+            run(right, depth + 1, off_r);
+            fut.get();
+        } else {
+            run(left, depth + 1, off);
+            run(right, depth + 1, off_r);
+        }
+        for (size_t k = 0; k < sep.size(); ++k) order[off_s + k] = sep[k];
     }
 };
 
@@ -173,17 +201,17 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     build_graph(n, m, gcp, gri, hcp, hri, adj);
     lap("pattern of S");
     // ---- ordering
-    std::vector<int> nodes(n), order;
+    std::vector<int> nodes(n), order(n, -1);
     std::iota(nodes.begin(), nodes.end(), 0);
-    order.reserve(n);
     {
         Dissector nd(adj, order);
-        nd.run(nodes, 0);
+        nd.run(nodes, 0, 0);
     }
-    if ((int)order.size() != n) {
-        set_last_error("symbolic_analyze: ordering produced %zu of %d nodes", order.size(), n);
-        return -1;
-    }
+    for (int k = 0; k < n; ++k)
+        if (order[k] < 0) {
+            set_last_error("symbolic_analyze: ordering left position %d empty", k);
+            return -1;
+        }
     lap("nested dissection");
     S.perm = order;                 // perm[new] = old
     S.iperm.assign(n, 0);
