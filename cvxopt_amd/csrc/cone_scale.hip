@@ -127,6 +127,46 @@ __global__ __launch_bounds__(256) void sdp_scale_pack_kernel(const double* __res
     }
 }
 
+// Blocks too large for the LDS-resident kernel above: Y = R' X R in 16-column panels of R, T = X R[:, panel] staged in LDS
+// (nk x 16), X read from global memory through its lower triangle.  Plain FP64 FMAs: a functional path for the occasional
+// large block (mcsdp-style problems), not a tuned one.
+constexpr int SDP_PANEL = 16;
+__global__ __launch_bounds__(256) void sdp_scale_pack_big_kernel(const double* __restrict__ in, int64_t ldi,
+                                                                 double* __restrict__ out, int64_t ldo,
+                                                                 const int* __restrict__ sdim, const int* __restrict__ soff,
+                                                                 const int* __restrict__ spoff, const int* __restrict__ sroff,
+                                                                 const double* __restrict__ rti, double extra) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];     // T: nk x SDP_PANEL
+    const int k = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
+    const int nk = sdim[k];
+    const double* __restrict__ x = in + soff[k] + (int64_t)j * ldi;
+    const double* __restrict__ Rm = rti + sroff[k];
+    double* __restrict__ y = out + spoff[k] + (int64_t)j * ldo;
+    const double r2 = 1.4142135623730951;
+    for (int b0 = 0; b0 < nk; b0 += SDP_PANEL) {
+        const int pw = min(SDP_PANEL, nk - b0);
+        for (int e = tid; e < nk * pw; e += 256) {      // T[a][bb] = sum_c X[a][c] R[c][b0 + bb], X symmetric from its lower part
+            const int a = e % nk, bb = e / nk;
+            const double* __restrict__ rc = Rm + (int64_t)(b0 + bb) * nk;
+            double s = 0.0;
+            for (int c = 0; c < a; ++c) s += x[a + (int64_t)c * nk] * rc[c];
+            for (int c = a; c < nk; ++c) s += x[c + (int64_t)a * nk] * rc[c];
+            sm[a + bb * nk] = s;
+        }
+        __syncthreads();
+        for (int e = tid; e < nk * pw; e += 256) {      // Y[a][b0 + bb] = sum_c R[c][a] T[c][bb], lower triangle, packed
+            const int a = e % nk, bb = e / nk, b = b0 + bb;
+            if (a < b) continue;
+            const double* __restrict__ ra = Rm + (int64_t)a * nk;
+            double s = 0.0;
+            for (int c = 0; c < nk; ++c) s += ra[c] * sm[c + bb * nk];
+            const int64_t idx = (int64_t)b * nk - ((int64_t)b * (b - 1)) / 2 + (a - b);
+            y[idx] = extra * ((a == b) ? s : r2 * s);
+        }
+        __syncthreads();
+    }
+}
+
 // packed -> unpacked for the 's' part of a single vector (misc_solvers.c:552-601): lower triangle only
 __global__ __launch_bounds__(256) void sdp_unpack_kernel(const double* __restrict__ packed, double* __restrict__ out,
                                                          const int* __restrict__ sdim, const int* __restrict__ soff,
@@ -178,8 +218,21 @@ int launch_sdp_scale_pack(const ConeLayout& cl, const double* in, int64_t ldi, d
                           const double* d_rti, double extra, hipStream_t st) {
     if (cl.ns == 0 || ncols <= 0) return 0;
     if (cl.s_maxn > SDP_MAXN) {
-        set_last_error("semidefinite blocks larger than %d x %d are not supported on the device yet", SDP_MAXN, SDP_MAXN);
-        return -4;
+        if ((size_t)cl.s_maxn * SDP_PANEL * sizeof(double) > 150 * 1024) {
+            set_last_error("semidefinite blocks larger than %d x %d are not supported on the device", 150 * 1024 / 8 / SDP_PANEL,
+                           150 * 1024 / 8 / SDP_PANEL);
+            return -4;
+        }
+        static bool attr_big = false;
+        if (!attr_big) {
+            KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sdp_scale_pack_big_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_big = true;
+        }
+        hipLaunchKernelGGL(sdp_scale_pack_big_kernel, dim3(cl.ns, ncols), dim3(256), sizeof(double) * cl.s_maxn * SDP_PANEL, st, in,
+                           ldi, out, ldo, cl.d_sdim, cl.d_soff, cl.d_spoff, cl.d_sroff, d_rti, extra);
+        KKT_HIP_CHECK(hipGetLastError());
+        return 0;
     }
     static bool attr = false;
     const size_t lds = sizeof(double) * 2 * SDP_MAXN * SDP_MAXN;

@@ -451,7 +451,8 @@ def test_sdp_hook_matches_reference_golden():
 
 
 @pytest.mark.parametrize("dims,n,p", [({'l': 0, 'q': [], 's': [5]}, 8, 0), ({'l': 4, 'q': [3, 6], 's': [2, 7, 12]}, 30, 3),
-                                      ({'l': 0, 'q': [], 's': [40, 1]}, 100, 0)])
+                                      ({'l': 0, 'q': [], 's': [40, 1]}, 100, 0),
+                                      ({'l': 3, 'q': [4], 's': [96, 7, 130]}, 24, 2)])     # blocks beyond the LDS-resident kernel
 def test_sdp_factor_solve_matches_oracle(dims, n, p):
     m = ko.cdim(dims)
     rng = np.random.default_rng(n + m)
@@ -502,3 +503,24 @@ def test_sdp_drop_in_matches_reference(ref_cvxopt):
         assert abs(g['primal objective'] - ref['primal objective']) <= 1e-7 * max(1, abs(ref['primal objective']))
         assert relerr(np.array(g['x']).ravel(), np.array(ref['x']).ravel()) < 1e-6
     assert got['iterations'] == ref['iterations']
+
+
+def test_large_sdp_block_drop_in_matches_reference(ref_cvxopt):
+    """mcsdp-style problem (reference examples/doc/chap8/mcsdp.py: maximise 1'x s.t. w + diag(x) <= 0) with one 100 x 100
+    block: beyond the 80 x 80 LDS kernel, through the panel kernel."""
+    from cvxopt import matrix, solvers, spmatrix
+    n = 100
+    rng = np.random.default_rng(0)
+    Wm = rng.standard_normal((n, n)); Wm = (Wm + Wm.T) / 2
+    c = matrix(-1.0, (n, 1))
+    G = spmatrix(1.0, [i * (n + 1) for i in range(n)], list(range(n)), (n * n, n))
+    h = matrix(-Wm.reshape(-1, order='F'))
+    dims = {'l': 0, 'q': [], 's': [n]}
+    Gd = matrix(G)
+    ref = solvers.conelp(c, Gd, h, dims)
+    ks = kkt.kktsolver_lp(Gd, dims, spmatrix([], [], [], (0, n)))
+    got = solvers.conelp(c, Gd, h, dims, kktsolver=ks)
+    ks.engine.close()
+    assert got['status'] == ref['status'] == 'optimal' and got['iterations'] == ref['iterations']
+    assert abs(got['primal objective'] - ref['primal objective']) <= 1e-8 * max(1.0, abs(ref['primal objective']))
+    assert relerr(np.array(got['x']).ravel(), np.array(ref['x']).ravel()) < 1e-6
