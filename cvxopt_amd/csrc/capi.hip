@@ -624,14 +624,11 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
         h->firstcall = false;
         if (sinfo > 0) return sinfo;     // (the S + A'A fallback of misc.py:1433-1447 would change the sparsity pattern: not done)
         if (h->p > 0) {
-            // equality constraints (misc.py:1464-1487, sparse branch): Asct = L^-1 P A' column by column through the
-            // supernodal forward solve (kept in the permuted ordering), K = Asct' Asct, dense Cholesky of K
+            // equality constraints (misc.py:1464-1487, sparse branch): Asct = L^-1 P A' with all p right-hand sides in
+            // one pass of the supernodal forward solve (kept in the permuted ordering), K = Asct' Asct, dense Cholesky of K
             if (!h->dA) { set_last_error("factor: A not set"); return MI355KKT_EINVAL; }
             if (!h->dSpWork) KKT_HIP_CHECK(hipMalloc(&h->dSpWork, sizeof(double) * gemv_work_doubles(h->n, h->p)));
-            for (int j = 0; j < h->p; ++j) {
-                hipLaunchKernelGGL(row_gather_kernel, g1(h->n), dim3(256), 0, h->st, h->dA + j, h->ldA, h->n, h->dtn);
-                if (int e = sparse_engine_forward(h->sp, h->dtn, h->dAsct + (size_t)j * h->n, h->st)) return e;
-            }
+            if (int e = sparse_engine_forward_rows(h->sp, h->dA, h->ldA, h->p, h->dAsct, h->st)) return e;
             KKT_HIP_CHECK(hipMemsetAsync(h->pw.d_info, 0, sizeof(int), h->st));
             if (int e = launch_syrk_scaled(h->planK, h->dAsct, h->n, nullptr, h->dK, h->p, nullptr, 0, h->st)) return e;
             if (h->kktreg != 0.0) hipLaunchKernelGGL(diag_add_kernel, g1(h->p), dim3(256), 0, h->st, h->dK, (int64_t)h->p, h->p, h->kktreg);

@@ -152,7 +152,9 @@ struct SparseEngine {
     int64_t *d_sn_rowptr = nullptr, *d_panel_off = nullptr, *d_upd_off = nullptr, *d_relmap_off = nullptr,
             *d_asm_slot = nullptr, *d_asm_ptr = nullptr, *d_gcp = nullptr, *d_grp = nullptr, *d_rem_off = nullptr,
             *d_hrp = nullptr;
-    double *d_gv = nullptr, *d_hv = nullptr, *d_rem = nullptr, *d_panels = nullptr, *d_upd = nullptr, *d_xp = nullptr;
+    double *d_gv = nullptr, *d_hv = nullptr, *d_rem = nullptr, *d_panels = nullptr, *d_upd = nullptr, *d_xp = nullptr,
+           *d_rem_multi = nullptr;
+    int rem_multi_cols = 0;
 };
 int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const int64_t* gri, const int64_t* hcp,
                      const int64_t* hri);
@@ -162,7 +164,8 @@ void sparse_engine_free(SparseEngine& E);
 int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, int* info);
 int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st);
 int sparse_engine_forward(SparseEngine& E, const double* d_in, double* d_out_perm, hipStream_t st);   // E.d_xp = L^-1 P b
-int sparse_engine_backward(SparseEngine& E, double* d_out, hipStream_t st);                           // d_out = P' L^-T E.d_xp
+int sparse_engine_backward(SparseEngine& E, double* d_out, hipStream_t st);
+int sparse_engine_forward_rows(SparseEngine& E, const double* d_A, int64_t lda, int nrhs, double* d_out, hipStream_t st);                           // d_out = P' L^-T E.d_xp
 int sparse_engine_product(SparseEngine& E, int which, int trans, const double* d_in, double* d_out, hipStream_t st);
 int sparse_engine_products(SparseEngine& E, const double* d_x, const double* d_z, double* d_Gx, double* d_GTz, double* d_Px,
                            hipStream_t st);

@@ -801,8 +801,11 @@ __device__ __forceinline__ void sp_trsv_bwd_lds(const double* __restrict__ P, in
 // (by sp_fwd_rem_kernel, many workgroups, when the panel is large).
 __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, const double* __restrict__ panels,
                                                      double* __restrict__ x, double* __restrict__ rem,
-                                                     const int64_t* __restrict__ rem_off) {
+                                                     const int64_t* __restrict__ rem_off, int64_t xstride,
+                                                     int64_t remstride) {
     __shared__ double xs[256];
+    x += (int64_t)blockIdx.y * xstride;          // several right-hand sides: one grid row each
+    rem += (int64_t)blockIdx.y * remstride;
     const int s = d.level_sn[level_begin + blockIdx.x];
     const int tid = threadIdx.x;
     const int f = d.sn_first[s];
@@ -847,8 +850,11 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
 // R_s -= L21 y_s for the heavy supernodes of a level: grid (row chunks of 256, heavy supernodes)
 __global__ __launch_bounds__(256) void sp_fwd_rem_kernel(SpDev d, const int* __restrict__ heavy,
                                                          const double* __restrict__ panels, const double* __restrict__ x,
-                                                         double* __restrict__ rem, const int64_t* __restrict__ rem_off) {
+                                                         double* __restrict__ rem, const int64_t* __restrict__ rem_off,
+                                                         int64_t xstride, int64_t remstride) {
     __shared__ double xs[256];
+    x += (int64_t)blockIdx.z * xstride;
+    rem += (int64_t)blockIdx.z * remstride;
     const int s = heavy[blockIdx.y];
     const int f = d.sn_first[s];
     const int w = d.sn_first[s + 1] - f;
@@ -1078,7 +1084,7 @@ void sparse_engine_free(SparseEngine& E) {
     void* ptrs[] = {E.d_sn_first, E.d_sn_rowptr, E.d_sn_rows, E.d_panel_off, E.d_upd_off, E.d_child_ptr, E.d_child_list,
                     E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
-                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap};
+                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap, E.d_rem_multi};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
@@ -1147,13 +1153,49 @@ int sparse_engine_forward(SparseEngine& E, const double* d_in, double* d_out_per
         const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
         if (cnt > 0)
             hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp, E.d_rem,
-                               E.d_rem_off);
+                               E.d_rem_off, (int64_t)0, (int64_t)0);
         const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
         if (nh > 0)
             hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 255) / 256, nh), dim3(256), 0, st, d,
-                               E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp, E.d_rem, E.d_rem_off);
+                               E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp, E.d_rem, E.d_rem_off, (int64_t)0, (int64_t)0);
     }
     if (d_out_perm) KKT_HIP_CHECK(hipMemcpyAsync(d_out_perm, E.d_xp, sizeof(double) * E.n, hipMemcpyDeviceToDevice, st));
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// out (n x nrhs, permuted ordering, ld n) := L^-1 P A' for the nrhs rows of the dense A (nrhs x n, ld lda): all right-hand
+// sides go through the level-scheduled forward substitution together (one grid row per right-hand side)
+__global__ __launch_bounds__(256) void sp_gather_rows_kernel(const double* __restrict__ A, int64_t lda, const int* __restrict__ perm,
+                                                             int n, double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i < n) out[i + (int64_t)j * n] = A[j + (int64_t)perm[i] * lda];
+}
+int sparse_engine_forward_rows(SparseEngine& E, const double* d_A, int64_t lda, int nrhs, double* d_out, hipStream_t st) {
+    const SparseSymbolic& S = E.sym;
+    if (E.n == 0 || nrhs <= 0) return 0;
+    const SpDev d = devview(E);
+    const int64_t remtot = S.sn_rowptr[S.ns] - (int64_t)E.n;        // sum over supernodes of (h - w)
+    if (E.rem_multi_cols < nrhs) {
+        if (E.d_rem_multi) (void)hipFree(E.d_rem_multi);
+        E.d_rem_multi = nullptr;
+        KKT_HIP_CHECK(hipMalloc(&E.d_rem_multi, sizeof(double) * (size_t)(remtot > 0 ? remtot : 1) * nrhs));
+        E.rem_multi_cols = nrhs;
+    }
+    for (int j0 = 0; j0 < nrhs; j0 += 65535) {                      // grid.y / grid.z limit
+        const int nj = std::min(65535, nrhs - j0);
+        double* out = d_out + (size_t)j0 * E.n;
+        hipLaunchKernelGGL(sp_gather_rows_kernel, dim3((E.n + 255) / 256, nj), dim3(256), 0, st, d_A + j0, lda, E.d_perm, E.n, out);
+        for (int l = 0; l < S.nlevels; ++l) {
+            const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
+            if (cnt > 0)
+                hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt, nj), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, out, E.d_rem_multi,
+                                   E.d_rem_off, (int64_t)E.n, remtot);
+            const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
+            if (nh > 0)
+                hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 255) / 256, nh, nj), dim3(256), 0, st, d,
+                                   E.d_heavy + S.heavy_ptr[l], E.d_panels, out, E.d_rem_multi, E.d_rem_off, (int64_t)E.n, remtot);
+        }
+    }
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -176,7 +176,7 @@ def test_sparse_resident_coneqp_matches_dense_resident(maker, arg):
     assert relerr(a['x'], b['x']) < 1e-7 and relerr(a['z'], b['z']) < 1e-6
 
 
-@pytest.mark.parametrize("maker,arg,p", [(laplace2d, (30, 24), 5), (laplace3d, (10,), 12)])
+@pytest.mark.parametrize("maker,arg,p", [(laplace2d, (30, 24), 5), (laplace3d, (10,), 12), (laplace3d, (16,), 70)])
 def test_sparse_factor_solve_with_equalities_matches_dense_oracle(maker, arg, p):
     """p > 0 on the sparse engine: Asct = L^-1 P A' through the supernodal forward solve, K = Asct'Asct dense
     (reference misc.py:1464-1487 / :1528-1558, sparse branch) vs the dense NumPy oracle of the same KKT system."""
