@@ -336,6 +336,15 @@ class _Engine(object):
                 'gap': g, 'relative gap': relgap, 'primal objective': pcost, 'dual objective': dcost,
                 'iterations': iters.value}
 
+    def _slack(self, v):
+        """-max_step(v) (misc.py:1018-1052): min over the 'l' entries and v0 - ||v1|| per second-order cone"""
+        t = [float(np.min(v[:self.dims['l']]))] if self.dims['l'] else []
+        ind = self.dims['l']
+        for mk in self.dims['q']:
+            t.append(float(v[ind] - np.linalg.norm(v[ind + 1:ind + mk])))
+            ind += mk
+        return min(t) if t else 0.0
+
     def coneqp_cones(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None):
         """The reference coneqp loop (coneprog.py:2044-2547) for 'l' and 'q' cones resident on the device around this
         handle (`mi355kkt_coneqp`; refinement 1 with second-order cones like the reference)."""
@@ -360,7 +369,8 @@ class _Engine(object):
         gap, relgap, pcost, dcost, pres, dres = [float(v) for v in st]
         return {'x': x, 'y': y, 's': s, 'z': z, 'status': 'optimal' if status.value == 1 else 'unknown', 'gap': gap,
                 'relative gap': None if relgap >= 1e299 else relgap, 'primal objective': pcost, 'dual objective': dcost,
-                'primal infeasibility': pres, 'dual infeasibility': dres, 'iterations': iters.value}
+                'primal infeasibility': pres, 'dual infeasibility': dres, 'primal slack': self._slack(s),
+                'dual slack': self._slack(z), 'iterations': iters.value}
 
     def conelp(self, c, h, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None):
         """The reference conelp loop (coneprog.py:586-1436; 'l' and 'q' cones, default starting point) resident on the
@@ -387,14 +397,7 @@ class _Engine(object):
             raise ValueError("Rank(A) < p or Rank([G; A]) < n")           # coneprog.py:690-691
         _capi.check(rc, "mi355kkt_conelp")
         none = lambda v: None if v >= 1e299 else v
-
-        def slack(v):                               # -max_step(v): min over the 'l' entries and v0 - ||v1|| per cone
-            t = [float(np.min(v[:self.dims['l']]))] if self.dims['l'] else []
-            ind = self.dims['l']
-            for mk in self.dims['q']:
-                t.append(float(v[ind] - np.linalg.norm(v[ind + 1:ind + mk])))
-                ind += mk
-            return min(t) if t else 0.0
+        slack = self._slack
         gap, relgap, pcost, dcost, pres, dres, pinf, dinf, ts, tz = [float(v) for v in st]
         code = status.value
         out = {'iterations': iters.value}

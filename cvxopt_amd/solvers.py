@@ -4,6 +4,8 @@ operator + kktsolver plug-in API.
 The reference drivers accept G, A (and P) as Python callables instead of matrices (`conelp`: coneprog.py:521-550,
 `coneqp`: :1838-1917) as long as `kktsolver` is a callable too.  Here both are device backed:
 
+    * when the cones are 'l' / 'q' only and the default starting point is used, the whole loop runs on the device
+      (`cvxopt_amd.conelp_device` / `coneqp_device`; `device_loop=False` forces the host-driver path below),
     * `kktsolver`     = the GPU KKT engine of `cvxopt_amd.kkt` (factor + solves in HBM),
     * `G`, `A`, `P`   = closures around `mi355kkt_product`: y := alpha op(M) x + beta y with M resident in HBM
                         (for 's' cones with the trisc/triusc convention of misc.sgemv, misc.py:801-832),
@@ -67,11 +69,37 @@ def _operators(eng, dims):
     return Gop, Aop, Pop
 
 
-def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None, kktsolver='chol', **kwargs):
-    """cvxopt.solvers.conelp with G, A as device operators and the GPU kktsolver ('chol' | 'chol2' | 'ldl' | 'ldl2')."""
+def _as_cvxopt(sol):
+    """device-loop result (NumPy vectors) -> the reference's types (cvxopt 'd' matrices)"""
+    from cvxopt import matrix
+    out = dict(sol)
+    for k in ('x', 'y', 's', 'z'):
+        if out.get(k) is not None:
+            out[k] = matrix(np.asarray(out[k], dtype=float).reshape(-1, 1)) if len(out[k]) else matrix(0.0, (0, 1))
+    return out
+
+
+def _options(kwargs):
+    """solver options as the reference reads them (kwargs['options'] over solvers.options; coneprog.py:456-500)"""
+    from cvxopt import solvers
+    o = kwargs.get('options', solvers.options)
+    return dict(maxiters=o.get('maxiters', 100), abstol=o.get('abstol', 1e-7), reltol=o.get('reltol', 1e-6),
+                feastol=o.get('feastol', 1e-7), refinement=o.get('refinement', None)), o.get('kktreg', None)
+
+
+def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None, kktsolver='chol', device_loop='auto',
+           **kwargs):
+    """cvxopt.solvers.conelp on the MI355X, same signature and result dict.  Without 's' cones and with the default
+    starting point the whole loop runs on the device (`mi355kkt_conelp`); otherwise the reference driver runs on the
+    host with G, A as device operators and the GPU kktsolver ('chol' | 'chol2' | 'ldl' | 'ldl2')."""
     from cvxopt import solvers, spmatrix
     dims = _dims_of(h, dims)
     n = c.size[0]
+    extra = set(kwargs) - {'options'}
+    o, kktreg = _options(kwargs)
+    if device_loop and not dims['s'] and primalstart is None and dualstart is None and not extra \
+            and kktreg is None and (dims['l'] + sum(dims['q'])) > 0:
+        return _as_cvxopt(_kkt.conelp_device(c, G, h, dims, A, b, kktsolver={'qr': 'chol'}.get(kktsolver, kktsolver), **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
     ks = _kkt.kktsolver_lp(G, dims, Am, kind={'qr': 'chol'}.get(kktsolver, kktsolver))
     eng = ks.engine
@@ -86,8 +114,10 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
         eng.close()
 
 
-def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktsolver='chol2', **kwargs):
-    """cvxopt.solvers.coneqp with P, G, A as device operators and the GPU kktsolver."""
+def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktsolver='chol2', device_loop='auto',
+           **kwargs):
+    """cvxopt.solvers.coneqp on the MI355X, same signature and result dict.  Without 's' cones and initvals the whole loop
+    runs on the device (`mi355kkt_coneqp`); otherwise the reference driver runs with P, G, A as device operators."""
     from cvxopt import solvers, spmatrix, matrix
     n = q.size[0]
     if G is None:
@@ -95,6 +125,11 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
     dims = _dims_of(h, dims)
     if (dims['q'] or dims['s']) and kktsolver == 'chol2':
         kktsolver = 'chol'                      # like the reference's default for non-LP cones (coneprog.py:1775-1781)
+    extra = set(kwargs) - {'options'}
+    o, kktreg = _options(kwargs)
+    if device_loop and not dims['s'] and initvals is None and not extra and (dims['l'] + sum(dims['q'])) > 0 \
+            and kktreg is None:
+        return _as_cvxopt(_kkt.coneqp_device(P, q, G, h, dims, A, b, kktsolver=kktsolver, **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
     ks = _kkt.kktsolver_qp(G, dims, Am, P, kind=kktsolver)
     eng = ks.engine

@@ -35,6 +35,34 @@ def test_products_match_numpy():
     e.close()
 
 
+def test_default_dispatch_uses_device_loop_and_returns_reference_types(ref_cvxopt):
+    from cvxopt import matrix, solvers
+    import cvxopt_amd.solvers as gs
+    pr = synth.socp(n=40, ncones=10, r=5, seed=4, ml=6)
+    c, G, h, dims = matrix(pr['c']), matrix(pr['G']), matrix(pr['h']), pr['dims']
+    ref = solvers.conelp(c, G, h, dims)
+    dev = gs.conelp(c, G, h, dims)                       # 'l' + 'q' cones, default start: whole loop on the device
+    host = gs.conelp(c, G, h, dims, device_loop=False)   # reference driver + device operators
+    for sol in (dev, host):
+        _same(sol, ref, xt=1e-6)
+        assert isinstance(sol['x'], type(ref['x'])) and sol['x'].size == ref['x'].size
+        assert abs(sol['primal slack'] - ref['primal slack']) <= 1e-5 * abs(ref['primal slack']) + 1e-9
+    qp = synth.dense_qp(30, 70, seed=1, p=3)
+    P, q, Gq, hq = matrix(qp['P']), matrix(qp['q']), matrix(qp['G']), matrix(qp['h'])
+    A, b = matrix(qp['A']), matrix(qp['b'])
+    ref = solvers.coneqp(P, q, Gq, hq, A=A, b=b)
+    for sol in (gs.coneqp(P, q, Gq, hq, A=A, b=b), gs.coneqp(P, q, Gq, hq, A=A, b=b, device_loop=False)):
+        _same(sol, ref)
+        assert abs(sol['dual slack'] - ref['dual slack']) <= 1e-5 * abs(ref['dual slack']) + 1e-9
+    old = dict(solvers.options)
+    try:
+        solvers.options['maxiters'] = 3                  # options are honoured by the device loop like by the reference
+        assert gs.conelp(c, G, h, dims)['iterations'] == 3
+    finally:
+        solvers.options.clear()
+        solvers.options.update(old)
+
+
 def test_socp_config3_class_matches_reference(ref_cvxopt):
     """BASELINE configs[2] class scaled down: many small second-order cones through solvers.socp's path (conelp)."""
     from cvxopt import matrix, solvers
@@ -42,7 +70,7 @@ def test_socp_config3_class_matches_reference(ref_cvxopt):
     pr = synth.socp(n=96, ncones=48, r=8, seed=3, ml=10)
     c, G, h, dims = matrix(pr['c']), matrix(pr['G']), matrix(pr['h']), pr['dims']
     ref = solvers.conelp(c, G, h, dims)
-    sol = gs.conelp(c, G, h, dims)
+    sol = gs.conelp(c, G, h, dims, device_loop=False)
     _same(sol, ref)
     assert relerr(np.array(sol['z']).ravel(), np.array(ref['z']).ravel()) < 1e-6
 
@@ -91,7 +119,7 @@ def test_coneqp_with_soc_and_equalities_through_operators(ref_cvxopt):
     b = matrix(np.array(A) @ pr['x0']) if 'x0' in pr else matrix(np.zeros(p))
     q, G, h, dims = matrix(pr['c']), matrix(pr['G']), matrix(pr['h']), pr['dims']
     ref = solvers.coneqp(P, q, G, h, dims, A, b)
-    sol = gs.coneqp(P, q, G, h, dims, A, b)
+    sol = gs.coneqp(P, q, G, h, dims, A, b, device_loop=False)
     _same(sol, ref, xt=1e-6)
 
 
@@ -118,7 +146,7 @@ def test_socp_config3_full_size_timing(ref_cvxopt):
     from cvxopt_amd import kkt
     pr = synth.socp(n=2048, ncones=1024, r=8, seed=0)
     c, G, h, dims = matrix(pr['c']), matrix(pr['G']), matrix(pr['h']), pr['dims']
-    t = time.perf_counter(); sol = gs.conelp(c, G, h, dims); t_ops = time.perf_counter() - t
+    t = time.perf_counter(); sol = gs.conelp(c, G, h, dims, device_loop=False); t_ops = time.perf_counter() - t
     ks = kkt.kktsolver_lp(G, dims, spmatrix([], [], [], (0, 2048)))
     t = time.perf_counter(); hook = solvers.conelp(c, G, h, dims, kktsolver=ks); t_hook = time.perf_counter() - t
     ks.engine.close()
