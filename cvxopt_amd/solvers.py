@@ -175,3 +175,13 @@ def socp(c, Gl=None, hl=None, Gq=None, hq=None, A=None, b=None, **kwargs):
             ind += mk
         sol[key + 'q'] = parts
     return sol
+
+
+def lp(c, G, h, A=None, b=None, **kwargs):
+    """cvxopt.solvers.lp (coneprog.py:2562: conelp with dims = {'l': m})."""
+    return conelp(c, G, h, {'l': h.size[0], 'q': [], 's': []}, A, b, **kwargs)
+
+
+def qp(P, q, G=None, h=None, A=None, b=None, **kwargs):
+    """cvxopt.solvers.qp (coneprog.py:4258: coneqp with dims = {'l': m})."""
+    return coneqp(P, q, G, h, None, A, b, **kwargs)

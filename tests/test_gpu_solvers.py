@@ -63,6 +63,21 @@ def test_default_dispatch_uses_device_loop_and_returns_reference_types(ref_cvxop
         solvers.options.update(old)
 
 
+def test_lp_qp_wrappers(ref_cvxopt):
+    from cvxopt import matrix, solvers
+    import cvxopt_amd.solvers as gs
+    c = matrix([-4., -5.])
+    G = matrix([[2., 1., -1., 0.], [1., 2., 0., -1.]])
+    h = matrix([3., 3., 0., 0.])
+    sol = gs.lp(c, G, h)                                  # reference tests/test_examples.py:31-34: x = [1, 1]
+    ref = solvers.lp(c, G, h)
+    _same(sol, ref)
+    assert np.allclose(np.array(sol['x']).ravel(), [1.0, 1.0], atol=1e-6)
+    qp = synth.dense_qp(20, 50, seed=9)
+    ref = solvers.qp(matrix(qp['P']), matrix(qp['q']), matrix(qp['G']), matrix(qp['h']))
+    _same(gs.qp(matrix(qp['P']), matrix(qp['q']), matrix(qp['G']), matrix(qp['h'])), ref)
+
+
 def test_socp_config3_class_matches_reference(ref_cvxopt):
     """BASELINE configs[2] class scaled down: many small second-order cones through solvers.socp's path (conelp)."""
     from cvxopt import matrix, solvers
