@@ -31,19 +31,38 @@ class BatchKkt(object):
 
     def __init__(self, Gt, P=None, device=0):
         self.L = _capi.lib()
-        Gt = np.ascontiguousarray(Gt, dtype=np.float64)
-        self.B, self.n, self.m = Gt.shape
         if _capi.device_count() <= 0:
             raise RuntimeError("cvxopt_amd.batch: no HIP device visible (there is no CPU fallback)")
+        on_device = hasattr(Gt, "data_ptr")                       # torch CUDA tensors: the data is already in HBM
+        if on_device:
+            if not (Gt.is_cuda and Gt.is_contiguous() and Gt.dtype.is_floating_point and Gt.element_size() == 8):
+                raise TypeError("Gt must be a contiguous float64 CUDA tensor")
+            device = Gt.device.index if Gt.device.index is not None else device
+            self.B, self.n, self.m = (int(v) for v in Gt.shape)
+            gptr = Gt.data_ptr()
+        else:
+            Gt = np.ascontiguousarray(Gt, dtype=np.float64)
+            self.B, self.n, self.m = Gt.shape
+            gptr = Gt.ctypes.data
         h = C.c_void_p()
         _capi.check(self.L.mi355kkt_batch_create(C.byref(h), device, self.B, self.n, self.m), "batch_create")
         self.h = h
         Pp = None
         if P is not None:
-            P = np.ascontiguousarray(P, dtype=np.float64)        # symmetric: C order == column-major
-            assert P.shape == (self.B, self.n, self.n)
-            Pp = P.ctypes.data
-        _capi.check(self.L.mi355kkt_batch_set_problem(h, Gt.ctypes.data, Pp, 0), "batch_set_problem")
+            if on_device:
+                if not (hasattr(P, "data_ptr") and P.is_cuda and P.is_contiguous() and P.element_size() == 8):
+                    raise TypeError("P must be a contiguous float64 CUDA tensor when Gt is one")
+                assert tuple(P.shape) == (self.B, self.n, self.n)
+                Pp = P.data_ptr()
+            else:
+                P = np.ascontiguousarray(P, dtype=np.float64)        # symmetric: C order == column-major
+                assert P.shape == (self.B, self.n, self.n)
+                Pp = P.ctypes.data
+        if on_device:
+            import torch
+            torch.cuda.synchronize(Gt.device)                     # the copies below run on the library's own stream
+        _capi.check(self.L.mi355kkt_batch_set_problem(h, C.c_void_p(gptr), C.c_void_p(Pp) if Pp else None,
+                                                      1 if on_device else 0), "batch_set_problem")
 
     def factor(self, di):
         di = np.ascontiguousarray(di, dtype=np.float64)
@@ -316,12 +335,18 @@ def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, dev
             buf = torch.empty((mx,) + tail_shape, dtype=torch.float64, device=dev)
             dist.scatter(buf, None, src=root, group=group)
         recv.copy_(buf[:hi - lo])
-        return recv.cpu().numpy()
+        return recv
 
-    q_l = scatter(q, (n,))
-    h_l = scatter(h, (m,))
+    # with RCCL the scattered shard of G and P lands in this rank's HBM over xGMI and STAYS there (BatchKkt takes the
+    # device pointers); only the small q, h go to the host, where the loop's inputs are staged
+    keep_on_device = (backend == "nccl" and local_solver is None and opts.get("resident", True))
+    q_l = scatter(q, (n,)).cpu().numpy()
+    h_l = scatter(h, (m,)).cpu().numpy()
     G_l = scatter(Gt, (n, m))
     P_l = scatter(P, (n, n)) if hasP else None
+    if not keep_on_device:
+        G_l = G_l.cpu().numpy()
+        P_l = P_l.cpu().numpy() if P_l is not None else None
 
     if hi > lo:
         if local_solver is None:

@@ -122,6 +122,20 @@ def test_resident_loop_iteration_limit_and_rank_failure():
         coneqp_batch(P, q, Gt, h, resident=True)
 
 
+def test_batchkkt_takes_problem_data_already_in_hbm():
+    """torch CUDA tensors (e.g. the shard an RCCL scatter delivered) are taken by device pointer: no host round trip."""
+    import torch
+    probs = [synth.dense_qp(48, 100, seed=70 + i) for i in range(6)]
+    P, q, Gt, h = pack_problems(probs)
+    host = coneqp_batch(P, q, Gt, h, resident=True)
+    Gd, Pd = torch.from_numpy(np.ascontiguousarray(Gt)).cuda(), torch.from_numpy(np.ascontiguousarray(P)).cuda()
+    dev = coneqp_batch(Pd, q, Gd, h, resident=True)
+    assert np.array_equal(dev['iterations'], host['iterations'])
+    assert np.array_equal(dev['x'], host['x'])            # same kernels, same data: bit-identical
+    with pytest.raises(TypeError):
+        BatchKkt(Gd.float(), None)
+
+
 def test_sharded_batch_on_rccl():
     """coneqp_batch_sharded on the real nccl (= RCCL) backend, launched like bench.py is (torch.distributed.run)."""
     import os
