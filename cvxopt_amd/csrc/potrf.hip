@@ -480,46 +480,12 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
         KKT_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    static const int outer1_max_n = getenv("MI355KKT_POTRF_OUTER1") ? atoi(getenv("MI355KKT_POTRF_OUTER1")) : 5120;
-    if (nbatch == 1 && n >= 8 * NB && w.side && lookahead_streams == 2 && n <= outer1_max_n) {
-        // moderate n: the chain of panels dominates, the bulk is small -> outer panel = one 128-column panel (shorter chain per
-        // column: potf2 + trsm + one K=128 skinny update), rank-128 bulk updates on the side stream
-        const int nsteps = (n + NB - 1) / NB;
-        while ((int)w.ev_panel.size() < nsteps + 1) {
-            hipEvent_t e1, e2;
-            KKT_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-            KKT_HIP_CHECK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-            w.ev_panel.push_back(e1);
-            w.ev_bulk.push_back(e2);
-        }
-        int step = 0;
-        bool bulk_pending = false;
-        for (int k0 = 0; k0 < n; k0 += NB, ++step) {
-            const int nb1 = (n - k0 < NB) ? (n - k0) : NB;
-            if (int e = panel(k0, nb1)) return e;
-            const int k2 = k0 + nb1;
-            if (k2 >= n) break;
-            const int wnext = (n - k2 < NB) ? (n - k2) : NB;
-            const double* Lp = A + k2 + (int64_t)k0 * lda;
-            if (bulk_pending) KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_bulk[step - 1], 0));
-            if (int e = launch_gemm_nt_update(A + k2 + (int64_t)k2 * lda, lda, Lp, lda, Lp, lda, n - k2, wnext, nb1, st)) return e;
-            KKT_HIP_CHECK(hipEventRecord(w.ev_panel[step], st));
-            const int k3 = k2 + wnext;
-            if (k3 < n) {
-                KKT_HIP_CHECK(hipStreamWaitEvent(w.side, w.ev_panel[step], 0));
-                if (int e = launch_syrk_nt_update(A + k3 + (int64_t)k3 * lda, lda, A + k3 + (int64_t)k0 * lda, lda, n - k3, nb1, w.side))
-                    return e;
-                KKT_HIP_CHECK(hipEventRecord(w.ev_bulk[step], w.side));
-                bulk_pending = true;
-            } else {
-                bulk_pending = false;
-            }
-        }
-        if (bulk_pending) KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_bulk[step > 0 ? step - 1 : 0], 0));
-        return 0;
-    }
+    static const int outer1_max_n = getenv("MI355KKT_POTRF_OUTER1") ? atoi(getenv("MI355KKT_POTRF_OUTER1")) : 4096;
     if (nbatch == 1 && n >= 8 * NB && w.side && lookahead_streams == 2) {
-        const int nsteps = (n + 2 * NB - 1) / (2 * NB);
+        // Outer panels of two 128-column sub-panels while the trailing matrix is large (rank-256 bulk updates touch it half
+        // as often), of ONE sub-panel once at most outer1_max_n columns remain: there the chain of panel kernels dominates
+        // and potf2 + trsm + one K=128 skinny update per 128 columns is the shorter chain.
+        const int nsteps = (n + NB - 1) / NB + 1;
         while ((int)w.ev_panel.size() < nsteps + 1) {
             hipEvent_t e1, e2;
             KKT_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
@@ -529,20 +495,26 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
         }
         int step = 0;
         bool bulk_pending = false;
-        for (int k0 = 0; k0 < n; k0 += 2 * NB, ++step) {
+        auto width_at = [&](int k) { return (n - k > outer1_max_n) ? 2 * NB : NB; };   // outer-panel width that starts at column k
+        for (int k0 = 0; k0 < n; ++step) {
+            const bool two = width_at(k0) == 2 * NB;
             const int nb1 = (n - k0 < NB) ? (n - k0) : NB;
             if (int e = panel(k0, nb1)) return e;
-            const int k1 = k0 + nb1;
-            if (k1 >= n) break;
-            const int nb2 = (n - k1 < NB) ? (n - k1) : NB;
-            if (int e = launch_gemm_nt_update(A + k1 + (int64_t)k1 * lda, lda, A + k1 + (int64_t)k0 * lda, lda,
-                                              A + k1 + (int64_t)k0 * lda, lda, n - k1, nb2, nb1, st))
-                return e;
-            if (int e = panel(k1, nb2)) return e;
-            const int k2 = k1 + nb2;
+            int k2 = k0 + nb1;
             if (k2 >= n) break;
-            const int K = nb1 + nb2;
-            const int wnext = (n - k2 < 2 * NB) ? (n - k2) : 2 * NB;      // width of the next outer panel
+            if (two) {
+                const int k1 = k2;
+                const int nb2 = (n - k1 < NB) ? (n - k1) : NB;
+                if (int e = launch_gemm_nt_update(A + k1 + (int64_t)k1 * lda, lda, A + k1 + (int64_t)k0 * lda, lda,
+                                                  A + k1 + (int64_t)k0 * lda, lda, n - k1, nb2, nb1, st))
+                    return e;
+                if (int e = panel(k1, nb2)) return e;
+                k2 = k1 + nb2;
+                if (k2 >= n) break;
+            }
+            const int K = k2 - k0;
+            int wnext = width_at(k2);
+            if (wnext > n - k2) wnext = n - k2;
             const double* Lp = A + k2 + (int64_t)k0 * lda;                // rows k2.., panel columns
             // the previous bulk update wrote the region both updates below touch
             if (bulk_pending) KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_bulk[step - 1], 0));
@@ -564,6 +536,7 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
             } else {
                 bulk_pending = false;
             }
+            k0 = k2;
         }
         if (bulk_pending) KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_bulk[step > 0 ? step - 1 : 0], 0));
         return 0;
