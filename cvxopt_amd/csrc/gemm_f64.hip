@@ -526,12 +526,133 @@ __global__ __launch_bounds__(256, 2) void nt_update_kernel(double* __restrict__ 
             }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Short-tile variants for the skinny updates on the Cholesky critical path (a few dozen 128 x 128 tiles on 256 CUs):
+// a workgroup owns a 64 or 32 (rows) x 128 (columns) tile, the four waves split the columns (32 each, 2 x 4 or 2 x 2 MFMA
+// tiles).  Two / four times as many workgroups, a half / quarter of the MFMA work each: the kernel's latency is one short tile.
+// ---------------------------------------------------------------------------------------------------
+template <bool FAST, int ROWS>
+__device__ __forceinline__ void nt_load_rows(const double* __restrict__ X, int64_t ldx, int row0, int nrows, int k0, int K,
+                                             int tid, double (&reg)[ROWS / 16]) {
+    constexpr int TPK = ROWS / 2, KPP = 256 / TPK, PASSES = BK / KPP;    // threads per k, k rows per pass, passes
+    const int ip = (tid % TPK) * 2;
+#pragma unroll
+    for (int r = 0; r < PASSES; ++r) {
+        const int k = k0 + tid / TPK + KPP * r;
+        const double* p = X + (int64_t)k * ldx + row0 + ip;
+        if (FAST) {
+            const d2u v = *reinterpret_cast<const d2u*>(p);
+            reg[2 * r] = v.x;
+            reg[2 * r + 1] = v.y;
+        } else {
+            const bool kok = k < K;
+            reg[2 * r] = (kok && row0 + ip < nrows) ? p[0] : 0.0;
+            reg[2 * r + 1] = (kok && row0 + ip + 1 < nrows) ? p[1] : 0.0;
+        }
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void nt_store_rows(double* __restrict__ Xs, int tid, const double (&reg)[ROWS / 16]) {
+    constexpr int TPK = ROWS / 2, KPP = 256 / TPK, PASSES = BK / KPP;
+    const int ip = (tid % TPK) * 2;
+#pragma unroll
+    for (int r = 0; r < PASSES; ++r) {
+        const int k = tid / TPK + KPP * r;
+        d2 v = {reg[2 * r], reg[2 * r + 1]};
+        *reinterpret_cast<d2*>(Xs + k * LDT_M + ip) = v;
+    }
+}
+
+// ROWS = 64 or 32 rows of C per workgroup, 128 columns (32 per wave)
+template <int ROWS>
+__global__ __launch_bounds__(256, 2) void nt_update_short_kernel(double* __restrict__ C, int64_t ldc,
+                                                                 const double* __restrict__ A, int64_t lda,
+                                                                 const double* __restrict__ B, int64_t ldb,
+                                                                 int M, int N, int K, int fast_ok) {
+    constexpr int UI = ROWS / 16;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wj = tid >> 6;
+    const int i0 = ti * ROWS, j0 = tj * TILE;
+    const bool tile_fast = fast_ok && (i0 + ROWS <= M) && (j0 + TILE <= N);
+    auto sJ = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES; };
+    auto sI = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES + STAGE_DOUBLES; };
+    const int nkt = (K + BK - 1) / BK;
+    double rJ[8], rI[ROWS / 16];
+    auto fetch = [&](int kt) {
+        const bool fast = tile_fast && ((kt + 1) * BK <= K);
+        if (fast) {
+            nt_load<true>(B, ldb, j0, N, kt * BK, K, tid, rJ);
+            nt_load_rows<true, ROWS>(A, lda, i0, M, kt * BK, K, tid, rI);
+        } else {
+            nt_load<false>(B, ldb, j0, N, kt * BK, K, tid, rJ);
+            nt_load_rows<false, ROWS>(A, lda, i0, M, kt * BK, K, tid, rI);
+        }
+    };
+    auto stash = [&](int s) {      // the J operand is stored negated: the MFMAs then accumulate C - A B'
+        double nJ[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nJ[q] = -rJ[q];
+        nt_store(sJ(s), tid, nJ);
+        nt_store_rows<ROWS>(sI(s), tid, rI);
+    };
+    if (nkt > 0) fetch(0);
+    const int li = lane & 15, lq = lane >> 4;
+    d4 acc[2][UI];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < UI; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + u * 16 + li;
+                const int j = j0 + wj * 32 + t * 16 + lq + 4 * r;
+                acc[t][u][r] = (i < M && j < N) ? C[i + (int64_t)j * ldc] : 0.0;
+            }
+    if (nkt > 0) stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) fetch(kt + 1);
+        const double* __restrict__ Js = sJ(cur) + wj * 32;
+        const double* __restrict__ Is = sI(cur);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 4) {
+            double a[2], b[UI];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) a[t] = Js[(t * 16 + li) + (kk + lq) * LDT_M];
+#pragma unroll
+            for (int u = 0; u < UI; ++u) b[u] = Is[(u * 16 + li) + (kk + lq) * LDT_M];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < UI; ++u) acc[t][u] = MFMA_F64(a[t], b[u], acc[t][u]);
+        }
+        if (kt + 1 < nkt) stash(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < UI; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + u * 16 + li;
+                const int j = j0 + wj * 32 + t * 16 + lq + 4 * r;
+                if (i < M && j < N) C[i + (int64_t)j * ldc] = acc[t][u][r];
+            }
+}
+
 static int nt_attr() {
     static bool done = false;
     if (!done) {
         KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLdsWide));
         KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_short_kernel<64>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_short_kernel<32>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
         done = true;
     }
@@ -568,6 +689,20 @@ int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, 
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     if (int e = nt_attr()) return e;
     const int fast_ok = (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 7) == 0) ? 1 : 0;
+    // skinny updates of the Cholesky chain (few tiles): half-height tiles, twice the workgroups, half the latency
+    static const bool half_ok = getenv("MI355KKT_NO_HALF_TILES") == nullptr;
+    const int full_tiles = ((M + TILE - 1) / TILE) * ((N + TILE - 1) / TILE);
+    static const int quarter_max = getenv("MI355KKT_QUARTER_TILES") ? atoi(getenv("MI355KKT_QUARTER_TILES")) : 128;
+    if (half_ok && nbatch == 1 && full_tiles <= 192) {
+        if (full_tiles <= quarter_max)
+            hipLaunchKernelGGL(nt_update_short_kernel<32>, dim3((M + 31) / 32, (N + TILE - 1) / TILE), dim3(256), kGemmLds, st, C, ldc,
+                               A, lda, B, ldb, M, N, K, fast_ok);
+        else
+            hipLaunchKernelGGL(nt_update_short_kernel<64>, dim3((M + 63) / 64, (N + TILE - 1) / TILE), dim3(256), kGemmLds, st, C, ldc,
+                               A, lda, B, ldb, M, N, K, fast_ok);
+        KKT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(nt_update_kernel<false>, dim3((M + TILE - 1) / TILE, (N + TILE - 1) / TILE, nbatch), dim3(256),
                        kGemmLds, st, C, ldc, A, lda, B, ldb, M, N, K, fast_ok, bstride, nullptr);
     KKT_HIP_CHECK(hipGetLastError());
