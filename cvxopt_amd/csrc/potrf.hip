@@ -480,7 +480,7 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
         KKT_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    static const int outer1_max_n = getenv("MI355KKT_POTRF_OUTER1") ? atoi(getenv("MI355KKT_POTRF_OUTER1")) : 4096;
+    static const int outer1_max_n = getenv("MI355KKT_POTRF_OUTER1") ? atoi(getenv("MI355KKT_POTRF_OUTER1")) : 2048;
     if (nbatch == 1 && n >= 8 * NB && w.side && lookahead_streams == 2) {
         // Outer panels of two 128-column sub-panels while the trailing matrix is large (rank-256 bulk updates touch it half
         // as often), of ONE sub-panel once at most outer1_max_n columns remain: there the chain of panel kernels dominates
