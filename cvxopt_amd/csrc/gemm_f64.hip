@@ -564,16 +564,31 @@ __device__ __forceinline__ void nt_store_rows(double* __restrict__ Xs, int tid, 
 }
 
 // ROWS = 64 or 32 rows of C per workgroup, 128 columns (32 per wave)
-template <int ROWS>
+template <int ROWS, bool VB>
 __global__ __launch_bounds__(256, 2) void nt_update_short_kernel(double* __restrict__ C, int64_t ldc,
                                                                  const double* __restrict__ A, int64_t lda,
                                                                  const double* __restrict__ B, int64_t ldb,
-                                                                 int M, int N, int K, int fast_ok) {
+                                                                 int M, int N, int K, int fast_ok,
+                                                                 const VbDesc* __restrict__ vb) {
     constexpr int UI = ROWS / 16;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int ti = blockIdx.x, tj = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wj = tid >> 6;
     const int i0 = ti * ROWS, j0 = tj * TILE;
+    if (VB) {      // fronts of a sparse level (symmetric update, lower part): K carries the panel offset k0; C = A = B = base
+        const VbDesc dd = vb[blockIdx.z];
+        const int k0 = K;
+        if (k0 >= dd.w) return;
+        const int nb = min(128, dd.w - k0);
+        const int m = dd.h - k0 - nb;
+        if (i0 >= m || j0 >= m || i0 + ROWS - 1 < j0) return;      // outside the front / strictly above the diagonal
+        ldc = lda = ldb = dd.h;
+        A += dd.off + (k0 + nb) + (int64_t)k0 * dd.h;
+        B = A;
+        C += dd.off + (k0 + nb) + (int64_t)(k0 + nb) * dd.h;
+        M = N = m;
+        K = nb;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wj = tid >> 6;
     const bool tile_fast = fast_ok && (i0 + ROWS <= M) && (j0 + TILE <= N);
     auto sJ = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES; };
     auto sI = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES + STAGE_DOUBLES; };
@@ -607,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void nt_update_short_kernel(double* __restr
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + u * 16 + li;
                 const int j = j0 + wj * 32 + t * 16 + lq + 4 * r;
-                acc[t][u][r] = (i < M && j < N) ? C[i + (int64_t)j * ldc] : 0.0;
+                acc[t][u][r] = (i < M && j < N && (!VB || i >= j)) ? C[i + (int64_t)j * ldc] : 0.0;
             }
     if (nkt > 0) stash(0);
     __syncthreads();
@@ -639,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void nt_update_short_kernel(double* __restr
             for (int r = 0; r < 4; ++r) {
                 const int i = i0 + u * 16 + li;
                 const int j = j0 + wj * 32 + t * 16 + lq + 4 * r;
-                if (i < M && j < N) C[i + (int64_t)j * ldc] = acc[t][u][r];
+                if (i < M && j < N && (!VB || i >= j)) C[i + (int64_t)j * ldc] = acc[t][u][r];
             }
 }
 
@@ -650,9 +665,11 @@ static int nt_attr() {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLdsWide));
         KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_short_kernel<64>),
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nt_update_short_kernel<64, false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(nt_update_short_kernel<32>),
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nt_update_short_kernel<32, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nt_update_short_kernel<32, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
         done = true;
     }
@@ -678,6 +695,14 @@ int launch_syrk_nt_update_vb(double* base, const VbDesc* d_desc, int nfronts, in
     if (int e = nt_attr()) return e;
     const int nt = (maxh - k0 - 1 + TILE - 1) / TILE;
     if (nt <= 0) return 0;
+    // few tiles in the whole level (the top of the supernodal tree): 32-row tiles, four times the workgroups
+    static const int vb_short_max = getenv("MI355KKT_VB_SHORT_TILES") ? atoi(getenv("MI355KKT_VB_SHORT_TILES")) : 1024;
+    if ((int64_t)nfronts * (nt * (nt + 1) / 2) <= vb_short_max) {
+        hipLaunchKernelGGL((nt_update_short_kernel<32, true>), dim3((maxh - k0 - 1 + 31) / 32, nt, nfronts), dim3(256), kGemmLds, st, base,
+                           (int64_t)0, base, (int64_t)0, base, (int64_t)0, 0, 0, k0, 1, d_desc);
+        KKT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(nt_update_kernel<true>, dim3(nt * (nt + 1) / 2, 1, nfronts), dim3(256), kGemmLds, st, base, (int64_t)0,
                        base, (int64_t)0, base, (int64_t)0, 0, 0, k0, 1, (int64_t)0, d_desc);
     KKT_HIP_CHECK(hipGetLastError());
@@ -695,11 +720,11 @@ int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, 
     static const int quarter_max = getenv("MI355KKT_QUARTER_TILES") ? atoi(getenv("MI355KKT_QUARTER_TILES")) : 128;
     if (half_ok && nbatch == 1 && full_tiles <= 192) {
         if (full_tiles <= quarter_max)
-            hipLaunchKernelGGL(nt_update_short_kernel<32>, dim3((M + 31) / 32, (N + TILE - 1) / TILE), dim3(256), kGemmLds, st, C, ldc,
-                               A, lda, B, ldb, M, N, K, fast_ok);
+            hipLaunchKernelGGL((nt_update_short_kernel<32, false>), dim3((M + 31) / 32, (N + TILE - 1) / TILE), dim3(256), kGemmLds, st, C, ldc,
+                               A, lda, B, ldb, M, N, K, fast_ok, nullptr);
         else
-            hipLaunchKernelGGL(nt_update_short_kernel<64>, dim3((M + 63) / 64, (N + TILE - 1) / TILE), dim3(256), kGemmLds, st, C, ldc,
-                               A, lda, B, ldb, M, N, K, fast_ok);
+            hipLaunchKernelGGL((nt_update_short_kernel<64, false>), dim3((M + 63) / 64, (N + TILE - 1) / TILE), dim3(256), kGemmLds, st, C, ldc,
+                               A, lda, B, ldb, M, N, K, fast_ok, nullptr);
         KKT_HIP_CHECK(hipGetLastError());
         return 0;
     }
