@@ -34,9 +34,10 @@ def parse():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--m", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="dense", choices=["dense", "batch", "sparse"],
-                    help="dense = BASELINE configs[1] (the headline line, default); batch = configs[4] class "
-                         "(independent n=512 problems, sharded over ranks); sparse = configs[3] class (3-D Laplacian box-QP)")
+    ap.add_argument("--workload", default="dense", choices=["dense", "batch", "sparse", "socp"],
+                    help="dense = BASELINE configs[1] (the headline line, default; --n 256 --m 512 gives configs[0]); "
+                         "batch = configs[4] class (independent n=512 problems, sharded over ranks); sparse = configs[3] "
+                         "class (3-D Laplacian box-QP); socp = configs[2] (n=2048, 1024 second-order cones of dimension 8)")
     ap.add_argument("--batch", type=int, default=512, help="problems per GPU for --workload batch")
     ap.add_argument("--grid", type=int, default=46, help="k for the k^3 Laplacian of --workload sparse")
     ap.add_argument("--cpu-iters", type=int, default=2, help="reference CPU iterations timed (bounded sample)")
@@ -218,8 +219,61 @@ def main_sparse(args):
         dist.destroy_process_group()
 
 
+def main_socp(args):
+    """configs[2]: SOCP, n=2048, 1024 cones of dimension 8 (cdim 8192); a step = what one conelp iteration asks of the
+    kktsolver hook with second-order cones: 1 factor(W) + 5 solves (refinement 1: (x1,y1,z1) + 2 right-hand sides x 2)."""
+    rank, world, local_rank, torch, dist = _dist_setup()
+    import numpy as np
+    from cvxopt_amd import kkt, synth, _capi
+    import cvxopt_amd
+    kkt.options["device"] = local_rank
+    n, ncones, r = 2048, 1024, 8
+    pr = synth.socp(n=n, ncones=ncones, r=r, seed=rank)
+    cdim = ncones * r
+    W = synth.random_scaling(pr['dims'], seed=100 + rank, spread=1.0)
+    f = kkt.kkt_chol(pr['G'], pr['dims'], np.zeros((0, n)))
+    eng = f.engine
+    f(W)                                                   # first call: uploads, allocations
+    rng = np.random.default_rng(rank)
+    v = np.concatenate([np.asarray(vk, dtype=float).ravel() for vk in W['v']])
+    d_v = _capi.DeviceBuffer.from_array(v)
+    d_beta = _capi.DeviceBuffer.from_array(np.array([float(b) for b in W['beta']]))
+    rhs = [(_capi.DeviceBuffer.from_array(rng.standard_normal(n)), _capi.DeviceBuffer.from_array(rng.standard_normal(cdim)))
+           for _ in range(5)]
+    d_y = _capi.DeviceBuffer(8)
+
+    def step():
+        eng.factor_device(v_ptr=d_v.ptr, beta_ptr=d_beta.ptr)
+        for dx, dz in rhs:
+            eng.solve_device(dx.ptr, d_y.ptr, dz.ptr)
+        eng.sync()
+    elapsed = _timed(step, args, torch, dist)
+    tm = eng.timings()
+    e2e = None
+    if rank == 0:
+        for _ in range(2):
+            t1 = time.perf_counter()
+            sol = cvxopt_amd.conelp_device(pr['c'], pr['G'], pr['h'], pr['dims'])
+            t1 = time.perf_counter() - t1
+        e2e = {"solver": "device-resident conelp loop (mi355kkt_conelp)", "status": sol['status'], "iterations": sol['iterations'],
+               "seconds": round(t1, 4)}
+        print(json.dumps({
+            "metric": "SOCP KKT factor+solve ms/iter (BASELINE configs[2])", "value": round(world * args.steps / elapsed, 3),
+            "unit": "KKT iterations/s (1 factor + 5 solves each)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "conelp SOCP n=%d, %d second-order cones of dimension %d (cdim %d); hook = 1 factor(W) + 5 "
+                                   "solve(x,y,z) per step, inputs resident in HBM" % (n, ncones, r, cdim), "replicas": world},
+            "phases_ms": {k: round(v, 3) for k, v in tm.items()}, "ipm_end_to_end": e2e}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.workload == "socp":
+        return main_socp(args)
     if args.workload == "batch":
         return main_batch(args)
     if args.workload == "sparse":
@@ -322,8 +376,9 @@ def main():
             "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: coneqp dense QP n=%d, m=%d, p=0, LP cone; kktsolver hook "
-                                   "= 1 factor(W,P) + 2 solve(x,y,z) per step, inputs resident in HBM" % (n, m),
+            "config": {"workload": "BASELINE configs[%d]: coneqp dense QP n=%d, m=%d, p=0, LP cone; kktsolver hook "
+                                   "= 1 factor(W,P) + 2 solve(x,y,z) per step, inputs resident in HBM"
+                                   % (0 if (n, m) == (256, 512) else 1, n, m),
                        "replicas": world, "formulation": "reduced S = P + G'D^2G, Cholesky (kkt_chol2/ldl engine)"},
             "phases_ms": {k: round(v, 3) for k, v in tm.items()},
             "ipm_end_to_end": ipm,
