@@ -16,6 +16,7 @@
 
 #include "../../include/mi355kkt.h"
 #include "kkt_common.h"
+#include "cone_ops.h"
 #include <functional>
 
 namespace mi355kkt {
@@ -1621,6 +1622,28 @@ int mi355kkt_debug_hwid(unsigned* out, int nblocks) {
     hipLaunchKernelGGL(hwid_probe_kernel, dim3(nblocks), dim3(64), 0, nullptr, d);
     KKT_HIP_CHECK(hipMemcpy(out, d, sizeof(unsigned) * 2 * nblocks, hipMemcpyDeviceToHost));
     (void)hipFree(d);
+    return 0;
+}
+/* Host execution of the second-order-cone operations the device-resident loops use (the SAME source, cone_ops.h, compiled
+ * for the host): for the CPU parity tests against the reference's misc / misc_solvers functions.  One cone of dimension mk.
+ * op: 0 sprod (x := x o y), 1 sinv (x := y o\ x), 2 ssqr (x := y o y), 3 scale2 (x := H(y^{1/2}) x; inverse: arg),
+ * 4 scale (x := W x with v = y, beta = w[0]; inverse: arg), 5 jnrm2 -> w[0], 6 compute_scaling (s = x, z = y -> v = w[0:mk],
+ * lambda = w[mk:2mk], beta = w[2mk]), 7 update_scaling (s = x, z = y normalised in place; v = w[0:mk], lambda = w[mk:2mk],
+ * beta = w[2mk] updated), 8 max_step term ||x1|| - x0 -> w[0]. */
+int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w) {
+    if (mk < 1 || !x) return MI355KKT_EINVAL;
+    switch (op) {
+        case 0: mi355kkt::q_sprod(x, y, mk); break;
+        case 1: mi355kkt::q_sinv(x, y, mk); break;
+        case 2: mi355kkt::q_ssqr(x, y, mk); break;
+        case 3: mi355kkt::q_scale2(y, x, mk, arg != 0); break;
+        case 4: mi355kkt::q_scale(x, y, w[0], mk, arg != 0); break;
+        case 5: w[0] = mi355kkt::q_jnrm2(x, mk); break;
+        case 6: mi355kkt::q_compute_scaling(x, y, w, w + 2 * mk, w + mk, mk); break;
+        case 7: mi355kkt::q_update_scaling(x, y, w, w + 2 * mk, w + mk, mk); break;
+        case 8: w[0] = mi355kkt::q_nrm1(x, mk) - x[0]; break;
+        default: return MI355KKT_EINVAL;
+    }
     return 0;
 }
 int mi355kkt_debug_potf2_skip(int mask) { return mi355kkt::set_potf2_skip(mask); }

@@ -33,23 +33,23 @@ __device__ __forceinline__ double lp_dot(const double* a, const double* b, int n
 }
 
 // ---- second-order-cone pieces, one cone (x: the cone's own entries, mk of them) -----------------------------
-__device__ __forceinline__ double q_nrm1(const double* x, int mk) {      // ||x[1:]||
+__host__ __device__ __forceinline__ double q_nrm1(const double* x, int mk) {      // ||x[1:]||
     double a = 0.0;
     for (int i = 1; i < mk; ++i) a += x[i] * x[i];
     return sqrt(a);
 }
-__device__ __forceinline__ double q_jnrm2(const double* x, int mk) {     // misc.py:848-857
+__host__ __device__ __forceinline__ double q_jnrm2(const double* x, int mk) {     // misc.py:848-857
     const double a = q_nrm1(x, mk);
     return sqrt(x[0] - a) * sqrt(x[0] + a);
 }
-__device__ __forceinline__ void q_sprod(double* x, const double* y, int mk) {           // x := x o y
+__host__ __device__ __forceinline__ void q_sprod(double* x, const double* y, int mk) {           // x := x o y
     double a = 0.0;
     for (int i = 0; i < mk; ++i) a += y[i] * x[i];
     const double x0 = x[0], y0 = y[0];
     for (int i = 1; i < mk; ++i) x[i] = y0 * x[i] + x0 * y[i];
     x[0] = a;
 }
-__device__ __forceinline__ void q_sinv(double* x, const double* y, int mk) {            // x := y o\ x
+__host__ __device__ __forceinline__ void q_sinv(double* x, const double* y, int mk) {            // x := y o\ x
     double a = q_nrm1(y, mk);
     a = (y[0] + a) * (y[0] - a);
     const double c = x[0];
@@ -60,14 +60,14 @@ __device__ __forceinline__ void q_sinv(double* x, const double* y, int mk) {    
     for (int i = 1; i < mk; ++i) x[i] = (al * x[i] + be * y[i]) * ia;
     x[0] = x0 * ia;
 }
-__device__ __forceinline__ void q_ssqr(double* x, const double* y, int mk) {            // x := y o y
+__host__ __device__ __forceinline__ void q_ssqr(double* x, const double* y, int mk) {            // x := y o y
     double a = 0.0;
     for (int i = 0; i < mk; ++i) a += y[i] * y[i];
     const double y0 = y[0];
     for (int i = 1; i < mk; ++i) x[i] = 2.0 * y0 * y[i];
     x[0] = a;
 }
-__device__ __forceinline__ void q_scale2(const double* l, double* x, int mk, bool inverse) {
+__host__ __device__ __forceinline__ void q_scale2(const double* l, double* x, int mk, bool inverse) {
     double a = q_nrm1(l, mk);
     a = sqrt(l[0] + a) * sqrt(l[0] - a);
     double lx = 0.0;
@@ -85,7 +85,7 @@ __device__ __forceinline__ void q_scale2(const double* l, double* x, int mk, boo
     for (int i = 1; i < mk; ++i) x[i] = (x[i] + b * l[i]) * sc;
     x[0] = lx * sc;
 }
-__device__ __forceinline__ void q_scale(double* x, const double* v, double beta, int mk, bool inverse) {   // W x / W^-1 x
+__host__ __device__ __forceinline__ void q_scale(double* x, const double* v, double beta, int mk, bool inverse) {   // W x / W^-1 x
     double w = 0.0;
     if (!inverse) {
         for (int i = 0; i < mk; ++i) w += v[i] * x[i];
@@ -141,6 +141,68 @@ __device__ __forceinline__ void cv_scale(const ST& S, double* x, bool inverse) {
         q_scale(x + S.qoff[k], S.v + (S.qoff[k] - S.ml), S.beta[k], S.qdim[k], inverse);
 }
 
+// misc.compute_scaling for one second-order cone (misc.py:307-354): v_k, beta_k, lambda_k from s_k, z_k
+__host__ __device__ __forceinline__ void q_compute_scaling(const double* sk, const double* zk, double* v, double* beta,
+                                                           double* lk, int mk) {
+    const double aa = q_jnrm2(sk, mk), bb = q_jnrm2(zk, mk);
+    *beta = sqrt(aa / bb);
+    double dsz = 0.0;
+    for (int i = 0; i < mk; ++i) dsz += sk[i] * zk[i];
+    const double cc = sqrt((dsz / aa / bb + 1.0) / 2.0);
+    // vk = 1/(2c) (sk/a + J zk/b);  then v = (vk + e) / sqrt(2 (vk0 + 1))
+    for (int i = 0; i < mk; ++i) {
+        double t = zk[i] * (-1.0 / bb);
+        if (i == 0) t = -t;
+        t += sk[i] * (1.0 / aa);
+        v[i] = t * (1.0 / 2.0 / cc);
+    }
+    v[0] += 1.0;
+    const double f = 1.0 / sqrt(2.0 * v[0]);
+    for (int i = 0; i < mk; ++i) v[i] *= f;
+    const double dd = 2.0 * cc + sk[0] / aa + zk[0] / bb;
+    const double fs = (cc + zk[0] / bb) / dd / aa, fz = (cc + sk[0] / aa) / dd / bb, sq = sqrt(aa * bb);
+    lk[0] = cc * sq;
+    for (int i = 1; i < mk; ++i) lk[i] = (sk[i] * fs + zk[i] * fz) * sq;
+}
+
+// misc.update_scaling for one second-order cone (misc.py:503-573); sk, zk: the updated variables in the current scaling
+// (normalised in place), v_k, beta_k, lambda_k updated
+__host__ __device__ __forceinline__ void q_update_scaling(double* sk, double* zk, double* v, double* beta, double* lk, int mk) {
+    const double aa = q_jnrm2(sk, mk);
+    for (int i = 0; i < mk; ++i) sk[i] *= 1.0 / aa;
+    const double bb = q_jnrm2(zk, mk);
+    for (int i = 0; i < mk; ++i) zk[i] *= 1.0 / bb;
+    double dsz = 0.0, vs = 0.0, vz1 = 0.0;
+    for (int i = 0; i < mk; ++i) {
+        dsz += sk[i] * zk[i];
+        vs += v[i] * sk[i];
+        if (i > 0) vz1 += v[i] * zk[i];
+    }
+    const double cc = sqrt((1.0 + dsz) / 2.0);
+    const double vz = v[0] * zk[0] - vz1;                       // v' J z
+    const double vq = (vs + vz) / 2.0 / cc;
+    const double vu = vs - vz;
+    const double wk0 = 2.0 * v[0] * vq - (sk[0] + zk[0]) / 2.0 / cc;
+    const double dd = (v[0] * vu - sk[0] / 2.0 + zk[0] / 2.0) / (wk0 + 1.0);
+    const double fv = 2.0 * (-dd * vq + 0.5 * vu), fs = 0.5 * (1.0 - dd / cc), fz = 0.5 * (1.0 + dd / cc);
+    const double sq = sqrt(aa * bb);
+    lk[0] = cc * sq;
+    for (int i = 1; i < mk; ++i) lk[i] = (v[i] * fv + sk[i] * fs + zk[i] * fz) * sq;
+    // v := (2 v v' - J) q, then v := v^{1/2}
+    const double s0 = sk[0];
+    for (int i = 0; i < mk; ++i) {
+        double t = 2.0 * vq * v[i];
+        if (i == 0) t -= s0 / 2.0 / cc;
+        else t += sk[i] * (0.5 / cc);
+        t += zk[i] * (-0.5 / cc);
+        v[i] = t;
+    }
+    v[0] += 1.0;
+    const double f = 1.0 / sqrt(2.0 * v[0]);
+    for (int i = 0; i < mk; ++i) v[i] *= f;
+    *beta *= sqrt(aa / bb);
+}
+
 // misc.compute_scaling, 'l' and 'q' blocks: d, (v, beta), lmbda from s, z
 template <class ST>
 __device__ __forceinline__ void cv_compute_scaling(const ST& S, const double* s, const double* z, double* lmbda) {
@@ -150,30 +212,8 @@ __device__ __forceinline__ void cv_compute_scaling(const ST& S, const double* s,
         lmbda[i] = sqrt(s[i] * z[i]);
     }
     for (int k = tid; k < S.nq; k += 256) {
-        const int o = S.qoff[k], mk = S.qdim[k];
-        const double* sk = s + o;
-        const double* zk = z + o;
-        double* v = S.v + (o - S.ml);
-        double* lk = lmbda + o;
-        const double aa = q_jnrm2(sk, mk), bb = q_jnrm2(zk, mk);
-        S.beta[k] = sqrt(aa / bb);
-        double dsz = 0.0;
-        for (int i = 0; i < mk; ++i) dsz += sk[i] * zk[i];
-        const double cc = sqrt((dsz / aa / bb + 1.0) / 2.0);
-        // vk = 1/(2c) (sk/a + J zk/b);  then v = (vk + e) / sqrt(2 (vk0 + 1))
-        for (int i = 0; i < mk; ++i) {
-            double t = zk[i] * (-1.0 / bb);
-            if (i == 0) t = -t;
-            t += sk[i] * (1.0 / aa);
-            v[i] = t * (1.0 / 2.0 / cc);
-        }
-        v[0] += 1.0;
-        const double f = 1.0 / sqrt(2.0 * v[0]);
-        for (int i = 0; i < mk; ++i) v[i] *= f;
-        const double dd = 2.0 * cc + sk[0] / aa + zk[0] / bb;
-        const double fs = (cc + zk[0] / bb) / dd / aa, fz = (cc + sk[0] / aa) / dd / bb, sq = sqrt(aa * bb);
-        lk[0] = cc * sq;
-        for (int i = 1; i < mk; ++i) lk[i] = (sk[i] * fs + zk[i] * fz) * sq;
+        const int o = S.qoff[k];
+        q_compute_scaling(s + o, z + o, S.v + (o - S.ml), S.beta + k, lmbda + o, S.qdim[k]);
     }
 }
 
@@ -188,44 +228,8 @@ __device__ __forceinline__ void cv_update_scaling(const ST& S, double* lmbda, do
         lmbda[i] = a * c;
     }
     for (int k = tid; k < S.nq; k += 256) {
-        const int o = S.qoff[k], mk = S.qdim[k];
-        double* sk = ds + o;
-        double* zk = dz + o;
-        double* v = S.v + (o - S.ml);
-        double* lk = lmbda + o;
-        const double aa = q_jnrm2(sk, mk);
-        for (int i = 0; i < mk; ++i) sk[i] *= 1.0 / aa;
-        const double bb = q_jnrm2(zk, mk);
-        for (int i = 0; i < mk; ++i) zk[i] *= 1.0 / bb;
-        double dsz = 0.0, vs = 0.0, vz1 = 0.0;
-        for (int i = 0; i < mk; ++i) {
-            dsz += sk[i] * zk[i];
-            vs += v[i] * sk[i];
-            if (i > 0) vz1 += v[i] * zk[i];
-        }
-        const double cc = sqrt((1.0 + dsz) / 2.0);
-        const double vz = v[0] * zk[0] - vz1;                       // v' J z
-        const double vq = (vs + vz) / 2.0 / cc;
-        const double vu = vs - vz;
-        const double wk0 = 2.0 * v[0] * vq - (sk[0] + zk[0]) / 2.0 / cc;
-        const double dd = (v[0] * vu - sk[0] / 2.0 + zk[0] / 2.0) / (wk0 + 1.0);
-        const double fv = 2.0 * (-dd * vq + 0.5 * vu), fs = 0.5 * (1.0 - dd / cc), fz = 0.5 * (1.0 + dd / cc);
-        const double sq = sqrt(aa * bb);
-        lk[0] = cc * sq;
-        for (int i = 1; i < mk; ++i) lk[i] = (v[i] * fv + sk[i] * fs + zk[i] * fz) * sq;
-        // v := (2 v v' - J) q, then v := v^{1/2}
-        const double s0 = sk[0];
-        for (int i = 0; i < mk; ++i) {
-            double t = 2.0 * vq * v[i];
-            if (i == 0) t -= s0 / 2.0 / cc;
-            else t += sk[i] * (0.5 / cc);
-            t += zk[i] * (-0.5 / cc);
-            v[i] = t;
-        }
-        v[0] += 1.0;
-        const double f = 1.0 / sqrt(2.0 * v[0]);
-        for (int i = 0; i < mk; ++i) v[i] *= f;
-        S.beta[k] *= sqrt(aa / bb);
+        const int o = S.qoff[k];
+        q_update_scaling(ds + o, dz + o, S.v + (o - S.ml), S.beta + k, lmbda + o, S.qdim[k]);
     }
 }
 

@@ -207,6 +207,9 @@ int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX
                            const double* dv, const double* dbeta, float* ms);
 /* developer ablation switch for potf2_kernel phases (timing experiments only; results are wrong when != 0) */
 int mi355kkt_debug_hwid(unsigned* out, int nblocks);
+/* the second-order-cone operations of the device-resident loops (csrc/cone_ops.h) executed on the HOST, one cone: for the CPU
+ * parity tests against misc.sprod / sinv / ssqr / scale2 / scale / jnrm2 / compute_scaling / update_scaling / max_step */
+int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w);
 int mi355kkt_debug_potf2_skip(int mask);
 int mi355kkt_debug_syrk_skip(int mask);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
