@@ -1646,6 +1646,22 @@ int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, d
     }
     return 0;
 }
+/* The static SYRK schedule for an n x n result contracted over K on a device with num_cus compute units, as plain integers
+ * (host only): out[8 * i + 0..7] = ti, tj, k0, k1, slot, first, nparts, 0 of work item i, in launch order.  For the CPU tests
+ * of the plan's invariants.  Returns the number of items (<= max_items are written). */
+int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit) {
+    std::vector<mi355kkt::SyrkItem> items, split_tiles;
+    int ns = 0;
+    mi355kkt::make_syrk_items(n, K, num_cus, allow_split != 0, items, split_tiles, ns);
+    for (size_t i = 0; i < items.size() && (int)i < max_items; ++i) {
+        const mi355kkt::SyrkItem& it = items[i];
+        int* o = out + 8 * i;
+        o[0] = it.ti; o[1] = it.tj; o[2] = it.k0; o[3] = it.k1; o[4] = it.slot; o[5] = it.first; o[6] = it.nparts; o[7] = 0;
+    }
+    if (nslabs) *nslabs = ns;
+    if (nsplit) *nsplit = (int)split_tiles.size();
+    return (int)items.size();
+}
 int mi355kkt_debug_potf2_skip(int mask) { return mi355kkt::set_potf2_skip(mask); }
 int mi355kkt_debug_syrk_skip(int mask) { return mi355kkt::set_syrk_skip(mask); }
 

@@ -285,11 +285,13 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkItem* __rest
 // that XCD's private L2; whole rounds run unsplit tiles, the remainder is split along k so the last
 // round is also full (hybrid stream-K), with slabs summed in a fixed order by syrk_reduce_kernel.
 // ---------------------------------------------------------------------------------------------------
-int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split) {
-    free_syrk_plan(plan);
-    plan.n = n;
-    plan.K = K;
-    if (n <= 0) return 0;
+// the static schedule itself (host only, no device memory): work items in launch order, the split tiles, the slab count
+void make_syrk_items(int n, int K, int num_cus, bool allow_split, std::vector<SyrkItem>& items, std::vector<SyrkItem>& split_tiles,
+                     int& nslabs) {
+    items.clear();
+    split_tiles.clear();
+    nslabs = 0;
+    if (n <= 0) return;
     const int nt = (n + TILE - 1) / TILE;
     std::vector<std::pair<int, int>> seq;
     const int ns = (nt + 7) / 8;
@@ -308,7 +310,7 @@ int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split)
     int split = 1;
     if (R > 0 && allow_split) split = std::max(1, std::min(slots / R, max_split));
 
-    std::vector<SyrkItem> ordered_full, items, split_tiles;
+    std::vector<SyrkItem> ordered_full;
     for (int t = 0; t < nfull; ++t) ordered_full.push_back({seq[t].first, seq[t].second, 0, K, -1, 0, 0, 0});
     // XCD-contiguous permutation of the full tiles: id -> xcd = id % 8 gets a contiguous chunk
     {
@@ -320,7 +322,6 @@ int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split)
             items[id] = ordered_full[pos];
         }
     }
-    int nslabs = 0;
     for (int t = nfull; t < T; ++t) {
         if (split == 1) {
             items.push_back({seq[t].first, seq[t].second, 0, K, -1, 0, 0, 0});
@@ -338,6 +339,16 @@ int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split)
         nslabs += parts;
         split_tiles.push_back(st);
     }
+}
+
+int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split) {
+    free_syrk_plan(plan);
+    plan.n = n;
+    plan.K = K;
+    if (n <= 0) return 0;
+    std::vector<SyrkItem> items, split_tiles;
+    int nslabs = 0;
+    make_syrk_items(n, K, num_cus, allow_split, items, split_tiles, nslabs);
     plan.nitems = (int)items.size();
     plan.nslabs = nslabs;
     plan.nsplit_tiles = (int)split_tiles.size();

@@ -50,6 +50,8 @@ struct SyrkPlan {
 };
 
 int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split = true);
+void make_syrk_items(int n, int K, int num_cus, bool allow_split, std::vector<SyrkItem>& items, std::vector<SyrkItem>& split_tiles,
+                     int& nslabs);
 void free_syrk_plan(SyrkPlan& plan);
 
 // C(lower) = P(lower) + Gs' Gs with Gs = diag(di) G   (di == nullptr: no scaling; P == nullptr: 0)

@@ -210,6 +210,8 @@ int mi355kkt_debug_hwid(unsigned* out, int nblocks);
 /* the second-order-cone operations of the device-resident loops (csrc/cone_ops.h) executed on the HOST, one cone: for the CPU
  * parity tests against misc.sprod / sinv / ssqr / scale2 / scale / jnrm2 / compute_scaling / update_scaling / max_step */
 int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w);
+/* the static work list of the scaled SYRK (host only): 8 ints per item = ti, tj, k0, k1, slot, first, nparts, 0; returns #items */
+int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit);
 int mi355kkt_debug_potf2_skip(int mask);
 int mi355kkt_debug_syrk_skip(int mask);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
