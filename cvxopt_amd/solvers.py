@@ -16,7 +16,8 @@ the reference's.  (For LP-cone problems `cvxopt_amd.coneqp_lp` / `conelp_lp` mov
     import cvxopt_amd.solvers as gsolvers
     sol = gsolvers.conelp(c, G, h, dims)            # same signature and result dict as cvxopt.solvers.conelp
     sol = gsolvers.coneqp(P, q, G, h, dims, A, b)
-    sol = gsolvers.socp(c, Gl, hl, Gq, hq)          # via the reference's own argument packing
+    sol = gsolvers.socp(c, Gl, hl, Gq, hq)          # the reference's own argument packing
+    sol = gsolvers.sdp(c, Gl, hl, Gs, hs)           # 's' cones: host driver + device operators + GPU kktsolver
 """
 import numpy as np
 
@@ -144,37 +145,98 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
         eng.close()
 
 
-def socp(c, Gl=None, hl=None, Gq=None, hq=None, A=None, b=None, **kwargs):
-    """cvxopt.solvers.socp's argument convention (coneprog.py:2862-3100: stacks Gl, Gq[k] and calls conelp)."""
+def _stack(blocks, n):
+    """[Gl; G_1; ...; G_N] as one matrix: sparse when every block is, dense otherwise (coneprog.py:3303-3318, :4085-4098)"""
     from cvxopt import matrix, sparse, spmatrix
-    n = c.size[0]
-    blocks, hs = [], []
-    ml = 0
-    if Gl is not None:
-        blocks.append(Gl)
-        hs.append(hl)
-        ml = Gl.size[0]
-    q = []
-    for Gk, hk in zip(Gq or [], hq or []):
-        blocks.append(Gk)
-        hs.append(hk)
-        q.append(Gk.size[0])
-    G = sparse(blocks) if all(isinstance(B, spmatrix) for B in blocks) \
-        else matrix([matrix(B) for B in blocks])
-    h = matrix([matrix(v) for v in hs])
-    sol = conelp(c, G, h, {'l': ml, 'q': q, 's': []}, A, b, **kwargs)
-    for key in ('s', 'z'):                      # the reference returns the blocks separately ('sl', 'sq', 'zl', 'zq')
+    if not blocks:
+        return spmatrix([], [], [], (0, n))
+    if all(isinstance(B, spmatrix) for B in blocks):
+        return sparse(blocks)
+    return matrix([matrix(B) for B in blocks])
+
+
+def _stack_start(start, ml, sizes, lkey, bkey):
+    """primalstart / dualstart of socp / sdp ('sl' + 'sq'|'ss' blocks, 'zl' + 'zq'|'zs') as one stacked cone vector"""
+    from cvxopt import matrix
+    v = matrix(0.0, (ml + sum(sizes), 1))
+    if ml:
+        v[:ml] = start[lkey]
+    ind = ml
+    for k, sz in enumerate(sizes):
+        v[ind:ind + sz] = start[bkey][k][:]
+        ind += sz
+    return v
+
+
+def _split_cone_vectors(sol, ml, sizes, suffix, shape):
+    """conelp's 's', 'z' -> the reference's per-block entries ('sl', 'sq'|'ss', 'zl', 'zq'|'zs'; coneprog.py:3351-3377,
+    :4129-4153); `shape(k)` is the size of block k in the result."""
+    from cvxopt import matrix
+    for key in ('s', 'z'):
         v = sol.pop(key)
         if v is None:
-            sol[key + 'l'], sol[key + 'q'] = None, None
+            sol[key + 'l'], sol[key + suffix] = None, None
             continue
         sol[key + 'l'] = v[:ml]
         parts, ind = [], ml
-        for mk in q:
-            parts.append(v[ind:ind + mk])
-            ind += mk
-        sol[key + 'q'] = parts
+        for k, sz in enumerate(sizes):
+            parts.append(matrix(v[ind:ind + sz], shape(k)))
+            ind += sz
+        sol[key + suffix] = parts
     return sol
+
+
+def socp(c, Gl=None, hl=None, Gq=None, hq=None, A=None, b=None, primalstart=None, dualstart=None, **kwargs):
+    """cvxopt.solvers.socp's argument convention (coneprog.py:3013-3378: stacks Gl, Gq[k] and calls conelp)."""
+    from cvxopt import matrix
+    n = c.size[0]
+    Gq, hq = list(Gq or []), list(hq or [])
+    if len(Gq) != len(hq):
+        raise TypeError("'hq' must be a list of %d dense 'd' matrices" % len(Gq))
+    ml = Gl.size[0] if Gl is not None else 0
+    q = [Gk.size[0] for Gk in Gq]
+    G = _stack(([Gl] if Gl is not None else []) + Gq, n)
+    h = matrix([matrix(v) for v in ([hl] if Gl is not None else []) + hq]) if (ml or q) else matrix(0.0, (0, 1))
+    ps = ds = None
+    if primalstart:
+        ps = {'x': primalstart['x'], 's': _stack_start(primalstart, ml, q, 'sl', 'sq')}
+    if dualstart:
+        ds = {'z': _stack_start(dualstart, ml, q, 'zl', 'zq')}
+        if A is not None and A.size[0]:
+            ds['y'] = dualstart['y']
+    sol = conelp(c, G, h, {'l': ml, 'q': q, 's': []}, A, b, primalstart=ps, dualstart=ds, **kwargs)
+    return _split_cone_vectors(sol, ml, q, 'q', lambda k: (q[k], 1))
+
+
+def sdp(c, Gl=None, hl=None, Gs=None, hs=None, A=None, b=None, primalstart=None, dualstart=None, **kwargs):
+    """cvxopt.solvers.sdp's argument convention (coneprog.py:3566-4153): Gs[k] is m_k^2 x n (column j = vec of the j-th
+    coefficient matrix), hs[k] is m_k x m_k; stacked into one cone LP with dims['s'] = [m_k]; 'ss', 'zs' come back as
+    m_k x m_k matrices.  The 's' cone runs through the host driver with device operators + the GPU kktsolver."""
+    from cvxopt import matrix
+    n = c.size[0]
+    Gs, hs = list(Gs or []), list(hs or [])
+    ms = [int(round(Gk.size[0] ** 0.5)) for Gk in Gs]
+    for k, (m, Gk) in enumerate(zip(ms, Gs)):
+        if m * m != Gk.size[0]:
+            raise TypeError("the squareroot of the number of rows in 'Gs[%d]' is not an integer" % k)
+    if len(hs) != len(ms):
+        raise TypeError("'hs' must be a list of %d dense or sparse 'd' matrices" % len(ms))
+    for k, (m, hk) in enumerate(zip(ms, hs)):
+        if hk.size != (m, m):
+            raise TypeError("hs[%d] has size (%d,%d).  Expected size is (%d,%d)." % (k, hk.size[0], hk.size[1], m, m))
+    ml = Gl.size[0] if Gl is not None else 0
+    sizes = [m * m for m in ms]
+    G = _stack(([Gl] if Gl is not None else []) + Gs, n)
+    h = matrix(([matrix(hl)] if Gl is not None else []) + [matrix(hk)[:] for hk in hs]) if (ml or ms) else matrix(0.0, (0, 1))
+    ps = ds = None
+    if primalstart:
+        ps = {'x': primalstart['x'], 's': _stack_start(primalstart, ml, sizes, 'sl', 'ss')}
+    if dualstart:
+        ds = {'z': _stack_start(dualstart, ml, sizes, 'zl', 'zs')}
+        if A is not None and A.size[0]:
+            ds['y'] = dualstart['y']
+    sol = conelp(c, G, h, {'l': ml, 'q': [], 's': ms}, A, b, primalstart=ps, dualstart=ds, **kwargs)
+    return _split_cone_vectors(sol, ml, sizes, 's', lambda k: (ms[k], ms[k]))
 
 
 def lp(c, G, h, A=None, b=None, **kwargs):

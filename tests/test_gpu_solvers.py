@@ -122,6 +122,27 @@ def test_sdp_and_mixed_cones_through_operators(ref_cvxopt):
     assert np.allclose(np.array(sol['x']).ravel(), [-1.22, 9.66e-02, 3.58], rtol=5e-3)     # doc transcript (coneprog.rst:332-335)
 
 
+def test_sdp_wrapper_matches_reference(ref_cvxopt):
+    """solvers.sdp's argument convention (examples/doc/chap8/sdp.py; known answer coneprog.rst:957-969)"""
+    from cvxopt import matrix, solvers
+    import cvxopt_amd.solvers as gs
+    c = matrix([1., -1., 1.])
+    G = [matrix([[-7., -11., -11., 3.], [7., -18., -18., 8.], [-2., -8., -8., 1.]])]
+    G += [matrix([[-21., -11., 0., -11., 10., 8., 0., 8., 5.], [0., 10., 16., 10., -10., -10., 16., -10., 3.],
+                  [-5., 2., -17., 2., -6., 8., -17., -7., 6.]])]
+    h = [matrix([[33., -9.], [-9., 26.]]), matrix([[14., 9., 40.], [9., 91., 10.], [40., 10., 15.]])]
+    ref = solvers.sdp(c, Gs=G, hs=h)
+    sol = gs.sdp(c, Gs=G, hs=h)
+    assert sol['status'] == ref['status'] == 'optimal' and sol['iterations'] == ref['iterations']
+    assert abs(sol['primal objective'] - ref['primal objective']) < 1e-8 * max(1, abs(ref['primal objective']))
+    assert relerr(np.array(sol['x']).ravel(), np.array(ref['x']).ravel()) < 1e-6
+    assert np.allclose(np.array(sol['x']).ravel(), [-0.367, 1.898, -0.887], atol=1e-3)
+    for k in range(2):
+        assert sol['zs'][k].size == ref['zs'][k].size
+        assert relerr(np.array(sol['zs'][k]), np.array(ref['zs'][k])) < 1e-6
+        assert relerr(np.array(sol['ss'][k]), np.array(ref['ss'][k])) < 1e-5
+
+
 def test_coneqp_with_soc_and_equalities_through_operators(ref_cvxopt):
     from cvxopt import matrix, solvers
     import cvxopt_amd.solvers as gs

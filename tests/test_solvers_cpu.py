@@ -60,3 +60,78 @@ def test_dims_default():
         size = (7, 1)
     assert gs._dims_of(H(), None) == {'l': 7, 'q': [], 's': []}
     assert gs._dims_of(H(), {'l': 1, 'q': (2, 4), 's': [0]}) == {'l': 1, 'q': [2, 4], 's': [0]}
+
+
+def _host_conelp(monkeypatch):
+    """route the wrappers' conelp to the reference's (CPU) so that only the argument packing / result splitting of
+    cvxopt_amd.solvers.socp / sdp is under test"""
+    from cvxopt import solvers
+
+    def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None, **kw):
+        kw.pop('device_loop', None)
+        return solvers.conelp(c, G, h, dims, A, b, primalstart, dualstart, options={'show_progress': False}, **kw)
+    monkeypatch.setattr(gs, 'conelp', conelp)
+
+
+def _same(a, b):
+    if a is None or b is None:
+        return a is None and b is None
+    if isinstance(a, list):
+        return len(a) == len(b) and all(_same(x, y) for x, y in zip(a, b))
+    if isinstance(a, (float, int, str)):
+        return a == b
+    return a.size == b.size and np.array_equal(np.array(a), np.array(b))
+
+
+def test_sdp_wrapper_packs_and_splits_like_the_reference(ref_cvxopt, monkeypatch):
+    """the SDP of the reference's doc section 8.6 (examples/doc/chap8/sdp.py; coneprog.rst known answer for x) + an 'l'
+    block, sparse blocks, and user starting points"""
+    from cvxopt import matrix, solvers, sparse
+    _host_conelp(monkeypatch)
+    c = matrix([1., -1., 1.])
+    G = [matrix([[-7., -11., -11., 3.], [7., -18., -18., 8.], [-2., -8., -8., 1.]])]
+    G += [matrix([[-21., -11., 0., -11., 10., 8., 0., 8., 5.], [0., 10., 16., 10., -10., -10., 16., -10., 3.],
+                  [-5., 2., -17., 2., -6., 8., -17., -7., 6.]])]
+    h = [matrix([[33., -9.], [-9., 26.]]), matrix([[14., 9., 40.], [9., 91., 10.], [40., 10., 15.]])]
+    opts = {'show_progress': False}
+    ref = solvers.sdp(c, Gs=G, hs=h, options=opts)
+    got = gs.sdp(c, Gs=G, hs=h)
+    assert set(ref) == set(got)
+    assert all(_same(ref[k], got[k]) for k in ref), [k for k in ref if not _same(ref[k], got[k])]
+    assert np.allclose(np.array(got['x']).ravel(), [-0.367, 1.898, -0.887], atol=1e-3)      # coneprog.rst:957-969
+    assert got['zs'][1].size == (3, 3) and got['ss'][0].size == (2, 2)
+    # with an 'l' block, sparse data, and both starting points
+    Gl, hl = matrix([[1., 0.], [0., 1.], [1., 1.]]), matrix([10., 10.])
+    ps = {'x': matrix(0.0, (3, 1)), 'sl': matrix([1., 1.]), 'ss': [matrix([[2., 0.], [0., 2.]]), matrix(np.eye(3) * 3)]}
+    ds = {'zl': matrix([1., 2.]), 'zs': [matrix([[1., 0.], [0., 1.]]), matrix(np.eye(3))]}
+    for conv in (lambda M: M, sparse):
+        ref = solvers.sdp(c, conv(Gl), hl, [conv(g) for g in G], h, primalstart=ps, dualstart=ds, options=opts)
+        got = gs.sdp(c, conv(Gl), hl, [conv(g) for g in G], h, primalstart=ps, dualstart=ds)
+        assert ref['status'] == 'optimal'
+        assert all(_same(ref[k], got[k]) for k in ref), [k for k in ref if not _same(ref[k], got[k])]
+    with pytest.raises(TypeError):
+        gs.sdp(c, Gs=[G[0][:3, :]], hs=[h[0]])
+    with pytest.raises(TypeError):
+        gs.sdp(c, Gs=G, hs=[h[1], h[0]])
+
+
+def test_socp_wrapper_packs_and_splits_like_the_reference(ref_cvxopt, monkeypatch):
+    """the SOCP of the reference's doc section 8.5 (examples/doc/chap8/socp.py) + an 'l' block and starting points"""
+    from cvxopt import matrix, solvers
+    _host_conelp(monkeypatch)
+    c = matrix([-2., 1., 5.])
+    G = [matrix([[12., 13., 12.], [6., -3., -12.], [-5., -5., 6.]]),
+         matrix([[3., 3., -1., 1.], [-6., -6., -9., 19.], [10., -2., -2., -3.]])]
+    h = [matrix([-12., -3., -2.]), matrix([27., 0., 3., -42.])]
+    opts = {'show_progress': False}
+    ref = solvers.socp(c, Gq=G, hq=h, options=opts)
+    got = gs.socp(c, Gq=G, hq=h)
+    assert ref['status'] == 'optimal' and set(ref) == set(got)
+    assert all(_same(ref[k], got[k]) for k in ref), [k for k in ref if not _same(ref[k], got[k])]
+    Gl, hl = matrix([[1., 0.], [0., 1.], [1., -1.]]), matrix([50., 50.])
+    ps = {'x': matrix(0.0, (3, 1)), 'sl': matrix([1., 1.]), 'sq': [matrix([2., 0., 0.]), matrix([3., 0., 0., 0.])]}
+    ds = {'zl': matrix([1., 1.]), 'zq': [matrix([1., 0., 0.]), matrix([1., 0., 0., 0.])]}
+    ref = solvers.socp(c, Gl, hl, G, h, primalstart=ps, dualstart=ds, options=opts)
+    got = gs.socp(c, Gl, hl, G, h, primalstart=ps, dualstart=ds)
+    assert ref['status'] == 'optimal'
+    assert all(_same(ref[k], got[k]) for k in ref), [k for k in ref if not _same(ref[k], got[k])]
