@@ -16,6 +16,7 @@
 
 #include "../../include/mi355kkt.h"
 #include "kkt_common.h"
+#include "ordering.h"
 #include "cone_ops.h"
 #include <functional>
 
@@ -1661,6 +1662,34 @@ int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* ou
     if (nslabs) *nslabs = ns;
     if (nsplit) *nsplit = (int)split_tiles.size();
     return (int)items.size();
+}
+/* Fill-reducing ordering of a symmetric pattern (host only, for the CPU tests of csrc/ordering.cpp): colptr/rowind = CSC
+ * pattern of any part of the matrix that contains each off-diagonal pair at least once; method 0 = choose, 1 = nested
+ * dissection, 2 = approximate minimum degree.  perm[new] = old.  stats[0..6] = method chosen, nnz(L) and flops of the
+ * dissection candidate, nnz(L) and flops of the minimum-degree candidate, supernodal tree heights of the two. */
+int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats) {
+    if (n < 0 || !colptr || !perm) return MI355KKT_EINVAL;
+    mi355kkt::Graph adj(n);
+    for (int j = 0; j < n; ++j)
+        for (int64_t k = colptr[j]; k < colptr[j + 1]; ++k) {
+            const int i = (int)rowind[k];
+            if (i < 0 || i >= n) return MI355KKT_EINVAL;
+            if (i != j) { adj[i].push_back(j); adj[j].push_back(i); }
+        }
+    for (auto& a : adj) {
+        std::sort(a.begin(), a.end());
+        a.erase(std::unique(a.begin(), a.end()), a.end());
+    }
+    std::vector<int> order;
+    mi355kkt::OrderingInfo info;
+    mi355kkt::fill_reducing_ordering(adj, order, method, &info);
+    if ((int)order.size() != n) return MI355KKT_EINVAL;
+    std::copy(order.begin(), order.end(), perm);
+    if (stats) {
+        stats[0] = info.method; stats[1] = (double)info.nnz_nd; stats[2] = info.flops_nd; stats[3] = (double)info.nnz_amd;
+        stats[4] = info.flops_amd; stats[5] = info.levels_nd; stats[6] = info.levels_amd;
+    }
+    return 0;
 }
 int mi355kkt_debug_potf2_skip(int mask) { return mi355kkt::set_potf2_skip(mask); }
 int mi355kkt_debug_syrk_skip(int mask) { return mi355kkt::set_syrk_skip(mask); }

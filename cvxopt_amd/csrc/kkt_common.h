@@ -124,6 +124,7 @@ int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ld
 // ---- sparse Cholesky (sparse_chol.hip) -------------------------------------------------------------
 struct SparseSymbolic {
     int n = 0, m = 0, ns = 0, nlevels = 0;
+    int order_method = 0;                         // 1 nested dissection, 2 approximate minimum degree (ordering.h)
     int64_t nnzL = 0;
     double flops = 0.0;
     std::vector<int> perm, iperm;                 // perm[new] = old

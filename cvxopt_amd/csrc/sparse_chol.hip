@@ -18,6 +18,7 @@
 #include <queue>
 
 #include "kkt_common.h"
+#include "ordering.h"
 #include <chrono>
 #include <memory>
 #include <future>
@@ -59,128 +60,6 @@ void build_graph(int n, int m, const int64_t* gcp, const int64_t* gri, const int
     }
 }
 
-// Nested dissection (George 1973, automatic version): the separator of a connected part is one level of a BFS
-// level structure rooted at a pseudo-peripheral node; the two sides are ordered first (recursively), the separator
-// last.  Parts of <= 48 nodes are ordered in BFS order.
-struct Dissector {
-    const std::vector<std::vector<int>>& adj;
-    std::unique_ptr<std::atomic<int>[]> part;     // relaxed atomics: sibling subproblems relabel their own nodes concurrently
-    std::vector<int> level;
-    std::vector<int>& order;                      // preallocated, every call fills its own range [off, off + |nodes|)
-    std::atomic<int> next_id{1};
-    Dissector(const std::vector<std::vector<int>>& a, std::vector<int>& o)
-        : adj(a), part(new std::atomic<int>[a.size() ? a.size() : 1]), level(a.size(), -1), order(o) {
-        for (size_t i = 0; i < a.size(); ++i) part[i].store(0, std::memory_order_relaxed);
-    }
-
-    // BFS inside part `id` from root; fills levels, leaves level[] set for the visited nodes
-    void bfs(int root, int id, std::vector<std::vector<int>>& levels) {
-        levels.clear();
-        std::vector<int> cur{root};
-        level[root] = 0;
-        while (!cur.empty()) {
-            levels.push_back(cur);
-            std::vector<int> nxt;
-            for (int v : cur)
-                for (int u : adj[v])
-                    if (part[u].load(std::memory_order_relaxed) == id && level[u] < 0) {
-                        level[u] = (int)levels.size();
-                        nxt.push_back(u);
-                    }
-            cur.swap(nxt);
-        }
-    }
-    void clear(const std::vector<std::vector<int>>& levels) {
-        for (auto& L : levels)
-            for (int v : L) level[v] = -1;
-    }
-    void emit(const std::vector<std::vector<int>>& levels, size_t off) {
-        for (auto& L : levels)
-            for (int v : L) order[off++] = v;
-    }
-    void run(std::vector<int>& nodes, int depth, size_t off) {
-        if (nodes.empty()) return;
-        const int id = next_id.fetch_add(1);
-        for (int v : nodes) part[v].store(id, std::memory_order_relaxed);
-        std::vector<std::vector<int>> levels;
-        // first sweep from nodes[0]: if it does not reach every node the part is disconnected -> one call per component
-        bfs(nodes[0], id, levels);
-        size_t reached = 0;
-        for (auto& L : levels) reached += L.size();
-        if (reached != nodes.size()) {
-            std::vector<std::vector<int>> comps;
-            {
-                std::vector<int> c;
-                for (auto& L : levels) c.insert(c.end(), L.begin(), L.end());
-                comps.push_back(std::move(c));
-            }
-            for (int v : nodes)
-                if (level[v] < 0) {
-                    bfs(v, id, levels);
-                    std::vector<int> c;
-                    for (auto& L : levels) c.insert(c.end(), L.begin(), L.end());
-                    comps.push_back(std::move(c));
-                }
-            for (int v : nodes) level[v] = -1;
-            for (auto& c : comps) {
-                run(c, depth, off);
-                off += c.size();
-            }
-            return;
-        }
-        if ((int)nodes.size() <= 48 || depth > 60) {
-            emit(levels, off);
-            clear(levels);
-            return;
-        }
-        // pseudo-peripheral root: restart from a minimum-degree node of the last level, at most twice more; the level
-        // structure of the last sweep is the one that is cut
-        int root = nodes[0];
-        for (int sweep = 0; sweep < 3; ++sweep) {
-            int best = levels.back()[0];
-            for (int v : levels.back())
-                if (adj[v].size() < adj[best].size()) best = v;
-            clear(levels);
-            if (best == root || sweep == 2) break;
-            root = best;
-            bfs(root, id, levels);
-        }
-        if (levels.size() < 3) {   // (nearly) complete graph: no useful separator
-            emit(levels, off);
-            return;
-        }
-        const size_t total = nodes.size();
-        std::vector<size_t> prefix(levels.size() + 1, 0);
-        for (size_t l = 0; l < levels.size(); ++l) prefix[l + 1] = prefix[l] + levels[l].size();
-        size_t best_l = levels.size() / 2;
-        double best_cost = 1e300;
-        for (size_t l = 1; l + 1 < levels.size(); ++l) {
-            const double a = (double)prefix[l], b = (double)(total - prefix[l + 1]);
-            const double imbalance = std::abs(a - b) / (double)total;
-            const double cost = (double)levels[l].size() * (1.0 + 4.0 * imbalance);
-            if (imbalance < 0.6 && cost < best_cost) {
-                best_cost = cost;
-                best_l = l;
-            }
-        }
-        std::vector<int> left, right, sep = levels[best_l];
-        for (size_t l = 0; l < best_l; ++l) left.insert(left.end(), levels[l].begin(), levels[l].end());
-        for (size_t l = best_l + 1; l < levels.size(); ++l) right.insert(right.end(), levels[l].begin(), levels[l].end());
-        const size_t off_r = off + left.size(), off_s = off_r + right.size();
-        // the two sides are independent subproblems (disjoint nodes, disjoint output ranges): the first few levels of
-        // the recursion run them on separate host threads
-        if (depth < 5 && left.size() > 2048 && right.size() > 2048) {
-            auto fut = std::async(std::launch::async, [&]() { run(left, depth + 1, off); });
-            run(right, depth + 1, off_r);
-            fut.get();
-        } else {
-            run(left, depth + 1, off);
-            run(right, depth + 1, off_r);
-        }
-        for (size_t k = 0; k < sep.size(); ++k) order[off_s + k] = sep[k];
-    }
-};
-
 }  // namespace
 
 int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const int64_t* gri, const int64_t* hcp,
@@ -201,18 +80,29 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     build_graph(n, m, gcp, gri, hcp, hri, adj);
     lap("pattern of S");
     // ---- ordering
-    std::vector<int> nodes(n), order(n, -1);
-    std::iota(nodes.begin(), nodes.end(), 0);
-    {
-        Dissector nd(adj, order);
-        nd.run(nodes, 0, 0);
+    std::vector<int> order;
+    OrderingInfo oinfo;
+    fill_reducing_ordering(adj, order, 0, &oinfo);
+    if ((int)order.size() != n) {
+        set_last_error("symbolic_analyze: ordering has %d entries, expected %d", (int)order.size(), n);
+        return -1;
     }
-    for (int k = 0; k < n; ++k)
-        if (order[k] < 0) {
-            set_last_error("symbolic_analyze: ordering left position %d empty", k);
-            return -1;
+    {
+        std::vector<char> seen(n, 0);
+        for (int k = 0; k < n; ++k) {
+            if (order[k] < 0 || order[k] >= n || seen[order[k]]) {
+                set_last_error("symbolic_analyze: ordering is not a permutation (position %d)", k);
+                return -1;
+            }
+            seen[order[k]] = 1;
         }
-    lap("nested dissection");
+    }
+    S.order_method = oinfo.method;
+    if (dbg)
+        fprintf(stderr, "[sparse] ordering: %s (nested dissection nnz %lld flops %.3e height %d | minimum degree nnz %lld flops %.3e height %d)\n",
+                oinfo.method == 2 ? "approximate minimum degree" : "nested dissection", (long long)oinfo.nnz_nd, oinfo.flops_nd,
+                oinfo.levels_nd, (long long)oinfo.nnz_amd, oinfo.flops_amd, oinfo.levels_amd);
+    lap("ordering");
     S.perm = order;                 // perm[new] = old
     S.iperm.assign(n, 0);
     for (int k = 0; k < n; ++k) S.iperm[order[k]] = k;
@@ -226,70 +116,18 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         }
     }
     for (auto& c : low) std::sort(c.begin(), c.end());
-    // ---- elimination tree (Liu) via path compression on the permuted pattern
-    std::vector<int> parent(n, -1), anc(n, -1);
-    {
-        // need row-wise access: for each i, the columns j < i with S_ij != 0
-        std::vector<std::vector<int>> rowcols(n);
-        for (int j = 0; j < n; ++j)
-            for (int i : low[j]) rowcols[i].push_back(j);
-        for (int i = 0; i < n; ++i)
-            for (int j : rowcols[i]) {
-                int r = j;
-                while (anc[r] != -1 && anc[r] != i) {
-                    const int nx = anc[r];
-                    anc[r] = i;
-                    r = nx;
-                }
-                if (anc[r] == -1) {
-                    anc[r] = i;
-                    parent[r] = i;
-                }
-            }
+    // ---- elimination tree and column counts cc[j] = |struct(j)| (rows > j of L(:, j)) of the permuted matrix: computed
+    //      by the ordering step for its cost model (ordering.cpp, etree_and_counts), already in postorder
+    const std::vector<int>& parent = oinfo.parent;
+    const std::vector<int64_t>& cc = oinfo.colcount;
+    if ((int)parent.size() != n || (int)cc.size() != n) {
+        set_last_error("symbolic_analyze: ordering returned no elimination tree");
+        return -1;
     }
-    lap("elimination tree");
-    // ---- column counts cc[j] = |struct(j)| (rows > j of L(:, j)) without forming the structures: row i belongs to
-    //      struct(j) for every j on the etree paths from the columns k < i of row i's pattern up to i ("row subtrees");
-    //      each entry of L is visited once, nothing is stored or sorted
-    std::vector<int64_t> cc(n, 0);
-    {
-        std::vector<std::vector<int>> rowcols(n);
-        for (int j = 0; j < n; ++j)
-            for (int i : low[j]) rowcols[i].push_back(j);
-        std::vector<int> mark(n, -1);
-        for (int i = 0; i < n; ++i) {
-            mark[i] = i;
-            for (int k : rowcols[i])
-                for (int j = k; j != -1 && j < i && mark[j] != i; j = parent[j]) {
-                    mark[j] = i;
-                    cc[j]++;
-                }
-        }
-    }
-    lap("column counts");
-    // ---- supernodes: column j joins the supernode that ends at j-1 when parent[j-1] == j (so struct(j-1) \ {j} is
-    //      contained in struct(j)) and the explicit zeros this adds to the stored panel stay a small fraction of it.
-    //      Exact (fundamental) merges add none; relaxed merges trade a little fill for far fewer, denser fronts and a
-    //      much shallower supernodal tree (other subtrees may hang off any column of the supernode).
+    // ---- supernodes (relaxed amalgamation of chains, ordering.cpp)
     std::vector<int> sn_first;   // first column of each supernode
-    std::vector<int> sn_of(n, 0);
-    const int MAXW = 256;
-    int64_t true_nnz = 0;        // nonzeros of L in the columns of the current supernode
-    for (int j = 0; j < n; ++j) {
-        bool join = false;
-        const int64_t cj = 1 + cc[j];
-        if (j > 0 && parent[j - 1] == j) {
-            const int first = sn_first.back();
-            const int64_t wn = j - first + 1;
-            const int64_t stored = wn * cc[j] + wn * (wn + 1) / 2;   // trapezoid ending at column j
-            const int64_t zeros = stored - (true_nnz + cj);
-            const double lim = wn <= 4 ? 0.5 : (wn <= 16 ? 0.3 : (wn <= 64 ? 0.2 : 0.1));
-            if (wn <= MAXW && (zeros == 0 || (double)zeros <= lim * (double)stored)) join = true;
-        }
-        if (!join) { sn_first.push_back(j); true_nnz = 0; }
-        true_nnz += cj;
-        sn_of[j] = (int)sn_first.size() - 1;
-    }
+    std::vector<int> sn_of;
+    relaxed_supernodes(parent, cc, sn_first, sn_of);
     const int ns = (int)sn_first.size();
     S.ns = ns;
     S.sn_first = sn_first;

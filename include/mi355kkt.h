@@ -212,6 +212,10 @@ int mi355kkt_debug_hwid(unsigned* out, int nblocks);
 int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w);
 /* the static work list of the scaled SYRK (host only): 8 ints per item = ti, tj, k0, k1, slot, first, nparts, 0; returns #items */
 int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit);
+/* fill-reducing ordering of a symmetric CSC pattern (host only; csrc/ordering.cpp -- the step cholmod.symbolic performs through
+ * cholmod_analyze_p, reference src/C/cholmod.c:309): method 0 choose / 1 nested dissection / 2 approximate minimum degree;
+ * perm[new] = old; stats[7] = chosen method, nnz and flops of both candidates, supernodal tree heights */
+int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats);
 int mi355kkt_debug_potf2_skip(int mask);
 int mi355kkt_debug_syrk_skip(int mask);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */

@@ -242,3 +242,57 @@ def test_sparse_resident_loops_with_equalities(ref_cvxopt):
     d = cvxopt_amd.conelp_device(c, np.asfortranarray(G.toarray()), np.ones(2 * n), A=A, b=b)
     assert a['status'] == d['status'] == 'optimal' and a['iterations'] == d['iterations']
     assert relerr(a['x'], d['x']) < 1e-7 and abs(a['primal objective'] - d['primal objective']) <= 1e-9 * max(1, abs(d['primal objective']))
+
+
+def _mesh_laplacian(n, seed=0):
+    from scipy.spatial import Delaunay
+    tri = Delaunay(np.random.default_rng(seed).random((n, 2))).simplices
+    r = np.concatenate([tri[:, 0], tri[:, 1], tri[:, 2]])
+    c = np.concatenate([tri[:, 1], tri[:, 2], tri[:, 0]])
+    A = sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n))
+    A = ((A + A.T) > 0).astype(float)
+    return (sp.diags(np.asarray(A.sum(1)).ravel() + 0.05) - A).tocsc()
+
+
+def _hub_laplacian(n, seed=0):
+    rng = np.random.default_rng(seed)
+    r = np.arange(1, n)
+    c = (rng.random(n - 1) ** 3 * r).astype(int)          # attaches preferentially to early nodes: a few large hubs
+    A = sp.coo_matrix((np.ones(n - 1), (r, c)), shape=(n, n))
+    r2, c2 = rng.integers(0, n, n // 2), rng.integers(0, n, n // 2)
+    A = A + sp.coo_matrix((np.ones(n // 2), (r2, c2)), shape=(n, n))
+    A = ((A + A.T) > 0).astype(float).tolil()
+    A.setdiag(0)
+    A = A.tocsc()
+    return (sp.diags(np.asarray(A.sum(1)).ravel() + 0.05) - A).tocsc()
+
+
+@pytest.mark.parametrize("pattern", ["mesh", "hubs"])
+@pytest.mark.parametrize("ordering", ["auto", "amd", "nd", "nd+amd-leaves", "nd-multilevel"])
+def test_sparse_unstructured_patterns_with_every_ordering(pattern, ordering, monkeypatch):
+    """the orderings of csrc/ordering.cpp (approximate minimum degree, nested dissection with level-set / multilevel
+    separators, minimum-degree leaves) only change the elimination order: same solution as the dense oracle"""
+    env = {"auto": {}, "amd": {"MI355KKT_ORDERING": "amd"}, "nd": {"MI355KKT_ORDERING": "nd"},
+           "nd+amd-leaves": {"MI355KKT_ORDERING": "nd", "MI355KKT_ND_LEAF_AMD": "1"},
+           "nd-multilevel": {"MI355KKT_ORDERING": "nd", "MI355KKT_ND_MODE": "2"}}[ordering]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P = _mesh_laplacian(1800, seed=2) if pattern == "mesh" else _hub_laplacian(1500, seed=2)
+    n = P.shape[0]
+    G = box(n)
+    dims = {'l': 2 * n, 'q': [], 's': []}
+    A = np.zeros((0, n))
+    f = kkt.kkt_chol2(FakeSp(G), dims, A)
+    rng = np.random.default_rng(n)
+    W = synth.random_scaling(dims, seed=3, spread=1.5)
+    bx, bz = rng.standard_normal(n), rng.standard_normal(2 * n)
+    x, y, z = bx.copy(), np.zeros(0), bz.copy()
+    f(W, FakeSp(sp.tril(P)))(x, y, z)
+    assert f.engine._mode == "sparse"
+    xo, yo, zo = bx.copy(), np.zeros(0), bz.copy()
+    ko.KktChol2(G.toarray(), dims, A).factor(W, P.toarray())(xo, yo, zo)
+    assert relerr(x, xo) < 1e-9 and relerr(z, zo) < 1e-9
+    S = (P + G.T @ sp.diags(W['di'] ** 2) @ G).tocsc()
+    rhs = bx + G.T @ (W['di'] ** 2 * bz)
+    assert np.linalg.norm(S @ x - rhs) / np.linalg.norm(rhs) < 1e-11
+    f.engine.close()

@@ -1,0 +1,147 @@
+"""CPU tests of the fill-reducing orderings of the sparse engine (csrc/ordering.cpp, host only): approximate minimum
+degree, nested dissection (level sets / multilevel bisection + separator refinement) and the cost model that picks one.
+The role of cholmod.symbolic's ordering step (reference src/C/cholmod.c:309, AMD / METIS inside SuiteSparse); checked
+against exact symbolic elimination and against SuperLU's minimum-degree ordering from SciPy."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spl
+
+from test_sparse_symbolic_cpu import exact_fill, grid
+
+
+def ordering(S, method=0):
+    from cvxopt_amd import _capi
+    L = _capi.lib()
+    S = sp.csc_matrix(S); S.sort_indices()
+    n = S.shape[0]
+    cp = np.ascontiguousarray(S.indptr, dtype=np.int64)
+    ri = np.ascontiguousarray(S.indices, dtype=np.int64)
+    perm = np.full(n, -1, dtype=np.int32)
+    stats = np.zeros(8)
+    rc = L.mi355kkt_debug_ordering(n, cp.ctypes.data_as(_capi.c_i64_p), ri.ctypes.data_as(_capi.c_i64_p), method,
+                                   perm.ctypes.data_as(_capi.c_int_p), stats.ctypes.data_as(_capi.c_double_p))
+    assert rc == 0
+    assert sorted(perm.tolist()) == list(range(n))
+    return perm, dict(method=int(stats[0]), nnz_nd=int(stats[1]), flops_nd=stats[2], nnz_amd=int(stats[3]),
+                      flops_amd=stats[4], levels_nd=int(stats[5]), levels_amd=int(stats[6]))
+
+
+def laplacian_of(A):
+    A = ((A + A.T) > 0).astype(float).tolil()
+    A.setdiag(0)
+    A = A.tocsc(); A.eliminate_zeros()
+    return (sp.diags(np.asarray(A.sum(1)).ravel() + 1) - A).tocsc()
+
+
+def delaunay(n, seed=0):
+    from scipy.spatial import Delaunay
+    pts = np.random.default_rng(seed).random((n, 2))
+    tri = Delaunay(pts).simplices
+    r = np.concatenate([tri[:, 0], tri[:, 1], tri[:, 2]])
+    c = np.concatenate([tri[:, 1], tri[:, 2], tri[:, 0]])
+    return laplacian_of(sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)))
+
+
+def random_graph(n, deg, seed=0):
+    rng = np.random.default_rng(seed)
+    r, c = rng.integers(0, n, n * deg), rng.integers(0, n, n * deg)
+    return laplacian_of(sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)))
+
+
+def preferential_attachment(n, seed=0):
+    rng = np.random.default_rng(seed)
+    r, c, deg = [], [], np.ones(n)
+    for i in range(1, n):
+        p = deg[:i] / deg[:i].sum()
+        for j in rng.choice(i, size=min(i, 2), replace=False, p=p):
+            r.append(i); c.append(int(j)); deg[i] += 1; deg[j] += 1
+    return laplacian_of(sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)))
+
+
+def mmd_fill(S):
+    lu = spl.splu(sp.csc_matrix(S), permc_spec='MMD_AT_PLUS_A', diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    return lu.L.nnz
+
+
+CASES = {
+    'grid': lambda: grid(40, 31),
+    'delaunay': lambda: delaunay(2500),
+    'random': lambda: random_graph(1500, 2),
+    'hubs': lambda: preferential_attachment(1200),
+    'tiny': lambda: grid(2, 1),
+    'diagonal': lambda: sp.eye(17).tocsc(),
+    'dense': lambda: sp.csc_matrix(np.ones((23, 23))),
+    'two components + isolated': lambda: sp.block_diag([grid(9, 9), delaunay(150), sp.eye(3)]).tocsc(),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("method", [1, 2])
+def test_reported_fill_is_the_exact_fill_of_the_permutation(name, method):
+    S = CASES[name]()
+    perm, st = ordering(S, method)
+    nnz = st['nnz_nd'] if method == 1 else st['nnz_amd']
+    assert st['method'] == method
+    assert nnz == exact_fill(S, perm)        # the etree / column-count cost model is exact
+
+
+@pytest.mark.parametrize("name", ['grid', 'delaunay', 'random', 'hubs'])
+def test_fill_is_competitive_with_superlu_minimum_degree(name):
+    S = CASES[name]()
+    ref = mmd_fill(S)
+    _, amd = ordering(S, 2)
+    _, nd = ordering(S, 1)
+    assert amd['nnz_amd'] <= 1.25 * ref      # approximate vs multiple minimum degree: same class of ordering
+    best = min(amd['nnz_amd'], nd['nnz_nd'])
+    assert best <= 1.15 * ref
+
+
+def test_choice_follows_the_cost_model():
+    # regular grid: dissection (less arithmetic and the shallower tree); hubs / small-world graphs: minimum degree
+    _, st = ordering(grid(60, 60), 0)
+    assert st['method'] == 1 and st['levels_nd'] < st['levels_amd']
+    _, st = ordering(preferential_attachment(3000), 0)
+    assert st['method'] == 2 and st['flops_amd'] < 0.7 * st['flops_nd']
+    # a band matrix: minimum degree keeps the natural order, a path of n supernodes -- n dependent launches on the device;
+    # dissection pays a little fill for a tree of logarithmic height
+    n = 4000
+    B = sp.diags([np.ones(n - 2), np.ones(n - 1), 4 * np.ones(n), np.ones(n - 1), np.ones(n - 2)], [-2, -1, 0, 1, 2]).tocsc()
+    _, st = ordering(B, 0)
+    assert st['levels_amd'] > 500 and st['levels_nd'] < 40 and st['method'] == 1
+
+
+def test_dissection_beats_natural_and_bfs_orderings_on_an_unstructured_mesh(monkeypatch):
+    S = delaunay(6000, seed=3)
+    n = S.shape[0]
+    perm, st = ordering(S, 1)
+    natural = exact_fill(S, np.arange(n))
+    rcm = exact_fill(S, sp.csgraph.reverse_cuthill_mckee(sp.csr_matrix(S), symmetric_mode=True))
+    ref = mmd_fill(S)
+    assert st['nnz_nd'] < 0.35 * min(natural, rcm)
+    assert st['nnz_nd'] <= 1.5 * ref             # breadth-first leaves (wide supernodes for the device kernels)
+    monkeypatch.setenv('MI355KKT_ND_LEAF_AMD', '1')
+    perm, st2 = ordering(S, 1)
+    assert st2['nnz_nd'] <= 1.1 * ref            # constrained-minimum-degree leaves: the fill of a minimum-degree ordering
+    assert st2['nnz_nd'] == exact_fill(S, perm)
+    monkeypatch.setenv('MI355KKT_ND_MODE', '1')  # level-set separators only: visibly worse on a mesh
+    _, st3 = ordering(S, 1)
+    assert st3['nnz_nd'] > st2['nnz_nd']
+
+
+def test_dense_rows_go_last():
+    n = 3000
+    A = sp.diags([np.ones(n - 1), 4 * np.ones(n), np.ones(n - 1)], [-1, 0, 1]).tolil()
+    A[7, :] = 1; A[:, 7] = 1                     # one dense row
+    perm, st = ordering(A.tocsc(), 2)
+    assert perm[-1] == 7
+    assert st['nnz_amd'] <= 3 * n + 16
+
+
+def test_deterministic():
+    S = delaunay(3000, seed=5)
+    p1, _ = ordering(S, 0)
+    p2, _ = ordering(S, 0)
+    assert np.array_equal(p1, p2)
