@@ -296,3 +296,25 @@ def test_sparse_unstructured_patterns_with_every_ordering(pattern, ordering, mon
     rhs = bx + G.T @ (W['di'] ** 2 * bz)
     assert np.linalg.norm(S @ x - rhs) / np.linalg.norm(rhs) < 1e-11
     f.engine.close()
+
+
+def test_sparse_engine_reproduces_the_reference_doc_cholmod_example():
+    """The only sparse-Cholesky known answer the reference holds (doc/source/spsolvers.rst:281-302 and :440-448,
+    cholmod.linsolve / symbolic + numeric + solve on the 4x4 matrix e-A-pd).  Here S = H + G'D^2G with H = A - e0 e0',
+    G = e0', d = 1, so the sparse engine factors exactly that A."""
+    A = sp.csc_matrix(np.array([[10., 0, 3, 0], [0, 5, 0, -2], [3, 0, 5, 0], [0, -2, 0, 2]]))
+    H = A.copy().tolil(); H[0, 0] = 9.0; H = sp.csc_matrix(H)
+    G = sp.csc_matrix(np.array([[1., 0, 0, 0]]))
+    dims = {'l': 1, 'q': [], 's': []}
+    f = kkt.kkt_chol2(FakeSp(G), dims, np.zeros((0, 4)))
+    W = {'d': np.ones(1), 'di': np.ones(1), 'v': [], 'beta': [], 'r': [], 'rti': []}
+    solve = f(W, FakeSp(sp.tril(H)))
+    assert f.engine._mode == "sparse"
+    X = np.arange(8.0).reshape(4, 2, order='F')
+    doc = np.array([[-1.46e-01, 4.88e-02], [1.33e+00, 4.00e+00], [4.88e-01, 1.17e+00], [2.83e+00, 7.50e+00]])
+    for k in range(2):
+        x, y, z = X[:, k].copy(), np.zeros(0), np.zeros(1)
+        solve(x, y, z)
+        assert np.allclose(x, doc[:, k], rtol=5e-3)                      # the printed transcript (3 digits)
+        assert np.allclose(A @ x, X[:, k], rtol=0, atol=1e-13)
+    f.engine.close()
