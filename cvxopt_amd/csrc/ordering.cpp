@@ -19,6 +19,7 @@
 #include <future>
 #include <memory>
 #include <numeric>
+#include <system_error>
 
 namespace mi355kkt {
 
@@ -863,9 +864,14 @@ struct Dissector {
         // the two sides are independent subproblems (disjoint nodes, disjoint output ranges): the first few levels of
         // the recursion run them on separate host threads
         if (depth < 5 && left.size() > 2048 && right.size() > 2048) {
-            auto fut = std::async(std::launch::async, [&]() { run(left, depth + 1, off); });
+            std::future<void> fut;
+            try {
+                fut = std::async(std::launch::async, [&]() { run(left, depth + 1, off); });
+            } catch (const std::system_error&) {   // no thread to be had: same work on this one
+                run(left, depth + 1, off);
+            }
             run(right, depth + 1, off_r);
-            fut.get();
+            if (fut.valid()) fut.get();
         } else {
             run(left, depth + 1, off);
             run(right, depth + 1, off_r);
@@ -915,8 +921,13 @@ void fill_reducing_ordering(const Graph& adj, std::vector<int>& order, int metho
         cost_of(cc_amd, I.nnz_amd, I.flops_amd);
     };
     std::future<void> amd_future;
-    if (method == 0) amd_future = std::async(std::launch::async, run_amd);    // beside the dissection, on its own thread
-    else if (method == 2) run_amd();
+    if (method == 0) {
+        try {
+            amd_future = std::async(std::launch::async, run_amd);               // beside the dissection, on its own thread
+        } catch (const std::system_error&) {
+            run_amd();
+        }
+    } else if (method == 2) run_amd();
     if (method != 2) {
         ond.assign(n, -1);
         std::vector<int> nodes(n);
