@@ -101,9 +101,10 @@ static int ipm_alloc(IpmWork& w, int nbatch, int n, int m, int np = 0) {
     if (w.f64) return 0;
     const size_t B = nbatch, N = n, M = m ? m : 1, Pq = np;
     const size_t nd = B * (8 * N + 13 * M + 6 * Pq + 9);
-    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
-    if (hipMalloc(&w.i32, sizeof(int) * (5 * B + 1)) != hipSuccess) return MI355KKT_ENOMEM;
-    if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
+    // all or nothing: a partially allocated state must not look complete to the next call
+    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) { ipm_free(w); return MI355KKT_ENOMEM; }
+    if (hipMalloc(&w.i32, sizeof(int) * (5 * B + 1)) != hipSuccess) { ipm_free(w); return MI355KKT_ENOMEM; }
+    if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) { ipm_free(w); return MI355KKT_ENOMEM; }
     w.B = nbatch;
     IpmState& S = w.S;
     S.n = n; S.m = m; S.p = np;
@@ -146,9 +147,10 @@ static int lp_alloc(LpWork& w, int n, int ml, const std::vector<int>& q, int np)
     const int m = ml + sumq, nq = (int)q.size();
     const size_t N = n ? n : 1, M = m ? m : 1, Pq = np ? np : 1;
     const size_t nd = 10 * N + 9 * Pq + 23 * M + (size_t)sumq + nq + LP_NSC + 8;
-    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
-    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq)) != hipSuccess) return MI355KKT_ENOMEM;
-    if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
+    // all or nothing: a partially allocated state must not look complete to the next call
+    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
+    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq)) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
+    if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
     LpState& S = w.S;
     S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq;
     double* p = w.f64;
@@ -194,9 +196,10 @@ static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, int np)
     const int m = ml + sumq, nq = (int)q.size();
     const size_t N = n ? n : 1, M = m ? m : 1, Pq = np ? np : 1;
     const size_t nd = 10 * N + 8 * Pq + 21 * M + (size_t)sumq + nq + QP_NSC + 8;
-    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) return MI355KKT_ENOMEM;
-    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq)) != hipSuccess) return MI355KKT_ENOMEM;
-    if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) return MI355KKT_ENOMEM;
+    // all or nothing: a partially allocated state must not look complete to the next call
+    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
+    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq)) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
+    if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
     QpState& S = w.S;
     S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq;
     double* p = w.f64;
@@ -649,12 +652,23 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     if (int e = bind(h)) return e;
     if (!h->dS) {   // dense engine state is created on first use (a sparse-mode handle never pays for it)
         const size_t N = (size_t)h->n;
-        KKT_HIP_CHECK(hipMalloc(&h->dS, sizeof(double) * dmax(N * N, 1)));
+        // all or nothing: dS doubles as the "dense state exists" flag, so it is set last
+        double *newS = nullptr, *newwork = nullptr;
+        const size_t work_doubles = dmax(dmax(gemv_work_doubles(h->cdim, h->n), gemv_work_doubles(h->n, h->p)), (size_t)h->cdim + 8);
+        if (hipMalloc(&newS, sizeof(double) * dmax(N * N, 1)) != hipSuccess ||
+            hipMalloc(&newwork, sizeof(double) * work_doubles) != hipSuccess) {
+            if (newS) (void)hipFree(newS);
+            set_last_error("factor: out of device memory for the %zu x %zu reduced KKT matrix", N, N);
+            return MI355KKT_ENOMEM;
+        }
+        if (int e = build_syrk_plan(h->planS, h->n, h->krows, h->num_cus)) {
+            (void)hipFree(newS);
+            (void)hipFree(newwork);
+            return e;
+        }
         (void)hipFree(h->dwork);
-        h->dwork = nullptr;
-        KKT_HIP_CHECK(hipMalloc(&h->dwork, sizeof(double) * dmax(dmax(gemv_work_doubles(h->cdim, h->n), gemv_work_doubles(h->n, h->p)),
-                                                                 (size_t)h->cdim + 8)));
-        if (int e = build_syrk_plan(h->planS, h->n, h->krows, h->num_cus)) return e;
+        h->dwork = newwork;
+        h->dS = newS;
     }
     h->factored = false;
     const double zscale = 1.0 / std::sqrt(1.0 + h->kktreg);   // K[z,z] = -(1+reg): fold into the row scaling
