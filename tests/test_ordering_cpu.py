@@ -145,3 +145,23 @@ def test_deterministic():
     p1, _ = ordering(S, 0)
     p2, _ = ordering(S, 0)
     assert np.array_equal(p1, p2)
+
+
+def delaunay3d(n, seed=0):
+    from scipy.spatial import Delaunay
+    t = Delaunay(np.random.default_rng(seed).random((n, 3))).simplices
+    r = np.concatenate([t[:, a] for a in range(4) for b in range(4) if a != b])
+    c = np.concatenate([t[:, b] for a in range(4) for b in range(4) if a != b])
+    return laplacian_of(sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)))
+
+
+def test_multilevel_dissection_on_a_tetrahedral_mesh(monkeypatch):
+    """the class config 4 stands for (finite-element stiffness patterns): the refined multilevel separators cut the
+    factorisation work well below both minimum degree and the plain level-set dissection"""
+    S = delaunay3d(8000, seed=1)
+    _, st = ordering(S, 0)
+    assert st['method'] == 1
+    assert st['flops_nd'] < 0.6 * st['flops_amd'] and st['nnz_nd'] < 0.85 * st['nnz_amd']
+    monkeypatch.setenv('MI355KKT_ND_MODE', '1')
+    _, levelset = ordering(S, 1)
+    assert st['flops_nd'] < 0.5 * levelset['flops_nd']
