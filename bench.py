@@ -40,6 +40,8 @@ def parse():
                          "class (3-D Laplacian box-QP); socp = configs[2] (n=2048, 1024 second-order cones of dimension 8)")
     ap.add_argument("--batch", type=int, default=512, help="problems per GPU for --workload batch")
     ap.add_argument("--grid", type=int, default=46, help="k for the k^3 Laplacian of --workload sparse")
+    ap.add_argument("--mesh", default="grid", choices=["grid", "tet"],
+                    help="--workload sparse: structured 7-point grid (default) or an unstructured tetrahedral mesh of k^3 nodes")
     ap.add_argument("--cpu-iters", type=int, default=2, help="reference CPU iterations timed (bounded sample)")
     return ap.parse_args()
 
@@ -171,10 +173,12 @@ def main_sparse(args):
     from cvxopt_amd import kkt, synth, _capi
     kkt.options["device"] = local_rank
     k = args.grid
-    e = np.ones(k)
-    T = sp.diags([-e[:-1], 2 * e, -e[:-1]], [-1, 0, 1])
-    I = sp.eye(k)
-    P = (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T) + 1e-2 * sp.eye(k ** 3)).tocsc()
+    if args.mesh == "tet":               # unstructured stand-in: Delaunay tetrahedralisation of k^3 random points
+        P = synth.tet_mesh_laplacian(k ** 3, seed=0)
+        what = "graph Laplacian of a random tetrahedral mesh with %d nodes" % (k ** 3)
+    else:
+        P = synth.grid_laplacian(k)
+        what = "%d^3 7-point Laplacian" % k
     n = k ** 3
     G = sp.vstack([sp.eye(n), -sp.eye(n)]).tocsc()
 
@@ -210,8 +214,9 @@ def main_sparse(args):
             "unit": "KKT iterations/s (1 factor + 2 solves each)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "box-QP on the %d^3 7-point Laplacian (n=%d, m=%d), supernodal multifrontal engine; stand-in for "
-                                   "the ssget-1288 class (no network)" % (k, n, 2 * n), "replicas": world,
+            "config": {"workload": "box-QP on the %s (n=%d, m=%d), supernodal multifrontal engine; stand-in for "
+                                   "the ssget-1288 class (no network)" % (what, n, 2 * n), "replicas": world,
+                       "ordering": {1: "nested dissection", 2: "approximate minimum degree"}.get(st.get("ordering"), "?"),
                        "nnzL": st["nnzL"], "supernodes": st["supernodes"], "levels": st["levels"], "flops_estimate": st["flops"],
                        "symbolic_plus_first_factor_s": round(t_sym, 3)}}))
     if dist is not None:

@@ -44,6 +44,7 @@ SIGNATURES = {
     "mi355kkt_set_G_csc": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p, c_double_p]),
     "mi355kkt_set_sparse_problem": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p, c_double_p, c_i64_p, c_i64_p, c_double_p]),
     "mi355kkt_sparse_stats": (C.c_int, [C.c_void_p, c_i64_p, c_int_p, c_int_p, c_double_p]),
+    "mi355kkt_sparse_ordering": (C.c_int, [C.c_void_p]),
     "mi355kkt_set_A_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_G_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_A_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

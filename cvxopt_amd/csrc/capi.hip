@@ -529,6 +529,12 @@ int mi355kkt_sparse_stats(const mi355kkt_solver* h, int64_t* nnzL, int* nsuperno
     return 0;
 }
 
+/* which fill-reducing ordering the symbolic analysis chose: 1 nested dissection, 2 approximate minimum degree */
+int mi355kkt_sparse_ordering(const mi355kkt_solver* h) {
+    if (!h || !h->sparse) return MI355KKT_EINVAL;
+    return h->sp.sym.order_method;
+}
+
 int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA) {
     if (!h || (!A && h->p > 0 && h->n > 0) || ldA < (h->p > 1 ? h->p : 1)) {
         set_last_error("set_A_dense: invalid argument");

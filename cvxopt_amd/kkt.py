@@ -203,7 +203,8 @@ class _Engine(object):
     def sparse_stats(self):
         nnzL, ns, nl, fl = C.c_int64(), C.c_int(), C.c_int(), C.c_double()
         _capi.check(self.L.mi355kkt_sparse_stats(self.h, C.byref(nnzL), C.byref(ns), C.byref(nl), C.byref(fl)), "sparse_stats")
-        return {"nnzL": nnzL.value, "supernodes": ns.value, "levels": nl.value, "flops": fl.value}
+        return {"nnzL": nnzL.value, "supernodes": ns.value, "levels": nl.value, "flops": fl.value,
+                "ordering": int(self.L.mi355kkt_sparse_ordering(self.h))}
 
     def _set_H(self, H):
         if self._mode == "undecided":

@@ -67,3 +67,26 @@ def random_scaling(dims, seed=0, spread=2.0):
         W['r'].append(np.asfortranarray(R))
         W['rti'].append(np.asfortranarray(np.linalg.inv(R).T))
     return W
+
+
+def grid_laplacian(k, shift=1e-2):
+    """7-point Laplacian of the k x k x k grid + shift I (scipy.sparse CSC): the structured stand-in for the sparse config."""
+    import scipy.sparse as sp
+    e = np.ones(k)
+    T = sp.diags([-e[:-1], 2 * e, -e[:-1]], [-1, 0, 1])
+    I = sp.eye(k)
+    return (sp.kron(sp.kron(T, I), I) + sp.kron(sp.kron(I, T), I) + sp.kron(sp.kron(I, I), T) + shift * sp.eye(k ** 3)).tocsc()
+
+
+def tet_mesh_laplacian(n, seed=0, shift=1e-2):
+    """Graph Laplacian of the Delaunay tetrahedralisation of n random points in the unit cube + shift I (scipy.sparse
+    CSC, about 15.5 off-diagonals per row): an unstructured finite-element stiffness pattern, the class the sparse
+    config's SuiteSparse matrix belongs to."""
+    import scipy.sparse as sp
+    from scipy.spatial import Delaunay
+    t = Delaunay(np.random.default_rng(seed).random((n, 3))).simplices
+    r = np.concatenate([t[:, a] for a in range(4) for b in range(4) if a != b])
+    c = np.concatenate([t[:, b] for a in range(4) for b in range(4) if a != b])
+    A = sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)).tocsc()
+    A.data[:] = 1.0                      # duplicates were summed: back to a 0/1 adjacency matrix
+    return (sp.diags(np.asarray(A.sum(1)).ravel() + shift) - A).tocsc()

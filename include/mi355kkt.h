@@ -94,6 +94,9 @@ int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA);     
 int mi355kkt_set_sparse_problem(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
                                 const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues);
 int mi355kkt_sparse_stats(const mi355kkt_solver* h, int64_t* nnzL, int* nsupernodes, int* nlevels, double* flops);
+/* the fill-reducing ordering chosen by the symbolic analysis (csrc/ordering.cpp): 1 nested dissection, 2 approximate
+ * minimum degree; MI355KKT_EINVAL when the handle is not in sparse mode */
+int mi355kkt_sparse_ordering(const mi355kkt_solver* h);
 /* device-resident variants: the solver borrows the pointers (no copy); they must outlive the handle */
 int mi355kkt_set_G_device(mi355kkt_solver* h, const double* dG, int64_t ldG);
 int mi355kkt_set_A_device(mi355kkt_solver* h, const double* dA, int64_t ldA);
