@@ -145,6 +145,16 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
         eng.close()
 
 
+def _no_external_solver(kwargs):
+    """`solver=` of solvers.lp / qp / socp / sdp selects GLPK / MOSEK / DSDP in the reference (coneprog.py:2550, :3013,
+    :3566, :4156): bridges to other codes, outside this backend.  None (the default) is accepted and dropped."""
+    solver = kwargs.pop('solver', None)
+    if solver is not None:
+        raise ValueError("cvxopt_amd.solvers: solver=%r selects an external solver of the reference; only the default "
+                         "(conelp / coneqp) runs on the device" % (solver,))
+    return kwargs
+
+
 def _stack(blocks, n):
     """[Gl; G_1; ...; G_N] as one matrix: sparse when every block is, dense otherwise (coneprog.py:3303-3318, :4085-4098)"""
     from cvxopt import matrix, sparse, spmatrix
@@ -189,6 +199,7 @@ def _split_cone_vectors(sol, ml, sizes, suffix, shape):
 def socp(c, Gl=None, hl=None, Gq=None, hq=None, A=None, b=None, primalstart=None, dualstart=None, **kwargs):
     """cvxopt.solvers.socp's argument convention (coneprog.py:3013-3378: stacks Gl, Gq[k] and calls conelp)."""
     from cvxopt import matrix
+    kwargs = _no_external_solver(kwargs)
     n = c.size[0]
     Gq, hq = list(Gq or []), list(hq or [])
     if len(Gq) != len(hq):
@@ -213,6 +224,7 @@ def sdp(c, Gl=None, hl=None, Gs=None, hs=None, A=None, b=None, primalstart=None,
     coefficient matrix), hs[k] is m_k x m_k; stacked into one cone LP with dims['s'] = [m_k]; 'ss', 'zs' come back as
     m_k x m_k matrices.  The 's' cone runs through the host driver with device operators + the GPU kktsolver."""
     from cvxopt import matrix
+    kwargs = _no_external_solver(kwargs)
     n = c.size[0]
     Gs, hs = list(Gs or []), list(hs or [])
     ms = [int(round(Gk.size[0] ** 0.5)) for Gk in Gs]
@@ -241,9 +253,9 @@ def sdp(c, Gl=None, hl=None, Gs=None, hs=None, A=None, b=None, primalstart=None,
 
 def lp(c, G, h, A=None, b=None, **kwargs):
     """cvxopt.solvers.lp (coneprog.py:2562: conelp with dims = {'l': m})."""
-    return conelp(c, G, h, {'l': h.size[0], 'q': [], 's': []}, A, b, **kwargs)
+    return conelp(c, G, h, {'l': h.size[0], 'q': [], 's': []}, A, b, **_no_external_solver(kwargs))
 
 
 def qp(P, q, G=None, h=None, A=None, b=None, **kwargs):
     """cvxopt.solvers.qp (coneprog.py:4258: coneqp with dims = {'l': m})."""
-    return coneqp(P, q, G, h, None, A, b, **kwargs)
+    return coneqp(P, q, G, h, None, A, b, **_no_external_solver(kwargs))

@@ -135,3 +135,19 @@ def test_socp_wrapper_packs_and_splits_like_the_reference(ref_cvxopt, monkeypatc
     got = gs.socp(c, Gl, hl, G, h, primalstart=ps, dualstart=ds)
     assert ref['status'] == 'optimal'
     assert all(_same(ref[k], got[k]) for k in ref), [k for k in ref if not _same(ref[k], got[k])]
+
+
+def test_external_solver_bridges_are_refused(ref_cvxopt, monkeypatch):
+    from cvxopt import matrix
+    seen = {}
+    monkeypatch.setattr(gs, 'conelp', lambda *a, **k: seen.setdefault('conelp', k) or {})
+    monkeypatch.setattr(gs, 'coneqp', lambda *a, **k: seen.setdefault('coneqp', k) or {})
+    c, G, h = matrix([1.0, 1.0]), matrix([[-1.0, 0.0], [0.0, -1.0]]), matrix([0.0, 0.0])
+    gs.lp(c, G, h, solver=None, kktsolver='ldl')
+    assert seen['conelp'] == {'kktsolver': 'ldl'}
+    gs.qp(matrix([[1.0, 0.0], [0.0, 1.0]]), c, G, h, solver=None)
+    assert seen['coneqp'] == {}
+    for call in (lambda: gs.lp(c, G, h, solver='glpk'), lambda: gs.qp(G, c, G, h, solver='mosek'),
+                 lambda: gs.socp(c, G, h, solver='mosek'), lambda: gs.sdp(c, G, h, solver='dsdp')):
+        with pytest.raises(ValueError):
+            call()
