@@ -259,3 +259,41 @@ def lp(c, G, h, A=None, b=None, **kwargs):
 def qp(P, q, G=None, h=None, A=None, b=None, **kwargs):
     """cvxopt.solvers.qp (coneprog.py:4258: coneqp with dims = {'l': m})."""
     return coneqp(P, q, G, h, None, A, b, **_no_external_solver(kwargs))
+
+
+class _gpu_factories(object):
+    """while active, cvxopt.misc.kkt_{chol,chol2,ldl,ldl2,qr} are the GPU factories (cvxprog resolves the kktsolver names
+    at call time, cvxprog.py:527-537, :1877-1887); restores the previous binding unless install() was already in force"""
+
+    def __enter__(self):
+        self._was_installed = bool(_kkt._saved)
+        _kkt.install()
+
+    def __exit__(self, *exc):
+        if not self._was_installed:
+            _kkt.uninstall()
+        return False
+
+
+def cpl(c, F, G=None, h=None, dims=None, A=None, b=None, kktsolver=None, **kwargs):
+    """cvxopt.solvers.cpl (cvxprog.py:35: convex problem with linear objective): the reference driver on the host, every
+    `factor(W, H, Df)` / solve on the device through the kktsolver names ('ldl', 'ldl2', 'chol', 'chol2'; default as the
+    reference: 'chol' with q / s cones, 'chol2' otherwise).  The nonlinear-constraint rows (mnl, Df) are refreshed on the
+    device at every call (`mi355kkt_set_G_rows`)."""
+    from cvxopt import solvers
+    with _gpu_factories():
+        return solvers.cpl(c, F, G, h, dims, A, b, kktsolver=kktsolver, **kwargs)
+
+
+def cp(F, G=None, h=None, dims=None, A=None, b=None, kktsolver=None, **kwargs):
+    """cvxopt.solvers.cp (cvxprog.py:1359) with the GPU factories behind the kktsolver names."""
+    from cvxopt import solvers
+    with _gpu_factories():
+        return solvers.cp(F, G, h, dims, A, b, kktsolver=kktsolver, **kwargs)
+
+
+def gp(K, F, g, G=None, h=None, A=None, b=None, kktsolver=None, **kwargs):
+    """cvxopt.solvers.gp (cvxprog.py:1967: geometric program, calls cp) with the GPU factories."""
+    from cvxopt import solvers
+    with _gpu_factories():
+        return solvers.gp(K, F, g, G, h, A, b, kktsolver=kktsolver, **kwargs)

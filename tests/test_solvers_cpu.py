@@ -151,3 +151,46 @@ def test_external_solver_bridges_are_refused(ref_cvxopt, monkeypatch):
                  lambda: gs.socp(c, G, h, solver='mosek'), lambda: gs.sdp(c, G, h, solver='dsdp')):
         with pytest.raises(ValueError):
             call()
+
+
+def test_cvxprog_wrappers_bind_the_gpu_factories_for_the_call_only(ref_cvxopt, monkeypatch):
+    """cp / cpl / gp run the reference drivers with cvxopt.misc.kkt_* pointing at the GPU factories during the call."""
+    import cvxopt.misc as misc
+    from cvxopt import solvers
+    from cvxopt_amd import kkt
+    before = {n: getattr(misc, n) for n in ('kkt_chol', 'kkt_chol2', 'kkt_ldl', 'kkt_ldl2', 'kkt_qr')}
+    seen = {}
+
+    def fake(name):
+        def f(*a, **k):
+            seen[name] = dict(bound={n: getattr(misc, n) for n in before}, args=a, kw=k)
+            return {'status': 'optimal'}
+        return f
+    for name in ('cp', 'cpl', 'gp'):
+        monkeypatch.setattr(solvers, name, fake(name))
+    assert gs.cp('F', 'G', 'h', kktsolver='ldl', options={'maxiters': 3}) == {'status': 'optimal'}
+    assert seen['cp']['args'] == ('F', 'G', 'h', None, None, None) and seen['cp']['kw'] == {'kktsolver': 'ldl', 'options': {'maxiters': 3}}
+    assert seen['cp']['bound'] == {'kkt_chol': kkt.kkt_chol, 'kkt_chol2': kkt.kkt_chol2, 'kkt_ldl': kkt.kkt_ldl,
+                                   'kkt_ldl2': kkt.kkt_ldl2, 'kkt_qr': kkt.kkt_qr}
+    assert {n: getattr(misc, n) for n in before} == before            # restored afterwards
+    gs.cpl('c', 'F')
+    assert seen['cpl']['args'][:2] == ('c', 'F') and seen['cpl']['kw'] == {'kktsolver': None}
+    gs.gp('K', 'F', 'g')
+    assert seen['gp']['args'][:3] == ('K', 'F', 'g')
+    assert {n: getattr(misc, n) for n in before} == before
+    # an install() made by the user stays in force
+    kkt.install()
+    try:
+        gs.cp('F')
+        assert misc.kkt_chol is kkt.kkt_chol
+    finally:
+        kkt.uninstall()
+    assert {n: getattr(misc, n) for n in before} == before
+
+    # and a failing driver does not leave the factories bound
+    def boom(*a, **k):
+        raise ArithmeticError(3)
+    monkeypatch.setattr(solvers, 'cp', boom)
+    with pytest.raises(ArithmeticError):
+        gs.cp('F')
+    assert {n: getattr(misc, n) for n in before} == before
