@@ -83,6 +83,7 @@ SIGNATURES = {
     "mi355kkt_op_syrk_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_int64, c_float_p]),
     "mi355kkt_op_symbolic": (C.c_int, [C.c_int, C.c_int, c_i64_p, c_i64_p, c_i64_p, c_i64_p, c_int_p, c_i64_p, c_int_p, c_int_p]),
+    "mi355kkt_debug_symbolic_plan": (C.c_int64, [C.c_int, C.c_int, c_i64_p, c_i64_p, c_i64_p, c_i64_p, c_i64_p, C.c_int64]),
     "mi355kkt_op_cone_scale": (C.c_int, [C.c_int, C.c_int, c_int_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, c_float_p]),
     "mi355kkt_debug_hwid": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1613,6 +1613,50 @@ int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* gr
     return 0;
 }
 
+/* host-only: the whole plan of the symbolic analysis as one flat int64 array, for the CPU tests that execute the plan in
+ * NumPy (tests/test_sparse_plan_cpu.py).  out = header[16] followed by the arrays in the order of the header counts:
+ *   header = { n, ns, nlevels, store_doubles, ntargets, ncontrib, order_method, nrows, nchildren, nrelmap, 0... }
+ *   perm[n], sn_first[ns+1], sn_rowptr[ns+1], sn_rows[nrows], panel_off[ns+1], upd_off[ns], upd_ld[ns], big[ns],
+ *   sn_level[ns], child_ptr[ns+1], child_list[nchildren], relmap_off[ns+1], relmap[nrelmap],
+ *   asm_slot[ntargets], asm_ptr[ntargets+1], asm_a[ncontrib], asm_b[ncontrib], asm_r[ncontrib].
+ * Returns the number of int64 entries of the plan (call with cap = 0 to size the buffer), or a negative error code. */
+int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
+                                     const int64_t* hrowind, int64_t* out, int64_t cap) {
+    SparseSymbolic S;
+    if (int e = symbolic_analyze(S, n, m, gcolptr, growind, hcolptr, hrowind)) return e;
+    const int ns = S.ns;
+    const int64_t nrows = ns ? S.sn_rowptr[ns] : 0, nch = ns ? S.child_ptr[ns] : 0, nrel = ns ? S.relmap_off[ns] : 0;
+    const int64_t nt = (int64_t)S.asm_slot.size(), nc = (int64_t)S.asm_a.size();
+    const int64_t need = 16 + (int64_t)n + 2 * (int64_t)(ns + 1) + nrows + (ns + 1) + 4 * (int64_t)ns + (ns + 1) + nch + (ns + 1) + nrel +
+                         nt + (nt + 1) + 3 * nc;
+    if (!out || cap < need) return need;
+    int64_t* p = out;
+    const int64_t header[16] = {n, ns, S.nlevels, S.store_doubles, nt, nc, S.order_method, nrows, nch, nrel, 0, 0, 0, 0, 0, 0};
+    for (int64_t v : header) *p++ = v;
+    auto put = [&](const auto& vec, int64_t count) {
+        for (int64_t k = 0; k < count; ++k) *p++ = (int64_t)vec[k];
+    };
+    put(S.perm, n);
+    put(S.sn_first, ns + 1);
+    put(S.sn_rowptr, ns + 1);
+    put(S.sn_rows, nrows);
+    put(S.panel_off, ns + 1);
+    put(S.upd_off, ns);
+    put(S.upd_ld, ns);
+    put(S.big, ns);
+    put(S.sn_level, ns);
+    put(S.child_ptr, ns + 1);
+    put(S.child_list, nch);
+    put(S.relmap_off, ns + 1);
+    put(S.relmap, nrel);
+    put(S.asm_slot, nt);
+    put(S.asm_ptr, nt + 1);
+    put(S.asm_a, nc);
+    put(S.asm_b, nc);
+    put(S.asm_r, nc);
+    return (p - out == need) ? need : (int64_t)MI355KKT_EINVAL;
+}
+
 int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
                            const double* dv, const double* dbeta, float* ms) {
     ConeLayout cl;

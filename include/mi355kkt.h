@@ -205,6 +205,10 @@ int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const d
 /* host-only: symbolic analysis of the sparse engine (nested-dissection ordering perm[new] = old, supernodal nnz(L)) */
 int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
                          const int64_t* hrowind, int* perm, int64_t* nnzL, int* nsupernodes, int* nlevels);
+/* host-only: the complete symbolic plan (supernodes, row lists, storage offsets, extend-add maps, assembly lists) as one flat
+ * int64 array -- layout in csrc/capi.hip; returns its length (cap = 0 sizes it) or a negative error code */
+int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
+                                     const int64_t* hrowind, int64_t* out, int64_t cap);
 /* X(:, 0:ncols) := W^-T X on the 'l' and 'q' rows, in place (misc_solvers.scale, trans='T', inverse='I') */
 int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
                            const double* dv, const double* dbeta, float* ms);
