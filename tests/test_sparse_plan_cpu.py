@@ -186,3 +186,38 @@ def test_big_front_threshold_switches_the_storage_layout(monkeypatch):
         assert bool(plan.big.all()) == (flops == 0) and bool(plan.big.any()) == (flops == 0)
         out.append((plan.perm.copy(), plan.factor(di)))
     assert np.array_equal(out[0][0], out[1][0]) and np.allclose(out[0][1], out[1][1], rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_patterns_orderings_and_thresholds(seed, monkeypatch):
+    """seeded fuzz: random H / G patterns (empty rows, dense-ish rows, disconnected parts), a random ordering variant and
+    random big-front thresholds per case"""
+    rng = np.random.default_rng(100 + seed)
+    done = 0
+    while done < 8:
+        n = int(rng.integers(1, 220))
+        m = int(rng.integers(1, 2 * n + 2))
+        dens = float(rng.choice([0.0, 0.5 / n, 2.0 / n, 8.0 / n, 0.3]))
+        H = sp.random(n, n, density=min(1.0, dens), random_state=int(rng.integers(1 << 30)), format='csc')
+        H = H + H.T
+        H = (H + sp.diags(np.asarray(abs(H).sum(1)).ravel() + float(rng.choice([0.0, 1.0])))).tocsc()
+        G = sp.random(m, n, density=min(1.0, float(rng.choice([1.0 / n, 3.0 / n, 0.2]))),
+                      random_state=int(rng.integers(1 << 30)), format='csc')
+        G = sp.vstack([G, sp.eye(n)]).tocsc()
+        name = list(ORDERINGS)[int(rng.integers(len(ORDERINGS)))]
+        for k in ('MI355KKT_ORDERING', 'MI355KKT_ND_LEAF_AMD', 'MI355KKT_ND_MODE', 'MI355KKT_ND_NOREFINE',
+                  'MI355KKT_SPARSE_BIG_FLOPS', 'MI355KKT_SPARSE_BIG_H'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in ORDERINGS[name].items():
+            monkeypatch.setenv(k, v)
+        if rng.random() < 0.4:
+            monkeypatch.setenv('MI355KKT_SPARSE_BIG_FLOPS', repr(float(rng.choice([0, 1e3, 1e30]))))
+            monkeypatch.setenv('MI355KKT_SPARSE_BIG_H', str(int(rng.choice([1, 8, 48]))))
+        di = 10.0 ** rng.uniform(-1, 1, G.shape[0])
+        plan = Plan(G, H)
+        plan.check_structure()
+        S = plan.S(di).toarray()
+        L = plan.factor(di)
+        Sp = S[np.ix_(plan.perm, plan.perm)]
+        assert np.linalg.norm(L @ L.T - Sp) <= 1e-11 * np.linalg.norm(Sp), (n, m, name)
+        done += 1
