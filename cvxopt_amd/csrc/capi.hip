@@ -1618,7 +1618,9 @@ int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* gr
  *   header = { n, ns, nlevels, store_doubles, ntargets, ncontrib, order_method, nrows, nchildren, nrelmap, 0... }
  *   perm[n], sn_first[ns+1], sn_rowptr[ns+1], sn_rows[nrows], panel_off[ns+1], upd_off[ns], upd_ld[ns], big[ns],
  *   sn_level[ns], child_ptr[ns+1], child_list[nchildren], relmap_off[ns+1], relmap[nrelmap],
- *   asm_slot[ntargets], asm_ptr[ntargets+1], asm_a[ncontrib], asm_b[ncontrib], asm_r[ncontrib].
+ *   asm_slot[ntargets], asm_ptr[ntargets+1], asm_a[ncontrib], asm_b[ncontrib], asm_r[ncontrib],
+ *   level_ptr[nlevels+1], level_sn[ns], level_nsmall[nlevels], vb_ptr[nlevels+1], vb[5 * nvb] (off, h, w, col0, supernode),
+ *   heavy_ptr[nlevels+1], heavy[nheavy]    (header[10] = nvb, header[11] = nheavy).
  * Returns the number of int64 entries of the plan (call with cap = 0 to size the buffer), or a negative error code. */
 int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
                                      const int64_t* hrowind, int64_t* out, int64_t cap) {
@@ -1627,11 +1629,12 @@ int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const
     const int ns = S.ns;
     const int64_t nrows = ns ? S.sn_rowptr[ns] : 0, nch = ns ? S.child_ptr[ns] : 0, nrel = ns ? S.relmap_off[ns] : 0;
     const int64_t nt = (int64_t)S.asm_slot.size(), nc = (int64_t)S.asm_a.size();
+    const int64_t nvb = (int64_t)S.vb.size(), nheavy = (int64_t)S.heavy.size(), nl = S.nlevels;
     const int64_t need = 16 + (int64_t)n + 2 * (int64_t)(ns + 1) + nrows + (ns + 1) + 4 * (int64_t)ns + (ns + 1) + nch + (ns + 1) + nrel +
-                         nt + (nt + 1) + 3 * nc;
+                         nt + (nt + 1) + 3 * nc + (nl + 1) + ns + nl + (nl + 1) + 5 * nvb + (nl + 1) + nheavy;
     if (!out || cap < need) return need;
     int64_t* p = out;
-    const int64_t header[16] = {n, ns, S.nlevels, S.store_doubles, nt, nc, S.order_method, nrows, nch, nrel, 0, 0, 0, 0, 0, 0};
+    const int64_t header[16] = {n, ns, S.nlevels, S.store_doubles, nt, nc, S.order_method, nrows, nch, nrel, nvb, nheavy, 0, 0, 0, 0};
     for (int64_t v : header) *p++ = v;
     auto put = [&](const auto& vec, int64_t count) {
         for (int64_t k = 0; k < count; ++k) *p++ = (int64_t)vec[k];
@@ -1654,6 +1657,13 @@ int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const
     put(S.asm_a, nc);
     put(S.asm_b, nc);
     put(S.asm_r, nc);
+    put(S.level_ptr, nl + 1);
+    put(S.level_sn, ns);
+    put(S.level_nsmall, nl);
+    put(S.vb_ptr, nl + 1);
+    for (const VbDesc& d : S.vb) { *p++ = d.off; *p++ = d.h; *p++ = d.w; *p++ = d.col0; *p++ = d.pad; }
+    put(S.heavy_ptr, nl + 1);
+    put(S.heavy, nheavy);
     return (p - out == need) ? need : (int64_t)MI355KKT_EINVAL;
 }
 

@@ -30,7 +30,7 @@ class Plan(object):
         out = np.zeros(need, dtype=np.int64)
         got = L.mi355kkt_debug_symbolic_plan(n, m, ptr[0], ptr[1], ptr[2], ptr[3], out.ctypes.data_as(_capi.c_i64_p), need)
         assert got == need
-        (self.n, self.ns, self.nlevels, self.store, nt, nc, self.method, nrows, nch, nrel) = [int(v) for v in out[:10]]
+        (self.n, self.ns, self.nlevels, self.store, nt, nc, self.method, nrows, nch, nrel, nvb, nheavy) = [int(v) for v in out[:12]]
         pos = [16]
 
         def take(k):
@@ -46,6 +46,10 @@ class Plan(object):
         self.relmap_off, self.relmap = take(ns + 1), take(nrel)
         self.asm_slot, self.asm_ptr = take(nt), take(nt + 1)
         self.asm_a, self.asm_b, self.asm_r = take(nc), take(nc), take(nc)
+        nl = self.nlevels
+        self.level_ptr, self.level_sn, self.level_nsmall = take(nl + 1), take(ns), take(nl)
+        self.vb_ptr, self.vb = take(nl + 1), take(5 * nvb).reshape(nvb, 5)
+        self.heavy_ptr, self.heavy = take(nl + 1), take(nheavy)
         assert pos[0] == need
 
     def S(self, di):
@@ -75,6 +79,23 @@ class Plan(object):
         assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])) and (not ends or ends[-1][1] <= self.store)   # no overlap
         assert np.all(self.panel_off[:ns] % 2 == 0)                                                    # 16-byte aligned fronts
         assert self.nlevels == (self.sn_level.max() + 1 if ns else 0)
+        # the level schedule: every supernode once, at its level; small fronts first (one batched launch), then the big
+        # ones in the order of the descriptor list the level-batched dense kernels read; the heavy list of the solves
+        assert sorted(self.level_sn.tolist()) == list(range(ns))
+        hgt = np.diff(self.sn_rowptr)
+        wid = np.diff(self.sn_first)
+        for l in range(self.nlevels):
+            sl = self.level_sn[self.level_ptr[l]:self.level_ptr[l + 1]]
+            assert len(sl) > 0 and np.all(self.sn_level[sl] == l)
+            k = int(self.level_nsmall[l])
+            assert not self.big[sl[:k]].any() and self.big[sl[k:]].all()
+            vb = self.vb[self.vb_ptr[l]:self.vb_ptr[l + 1]]
+            assert np.array_equal(vb[:, 4], sl[k:])
+            assert np.array_equal(vb[:, 0], self.panel_off[sl[k:]]) and np.array_equal(vb[:, 1], hgt[sl[k:]])
+            assert np.array_equal(vb[:, 2], wid[sl[k:]]) and np.array_equal(vb[:, 3], self.sn_first[sl[k:]])
+            heavy = self.heavy[self.heavy_ptr[l]:self.heavy_ptr[l + 1]]
+            expect = [int(s_) for s_ in sl if (hgt[s_] - wid[s_]) * wid[s_] > 32768]
+            assert heavy.tolist() == expect
 
     def factor(self, di):
         """executes the plan; returns the dense L (permuted order)"""
@@ -221,3 +242,13 @@ def test_random_patterns_orderings_and_thresholds(seed, monkeypatch):
         Sp = S[np.ix_(plan.perm, plan.perm)]
         assert np.linalg.norm(L @ L.T - Sp) <= 1e-11 * np.linalg.norm(Sp), (n, m, name)
         done += 1
+
+
+def test_structure_of_a_larger_plan_with_heavy_supernodes():
+    """structure only (no NumPy factorisation): a 3-D grid whose top separators give supernodes with large off-diagonal
+    panels -- the ones the solves hand to the multi-workgroup kernels"""
+    n = 22 ** 3
+    plan = Plan(box(n), lap3(22))
+    plan.check_structure()
+    assert len(plan.heavy) > 0 and plan.big.any() and not plan.big.all()
+    assert plan.nlevels < 40
