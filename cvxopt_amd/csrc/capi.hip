@@ -1740,7 +1740,8 @@ int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* ou
 /* Fill-reducing ordering of a symmetric pattern (host only, for the CPU tests of csrc/ordering.cpp): colptr/rowind = CSC
  * pattern of any part of the matrix that contains each off-diagonal pair at least once; method 0 = choose, 1 = nested
  * dissection, 2 = approximate minimum degree.  perm[new] = old.  stats[0..6] = method chosen, nnz(L) and flops of the
- * dissection candidate, nnz(L) and flops of the minimum-degree candidate, supernodal tree heights of the two. */
+ * dissection candidate, nnz(L) and flops of the minimum-degree candidate, supernodal tree heights of the two; stats[7] = 1
+ * when the two column-count algorithms agree on the returned order (and with the tree / counts the analysis keeps). */
 int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats) {
     if (n < 0 || !colptr || !perm) return MI355KKT_EINVAL;
     mi355kkt::Graph adj(n);
@@ -1762,6 +1763,12 @@ int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind,
     if (stats) {
         stats[0] = info.method; stats[1] = (double)info.nnz_nd; stats[2] = info.flops_nd; stats[3] = (double)info.nnz_amd;
         stats[4] = info.flops_amd; stats[5] = info.levels_nd; stats[6] = info.levels_amd;
+        // cross-check of the column counts (skeleton / LCA algorithm) against the row-subtree walk, on the final order
+        std::vector<int> par;
+        std::vector<int64_t> fast, slow;
+        mi355kkt::etree_and_counts(adj, order, par, fast);
+        mi355kkt::column_counts_by_row_subtrees(adj, order, par, slow);
+        stats[7] = (fast == slow && fast == info.colcount && par == info.parent) ? 1.0 : 0.0;
     }
     return 0;
 }

@@ -26,13 +26,17 @@ namespace mi355kkt {
 // =====================================================================================================
 // elimination tree, column counts, postorder
 // =====================================================================================================
+// Column counts by the skeleton / least-common-ancestor algorithm of Gilbert, Ng & Peyton ("An efficient algorithm to
+// compute row and column counts for sparse Cholesky factorization", SIMAX 1994; the formulation of Davis, "Direct
+// Methods for Sparse Linear Systems", section 4.5): O(nnz(A) alpha) instead of the O(nnz(L)) row-subtree walk -- the
+// counts feed the cost model of two candidate orderings, so they are on the analysis' critical path.
 void etree_and_counts(const Graph& adj, const std::vector<int>& order, std::vector<int>& parent, std::vector<int64_t>& cc) {
     const int n = (int)adj.size();
     std::vector<int> iperm(n);
     for (int k = 0; k < n; ++k) iperm[order[k]] = k;
     parent.assign(n, -1);
     cc.assign(n, 0);
-    std::vector<int> anc(n, -1), mark(n, -1);
+    std::vector<int> anc(n, -1);
     // Liu's algorithm with path compression, row by row; rows in permuted order
     for (int i = 0; i < n; ++i)
         for (int u : adj[order[i]]) {
@@ -48,7 +52,70 @@ void etree_and_counts(const Graph& adj, const std::vector<int>& order, std::vect
                 parent[r] = i;
             }
         }
-    // row subtrees: row i is in struct(j) for every j on the tree paths from the entries k < i of row i up to i
+    // a postorder of the tree (children in index order)
+    std::vector<int> post;
+    post.reserve(n);
+    {
+        std::vector<int> head(n, -1), next(n, -1), stack;
+        for (int v = n - 1; v >= 0; --v)
+            if (parent[v] >= 0) { next[v] = head[parent[v]]; head[parent[v]] = v; }
+        for (int r = 0; r < n; ++r) {
+            if (parent[r] >= 0) continue;
+            stack.push_back(r);
+            while (!stack.empty()) {
+                const int v = stack.back(), c = head[v];
+                if (c >= 0) { head[v] = next[c]; stack.push_back(c); }
+                else { post.push_back(v); stack.pop_back(); }
+            }
+        }
+    }
+    // first[j] = postorder rank of the first descendant of j; delta[j] = 1 for the leaves of the tree
+    std::vector<int> first(n, -1), maxfirst(n, -1), prevleaf(n, -1), ancestor(n);
+    std::vector<int64_t>& delta = cc;
+    for (int k = 0; k < n; ++k) {
+        int j = post[k];
+        delta[j] = (first[j] == -1) ? 1 : 0;
+        for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = k;
+    }
+    for (int i = 0; i < n; ++i) ancestor[i] = i;
+    for (int k = 0; k < n; ++k) {
+        const int j = post[k];
+        if (parent[j] != -1) delta[parent[j]]--;          // j is not a root
+        for (int u : adj[order[j]]) {
+            const int i = iperm[u];
+            // is j a leaf of the i-th row subtree?
+            if (i <= j || first[j] <= maxfirst[i]) continue;
+            maxfirst[i] = first[j];
+            const int jprev = prevleaf[i];
+            prevleaf[i] = j;
+            delta[j]++;                                    // j is a (first or subsequent) leaf: one more entry in column j
+            if (jprev != -1) {                             // subsequent leaf: the overlap starts at lca(jprev, j)
+                int q = jprev;
+                while (q != ancestor[q]) q = ancestor[q];
+                for (int sx = jprev; sx != q;) {
+                    const int sp = ancestor[sx];
+                    ancestor[sx] = q;
+                    sx = sp;
+                }
+                delta[q]--;
+            }
+        }
+        if (parent[j] != -1) ancestor[j] = parent[j];
+    }
+    for (int k = 0; k < n; ++k) {                          // sum the deltas up the tree, children before parents
+        const int j = post[k];
+        if (parent[j] != -1) cc[parent[j]] += cc[j];
+    }
+    for (int j = 0; j < n; ++j) cc[j] -= 1;                // entries below the diagonal
+}
+
+// the same counts by walking every row subtree (each entry of L is visited once): the check of the fast algorithm
+void column_counts_by_row_subtrees(const Graph& adj, const std::vector<int>& order, const std::vector<int>& parent,
+                                   std::vector<int64_t>& cc) {
+    const int n = (int)adj.size();
+    std::vector<int> iperm(n), mark(n, -1);
+    for (int k = 0; k < n; ++k) iperm[order[k]] = k;
+    cc.assign(n, 0);
     for (int i = 0; i < n; ++i) {
         mark[i] = i;
         for (int u : adj[order[i]]) {

@@ -26,6 +26,10 @@ void fill_reducing_ordering(const Graph& adj, std::vector<int>& order, int metho
 // elimination tree and column counts (entries below the diagonal) of the Cholesky factor of the graph permuted by order
 void etree_and_counts(const Graph& adj, const std::vector<int>& order, std::vector<int>& parent, std::vector<int64_t>& cc);
 
+// column counts by the O(nnz(L)) row-subtree walk (reference implementation for the tests of etree_and_counts)
+void column_counts_by_row_subtrees(const Graph& adj, const std::vector<int>& order, const std::vector<int>& parent,
+                                   std::vector<int64_t>& cc);
+
 // relaxed supernode partition of a postordered elimination tree (first column of every supernode, supernode of every column)
 void relaxed_supernodes(const std::vector<int>& parent, const std::vector<int64_t>& cc, std::vector<int>& sn_first,
                         std::vector<int>& sn_of);

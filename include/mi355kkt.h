@@ -221,7 +221,7 @@ int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, d
 int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit);
 /* fill-reducing ordering of a symmetric CSC pattern (host only; csrc/ordering.cpp -- the step cholmod.symbolic performs through
  * cholmod_analyze_p, reference src/C/cholmod.c:309): method 0 choose / 1 nested dissection / 2 approximate minimum degree;
- * perm[new] = old; stats[7] = chosen method, nnz and flops of both candidates, supernodal tree heights */
+ * perm[new] = old; stats[8] = chosen method, nnz and flops of both candidates, supernodal tree heights, count cross-check */
 int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats);
 int mi355kkt_debug_potf2_skip(int mask);
 int mi355kkt_debug_syrk_skip(int mask);

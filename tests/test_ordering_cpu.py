@@ -25,6 +25,7 @@ def ordering(S, method=0):
                                    perm.ctypes.data_as(_capi.c_int_p), stats.ctypes.data_as(_capi.c_double_p))
     assert rc == 0
     assert sorted(perm.tolist()) == list(range(n))
+    assert stats[7] == 1.0       # Gilbert-Ng-Peyton column counts == row-subtree counts; postordered tree kept by the analysis
     return perm, dict(method=int(stats[0]), nnz_nd=int(stats[1]), flops_nd=stats[2], nnz_amd=int(stats[3]),
                       flops_amd=stats[4], levels_nd=int(stats[5]), levels_amd=int(stats[6]))
 
