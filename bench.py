@@ -40,6 +40,7 @@ def parse():
                          "class (3-D Laplacian box-QP); socp = configs[2] (n=2048, 1024 second-order cones of dimension 8)")
     ap.add_argument("--batch", type=int, default=512, help="problems per GPU for --workload batch")
     ap.add_argument("--grid", type=int, default=46, help="k for the k^3 Laplacian of --workload sparse")
+    ap.add_argument("--cone-dim", type=int, default=8, help="--workload socp: dimension of each of the 1024 second-order cones")
     ap.add_argument("--mesh", default="grid", choices=["grid", "tet"],
                     help="--workload sparse: structured 7-point grid (default) or an unstructured tetrahedral mesh of k^3 nodes")
     ap.add_argument("--cpu-iters", type=int, default=2, help="reference CPU iterations timed (bounded sample)")
@@ -232,7 +233,7 @@ def main_socp(args):
     from cvxopt_amd import kkt, synth, _capi
     import cvxopt_amd
     kkt.options["device"] = local_rank
-    n, ncones, r = 2048, 1024, 8
+    n, ncones, r = 2048, 1024, args.cone_dim      # dimension 8 is the survey's choice; 4 and 64 are the side cases
     pr = synth.socp(n=n, ncones=ncones, r=r, seed=rank)
     cdim = ncones * r
     W = synth.random_scaling(pr['dims'], seed=100 + rank, spread=1.0)
