@@ -906,7 +906,7 @@ struct Dissector {
         // the multilevel bisection is the expensive candidate: it pays when the level set was a poor separator, which
         // shows as a large reduction by the thinning + refinement (jagged level sets of unstructured meshes); the level
         // sets of regular grids come out of the refinement unchanged
-        const bool jagged = 10 * sep.size() < 9 * raw;
+        const bool jagged = 10 * sep.size() < 8 * raw && nodes.size() >= 600;    // small parts: their separators carry no weight
         if ((nd_mode & 2) && (jagged || nd_mode == 2 || nd_mode == 7)) {
             std::vector<int> l2, r2, s2;
             multilevel_sides(nodes, id, l2, r2, s2);
