@@ -122,7 +122,7 @@ def test_dissection_beats_natural_and_bfs_orderings_on_an_unstructured_mesh(monk
     rcm = exact_fill(S, sp.csgraph.reverse_cuthill_mckee(sp.csr_matrix(S), symmetric_mode=True))
     ref = mmd_fill(S)
     assert st['nnz_nd'] < 0.35 * min(natural, rcm)
-    assert st['nnz_nd'] <= 1.5 * ref             # breadth-first leaves (wide supernodes for the device kernels)
+    assert st['nnz_nd'] <= 1.6 * ref             # breadth-first leaves (wide supernodes for the device kernels), multilevel on parts >= 600
     monkeypatch.setenv('MI355KKT_ND_LEAF_AMD', '1')
     perm, st2 = ordering(S, 1)
     assert st2['nnz_nd'] <= 1.1 * ref            # constrained-minimum-degree leaves: the fill of a minimum-degree ordering
