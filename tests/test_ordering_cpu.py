@@ -124,8 +124,9 @@ def test_dissection_beats_natural_and_bfs_orderings_on_an_unstructured_mesh(monk
     assert st['nnz_nd'] < 0.35 * min(natural, rcm)
     assert st['nnz_nd'] <= 1.6 * ref             # breadth-first leaves (wide supernodes for the device kernels), multilevel on parts >= 600
     monkeypatch.setenv('MI355KKT_ND_LEAF_AMD', '1')
+    monkeypatch.setenv('MI355KKT_ND_MODE', '7')  # multilevel separators for every part
     perm, st2 = ordering(S, 1)
-    assert st2['nnz_nd'] <= 1.1 * ref            # constrained-minimum-degree leaves: the fill of a minimum-degree ordering
+    assert st2['nnz_nd'] <= 1.1 * ref            # + constrained-minimum-degree leaves: the fill of a minimum-degree ordering
     assert st2['nnz_nd'] == exact_fill(S, perm)
     monkeypatch.setenv('MI355KKT_ND_MODE', '1')  # level-set separators only: visibly worse on a mesh
     _, st3 = ordering(S, 1)
