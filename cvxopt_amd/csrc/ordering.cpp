@@ -138,8 +138,8 @@ void postorder(const std::vector<int>& parent, const std::vector<int64_t>& cc, s
     std::vector<int> head(n, -1), next(n, -1), roots;
     std::vector<int> idx(n);
     std::iota(idx.begin(), idx.end(), 0);
-    // insert in increasing (cc, index) order at the front => lists end up in decreasing order; we then visit the list
-    // from its head, which would put the largest FIRST; so insert in decreasing order instead
+    // children are pushed at the front of their parent's list in decreasing count order, so every list runs from the
+    // smallest to the largest count and is visited in that order
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cc[a] > cc[b]; });
     for (int v : idx) {
         if (parent[v] < 0) { roots.push_back(v); continue; }
