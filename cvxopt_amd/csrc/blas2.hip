@@ -4,6 +4,8 @@
 //   trsm_lower      x := L^-1 x / L^-T x   misc.py:1529 / :1555 blas.trsv  (and :1470 blas.trsm for Asct)
 // G is never rescaled in memory: Gs = diag(w) G is applied on the fly, so the 1 GB G block is read
 // exactly once per product and no Gs copy is written.
+#include <cstdlib>
+
 #include "kkt_common.h"
 
 namespace mi355kkt {
@@ -406,9 +408,14 @@ __device__ __forceinline__ void publish_flag(u32* flag, u32 epoch) {
     __hip_atomic_store(flag, epoch, RLX_AGENT);
 }
 
-template <bool TRANS>
+// GRAN (round 2): the solved block travels as 256 data-tagged 8-byte granules {epoch, 32-bit half of a double}, each
+// written by ONE relaxed agent-scope (write-through) store and polled with relaxed agent-scope loads by the thread that
+// needs it (guide G16 form R2: the data is the flag) -- no release fence, no acquire fence, no second trip for the payload:
+// a hop costs ~1 us instead of ~4 (flag + two fences + the x reload).  gran[block][256], zeroed once; epochs never repeat.
+typedef unsigned long long u64;
+template <bool TRANS, bool GRAN>
 __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __restrict__ L, int64_t ldl, int n,
-                                                              double* x, u32* flags, u32 epoch, int* err) {
+                                                              double* x, u32* flags, u32 epoch, int* err, u64* gran) {
     // 256 threads: two per row (forward) / column (backward) of the block row; each holds one 64-wide half of the strip
     // of every off-diagonal block in registers BEFORE waiting for that block's x, so that nothing but 64 FMAs, one
     // partial-sum exchange and the diagonal solve sits between "x_j published" and "x_k published".
@@ -468,13 +475,29 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
             for (int c = 0; c < 64; ++c) l0[c] = (mine && ch + c < jb) ? L[idx + (int64_t)(j0 + ch + c) * ldl] : 0.0;   // mirrored L'
 
         }
-        if (tid == 0) ok = wait_flag(flags + j, epoch, err) ? 1 : 0;
-        __syncthreads();
-        if (!ok) return;                                // timeout: give up (err is set)
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __syncthreads();
-        if (tid < TB) xs[tid] = (tid < jb) ? x[j0 + tid] : 0.0;
-        __syncthreads();
+        if (GRAN) {
+            const u64* g = gran + (int64_t)j * 256 + tid;
+            u64 v = 0;
+            bool got = false;
+            for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+                v = __hip_atomic_load(g, RLX_AGENT);
+                if ((u32)(v >> 32) == epoch) { got = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            reinterpret_cast<u32*>(xs)[tid] = (u32)v;          // little endian: granule 2i / 2i+1 = low / high word of x_i
+            if (__syncthreads_or(got ? 0 : 1)) {
+                if (tid == 0) atomicExch(err, 1);
+                return;                                     // timeout: give up (err is set)
+            }
+        } else {
+            if (tid == 0) ok = wait_flag(flags + j, epoch, err) ? 1 : 0;
+            __syncthreads();
+            if (!ok) return;                                // timeout: give up (err is set)
+            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            if (tid < TB) xs[tid] = (tid < jb) ? x[j0 + tid] : 0.0;
+            __syncthreads();
+        }
 #pragma unroll
         for (int c = 0; c < 64; ++c) acc = fma(-l0[c], xs[ch + c], acc);
         __syncthreads();                               // xs is reused by the next step
@@ -529,18 +552,34 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
         }
     }
     if (mine && half == 0) x[idx] = acc;
+    if (GRAN) {
+        if (half == 0) {          // rows beyond nb publish zeros (consumers mask them anyway): every granule gets its tag
+            const double v = mine ? acc : 0.0;
+            u64* g = gran + (int64_t)k * 256 + 2 * r;
+            const u64 tag = (u64)epoch << 32;
+            __hip_atomic_store(g, tag | (u32)__double2loint(v), RLX_AGENT);
+            __hip_atomic_store(g + 1, tag | (u32)__double2hiint(v), RLX_AGENT);
+        }
+        return;
+    }
     __syncthreads();
     if (tid == 0) publish_flag(flags + k, epoch);
 }
 
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
-                           unsigned int epoch, int* err, hipStream_t st) {
+                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran) {
     const int nblk = (n + TB - 1) / TB;
     if (nblk <= 0) return 0;
-    if (trans)
-        hipLaunchKernelGGL(trsv_persistent_kernel<true>, dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err);
+    static const bool use_flags = getenv("MI355KKT_TRSV") && !strcmp(getenv("MI355KKT_TRSV"), "flag");
+    if (gran && !use_flags) {
+        if (trans)
+            hipLaunchKernelGGL((trsv_persistent_kernel<true, true>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err, gran);
+        else
+            hipLaunchKernelGGL((trsv_persistent_kernel<false, true>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err, gran);
+    } else if (trans)
+        hipLaunchKernelGGL((trsv_persistent_kernel<true, false>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err, gran);
     else
-        hipLaunchKernelGGL(trsv_persistent_kernel<false>, dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err);
+        hipLaunchKernelGGL((trsv_persistent_kernel<false, false>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err, gran);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

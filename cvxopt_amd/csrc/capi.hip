@@ -249,6 +249,7 @@ struct mi355kkt_solver {
     double* dWst = nullptr;    // staging for host-side W (di | v | beta)
     // persistent triangular solves: hand-off flags (one word per 128-block), launch epoch, timeout word
     unsigned int* dflags = nullptr;
+    unsigned long long* dgran = nullptr;   // data-tagged granules of the solved blocks (256 per 128-block)
     unsigned int epoch = 0;
     int* derr = nullptr;
     int* herr = nullptr;   // pinned
@@ -396,6 +397,8 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
         const size_t nfl = N / 128 + 2;
         if (hipMalloc(&h->dflags, sizeof(unsigned int) * nfl) != hipSuccess) return fail(MI355KKT_ENOMEM);
         if (hipMemset(h->dflags, 0, sizeof(unsigned int) * nfl) != hipSuccess) return fail(MI355KKT_EHIP);
+        if (hipMalloc(&h->dgran, sizeof(unsigned long long) * nfl * 256) != hipSuccess) return fail(MI355KKT_ENOMEM);
+        if (hipMemset(h->dgran, 0, sizeof(unsigned long long) * nfl * 256) != hipSuccess) return fail(MI355KKT_EHIP);
         if (hipMalloc(&h->derr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
         if (hipMemset(h->derr, 0, sizeof(int)) != hipSuccess) return fail(MI355KKT_EHIP);
         if (hipHostMalloc(&h->herr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
@@ -439,6 +442,7 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     if (h->dIpmWork) (void)hipFree(h->dIpmWork);
     if (h->dSpWork) (void)hipFree(h->dSpWork);
     if (h->dflags) (void)hipFree(h->dflags);
+    if (h->dgran) (void)hipFree(h->dgran);
     if (h->derr) (void)hipFree(h->derr);
     if (h->herr) (void)hipHostFree(h->herr);
     for (double* b : bufs)
@@ -803,7 +807,7 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     // triangular solves with L: one persistent launch each when every 128-block can own a resident workgroup
     const bool persistent = (n + 127) / 128 <= h->num_cus && !getenv("MI355KKT_NO_PERSISTENT_TRSV");
     auto tri_solve = [&](int trans) -> int {
-        if (persistent) return launch_trsv_persistent(h->dS, n, n, dx, trans, h->dflags, ++h->epoch, h->derr, st);
+        if (persistent) return launch_trsv_persistent(h->dS, n, n, dx, trans, h->dflags, ++h->epoch, h->derr, st, h->dgran);
         return launch_trsm_lower(h->dS, n, n, dx, n, 1, trans, st);
     };
     if (int e = tri_solve(0)) return e;                                             // :1529

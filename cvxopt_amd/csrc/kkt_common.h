@@ -114,8 +114,9 @@ size_t gemv_work_doubles(int m, int n);
 // copies the strictly lower triangle, transposed, into the strictly upper triangle (needed by the transposed persistent solve)
 int launch_mirror_lower(double* A, int64_t lda, int n, hipStream_t st);
 // trans != 0 solves L' x = b and REQUIRES the mirrored upper triangle (launch_mirror_lower after the factorisation)
+// gran != nullptr: data-tagged granule hand-off (256 u64 per 128-block, zeroed once) instead of flag + fences
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
-                           unsigned int epoch, int* err, hipStream_t st);
+                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran = nullptr);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);

@@ -235,6 +235,252 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// potf2_la_kernel: the same diagonal-block factorisation restructured around its dependency chain (round 2).
+// 512 threads.  Wave 0 is the *panel wave*: it holds the current 16-column micro panel of ALL remaining rows in
+// registers (lane l <-> rows jb + l and jb + 64 + l), so the factorisation of the 16x16 diagonal block and the
+// triangular solve of every row below it are ONE instruction stream - the multipliers of column j are broadcast
+// with v_readlane once and applied to both row sets, no LDS round trip and no barrier inside the 16 columns.
+// 1/sqrt(pivot) comes from v_rsq_f64 + one third-order (Halley) step: 4 dependent FP64 operations instead of 11.
+// Waves 1..7 apply the rank-16 updates on the matrix cores one step behind (look-ahead): while the panel wave
+// works on micro panel jb they finish the update of micro panel jb - 16 on the columns right of jb + 16; only the
+// tiles of column block jb + 16 (<= 7, one per wave) sit between two panel phases.  The panel wave writes finished
+// columns straight to global memory; the 16x16 inverses for trsm_panel_kernel are formed at the end, one wave per
+// block (column-oriented forward substitution with LDS broadcasts).
+// ---------------------------------------------------------------------------------------------------
+constexpr int P2T = 512;
+
+// rank-16 update of one 16x16 tile (ct, rt >= ct) of the LDS-resident block with micro panel jb
+__device__ __forceinline__ void potf2_tile_update(double* __restrict__ As, int jb, int ct, int rt, int lane) {
+    const int li = lane & 15, lq = lane >> 4;
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = As[(ct * 16 + lq + 4 * r) * PLD + rt * 16 + li];
+    double av[4], bv[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        av[s4] = -As[(jb + 4 * s4 + lq) * PLD + ct * 16 + li];
+        bv[s4] = As[(jb + 4 * s4 + lq) * PLD + rt * 16 + li];
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = MFMA_F64(av[s4], bv[s4], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) As[(ct * 16 + lq + 4 * r) * PLD + rt * 16 + li] = acc[r];
+}
+
+// 16 columns of the panel wave: a[c] / b[c] = rows (jb + lane) / (jb + 64 + lane), column jb + c.
+// Returns 0 or the 1-based index of the first non-positive pivot.  dinv16[j] (LDS) = 1 / L[jb+j][jb+j].
+// 1/sqrt(p) for a normal p > 0: v_rsq_f64 (~23 good bits) + one third-order step -> ~1 ulp, 4 dependent operations
+__device__ __forceinline__ double rsqrt_halley(double p) {
+    const double y0 = __builtin_amdgcn_rsq(p);
+    const double t = p * y0;
+    const double e = fma(-t, y0, 1.0);                         // 1 - p y0^2
+    const double q = fma(0.375, e, 0.5);
+    const double w = y0 * e;
+    return fma(w, q, y0);                                      // y0 (1 + e/2 + 3 e^2 / 8)
+}
+
+// The scalar recurrence of the pivots runs ahead of the vector updates: with x = A[j+1][j], y = A[j+1][j+1] (both final
+// before column j is scaled) the next pivot is y - (x inv_j)^2 -- bit-identical to what the vector update of lane j+1
+// produces (fma(-t, t, y) with t = x inv_j) -- so the chain per column is  mul, fma, rsq, 4 Halley operations,
+// all on wave-uniform values, and the readlane broadcasts + FMAs of the column update fill its latency.
+// A non-positive pivot is recorded (first one wins) and the arithmetic simply continues (NaN/Inf stay in this block,
+// the caller discards it).
+template <bool TWO>
+__device__ __forceinline__ int potf2_panel16(double (&a)[16], double (&b)[16], double* __restrict__ dinv16,
+                                              double* __restrict__ dummy, int lane) {
+    double* __restrict__ dst = (lane == 0) ? dinv16 : dummy + lane;
+    const double p0 = readlane_d(a[0], 0);
+    int badv = (p0 > 0.0) ? 0 : 1;
+    double inv = rsqrt_halley(p0);
+#define P2_SB __builtin_amdgcn_sched_barrier(0)
+#define P2_UPD(c_)                                                         \
+    if ((c_) < 16) {                                                       \
+        const double s_ = readlane_d(la, (c_) < 16 ? (c_) : 15);           \
+        a[(c_) & 15] = fma(-la, s_, a[(c_) & 15]);                         \
+        if (TWO) b[(c_) & 15] = fma(-lb, s_, b[(c_) & 15]);                \
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        // one operation of the scalar chain, then one column update, pinned in that order: the in-order issue then
+        // hides every link of the chain under the broadcasts + FMAs of an update
+        double x = 0.0, y = 1.0;
+        if (j < 15) {
+            x = readlane_d(a[j], j + 1);
+            y = readlane_d(a[j + 1], j + 1);
+        }
+        dst[j] = inv;                                          // lane 0 -> dinv16[j]; the other lanes hit a dummy area (no branch)
+        const double la = a[j] * inv;
+        a[j] = la;
+        double lb = 0.0;
+        if (TWO) {
+            lb = b[j] * inv;
+            b[j] = lb;
+        }
+        const double t = x * inv;
+        P2_SB;
+        P2_UPD(j + 1)
+        const double pn = fma(-t, t, y);
+        P2_SB;
+        P2_UPD(j + 2)
+        const double y0 = __builtin_amdgcn_rsq(pn);
+        badv = (j < 15 && !(pn > 0.0) && badv == 0) ? j + 2 : badv;
+        P2_SB;
+        P2_UPD(j + 3)
+        const double tt = pn * y0;
+        P2_SB;
+        P2_UPD(j + 4)
+        const double e = fma(-tt, y0, 1.0);                    // 1 - p y0^2
+        P2_SB;
+        P2_UPD(j + 5)
+        const double q = fma(0.375, e, 0.5);
+        const double w = y0 * e;
+        P2_SB;
+        P2_UPD(j + 6)
+        const double invn = fma(w, q, y0);                     // y0 (1 + e/2 + 3 e^2 / 8)
+        P2_SB;
+#pragma unroll
+        for (int c = j + 7; c < 16; ++c) { P2_UPD(c) }
+        inv = invn;
+        // pin the finished column here: otherwise LLVM sinks the whole second row set into the (conditional) stores of the
+        // caller and keeps all 120 broadcast values alive in spilled SGPRs
+        asm volatile("" : "+v"(a[j]));
+        if (TWO) asm volatile("" : "+v"(b[j]));
+        P2_SB;
+    }
+#undef P2_UPD
+#undef P2_SB
+    return __builtin_amdgcn_readfirstlane(badv);
+}
+
+__global__ __launch_bounds__(P2T) void potf2_la_kernel(double* __restrict__ A, int64_t lda, int nb, int col0,
+                                                       int* __restrict__ info, double* __restrict__ linv_out,
+                                                       int64_t bstride, const VbDesc* __restrict__ vb) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (vb) {                                    // variable batched fronts: col0 carries the panel offset k0
+        const VbDesc dd = vb[blockIdx.z];
+        const int k0 = col0;
+        if (k0 >= dd.w) return;
+        nb = min(NB, dd.w - k0);
+        lda = dd.h;
+        A += dd.off + k0 + (int64_t)k0 * lda;
+        col0 = dd.col0 + k0;
+    } else {
+        A += (int64_t)blockIdx.z * bstride;
+    }
+    info += blockIdx.z;
+    if (linv_out) linv_out += (int64_t)blockIdx.z * 2048;
+    double* As = smem;                           // NB x PLD, column-major
+    double* dinv = smem + NB * PLD;              // 128 reciprocal pivots
+    double* dummy = dinv + NB;                   // 80 doubles: sink of the non-leader lanes' reciprocal-pivot stores
+    int* flag = reinterpret_cast<int*>(dummy + 80);
+    if (*info != 0) return;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    int lane = tid & 63;
+    const int nt = (nb + 15) >> 4;
+    if (tid == 0) *flag = 0;
+    double a[16], b[16];
+    if (wave == 0) {                             // micro panel 0 straight from global memory into the panel wave
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            a[c] = (lane < nb && c < nb) ? A[lane + (int64_t)c * lda] : 0.0;
+            b[c] = (lane + 64 < nb && c < nb) ? A[lane + 64 + (int64_t)c * lda] : 0.0;
+        }
+    } else {                                     // columns 16.. -> LDS (tiles on or below the diagonal), 32 elements per thread
+        const int tt = tid - 64;
+        double v[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int e = tt + (P2T - 64) * i;
+            const int r = e & (NB - 1), c = 16 + (e >> 7);
+            v[i] = (r < nb && c < nb && r >= (c & ~15)) ? A[r + (int64_t)c * lda] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int e = tt + (P2T - 64) * i;
+            const int r = e & (NB - 1), c = 16 + (e >> 7);
+            As[c * PLD + r] = v[i];
+        }
+    }
+    for (int jb = 0; jb < nb; jb += 16) {
+        const int pw = min(16, nb - jb);
+        asm volatile("" : "+v"(lane));           // opaque per iteration: the per-lane predicates below stay out of (spilled) SGPRs
+        if (wave == 0) {
+            if (jb > 0) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    a[c] = As[(jb + c) * PLD + min(jb + lane, NB - 1)];
+                    b[c] = As[(jb + c) * PLD + min(jb + 64 + lane, NB - 1)];
+                }
+            }
+            if (pw < 16 && lane < 16) {          // ragged last block: rows >= pw of the diagonal block act as identity rows
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] = (lane < pw) ? ((c < pw) ? a[c] : 0.0) : ((c == lane) ? 1.0 : 0.0);
+            }
+            const bool two = nb - jb > 64;       // wave-uniform
+            const int bad = two ? potf2_panel16<true>(a, b, dinv + jb, dummy, lane) : potf2_panel16<false>(a, b, dinv + jb, dummy, lane);
+            if (bad) {
+                if (lane == 0) *flag = jb + bad;
+            } else {
+                const int r1 = jb + lane, r2 = jb + 64 + lane;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    if (r1 < NB) As[(jb + c) * PLD + r1] = a[c];
+                    if (two && r2 < NB) As[(jb + c) * PLD + r2] = b[c];
+                }
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {   // finished columns -> global memory (lower triangle only)
+                    if (c < pw) {
+                        if (r1 < nb && lane >= c) A[r1 + (int64_t)(jb + c) * lda] = a[c];
+                        if (two && r2 < nb) A[r2 + (int64_t)(jb + c) * lda] = b[c];
+                    }
+                }
+            }
+        } else if (jb >= 16) {                   // look-ahead: the rest of the previous micro panel's update
+            const int pjb = jb - 16, t1 = pjb / 16 + 2;          // column blocks t1 .. nt-1
+            const int ntr = nt - t1;
+            const int ntiles = ntr > 0 ? ntr * (ntr + 1) / 2 : 0;
+            for (int t = wave - 1; t < ntiles; t += 7) {
+                int aa = 0, rem = t;
+                while (rem >= ntr - aa) {
+                    rem -= ntr - aa;
+                    ++aa;
+                }
+                potf2_tile_update(As, pjb, t1 + aa, t1 + aa + rem, lane);
+            }
+        }
+        __syncthreads();                         // micro panel jb is in LDS; update jb-16 is complete
+        if (*flag) break;
+        if (jb + 16 >= nb) break;
+        {   // column block jb/16 + 1 (the next micro panel): one tile per wave
+            const int t0 = jb / 16 + 1;
+            if (t0 + wave < nt) potf2_tile_update(As, jb, t0, t0 + wave, lane);
+        }
+        __syncthreads();
+    }
+    if (*flag) {
+        if (tid == 0) *info = col0 + *flag;
+        return;
+    }
+    // inverses of the 16x16 diagonal blocks (trsm_panel_kernel): wave w <-> block w, lane j <-> column j of inv(L_d)
+    if (linv_out && wave < nt) {
+        const int jb = wave * 16, pw = min(16, nb - jb);
+        const int j = lane & 15;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double s = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; ++k) s = fma(-As[(jb + k) * PLD + jb + i], x[k], s);
+            x[i] = s * dinv[jb + i];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) linv_out[wave * 256 + j * 16 + i] = (i < pw && j < pw && i >= j) ? x[i] : 0.0;
+        }
+    }
+}
+
 // X L' = B for the rows below a full 128x128 diagonal block, entirely on the matrix cores.
 // One wave owns a strip of 16 rows; tiles are kept transposed (MFMA row index = column of X, MFMA
 // column index = row of the strip), so that a solved tile's D registers are *directly* the B operand
@@ -317,6 +563,28 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restric
     }
 }
 
+// One diagonal-block factorisation launch (nz blocks along blockIdx.z).  MI355KKT_POTF2=old selects the round-1 kernel.
+static int launch_potf2(double* A, int64_t lda, int nb, int col0, int* info, double* linv, int64_t bstride,
+                        const VbDesc* vb, int nz, hipStream_t st) {
+    static const bool use_old = getenv("MI355KKT_POTF2") && !strcmp(getenv("MI355KKT_POTF2"), "old");
+    static bool attr_set = false;
+    constexpr size_t lds_old = sizeof(double) * (NB * PLD + 256 + 16) + 16;
+    constexpr size_t lds_la = sizeof(double) * (NB * PLD + NB + 80) + 16;
+    if (!attr_set) {
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_la_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_la));
+        attr_set = true;
+    }
+    if (use_old)
+        hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, nz), dim3(256), lds_old, st, A, lda, nb, col0, info, linv, bstride, vb);
+    else
+        hipLaunchKernelGGL(potf2_la_kernel, dim3(1, 1, nz), dim3(P2T), lds_la, st, A, lda, nb, col0, info, linv, bstride, vb);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int potrf_work_init_batched(PotrfWork& w, int nbatch) {
     KKT_HIP_CHECK(hipMalloc(&w.d_info, sizeof(int) * nbatch));
     KKT_HIP_CHECK(hipMalloc(&w.d_dinv, sizeof(double) * 8 * 256 * nbatch));   // inverses of the 16x16 diagonal blocks
@@ -350,21 +618,12 @@ void potrf_work_free(PotrfWork& w) {
 }
 
 int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st) {
-    static bool attr_set = false;
-    constexpr size_t lds = sizeof(double) * (NB * PLD + 256 + 16) + 16;
-    if (!attr_set) {
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     KKT_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int) * nbatch, st));
     // Outer panels of 256 columns = two 128-column sub-panels; the trailing matrix is touched once per
     // outer panel with a rank-256 update (halves the C read-modify-write traffic of a rank-128 scheme).
     auto panel = [&](int k0, int nb) -> int {   // factor diagonal block at k0 and solve the rows below it
         double* Akk = A + k0 + (int64_t)k0 * lda;
-        hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, nbatch), dim3(256), lds, st, Akk, lda, nb, k0, w.d_info, w.d_dinv,
-                           bstride, nullptr);
-        KKT_HIP_CHECK(hipGetLastError());
+        if (int e = launch_potf2(Akk, lda, nb, k0, w.d_info, w.d_dinv, bstride, nullptr, nbatch, st)) return e;
         const int m = n - k0 - nb;
         if (m > 0) {
             if (nb == NB)
@@ -401,8 +660,7 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
         if (int e = grow(w.ev_usr)) return e;
         if (int e = grow(w.ev_ir)) return e;
         auto potf2 = [&](int k0, int nb) {
-            hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), lds, st, A + k0 + (int64_t)k0 * lda, lda, nb, k0, w.d_info,
-                               w.d_dinv, (int64_t)0, nullptr);
+            (void)launch_potf2(A + k0 + (int64_t)k0 * lda, lda, nb, k0, w.d_info, w.d_dinv, (int64_t)0, nullptr, 1, st);
         };
         auto trsm = [&](int k0, int nb) {
             const int m = n - k0 - nb;
@@ -565,17 +823,10 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
 // Partial factorisation of a frontal matrix: eliminate the first `ncols` columns of the h x h matrix F (lower), leaving
 // the Schur complement in F[ncols:, ncols:].  Same kernels as launch_potrf; *w.d_info is NOT reset here.
 int launch_potrf_partial(double* F, int64_t ld, int h, int ncols, PotrfWork& w, hipStream_t st) {
-    static bool attr_set = false;
-    constexpr size_t lds = sizeof(double) * (NB * PLD + 256 + 16) + 16;
-    if (!attr_set) {
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     for (int k0 = 0; k0 < ncols; k0 += NB) {
         const int nb = (ncols - k0 < NB) ? (ncols - k0) : NB;
         double* Fkk = F + k0 + (int64_t)k0 * ld;
-        hipLaunchKernelGGL(potf2_kernel, dim3(1), dim3(256), lds, st, Fkk, ld, nb, k0, w.d_info, w.d_dinv, (int64_t)0, nullptr);
+        if (int e = launch_potf2(Fkk, ld, nb, k0, w.d_info, w.d_dinv, (int64_t)0, nullptr, 1, st)) return e;
         const int m = h - k0 - nb;
         if (m > 0) {
             if (nb == NB)
@@ -594,13 +845,9 @@ int launch_potrf_partial(double* F, int64_t ld, int h, int ncols, PotrfWork& w, 
 int launch_potrf_partial_vb(double* base, const VbDesc* d_desc, int nfronts, int maxh, int maxw, PotrfWork& w,
                             hipStream_t st) {
     if (nfronts <= 0) return 0;
-    constexpr size_t lds = sizeof(double) * (NB * PLD + 256 + 16) + 16;
-    KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     KKT_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int) * nfronts, st));
     for (int k0 = 0; k0 < maxw; k0 += NB) {
-        hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, nfronts), dim3(256), lds, st, base, (int64_t)0, 0, k0, w.d_info, w.d_dinv,
-                           (int64_t)0, d_desc);
+        if (int e = launch_potf2(base, (int64_t)0, 0, k0, w.d_info, w.d_dinv, (int64_t)0, d_desc, nfronts, st)) return e;
         const int mmax = maxh - k0 - 1;           // a front's panel may be as narrow as one column
         if (mmax > 0) {
             hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((mmax + TRSM_ROWS - 1) / TRSM_ROWS, 1, nfronts), dim3(256), 0, st,
