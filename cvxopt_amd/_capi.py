@@ -49,6 +49,7 @@ SIGNATURES = {
     "mi355kkt_set_G_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_A_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_H_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_set_H_dense_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_H_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_kktreg": (C.c_int, [C.c_void_p, C.c_double]),
     "mi355kkt_factor": (C.c_int, [C.c_void_p, C.POINTER(Scaling)]),
@@ -91,6 +92,8 @@ SIGNATURES = {
     "mi355kkt_debug_syrk_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p]),
     "mi355kkt_debug_ordering": (C.c_int, [C.c_int, c_i64_p, c_i64_p, C.c_int, c_int_p, c_double_p]),
     "mi355kkt_debug_potf2_skip": (C.c_int, [C.c_int]),
+    "mi355kkt_debug_potf2_ts": (C.c_int, [C.c_void_p]),
+    "mi355kkt_debug_tile_ts": (C.c_int, [C.c_void_p]),
     "mi355kkt_debug_syrk_skip": (C.c_int, [C.c_int]),
     "mi355kkt_op_mfma_f64_peak": (C.c_int, [C.c_int, c_float_p]),
     "mi355kkt_op_potrf": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_int_p, c_float_p]),

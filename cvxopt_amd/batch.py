@@ -89,23 +89,45 @@ class BatchKkt(object):
 
     def coneqp(self, q, h, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):
         """The whole interior-point loop on the device (`mi355kkt_batch_coneqp`): same result dict as
-        `coneqp_batch`; only the count of active problems crosses PCIe per iteration."""
-        q = np.ascontiguousarray(q, dtype=np.float64)
-        h = np.ascontiguousarray(h, dtype=np.float64)
+        `coneqp_batch`; only the count of active problems crosses PCIe per iteration.  q, h may be float64 CUDA tensors
+        (a sharded batch: they arrived over RCCL); the result arrays are then CUDA tensors too and nothing but the
+        per-iteration word touches the host."""
         B, n, m = self.B, self.n, self.m
-        assert q.shape == (B, n) and h.shape == (B, m)
-        x, s, z = np.zeros((B, n)), np.zeros((B, m)), np.zeros((B, m))
-        status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
-        pc, dc, gap = np.zeros(B), np.zeros(B), np.zeros(B)
-        nrun = C.c_int(0)
+        on_device = hasattr(q, "data_ptr")
         ip = _capi.c_int_p
-        rc = self.L.mi355kkt_batch_coneqp(self.h, q.ctypes.data, h.ctypes.data, int(maxiters), float(abstol),
-                                          float(reltol), float(feastol), x.ctypes.data, s.ctypes.data, z.ctypes.data,
-                                          status.ctypes.data_as(ip), iters.ctypes.data_as(ip), pc.ctypes.data,
-                                          dc.ctypes.data, gap.ctypes.data, C.byref(nrun))
+        nrun = C.c_int(0)
+        if on_device:
+            import torch
+            if not (q.is_cuda and h.is_cuda and q.dtype == torch.float64 and h.dtype == torch.float64):
+                raise TypeError("q, h must be float64 CUDA tensors")
+            q, h = q.contiguous(), h.contiguous()
+            assert tuple(q.shape) == (B, n) and tuple(h.shape) == (B, m)
+            dev = q.device
+            x, s, z = (torch.zeros((B, k), dtype=torch.float64, device=dev) for k in (n, m, m))
+            status, iters = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
+            pc, dc, gap = (torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(3))
+            torch.cuda.synchronize(dev)                           # the loop runs on the library's own stream
+            ptr = lambda t: C.c_void_p(t.data_ptr())
+            rc = self.L.mi355kkt_batch_coneqp(self.h, ptr(q), ptr(h), int(maxiters), float(abstol), float(reltol),
+                                              float(feastol), ptr(x), ptr(s), ptr(z), C.cast(ptr(status), ip),
+                                              C.cast(ptr(iters), ip), ptr(pc), ptr(dc), ptr(gap), C.byref(nrun))
+        else:
+            q = np.ascontiguousarray(q, dtype=np.float64)
+            h = np.ascontiguousarray(h, dtype=np.float64)
+            assert q.shape == (B, n) and h.shape == (B, m)
+            x, s, z = np.zeros((B, n)), np.zeros((B, m)), np.zeros((B, m))
+            status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+            pc, dc, gap = np.zeros(B), np.zeros(B), np.zeros(B)
+            rc = self.L.mi355kkt_batch_coneqp(self.h, q.ctypes.data, h.ctypes.data, int(maxiters), float(abstol),
+                                              float(reltol), float(feastol), x.ctypes.data, s.ctypes.data, z.ctypes.data,
+                                              status.ctypes.data_as(ip), iters.ctypes.data_as(ip), pc.ctypes.data,
+                                              dc.ctypes.data, gap.ctypes.data, C.byref(nrun))
         if rc == 1:
             raise ValueError("Rank([P; A; G]) < n (%s)" % _capi.last_error())
         _capi.check(rc, "batch_coneqp")
+        if on_device:        # status stays numeric on the device: 1 optimal, 2 / 3 unknown (see include/mi355kkt.h)
+            return {'x': x, 's': s, 'z': z, 'status_code': status, 'iterations': iters, 'primal objective': pc,
+                    'dual objective': dc, 'gap': gap, 'lockstep iterations': nrun.value}
         names = np.array(['unknown', 'optimal', 'unknown', 'unknown'], dtype=object)
         return {'x': x, 's': s, 'z': z, 'status': names[status], 'iterations': iters.astype(int),
                 'primal objective': pc, 'dual objective': dc, 'gap': gap, 'lockstep iterations': nrun.value}
@@ -301,9 +323,18 @@ def shard_bounds(B, world):
     return [(starts[r], starts[r + 1]) for r in range(world)]
 
 
+_STATUS_NAMES = np.array(['unknown', 'optimal', 'unknown', 'unknown'], dtype=object)
+
+
 def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, device_of_rank=None, **opts):
-    """P, q, Gt, h are only read on `root` (other ranks may pass None).  Every rank returns the FULL
-    gathered result dict on root and its local shard's dict elsewhere."""
+    """P, q, Gt, h are only read on `root` (other ranks may pass None): NumPy arrays, or -- with RCCL -- float64 CUDA
+    tensors already resident in the root's HBM (then the scatter sends views of them, nothing is staged or copied).
+    Root returns the FULL gathered result dict (NumPy), the other ranks their local shard's.
+
+    Data path: `dist.scatter` of contiguous shards (RCCL: grouped send/recv, one xGMI link per peer, concurrently) ->
+    local device-resident solve -> ONE packed float64 tensor per rank [x | s | z | pcost dcost gap status iters]
+    -> `dist.gather`.  No collective inside the interior-point loop; with RCCL nothing but the per-iteration "still active"
+    word of the local loop touches a host."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -311,62 +342,87 @@ def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, dev
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     meta = [None]
     if rank == root:
-        meta = [(q.shape[0], q.shape[1], h.shape[1], P is not None)]
+        meta = [(int(q.shape[0]), int(q.shape[1]), int(h.shape[1]), P is not None)]
     dist.broadcast_object_list(meta, src=root, group=group)
     B, n, m, hasP = meta[0]
     bounds = shard_bounds(B, world)
     lo, hi = bounds[rank]
+    mx = max(b - a for a, b in bounds)
+
+    def as_tensor(arr):
+        if hasattr(arr, "data_ptr"):
+            return arr if arr.device == dev else arr.to(dev)
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(dev)
 
     def scatter(arr, tail_shape):
-        recv = torch.empty((hi - lo,) + tail_shape, dtype=torch.float64, device=dev)
+        buf = torch.empty((mx,) + tail_shape, dtype=torch.float64, device=dev)
         if rank == root:
-            chunks = [torch.from_numpy(np.ascontiguousarray(arr[a:b])).to(dev) for a, b in bounds]
-            # dist.scatter needs equal sizes: pad to the largest shard
-            mx = max(b - a for a, b in bounds)
-            padded = []
-            for c in chunks:
-                if c.shape[0] < mx:
-                    c = torch.cat([c, torch.zeros((mx - c.shape[0],) + tail_shape, dtype=torch.float64, device=dev)])
-                padded.append(c.contiguous())
-            buf = torch.empty((mx,) + tail_shape, dtype=torch.float64, device=dev)
-            dist.scatter(buf, padded, src=root, group=group)
+            full = as_tensor(arr)
+            chunks = []
+            for a, b in bounds:
+                c = full[a:b]                     # a view: equal shards go out without a copy
+                if b - a < mx:                    # dist.scatter needs equal sizes: only the short shards are padded
+                    c = torch.cat([c, torch.zeros((mx - (b - a),) + tail_shape, dtype=torch.float64, device=dev)])
+                chunks.append(c.contiguous())
+            dist.scatter(buf, chunks, src=root, group=group)
         else:
-            mx = max(b - a for a, b in bounds)
-            buf = torch.empty((mx,) + tail_shape, dtype=torch.float64, device=dev)
             dist.scatter(buf, None, src=root, group=group)
-        recv.copy_(buf[:hi - lo])
-        return recv
+        return buf[:hi - lo]
 
-    # with RCCL the scattered shard of G and P lands in this rank's HBM over xGMI and STAYS there (BatchKkt takes the
-    # device pointers); only the small q, h go to the host, where the loop's inputs are staged
-    keep_on_device = (backend == "nccl" and local_solver is None and opts.get("resident", True))
-    q_l = scatter(q, (n,)).cpu().numpy()
-    h_l = scatter(h, (m,)).cpu().numpy()
+    q_l = scatter(q, (n,))
+    h_l = scatter(h, (m,))
     G_l = scatter(Gt, (n, m))
     P_l = scatter(P, (n, n)) if hasP else None
-    if not keep_on_device:
-        G_l = G_l.cpu().numpy()
-        P_l = P_l.cpu().numpy() if P_l is not None else None
+    # with RCCL the shard landed in this rank's HBM over xGMI and STAYS there (BatchKkt borrows the device pointers)
+    on_device = (backend == "nccl" and local_solver is None and opts.get("resident", True))
+    width = n + 2 * m + 5
+    pack = torch.zeros((mx, width), dtype=torch.float64, device=dev)
+    nloc = hi - lo
+    lockstep = 0
+    if nloc > 0:
+        if on_device:
+            kk = BatchKkt(G_l.contiguous(), P_l.contiguous() if P_l is not None else None, device=dev.index)
+            try:
+                res = kk.coneqp(q_l, h_l, **{k: v for k, v in opts.items() if k != "resident"})
+            finally:
+                kk.close()
+            pack[:nloc, :n] = res['x']
+            pack[:nloc, n:n + m] = res['s']
+            pack[:nloc, n + m:n + 2 * m] = res['z']
+            pack[:nloc, n + 2 * m] = res['primal objective']
+            pack[:nloc, n + 2 * m + 1] = res['dual objective']
+            pack[:nloc, n + 2 * m + 2] = res['gap']
+            pack[:nloc, n + 2 * m + 3] = res['status_code'].to(torch.float64)
+            pack[:nloc, n + 2 * m + 4] = res['iterations'].to(torch.float64)
+            lockstep = res['lockstep iterations']
+        else:
+            Pn = P_l.cpu().numpy() if P_l is not None else None
+            qn, Gn, hn = q_l.cpu().numpy(), G_l.cpu().numpy(), h_l.cpu().numpy()
+            if local_solver is None:
+                device = device_of_rank(rank) if device_of_rank else (torch.cuda.current_device() if backend == "nccl" else 0)
+                res = coneqp_batch(Pn, qn, Gn, hn, device=device, **opts)
+            else:
+                res = local_solver(Pn, qn, Gn, hn, **opts)
+            host = np.zeros((nloc, width))
+            host[:, :n], host[:, n:n + m], host[:, n + m:n + 2 * m] = res['x'], res['s'], res['z']
+            host[:, n + 2 * m], host[:, n + 2 * m + 1] = res['primal objective'], res['dual objective']
+            host[:, n + 2 * m + 2] = res['gap']
+            host[:, n + 2 * m + 3] = (np.asarray(res['status']) == 'optimal').astype(float) + 2.0 * (np.asarray(res['status']) != 'optimal')
+            host[:, n + 2 * m + 4] = res['iterations']
+            pack[:nloc] = torch.from_numpy(host).to(dev)
+            lockstep = int(res.get('lockstep iterations', 0))
+    gathered = [torch.empty_like(pack) for _ in range(world)] if rank == root else None
+    dist.gather(pack, gathered, dst=root, group=group)
 
-    if hi > lo:
-        if local_solver is None:
-            device = device_of_rank(rank) if device_of_rank else (torch.cuda.current_device() if backend == "nccl" else 0)
-            opts.setdefault("resident", True)          # whole loop on the rank's GPU; only results come back
-            res = coneqp_batch(P_l, q_l, G_l, h_l, device=device, **opts)
-        else:
-            res = local_solver(P_l, q_l, G_l, h_l, **opts)
-    else:
-        res = {'x': np.zeros((0, n)), 's': np.zeros((0, m)), 'z': np.zeros((0, m)), 'status': np.zeros(0, dtype=object),
-               'iterations': np.zeros(0, dtype=int), 'primal objective': np.zeros(0), 'dual objective': np.zeros(0),
-               'gap': np.zeros(0)}
-    gathered = [None] * world if rank == root else None
-    dist.gather_object(res, gathered, dst=root, group=group)
+    def unpack(t, cnt, ls):
+        a = t[:cnt].cpu().numpy()
+        return {'x': a[:, :n].copy(), 's': a[:, n:n + m].copy(), 'z': a[:, n + m:n + 2 * m].copy(),
+                'primal objective': a[:, n + 2 * m].copy(), 'dual objective': a[:, n + 2 * m + 1].copy(),
+                'gap': a[:, n + 2 * m + 2].copy(), 'status': _STATUS_NAMES[a[:, n + 2 * m + 3].astype(int)],
+                'iterations': a[:, n + 2 * m + 4].astype(int), 'lockstep iterations': ls}
     if rank != root:
-        return res
-    full = {}
-    for k in res:
-        if k == 'lockstep iterations':
-            full[k] = max(g.get(k, 0) for g in gathered)
-        else:
-            full[k] = np.concatenate([g[k] for g in gathered])
+        return unpack(pack, nloc, lockstep)
+    parts = [unpack(g, b - a, 0) for g, (a, b) in zip(gathered, bounds)]
+    full = {k: np.concatenate([pp[k] for pp in parts]) for k in parts[0] if k != 'lockstep iterations'}
+    full['lockstep iterations'] = lockstep          # the root's own count (shards stop independently)
     return full

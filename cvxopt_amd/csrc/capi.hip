@@ -236,6 +236,11 @@ struct mi355kkt_solver {
     const double* dG = nullptr;  int64_t ldG = 0;  double* G_owned = nullptr;
     const double* dA = nullptr;  int64_t ldA = 0;  double* A_owned = nullptr;
     const double* dH = nullptr;  int64_t ldH = 0;  double* H_owned = nullptr;
+    // asynchronous upload of a host H (mi355kkt_set_H_dense_async): own copy stream, the SYRK does not wait for it
+    hipStream_t cst = nullptr;
+    hipEvent_t ev_h = nullptr;
+    bool h_pending = false;
+    const void* reg_ptr = nullptr;  size_t reg_bytes = 0;    // host range currently pinned with hipHostRegister
     double kktreg = 0.0;
     // per-factor state
     double* dW = nullptr;      // effective diagonal scaling of the 'l' block (di, possibly / sqrt(1+reg))
@@ -427,6 +432,7 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     return 0;
 }
 
+static void h_unregister(mi355kkt_solver* h);
 void mi355kkt_destroy(mi355kkt_solver* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -441,6 +447,9 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     if (h->dHsym) (void)hipFree(h->dHsym);
     if (h->dIpmWork) (void)hipFree(h->dIpmWork);
     if (h->dSpWork) (void)hipFree(h->dSpWork);
+    h_unregister(h);
+    if (h->cst) (void)hipStreamDestroy(h->cst);
+    if (h->ev_h) (void)hipEventDestroy(h->ev_h);
     if (h->dflags) (void)hipFree(h->dflags);
     if (h->dgran) (void)hipFree(h->dgran);
     if (h->derr) (void)hipFree(h->derr);
@@ -568,6 +577,10 @@ int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) {
     if (!h) return MI355KKT_EINVAL;
     if (int e = bind(h)) return e;
     h->hsym_valid = false;
+    if (h->h_pending) {                                    // an asynchronous upload is still in flight: let it land first
+        KKT_HIP_CHECK(hipStreamSynchronize(h->cst));
+        h->h_pending = false;
+    }
     if (!H) {
         h->dH = nullptr;
         return 0;
@@ -581,8 +594,50 @@ int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) {
     h->ldH = h->n > 1 ? h->n : 1;
     return 0;
 }
+static void h_unregister(mi355kkt_solver* h) {
+    if (h->reg_ptr) {
+        if (h->cst) (void)hipStreamSynchronize(h->cst);
+        (void)hipHostUnregister(const_cast<void*>(h->reg_ptr));
+        h->reg_ptr = nullptr;
+        h->reg_bytes = 0;
+    }
+}
+/* Same as set_H_dense, but the copy is enqueued on the handle's copy stream from the caller's buffer pinned in place
+ * (hipHostRegister, cached while the same buffer is passed again) and the NEXT factor() only waits for it after the
+ * scaled SYRK: S = Gs'Gs runs while H crosses PCIe, then S += tril(H).  The caller keeps H alive and unmodified until
+ * that factor() returns, and alive until the next set_H_* call or destroy (the Python mirror holds a reference). */
+int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH) {
+    if (!h) return MI355KKT_EINVAL;
+    if (!H || h->n == 0) { h_unregister(h); h->h_pending = false; return mi355kkt_set_H_dense(h, H, ldH); }
+    if (int e = bind(h)) return e;
+    if (ldH < (h->n > 1 ? h->n : 1)) { set_last_error("set_H_dense_async: ldH too small"); return MI355KKT_EINVAL; }
+    const size_t bytes = sizeof(double) * ((size_t)ldH * (h->n - 1) + h->n);
+    if (h->reg_ptr != (const void*)H || h->reg_bytes != bytes) {
+        h_unregister(h);
+        if (hipHostRegister(const_cast<double*>(H), bytes, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();                       // not pinnable: plain synchronous upload
+            h->h_pending = false;
+            return mi355kkt_set_H_dense(h, H, ldH);
+        }
+        h->reg_ptr = H;
+        h->reg_bytes = bytes;
+    }
+    if (!h->cst) KKT_HIP_CHECK(hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking));
+    if (!h->ev_h) KKT_HIP_CHECK(hipEventCreateWithFlags(&h->ev_h, hipEventDisableTiming));
+    if (!h->H_owned) KKT_HIP_CHECK(hipMalloc(&h->H_owned, sizeof(double) * dmax((size_t)h->n * h->n, 1)));
+    KKT_HIP_CHECK(hipStreamSynchronize(h->st));            // nothing on the compute stream may still read the old H
+    KKT_HIP_CHECK(hipMemcpy2DAsync(h->H_owned, sizeof(double) * h->n, H, sizeof(double) * ldH, sizeof(double) * h->n, h->n,
+                                   hipMemcpyHostToDevice, h->cst));
+    KKT_HIP_CHECK(hipEventRecord(h->ev_h, h->cst));
+    h->dH = h->H_owned;
+    h->ldH = h->n > 1 ? h->n : 1;
+    h->hsym_valid = false;
+    h->h_pending = true;
+    return 0;
+}
 int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH) {
     if (!h) return MI355KKT_EINVAL;
+    h->h_pending = false;
     h->dH = dH;
     h->ldH = ldH;
     h->hsym_valid = false;
@@ -599,21 +654,46 @@ static int fetch_info(mi355kkt_solver* h, int* info) {
     KKT_HIP_CHECK(hipMemcpyAsync(h->pw.h_info, h->pw.d_info, sizeof(int), hipMemcpyDeviceToHost, h->st));
     KKT_HIP_CHECK(hipStreamSynchronize(h->st));
     *info = *h->pw.h_info;
+    if (*info < 0) {          // the persistent tile Cholesky gave up on a hand-off (a workgroup was starved for ~seconds)
+        set_last_error("potrf: tile hand-off timeout (info = %d)", *info);
+        return MI355KKT_EHIP;
+    }
     return 0;
 }
 
 // assemble S = H + [reg I] + Gs' Gs [+ A'A]
+__global__ void add_lower_kernel(double* __restrict__ S, int64_t lds, const double* __restrict__ H, int64_t ldh, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;      // column j, rows i >= j
+    if (i < n && i >= j) S[i + (int64_t)j * lds] += H[i + (int64_t)j * ldh];
+}
+
 static int assemble_S(mi355kkt_solver* h, bool add_AtA) {
+    // H still crossing PCIe on the copy stream (set_H_dense_async): S = Gs'Gs first, S += tril(H) once it has landed
+    const bool late_H = h->h_pending && h->dH != nullptr;
+    const double* Hnow = late_H ? nullptr : h->dH;
+    struct Late {
+        mi355kkt_solver* h; bool on;
+        int add() {
+            if (!on) return 0;
+            KKT_HIP_CHECK(hipStreamWaitEvent(h->st, h->ev_h, 0));
+            if (h->n > 0)
+                hipLaunchKernelGGL(add_lower_kernel, dim3((h->n + 255) / 256, h->n), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->dH,
+                                   h->ldH, h->n);
+            h->h_pending = false;
+            return 0;
+        }
+    } late{h, late_H};
     if (!h->q.empty() || !h->s.empty()) {
         // Gs = W^-T G once (HBM-bound; 's' rows land in packed storage), then the unscaled SYRK on Gs
         const double zs = 1.0 / std::sqrt(1.0 + h->kktreg);
         if (int e = launch_cone_scale(h->cl, h->dG, h->ldG, h->dGs, h->krows, h->n, h->dW, h->dV, h->dBeta, zs, h->st)) return e;
         if (int e = launch_sdp_scale_pack(h->cl, h->dG, h->ldG, h->dGs, h->krows, h->n, h->dRti, zs, h->st)) return e;
-        if (int e = launch_syrk_scaled(h->planS, h->dGs, h->krows, nullptr, h->dS, h->n, h->dH, h->ldH, h->st, &h->ev[6]))
+        if (int e = launch_syrk_scaled(h->planS, h->dGs, h->krows, nullptr, h->dS, h->n, Hnow, h->ldH, h->st, &h->ev[6]))
             return e;
-    } else if (int e = launch_syrk_scaled(h->planS, h->dG, h->ldG, h->ml > 0 ? h->dW : nullptr, h->dS, h->n, h->dH,
+    } else if (int e = launch_syrk_scaled(h->planS, h->dG, h->ldG, h->ml > 0 ? h->dW : nullptr, h->dS, h->n, Hnow,
                                           h->ldH, h->st, &h->ev[6]))
         return e;
+    if (int e = late.add()) return e;
     if (h->kktreg != 0.0 && h->n > 0) hipLaunchKernelGGL(diag_add_kernel, g1(h->n), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->n, h->kktreg);
     if (add_AtA && h->p > 0)
         if (int e = launch_syrk_scaled(h->planAtA, h->dA, h->ldA, nullptr, h->dS, h->n, h->dS, h->n, h->st)) return e;
@@ -1086,10 +1166,10 @@ static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, con
                    int maxiters, double abstol, double reltol, double feastol, const IpmHostOut& o) {
     const IpmState& S = w.S;
     const size_t B = w.B, N = S.n, M = S.m, Pq = S.p;
-    if (Pq > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bvec, sizeof(double) * B * Pq, hipMemcpyHostToDevice, st));
+    if (Pq > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bvec, sizeof(double) * B * Pq, hipMemcpyDefault, st));
     int* d_info = ipm_info_words(w);
-    KKT_HIP_CHECK(hipMemcpyAsync(S.q, q, sizeof(double) * B * N, hipMemcpyHostToDevice, st));
-    KKT_HIP_CHECK(hipMemcpyAsync(S.h, h, sizeof(double) * B * M, hipMemcpyHostToDevice, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.q, q, sizeof(double) * B * N, hipMemcpyDefault, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.h, h, sizeof(double) * B * M, hipMemcpyDefault, st));
     KKT_HIP_CHECK(hipMemsetAsync(w.i32, 0, sizeof(int) * (5 * B + 1), st));
     // ---- starting point: W = I  (coneprog.py:2055-2106)
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((B * M + 255) / 256)), dim3(256), 0, st, S.di, 1.0, (int64_t)(B * M));
@@ -1118,15 +1198,15 @@ static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, con
         }
         ipm_launch_update(S, (int)B, st);
     }
-    KKT_HIP_CHECK(hipMemcpyAsync(o.x, S.x_out, sizeof(double) * B * N, hipMemcpyDeviceToHost, st));
-    if (o.s) KKT_HIP_CHECK(hipMemcpyAsync(o.s, S.s_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
-    if (o.z) KKT_HIP_CHECK(hipMemcpyAsync(o.z, S.z_out, sizeof(double) * B * M, hipMemcpyDeviceToHost, st));
-    if (o.y && Pq > 0) KKT_HIP_CHECK(hipMemcpyAsync(o.y, S.y_out, sizeof(double) * B * Pq, hipMemcpyDeviceToHost, st));
-    KKT_HIP_CHECK(hipMemcpyAsync(o.status, S.status, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    KKT_HIP_CHECK(hipMemcpyAsync(o.iters, S.iters, sizeof(int) * B, hipMemcpyDeviceToHost, st));
-    if (o.pcost) KKT_HIP_CHECK(hipMemcpyAsync(o.pcost, S.pcost, sizeof(double) * B, hipMemcpyDeviceToHost, st));
-    if (o.dcost) KKT_HIP_CHECK(hipMemcpyAsync(o.dcost, S.dcost, sizeof(double) * B, hipMemcpyDeviceToHost, st));
-    if (o.gap) KKT_HIP_CHECK(hipMemcpyAsync(o.gap, S.gap_out, sizeof(double) * B, hipMemcpyDeviceToHost, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(o.x, S.x_out, sizeof(double) * B * N, hipMemcpyDefault, st));
+    if (o.s) KKT_HIP_CHECK(hipMemcpyAsync(o.s, S.s_out, sizeof(double) * B * M, hipMemcpyDefault, st));
+    if (o.z) KKT_HIP_CHECK(hipMemcpyAsync(o.z, S.z_out, sizeof(double) * B * M, hipMemcpyDefault, st));
+    if (o.y && Pq > 0) KKT_HIP_CHECK(hipMemcpyAsync(o.y, S.y_out, sizeof(double) * B * Pq, hipMemcpyDefault, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(o.status, S.status, sizeof(int) * B, hipMemcpyDefault, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(o.iters, S.iters, sizeof(int) * B, hipMemcpyDefault, st));
+    if (o.pcost) KKT_HIP_CHECK(hipMemcpyAsync(o.pcost, S.pcost, sizeof(double) * B, hipMemcpyDefault, st));
+    if (o.dcost) KKT_HIP_CHECK(hipMemcpyAsync(o.dcost, S.dcost, sizeof(double) * B, hipMemcpyDefault, st));
+    if (o.gap) KKT_HIP_CHECK(hipMemcpyAsync(o.gap, S.gap_out, sizeof(double) * B, hipMemcpyDefault, st));
     KKT_HIP_CHECK(hipStreamSynchronize(st));
     if (o.iterations_run) *o.iterations_run = it;
     return 0;
@@ -1169,6 +1249,7 @@ int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, i
 static int ensure_hsym(mi355kkt_solver* hs) {
     if (!hs->dH || hs->sparse || hs->hsym_valid) return 0;
     const int n = hs->n;
+    if (hs->h_pending) KKT_HIP_CHECK(hipStreamWaitEvent(hs->st, hs->ev_h, 0));   // asynchronous upload of H in flight
     if (!hs->dHsym) KKT_HIP_CHECK(hipMalloc(&hs->dHsym, sizeof(double) * dmax((size_t)n * n, 1)));
     if (n > 0) {
         KKT_HIP_CHECK(hipMemcpy2DAsync(hs->dHsym, sizeof(double) * n, hs->dH, sizeof(double) * hs->ldH, sizeof(double) * n, n,
@@ -1777,6 +1858,8 @@ int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind,
     return 0;
 }
 int mi355kkt_debug_potf2_skip(int mask) { return mi355kkt::set_potf2_skip(mask); }
+int mi355kkt_debug_tile_ts(void* dptr) { return mi355kkt::set_tile_ts((long long*)dptr); }
+int mi355kkt_debug_potf2_ts(void* dptr) { return mi355kkt::set_potf2_ts((long long*)dptr); }
 int mi355kkt_debug_syrk_skip(int mask) { return mi355kkt::set_syrk_skip(mask); }
 
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops) { return run_mfma_f64_peak(iters, cur_num_cus(), tflops); }
@@ -1784,6 +1867,7 @@ int mi355kkt_op_mfma_f64_peak(int iters, float* tflops) { return run_mfma_f64_pe
 int mi355kkt_op_potrf(double* dA, int64_t ldA, int n, int* info, float* ms) {
     PotrfWork w;
     if (int e = potrf_work_init(w)) return e;
+    if (int e = potrf_work_reserve(w, n)) { potrf_work_free(w); return e; }
     OpTimer t(ms);
     int rc = launch_potrf(dA, ldA, n, w, nullptr);
     if (!rc) rc = t.finish();

@@ -79,13 +79,20 @@ struct PotrfWork {
     int* d_info = nullptr;   // device int: 0 ok, >0 first failing pivot (1-based, LAPACK convention)
     int* h_info = nullptr;   // pinned host mirror
     double* d_dinv = nullptr; // inverses of the 16x16 diagonal blocks of the current panel (potf2 -> trsm)
+    // persistent tile kernel: ticket / abort / per-block-row progress words, inverses of every column's diagonal blocks
+    void* d_ctl = nullptr;
+    double* d_linv_all = nullptr;
+    int linv_tiles = 0;
     // look-ahead: the bulk of each trailing update runs on `side` while the next panel is factored on the main stream
     hipStream_t side = nullptr, aux = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_bulk, ev_t1, ev_usr, ev_ir;
 };
 int set_potf2_skip(int v);   // developer ablation switch
+int set_tile_ts(long long* dptr);    // developer aid: 8 int64 stamps per tile written by potrf_tiles_kernel (nullptr: off)
+int set_potf2_ts(long long* dptr);   // developer aid: device buffer of 48 timestamps written by potf2_la_kernel (nullptr: off)
 int set_syrk_skip(int v);    // developer ablation switch
 int potrf_work_init(PotrfWork& w);
+int potrf_work_reserve(PotrfWork& w, int n);   // state of the persistent tile kernel (allocated lazily otherwise)
 void potrf_work_free(PotrfWork& w);
 // In-place lower Cholesky of the n x n column-major matrix A (only tril referenced/overwritten).
 // Asynchronous on `st`; *w.d_info is updated on device.  Returns 0 or a negative error code.

@@ -15,6 +15,8 @@
 namespace mi355kkt {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2_ __attribute__((ext_vector_type(2)));
+struct __attribute__((aligned(8))) d2u_ { double x, y; };   // 8-byte aligned pair (one dwordx4 load)
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 __device__ int g_potf2_skip = 0;   // developer ablation switch (bit0 a, bit1 b, bit2 c, bit3 inverses); 0 in production
@@ -249,6 +251,8 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
 // block (column-oriented forward substitution with LDS broadcasts).
 // ---------------------------------------------------------------------------------------------------
 constexpr int P2T = 512;
+__device__ long long* g_potf2_ts = nullptr;   // developer aid: when set, wave 0 / lane 0 logs s_memtime at phase boundaries
+#define P2_TS(i_) do { if (ts && tid == 0) ts[(i_)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 // rank-16 update of one 16x16 tile (ct, rt >= ct) of the LDS-resident block with micro panel jb
 __device__ __forceinline__ void potf2_tile_update(double* __restrict__ As, int jb, int ct, int rt, int lane) {
@@ -283,27 +287,34 @@ __device__ __forceinline__ double rsqrt_halley(double p) {
 // The scalar recurrence of the pivots runs ahead of the vector updates: with x = A[j+1][j], y = A[j+1][j+1] (both final
 // before column j is scaled) the next pivot is y - (x inv_j)^2 -- bit-identical to what the vector update of lane j+1
 // produces (fma(-t, t, y) with t = x inv_j) -- so the chain per column is  mul, fma, rsq, 4 Halley operations,
-// all on wave-uniform values, and the readlane broadcasts + FMAs of the column update fill its latency.
+// all on wave-uniform values.  Column j is written to its final place in LDS as soon as it is scaled; the multipliers
+// L[jb+c][jb+j] of the columns c >= j+3 are then read back as LDS broadcasts (one ds_read per value, no SGPR hop), only
+// the two columns the scalar chain needs next (j+1, j+2) take the v_readlane path.  (Measured on gfx950: the all-readlane
+// version issues ~45 instructions per column = 277 clocks; this one ~27.)
 // A non-positive pivot is recorded (first one wins) and the arithmetic simply continues (NaN/Inf stay in this block,
-// the caller discards it).
+// the caller discards it).  col = LDS address of element (row jb, column jb); rowa / rowb = row offsets of the lane's
+// two rows relative to jb (rows past the block are redirected to the padding rows 128..143 of the column).
 template <bool TWO>
-__device__ __forceinline__ int potf2_panel16(double (&a)[16], double (&b)[16], double* __restrict__ dinv16,
-                                              double* __restrict__ dummy, int lane) {
+__device__ __forceinline__ int potf2_panel16(double (&a)[16], double (&b)[16], double* __restrict__ col, int rowa, int rowb,
+                                              double* __restrict__ dinv16, double* __restrict__ dummy, int lane) {
     double* __restrict__ dst = (lane == 0) ? dinv16 : dummy + lane;
     const double p0 = readlane_d(a[0], 0);
     int badv = (p0 > 0.0) ? 0 : 1;
     double inv = rsqrt_halley(p0);
 #define P2_SB __builtin_amdgcn_sched_barrier(0)
-#define P2_UPD(c_)                                                         \
+#define P2_UPD_RL(c_)                                                      \
     if ((c_) < 16) {                                                       \
         const double s_ = readlane_d(la, (c_) < 16 ? (c_) : 15);           \
         a[(c_) & 15] = fma(-la, s_, a[(c_) & 15]);                         \
         if (TWO) b[(c_) & 15] = fma(-lb, s_, b[(c_) & 15]);                \
     }
+#define P2_UPD_LDS(c_)                                                     \
+    if ((c_) < 16) {                                                       \
+        a[(c_) & 15] = fma(-la, sv[(c_) & 15], a[(c_) & 15]);              \
+        if (TWO) b[(c_) & 15] = fma(-lb, sv[(c_) & 15], b[(c_) & 15]);     \
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        // one operation of the scalar chain, then one column update, pinned in that order: the in-order issue then
-        // hides every link of the chain under the broadcasts + FMAs of an update
         double x = 0.0, y = 1.0;
         if (j < 15) {
             x = readlane_d(a[j], j + 1);
@@ -311,46 +322,177 @@ __device__ __forceinline__ int potf2_panel16(double (&a)[16], double (&b)[16], d
         }
         dst[j] = inv;                                          // lane 0 -> dinv16[j]; the other lanes hit a dummy area (no branch)
         const double la = a[j] * inv;
-        a[j] = la;
         double lb = 0.0;
+        col[j * PLD + rowa] = la;                              // column j is final: to its place in the LDS block
         if (TWO) {
             lb = b[j] * inv;
-            b[j] = lb;
+            col[j * PLD + rowb] = lb;
         }
+        double sv[16];
+#pragma unroll
+        for (int c = j + 3; c < 16; ++c) sv[c] = col[j * PLD + c];   // wave-uniform addresses: LDS broadcasts (in order behind the store)
+        // order pinned: the two readlane-path columns and the whole scalar chain first (they run while the LDS broadcasts
+        // are in flight), then the LDS-path columns
         const double t = x * inv;
         P2_SB;
-        P2_UPD(j + 1)
+        P2_UPD_RL(j + 1)
         const double pn = fma(-t, t, y);
         P2_SB;
-        P2_UPD(j + 2)
+        P2_UPD_RL(j + 2)
         const double y0 = __builtin_amdgcn_rsq(pn);
         badv = (j < 15 && !(pn > 0.0) && badv == 0) ? j + 2 : badv;
-        P2_SB;
-        P2_UPD(j + 3)
         const double tt = pn * y0;
-        P2_SB;
-        P2_UPD(j + 4)
         const double e = fma(-tt, y0, 1.0);                    // 1 - p y0^2
-        P2_SB;
-        P2_UPD(j + 5)
         const double q = fma(0.375, e, 0.5);
         const double w = y0 * e;
-        P2_SB;
-        P2_UPD(j + 6)
         const double invn = fma(w, q, y0);                     // y0 (1 + e/2 + 3 e^2 / 8)
         P2_SB;
 #pragma unroll
-        for (int c = j + 7; c < 16; ++c) { P2_UPD(c) }
+        for (int c = j + 3; c < 16; ++c) { P2_UPD_LDS(c) }
         inv = invn;
-        // pin the finished column here: otherwise LLVM sinks the whole second row set into the (conditional) stores of the
-        // caller and keeps all 120 broadcast values alive in spilled SGPRs
-        asm volatile("" : "+v"(a[j]));
-        if (TWO) asm volatile("" : "+v"(b[j]));
         P2_SB;
     }
-#undef P2_UPD
+#undef P2_UPD_RL
+#undef P2_UPD_LDS
 #undef P2_SB
     return __builtin_amdgcn_readfirstlane(badv);
+}
+
+// The diagonal-block factorisation proper.  FROM_LDS: the block (lower triangle, column-major, leading dimension PLD)
+// already sits at the start of `smem` (the persistent tile kernel dumps its accumulators there); otherwise it is read
+// from A.  L goes to A (lower triangle only), the inverses of the 16x16 diagonal blocks to linv_out (may be null).
+// Returns 0 or the 1-based column of the first non-positive pivot (uniform over the workgroup).  All P2T threads call it.
+template <bool FROM_LDS>
+__device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda, int nb, double* __restrict__ linv_out,
+                                             double* __restrict__ smem, long long* ts) {
+    double* As = smem;                           // NB x PLD, column-major
+    double* dinv = smem + NB * PLD;              // 128 reciprocal pivots
+    double* dummy = dinv + NB;                   // 80 doubles: sink of the non-leader lanes' reciprocal-pivot stores
+    int* flag = reinterpret_cast<int*>(dummy + 80);
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));                 // keeps this body's per-thread addresses out of the caller's loop preheader
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = tid & 63;
+    const int nt = (nb + 15) >> 4;
+    P2_TS(0);
+    if (tid == 0) *flag = 0;
+    double a[16], b[16];
+    if (!FROM_LDS) {
+        if (wave == 0) {                         // micro panel 0 straight from global memory into the panel wave
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                a[c] = (lane < nb && c < nb) ? A[lane + (int64_t)c * lda] : 0.0;
+                b[c] = (lane + 64 < nb && c < nb) ? A[lane + 64 + (int64_t)c * lda] : 0.0;
+            }
+        } else {                                 // columns 16.. -> LDS (tiles on or below the diagonal), 32 elements per thread
+            const int tt = tid - 64;
+            double v[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int e = tt + (P2T - 64) * i;
+                const int r = e & (NB - 1), c = 16 + (e >> 7);
+                v[i] = (r < nb && c < nb && r >= (c & ~15)) ? A[r + (int64_t)c * lda] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const int e = tt + (P2T - 64) * i;
+                const int r = e & (NB - 1), c = 16 + (e >> 7);
+                As[c * PLD + r] = v[i];
+            }
+        }
+    } else {
+        __syncthreads();                         // flag reset visible; the caller's block is complete in LDS
+    }
+    for (int jb = 0; jb < nb; jb += 16) {
+        const int pw = min(16, nb - jb);
+        asm volatile("" : "+v"(lane));           // opaque per iteration: the per-lane predicates below stay out of (spilled) SGPRs
+        P2_TS(1 + (jb >> 4) * 5);
+        if (wave == 0) {
+            if (FROM_LDS || jb > 0) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    a[c] = As[(jb + c) * PLD + min(jb + lane, NB - 1)];
+                    b[c] = As[(jb + c) * PLD + min(jb + 64 + lane, NB - 1)];
+                }
+            }
+            if (pw < 16 && lane < 16) {          // ragged last block: rows >= pw of the diagonal block act as identity rows
+#pragma unroll
+                for (int c = 0; c < 16; ++c) a[c] = (lane < pw) ? ((c < pw) ? a[c] : 0.0) : ((c == lane) ? 1.0 : 0.0);
+            }
+            const bool two = nb - jb > 64;       // wave-uniform
+            const int rowa = (jb + lane < NB) ? lane : NB - jb + (lane & 15);
+            const int rowb = (jb + 64 + lane < NB) ? 64 + lane : NB - jb + (lane & 15);
+            double* col = As + jb * PLD + jb;
+            P2_TS(2 + (jb >> 4) * 5);
+            const int bad = two ? potf2_panel16<true>(a, b, col, rowa, rowb, dinv + jb, dummy, lane)
+                                : potf2_panel16<false>(a, b, col, rowa, rowb, dinv + jb, dummy, lane);
+            P2_TS(3 + (jb >> 4) * 5);
+            if (bad && lane == 0) *flag = jb + bad;
+        } else if (jb >= 16) {                   // look-ahead: the rest of the previous micro panel's update
+            const int pjb = jb - 16, t1 = pjb / 16 + 2;          // column blocks t1 .. nt-1
+            {   // micro panel pjb is final: LDS -> global memory (lower triangle), off the panel wave's chain
+                const int tt = tid - 64;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int e = tt + (P2T - 64) * i;
+                    const int r = e & (NB - 1), c = pjb + (e >> 7);
+                    if (e < 16 * NB && r >= c && r < nb && c < nb) A[r + (int64_t)c * lda] = As[c * PLD + r];
+                }
+            }
+            const int ntr = nt - t1;
+            const int ntiles = ntr > 0 ? ntr * (ntr + 1) / 2 : 0;
+            for (int t = wave - 1; t < ntiles; t += 7) {
+                int aa = 0, rem = t;
+                while (rem >= ntr - aa) {
+                    rem -= ntr - aa;
+                    ++aa;
+                }
+                potf2_tile_update(As, pjb, t1 + aa, t1 + aa + rem, lane);
+            }
+        }
+        P2_TS(4 + (jb >> 4) * 5);
+        __syncthreads();                         // micro panel jb is in LDS; update jb-16 is complete
+        P2_TS(5 + (jb >> 4) * 5);
+        if (*flag) break;
+        if (jb + 16 >= nb) break;
+        {   // column block jb/16 + 1 (the next micro panel): one tile per wave
+            const int t0 = jb / 16 + 1;
+            if (t0 + wave < nt) potf2_tile_update(As, jb, t0, t0 + wave, lane);
+        }
+        __syncthreads();
+    }
+    P2_TS(41);
+    const int failed = *flag;
+    if (failed) return failed;
+    {   // the last micro panel -> global memory
+        const int ljb = (nt - 1) * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + P2T * i;
+            const int r = e & (NB - 1), c = ljb + (e >> 7);
+            if (r >= c && r < nb && c < nb) A[r + (int64_t)c * lda] = As[c * PLD + r];
+        }
+    }
+    // inverses of the 16x16 diagonal blocks (trsm_panel_kernel): wave w <-> block w, lane j <-> column j of inv(L_d)
+    if (linv_out && wave < nt) {
+        const int jb = wave * 16, pw = min(16, nb - jb);
+        const int j = lane & 15;
+        double x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {            // column-oriented substitution: 16-step chain, independent FMAs behind it
+            x[k] *= dinv[jb + k];
+#pragma unroll
+            for (int i = k + 1; i < 16; ++i) x[i] = fma(-As[(jb + k) * PLD + jb + i], x[k], x[i]);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) linv_out[wave * 256 + j * 16 + i] = (i < pw && j < pw && i >= j) ? x[i] : 0.0;
+        }
+    }
+    P2_TS(42);
+    return 0;
 }
 
 __global__ __launch_bounds__(P2T) void potf2_la_kernel(double* __restrict__ A, int64_t lda, int nb, int col0,
@@ -370,116 +512,12 @@ __global__ __launch_bounds__(P2T) void potf2_la_kernel(double* __restrict__ A, i
     }
     info += blockIdx.z;
     if (linv_out) linv_out += (int64_t)blockIdx.z * 2048;
-    double* As = smem;                           // NB x PLD, column-major
-    double* dinv = smem + NB * PLD;              // 128 reciprocal pivots
-    double* dummy = dinv + NB;                   // 80 doubles: sink of the non-leader lanes' reciprocal-pivot stores
-    int* flag = reinterpret_cast<int*>(dummy + 80);
     if (*info != 0) return;
-    const int tid = threadIdx.x, wave = tid >> 6;
-    int lane = tid & 63;
-    const int nt = (nb + 15) >> 4;
-    if (tid == 0) *flag = 0;
-    double a[16], b[16];
-    if (wave == 0) {                             // micro panel 0 straight from global memory into the panel wave
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            a[c] = (lane < nb && c < nb) ? A[lane + (int64_t)c * lda] : 0.0;
-            b[c] = (lane + 64 < nb && c < nb) ? A[lane + 64 + (int64_t)c * lda] : 0.0;
-        }
-    } else {                                     // columns 16.. -> LDS (tiles on or below the diagonal), 32 elements per thread
-        const int tt = tid - 64;
-        double v[32];
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int e = tt + (P2T - 64) * i;
-            const int r = e & (NB - 1), c = 16 + (e >> 7);
-            v[i] = (r < nb && c < nb && r >= (c & ~15)) ? A[r + (int64_t)c * lda] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            const int e = tt + (P2T - 64) * i;
-            const int r = e & (NB - 1), c = 16 + (e >> 7);
-            As[c * PLD + r] = v[i];
-        }
-    }
-    for (int jb = 0; jb < nb; jb += 16) {
-        const int pw = min(16, nb - jb);
-        asm volatile("" : "+v"(lane));           // opaque per iteration: the per-lane predicates below stay out of (spilled) SGPRs
-        if (wave == 0) {
-            if (jb > 0) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    a[c] = As[(jb + c) * PLD + min(jb + lane, NB - 1)];
-                    b[c] = As[(jb + c) * PLD + min(jb + 64 + lane, NB - 1)];
-                }
-            }
-            if (pw < 16 && lane < 16) {          // ragged last block: rows >= pw of the diagonal block act as identity rows
-#pragma unroll
-                for (int c = 0; c < 16; ++c) a[c] = (lane < pw) ? ((c < pw) ? a[c] : 0.0) : ((c == lane) ? 1.0 : 0.0);
-            }
-            const bool two = nb - jb > 64;       // wave-uniform
-            const int bad = two ? potf2_panel16<true>(a, b, dinv + jb, dummy, lane) : potf2_panel16<false>(a, b, dinv + jb, dummy, lane);
-            if (bad) {
-                if (lane == 0) *flag = jb + bad;
-            } else {
-                const int r1 = jb + lane, r2 = jb + 64 + lane;
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    if (r1 < NB) As[(jb + c) * PLD + r1] = a[c];
-                    if (two && r2 < NB) As[(jb + c) * PLD + r2] = b[c];
-                }
-#pragma unroll
-                for (int c = 0; c < 16; ++c) {   // finished columns -> global memory (lower triangle only)
-                    if (c < pw) {
-                        if (r1 < nb && lane >= c) A[r1 + (int64_t)(jb + c) * lda] = a[c];
-                        if (two && r2 < nb) A[r2 + (int64_t)(jb + c) * lda] = b[c];
-                    }
-                }
-            }
-        } else if (jb >= 16) {                   // look-ahead: the rest of the previous micro panel's update
-            const int pjb = jb - 16, t1 = pjb / 16 + 2;          // column blocks t1 .. nt-1
-            const int ntr = nt - t1;
-            const int ntiles = ntr > 0 ? ntr * (ntr + 1) / 2 : 0;
-            for (int t = wave - 1; t < ntiles; t += 7) {
-                int aa = 0, rem = t;
-                while (rem >= ntr - aa) {
-                    rem -= ntr - aa;
-                    ++aa;
-                }
-                potf2_tile_update(As, pjb, t1 + aa, t1 + aa + rem, lane);
-            }
-        }
-        __syncthreads();                         // micro panel jb is in LDS; update jb-16 is complete
-        if (*flag) break;
-        if (jb + 16 >= nb) break;
-        {   // column block jb/16 + 1 (the next micro panel): one tile per wave
-            const int t0 = jb / 16 + 1;
-            if (t0 + wave < nt) potf2_tile_update(As, jb, t0, t0 + wave, lane);
-        }
-        __syncthreads();
-    }
-    if (*flag) {
-        if (tid == 0) *info = col0 + *flag;
-        return;
-    }
-    // inverses of the 16x16 diagonal blocks (trsm_panel_kernel): wave w <-> block w, lane j <-> column j of inv(L_d)
-    if (linv_out && wave < nt) {
-        const int jb = wave * 16, pw = min(16, nb - jb);
-        const int j = lane & 15;
-        double x[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            double s = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < i; ++k) s = fma(-As[(jb + k) * PLD + jb + i], x[k], s);
-            x[i] = s * dinv[jb + i];
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) linv_out[wave * 256 + j * 16 + i] = (i < pw && j < pw && i >= j) ? x[i] : 0.0;
-        }
-    }
+    long long* ts = (blockIdx.z == 0) ? g_potf2_ts : nullptr;
+    const int failed = potf2_la_body<false>(A, lda, nb, linv_out, smem, ts);
+    if (failed && threadIdx.x == 0) *info = col0 + failed;
 }
+int set_potf2_ts(long long* dptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_potf2_ts), &dptr, sizeof(dptr)) == hipSuccess ? 0 : -2; }
 
 // X L' = B for the rows below a full 128x128 diagonal block, entirely on the matrix cores.
 // One wave owns a strip of 16 rows; tiles are kept transposed (MFMA row index = column of X, MFMA
@@ -563,6 +601,332 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restric
     }
 }
 
+// ===================================================================================================
+// potrf_tiles_kernel (round 2): the whole dense Cholesky as ONE persistent launch, left-looking by 128 x 128 tiles.
+//
+// Why: as a chain of ~330 launches (potf2 / trsm / skinny update per 128 columns, bulk updates on a side stream) the
+// factorisation is bound by the chain kernels, and every chain kernel that overlaps the bulk update runs 3-5 x slower
+// (profiles/r02_*: trsm 18 -> 88 us, update 33 -> 99 us) because it has to queue for compute units behind bulk
+// workgroups.  Here every compute unit runs one 512-thread workgroup for the whole factorisation:
+//   * tiles (i, j), i >= j, are handed out in column-major order by a ticket counter (dynamic, so the scheme cannot
+//     deadlock whatever subset of the grid is resident: the smallest unfinished tile is always owned by a running
+//     workgroup and depends only on smaller tiles);
+//   * the owner keeps the tile in its MFMA accumulators and subtracts L(i, k) L(j, k)' for k = 0 .. j-1 as those
+//     tiles become final (left-looking: C is read and written ONCE, K grows to 128 j), operands staged through LDS;
+//   * diagonal tile: accumulators -> LDS -> the look-ahead potf2 above; off-diagonal: wait for L(j, j), accumulators
+//     -> LDS -> X L(j,j)' = B on the matrix cores (same 16 x 16 inverse + refinement scheme as trsm_panel_kernel);
+//   * prog[r] = number of final tiles in block row r (they become final in column order) is the only synchronisation:
+//     producer: all stores drained -> __syncthreads -> one lane: agent-scope release fence, s_waitcnt, relaxed agent store;
+//     consumer: one lane polls relaxed (bounded, s_sleep) -> agent-scope acquire fence -> __syncthreads -> plain loads
+//     (guide G16; one acquire covers every k that has become available since the last look).
+// ===================================================================================================
+constexpr int PT_THREADS = 512;
+__device__ long long* g_tile_ts = nullptr;    // developer aid: 8 stamps per tile (s_memtime) when set
+#define PT_TS(k_) do { if (tts && tid == 0) tts[(int64_t)t * 8 + (k_)] = (long long)__builtin_readcyclecounter(); } while (0)
+struct TileCtl {
+    unsigned ticket, abort_flag, pad0, pad1;
+    unsigned prog[252];          // up to 252 block rows (n <= 32256); zeroed before every launch
+};
+#define RLX_AGENT_ __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+// acc -= Xi[:, 0:K] Xj[:, 0:K]'  (Xi: rows of the tile, Xj: its columns; both 128 x K panels of L, column-major, lda)
+// 8 waves: wave w owns rows 16 w .. 16 w + 15 and ALL 128 columns: acc[t] = 16-column block t in the transposed MFMA
+// layout (lane (li, lq), register r <-> row 16 w + li, column 16 t + lq + 4 r) -- exactly the layout the triangular
+// solve of the finished tile works in, so an off-diagonal tile never leaves its registers.
+template <bool diag>
+__device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __restrict__ Xi, const double* __restrict__ Xj,
+                                                int64_t lda, int K, int mi, int mj, double* __restrict__ smem, int tid) {
+    constexpr int PF = 2;                                     // k-steps of operands in flight (global -> registers)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int ip = (tid & 63) * 2, kq = tid >> 6;            // staging: index pair, k = kq + 8 r
+    auto sJ = [&](int s_) -> double* { return smem + s_ * 2 * STAGE_DOUBLES; };
+    auto sI = [&](int s_) -> double* { return smem + s_ * 2 * STAGE_DOUBLES + STAGE_DOUBLES; };
+    const int nkt = K / BK;                                   // K is a multiple of 128: nkt is a multiple of 8
+    double rJ[PF][4], rI[PF][4];
+    const bool fullJ = (mj == 128), fullI = (mi == 128);
+    auto fetch = [&](int kt, double (&J)[4], double (&I)[4]) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t k = (int64_t)kt * BK + kq + 8 * r;
+            const double* pj = Xj + k * lda + ip;
+            if (fullJ) {
+                const d2u_ v = *reinterpret_cast<const d2u_*>(pj);
+                J[2 * r] = v.x;
+                J[2 * r + 1] = v.y;
+            } else {
+                J[2 * r] = (ip < mj) ? pj[0] : 0.0;
+                J[2 * r + 1] = (ip + 1 < mj) ? pj[1] : 0.0;
+            }
+            if (!diag) {
+                const double* pi = Xi + k * lda + ip;
+                if (fullI) {
+                    const d2u_ v = *reinterpret_cast<const d2u_*>(pi);
+                    I[2 * r] = v.x;
+                    I[2 * r + 1] = v.y;
+                } else {
+                    I[2 * r] = (ip < mi) ? pi[0] : 0.0;
+                    I[2 * r + 1] = (ip + 1 < mi) ? pi[1] : 0.0;
+                }
+            }
+        }
+    };
+    auto stash = [&](int s_, const double (&J)[4], const double (&I)[4]) {   // J stored negated: the MFMAs accumulate C - A B'
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int k = kq + 8 * r;
+            d2_ vj = {-J[2 * r], -J[2 * r + 1]};
+            *reinterpret_cast<d2_*>(sJ(s_) + k * LDT_M + ip) = vj;
+            d2_ vi = {diag ? J[2 * r] : I[2 * r], diag ? J[2 * r + 1] : I[2 * r + 1]};
+            *reinterpret_cast<d2_*>(sI(s_) + k * LDT_M + ip) = vi;
+        }
+    };
+    if (nkt <= 0) return;
+    // Operands that were written a moment ago by another compute unit come from HBM / the other XCD's write-back (2-3 us):
+    // with one step of look-ahead every 16-deep step of the chain-critical last column waits for them; PF steps are in flight.
+#pragma unroll
+    for (int q = 0; q < PF; ++q) fetch(q, rJ[q], rI[q]);      // nkt >= 8
+    stash(0, rJ[0], rI[0]);
+    __syncthreads();
+    for (int kt0 = 0; kt0 < nkt; kt0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int kt = kt0 + u;
+            if (kt + PF < nkt) fetch(kt + PF, rJ[u], rI[u]);  // slot u held step kt, which went to LDS one step ago
+            const double* __restrict__ Js = sJ(u & 1);
+            const double* __restrict__ Is = sI(u & 1) + wave * 16;
+            if (!diag) {                                      // branch-free body for the common case
+#pragma unroll
+                for (int kk = 0; kk < BK; kk += 4) {
+                    const double bv = Is[li + (kk + lq) * LDT_M];
+                    double av[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) av[t] = Js[(t * 16 + li) + (kk + lq) * LDT_M];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) acc[t] = MFMA_F64(av[t], bv, acc[t]);
+                }
+            } else {                                          // diagonal tile: column blocks right of the row block are not needed
+#pragma unroll
+                for (int kk = 0; kk < BK; kk += 4) {
+                    const double bv = Is[li + (kk + lq) * LDT_M];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        if (t <= wave) {
+                            const double av = Js[(t * 16 + li) + (kk + lq) * LDT_M];
+                            acc[t] = MFMA_F64(av, bv, acc[t]);
+                        }
+                    }
+                }
+            }
+            if (kt + 1 < nkt) stash((u + 1) & 1, rJ[(u + 1) % PF], rI[(u + 1) % PF]);
+            __syncthreads();
+        }
+    }
+}
+
+// one lane: wait until *p >= need (or abort); returns the value seen, 0xffffffff on abort / timeout
+__device__ __forceinline__ unsigned tile_wait(const unsigned* p, const unsigned* p2, unsigned need, TileCtl* ctl, int* err) {
+    for (unsigned spins = 0; spins < (1u << 24); ++spins) {
+        unsigned v = __hip_atomic_load(p, RLX_AGENT_);
+        if (p2) {
+            const unsigned v2 = __hip_atomic_load(p2, RLX_AGENT_);
+            v = v < v2 ? v : v2;
+        }
+        if (v >= need) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            return v;
+        }
+        if (__hip_atomic_load(&ctl->abort_flag, RLX_AGENT_)) return 0xffffffffu;
+        __builtin_amdgcn_s_sleep(4);
+    }
+    atomicExch(err, -7);                                      // err aliases *info: a negative value = hand-off timeout
+    __hip_atomic_store(&ctl->abort_flag, 1u, RLX_AGENT_);
+    return 0xffffffffu;
+}
+
+// all threads: make this workgroup's global stores visible device-wide, then publish *p = value
+__device__ __forceinline__ void tile_publish(unsigned* p, unsigned value, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave drains its own stores
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(p, value, RLX_AGENT_);
+    }
+}
+
+__global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int n, TileCtl* ctl,
+                                                                 double* __restrict__ linv_all, int* __restrict__ info,
+                                                                 int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // the control words of the workgroup live behind the potf2 image (all LDS in the dynamic region, guide G17)
+    unsigned* ctlw = reinterpret_cast<unsigned*>(smem + NB * PLD + NB + 80 + 2);
+    const int NT = (n + NB - 1) / NB;
+    const unsigned ntiles = (unsigned)NT * (NT + 1) / 2;
+    double* As = smem;
+    for (;;) {
+        // the thread index is made opaque once per tile: otherwise every per-thread address (column * lda products of the
+        // loads / stores below) is hoisted out of the tile loop and lives in spilled registers
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int li = lane & 15, lq = lane >> 4;
+        if (tid == 0) ctlw[0] = __hip_atomic_fetch_add(&ctl->ticket, 1u, RLX_AGENT_);
+        __syncthreads();
+        const unsigned t = ctlw[0];
+        __syncthreads();                                      // ctlw[0] may be rewritten below
+        if (t >= ntiles) return;
+        int j = 0, rem = (int)t;                              // column-major tile order
+        while (rem >= NT - j) {
+            rem -= NT - j;
+            ++j;
+        }
+        const int i = j + rem;
+        const int i0 = i * NB, j0 = j * NB;
+        const int mi = min(NB, n - i0), mj = min(NB, n - j0);
+        const bool diag = (i == j);
+        long long* tts = g_tile_ts;
+        PT_TS(0);
+        // ---- the tile itself -> accumulators (its loads fly while the first operands are fetched)
+        const int row = wave * 16 + li;                       // my row of the tile
+        d4 acc[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = tt * 16 + lq + 4 * r;
+                acc[tt][r] = (row < mi && col < mj && (!diag || row >= col)) ? A[i0 + row + (int64_t)(j0 + col) * lda] : 0.0;
+            }
+        // ---- left-looking accumulation over the columns that are final, as they become final
+        int kdone = 0;
+        while (kdone < j) {
+            if (tid == 0) {
+                const unsigned v = tile_wait(&ctl->prog[i], diag ? nullptr : &ctl->prog[j], (unsigned)kdone + 1, ctl, err);
+                ctlw[1] = (v == 0xffffffffu) ? v : (v < (unsigned)j ? v : (unsigned)j);
+            }
+            __syncthreads();
+            const unsigned ka = ctlw[1];
+            if (ka == 0xffffffffu) return;
+            if ((int)ka == j && kdone == j - 1) PT_TS(5);     // exactly the last missing column has arrived
+            if (diag)
+                tile_accumulate<true>(acc, A + i0 + (int64_t)kdone * NB * lda, A + j0 + (int64_t)kdone * NB * lda, lda,
+                                      ((int)ka - kdone) * NB, mi, mj, smem, tid);
+            else
+                tile_accumulate<false>(acc, A + i0 + (int64_t)kdone * NB * lda, A + j0 + (int64_t)kdone * NB * lda, lda,
+                                       ((int)ka - kdone) * NB, mi, mj, smem, tid);
+            kdone = (int)ka;                                  // (tile_accumulate ends with a barrier: ctlw[1] is free again)
+        }
+        PT_TS(1);
+        if (diag) {
+            // ---- accumulators -> LDS image of the tile (column-major, leading dimension PLD), then the look-ahead potf2
+            __syncthreads();
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) As[(tt * 16 + lq + 4 * r) * PLD + row] = acc[tt][r];
+            const int failed = potf2_la_body<true>(A + j0 + (int64_t)j0 * lda, lda, mj, linv_all + (int64_t)j * 2048, smem, nullptr);
+            if (failed) {
+                if (tid == 0) {
+                    *info = j0 + failed;
+                    __hip_atomic_store(&ctl->abort_flag, 1u, RLX_AGENT_);
+                }
+                return;
+            }
+            PT_TS(3);
+            tile_publish(&ctl->prog[j], (unsigned)j + 1, tid);
+            PT_TS(4);
+        } else {
+            if (tid == 0) ctlw[1] = tile_wait(&ctl->prog[j], nullptr, (unsigned)j + 1, ctl, err);
+            __syncthreads();
+            if (ctlw[1] == 0xffffffffu) return;
+            PT_TS(2);
+            // ---- L(j,j) (tiles on / below the diagonal) and the inverses of its 16 x 16 diagonal blocks -> LDS, once for
+            //      the eight waves: one coalesced sweep instead of strided global loads in front of every MFMA group.  The
+            //      inverses ride in the 16 padding rows of the image: element (block cb, column k, row g) at As[(16cb+k) PLD + 128 + g].
+            {
+                const double* __restrict__ Lg = A + j0 + (int64_t)j0 * lda;
+                const double* __restrict__ linv = linv_all + (int64_t)j * 2048;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {        // two passes: 18 values in flight per thread (register budget)
+                    double v[18];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int e = tid + PT_THREADS * (16 * half + q);
+                        const int r = e & (NB - 1), c = e >> 7;
+                        v[q] = (r >= (c & ~15) && r < mj && c < mj) ? Lg[r + (int64_t)c * lda] : 0.0;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) v[16 + q] = linv[tid + PT_THREADS * (2 * half + q)];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int e = tid + PT_THREADS * (16 * half + q);
+                        As[(e >> 7) * PLD + (e & (NB - 1))] = v[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int e = tid + PT_THREADS * (2 * half + q);     // e = cb * 256 + k * 16 + g
+                        As[(e >> 4) * PLD + NB + (e & 15)] = v[16 + q];
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- X L(j,j)' = B on the accumulators (transposed tiles, diagonal blocks by inverse + one refinement step,
+            //      as trsm_panel_kernel), operands from LDS
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) {
+                d4 a4 = acc[cb];
+#pragma unroll
+                for (int c = 0; c < cb; ++c) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const double lv = As[(16 * c + 4 * s4 + lq) * PLD + 16 * cb + li];
+                        a4 = MFMA_F64(-lv, acc[c][s4], a4);
+                    }
+                }
+                double mi4[4], ld4[4];
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    mi4[s4] = As[(16 * cb + 4 * s4 + lq) * PLD + NB + li];
+                    const double lv = As[(16 * cb + 4 * s4 + lq) * PLD + 16 * cb + li];
+                    ld4[s4] = (4 * s4 + lq <= li) ? -lv : 0.0;
+                }
+                d4 x0 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x0 = MFMA_F64(mi4[s4], a4[s4], x0);
+                d4 e4 = a4;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) e4 = MFMA_F64(ld4[s4], x0[s4], e4);
+                d4 xx = x0;
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) xx = MFMA_F64(mi4[s4], e4[s4], xx);
+                acc[cb] = xx;
+                __builtin_amdgcn_sched_barrier(0);            // operand reads run ahead inside one column block only (register budget)
+            }
+            // (stores after the branch-free solve: the compiler can then run the LDS operand reads ahead of the MFMAs)
+            if (mi == NB && mj == NB) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) A[i0 + row + (int64_t)(j0 + 16 * cb + lq + 4 * r) * lda] = acc[cb][r];
+            } else if (row < mi) {
+#pragma unroll
+                for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int col = 16 * cb + lq + 4 * r;
+                        if (col < mj) A[i0 + row + (int64_t)(j0 + col) * lda] = acc[cb][r];
+                    }
+            }
+            PT_TS(3);
+            tile_publish(&ctl->prog[i], (unsigned)j + 1, tid);
+            PT_TS(4);
+        }
+        __syncthreads();                                      // LDS (image, control words) is reused by the next tile
+    }
+}
+
+int set_tile_ts(long long* dptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_ts), &dptr, sizeof(dptr)) == hipSuccess ? 0 : -2; }
+
 // One diagonal-block factorisation launch (nz blocks along blockIdx.z).  MI355KKT_POTF2=old selects the round-1 kernel.
 static int launch_potf2(double* A, int64_t lda, int nb, int col0, int* info, double* linv, int64_t bstride,
                         const VbDesc* vb, int nz, hipStream_t st) {
@@ -607,6 +971,8 @@ void potrf_work_free(PotrfWork& w) {
     if (w.d_info) (void)hipFree(w.d_info);
     if (w.d_dinv) (void)hipFree(w.d_dinv);
     if (w.h_info) (void)hipHostFree(w.h_info);
+    if (w.d_ctl) (void)hipFree(w.d_ctl);
+    if (w.d_linv_all) (void)hipFree(w.d_linv_all);
     for (auto e : w.ev_panel) (void)hipEventDestroy(e);
     for (auto e : w.ev_bulk) (void)hipEventDestroy(e);
     for (auto e : w.ev_t1) (void)hipEventDestroy(e);
@@ -617,8 +983,53 @@ void potrf_work_free(PotrfWork& w) {
     w = PotrfWork();
 }
 
+// device state of the persistent tile kernel for matrices up to n x n (idempotent; launch_potrf calls it lazily)
+int potrf_work_reserve(PotrfWork& w, int n) {
+    const int NT = (n + NB - 1) / NB;
+    if (!w.d_ctl) KKT_HIP_CHECK(hipMalloc(&w.d_ctl, sizeof(TileCtl)));
+    if (w.linv_tiles < NT) {
+        if (w.d_linv_all) (void)hipFree(w.d_linv_all);
+        w.d_linv_all = nullptr;
+        w.linv_tiles = 0;
+        KKT_HIP_CHECK(hipMalloc(&w.d_linv_all, sizeof(double) * 2048 * (size_t)NT));
+        w.linv_tiles = NT;
+    }
+    return 0;
+}
+
+// the persistent tile kernel: one 512-thread workgroup per compute unit, all of the factorisation in one launch
+static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipStream_t st) {
+    static int num_cus = 0;
+    static bool attr_set = false;
+    constexpr size_t lds = sizeof(double) * (NB * PLD + NB + 80 + 2 + 2) + 16;
+    if (!attr_set) {
+        int dev = 0;
+        KKT_HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        KKT_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int NT = (n + NB - 1) / NB;
+    if (int e = potrf_work_reserve(w, n)) return e;
+    KKT_HIP_CHECK(hipMemsetAsync(w.d_ctl, 0, sizeof(TileCtl), st));
+    const int ntiles = NT * (NT + 1) / 2;
+    const int grid = ntiles < num_cus ? ntiles : num_cus;
+    hipLaunchKernelGGL(potrf_tiles_kernel, dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n, reinterpret_cast<TileCtl*>(w.d_ctl),
+                       w.d_linv_all, w.d_info, w.d_info);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st) {
     KKT_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int) * nbatch, st));
+    {   // single large matrix: the persistent left-looking tile kernel (MI355KKT_POTRF=streams keeps the launch chain below)
+        static const bool use_streams = getenv("MI355KKT_POTRF") && !strcmp(getenv("MI355KKT_POTRF"), "streams");
+        static const int tiles_min_n = getenv("MI355KKT_TILES_MIN_N") ? atoi(getenv("MI355KKT_TILES_MIN_N")) : 1024;
+        if (nbatch == 1 && !use_streams && n >= tiles_min_n && (n + NB - 1) / NB <= 252) return launch_potrf_tiles(A, lda, n, w, st);
+    }
     // Outer panels of 256 columns = two 128-column sub-panels; the trailing matrix is touched once per
     // outer panel with a rank-256 update (halves the C read-modify-write traffic of a rank-128 scheme).
     auto panel = [&](int k0, int nb) -> int {   // factor diagonal block at k0 and solve the rows below it

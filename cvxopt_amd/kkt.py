@@ -22,7 +22,12 @@ import numpy as np
 
 from . import _capi
 
-options = {"device": None}   # None -> $CVXOPT_AMD_DEVICE, else $LOCAL_RANK, else 0
+# "device": None -> $CVXOPT_AMD_DEVICE, else $LOCAL_RANK, else 0.
+# "assume_constant_H": the hook re-uploads a dense host H at EVERY factor(W, H) (overlapped with the SYRK) because a caller
+#   may have changed it in place (cvxprog.cp / cpl build a new H per iteration, possibly in the same storage); True skips the
+#   upload while the very same object is passed again -- only for callers that guarantee H is immutable (cvxopt_amd.solvers
+#   sets it around coneqp, whose P is constant by contract, coneprog.py:1440-1477).
+options = {"device": None, "assume_constant_H": False}
 
 
 def _device():
@@ -137,6 +142,7 @@ class _Engine(object):
         if kktreg:
             _capi.check(self.L.mi355kkt_set_kktreg(h, float(kktreg)), "set_kktreg")
         self._H_tag = None
+        self._H_ref = self._H_view = None     # the dense host H whose buffer is currently pinned by the handle
 
     @staticmethod
     def _densify(M, what):
@@ -144,15 +150,16 @@ class _Engine(object):
             cp, ri, v = _csc_parts(M)
             m, n = _size(M)
             out = np.zeros((m, n), order='F')
-            for j in range(n):
-                out[ri[cp[j]:cp[j + 1]], j] += v[cp[j]:cp[j + 1]]
+            cols = np.repeat(np.arange(n, dtype=np.int64), np.diff(cp))
+            np.add.at(out, (ri, cols), v)          # duplicates add up, like the reference's spmatrix -> matrix conversion
             return out
         return _dense_view(M, what)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
-            self.L.mi355kkt_destroy(self.h)
+            self.L.mi355kkt_destroy(self.h)       # also unpins the caller's H buffer
             self.h = None
+        self._H_ref = self._H_view = None
 
     def __del__(self):
         try:
@@ -160,13 +167,7 @@ class _Engine(object):
         except Exception:
             pass
 
-    # ---- H upload with change detection ------------------------------------------------------------
-    def _fingerprint(self, H, a):
-        n = a.shape[0]
-        step = max(1, (n * n) // 65536)
-        flat = a.reshape(-1, order='F')
-        return (id(H), a.ctypes.data, float(np.sum(np.diagonal(a))), float(np.sum(flat[::step])))
-
+    # ---- H upload ---------------------------------------------------------------------------------
     def _upload_G_csc_dense(self):
         cp, ri, v = self._G_csc
         _capi.check(self.L.mi355kkt_set_G_csc(self.h, cp.ctypes.data_as(_capi.c_i64_p), ri.ctypes.data_as(_capi.c_i64_p),
@@ -189,16 +190,23 @@ class _Engine(object):
                                                            as_i64(hp[1]), as_f64(hp[2])), "set_sparse_problem")
             self._mode = "sparse"
             self._H_tag = self._sparse_tag(H)
+            self._H_ref = self._H_view = None
         else:
             self._upload_G_csc_dense()
             self._mode = "dense"
 
     @staticmethod
     def _sparse_tag(H):
+        """The complete CCS image of H (pattern and values): compared entry by entry, O(nnz), no sampling."""
         if H is None:
-            return ("sparse", None, None, None)
-        v = _csc_parts(H)[2]
-        return ("sparse", id(H), float(np.sum(v)), int(v.size))
+            return None
+        return _csc_parts(H)
+
+    @staticmethod
+    def _same_sparse(a, b):
+        if a is None or b is None:
+            return a is None and b is None
+        return all(x.shape == y.shape and np.array_equal(x, y) for x, y in zip(a, b))
 
     def sparse_stats(self):
         nnzL, ns, nl, fl = C.c_int64(), C.c_int(), C.c_int(), C.c_double()
@@ -209,25 +217,41 @@ class _Engine(object):
     def _set_H(self, H):
         if self._mode == "undecided":
             self._decide_mode(H)
+            if self._mode == "sparse":
+                return
         if self._mode == "sparse":
-            if self._sparse_tag(H)[2:] != self._H_tag[2:]:
-                # H changed: rebuild the sparse problem (pattern and values) -- rare (cp/cpl style callers)
+            if H is not None and not _is_sparse(H):
+                # the engine is chosen by the types seen at the first factor() (as in the reference, misc.py:1401-1411);
+                # the handle holds the sparse problem and cannot silently switch
+                raise TypeError("H was sparse (or absent) at the first factor() call and is dense now: create a new factory")
+            tag = self._sparse_tag(H)
+            if not self._same_sparse(tag, self._H_tag):
+                # H changed (pattern or values): rebuild the sparse problem -- cp/cpl style callers
                 self._mode = "undecided"
                 self._decide_mode(H)
             return
         if H is None:
             _capi.check(self.L.mi355kkt_set_H_dense(self.h, None, 1), "set_H_dense")
-            self._H_tag = None
+            self._H_ref = self._H_view = None
             return
         hm, hn = _size(H)
         if hm != self.n or hn != self.n:
             raise TypeError("H must be a 'd' matrix of size (%d, %d)" % (self.n, self.n))
-        a = self._densify(H, "H")
-        tag = self._fingerprint(H, a)
-        if tag == self._H_tag:
-            return                      # same object, same storage, same sampled content: already in HBM
-        _capi.check(self.L.mi355kkt_set_H_dense(self.h, _ptr(a), max(1, a.shape[0])), "set_H_dense")
-        self._H_tag = tag
+        if options.get("assume_constant_H") and H is self._H_ref:
+            return                      # the caller vouches for immutability: already in HBM
+        if _is_sparse(H):
+            tag = self._sparse_tag(H)
+            if self._H_ref is None and self._same_sparse(tag, self._H_tag) and self._H_tag is not None:
+                return                  # same pattern and values as the dense image already uploaded
+            a = self._densify(H, "H")
+            _capi.check(self.L.mi355kkt_set_H_dense(self.h, _ptr(a), max(1, a.shape[0])), "set_H_dense")
+            self._H_tag, self._H_ref, self._H_view = tag, None, None
+            return
+        a = _dense_view(H, "H")
+        # every call: the caller may have rewritten H in place.  The copy is asynchronous from the caller's buffer (pinned
+        # in place) and overlapped with the SYRK; `a` and H are kept referenced so the buffer outlives the registration.
+        _capi.check(self.L.mi355kkt_set_H_dense_async(self.h, _ptr(a), max(1, a.shape[0])), "set_H_dense_async")
+        self._H_ref, self._H_view, self._H_tag = H, a, None
 
     # ---- factor / solve ----------------------------------------------------------------------------
     def _scaling(self, W):
@@ -282,7 +306,7 @@ class _Engine(object):
     # ---- device-resident entry points (inputs already in HBM; used by bench.py and the batch driver) ----
     def set_H_device(self, ptr, ld):
         _capi.check(self.L.mi355kkt_set_H_device(self.h, C.c_void_p(ptr), ld), "set_H_device")
-        self._H_tag = None
+        self._H_tag = self._H_ref = self._H_view = None
 
     def factor_device(self, di_ptr=None, d_ptr=None, v_ptr=None, beta_ptr=None):
         sc = _capi.Scaling()

@@ -105,6 +105,12 @@ int mi355kkt_set_A_device(mi355kkt_solver* h, const double* dA, int64_t ldA);
  * (reference coneprog.py:1475-1477).  Copied to HBM; call again whenever H changes. */
 int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH);
 int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH);
+/* set_H_dense without the wait: the host buffer is pinned in place (hipHostRegister, cached while the same buffer is
+ * passed again), the copy runs on the handle's copy stream and the next factor() overlaps it with the scaled SYRK
+ * (S = Gs'Gs, then S += tril(H)).  This is what makes "re-upload H at every factor(W, H)" -- the only safe reading of the
+ * hook when the caller may have changed H in place (cvxprog.py:526-537) -- cost next to nothing at n = 8192.
+ * The caller keeps H alive and unmodified until that factor() returns and alive until the next set_H_* / destroy. */
+int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH);
 /* diagonal regularisation of kkt_ldl (reference misc.py:1095-1098): K[x,x] += reg, K[y,y] -= reg,
  * K[z,z] = -1 - reg.  0 disables it. */
 int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg);
@@ -189,7 +195,8 @@ int mi355kkt_batch_products(mi355kkt_batch* b, const double* x, const double* z,
 float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b);
 /* The whole coneqp loop (coneprog.py:2044-2547, dims = {'l': ml}, no equality constraints) for every problem of the
  * batch with iterates, scaling and step bookkeeping resident in HBM; after set_problem().  q: [nbatch][n],
- * h: [nbatch][ml] (host).  Outputs (host): x [nbatch][n], s, z [nbatch][ml], status [nbatch] (1 optimal, 2 unknown:
+ * h: [nbatch][ml]; q, h and every output array may be HOST or DEVICE pointers (copied with hipMemcpyDefault; a sharded
+ * batch keeps them in the rank's HBM between the RCCL scatter and gather).  Outputs: x [nbatch][n], s, z [nbatch][ml], status [nbatch] (1 optimal, 2 unknown:
  * iteration limit, 3 unknown: singular KKT matrix), iters, pcost, dcost, gap [nbatch]; *iterations_run = lock-step
  * iterations executed.  Returns 0; <0 on error; 1 if the initial factorisation failed (Rank([P; G]) < n, the
  * ValueError of coneprog.py:2065-2066). */
@@ -224,6 +231,10 @@ int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* ou
  * perm[new] = old; stats[8] = chosen method, nnz and flops of both candidates, supernodal tree heights, count cross-check */
 int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats);
 int mi355kkt_debug_potf2_skip(int mask);
+/* developer aid: device buffer of 48 int64 shader-clock stamps written by the diagonal-block kernel at its phase boundaries (NULL: off) */
+int mi355kkt_debug_potf2_ts(void* dptr);
+/* developer aid: 8 int64 stamps per 128 x 128 tile (column-major tile order) written by the persistent Cholesky kernel */
+int mi355kkt_debug_tile_ts(void* dptr);
 int mi355kkt_debug_syrk_skip(int mask);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops);
