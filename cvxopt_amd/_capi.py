@@ -43,6 +43,8 @@ SIGNATURES = {
     "mi355kkt_set_G_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_G_csc": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p, c_double_p]),
     "mi355kkt_set_sparse_problem": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p, c_double_p, c_i64_p, c_i64_p, c_double_p]),
+    "mi355kkt_set_sparse_problem_aug": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p, c_double_p, c_i64_p, c_i64_p, c_double_p, C.c_int]),
+    "mi355kkt_set_A_csr": (C.c_int, [C.c_void_p, c_i64_p, c_i64_p, c_double_p]),
     "mi355kkt_sparse_stats": (C.c_int, [C.c_void_p, c_i64_p, c_int_p, c_int_p, c_double_p]),
     "mi355kkt_sparse_ordering": (C.c_int, [C.c_void_p]),
     "mi355kkt_set_A_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
@@ -50,6 +52,7 @@ SIGNATURES = {
     "mi355kkt_set_A_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_H_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_H_dense_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mi355kkt_set_progress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355kkt_set_H_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_kktreg": (C.c_int, [C.c_void_p, C.c_double]),
     "mi355kkt_factor": (C.c_int, [C.c_void_p, C.POINTER(Scaling)]),
@@ -151,6 +154,9 @@ def check(rc, what):
 
 def device_count():
     return lib().mi355kkt_device_count()
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_void_p)
 
 
 class DeviceBuffer(object):

@@ -326,7 +326,7 @@ def shard_bounds(B, world):
 _STATUS_NAMES = np.array(['unknown', 'optimal', 'unknown', 'unknown'], dtype=object)
 
 
-def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, device_of_rank=None, **opts):
+def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, device_of_rank=None, return_device=False, **opts):
     """P, q, Gt, h are only read on `root` (other ranks may pass None): NumPy arrays, or -- with RCCL -- float64 CUDA
     tensors already resident in the root's HBM (then the scatter sends views of them, nothing is staged or copied).
     Root returns the FULL gathered result dict (NumPy), the other ranks their local shard's.
@@ -334,7 +334,8 @@ def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, dev
     Data path: `dist.scatter` of contiguous shards (RCCL: grouped send/recv, one xGMI link per peer, concurrently) ->
     local device-resident solve -> ONE packed float64 tensor per rank [x | s | z | pcost dcost gap status iters]
     -> `dist.gather`.  No collective inside the interior-point loop; with RCCL nothing but the per-iteration "still active"
-    word of the local loop touches a host."""
+    word of the local loop touches a host.  return_device=True leaves x, s, z of the result as tensors on the gathering
+    device (only the O(B) scalars are copied to the host)."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -415,14 +416,21 @@ def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, dev
     dist.gather(pack, gathered, dst=root, group=group)
 
     def unpack(t, cnt, ls):
-        a = t[:cnt].cpu().numpy()
-        return {'x': a[:, :n].copy(), 's': a[:, n:n + m].copy(), 'z': a[:, n + m:n + 2 * m].copy(),
-                'primal objective': a[:, n + 2 * m].copy(), 'dual objective': a[:, n + 2 * m + 1].copy(),
-                'gap': a[:, n + 2 * m + 2].copy(), 'status': _STATUS_NAMES[a[:, n + 2 * m + 3].astype(int)],
-                'iterations': a[:, n + 2 * m + 4].astype(int), 'lockstep iterations': ls}
+        t = t[:cnt]
+        sc = t[:, n + 2 * m:].cpu().numpy()                    # pcost dcost gap status iters: O(B) doubles
+        if return_device:
+            vec = {'x': t[:, :n], 's': t[:, n:n + m], 'z': t[:, n + m:n + 2 * m]}
+        else:
+            a = t[:, :n + 2 * m].cpu().numpy()
+            vec = {'x': a[:, :n].copy(), 's': a[:, n:n + m].copy(), 'z': a[:, n + m:n + 2 * m].copy()}
+        vec.update({'primal objective': sc[:, 0].copy(), 'dual objective': sc[:, 1].copy(), 'gap': sc[:, 2].copy(),
+                    'status': _STATUS_NAMES[sc[:, 3].astype(int)], 'iterations': sc[:, 4].astype(int),
+                    'lockstep iterations': ls})
+        return vec
     if rank != root:
         return unpack(pack, nloc, lockstep)
     parts = [unpack(g, b - a, 0) for g, (a, b) in zip(gathered, bounds)]
-    full = {k: np.concatenate([pp[k] for pp in parts]) for k in parts[0] if k != 'lockstep iterations'}
+    cat = lambda xs: torch.cat(list(xs)) if hasattr(xs[0], "data_ptr") else np.concatenate(xs)
+    full = {k: cat([pp[k] for pp in parts]) for k in parts[0] if k != 'lockstep iterations'}
     full['lockstep iterations'] = lockstep          # the root's own count (shards stop independently)
     return full

@@ -413,9 +413,15 @@ __device__ __forceinline__ void publish_flag(u32* flag, u32 epoch) {
 // needs it (guide G16 form R2: the data is the flag) -- no release fence, no acquire fence, no second trip for the payload:
 // a hop costs ~1 us instead of ~4 (flag + two fences + the x reload).  gran[block][256], zeroed once; epochs never repeat.
 typedef unsigned long long u64;
-template <bool TRANS, bool GRAN>
+// INV (round 2): the diagonal block is not solved by two 64-step substitution chains (2 x ~2200 clocks of readlane / FMA
+// dependencies per hop) but with M = inv(L_kk) from the factorisation (potrf_tiles_kernel) and ONE step of fixed-precision
+// iterative refinement, three 128 x 128 matrix-vector products spread over the 256 threads:
+//     x0 = M b,   e = b - L_kk x0,   x = x0 + M e        (backward stable like the substitution: Skeel 1980)
+// minv: per 128-block 2 x 16384 doubles, M column-major then M' column-major (the backward solve reads rows of M').
+template <bool TRANS, bool GRAN, bool INV>
 __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __restrict__ L, int64_t ldl, int n,
-                                                              double* x, u32* flags, u32 epoch, int* err, u64* gran) {
+                                                              double* x, u32* flags, u32 epoch, int* err, u64* gran,
+                                                              const double* __restrict__ minv) {
     // 256 threads: two per row (forward) / column (backward) of the block row; each holds one 64-wide half of the strip
     // of every off-diagonal block in registers BEFORE waiting for that block's x, so that nothing but 64 FMAs, one
     // partial-sum exchange and the diagonal solve sits between "x_j published" and "x_k published".
@@ -435,7 +441,19 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
     const double* Lkk = L + k0 + (int64_t)k0 * ldl;
     const int n0 = min(nb, 64), n1 = nb - n0;
     double ra[64], rb[64];
-    if (!TRANS) {
+    if (INV) {
+        // my half (columns 64 half .. + 63) of row r of M (forward) / of M' (backward) and of the same row of L_kk / L_kk'
+        const double* Mk = minv + (int64_t)k * (2 * TB * TB) + (TRANS ? TB * TB : 0);
+        const int c0 = 64 * half;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) ra[j] = Mk[r + (int64_t)(c0 + j) * TB];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const int c = c0 + j;
+            const bool in = mine && c < nb && (TRANS ? c >= r : c <= r);      // (the other triangle holds the mirrored copy)
+            rb[j] = in ? Lkk[r + (int64_t)c * ldl] : 0.0;
+        }
+    } else if (!TRANS) {
         if (wave == 0) {   // rows 0..63: row of L11
 #pragma unroll
             for (int j = 0; j < 64; ++j) ra[j] = (j < lane && lane < n0) ? Lkk[lane + (int64_t)j * ldl] : 0.0;
@@ -508,7 +526,39 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
     if (half == 0) acc += ps[r];
     // ---- diagonal block (threads 0..127): two 64-wide halves, the first half's solution goes through LDS to the second
     const double dinv = 1.0 / dg;
-    if (!TRANS) {
+    if (INV) {
+        const int ch2 = 64 * half;
+        // x0 = M b
+        __syncthreads();
+        if (half == 0) xs[r] = acc;                      // b (rows beyond nb carry zeros)
+        __syncthreads();
+        double p0 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) p0 = fma(ra[c], xs[ch2 + c], p0);
+        if (half == 1) ps[r] = p0;
+        __syncthreads();
+        const double x0 = p0 + ps[r];                    // (meaningful in half 0)
+        // e = b - L x0
+        __syncthreads();
+        if (half == 0) xs[r] = x0;
+        __syncthreads();
+        double q0 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) q0 = fma(rb[c], xs[ch2 + c], q0);
+        if (half == 1) ps[r] = q0;
+        __syncthreads();
+        const double e = acc - (q0 + ps[r]);
+        // x = x0 + M e
+        __syncthreads();
+        if (half == 0) xs[r] = e;
+        __syncthreads();
+        double p1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) p1 = fma(ra[c], xs[ch2 + c], p1);
+        if (half == 1) ps[r] = p1;
+        __syncthreads();
+        acc = x0 + (p1 + ps[r]);
+    } else if (!TRANS) {
         if (wave == 0) {
 #pragma unroll
             for (int j = 0; j < 64; ++j) {
@@ -567,19 +617,26 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
 }
 
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
-                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran) {
+                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran, const double* minv) {
     const int nblk = (n + TB - 1) / TB;
     if (nblk <= 0) return 0;
     static const bool use_flags = getenv("MI355KKT_TRSV") && !strcmp(getenv("MI355KKT_TRSV"), "flag");
-    if (gran && !use_flags) {
+    static const bool no_inv = getenv("MI355KKT_TRSV_NOINV") != nullptr;
+    const dim3 g(nblk), b(256);
+    if (gran && !use_flags && minv && !no_inv) {
         if (trans)
-            hipLaunchKernelGGL((trsv_persistent_kernel<true, true>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err, gran);
+            hipLaunchKernelGGL((trsv_persistent_kernel<true, true, true>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
         else
-            hipLaunchKernelGGL((trsv_persistent_kernel<false, true>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err, gran);
+            hipLaunchKernelGGL((trsv_persistent_kernel<false, true, true>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
+    } else if (gran && !use_flags) {
+        if (trans)
+            hipLaunchKernelGGL((trsv_persistent_kernel<true, true, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
+        else
+            hipLaunchKernelGGL((trsv_persistent_kernel<false, true, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
     } else if (trans)
-        hipLaunchKernelGGL((trsv_persistent_kernel<true, false>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err, gran);
+        hipLaunchKernelGGL((trsv_persistent_kernel<true, false, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
     else
-        hipLaunchKernelGGL((trsv_persistent_kernel<false, false>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, flags, epoch, err, gran);
+        hipLaunchKernelGGL((trsv_persistent_kernel<false, false, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -261,6 +261,12 @@ struct mi355kkt_solver {
     // sparse mode (config 4): S is factored by the supernodal multifrontal engine instead of the dense one
     bool sparse = false;
     SparseEngine sp;
+    int sp_extra = 0;          // > 0: the engine's G carries the p rows of A below the cone rows (S + A'A fallback, misc.py:1433-1447)
+    // sparse A (mi355kkt_set_A_csr): CSR for A x and the forward solves, CSC (= CSR of A') for A' y; no dense copy
+    bool A_sparse = false;
+    int64_t *dArp = nullptr, *dAcp = nullptr;
+    int *dAci = nullptr, *dAri = nullptr;
+    double *dAv = nullptr, *dAvc = nullptr;
     double* dS = nullptr;      // n x n: S then its Cholesky factor L
     double* dAsct = nullptr;   // n x p
     double* dK = nullptr;      // p x p
@@ -279,7 +285,25 @@ struct mi355kkt_solver {
     bool hsym_valid = false;
     double* dIpmWork = nullptr;
     double* dSpWork = nullptr;  // GEMV workspace of the sparse engine's Schur-complement step (p > 0)
+    // options['show_progress'] of the reference drivers: called once per iteration of the device-resident loops
+    mi355kkt_progress_fn progress = nullptr;
+    void* progress_user = nullptr;
 };
+
+// per-iteration report of a device-resident loop: the scalar block comes back with one small copy (the loop has just
+// synchronised on the "still active" word anyway)
+static int report_progress(mi355kkt_solver* h, int it, const double* d_sc, int nsc, const int* idx, int nidx, int itau, int ikappa) {
+    if (!h->progress) return 0;
+    double sc[64];
+    if (nsc > 64) nsc = 64;
+    KKT_HIP_CHECK(hipMemcpy(sc, d_sc, sizeof(double) * nsc, hipMemcpyDeviceToHost));
+    double vals[8];
+    for (int k = 0; k < nidx; ++k) vals[k] = sc[idx[k]];
+    int nv = nidx;
+    if (itau >= 0) vals[nv++] = sc[ikappa] / sc[itau];
+    h->progress(it, nv, vals, h->progress_user);
+    return 0;
+}
 
 static int bind(const mi355kkt_solver* h) {
     KKT_HIP_CHECK(hipSetDevice(h->device));
@@ -387,16 +411,16 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
         return 0;
     };
     const size_t N = (size_t)n, P = (size_t)p, C = (size_t)h->cdim;
-    if ((rc = alloc(&h->dW, C))) return fail(rc);
+    if ((rc = alloc(&h->dW, C + P))) return fail(rc);          // + p: the unit scaling of the A rows in the S + A'A sparse mode
     if ((rc = alloc(&h->dAsct, N * P))) return fail(rc);
     if ((rc = alloc(&h->dK, P * P))) return fail(rc);
     if ((rc = alloc(&h->dx, N))) return fail(rc);
     if ((rc = alloc(&h->dy, P))) return fail(rc);
-    if ((rc = alloc(&h->dz, C))) return fail(rc);
-    if ((rc = alloc(&h->dzs, C))) return fail(rc);
+    if ((rc = alloc(&h->dz, C + P))) return fail(rc);
+    if ((rc = alloc(&h->dzs, C + P))) return fail(rc);
     if ((rc = alloc(&h->dtn, N))) return fail(rc);
     if ((rc = alloc(&h->dtp, P))) return fail(rc);
-    if ((rc = alloc(&h->dwork, C + 8))) return fail(rc);   // grown to the dense GEMV workspace on first dense use
+    if ((rc = alloc(&h->dwork, C + P + 8))) return fail(rc);   // grown to the dense GEMV workspace on first dense use
     if ((rc = alloc(&h->dWst, 2 * C + (size_t)nq + 8))) return fail(rc);
     {
         const size_t nfl = N / 128 + 2;
@@ -448,6 +472,10 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     if (h->dIpmWork) (void)hipFree(h->dIpmWork);
     if (h->dSpWork) (void)hipFree(h->dSpWork);
     h_unregister(h);
+    {
+        void* ap[] = {h->dArp, h->dAcp, h->dAci, h->dAri, h->dAv, h->dAvc};
+        for (void* q : ap) if (q) (void)hipFree(q);
+    }
     if (h->cst) (void)hipStreamDestroy(h->cst);
     if (h->ev_h) (void)hipEventDestroy(h->ev_h);
     if (h->dflags) (void)hipFree(h->dflags);
@@ -516,23 +544,85 @@ int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t*
     return mi355kkt_set_G_dense(h, dense.data(), h->cdim > 1 ? h->cdim : 1);
 }
 
-int mi355kkt_set_sparse_problem(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
-                                const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues) {
+/* A (p x n) in CSR: rowptr[p + 1], colind[nnz] (int64, like the CCS arrays of cvxopt), values[nnz].  The handle keeps A sparse
+ * on the device (CSR + its transpose) -- reference misc.py:1483-1487 / cholmod.spsolve keep A' sparse too.  Sparse engine only. */
+int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr, const int64_t* colind, const double* values) {
+    if (!h || (h->p > 0 && !rowptr)) { set_last_error("set_A_csr: null argument"); return MI355KKT_EINVAL; }
+    if (int e = bind(h)) return e;
+    const int p = h->p, n = h->n;
+    if (p == 0) { h->A_sparse = true; return 0; }
+    const int64_t nnz = rowptr[p];
+    std::vector<int> ci((size_t)nnz), ri((size_t)nnz);
+    std::vector<int64_t> cp((size_t)n + 1, 0), rp(rowptr, rowptr + p + 1);
+    std::vector<double> vc((size_t)nnz);
+    for (int64_t k = 0; k < nnz; ++k) {
+        if (colind[k] < 0 || colind[k] >= n) { set_last_error("set_A_csr: column index out of range"); return MI355KKT_EINVAL; }
+        ci[k] = (int)colind[k];
+        ++cp[colind[k] + 1];
+    }
+    for (int j = 0; j < n; ++j) cp[j + 1] += cp[j];
+    {
+        std::vector<int64_t> nxt(cp.begin(), cp.end() - 1);
+        for (int r = 0; r < p; ++r)
+            for (int64_t k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+                const int64_t q = nxt[colind[k]]++;
+                ri[q] = r;
+                vc[q] = values[k];
+            }
+    }
+    void* old[] = {h->dArp, h->dAcp, h->dAci, h->dAri, h->dAv, h->dAvc};
+    for (void* q : old) if (q) (void)hipFree(q);
+    h->dArp = h->dAcp = nullptr; h->dAci = h->dAri = nullptr; h->dAv = h->dAvc = nullptr;
+    const size_t z = (size_t)(nnz > 0 ? nnz : 1);
+    KKT_HIP_CHECK(hipMalloc(&h->dArp, sizeof(int64_t) * (p + 1)));
+    KKT_HIP_CHECK(hipMalloc(&h->dAcp, sizeof(int64_t) * ((size_t)n + 1)));
+    KKT_HIP_CHECK(hipMalloc(&h->dAci, sizeof(int) * z));
+    KKT_HIP_CHECK(hipMalloc(&h->dAri, sizeof(int) * z));
+    KKT_HIP_CHECK(hipMalloc(&h->dAv, sizeof(double) * z));
+    KKT_HIP_CHECK(hipMalloc(&h->dAvc, sizeof(double) * z));
+    KKT_HIP_CHECK(hipMemcpy(h->dArp, rp.data(), sizeof(int64_t) * (p + 1), hipMemcpyHostToDevice));
+    KKT_HIP_CHECK(hipMemcpy(h->dAcp, cp.data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        KKT_HIP_CHECK(hipMemcpy(h->dAci, ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(hipMemcpy(h->dAri, ri.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(hipMemcpy(h->dAv, values, sizeof(double) * nnz, hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(hipMemcpy(h->dAvc, vc.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+    }
+    h->A_sparse = true;
+    h->dA = nullptr;
+    return 0;
+}
+
+/* set_sparse_problem whose G carries `extra_rows` more rows below the cdim cone rows: the rows of A with unit scaling, i.e.
+ * S = H + G'D^2 G + A'A -- the reference's fallback for a singular S on the first factorisation (misc.py:1433-1447), which in
+ * sparse mode needs a new symbolic analysis because the pattern of S grows.  The handle is in "singular" mode afterwards
+ * (solve() adds A'by to bx, misc.py:1527).  extra_rows is 0 or p. */
+int mi355kkt_set_sparse_problem_aug(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
+                                    const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues, int extra_rows) {
     if (!h || !gcolptr) { set_last_error("set_sparse_problem: null argument"); return MI355KKT_EINVAL; }
+    if (extra_rows != 0 && extra_rows != h->p) { set_last_error("set_sparse_problem_aug: extra_rows must be 0 or p"); return MI355KKT_EINVAL; }
     if (!h->q.empty() || !h->s.empty()) {
         set_last_error("set_sparse_problem: the sparse engine handles LP cones");
         return MI355KKT_ENOTIMPL;
     }
     if (int e = bind(h)) return e;
+    const int rows = h->cdim + extra_rows;
     for (int j = 0; j < h->n; ++j)
         for (int64_t k = gcolptr[j]; k < gcolptr[j + 1]; ++k)
-            if (growind[k] < 0 || growind[k] >= h->cdim) { set_last_error("set_sparse_problem: G row index out of range"); return MI355KKT_EINVAL; }
-    if (int e = sparse_engine_create(h->sp, h->n, h->cdim, gcolptr, growind, gvalues, hcolptr, hrowind, hvalues)) return e;
+            if (growind[k] < 0 || growind[k] >= rows) { set_last_error("set_sparse_problem: G row index out of range"); return MI355KKT_EINVAL; }
+    if (int e = sparse_engine_create(h->sp, h->n, rows, gcolptr, growind, gvalues, hcolptr, hrowind, hvalues)) return e;
     h->sparse = true;
     h->firstcall = true;
+    h->sp_extra = extra_rows;
+    h->singular = extra_rows > 0;
+    h->factored = false;
     return 0;
 }
 
+int mi355kkt_set_sparse_problem(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
+                                const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues) {
+    return mi355kkt_set_sparse_problem_aug(h, gcolptr, growind, gvalues, hcolptr, hrowind, hvalues, 0);
+}
 int mi355kkt_sparse_stats(const mi355kkt_solver* h, int64_t* nnzL, int* nsupernodes, int* nlevels, double* flops) {
     if (!h || !h->sparse) return MI355KKT_EINVAL;
     if (nnzL) *nnzL = h->sp.sym.nnzL;
@@ -643,6 +733,12 @@ int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH) {
     h->hsym_valid = false;
     return 0;
 }
+int mi355kkt_set_progress(mi355kkt_solver* h, mi355kkt_progress_fn fn, void* user) {
+    if (!h) return MI355KKT_EINVAL;
+    h->progress = fn;
+    h->progress_user = user;
+    return 0;
+}
 int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg) {
     if (!h || !(reg >= 0.0)) { set_last_error("set_kktreg: reg must be >= 0"); return MI355KKT_EINVAL; }
     h->kktreg = reg;
@@ -662,6 +758,42 @@ static int fetch_info(mi355kkt_solver* h, int* info) {
 }
 
 // assemble S = H + [reg I] + Gs' Gs [+ A'A]
+// out[r] = beta * out[r] + sum_k v[k] x[ci[k]] over row r of a CSR matrix: one wave per row, fixed-order tree reduction
+__global__ __launch_bounds__(256) void csr_mul_kernel(const int64_t* __restrict__ rp, const int* __restrict__ ci,
+                                                      const double* __restrict__ v, int nrows, const double* __restrict__ x,
+                                                      double* __restrict__ out, double beta) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= nrows) return;
+    double acc = 0.0;
+    for (int64_t k = rp[r] + lane; k < rp[r + 1]; k += 64) acc = fma(v[k], x[ci[k]], acc);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[r] = (beta == 0.0 ? 0.0 : beta * out[r]) + acc;
+}
+// A x -> Ax (p) with the handle's A, dense or sparse
+static int A_mul(mi355kkt_solver* hs, const double* x, double* Ax, double* gwork, hipStream_t st) {
+    const int n = hs->n, np = hs->p;
+    if (np <= 0) return 0;
+    if (hs->A_sparse) {
+        hipLaunchKernelGGL(csr_mul_kernel, dim3((np + 3) / 4), dim3(256), 0, st, hs->dArp, hs->dAci, hs->dAv, np, x, Ax, 0.0);
+        KKT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    return launch_gemv_n_scaled(hs->dA, hs->ldA, np, n, nullptr, x, Ax, Ax, 1.0, 0.0, gwork, st);
+}
+// out (n) := beta * out + A' y
+static int A_mulT(mi355kkt_solver* hs, const double* y, double* out, double beta, double* gwork, hipStream_t st) {
+    const int n = hs->n, np = hs->p;
+    if (np <= 0 || n <= 0) return 0;
+    if (hs->A_sparse) {
+        hipLaunchKernelGGL(csr_mul_kernel, dim3((n + 3) / 4), dim3(256), 0, st, hs->dAcp, hs->dAri, hs->dAvc, n, y, out, beta);
+        KKT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    if (beta == 0.0) KKT_HIP_CHECK(hipMemsetAsync(out, 0, sizeof(double) * n, st));
+    return launch_gemv_t_scaled(hs->dA, hs->ldA, np, n, nullptr, y, hs->dtp, out, gwork, st);
+}
+
 __global__ void add_lower_kernel(double* __restrict__ S, int64_t lds, const double* __restrict__ H, int64_t ldh, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;      // column j, rows i >= j
     if (i < n && i >= j) S[i + (int64_t)j * lds] += H[i + (int64_t)j * ldh];
@@ -710,6 +842,8 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
         h->factored = false;
         KKT_HIP_CHECK(hipEventRecord(h->ev[0], h->st));
         if (h->ml > 0) hipLaunchKernelGGL(scaled_copy_kernel, g1(h->ml), dim3(256), 0, h->st, W->di, h->dW, h->ml, 1.0);
+        if (h->sp_extra > 0)      // S + A'A mode: the A rows below the cone rows carry unit scaling
+            hipLaunchKernelGGL(fill_kernel, g1(h->sp_extra), dim3(256), 0, h->st, h->dW + h->ml, 1.0, (int64_t)h->sp_extra);
         int sinfo = 0;
         if (int e = sparse_engine_factor(h->sp, h->dW, h->st, &sinfo)) return e;
         KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
@@ -717,13 +851,18 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
         (void)hipEventElapsedTime(&h->t_factor, h->ev[0], h->ev[3]);
         h->t_syrk = h->t_potrf = h->t_schur = h->t_syrk_kernel = 0;
         h->firstcall = false;
-        if (sinfo > 0) return sinfo;     // (the S + A'A fallback of misc.py:1433-1447 would change the sparsity pattern: not done)
+        // singular S: the caller (the Python mirror, on the first factorisation with p > 0) re-creates the sparse problem with
+        // the rows of A appended -- mi355kkt_set_sparse_problem_aug, a new symbolic analysis since the pattern of S grows --
+        // and factors again: the S + A'A fallback of misc.py:1433-1447
+        if (sinfo > 0) return sinfo;
         if (h->p > 0) {
             // equality constraints (misc.py:1464-1487, sparse branch): Asct = L^-1 P A' with all p right-hand sides in
             // one pass of the supernodal forward solve (kept in the permuted ordering), K = Asct' Asct, dense Cholesky of K
-            if (!h->dA) { set_last_error("factor: A not set"); return MI355KKT_EINVAL; }
+            if (!h->dA && !h->A_sparse) { set_last_error("factor: A not set"); return MI355KKT_EINVAL; }
             if (!h->dSpWork) KKT_HIP_CHECK(hipMalloc(&h->dSpWork, sizeof(double) * gemv_work_doubles(h->n, h->p)));
-            if (int e = sparse_engine_forward_rows(h->sp, h->dA, h->ldA, h->p, h->dAsct, h->st)) return e;
+            if (h->A_sparse) {
+                if (int e = sparse_engine_forward_rows_csr(h->sp, h->dArp, h->dAci, h->dAv, h->p, h->dAsct, h->st)) return e;
+            } else if (int e = sparse_engine_forward_rows(h->sp, h->dA, h->ldA, h->p, h->dAsct, h->st)) return e;
             KKT_HIP_CHECK(hipMemsetAsync(h->pw.d_info, 0, sizeof(int), h->st));
             if (int e = launch_syrk_scaled(h->planK, h->dAsct, h->n, nullptr, h->dK, h->p, nullptr, 0, h->st)) return e;
             if (h->kktreg != 0.0) hipLaunchKernelGGL(diag_add_kernel, g1(h->p), dim3(256), 0, h->st, h->dK, (int64_t)h->p, h->p, h->kktreg);
@@ -850,7 +989,15 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     const int n = h->n, p = h->p, m = h->cdim;
     KKT_HIP_CHECK(hipEventRecord(h->ev[4], st));
     if (h->sparse) {                                                // misc.py:1513-1563, sparse branch
-        if (int e = sparse_engine_gemv_t(h->sp, h->dW, dz, h->dzs, h->dwork, dx, st)) return e;
+        double* zz = dz;
+        if (h->sp_extra > 0) {                                      // the engine's cone space has p more (A) rows: zero tail
+            zz = h->dz;
+            if (dz != h->dz) KKT_HIP_CHECK(hipMemcpyAsync(h->dz, dz, sizeof(double) * m, hipMemcpyDeviceToDevice, st));
+            KKT_HIP_CHECK(hipMemsetAsync(h->dz + m, 0, sizeof(double) * h->sp_extra, st));
+        }
+        if (int e = sparse_engine_gemv_t(h->sp, h->dW, zz, h->dzs, h->dwork, dx, st)) return e;
+        if (h->singular && p > 0)                                   // x += A' by  (misc.py:1527)
+            if (int e = A_mulT(h, dy, dx, 1.0, nullptr, st)) return e;
         if (p == 0) {
             if (int e = sparse_engine_solve(h->sp, dx, st)) return e;
         } else {
@@ -864,7 +1011,8 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
             if (int e = launch_gemv_n_scaled(h->dAsct, n, n, p, nullptr, dy, xp, xp, -1.0, 1.0, h->dSpWork, st)) return e;
             if (int e = sparse_engine_backward(h->sp, dx, st)) return e;
         }
-        if (int e = sparse_engine_gemv_n(h->sp, h->dW, dx, h->dzs, dz, st)) return e;
+        if (int e = sparse_engine_gemv_n(h->sp, h->dW, dx, h->dzs, zz, st)) return e;
+        if (zz != dz) KKT_HIP_CHECK(hipMemcpyAsync(dz, zz, sizeof(double) * m, hipMemcpyDeviceToDevice, st));
         KKT_HIP_CHECK(hipEventRecord(h->ev[5], st));
         return 0;
     }
@@ -887,7 +1035,8 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     // triangular solves with L: one persistent launch each when every 128-block can own a resident workgroup
     const bool persistent = (n + 127) / 128 <= h->num_cus && !getenv("MI355KKT_NO_PERSISTENT_TRSV");
     auto tri_solve = [&](int trans) -> int {
-        if (persistent) return launch_trsv_persistent(h->dS, n, n, dx, trans, h->dflags, ++h->epoch, h->derr, st, h->dgran);
+        if (persistent) return launch_trsv_persistent(h->dS, n, n, dx, trans, h->dflags, ++h->epoch, h->derr, st, h->dgran,
+                                                      (h->pw.minv_n == n && h->pw.minv_of == h->dS) ? h->pw.d_minv : nullptr);
         return launch_trsm_lower(h->dS, n, n, dx, n, 1, trans, st);
     };
     if (int e = tri_solve(0)) return e;                                             // :1529
@@ -922,6 +1071,14 @@ static int check_handoff(mi355kkt_solver* h) {   // stream must be idle
         return MI355KKT_EHIP;
     }
     return 0;
+}
+
+// for the device-resident loops: the persistent triangular solves report a hand-off timeout only through derr; read it
+// back with the per-iteration word (the stream has just been synchronised) instead of iterating on garbage
+static int loop_check_handoff(mi355kkt_solver* h) {
+    if (!h->derr) return 0;
+    KKT_HIP_CHECK(hipMemcpy(h->herr, h->derr, sizeof(int), hipMemcpyDeviceToHost));
+    return check_handoff(h);
 }
 
 int mi355kkt_sync(mi355kkt_solver* h) {
@@ -1158,6 +1315,7 @@ struct IpmOps {
     std::function<int()> products;
     std::function<int(const double* di, int* d_info, int* h_info_first)> factor;
     std::function<int(double* dx, double* dy, double* dz)> solve;
+    std::function<int()> check;      // optional, called once per iteration on an idle stream (hand-off timeouts of the solves)
 };
 struct IpmHostOut {
     double *x, *s, *z; int *status, *iters; double *pcost, *dcost, *gap; int* iterations_run; double* y;
@@ -1188,6 +1346,7 @@ static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, con
         ipm_launch_residual(S, (int)B, it, maxiters, abstol, reltol, feastol, st);
         KKT_HIP_CHECK(hipMemcpyAsync(w.pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
         KKT_HIP_CHECK(hipStreamSynchronize(st));
+        if (ops.check) if (int e = ops.check()) return e;
         if (w.pinned[0] == 0) break;
         if (int e = ops.factor(S.di, d_info, nullptr)) return e;
         ipm_launch_info(S, d_info, it, (int)B, st);
@@ -1259,13 +1418,24 @@ static int ensure_hsym(mi355kkt_solver* hs) {
     hs->hsym_valid = true;
     return 0;
 }
-// A xin -> Ax, A' yin -> ATy with the dense A of the handle (both engines keep A dense)
+// G x, G' z, P x of the sparse engine for the loops' cone-space vectors of length cdim.  In the S + A'A mode the engine's G
+// carries p more rows (the rows of A): z goes in with a zero tail and G x comes back through a (cdim + p)-vector.
+static int sparse_products_cdim(mi355kkt_solver* hs, const double* xin, const double* zin, double* Gx, double* GTz, double* Px,
+                                hipStream_t st) {
+    if (hs->sp_extra <= 0) return sparse_engine_products(hs->sp, xin, zin, Gx, GTz, Px, st);
+    const size_t m = (size_t)hs->cdim;
+    KKT_HIP_CHECK(hipMemcpyAsync(hs->dz, zin, sizeof(double) * m, hipMemcpyDeviceToDevice, st));
+    KKT_HIP_CHECK(hipMemsetAsync(hs->dz + m, 0, sizeof(double) * hs->sp_extra, st));
+    if (int e = sparse_engine_products(hs->sp, xin, hs->dz, hs->dzs, GTz, Px, st)) return e;
+    KKT_HIP_CHECK(hipMemcpyAsync(Gx, hs->dzs, sizeof(double) * m, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+// A xin -> Ax, A' yin -> ATy with the A of the handle (dense, or CSR/CSC in sparse mode)
 static int a_products(mi355kkt_solver* hs, const double* xin, const double* yin, double* Ax, double* ATy, double* gwork, hipStream_t st) {
     const int n = hs->n, np = hs->p;
     if (np <= 0) return 0;
-    if (int e = launch_gemv_n_scaled(hs->dA, hs->ldA, np, n, nullptr, xin, Ax, Ax, 1.0, 0.0, gwork, st)) return e;
-    KKT_HIP_CHECK(hipMemsetAsync(ATy, 0, sizeof(double) * n, st));
-    return launch_gemv_t_scaled(hs->dA, hs->ldA, np, n, nullptr, yin, hs->dtp, ATy, gwork, st);
+    if (int e = A_mul(hs, xin, Ax, gwork, st)) return e;
+    return A_mulT(hs, yin, ATy, 0.0, gwork, st);
 }
 static int ensure_gemv_work(mi355kkt_solver* hs) {
     if (hs->dIpmWork) return 0;
@@ -1298,8 +1468,14 @@ int mi355kkt_product(mi355kkt_solver* hs, int which, int trans, const double* x,
         KKT_HIP_CHECK(hipMemcpyAsync(din, hs->hbuf, sizeof(double) * nin, hipMemcpyHostToDevice, st));
     }
     if (hs->sparse && which != 1) {
+        if (which == 0 && trans && hs->sp_extra > 0)       // S + A'A mode: the engine's G has p more rows; they get zeros
+            KKT_HIP_CHECK(hipMemsetAsync(din + hs->cdim, 0, sizeof(double) * hs->sp_extra, st));
         if (int e = sparse_engine_product(hs->sp, which, trans, din, dout, st)) return e;
-    } else {                                       // A is kept dense by both engines
+    } else if (which == 1 && hs->A_sparse) {       // sparse A (CSR / CSC on the device)
+        if (nin == 0) KKT_HIP_CHECK(hipMemsetAsync(dout, 0, sizeof(double) * nout, st));
+        else if (!trans) { if (int e = A_mul(hs, din, dout, nullptr, st)) return e; }
+        else if (int e = A_mulT(hs, din, dout, 0.0, nullptr, st)) return e;
+    } else {
         if ((which == 0 && !hs->dG) || (which == 1 && np > 0 && !hs->dA)) { set_last_error("product: matrix not set"); return MI355KKT_EINVAL; }
         if (int e = ensure_gemv_work(hs)) return e;
         const double* M = which == 0 ? hs->dG : (which == 1 ? hs->dA : nullptr);
@@ -1336,7 +1512,7 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
         set_last_error("coneqp_lp: needs dims = {'l': m > 0}");
         return MI355KKT_ENOTIMPL;
     }
-    if (hs->p > 0 && !hs->dA) { set_last_error("coneqp_lp: A not set"); return MI355KKT_EINVAL; }
+    if (hs->p > 0 && !hs->dA && !hs->A_sparse) { set_last_error("coneqp_lp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->ml;
     const int np = hs->p;
@@ -1348,9 +1524,10 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
     if (int e = ensure_gemv_work(hs)) return e;
     double* gwork = hs->dIpmWork;
     IpmOps ops;
+    ops.check = [&]() { return loop_check_handoff(hs); };
     ops.products = [&]() -> int {
         if (hs->sparse) {
-            if (int e = sparse_engine_products(hs->sp, S.x, S.z, S.Gx, S.GTz, S.Px, st)) return e;
+            if (int e = sparse_products_cdim(hs, S.x, S.z, S.Gx, S.GTz, S.Px, st)) return e;
             return a_products(hs, S.x, S.y, S.Ax, S.ATy, gwork, st);
         }
         if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, S.x, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
@@ -1396,7 +1573,7 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
     }
     if (!hs->s.empty() || hs->cdim < 1) { set_last_error("conelp: needs dims = {'l': ml, 'q': [...]} with at least one row"); return MI355KKT_ENOTIMPL; }
     if (hs->dH) { set_last_error("conelp: the handle carries a quadratic term (H)"); return MI355KKT_EINVAL; }
-    if (hs->p > 0 && !hs->dA) { set_last_error("conelp: A not set"); return MI355KKT_EINVAL; }
+    if (hs->p > 0 && !hs->dA && !hs->A_sparse) { set_last_error("conelp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->cdim, np = hs->p;
     if (refinement < 0) refinement = hs->q.empty() ? 0 : 1;
@@ -1410,7 +1587,7 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
     // G xin -> Gx, A xin -> Ax, G' zin -> GTz, A' yin -> ATy
     auto products = [&](const double* xin, const double* yin, const double* zin) -> int {
         if (hs->sparse) {
-            if (int e = sparse_engine_products(hs->sp, xin, zin, S.Gx, S.GTz, S.x_out /* P x = 0 lands in a scratch n-vector */, st)) return e;
+            if (int e = sparse_products_cdim(hs, xin, zin, S.Gx, S.GTz, hs->dtn /* P x = 0 lands in the handle's scratch n-vector (only used inside solve()); NOT x_out: when the constructed starting point is already optimal it holds the answer (coneprog.py:752-790) */, st)) return e;
             return a_products(hs, xin, yin, S.Ax, S.ATy, gwork, st);
         }
         if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, xin, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
@@ -1469,6 +1646,11 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
         lp_launch_residual(S, it, maxiters, abstol, reltol, feastol, st);
         KKT_HIP_CHECK(hipMemcpyAsync(w.pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
         KKT_HIP_CHECK(hipStreamSynchronize(st));
+        {   // coneprog.py:984-990: pcost dcost gap pres dres k/t
+            static const int idx[5] = {LP_PCOST, LP_DCOST, LP_GAP_OUT, LP_PRES, LP_DRES};
+            if (int e = report_progress(hs, it, S.sc, LP_NSC, idx, 5, LP_TAU, LP_KAPPA)) return e;
+        }
+        if (int e = loop_check_handoff(hs)) return e;
         if (w.pinned[0] == 0) break;
         if (int e = factor(&info)) return e;
         lp_launch_singular(S, d_info, it, st);
@@ -1522,7 +1704,7 @@ int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, cons
         return MI355KKT_EINVAL;
     }
     if (!hs->s.empty() || hs->cdim < 1) { set_last_error("coneqp: needs dims = {'l': ml, 'q': [...]} with at least one row"); return MI355KKT_ENOTIMPL; }
-    if (hs->p > 0 && !hs->dA) { set_last_error("coneqp: A not set"); return MI355KKT_EINVAL; }
+    if (hs->p > 0 && !hs->dA && !hs->A_sparse) { set_last_error("coneqp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->cdim, np = hs->p;
     if (refinement < 0) refinement = hs->q.empty() ? 0 : 1;
@@ -1537,7 +1719,7 @@ int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, cons
     // P xin -> Px, G xin -> Gx, A xin -> Ax, G' zin -> GTz, A' yin -> ATy
     auto products = [&](const double* xin, const double* yin, const double* zin) -> int {
         if (hs->sparse) {
-            if (int e = sparse_engine_products(hs->sp, xin, zin, S.Gx, S.GTz, S.Px, st)) return e;
+            if (int e = sparse_products_cdim(hs, xin, zin, S.Gx, S.GTz, S.Px, st)) return e;
             return a_products(hs, xin, yin, S.Ax, S.ATy, gwork, st);
         }
         if (int e = launch_gemv_n_scaled(hs->dG, hs->ldG, m, n, nullptr, xin, S.Gx, S.Gx, 1.0, 0.0, gwork, st)) return e;
@@ -1592,6 +1774,11 @@ int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, cons
         qp_launch_residual(S, it, maxiters, abstol, reltol, feastol, st);
         KKT_HIP_CHECK(hipMemcpyAsync(w.pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
         KKT_HIP_CHECK(hipStreamSynchronize(st));
+        {   // coneprog.py:2206-2208: pcost dcost gap pres dres
+            static const int idx[5] = {QP_PCOST, QP_DCOST, QP_GAP_OUT, QP_PRES, QP_DRES};
+            if (int e = report_progress(hs, it, S.sc, QP_NSC, idx, 5, -1, -1)) return e;
+        }
+        if (int e = loop_check_handoff(hs)) return e;
         if (w.pinned[0] == 0) break;
         if (int e = factor(&info)) return e;
         if (info > 0 && it == 0) { set_last_error("coneqp: Rank(A) < p or Rank([P; A; G]) < n"); return 1; }

@@ -83,6 +83,11 @@ struct PotrfWork {
     void* d_ctl = nullptr;
     double* d_linv_all = nullptr;
     int linv_tiles = 0;
+    // inverses of the 128 x 128 diagonal blocks of the last factor produced by the tile kernel (column-major, one after the
+    // other); valid for the matrix `minv_of` of order `minv_n` (0: not available)
+    double* d_minv = nullptr;
+    int minv_n = 0;
+    const double* minv_of = nullptr;
     // look-ahead: the bulk of each trailing update runs on `side` while the next panel is factored on the main stream
     hipStream_t side = nullptr, aux = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_bulk, ev_t1, ev_usr, ev_ir;
@@ -122,8 +127,10 @@ size_t gemv_work_doubles(int m, int n);
 int launch_mirror_lower(double* A, int64_t lda, int n, hipStream_t st);
 // trans != 0 solves L' x = b and REQUIRES the mirrored upper triangle (launch_mirror_lower after the factorisation)
 // gran != nullptr: data-tagged granule hand-off (256 u64 per 128-block, zeroed once) instead of flag + fences
+// minv != nullptr: inverses of the 128 x 128 diagonal blocks (per block M then M', 2 x 16384 doubles) from the tile Cholesky
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
-                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran = nullptr);
+                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran = nullptr,
+                           const double* minv = nullptr);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);
@@ -157,7 +164,7 @@ struct SparseEngine {
     int *d_sn_first = nullptr, *d_sn_rows = nullptr, *d_child_ptr = nullptr, *d_child_list = nullptr, *d_relmap = nullptr,
         *d_level_sn = nullptr, *d_asm_a = nullptr, *d_asm_b = nullptr, *d_asm_r = nullptr, *d_perm = nullptr,
         *d_gri = nullptr, *d_gci = nullptr, *d_gnzmap = nullptr, *d_info = nullptr, *h_info = nullptr, *d_upd_ld = nullptr,
-        *d_heavy = nullptr, *d_hci = nullptr, *d_hmap = nullptr;
+        *d_heavy = nullptr, *d_hci = nullptr, *d_hmap = nullptr, *d_iperm = nullptr;
     VbDesc* d_vb = nullptr;
     PotrfWork pw_vb;
     int64_t *d_sn_rowptr = nullptr, *d_panel_off = nullptr, *d_upd_off = nullptr, *d_relmap_off = nullptr,
@@ -176,7 +183,10 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
 int sparse_engine_solve(SparseEngine& E, double* d_x, hipStream_t st);
 int sparse_engine_forward(SparseEngine& E, const double* d_in, double* d_out_perm, hipStream_t st);   // E.d_xp = L^-1 P b
 int sparse_engine_backward(SparseEngine& E, double* d_out, hipStream_t st);
-int sparse_engine_forward_rows(SparseEngine& E, const double* d_A, int64_t lda, int nrhs, double* d_out, hipStream_t st);                           // d_out = P' L^-T E.d_xp
+int sparse_engine_forward_rows(SparseEngine& E, const double* d_A, int64_t lda, int nrhs, double* d_out, hipStream_t st);
+// rows of a sparse A (CSR on the device) as right-hand sides, `chunk` at a time
+int sparse_engine_forward_rows_csr(SparseEngine& E, const int64_t* d_rp, const int* d_ci, const double* d_v, int nrhs, double* d_out,
+                                   hipStream_t st, int chunk = 256);                           // d_out = P' L^-T E.d_xp
 int sparse_engine_product(SparseEngine& E, int which, int trans, const double* d_in, double* d_out, hipStream_t st);
 int sparse_engine_products(SparseEngine& E, const double* d_x, const double* d_z, double* d_Gx, double* d_GTz, double* d_Px,
                            hipStream_t st);

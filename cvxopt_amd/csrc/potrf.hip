@@ -755,9 +755,67 @@ __device__ __forceinline__ void tile_publish(unsigned* p, unsigned value, int ti
     }
 }
 
+// M = inv(L(j,j)) for the persistent triangular solves (blas2.hip: one hop = three 128 x 128 matrix-vector products
+// instead of two 64-step substitution chains).  L(j,j) is still in the LDS image; the inverses D_i of its 16 x 16 diagonal
+// blocks are brought into the padding rows.  Block column c of M is independent of the others: wave c computes
+//     M_cc = D_c,   M_ic = -D_i * sum_{k=c}^{i-1} L_ik M_kc   (i = c+1 .. 7)
+// on the matrix cores with tiles held transposed-free: a finished block's D registers (rows lq + 4 r) are exactly the B
+// operand of the next products (k = 4 s + lq with s = r).  Off the factorisation's critical path (runs after the publish).
+__device__ __forceinline__ void tile_invert_diag(double* __restrict__ As, const double* __restrict__ linv, int mj,
+                                                 double* __restrict__ Mout, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = tid + PT_THREADS * q;                     // e = cb * 256 + k * 16 + g  ->  As[(16 cb + k) PLD + 128 + g]
+        As[(e >> 4) * PLD + NB + (e & 15)] = linv[e];
+    }
+    __syncthreads();
+    const int c = wave;                                       // my block column
+    d4 Mb[8];                                                 // Mb[i]: rows 16 i + lq + 4 r, columns 16 c + li
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (i < c) {
+            Mb[i] = d4{0.0, 0.0, 0.0, 0.0};
+        } else if (i == c) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Mb[i][r] = As[(16 * c + li) * PLD + NB + lq + 4 * r];     // D_c[lq+4r][li]
+        } else {
+            d4 t = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k >= c && k < i) {
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; ++s4) {
+                        const double lv = As[(16 * k + 4 * s4 + lq) * PLD + 16 * i + li];   // L[16i+li][16k+4s+lq]
+                        t = MFMA_F64(lv, Mb[k][s4], t);
+                    }
+                }
+            }
+            d4 m = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const double dv = -As[(16 * i + 4 * s4 + lq) * PLD + NB + li];              // -D_i[li][4s+lq]
+                m = MFMA_F64(dv, t[s4], m);
+            }
+            Mb[i] = m;
+        }
+    }
+    // column-major 128 x 128, M[row][col] at Mout[col * 128 + row]; rows / columns beyond mj come out as zeros
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = (i >= c) ? Mb[i][r] : 0.0;
+            Mout[(16 * c + li) * NB + 16 * i + lq + 4 * r] = v;                  // M, column-major
+            Mout[NB * NB + (16 * i + lq + 4 * r) * NB + 16 * c + li] = v;         // M', column-major (upper triangular)
+        }
+    (void)mj;
+}
+
 __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int n, TileCtl* ctl,
                                                                  double* __restrict__ linv_all, int* __restrict__ info,
-                                                                 int* __restrict__ err) {
+                                                                 int* __restrict__ err, double* __restrict__ minv_all) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // the control words of the workgroup live behind the potf2 image (all LDS in the dynamic region, guide G17)
     unsigned* ctlw = reinterpret_cast<unsigned*>(smem + NB * PLD + NB + 80 + 2);
@@ -835,6 +893,10 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
             PT_TS(3);
             tile_publish(&ctl->prog[j], (unsigned)j + 1, tid);
             PT_TS(4);
+            if (minv_all) {       // after the publish: nobody on the factorisation's chain waits for this
+                __syncthreads();
+                tile_invert_diag(As, linv_all + (int64_t)j * 2048, mj, minv_all + (int64_t)j * 2 * NB * NB, tid);
+            }
         } else {
             if (tid == 0) ctlw[1] = tile_wait(&ctl->prog[j], nullptr, (unsigned)j + 1, ctl, err);
             __syncthreads();
@@ -973,6 +1035,7 @@ void potrf_work_free(PotrfWork& w) {
     if (w.h_info) (void)hipHostFree(w.h_info);
     if (w.d_ctl) (void)hipFree(w.d_ctl);
     if (w.d_linv_all) (void)hipFree(w.d_linv_all);
+    if (w.d_minv) (void)hipFree(w.d_minv);
     for (auto e : w.ev_panel) (void)hipEventDestroy(e);
     for (auto e : w.ev_bulk) (void)hipEventDestroy(e);
     for (auto e : w.ev_t1) (void)hipEventDestroy(e);
@@ -991,7 +1054,11 @@ int potrf_work_reserve(PotrfWork& w, int n) {
         if (w.d_linv_all) (void)hipFree(w.d_linv_all);
         w.d_linv_all = nullptr;
         w.linv_tiles = 0;
+        w.minv_n = 0;
         KKT_HIP_CHECK(hipMalloc(&w.d_linv_all, sizeof(double) * 2048 * (size_t)NT));
+        if (w.d_minv) (void)hipFree(w.d_minv);
+        w.d_minv = nullptr;
+        KKT_HIP_CHECK(hipMalloc(&w.d_minv, sizeof(double) * 2 * NB * NB * (size_t)NT));
         w.linv_tiles = NT;
     }
     return 0;
@@ -1017,9 +1084,12 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
     KKT_HIP_CHECK(hipMemsetAsync(w.d_ctl, 0, sizeof(TileCtl), st));
     const int ntiles = NT * (NT + 1) / 2;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
+    static const bool no_minv = getenv("MI355KKT_NO_MINV") != nullptr;
     hipLaunchKernelGGL(potrf_tiles_kernel, dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n, reinterpret_cast<TileCtl*>(w.d_ctl),
-                       w.d_linv_all, w.d_info, w.d_info);
+                       w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv);
     KKT_HIP_CHECK(hipGetLastError());
+    w.minv_n = no_minv ? 0 : n;          // the 128 x 128 inverses of this factor's diagonal blocks are valid
+    w.minv_of = A;
     return 0;
 }
 
@@ -1030,6 +1100,7 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
         static const int tiles_min_n = getenv("MI355KKT_TILES_MIN_N") ? atoi(getenv("MI355KKT_TILES_MIN_N")) : 1024;
         if (nbatch == 1 && !use_streams && n >= tiles_min_n && (n + NB - 1) / NB <= 252) return launch_potrf_tiles(A, lda, n, w, st);
     }
+    w.minv_n = 0;                         // the launch chain below does not produce the 128 x 128 diagonal-block inverses
     // Outer panels of 256 columns = two 128-column sub-panels; the trailing matrix is touched once per
     // outer panel with a rank-256 update (halves the C read-modify-write traffic of a rank-128 scheme).
     auto panel = [&](int k0, int nb) -> int {   // factor diagonal block at k0 and solve the rows below it

@@ -852,6 +852,7 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     if (int e = up(&E.d_asm_b, S.asm_b)) return e;
     if (int e = up(&E.d_asm_r, S.asm_r)) return e;
     if (int e = up(&E.d_perm, S.perm)) return e;
+    if (int e = up(&E.d_iperm, S.iperm)) return e;
     if (int e = up(&E.d_heavy, S.heavy)) return e;
     if (int e = up(&E.d_vb, S.vb)) return e;
     if (int e = potrf_work_init_batched(E.pw_vb, std::max(1, S.vb_maxcount))) return e;
@@ -922,7 +923,7 @@ void sparse_engine_free(SparseEngine& E) {
     void* ptrs[] = {E.d_sn_first, E.d_sn_rowptr, E.d_sn_rows, E.d_panel_off, E.d_upd_off, E.d_child_ptr, E.d_child_list,
                     E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
-                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap, E.d_rem_multi};
+                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap, E.d_rem_multi, E.d_iperm};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
@@ -1023,6 +1024,54 @@ int sparse_engine_forward_rows(SparseEngine& E, const double* d_A, int64_t lda, 
         const int nj = std::min(65535, nrhs - j0);
         double* out = d_out + (size_t)j0 * E.n;
         hipLaunchKernelGGL(sp_gather_rows_kernel, dim3((E.n + 255) / 256, nj), dim3(256), 0, st, d_A + j0, lda, E.d_perm, E.n, out);
+        for (int l = 0; l < S.nlevels; ++l) {
+            const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
+            if (cnt > 0)
+                hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt, nj), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, out, E.d_rem_multi,
+                                   E.d_rem_off, (int64_t)E.n, remtot);
+            const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
+            if (nh > 0)
+                hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 255) / 256, nh, nj), dim3(256), 0, st, d,
+                                   E.d_heavy + S.heavy_ptr[l], E.d_panels, out, E.d_rem_multi, E.d_rem_off, (int64_t)E.n, remtot);
+        }
+    }
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+// The same for a SPARSE A (CSR on the device: row r = right-hand side r): reference misc.py:1483-1487 keeps A' sparse through
+// cholmod.spsolve (src/C/cholmod.c:583-654); here every row is scattered straight into its permuted dense right-hand side
+// (no dense copy of A anywhere) and the rows go through the level-scheduled forward substitution `chunk` at a time, so the
+// transient workspace stays bounded for any number of equality constraints.  d_out: n x nrhs, ld n.
+__global__ __launch_bounds__(256) void sp_scatter_rows_csr_kernel(const int64_t* __restrict__ rp, const int* __restrict__ ci,
+                                                                  const double* __restrict__ v, int r0, const int* __restrict__ iperm,
+                                                                  int n, double* __restrict__ out) {
+    const int j = blockIdx.x;                           // right-hand side j <- row r0 + j of A
+    double* o = out + (int64_t)j * n;
+    for (int i = threadIdx.x; i < n; i += 256) o[i] = 0.0;
+    __syncthreads();
+    const int64_t a = rp[r0 + j], b = rp[r0 + j + 1];
+    for (int64_t k = a + threadIdx.x; k < b; k += 256) o[iperm[ci[k]]] = v[k];
+}
+int sparse_engine_forward_rows_csr(SparseEngine& E, const int64_t* d_rp, const int* d_ci, const double* d_v, int nrhs, double* d_out,
+                                   hipStream_t st, int chunk) {
+    const SparseSymbolic& S = E.sym;
+    if (E.n == 0 || nrhs <= 0) return 0;
+    if (chunk <= 0) chunk = 256;
+    if (chunk > 65535) chunk = 65535;
+    const SpDev d = devview(E);
+    const int64_t remtot = S.sn_rowptr[S.ns] - (int64_t)E.n;
+    const int need = std::min(chunk, nrhs);
+    if (E.rem_multi_cols < need) {
+        if (E.d_rem_multi) (void)hipFree(E.d_rem_multi);
+        E.d_rem_multi = nullptr;
+        E.rem_multi_cols = 0;
+        KKT_HIP_CHECK(hipMalloc(&E.d_rem_multi, sizeof(double) * (size_t)(remtot > 0 ? remtot : 1) * need));
+        E.rem_multi_cols = need;
+    }
+    for (int j0 = 0; j0 < nrhs; j0 += chunk) {
+        const int nj = std::min(chunk, nrhs - j0);
+        double* out = d_out + (size_t)j0 * E.n;
+        hipLaunchKernelGGL(sp_scatter_rows_csr_kernel, dim3(nj), dim3(256), 0, st, d_rp, d_ci, d_v, j0, E.d_iperm, E.n, out);
         for (int l = 0; l < S.nlevels; ++l) {
             const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
             if (cnt > 0)

@@ -81,14 +81,33 @@ def _as_cvxopt(sol):
 
 
 def _options(kwargs):
-    """solver options as the reference reads them (kwargs['options'] over solvers.options; coneprog.py:456-500)"""
+    """solver options as the reference reads them (kwargs['options'] over solvers.options; coneprog.py:428-500, :1772-1803)"""
     from cvxopt import solvers
     o = kwargs.get('options', solvers.options)
+    kktreg = o.get('kktreg', None)
+    if kktreg is not None and (not isinstance(kktreg, (float, int)) or kktreg < 0.0):
+        raise ValueError("options['kktreg'] must be a nonnegative scalar")                 # coneprog.py:430-434
     return dict(maxiters=o.get('maxiters', 100), abstol=o.get('abstol', 1e-7), reltol=o.get('reltol', 1e-6),
-                feastol=o.get('feastol', 1e-7), refinement=o.get('refinement', None)), o.get('kktreg', None)
+                feastol=o.get('feastol', 1e-7), refinement=o.get('refinement', None), kktreg=kktreg,
+                show_progress=bool(o.get('show_progress', True))), kktreg, bool(o.get('debug', False))
 
 
-def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None, kktsolver='chol', device_loop='auto',
+def _resolve_kktsolver(kktsolver, dims, lp):
+    """None -> the reference's default (coneprog.py:458-462 / :1805-1809); strings are validated like :463-466 / :1810-1813;
+    a callable is the documented plug-in API and is handed to the reference driver untouched (returns None here)."""
+    if kktsolver is None:
+        if dims['q'] or dims['s']:
+            return 'qr' if lp else 'chol'
+        return 'chol2'
+    if isinstance(kktsolver, str):
+        valid = ('ldl', 'ldl2', 'qr', 'chol', 'chol2') if lp else ('ldl', 'ldl2', 'chol', 'chol2')
+        if kktsolver not in valid:
+            raise ValueError("'%s' is not a valid value for kktsolver" % kktsolver)
+        return kktsolver
+    return None
+
+
+def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None, kktsolver=None, device_loop='auto',
            **kwargs):
     """cvxopt.solvers.conelp on the MI355X, same signature and result dict.  Without 's' cones and with the default
     starting point the whole loop runs on the device (`mi355kkt_conelp`); otherwise the reference driver runs on the
@@ -96,13 +115,19 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
     from cvxopt import solvers, spmatrix
     dims = _dims_of(h, dims)
     n = c.size[0]
+    ks_name = _resolve_kktsolver(kktsolver, dims, lp=True)
+    if ks_name is None:                        # a user kktsolver(W): the reference driver and the user's code, nothing of ours
+        return solvers.conelp(c, G, h, dims, A=A, b=b, primalstart=primalstart, dualstart=dualstart, kktsolver=kktsolver,
+                              **kwargs)
+    if ks_name == 'chol2' and (dims['q'] or dims['s']):
+        ks_name = 'chol'
     extra = set(kwargs) - {'options'}
-    o, kktreg = _options(kwargs)
+    o, kktreg, debug = _options(kwargs)
     if device_loop and not dims['s'] and primalstart is None and dualstart is None and not extra \
-            and kktreg is None and (dims['l'] + sum(dims['q'])) > 0:
-        return _as_cvxopt(_kkt.conelp_device(c, G, h, dims, A, b, kktsolver={'qr': 'chol'}.get(kktsolver, kktsolver), **o))
+            and not debug and (dims['l'] + sum(dims['q'])) > 0:
+        return _as_cvxopt(_kkt.conelp_device(c, G, h, dims, A, b, kktsolver=ks_name, **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
-    ks = _kkt.kktsolver_lp(G, dims, Am, kind={'qr': 'chol'}.get(kktsolver, kktsolver))
+    ks = _kkt.kktsolver_lp(G, dims, Am, kind={'qr': 'chol'}.get(ks_name, ks_name), kktreg=kktreg)
     eng = ks.engine
     try:
         eng._set_H(None)                       # decides dense / sparse mode and places G in HBM
@@ -115,7 +140,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
         eng.close()
 
 
-def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktsolver='chol2', device_loop='auto',
+def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktsolver=None, device_loop='auto',
            **kwargs):
     """cvxopt.solvers.coneqp on the MI355X, same signature and result dict.  Without 's' cones and initvals the whole loop
     runs on the device (`mi355kkt_coneqp`); otherwise the reference driver runs with P, G, A as device operators."""
@@ -124,15 +149,18 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
     if G is None:
         G, h = spmatrix([], [], [], (0, n)), matrix(0.0, (0, 1))
     dims = _dims_of(h, dims)
-    if (dims['q'] or dims['s']) and kktsolver == 'chol2':
-        kktsolver = 'chol'                      # like the reference's default for non-LP cones (coneprog.py:1775-1781)
+    ks_name = _resolve_kktsolver(kktsolver, dims, lp=False)
+    if ks_name is None:                        # a user kktsolver(W): the reference driver and the user's code, nothing of ours
+        return solvers.coneqp(P, q, G, h, dims, A=A, b=b, initvals=initvals, kktsolver=kktsolver, **kwargs)
+    if (dims['q'] or dims['s']) and ks_name == 'chol2':
+        ks_name = 'chol'                        # kkt_chol2 is LP-cone only (misc.py:1381-1384); the reference's own default here
     extra = set(kwargs) - {'options'}
-    o, kktreg = _options(kwargs)
-    if device_loop and not dims['s'] and initvals is None and not extra and (dims['l'] + sum(dims['q'])) > 0 \
-            and kktreg is None:
-        return _as_cvxopt(_kkt.coneqp_device(P, q, G, h, dims, A, b, kktsolver=kktsolver, **o))
+    o, kktreg, debug = _options(kwargs)
+    if device_loop and not dims['s'] and initvals is None and not extra and not debug \
+            and (dims['l'] + sum(dims['q'])) > 0:
+        return _as_cvxopt(_kkt.coneqp_device(P, q, G, h, dims, A, b, kktsolver=ks_name, **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
-    ks = _kkt.kktsolver_qp(G, dims, Am, P, kind=kktsolver)
+    ks = _kkt.kktsolver_qp(G, dims, Am, P, kind=ks_name, kktreg=kktreg)
     eng = ks.engine
     try:
         eng._set_H(P)

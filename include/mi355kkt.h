@@ -93,6 +93,15 @@ int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA);     
  * LP cone, p = 0 only. */
 int mi355kkt_set_sparse_problem(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
                                 const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues);
+/* The same with `extra_rows` (0 or p) more rows of G below the cdim cone rows: the rows of A with unit scaling, i.e.
+ * S = H + G'D^2 G + A'A -- the reference's fallback for a singular S on the first factorisation (misc.py:1433-1447); in
+ * sparse mode the pattern of S grows, so this runs a new symbolic analysis.  The handle is in singular mode afterwards. */
+int mi355kkt_set_sparse_problem_aug(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
+                                    const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues, int extra_rows);
+/* A (p x n) in CSR (rowptr[p+1], colind[nnz], values[nnz]) for the sparse engine: kept sparse on the device (CSR + its
+ * transpose); the Schur complement K = A S^-1 A' (misc.py:1464-1487, cholmod.spsolve src/C/cholmod.c:583-654) is formed from
+ * sparse right-hand sides, 256 rows of A per pass of the supernodal forward solve.  No dense copy of A exists. */
+int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr, const int64_t* colind, const double* values);
 int mi355kkt_sparse_stats(const mi355kkt_solver* h, int64_t* nnzL, int* nsupernodes, int* nlevels, double* flops);
 /* the fill-reducing ordering chosen by the symbolic analysis (csrc/ordering.cpp): 1 nested dissection, 2 approximate
  * minimum degree; MI355KKT_EINVAL when the handle is not in sparse mode */
@@ -114,6 +123,11 @@ int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH)
 /* diagonal regularisation of kkt_ldl (reference misc.py:1095-1098): K[x,x] += reg, K[y,y] -= reg,
  * K[z,z] = -1 - reg.  0 disables it. */
 int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg);
+/* options['show_progress'] of the reference drivers (coneprog.py:2161-2208, :984-990) for the device-resident loops
+ * mi355kkt_conelp / mi355kkt_coneqp: fn is called once per iteration, right after the stopping test, with
+ * values = pcost, dcost, gap, pres, dres [, kappa/tau for conelp]; NULL switches it off (the default). */
+typedef void (*mi355kkt_progress_fn)(int iteration, int nvalues, const double* values, void* user);
+int mi355kkt_set_progress(mi355kkt_solver* h, mi355kkt_progress_fn fn, void* user);
 
 /* factor(W, H): NT scaling + assembly + Cholesky/LDL' on the device.  `W` holds HOST pointers.
  * Returns 0, or info > 0 when a pivot is not positive (=> ArithmeticError(info)). */
