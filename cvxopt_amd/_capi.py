@@ -7,7 +7,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmi355kkt.so")
+# $CVXOPT_AMD_LIB: an alternative build of the SAME library (tools/asan_host.sh: host AddressSanitizer / UBSan build)
+LIB_PATH = os.environ.get("CVXOPT_AMD_LIB") or os.path.join(_HERE, "libmi355kkt.so")
 
 EINVAL, EHIP, ENOMEM, ENOTIMPL = -1, -2, -3, -4
 CHOL2, CHOL, LDL, LDL2 = 0, 1, 2, 3

@@ -633,9 +633,12 @@ struct TileCtl {
 // 8 waves: wave w owns rows 16 w .. 16 w + 15 and ALL 128 columns: acc[t] = 16-column block t in the transposed MFMA
 // layout (lane (li, lq), register r <-> row 16 w + li, column 16 t + lq + 4 r) -- exactly the layout the triangular
 // solve of the finished tile works in, so an off-diagonal tile never leaves its registers.
+// rt = the 16-row block of the tile this wave owns: its own index, except on DIAGONAL tiles, where row block r needs only
+// the r + 1 column blocks left of / on the diagonal: waves w and w + 4 share a SIMD, so they take row blocks w and 7 - w
+// (9 MFMA tiles per SIMD instead of up to 12).
 template <bool diag>
 __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __restrict__ Xi, const double* __restrict__ Xj,
-                                                int64_t lda, int K, int mi, int mj, double* __restrict__ smem, int tid) {
+                                                int64_t lda, int K, int mi, int mj, double* __restrict__ smem, int tid, int rt) {
     constexpr int PF = 2;                                     // k-steps of operands in flight (global -> registers)
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -694,7 +697,7 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
             const int kt = kt0 + u;
             if (kt + PF < nkt) fetch(kt + PF, rJ[u], rI[u]);  // slot u held step kt, which went to LDS one step ago
             const double* __restrict__ Js = sJ(u & 1);
-            const double* __restrict__ Is = sI(u & 1) + wave * 16;
+            const double* __restrict__ Is = sI(u & 1) + rt * 16;
             if (!diag) {                                      // branch-free body for the common case
 #pragma unroll
                 for (int kk = 0; kk < BK; kk += 4) {
@@ -711,7 +714,7 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
                     const double bv = Is[li + (kk + lq) * LDT_M];
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
-                        if (t <= wave) {
+                        if (t <= rt) {
                             const double av = Js[(t * 16 + li) + (kk + lq) * LDT_M];
                             acc[t] = MFMA_F64(av, bv, acc[t]);
                         }
@@ -846,7 +849,8 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
         long long* tts = g_tile_ts;
         PT_TS(0);
         // ---- the tile itself -> accumulators (its loads fly while the first operands are fetched)
-        const int row = wave * 16 + li;                       // my row of the tile
+        const int rt = (diag && wave >= 4) ? 11 - wave : wave; // my 16-row block (see tile_accumulate)
+        const int row = rt * 16 + li;                         // my row of the tile
         d4 acc[8];
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt)
@@ -868,10 +872,10 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
             if ((int)ka == j && kdone == j - 1) PT_TS(5);     // exactly the last missing column has arrived
             if (diag)
                 tile_accumulate<true>(acc, A + i0 + (int64_t)kdone * NB * lda, A + j0 + (int64_t)kdone * NB * lda, lda,
-                                      ((int)ka - kdone) * NB, mi, mj, smem, tid);
+                                      ((int)ka - kdone) * NB, mi, mj, smem, tid, rt);
             else
                 tile_accumulate<false>(acc, A + i0 + (int64_t)kdone * NB * lda, A + j0 + (int64_t)kdone * NB * lda, lda,
-                                       ((int)ka - kdone) * NB, mi, mj, smem, tid);
+                                       ((int)ka - kdone) * NB, mi, mj, smem, tid, rt);
             kdone = (int)ka;                                  // (tile_accumulate ends with a barrier: ctlw[1] is free again)
         }
         PT_TS(1);
@@ -936,15 +940,18 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
             //      as trsm_panel_kernel), operands from LDS
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
-                d4 a4 = acc[cb];
+                d4 a4 = acc[cb], a5 = d4{0.0, 0.0, 0.0, 0.0};     // two chains: the matrix pipe is not left waiting on one accumulator
 #pragma unroll
                 for (int c = 0; c < cb; ++c) {
 #pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) {
-                        const double lv = As[(16 * c + 4 * s4 + lq) * PLD + 16 * cb + li];
-                        a4 = MFMA_F64(-lv, acc[c][s4], a4);
+                    for (int s4 = 0; s4 < 4; s4 += 2) {
+                        const double lv0 = As[(16 * c + 4 * s4 + lq) * PLD + 16 * cb + li];
+                        const double lv1 = As[(16 * c + 4 * (s4 + 1) + lq) * PLD + 16 * cb + li];
+                        a4 = MFMA_F64(-lv0, acc[c][s4], a4);
+                        a5 = MFMA_F64(-lv1, acc[c][s4 + 1], a5);
                     }
                 }
+                if (cb > 0) a4 += a5;
                 double mi4[4], ld4[4];
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
