@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
         stash(0);
     }
     __syncthreads();
-    const int skip = g_syrk_skip;
+    const int skip = g_syrk_skip & 15;
+    const bool no_prio = (g_syrk_skip >> 4) & 1;
     if (tile_fast && ((it.k1 - it.k0) % BK) == 0 && !skip) {
         // ---- software-pipelined main loop (interior tiles): the 8 global loads of tile kt+1 are issued one
         //      after every second MFMA quad of the first half, the 8 {scale, ds_write} units that stage it into
@@ -160,6 +161,10 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
         }
         const double* dp = di ? di + it.k0 + sk + BK : nullptr;
         const int li = lane & 15, lk = lane >> 4;
+        // static priority for the second-dispatched half of the workgroup (guide T5 / MICROARCH "static priority for the younger
+        // half"): one s_setprio for the whole main loop, no per-phase flips.  Measured on the n = 8192, m = 16384 SYRK:
+        // 17.20 -> 16.97 ms (all waves at priority 1, or alternate workgroups: no gain).  g_syrk_skip bit 4 switches it off.
+        if (!no_prio && wave >= 2) __builtin_amdgcn_s_setprio(1);
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             const bool has_next = kt + 1 < nkt;

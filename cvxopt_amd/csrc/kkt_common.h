@@ -107,6 +107,12 @@ int launch_potrf_partial(double* F, int64_t ld, int h, int ncols, PotrfWork& w, 
 // w.d_info / w.d_dinv must hold nfronts ints / nfronts*2048 doubles; info[z] = global column + 1 of a failing pivot
 int launch_potrf_partial_vb(double* base, const VbDesc* d_desc, int nfronts, int maxh, int maxw, PotrfWork& w, hipStream_t st);
 int launch_syrk_nt_update_vb(double* base, const VbDesc* d_desc, int nfronts, int k0, int maxh, hipStream_t st);
+// one persistent launch for all big fronts of a level: tickets = 4 ints (front, i, j, 0) in the order (j, front, i); prog_off /
+// linv_off: per front offsets into the level's progress words / 2048-double inverse blocks
+int launch_potrf_tiles_vb(double* base, const VbDesc* d_desc, int nfronts, const void* d_tickets, int ntickets,
+                          const int* d_prog_off, const int* d_linv_off, void* d_ctl, unsigned* d_prog, int nprog, double* d_linv,
+                          int* d_info, hipStream_t st);
+size_t potrf_tile_ctl_bytes();
 // nbatch matrices `bstride` doubles apart; w.d_info / w.d_dinv must hold nbatch ints / nbatch*2048 doubles
 int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st);
 int potrf_work_init_batched(PotrfWork& w, int nbatch);
@@ -151,6 +157,9 @@ struct SparseSymbolic {
     std::vector<char> big;
     std::vector<VbDesc> vb;                       // big fronts, level by level (same order as level_sn's big part)
     std::vector<int> vb_ptr, vb_maxh, vb_maxw;    // per level
+    // persistent tile kernel over the big fronts of a level: tickets (front, i, j, 0), per level ranges, per front offsets
+    std::vector<int> tv_tickets, tv_ptr, tv_prog_off, tv_linv_off, tv_nprog;
+    int tv_prog_max = 0, tv_linv_max = 0;
     int vb_maxcount = 0;
     std::vector<int> heavy, heavy_ptr, heavy_maxhu, heavy_maxw;   // per level: supernodes with large off-diagonal panels
     int64_t store_doubles = 0;
@@ -166,6 +175,10 @@ struct SparseEngine {
         *d_gri = nullptr, *d_gci = nullptr, *d_gnzmap = nullptr, *d_info = nullptr, *h_info = nullptr, *d_upd_ld = nullptr,
         *d_heavy = nullptr, *d_hci = nullptr, *d_hmap = nullptr, *d_iperm = nullptr;
     VbDesc* d_vb = nullptr;
+    int *d_tv_tickets = nullptr, *d_tv_prog_off = nullptr, *d_tv_linv_off = nullptr;
+    unsigned* d_tv_prog = nullptr;
+    void* d_tv_ctl = nullptr;
+    double* d_tv_linv = nullptr;
     PotrfWork pw_vb;
     int64_t *d_sn_rowptr = nullptr, *d_panel_off = nullptr, *d_upd_off = nullptr, *d_relmap_off = nullptr,
             *d_asm_slot = nullptr, *d_asm_ptr = nullptr, *d_gcp = nullptr, *d_grp = nullptr, *d_rem_off = nullptr,

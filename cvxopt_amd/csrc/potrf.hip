@@ -636,23 +636,38 @@ struct TileCtl {
 // rt = the 16-row block of the tile this wave owns: its own index, except on DIAGONAL tiles, where row block r needs only
 // the r + 1 column blocks left of / on the diagonal: waves w and w + 4 share a SIMD, so they take row blocks w and 7 - w
 // (9 MFMA tiles per SIMD instead of up to 12).
-template <bool diag>
+constexpr int TILE_PF = 2;
+// TAIL: K need not be a multiple of TILE_PF * BK (the ragged last factored tile of a frontal matrix); the dense factorisation always
+// runs the TAIL = false instance, whose inner loop carries no extra checks.
+template <bool diag, bool TAIL>
 __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __restrict__ Xi, const double* __restrict__ Xj,
                                                 int64_t lda, int K, int mi, int mj, double* __restrict__ smem, int tid, int rt) {
-    constexpr int PF = 2;                                     // k-steps of operands in flight (global -> registers)
+    constexpr int PF = TILE_PF;                               // k-steps of operands in flight (global -> registers)
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int ip = (tid & 63) * 2, kq = tid >> 6;            // staging: index pair, k = kq + 8 r
     auto sJ = [&](int s_) -> double* { return smem + s_ * 2 * STAGE_DOUBLES; };
     auto sI = [&](int s_) -> double* { return smem + s_ * 2 * STAGE_DOUBLES + STAGE_DOUBLES; };
-    const int nkt = K / BK;                                   // K is a multiple of 128: nkt is a multiple of 8
+    const int nkt = (K + BK - 1) / BK;                        // dense potrf: K is a multiple of 128; fronts: any K > 0
     double rJ[PF][4], rI[PF][4];
     const bool fullJ = (mj == 128), fullI = (mi == 128);
     auto fetch = [&](int kt, double (&J)[4], double (&I)[4]) {
+        const bool ktail = TAIL && (kt + 1) * BK > K;         // last step of a ragged k range: rows k >= K read as zero
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int64_t k = (int64_t)kt * BK + kq + 8 * r;
             const double* pj = Xj + k * lda + ip;
+            if (ktail) {
+                const bool kin = k < K;
+                J[2 * r] = (kin && ip < mj) ? pj[0] : 0.0;
+                J[2 * r + 1] = (kin && ip + 1 < mj) ? pj[1] : 0.0;
+                if (!diag) {
+                    const double* pi = Xi + k * lda + ip;
+                    I[2 * r] = (kin && ip < mi) ? pi[0] : 0.0;
+                    I[2 * r + 1] = (kin && ip + 1 < mi) ? pi[1] : 0.0;
+                }
+                continue;
+            }
             if (fullJ) {
                 const d2u_ v = *reinterpret_cast<const d2u_*>(pj);
                 J[2 * r] = v.x;
@@ -688,13 +703,15 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
     // Operands that were written a moment ago by another compute unit come from HBM / the other XCD's write-back (2-3 us):
     // with one step of look-ahead every 16-deep step of the chain-critical last column waits for them; PF steps are in flight.
 #pragma unroll
-    for (int q = 0; q < PF; ++q) fetch(q, rJ[q], rI[q]);      // nkt >= 8
+    for (int q = 0; q < PF; ++q)
+        if (!TAIL || q < nkt) fetch(q, rJ[q], rI[q]);         // (TAIL = false: K is a multiple of 128, nkt >= 8)
     stash(0, rJ[0], rI[0]);
     __syncthreads();
     for (int kt0 = 0; kt0 < nkt; kt0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             const int kt = kt0 + u;
+            if (TAIL && kt >= nkt) break;                     // (uniform) odd number of steps
             if (kt + PF < nkt) fetch(kt + PF, rJ[u], rI[u]);  // slot u held step kt, which went to LDS one step ago
             const double* __restrict__ Js = sJ(u & 1);
             const double* __restrict__ Is = sI(u & 1) + rt * 16;
@@ -816,6 +833,201 @@ __device__ __forceinline__ void tile_invert_diag(double* __restrict__ As, const 
     (void)mj;
 }
 
+// One tile of a left-looking tiled (partial) Cholesky, shared by the dense kernel and the batched-fronts kernel.
+struct TileJob {
+    double* A;               // the matrix (dense S, or one frontal matrix), column-major
+    int64_t lda;
+    int i0, j0, mi, mj;      // tile origin and extent (<= 128 each)
+    bool diag;
+    int nk;                  // number of factored tile columns left of the tile to accumulate over
+    int q, w;                // k-tile boundaries: column 128 kt for kt <= q, w beyond (fronts: ragged last factored tile)
+    bool factored;           // true: the tile belongs to the factored columns (potf2 / trsm + publish); false: Schur part, store
+    unsigned* prog_i;        // progress word of the tile's block row (published to when factored)
+    unsigned* prog_j;        // progress word of block row j (the tile's column index); == prog_i on diagonal tiles
+    unsigned pub;            // value published / waited for once column j is final: j + 1
+    double* linv;            // 2048 doubles: inverses of the 16 x 16 diagonal blocks of L(j,j)
+    double* minv;            // dense only: 2 x 128 x 128 inverse of L(j,j) for the triangular solves, or nullptr
+    int* info;               // failing pivot -> *info = info_base + column (1-based inside the tile)
+    int info_base;
+    bool abort_on_fail;      // dense: a non-positive pivot ends the factorisation; fronts: the column is published anyway so
+                             // that the front's other tiles run to completion (on garbage) instead of waiting for it
+};
+__device__ __forceinline__ int tile_kcol(const TileJob& J, int kt) { return kt <= J.q ? kt * NB : J.w; }
+
+// returns false when the workgroup has to leave the kernel (abort / timeout).  VB: batched fronts (ragged k ranges possible)
+template <bool VB>
+__device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int* err, double* __restrict__ smem,
+                                             unsigned* ctlw, int tid, unsigned t, long long* tts) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lq = lane >> 4;
+    double* As = smem;
+    double* const A = J.A;
+    const int64_t lda = J.lda;
+    const int i0 = J.i0, j0 = J.j0, mi = J.mi, mj = J.mj;
+    const bool diag = J.diag;
+    PT_TS(0);
+    // ---- the tile itself -> accumulators (its loads fly while the first operands are fetched)
+    const int rt = (diag && wave >= 4) ? 11 - wave : wave; // my 16-row block (see tile_accumulate)
+    const int row = rt * 16 + li;                         // my row of the tile
+    d4 acc[8];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int col = tt * 16 + lq + 4 * r;
+            acc[tt][r] = (row < mi && col < mj && (!diag || row >= col)) ? A[i0 + row + (int64_t)(j0 + col) * lda] : 0.0;
+        }
+    // ---- left-looking accumulation over the columns that are final, as they become final
+    int kdone = 0;
+    while (kdone < J.nk) {
+        if (tid == 0) {
+            const unsigned v = tile_wait(J.prog_i, diag ? nullptr : J.prog_j, (unsigned)kdone + 1, ctl, err);
+            ctlw[1] = (v == 0xffffffffu) ? v : (v < (unsigned)J.nk ? v : (unsigned)J.nk);
+        }
+        __syncthreads();
+        const unsigned ka = ctlw[1];
+        if (ka == 0xffffffffu) return false;
+        if ((int)ka == J.nk && kdone == J.nk - 1) PT_TS(5);   // exactly the last missing column has arrived
+        const int c0 = tile_kcol(J, kdone), c1 = tile_kcol(J, (int)ka);
+        if (VB && ((c1 - c0) & (TILE_PF * BK - 1))) {         // k range that is not a whole number of unrolled steps (fronts only)
+            if (diag)
+                tile_accumulate<true, true>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
+            else
+                tile_accumulate<false, true>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
+        } else if (diag)
+            tile_accumulate<true, false>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
+        else
+            tile_accumulate<false, false>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
+        kdone = (int)ka;                                  // (tile_accumulate ends with a barrier: ctlw[1] is free again)
+    }
+    PT_TS(1);
+    if (!J.factored) {
+        // ---- Schur-complement tile of a frontal matrix: the update is complete, back to memory (lower part on the diagonal)
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = tt * 16 + lq + 4 * r;
+                if (row < mi && col < mj && (!diag || row >= col)) A[i0 + row + (int64_t)(j0 + col) * lda] = acc[tt][r];
+            }
+        return true;
+    }
+    if (diag) {
+        // ---- accumulators -> LDS image of the tile (column-major, leading dimension PLD), then the look-ahead potf2
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) As[(tt * 16 + lq + 4 * r) * PLD + row] = acc[tt][r];
+        const int failed = potf2_la_body<true>(A + j0 + (int64_t)j0 * lda, lda, mj, J.linv, smem, nullptr);
+        if (failed) {
+            if (tid == 0) atomicCAS(J.info, 0, J.info_base + failed);
+            if (J.abort_on_fail) {
+                if (tid == 0) __hip_atomic_store(&ctl->abort_flag, 1u, RLX_AGENT_);
+                return false;
+            }
+            tile_publish(J.prog_i, J.pub, tid);
+            return true;
+        }
+        PT_TS(3);
+        tile_publish(J.prog_i, J.pub, tid);
+        PT_TS(4);
+        if (J.minv) {             // after the publish: nobody on the factorisation's chain waits for this
+            __syncthreads();
+            tile_invert_diag(As, J.linv, mj, J.minv, tid);
+        }
+        return true;
+    }
+    if (tid == 0) ctlw[1] = tile_wait(J.prog_j, nullptr, J.pub, ctl, err);
+    __syncthreads();
+    if (ctlw[1] == 0xffffffffu) return false;
+    PT_TS(2);
+    // ---- L(j,j) (tiles on / below the diagonal) and the inverses of its 16 x 16 diagonal blocks -> LDS, once for
+    //      the eight waves: one coalesced sweep instead of strided global loads in front of every MFMA group.  The
+    //      inverses ride in the 16 padding rows of the image: element (block cb, column k, row g) at As[(16cb+k) PLD + 128 + g].
+    {
+        const double* __restrict__ Lg = A + j0 + (int64_t)j0 * lda;
+        const double* __restrict__ linv = J.linv;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {        // two passes: 18 values in flight per thread (register budget)
+            double v[18];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = tid + PT_THREADS * (16 * half + q);
+                const int r = e & (NB - 1), c = e >> 7;
+                v[q] = (r >= (c & ~15) && r < mj && c < mj) ? Lg[r + (int64_t)c * lda] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) v[16 + q] = linv[tid + PT_THREADS * (2 * half + q)];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int e = tid + PT_THREADS * (16 * half + q);
+                As[(e >> 7) * PLD + (e & (NB - 1))] = v[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = tid + PT_THREADS * (2 * half + q);     // e = cb * 256 + k * 16 + g
+                As[(e >> 4) * PLD + NB + (e & 15)] = v[16 + q];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- X L(j,j)' = B on the accumulators (transposed tiles, diagonal blocks by inverse + one refinement step,
+    //      as trsm_panel_kernel), operands from LDS
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+        d4 a4 = acc[cb], a5 = d4{0.0, 0.0, 0.0, 0.0};     // two chains: the matrix pipe is not left waiting on one accumulator
+#pragma unroll
+        for (int c = 0; c < cb; ++c) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4 += 2) {
+                const double lv0 = As[(16 * c + 4 * s4 + lq) * PLD + 16 * cb + li];
+                const double lv1 = As[(16 * c + 4 * (s4 + 1) + lq) * PLD + 16 * cb + li];
+                a4 = MFMA_F64(-lv0, acc[c][s4], a4);
+                a5 = MFMA_F64(-lv1, acc[c][s4 + 1], a5);
+            }
+        }
+        if (cb > 0) a4 += a5;
+        double mi4[4], ld4[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            mi4[s4] = As[(16 * cb + 4 * s4 + lq) * PLD + NB + li];
+            const double lv = As[(16 * cb + 4 * s4 + lq) * PLD + 16 * cb + li];
+            ld4[s4] = (4 * s4 + lq <= li) ? -lv : 0.0;
+        }
+        d4 x0 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) x0 = MFMA_F64(mi4[s4], a4[s4], x0);
+        d4 e4 = a4;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) e4 = MFMA_F64(ld4[s4], x0[s4], e4);
+        d4 xx = x0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) xx = MFMA_F64(mi4[s4], e4[s4], xx);
+        acc[cb] = xx;
+        __builtin_amdgcn_sched_barrier(0);            // operand reads run ahead inside one column block only (register budget)
+    }
+    // (stores after the branch-free solve: the compiler can then run the LDS operand reads ahead of the MFMAs)
+    if (mi == NB && mj == NB) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[i0 + row + (int64_t)(j0 + 16 * cb + lq + 4 * r) * lda] = acc[cb][r];
+    } else if (row < mi) {
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = 16 * cb + lq + 4 * r;
+                if (col < mj) A[i0 + row + (int64_t)(j0 + col) * lda] = acc[cb][r];
+            }
+    }
+    PT_TS(3);
+    tile_publish(J.prog_i, J.pub, tid);
+    PT_TS(4);
+    return true;
+}
+
 __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int n, TileCtl* ctl,
                                                                  double* __restrict__ linv_all, int* __restrict__ info,
                                                                  int* __restrict__ err, double* __restrict__ minv_all) {
@@ -824,14 +1036,11 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
     unsigned* ctlw = reinterpret_cast<unsigned*>(smem + NB * PLD + NB + 80 + 2);
     const int NT = (n + NB - 1) / NB;
     const unsigned ntiles = (unsigned)NT * (NT + 1) / 2;
-    double* As = smem;
     for (;;) {
         // the thread index is made opaque once per tile: otherwise every per-thread address (column * lda products of the
         // loads / stores below) is hoisted out of the tile loop and lives in spilled registers
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        const int li = lane & 15, lq = lane >> 4;
         if (tid == 0) ctlw[0] = __hip_atomic_fetch_add(&ctl->ticket, 1u, RLX_AGENT_);
         __syncthreads();
         const unsigned t = ctlw[0];
@@ -843,154 +1052,73 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
             ++j;
         }
         const int i = j + rem;
-        const int i0 = i * NB, j0 = j * NB;
-        const int mi = min(NB, n - i0), mj = min(NB, n - j0);
-        const bool diag = (i == j);
-        long long* tts = g_tile_ts;
-        PT_TS(0);
-        // ---- the tile itself -> accumulators (its loads fly while the first operands are fetched)
-        const int rt = (diag && wave >= 4) ? 11 - wave : wave; // my 16-row block (see tile_accumulate)
-        const int row = rt * 16 + li;                         // my row of the tile
-        d4 acc[8];
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = tt * 16 + lq + 4 * r;
-                acc[tt][r] = (row < mi && col < mj && (!diag || row >= col)) ? A[i0 + row + (int64_t)(j0 + col) * lda] : 0.0;
-            }
-        // ---- left-looking accumulation over the columns that are final, as they become final
-        int kdone = 0;
-        while (kdone < j) {
-            if (tid == 0) {
-                const unsigned v = tile_wait(&ctl->prog[i], diag ? nullptr : &ctl->prog[j], (unsigned)kdone + 1, ctl, err);
-                ctlw[1] = (v == 0xffffffffu) ? v : (v < (unsigned)j ? v : (unsigned)j);
-            }
-            __syncthreads();
-            const unsigned ka = ctlw[1];
-            if (ka == 0xffffffffu) return;
-            if ((int)ka == j && kdone == j - 1) PT_TS(5);     // exactly the last missing column has arrived
-            if (diag)
-                tile_accumulate<true>(acc, A + i0 + (int64_t)kdone * NB * lda, A + j0 + (int64_t)kdone * NB * lda, lda,
-                                      ((int)ka - kdone) * NB, mi, mj, smem, tid, rt);
-            else
-                tile_accumulate<false>(acc, A + i0 + (int64_t)kdone * NB * lda, A + j0 + (int64_t)kdone * NB * lda, lda,
-                                       ((int)ka - kdone) * NB, mi, mj, smem, tid, rt);
-            kdone = (int)ka;                                  // (tile_accumulate ends with a barrier: ctlw[1] is free again)
-        }
-        PT_TS(1);
-        if (diag) {
-            // ---- accumulators -> LDS image of the tile (column-major, leading dimension PLD), then the look-ahead potf2
-            __syncthreads();
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) As[(tt * 16 + lq + 4 * r) * PLD + row] = acc[tt][r];
-            const int failed = potf2_la_body<true>(A + j0 + (int64_t)j0 * lda, lda, mj, linv_all + (int64_t)j * 2048, smem, nullptr);
-            if (failed) {
-                if (tid == 0) {
-                    *info = j0 + failed;
-                    __hip_atomic_store(&ctl->abort_flag, 1u, RLX_AGENT_);
-                }
-                return;
-            }
-            PT_TS(3);
-            tile_publish(&ctl->prog[j], (unsigned)j + 1, tid);
-            PT_TS(4);
-            if (minv_all) {       // after the publish: nobody on the factorisation's chain waits for this
-                __syncthreads();
-                tile_invert_diag(As, linv_all + (int64_t)j * 2048, mj, minv_all + (int64_t)j * 2 * NB * NB, tid);
-            }
-        } else {
-            if (tid == 0) ctlw[1] = tile_wait(&ctl->prog[j], nullptr, (unsigned)j + 1, ctl, err);
-            __syncthreads();
-            if (ctlw[1] == 0xffffffffu) return;
-            PT_TS(2);
-            // ---- L(j,j) (tiles on / below the diagonal) and the inverses of its 16 x 16 diagonal blocks -> LDS, once for
-            //      the eight waves: one coalesced sweep instead of strided global loads in front of every MFMA group.  The
-            //      inverses ride in the 16 padding rows of the image: element (block cb, column k, row g) at As[(16cb+k) PLD + 128 + g].
-            {
-                const double* __restrict__ Lg = A + j0 + (int64_t)j0 * lda;
-                const double* __restrict__ linv = linv_all + (int64_t)j * 2048;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {        // two passes: 18 values in flight per thread (register budget)
-                    double v[18];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int e = tid + PT_THREADS * (16 * half + q);
-                        const int r = e & (NB - 1), c = e >> 7;
-                        v[q] = (r >= (c & ~15) && r < mj && c < mj) ? Lg[r + (int64_t)c * lda] : 0.0;
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) v[16 + q] = linv[tid + PT_THREADS * (2 * half + q)];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int e = tid + PT_THREADS * (16 * half + q);
-                        As[(e >> 7) * PLD + (e & (NB - 1))] = v[q];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int e = tid + PT_THREADS * (2 * half + q);     // e = cb * 256 + k * 16 + g
-                        As[(e >> 4) * PLD + NB + (e & 15)] = v[16 + q];
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- X L(j,j)' = B on the accumulators (transposed tiles, diagonal blocks by inverse + one refinement step,
-            //      as trsm_panel_kernel), operands from LDS
-#pragma unroll
-            for (int cb = 0; cb < 8; ++cb) {
-                d4 a4 = acc[cb], a5 = d4{0.0, 0.0, 0.0, 0.0};     // two chains: the matrix pipe is not left waiting on one accumulator
-#pragma unroll
-                for (int c = 0; c < cb; ++c) {
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; s4 += 2) {
-                        const double lv0 = As[(16 * c + 4 * s4 + lq) * PLD + 16 * cb + li];
-                        const double lv1 = As[(16 * c + 4 * (s4 + 1) + lq) * PLD + 16 * cb + li];
-                        a4 = MFMA_F64(-lv0, acc[c][s4], a4);
-                        a5 = MFMA_F64(-lv1, acc[c][s4 + 1], a5);
-                    }
-                }
-                if (cb > 0) a4 += a5;
-                double mi4[4], ld4[4];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    mi4[s4] = As[(16 * cb + 4 * s4 + lq) * PLD + NB + li];
-                    const double lv = As[(16 * cb + 4 * s4 + lq) * PLD + 16 * cb + li];
-                    ld4[s4] = (4 * s4 + lq <= li) ? -lv : 0.0;
-                }
-                d4 x0 = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) x0 = MFMA_F64(mi4[s4], a4[s4], x0);
-                d4 e4 = a4;
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) e4 = MFMA_F64(ld4[s4], x0[s4], e4);
-                d4 xx = x0;
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) xx = MFMA_F64(mi4[s4], e4[s4], xx);
-                acc[cb] = xx;
-                __builtin_amdgcn_sched_barrier(0);            // operand reads run ahead inside one column block only (register budget)
-            }
-            // (stores after the branch-free solve: the compiler can then run the LDS operand reads ahead of the MFMAs)
-            if (mi == NB && mj == NB) {
-#pragma unroll
-                for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) A[i0 + row + (int64_t)(j0 + 16 * cb + lq + 4 * r) * lda] = acc[cb][r];
-            } else if (row < mi) {
-#pragma unroll
-                for (int cb = 0; cb < 8; ++cb)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int col = 16 * cb + lq + 4 * r;
-                        if (col < mj) A[i0 + row + (int64_t)(j0 + col) * lda] = acc[cb][r];
-                    }
-            }
-            PT_TS(3);
-            tile_publish(&ctl->prog[i], (unsigned)j + 1, tid);
-            PT_TS(4);
-        }
+        TileJob J;
+        J.A = A; J.lda = lda;
+        J.i0 = i * NB; J.j0 = j * NB;
+        J.mi = min(NB, n - J.i0); J.mj = min(NB, n - J.j0);
+        J.diag = (i == j);
+        J.nk = j; J.q = 0x3fffffff; J.w = 0;
+        J.factored = true;
+        J.prog_i = &ctl->prog[i]; J.prog_j = &ctl->prog[j];
+        J.pub = (unsigned)j + 1;
+        J.linv = linv_all + (int64_t)j * 2048;
+        J.minv = minv_all ? minv_all + (int64_t)j * 2 * NB * NB : nullptr;
+        J.info = info; J.info_base = J.j0;
+        J.abort_on_fail = true;
+        if (!tile_process<false>(J, ctl, err, smem, ctlw, tid, t, g_tile_ts)) return;
         __syncthreads();                                      // LDS (image, control words) is reused by the next tile
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// potrf_tiles_vb_kernel: the same machine for ALL big frontal matrices of one level of the supernodal tree in one launch
+// (sparse engine; replaces, per level, a potf2 / trsm / update launch triple for every 128 columns of the widest front).
+// A front is h x h with its first w columns to eliminate: tile boundaries at 0, 128, .., 128 q, w, w + 128, .. (the last
+// factored tile is as narrow as it has to be, the Schur part starts on its own tile boundary), tiles (i, j) of all fronts
+// are handed out by ticket in the order (j, front, i) prepared by the symbolic analysis, so every front's chain starts at
+// once.  Tiles left of w are finalised and published exactly as in the dense kernel; tiles of the Schur complement just
+// receive the left-looking update and go back to memory.  A non-positive pivot is recorded for its front
+// (info[front] = permuted column + 1) and releases that front's waiters; the other fronts are unaffected.
+// ---------------------------------------------------------------------------------------------------
+struct VbTicket { int front, i, j, pad; };
+__global__ __launch_bounds__(PT_THREADS) void potrf_tiles_vb_kernel(double* __restrict__ base, const VbDesc* __restrict__ desc,
+                                                                    const VbTicket* __restrict__ tickets, unsigned ntickets,
+                                                                    const int* __restrict__ prog_off, const int* __restrict__ linv_off,
+                                                                    TileCtl* ctl, unsigned* __restrict__ prog,
+                                                                    double* __restrict__ linv_all, int* __restrict__ info,
+                                                                    int* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    unsigned* ctlw = reinterpret_cast<unsigned*>(smem + NB * PLD + NB + 80 + 2);
+    for (;;) {
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (tid == 0) ctlw[0] = __hip_atomic_fetch_add(&ctl->ticket, 1u, RLX_AGENT_);
+        __syncthreads();
+        const unsigned t = ctlw[0];
+        __syncthreads();
+        if (t >= ntickets) return;
+        const VbTicket tk = tickets[t];
+        const VbDesc dd = desc[tk.front];
+        const int q = dd.w / NB, wr = dd.w - q * NB, ntf = q + (wr > 0 ? 1 : 0);
+        auto origin = [&](int tt) { return tt < q ? tt * NB : (tt < ntf ? q * NB : dd.w + (tt - ntf) * NB); };
+        auto extent = [&](int tt) { return tt < q ? NB : (tt < ntf ? wr : min(NB, dd.h - (dd.w + (tt - ntf) * NB))); };
+        unsigned* fprog = prog + prog_off[tk.front];
+        TileJob J;
+        J.A = base + dd.off; J.lda = dd.h;
+        J.i0 = origin(tk.i); J.j0 = origin(tk.j);
+        J.mi = extent(tk.i); J.mj = extent(tk.j);
+        J.diag = (tk.i == tk.j);
+        J.factored = tk.j < ntf;
+        J.nk = J.factored ? tk.j : ntf;
+        J.q = q; J.w = dd.w;
+        J.prog_i = fprog + tk.i; J.prog_j = fprog + tk.j;
+        J.pub = (unsigned)tk.j + 1;
+        J.linv = linv_all + (int64_t)(linv_off[tk.front] + (J.factored ? tk.j : 0)) * 2048;
+        J.minv = nullptr;
+        J.info = info + tk.front; J.info_base = dd.col0 + J.j0;
+        J.abort_on_fail = false;
+        if (!tile_process<true>(J, ctl, err, smem, ctlw, tid, t, nullptr)) return;
+        __syncthreads();
     }
 }
 
@@ -1052,6 +1180,36 @@ void potrf_work_free(PotrfWork& w) {
     if (w.aux) (void)hipStreamDestroy(w.aux);
     w = PotrfWork();
 }
+
+// all big fronts of one level of the supernodal tree (see potrf_tiles_vb_kernel); d_info: nfronts ints, zeroed here
+int launch_potrf_tiles_vb(double* base, const VbDesc* d_desc, int nfronts, const void* d_tickets, int ntickets,
+                          const int* d_prog_off, const int* d_linv_off, void* d_ctl, unsigned* d_prog, int nprog, double* d_linv,
+                          int* d_info, hipStream_t st) {
+    if (nfronts <= 0 || ntickets <= 0) return 0;
+    static int num_cus = 0;
+    static bool attr_set = false;
+    constexpr size_t lds = sizeof(double) * (NB * PLD + NB + 80 + 2 + 2) + 16;
+    if (!attr_set) {
+        int dev = 0;
+        KKT_HIP_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        KKT_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_vb_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    KKT_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int) * nfronts, st));
+    KKT_HIP_CHECK(hipMemsetAsync(d_ctl, 0, sizeof(TileCtl), st));
+    KKT_HIP_CHECK(hipMemsetAsync(d_prog, 0, sizeof(unsigned) * (nprog > 0 ? nprog : 1), st));
+    const int grid = ntickets < num_cus ? ntickets : num_cus;
+    hipLaunchKernelGGL(potrf_tiles_vb_kernel, dim3(grid), dim3(PT_THREADS), lds, st, base, d_desc,
+                       reinterpret_cast<const VbTicket*>(d_tickets), (unsigned)ntickets, d_prog_off, d_linv_off,
+                       reinterpret_cast<TileCtl*>(d_ctl), d_prog, d_linv, d_info, d_info);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+size_t potrf_tile_ctl_bytes() { return sizeof(TileCtl); }
 
 // device state of the persistent tile kernel for matrices up to n x n (idempotent; launch_potrf calls it lazily)
 int potrf_work_reserve(PotrfWork& w, int n) {

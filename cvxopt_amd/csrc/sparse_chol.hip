@@ -17,6 +17,9 @@
 #include <numeric>
 #include <queue>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "kkt_common.h"
 #include "ordering.h"
 #include <chrono>
@@ -244,6 +247,43 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         }
         S.vb_ptr[l + 1] = (int)S.vb.size();
         S.vb_maxcount = std::max(S.vb_maxcount, S.vb_ptr[l + 1] - S.vb_ptr[l]);
+    }
+    // work list of the persistent tile kernel (potrf.hip: potrf_tiles_vb_kernel), per level: tiles (i >= j) of every big front
+    // with the tile boundaries 0, 128, .., 128 q, w, w + 128, ..; order (j, front, i) so that every front's chain starts at once
+    S.tv_tickets.clear();
+    S.tv_ptr.assign(S.nlevels + 1, 0);
+    S.tv_prog_off.assign(S.vb.size(), 0);
+    S.tv_linv_off.assign(S.vb.size(), 0);
+    S.tv_nprog.assign(S.nlevels, 0);
+    S.tv_prog_max = S.tv_linv_max = 0;
+    for (int l = 0; l < S.nlevels; ++l) {
+        int po = 0, lo = 0, maxnt = 0;
+        std::vector<int> ntt(S.vb_ptr[l + 1] - S.vb_ptr[l]);
+        for (int f = S.vb_ptr[l]; f < S.vb_ptr[l + 1]; ++f) {
+            const VbDesc& dd = S.vb[f];
+            const int q = dd.w / 128, wr = dd.w - q * 128, ntf = q + (wr > 0 ? 1 : 0);
+            const int nt = ntf + (dd.h - dd.w + 127) / 128;
+            ntt[f - S.vb_ptr[l]] = nt;
+            S.tv_prog_off[f] = po;
+            S.tv_linv_off[f] = lo;
+            po += nt;
+            lo += ntf;
+            maxnt = std::max(maxnt, nt);
+        }
+        for (int j = 0; j < maxnt; ++j)
+            for (int f = S.vb_ptr[l]; f < S.vb_ptr[l + 1]; ++f) {
+                const int nt = ntt[f - S.vb_ptr[l]];
+                for (int i = j; i < nt; ++i) {
+                    S.tv_tickets.push_back(f - S.vb_ptr[l]);
+                    S.tv_tickets.push_back(i);
+                    S.tv_tickets.push_back(j);
+                    S.tv_tickets.push_back(0);
+                }
+            }
+        S.tv_ptr[l + 1] = (int)(S.tv_tickets.size() / 4);
+        S.tv_nprog[l] = po;
+        S.tv_prog_max = std::max(S.tv_prog_max, po);
+        S.tv_linv_max = std::max(S.tv_linv_max, lo);
     }
     // supernodes whose off-diagonal panel is large: their solve-phase products run as multi-workgroup kernels
     S.heavy_ptr.assign(S.nlevels + 1, 0);
@@ -855,6 +895,12 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     if (int e = up(&E.d_iperm, S.iperm)) return e;
     if (int e = up(&E.d_heavy, S.heavy)) return e;
     if (int e = up(&E.d_vb, S.vb)) return e;
+    if (int e = up(&E.d_tv_tickets, S.tv_tickets)) return e;
+    if (int e = up(&E.d_tv_prog_off, S.tv_prog_off)) return e;
+    if (int e = up(&E.d_tv_linv_off, S.tv_linv_off)) return e;
+    KKT_HIP_CHECK(hipMalloc(&E.d_tv_prog, sizeof(unsigned) * (size_t)std::max(1, S.tv_prog_max)));
+    KKT_HIP_CHECK(hipMalloc(&E.d_tv_ctl, potrf_tile_ctl_bytes()));
+    KKT_HIP_CHECK(hipMalloc(&E.d_tv_linv, sizeof(double) * 2048 * (size_t)std::max(1, S.tv_linv_max)));
     if (int e = potrf_work_init_batched(E.pw_vb, std::max(1, S.vb_maxcount))) return e;
     {   // G in CSC (values + int rows) and CSR (for G x)
         std::vector<double> gvals(gv, gv + gnnz), hvals;
@@ -923,7 +969,8 @@ void sparse_engine_free(SparseEngine& E) {
     void* ptrs[] = {E.d_sn_first, E.d_sn_rowptr, E.d_sn_rows, E.d_panel_off, E.d_upd_off, E.d_child_ptr, E.d_child_list,
                     E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
-                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap, E.d_rem_multi, E.d_iperm};
+                    E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap, E.d_rem_multi, E.d_iperm,
+                    E.d_tv_tickets, E.d_tv_prog_off, E.d_tv_linv_off, E.d_tv_prog, E.d_tv_ctl, E.d_tv_linv};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
@@ -970,7 +1017,14 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
             const VbDesc* dv = E.d_vb + S.vb_ptr[l];
             hipLaunchKernelGGL(sp_extend_add_vb_kernel, dim3((S.vb_maxh[l] + EA_COLS - 1) / EA_COLS, (S.vb_maxh[l] + EA_ROWS - 1) / EA_ROWS, nbig),
                                dim3(256), 0, st, d, dv, E.d_panels);
-            if (int e = launch_potrf_partial_vb(E.d_panels, dv, nbig, S.vb_maxh[l], S.vb_maxw[l], E.pw_vb, st)) return e;
+            static const bool old_chain = getenv("MI355KKT_SPARSE_TILES") && !strcmp(getenv("MI355KKT_SPARSE_TILES"), "0");
+            if (old_chain) {
+                if (int e = launch_potrf_partial_vb(E.d_panels, dv, nbig, S.vb_maxh[l], S.vb_maxw[l], E.pw_vb, st)) return e;
+            } else if (int e = launch_potrf_tiles_vb(E.d_panels, dv, nbig, E.d_tv_tickets + 4 * (size_t)S.tv_ptr[l],
+                                                    S.tv_ptr[l + 1] - S.tv_ptr[l], E.d_tv_prog_off + S.vb_ptr[l],
+                                                    E.d_tv_linv_off + S.vb_ptr[l], E.d_tv_ctl, E.d_tv_prog, S.tv_nprog[l],
+                                                    E.d_tv_linv, E.pw_vb.d_info, st))
+                return e;
             hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3((nbig + 255) / 256), dim3(256), 0, st, E.pw_vb.d_info, nbig, E.d_info);
         }
     }
