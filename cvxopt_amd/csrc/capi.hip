@@ -921,8 +921,12 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     KKT_HIP_CHECK(hipEventRecord(h->ev[2], h->st));
     int info = 0;
     if (int e = fetch_info(h, &info)) return e;
-    if (info > 0 && h->firstcall && !h->singular && h->p > 0) {
-        // reference misc.py:1433-1447: singular S on the first call -> S += A'A for good
+    if (info > 0 && (h->firstcall || h->kind != MI355KKT_CHOL2) && !h->singular && h->p > 0) {
+        // reference misc.py:1433-1447: singular S on the first call -> S += A'A for good.  kkt_chol2 only looks at the first
+        // call; kkt_ldl / kkt_ldl2 (pivoted LDL' of the whole matrix, lapack.c:2282) and kkt_chol (QR elimination of A,
+        // misc.py:1250-1282) accept every nonsingular KKT matrix at every call.  S + A'A is positive definite exactly when
+        // the KKT matrix is nonsingular (x'Sx = 0 and Ax = 0 force x = 0), so for those flavours the switch may happen at
+        // any factorisation: the same set of systems, without pivoting.
         h->singular = true;
         if (int e = assemble_S(h, true)) return e;
         if (int e = launch_potrf(h->dS, h->n, h->n, h->pw, h->st)) return e;

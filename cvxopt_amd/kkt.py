@@ -369,7 +369,9 @@ class _Engine(object):
             # reference misc.py:1433-1447: a singular S on the FIRST factorisation (A pins what G and H leave free) switches
             # to S + A'A for the lifetime of the factory.  The dense engine does this inside the library; in sparse mode the
             # pattern of S grows, so the problem is re-analysed here with the rows of A stacked under G.
-            if not (self._mode == "sparse" and self._first_factor and self.p and not self._sparse_singular):
+            # (kkt_chol2 only at its first call; the other flavours at any call, like the library's dense engine.)
+            if not (self._mode == "sparse" and (self._first_factor or self.kind != _capi.CHOL2) and self.p
+                    and not self._sparse_singular):
                 raise
             self._sparse_singular = True
             self._upload_sparse_problem(H)

@@ -95,6 +95,36 @@ def test_singular_first_call_switches_to_S_plus_AtA():
     f.engine.close()
 
 
+@pytest.mark.parametrize("flavour", ["ldl", "ldl2", "chol"])
+def test_singular_S_at_a_later_call_ldl_and_chol_flavours(flavour):
+    # First factorisation: H = I, S positive definite.  Second: H = 0 and G with a null space, so S is singular while the
+    # KKT matrix is not (A restores the rank).  The reference's kkt_ldl / kkt_ldl2 (pivoted LDL', lapack.c:2282) and kkt_chol
+    # (QR elimination of A, misc.py:1250-1282) solve both; only kkt_chol2 restricts the S + A'A switch to its first call.
+    n, m, p = 40, 30, 15
+    rng = np.random.default_rng(5)
+    G = np.asfortranarray(rng.standard_normal((m, n)))
+    A = np.asfortranarray(rng.standard_normal((p, n)))
+    dims = {'l': m, 'q': [], 's': []}
+    fac = {"ldl": kkt.kkt_ldl, "ldl2": kkt.kkt_ldl2, "chol": kkt.kkt_chol}[flavour]
+    f = fac(G, dims, A)
+    o = {"ldl": ko.KktLdl, "ldl2": ko.KktLdl, "chol": ko.KktChol}[flavour](G, dims, A)
+    for H, seed in ((np.asfortranarray(np.eye(n)), 4), (None, 6)):
+        W = synth.random_scaling(dims, seed=seed, spread=0.5)
+        rhs = rand_rhs(rng, n, p, m)
+        got, ref = run_pair(f, o, W, H, rhs)
+        for g, r in zip(got, ref):
+            assert relerr(g, r) < 1e-7
+        assert ko.kkt_residual(H, A, G, W, dims, rhs[0], rhs[1], rhs[2], *got) < 1e-9
+    assert f.engine.L.mi355kkt_is_singular_mode(f.engine.h) == 1
+    f.engine.close()
+    # kkt_chol2: the same sequence raises at the second call, like misc.py:1440-1447 (the switch is first-call only)
+    f2 = kkt.kkt_chol2(G, dims, A)
+    f2(synth.random_scaling(dims, seed=4, spread=0.5), np.asfortranarray(np.eye(n)))
+    with pytest.raises(ArithmeticError):
+        f2(synth.random_scaling(dims, seed=6, spread=0.5), None)
+    f2.engine.close()
+
+
 def test_not_positive_definite_raises_arithmetic_error():
     n, m = 50, 20
     rng = np.random.default_rng(9)
