@@ -140,20 +140,50 @@ static void lp_free(LpWork& w) {
     if (w.pinned) (void)hipHostFree(w.pinned);
     w = LpWork();
 }
-static int lp_alloc(LpWork& w, int n, int ml, const std::vector<int>& q, int np) {
+// 's' blocks of the device loops: sizes of the extra state (r, rti, three scratch matrices per block, the Jacobi scratch,
+// sigs, sigz) and the int descriptors sdim | soff | sloff
+struct SBlocks {
+    int ns = 0, sums = 0, sums2 = 0, maxs = 0;
+    explicit SBlocks(const std::vector<int>& s) : ns((int)s.size()) {
+        for (int k : s) { sums += k; sums2 += k * k; maxs = std::max(maxs, k); }
+    }
+    size_t doubles() const { return ns ? 5 * (size_t)sums2 + 2 * (size_t)sums + s_jw_doubles(maxs, 256) + 8 : 8; }
+};
+template <class ST>
+static int sblocks_bind(ST& S, const SBlocks& sb, const std::vector<int>& s, int lq, double*& p, int* di) {
+    S.ns = sb.ns; S.lq = lq; S.ldim = lq + sb.sums;
+    auto take = [&](size_t k) { double* r = p; p += (k ? k : 1); return r; };
+    S.r = take(sb.sums2); S.rti = take(sb.sums2); S.sw1 = take(sb.sums2); S.sw2 = take(sb.sums2); S.sw3 = take(sb.sums2);
+    S.sigs = take(sb.sums); S.sigz = take(sb.sums); S.jw = take(sb.ns ? s_jw_doubles(sb.maxs, 256) : 1);
+    S.sdim = di; S.soff = di + sb.ns; S.sloff = di + 2 * sb.ns;
+    if (sb.ns) {
+        std::vector<int> h(3 * (size_t)sb.ns);
+        int off = lq, loff = lq;
+        for (int k = 0; k < sb.ns; ++k) {
+            h[k] = s[k]; h[sb.ns + k] = off; h[2 * sb.ns + k] = loff;
+            off += s[k] * s[k]; loff += s[k];
+        }
+        if (hipMemcpy(di, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return MI355KKT_EHIP;
+    }
+    return 0;
+}
+
+static int lp_alloc(LpWork& w, int n, int ml, const std::vector<int>& q, const std::vector<int>& sd, int np) {
     if (w.f64) return 0;
     int sumq = 0;
     for (int k : q) sumq += k;
-    const int m = ml + sumq, nq = (int)q.size();
+    const SBlocks sb(sd);
+    const int m = ml + sumq + sb.sums2, nq = (int)q.size();
     const size_t N = n ? n : 1, M = m ? m : 1, Pq = np ? np : 1;
-    const size_t nd = 10 * N + 9 * Pq + 23 * M + (size_t)sumq + nq + LP_NSC + 8;
+    const size_t nd = 10 * N + 9 * Pq + 23 * M + (size_t)sumq + nq + LP_NSC + 8 + sb.doubles();
     // all or nothing: a partially allocated state must not look complete to the next call
     if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
-    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq)) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
+    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq + 3 * (size_t)sb.ns)) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
     if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
     LpState& S = w.S;
     S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq;
     double* p = w.f64;
+    if (int e = sblocks_bind(S, sb, sd, ml + sumq, p, w.i32 + 8 + 2 * nq)) { lp_free(w); return e; }
     auto take = [&](size_t k) { double* r = p; p += k; return r; };
     S.c = take(N); S.x = take(N); S.dx = take(N); S.rx = take(N); S.x1 = take(N); S.GTz = take(N); S.ATy = take(N); S.x_out = take(N);
     S.wx = take(N); S.wx2 = take(N);
@@ -189,20 +219,22 @@ static void qp_free(QpWork& w) {
     if (w.pinned) (void)hipHostFree(w.pinned);
     w = QpWork();
 }
-static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, int np) {
+static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, const std::vector<int>& sd, int np) {
     if (w.f64) return 0;
     int sumq = 0;
     for (int k : q) sumq += k;
-    const int m = ml + sumq, nq = (int)q.size();
+    const SBlocks sb(sd);
+    const int m = ml + sumq + sb.sums2, nq = (int)q.size();
     const size_t N = n ? n : 1, M = m ? m : 1, Pq = np ? np : 1;
-    const size_t nd = 10 * N + 8 * Pq + 21 * M + (size_t)sumq + nq + QP_NSC + 8;
+    const size_t nd = 10 * N + 8 * Pq + 21 * M + (size_t)sumq + nq + QP_NSC + 8 + sb.doubles();
     // all or nothing: a partially allocated state must not look complete to the next call
     if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
-    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq)) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
+    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq + 3 * (size_t)sb.ns)) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
     if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
     QpState& S = w.S;
     S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq;
     double* p = w.f64;
+    if (int e = sblocks_bind(S, sb, sd, ml + sumq, p, w.i32 + 8 + 2 * nq)) { qp_free(w); return e; }
     auto take = [&](size_t k) { double* r = p; p += k; return r; };
     S.q = take(N); S.x = take(N); S.dx = take(N); S.rx = take(N); S.Px = take(N); S.GTz = take(N); S.ATy = take(N); S.x_out = take(N);
     S.wx = take(N); S.wx2 = take(N);
@@ -1565,6 +1597,28 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
     return run_ipm(hs->ipm, st, ops, q, hv, bv, maxiters, abstol, reltol, feastol, o);
 }
 
+// The device loops keep the 's' blocks of every cone vector as full symmetric matrices (cone_ops_s.h), so that G x is symmetric
+// and G'z is the reference's sgemv (misc.py:801-832: only the lower triangles of the 's' blocks of the columns of G count).
+// One pass over the handle's own copy of G: upper triangles := lower triangles.  Harmless for factor / solve, which read the
+// lower triangles only.
+__global__ __launch_bounds__(256) void g_symm_sblocks_kernel(double* G, int64_t ldG, const int* sdim, const int* soff) {
+    double* col = G + (size_t)blockIdx.x * ldG + soff[blockIdx.y];
+    const int m = sdim[blockIdx.y];
+    for (int e = threadIdx.x; e < m * m; e += 256)
+        if (e % m < e / m) col[e] = col[(e / m) + (size_t)(e % m) * m];
+}
+static int symmetrize_G_sblocks(mi355kkt_solver* hs) {
+    if (hs->s.empty() || hs->n == 0) return 0;
+    if (!hs->G_owned || hs->dG != hs->G_owned) {
+        set_last_error("device loops with 's' cones need G set with mi355kkt_set_G_dense / set_G_csc (the handle's own copy)");
+        return MI355KKT_ENOTIMPL;
+    }
+    hipLaunchKernelGGL(g_symm_sblocks_kernel, dim3(hs->n, (unsigned)hs->s.size()), dim3(256), 0, hs->st, hs->G_owned, hs->ldG,
+                       hs->cl.d_sdim, hs->cl.d_soff);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 /* Single problem, 'l' + 'q' cones: the conelp loop of coneprog.py:586-1436 (self-dual embedding, default starting point,
  * refinement 0 for the LP cone and 1 with second-order cones, :502-507) resident on the device around this handle's
  * factor/solve (H must be absent).  See include/mi355kkt.h. */
@@ -1575,13 +1629,14 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
         set_last_error("conelp: null argument");
         return MI355KKT_EINVAL;
     }
-    if (!hs->s.empty() || hs->cdim < 1) { set_last_error("conelp: needs dims = {'l': ml, 'q': [...]} with at least one row"); return MI355KKT_ENOTIMPL; }
+    if (hs->cdim < 1) { set_last_error("conelp: needs at least one cone row"); return MI355KKT_ENOTIMPL; }
     if (hs->dH) { set_last_error("conelp: the handle carries a quadratic term (H)"); return MI355KKT_EINVAL; }
     if (hs->p > 0 && !hs->dA && !hs->A_sparse) { set_last_error("conelp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->cdim, np = hs->p;
-    if (refinement < 0) refinement = hs->q.empty() ? 0 : 1;
-    if (int e = lp_alloc(hs->lp, n, hs->ml, hs->q, np)) return e;
+    if (refinement < 0) refinement = (hs->q.empty() && hs->s.empty()) ? 0 : 1;
+    if (int e = lp_alloc(hs->lp, n, hs->ml, hs->q, hs->s, np)) return e;
+    if (int e = symmetrize_G_sblocks(hs)) return e;
     LpWork& w = hs->lp;
     const LpState& S = w.S;
     hipStream_t st = hs->st;
@@ -1606,7 +1661,7 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
     };
     auto factor = [&](int* info_out) -> int {
         mi355kkt_scaling W = {};
-        W.di = S.di; W.d = S.d; W.v = S.v; W.beta = S.beta;
+        W.di = S.di; W.d = S.d; W.v = S.v; W.beta = S.beta; W.r = S.r; W.rti = S.rti;
         const int info = mi355kkt_factor_device(hs, &W);
         if (info < 0) return info;
         *info_out = info;
@@ -1615,7 +1670,12 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
         if (info > 0) hs->factored = true;   // the loop leaves before any solve result is used
         return 0;
     };
-    auto solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_solve_device(hs, dx, dy, dz); };
+    // (the solve returns the lower triangles of the 's' blocks of z, misc_solvers.c:552-601; the loop keeps both)
+    auto solve = [&](double* dx, double* dy, double* dz) -> int {
+        if (int e = mi355kkt_solve_device(hs, dx, dy, dz)) return e;
+        lp_launch_symm(S, dz, st);
+        return 0;
+    };
     auto dcopy = [&](double* dst, const double* src, size_t k) -> int {
         if (k) KKT_HIP_CHECK(hipMemcpyAsync(dst, src, sizeof(double) * k, hipMemcpyDeviceToDevice, st));
         return 0;
@@ -1625,6 +1685,7 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
     const LpBuf W2{S.wx2, S.wy2, S.wz2, S.ws2, LP_WTAU2, LP_WKAPPA2};
     KKT_HIP_CHECK(hipMemcpyAsync(S.c, c, sizeof(double) * n, hipMemcpyHostToDevice, st));
     KKT_HIP_CHECK(hipMemcpyAsync(S.h, hv, sizeof(double) * m, hipMemcpyHostToDevice, st));
+    lp_launch_symm(S, S.h, st);                       // only the lower triangles of the 's' blocks of h are significant
     if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bv, sizeof(double) * np, hipMemcpyHostToDevice, st));
     KKT_HIP_CHECK(hipMemsetAsync(w.i32, 0, sizeof(int) * 8, st));
     KKT_HIP_CHECK(hipMemsetAsync(S.sc, 0, sizeof(double) * LP_NSC, st));
@@ -1707,12 +1768,13 @@ int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, cons
         set_last_error("coneqp: null argument");
         return MI355KKT_EINVAL;
     }
-    if (!hs->s.empty() || hs->cdim < 1) { set_last_error("coneqp: needs dims = {'l': ml, 'q': [...]} with at least one row"); return MI355KKT_ENOTIMPL; }
+    if (hs->cdim < 1) { set_last_error("coneqp: needs at least one cone row"); return MI355KKT_ENOTIMPL; }
     if (hs->p > 0 && !hs->dA && !hs->A_sparse) { set_last_error("coneqp: A not set"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->cdim, np = hs->p;
-    if (refinement < 0) refinement = hs->q.empty() ? 0 : 1;
-    if (int e = qp_alloc(hs->qp, n, hs->ml, hs->q, np)) return e;
+    if (refinement < 0) refinement = (hs->q.empty() && hs->s.empty()) ? 0 : 1;
+    if (int e = qp_alloc(hs->qp, n, hs->ml, hs->q, hs->s, np)) return e;
+    if (int e = symmetrize_G_sblocks(hs)) return e;
     QpWork& w = hs->qp;
     const QpState& S = w.S;
     hipStream_t st = hs->st;
@@ -1743,7 +1805,7 @@ int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, cons
     };
     auto factor = [&](int* info_out) -> int {
         mi355kkt_scaling W = {};
-        W.di = S.di; W.d = S.d; W.v = S.v; W.beta = S.beta;
+        W.di = S.di; W.d = S.d; W.v = S.v; W.beta = S.beta; W.r = S.r; W.rti = S.rti;
         const int info = mi355kkt_factor_device(hs, &W);
         if (info < 0) return info;
         *info_out = info;
@@ -1752,12 +1814,17 @@ int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, cons
         if (info > 0) hs->factored = true;
         return 0;
     };
-    auto solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_solve_device(hs, dx, dy, dz); };
+    auto solve = [&](double* dx, double* dy, double* dz) -> int {
+        if (int e = mi355kkt_solve_device(hs, dx, dy, dz)) return e;
+        qp_launch_symm(S, dz, st);
+        return 0;
+    };
     const QpBuf D{S.dx, S.dy, S.dz, S.ds};
     const QpBuf Wsave{S.wx, S.wy, S.wz, S.ws};
     const QpBuf W2{S.wx2, S.wy2, S.wz2, S.ws2};
     KKT_HIP_CHECK(hipMemcpyAsync(S.q, q, sizeof(double) * n, hipMemcpyHostToDevice, st));
     KKT_HIP_CHECK(hipMemcpyAsync(S.h, hv, sizeof(double) * m, hipMemcpyHostToDevice, st));
+    qp_launch_symm(S, S.h, st);                       // only the lower triangles of the 's' blocks of h are significant
     if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bv, sizeof(double) * np, hipMemcpyHostToDevice, st));
     KKT_HIP_CHECK(hipMemsetAsync(w.i32, 0, sizeof(int) * 8, st));
     KKT_HIP_CHECK(hipMemsetAsync(S.sc, 0, sizeof(double) * QP_NSC, st));
@@ -1993,6 +2060,33 @@ int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, d
         case 6: mi355kkt::q_compute_scaling(x, y, w, w + 2 * mk, w + mk, mk); break;
         case 7: mi355kkt::q_update_scaling(x, y, w, w + 2 * mk, w + mk, mk); break;
         case 8: w[0] = mi355kkt::q_nrm1(x, mk) - x[0]; break;
+        default: return MI355KKT_EINVAL;
+    }
+    return 0;
+}
+/* The same for the 's'-block operations (cone_ops_s.h, instantiated with a team of one thread): one block of order m, column-
+ * major.  inverse = arg & 1, trans = arg & 2.
+ * op: 0 scale (x := W x: r'xr | rxr' (trans) | rti x rti' (inverse) | rti'x rti (both)), 1 sprod (x := (xy + yx)/2),
+ * 2 sprod diag = 'D' (x := x o diag(lam); inverse: sinv), 3 scale2 (lam, x; inverse), 4 smallest eigenvalue -> lam[0],
+ * 5 eigenvalue decomposition (x := eigenvectors, lam := eigenvalues ascending), 6 compute_scaling (s = x, z = y -> r, rti, lam),
+ * 7 update_scaling (Ls = x, Lz = y destroyed; r, rti, lam updated), 8 potrf (x := chol(x), strict upper zeroed). */
+int mi355kkt_debug_sdp_op_host(int op, int m, int arg, double* x, double* y, double* r, double* rti, double* lam) {
+    if (m < 1 || !x) return MI355KKT_EINVAL;
+    const mi355kkt::ParHost par;
+    const size_t mm = (size_t)m * m;
+    std::vector<double> w(3 * mm + mi355kkt::s_jw_doubles(m, 1) + m);
+    double *T1 = w.data(), *T2 = T1 + mm, *T3 = T2 + mm, *jw = T3 + mm, *sg = jw + mi355kkt::s_jw_doubles(m, 1);
+    const bool inverse = arg & 1, trans = arg & 2;
+    switch (op) {
+        case 0: mi355kkt::s_scale_blk(par, x, inverse ? rti : r, m, trans == inverse, T1); break;
+        case 1: mi355kkt::s_sprod_blk(par, x, y, m, T1); break;
+        case 2: mi355kkt::s_sprod_diag_blk(par, x, lam, m, inverse); break;
+        case 3: mi355kkt::s_scale2_blk(par, lam, x, m, inverse); break;
+        case 4: lam[0] = mi355kkt::s_min_eig_blk(par, x, m, T1, sg, jw); break;
+        case 5: mi355kkt::s_eig_blk(par, x, lam, m, T1, T2, jw); break;
+        case 6: return mi355kkt::s_compute_scaling_blk(par, x, y, r, rti, lam, m, T1, T2, T3, jw);
+        case 7: mi355kkt::s_update_scaling_blk(par, x, y, r, rti, lam, m, T1, T2, jw); break;
+        case 8: return mi355kkt::s_potrf(par, x, m);
         default: return MI355KKT_EINVAL;
     }
     return 0;

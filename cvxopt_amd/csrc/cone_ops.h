@@ -2,9 +2,11 @@
 // coneqp_ipm.hip: sprod, sinv, ssqr, scale2, max_step, scale (src/C/misc_solvers.c:634, :775, :256, :1052, :85; misc.py:945)
 // and the Nesterov-Todd scaling of second-order cones (misc.compute_scaling misc.py:307-354, update_scaling :503-573).
 // One 256-thread workgroup per problem; 'l' entries are strided over the workgroup, 'q' blocks walked one cone per
-// thread.  ST is a state struct with ml, nq, qoff, qdim, d, v, beta (LpState / QpState).
+// thread, 's' blocks one after the other by the whole workgroup (cone_ops_s.h).  ST is a state struct with ml, nq, qoff, qdim,
+// d, v, beta and the 's' descriptors ns, lq, ldim, sdim, soff, sloff, r, rti, sw1..3, jw (LpState / QpState).
 #pragma once
 #include "kkt_common.h"
+#include "cone_ops_s.h"
 
 namespace mi355kkt {
 
@@ -26,6 +28,15 @@ __device__ __forceinline__ double lp_block_max(double v, double* sh) {
     __syncthreads();
     return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
 }
+// the 256-thread workgroup as the team of the 's'-block operations (cone_ops_s.h)
+struct ParWG {
+    double* sh;
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ int nt() const { return 256; }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ double sum(double v) const { return lp_block_sum(v, sh); }
+    __device__ __forceinline__ double max(double v) const { return lp_block_max(v, sh); }
+};
 __device__ __forceinline__ double lp_dot(const double* a, const double* b, int n, double* sh) {
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) v += a[i] * b[i];
@@ -100,45 +111,145 @@ __host__ __device__ __forceinline__ void q_scale(double* x, const double* v, dou
     }
 }
 
-// ---- whole cone vectors (l part strided over the workgroup, q part one cone per thread) -----------------------
+// ---- whole cone vectors (l part strided over the workgroup, q part one cone per thread, 's' blocks one by one) ------
+// Functions that touch 's' blocks contain workgroup barriers: call them from uniform control flow only.
 template <class ST>
 __device__ __forceinline__ double cv_maxstep(const ST& S, const double* x, double* sh) {
     double t = -1e300;
     for (int i = threadIdx.x; i < S.ml; i += 256) t = fmax(t, -x[i]);
     for (int k = threadIdx.x; k < S.nq; k += 256) t = fmax(t, q_nrm1(x + S.qoff[k], S.qdim[k]) - x[S.qoff[k]]);
+    if (S.ns > 0) {                                      // max_step without sigma: -lambda_min of every block
+        const ParWG par{sh};
+        __syncthreads();
+        for (int k = 0; k < S.ns; ++k) {
+            const int o = S.soff[k] - S.lq;
+            t = fmax(t, -s_min_eig_blk(par, x + S.soff[k], S.sdim[k], S.sw1 + o, S.sw2 + o, S.jw));
+        }
+    }
+    return lp_block_max(t, sh);
+}
+// max_step with sigma (misc_solvers.c:1131-1136): the 's' blocks of x are replaced by their eigenvectors, sig (compact
+// layout, sum(s) entries) receives the eigenvalues
+template <class ST>
+__device__ __forceinline__ double cv_maxstep_sigma(const ST& S, double* x, double* sig, double* sh) {
+    double t = -1e300;
+    for (int i = threadIdx.x; i < S.ml; i += 256) t = fmax(t, -x[i]);
+    for (int k = threadIdx.x; k < S.nq; k += 256) t = fmax(t, q_nrm1(x + S.qoff[k], S.qdim[k]) - x[S.qoff[k]]);
+    if (S.ns > 0) {
+        const ParWG par{sh};
+        __syncthreads();
+        for (int k = 0; k < S.ns; ++k) {
+            const int o = S.soff[k] - S.lq;
+            double* sg = sig + (S.sloff[k] - S.lq);
+            s_eig_blk(par, x + S.soff[k], sg, S.sdim[k], S.sw1 + o, S.sw2 + o, S.jw);
+            t = fmax(t, -sg[0]);
+        }
+    }
     return lp_block_max(t, sh);
 }
 template <class ST>
-__device__ __forceinline__ void cv_add_e(const ST& S, double* x, double a) {
+__device__ __forceinline__ void cv_add_e(const ST& S, double* x, double a, bool with_s = true) {
     for (int i = threadIdx.x; i < S.ml; i += 256) x[i] += a;
     for (int k = threadIdx.x; k < S.nq; k += 256) x[S.qoff[k]] += a;
+    for (int k = 0; with_s && k < S.ns; ++k)
+        for (int i = threadIdx.x; i < S.sdim[k]; i += 256) x[S.soff[k] + i * (S.sdim[k] + 1)] += a;
 }
+// x := x o y, y a cone vector (sprod with diag = 'N')
 template <class ST>
-__device__ __forceinline__ void cv_sprod(const ST& S, double* x, const double* y) {
+__device__ __forceinline__ void cv_sprod(const ST& S, double* x, const double* y, double* sh) {
     for (int i = threadIdx.x; i < S.ml; i += 256) x[i] *= y[i];
     for (int k = threadIdx.x; k < S.nq; k += 256) q_sprod(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
+    if (S.ns > 0) {
+        const ParWG par{sh};
+        __syncthreads();
+        for (int k = 0; k < S.ns; ++k)
+            s_sprod_blk(par, x + S.soff[k], y + S.soff[k], S.sdim[k], S.sw1 + (S.soff[k] - S.lq));
+    }
 }
+// x := x o lmbda, lmbda in its compact layout (sprod with diag = 'D')
 template <class ST>
-__device__ __forceinline__ void cv_sinv(const ST& S, double* x, const double* y) {
-    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] /= y[i];
-    for (int k = threadIdx.x; k < S.nq; k += 256) q_sinv(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
+__device__ __forceinline__ void cv_sprod_diag(const ST& S, double* x, const double* l, double* sh) {
+    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] *= l[i];
+    for (int k = threadIdx.x; k < S.nq; k += 256) q_sprod(x + S.qoff[k], l + S.qoff[k], S.qdim[k]);
+    if (S.ns > 0) {
+        const ParWG par{sh};
+        for (int k = 0; k < S.ns; ++k) s_sprod_diag_blk(par, x + S.soff[k], l + S.sloff[k], S.sdim[k], false);
+    }
 }
+// x := lmbda o\ x (sinv: the second argument is always the compact lmbda)
+template <class ST>
+__device__ __forceinline__ void cv_sinv(const ST& S, double* x, const double* l, double* sh) {
+    for (int i = threadIdx.x; i < S.ml; i += 256) x[i] /= l[i];
+    for (int k = threadIdx.x; k < S.nq; k += 256) q_sinv(x + S.qoff[k], l + S.qoff[k], S.qdim[k]);
+    if (S.ns > 0) {
+        const ParWG par{sh};
+        for (int k = 0; k < S.ns; ++k) s_sprod_diag_blk(par, x + S.soff[k], l + S.sloff[k], S.sdim[k], true);
+    }
+}
+// x := y o y for the compact lmbda layout (misc.ssqr, misc.py:945-972: the 's' part is diagonal)
 template <class ST>
 __device__ __forceinline__ void cv_ssqr(const ST& S, double* x, const double* y) {
     for (int i = threadIdx.x; i < S.ml; i += 256) x[i] = y[i] * y[i];
     for (int k = threadIdx.x; k < S.nq; k += 256) q_ssqr(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
+    for (int i = S.lq + threadIdx.x; i < S.ldim; i += 256) x[i] = y[i] * y[i];
 }
 template <class ST>
-__device__ __forceinline__ void cv_scale2(const ST& S, const double* l, double* x, bool inverse) {
+__device__ __forceinline__ void cv_scale2(const ST& S, const double* l, double* x, bool inverse, double* sh) {
     for (int i = threadIdx.x; i < S.ml; i += 256) x[i] = inverse ? x[i] * l[i] : x[i] / l[i];
     for (int k = threadIdx.x; k < S.nq; k += 256) q_scale2(l + S.qoff[k], x + S.qoff[k], S.qdim[k], inverse);
+    if (S.ns > 0) {
+        const ParWG par{sh};
+        for (int k = 0; k < S.ns; ++k) s_scale2_blk(par, l + S.sloff[k], x + S.soff[k], S.sdim[k], inverse);
+    }
 }
-// x := W x (== W' x) or W^-1 x (== W^-T x): both symmetric for 'l' and 'q' blocks
+// misc.scale: x := W x (trans: W' x) or W^-1 x (trans: W^-T x).  'l' and 'q' blocks are symmetric; 's' blocks (misc.py:
+// 118-164): r' X r | r X r' (trans) | rti X rti' (inverse) | rti' X rti (inverse, trans)
 template <class ST>
-__device__ __forceinline__ void cv_scale(const ST& S, double* x, bool inverse) {
+__device__ __forceinline__ void cv_scale(const ST& S, double* x, bool inverse, bool trans, double* sh) {
     for (int i = threadIdx.x; i < S.ml; i += 256) x[i] = inverse ? x[i] / S.d[i] : x[i] * S.d[i];
     for (int k = threadIdx.x; k < S.nq; k += 256)
         q_scale(x + S.qoff[k], S.v + (S.qoff[k] - S.ml), S.beta[k], S.qdim[k], inverse);
+    if (S.ns > 0) {
+        const ParWG par{sh};
+        __syncthreads();
+        for (int k = 0; k < S.ns; ++k) {
+            const int o = S.soff[k] - S.lq;
+            s_scale_blk(par, x + S.soff[k], (inverse ? S.rti : S.r) + o, S.sdim[k], trans == inverse, S.sw1 + o);
+        }
+    }
+}
+// x := the cone vector with the compact lmbda on it: copy for 'l' / 'q', diag(lmbda_k) for the 's' blocks
+// (coneprog.py:1264-1273, :1404-1413)
+template <class ST>
+__device__ __forceinline__ void cv_expand(const ST& S, double* x, const double* l) {
+    for (int i = threadIdx.x; i < S.lq; i += 256) x[i] = l[i];
+    for (int k = 0; k < S.ns; ++k) {
+        const int m = S.sdim[k];
+        for (int e = threadIdx.x; e < m * m; e += 256) x[S.soff[k] + e] = (e % m == e / m) ? l[S.sloff[k] + e % m] : 0.0;
+    }
+}
+// upper triangles of the 's' blocks := lower triangles (after a KKT solve, which like the reference's returns lower
+// triangles only, misc_solvers.c:552-601)
+template <class ST>
+__device__ __forceinline__ void cv_symm(const ST& S, double* x) {
+    for (int k = 0; k < S.ns; ++k) {
+        const int m = S.sdim[k];
+        for (int e = threadIdx.x; e < m * m; e += 256)
+            if (e % m < e / m) x[S.soff[k] + e] = x[S.soff[k] + (e / m) + (e % m) * m];
+    }
+}
+// the 's' part of "ds, dz := the factors Ls, Lz of the updated variables in the current scaling" (coneprog.py:1364-1395):
+// sig := (1 + step sig) / lmbda, then column i of the block (eigenvectors scaled by scale2 inverse) *= sqrt(sig_i)
+template <class ST>
+__device__ __forceinline__ void cv_s_factors(const ST& S, const double* l, double* x, double* sig, double step) {
+    for (int k = 0; k < S.ns; ++k) {
+        const int m = S.sdim[k];
+        double* sg = sig + (S.sloff[k] - S.lq);
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += 256) sg[i] = (1.0 + step * sg[i]) / l[S.sloff[k] + i];
+        __syncthreads();
+        for (int e = threadIdx.x; e < m * m; e += 256) x[S.soff[k] + e] *= sqrt(sg[e / m]);
+    }
 }
 
 // misc.compute_scaling for one second-order cone (misc.py:307-354): v_k, beta_k, lambda_k from s_k, z_k
@@ -205,7 +316,7 @@ __host__ __device__ __forceinline__ void q_update_scaling(double* sk, double* zk
 
 // misc.compute_scaling, 'l' and 'q' blocks: d, (v, beta), lmbda from s, z
 template <class ST>
-__device__ __forceinline__ void cv_compute_scaling(const ST& S, const double* s, const double* z, double* lmbda) {
+__device__ __forceinline__ void cv_compute_scaling(const ST& S, const double* s, const double* z, double* lmbda, double* sh) {
     const int tid = threadIdx.x;
     for (int i = tid; i < S.ml; i += 256) {
         S.d[i] = sqrt(s[i] / z[i]);
@@ -215,12 +326,21 @@ __device__ __forceinline__ void cv_compute_scaling(const ST& S, const double* s,
         const int o = S.qoff[k];
         q_compute_scaling(s + o, z + o, S.v + (o - S.ml), S.beta + k, lmbda + o, S.qdim[k]);
     }
+    if (S.ns > 0) {                                      // misc.py:374-417
+        const ParWG par{sh};
+        __syncthreads();
+        for (int k = 0; k < S.ns; ++k) {
+            const int o = S.soff[k] - S.lq;
+            s_compute_scaling_blk(par, s + S.soff[k], z + S.soff[k], S.r + o, S.rti + o, lmbda + S.sloff[k], S.sdim[k], S.sw1 + o,
+                                  S.sw2 + o, S.sw3 + o, S.jw);
+        }
+    }
 }
 
 // misc.update_scaling, 'l' (misc.py:444-464) and 'q' (:503-573) blocks; ds, dz: the updated variables in the current
 // scaling (the 'q' parts are normalised in place)
 template <class ST>
-__device__ __forceinline__ void cv_update_scaling(const ST& S, double* lmbda, double* ds, double* dz) {
+__device__ __forceinline__ void cv_update_scaling(const ST& S, double* lmbda, double* ds, double* dz, double* sh) {
     const int tid = threadIdx.x;
     for (int i = tid; i < S.ml; i += 256) {
         const double a = sqrt(ds[i]), c = sqrt(dz[i]);
@@ -230,6 +350,15 @@ __device__ __forceinline__ void cv_update_scaling(const ST& S, double* lmbda, do
     for (int k = tid; k < S.nq; k += 256) {
         const int o = S.qoff[k];
         q_update_scaling(ds + o, dz + o, S.v + (o - S.ml), S.beta + k, lmbda + o, S.qdim[k]);
+    }
+    if (S.ns > 0) {                                      // misc.py:592-634; the 's' blocks of ds, dz hold Ls, Lz
+        const ParWG par{sh};
+        __syncthreads();
+        for (int k = 0; k < S.ns; ++k) {
+            const int o = S.soff[k] - S.lq;
+            s_update_scaling_blk(par, ds + S.soff[k], dz + S.soff[k], S.r + o, S.rti + o, lmbda + S.sloff[k], S.sdim[k], S.sw1 + o,
+                                 S.sw2 + o, S.jw);
+        }
     }
 }
 

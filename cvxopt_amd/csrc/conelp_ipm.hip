@@ -39,9 +39,13 @@ __device__ __forceinline__ void lp_store_result(const LpState& S, int status, in
 __global__ __launch_bounds__(256) void lp_unit_scaling_kernel(LpState S) {
     const int tid = threadIdx.x;
     for (int i = tid; i < S.ml; i += 256) { S.d[i] = 1.0; S.di[i] = 1.0; }
-    for (int i = tid; i < S.m - S.ml; i += 256) S.v[i] = 0.0;
+    for (int i = tid; i < S.lq - S.ml; i += 256) S.v[i] = 0.0;
     __syncthreads();
     for (int k = tid; k < S.nq; k += 256) { S.v[S.qoff[k] - S.ml] = 1.0; S.beta[k] = 1.0; }
+    for (int k = 0; k < S.ns; ++k) {                     // r_k = rti_k = I
+        const int mk = S.sdim[k], o = S.soff[k] - S.lq;
+        for (int e = tid; e < mk * mk; e += 256) S.r[o + e] = S.rti[o + e] = (e % mk == e / mk) ? 1.0 : 0.0;
+    }
 }
 
 __global__ __launch_bounds__(256) void lp_init_primal_kernel(LpState S) {
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
     }
     if (tid == 0) atomicAdd(S.nactive, 1);
     if (it == 0) {                                 // compute_scaling (misc.py:284-354); dg, lambda_g (:1026-1041)
-        cv_compute_scaling(S, S.s, S.z, S.lmbda);
+        cv_compute_scaling(S, S.s, S.z, S.lmbda, sh);
         if (tid == 0) {
             sc[LP_DG] = sqrt(kappa / tau);
             sc[LP_DGI] = sqrt(tau / kappa);
@@ -201,13 +205,13 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
         S.th[i] = S.h[i];
     }
     __syncthreads();
-    cv_scale(S, S.th, true);
+    cv_scale(S, S.th, true, true, sh);              // misc.scale(th, W, trans = 'T', inverse = 'I')
     cv_ssqr(S, S.lmbdasq, S.lmbda);
-    const double l2 = lp_dot(S.lmbda, S.lmbda, m, sh);
+    const double l2 = lp_dot(S.lmbda, S.lmbda, S.ldim, sh);
     if (tid == 0) {
         const double lg = sc[LP_LG];
         const double nr = sqrt(l2 + lg * lg);       // blas.nrm2(lmbda)**2 / (1 + cdim_diag)
-        sc[LP_MU] = nr * nr / (1.0 + m);
+        sc[LP_MU] = nr * nr / (1.0 + S.ldim);
         sc[LP_SIGMA] = 0.0;
     }
 }
@@ -239,11 +243,11 @@ __global__ __launch_bounds__(256) void lp_build_kernel(LpState S, LpBuf D, LpBuf
     double* sc = S.sc;
     const double sigma = (i01 == 0) ? 0.0 : sc[LP_SIGMA];
     const double mu = sc[LP_MU], lg = sc[LP_LG];
-    for (int i = tid; i < m; i += 256) {
-        double v = S.lmbdasq[i];
-        if (i01 == 1) v += S.ws3[i];
-        D.s[i] = v;
-        D.z[i] = (1.0 - sigma) * S.rz[i];
+    cv_expand(S, D.s, S.lmbdasq);                   // ds := lmbdasq ('s' blocks: diag(lmbdasq_k), coneprog.py:1264-1273)
+    for (int i = tid; i < m; i += 256) D.z[i] = (1.0 - sigma) * S.rz[i];
+    if (i01 == 1) {
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) D.s[i] += S.ws3[i];
     }
     for (int i = tid; i < n; i += 256) D.x[i] = (1.0 - sigma) * S.rx[i];
     for (int i = tid; i < p; i += 256) D.y[i] = (1.0 - sigma) * S.ry[i];
@@ -283,9 +287,10 @@ __global__ __launch_bounds__(256) void lp_add_kernel(LpState S, LpBuf dst, LpBuf
 
 // f6_no_ir, part before the KKT solve (:1158-1174): y := -y; s := -lmbda o\ s; z := -(z + W's)
 __global__ __launch_bounds__(256) void lp_f6pre_kernel(LpState S, LpBuf X) {
+    __shared__ double sh[4];
     const int tid = threadIdx.x, m = S.m;
     for (int i = tid; i < S.p; i += 256) X.y[i] = -X.y[i];
-    cv_sinv(S, X.s, S.lmbda);
+    cv_sinv(S, X.s, S.lmbda, sh);
     __syncthreads();
     for (int i = tid; i < m; i += 256) {
         const double v = -X.s[i];
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(256) void lp_f6pre_kernel(LpState S, LpBuf X) {
         S.t1[i] = v;
     }
     __syncthreads();
-    cv_scale(S, S.t1, false);
+    cv_scale(S, S.t1, false, true, sh);             // W' s
     __syncthreads();
     for (int i = tid; i < m; i += 256) X.z[i] = -(X.z[i] + S.t1[i]);
 }
@@ -329,9 +334,10 @@ __global__ __launch_bounds__(256) void lp_f6post_kernel(LpState S, LpBuf X) {
 
 // res() (:596-634), first half: wz3 = W^-1 uz (the products with G', A', G, A are launched by the host in between)
 __global__ __launch_bounds__(256) void lp_res_a_kernel(LpState S, LpBuf U) {
+    __shared__ double sh[4];
     for (int i = threadIdx.x; i < S.m; i += 256) S.wz3[i] = U.z[i];
     __syncthreads();
-    cv_scale(S, S.wz3, true);
+    cv_scale(S, S.wz3, true, false, sh);            // misc.scale(wz3, W, inverse = 'I')
 }
 // second half: S.GTz = G' wz3, S.ATy = A' uy, S.Gx = G ux, S.Ax = A ux are in place
 __global__ __launch_bounds__(256) void lp_res_b_kernel(LpState S, LpBuf U, LpBuf V) {
@@ -356,8 +362,8 @@ __global__ __launch_bounds__(256) void lp_res_b_kernel(LpState S, LpBuf U, LpBuf
         S.t2[i] = U.s[i] + U.z[i];                  // lmbda o (uz + us)
     }
     __syncthreads();
-    cv_scale(S, S.t1, false);
-    cv_sprod(S, S.t2, S.lmbda);
+    cv_scale(S, S.t1, false, true, sh);             // misc.scale(ws3, W, trans = 'T')
+    cv_sprod_diag(S, S.t2, S.lmbda, sh);            // misc.sprod(ws3, lmbda, dims, diag = 'D')
     __syncthreads();
     for (int i = tid; i < m; i += 256) {
         V.z[i] = V.z[i] + S.Gx[i] - S.h[i] * (utau / dg) + S.t1[i];
@@ -377,14 +383,16 @@ __global__ __launch_bounds__(256) void lp_step_kernel(LpState S, LpBuf D, int i0
     if (i01 == 0) {
         for (int i = tid; i < m; i += 256) S.ws3[i] = D.s[i];
         __syncthreads();
-        cv_sprod(S, S.ws3, D.z);
+        cv_sprod(S, S.ws3, D.z, sh);
     }
     __syncthreads();
-    cv_scale2(S, S.lmbda, D.s, false);
-    cv_scale2(S, S.lmbda, D.z, false);
+    cv_scale2(S, S.lmbda, D.s, false, sh);
+    cv_scale2(S, S.lmbda, D.z, false, sh);
     __syncthreads();
-    const double ts = cv_maxstep(S, D.s, sh);
-    const double tz = cv_maxstep(S, D.z, sh);
+    // i01 == 1: also the eigenvalue decomposition of the 's' blocks of ds, dz (eigenvectors in place, eigenvalues in
+    // sigs, sigz), coneprog.py:1308-1318
+    const double ts = (i01 == 0) ? cv_maxstep(S, D.s, sh) : cv_maxstep_sigma(S, D.s, S.sigs, sh);
+    const double tz = (i01 == 0) ? cv_maxstep(S, D.z, sh) : cv_maxstep_sigma(S, D.z, S.sigz, sh);
     if (tid == 0) {
         const double lg = sc[LP_LG];
         const double dtau = sc[D.itau], dkappa = sc[D.ikappa];
@@ -411,18 +419,22 @@ __global__ __launch_bounds__(256) void lp_update_kernel(LpState S, LpBuf D) {
     for (int i = tid; i < n; i += 256) S.x[i] += step * D.x[i];
     for (int i = tid; i < p; i += 256) S.y[i] += step * D.y[i];
     // ds := e + step ds, dz := e + step dz; then H(lambda)^{-1/2}: the updated variables in the current scaling
-    for (int i = tid; i < m; i += 256) {
+    // ('s' blocks: ds, dz hold the eigenvectors Qs, Qz; they become the factors Ls, Lz of the updated variables in the
+    // current scaling, coneprog.py:1348-1395)
+    for (int i = tid; i < S.lq; i += 256) {
         D.s[i] *= step;
         D.z[i] *= step;
     }
     __syncthreads();
-    cv_add_e(S, D.s, 1.0);
-    cv_add_e(S, D.z, 1.0);
+    cv_add_e(S, D.s, 1.0, false);
+    cv_add_e(S, D.z, 1.0, false);
     __syncthreads();
-    cv_scale2(S, S.lmbda, D.s, true);
-    cv_scale2(S, S.lmbda, D.z, true);
+    cv_scale2(S, S.lmbda, D.s, true, sh);
+    cv_scale2(S, S.lmbda, D.z, true, sh);
+    cv_s_factors(S, S.lmbda, D.s, S.sigs, step);
+    cv_s_factors(S, S.lmbda, D.z, S.sigz, step);
     __syncthreads();
-    cv_update_scaling(S, S.lmbda, D.s, D.z);
+    cv_update_scaling(S, S.lmbda, D.s, D.z, sh);
     __syncthreads();
     if (tid == 0) {
         const double tt = sc[LP_TT], tk = sc[LP_TK];
@@ -436,21 +448,23 @@ __global__ __launch_bounds__(256) void lp_update_kernel(LpState S, LpBuf D) {
         sc[LP_TAU] = lg * dgi;
     }
     // unscale: s = W' lmbda, z = W^-1 lmbda
-    for (int i = tid; i < m; i += 256) {
-        S.s[i] = S.lmbda[i];
-        S.z[i] = S.lmbda[i];
-    }
+    cv_expand(S, S.s, S.lmbda);
+    cv_expand(S, S.z, S.lmbda);
     __syncthreads();
-    cv_scale(S, S.s, false);
-    cv_scale(S, S.z, true);
-    const double g = lp_dot(S.lmbda, S.lmbda, m, sh);
+    cv_scale(S, S.s, false, true, sh);
+    cv_scale(S, S.z, true, false, sh);
+    const double g = lp_dot(S.lmbda, S.lmbda, S.ldim, sh);
     if (tid == 0) {
         const double r = sqrt(g) / sc[LP_TAU];
         sc[LP_GAP] = r * r;
     }
 }
 
+// upper triangles of the 's' blocks of a KKT-solve result := lower triangles
+__global__ __launch_bounds__(256) void lp_symm_kernel(LpState S, double* z) { cv_symm(S, z); }
+
 #define LP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(256), 0, st, __VA_ARGS__)
+void lp_launch_symm(const LpState& S, double* z, hipStream_t st) { if (S.ns > 0) LP1(lp_symm_kernel, S, z); }
 void lp_launch_unit_scaling(const LpState& S, hipStream_t st) { LP1(lp_unit_scaling_kernel, S); }
 void lp_launch_init_primal(const LpState& S, hipStream_t st) { LP1(lp_init_primal_kernel, S); }
 void lp_launch_init_dual(const LpState& S, double abstol, double reltol, hipStream_t st) { LP1(lp_init_dual_kernel, S, abstol, reltol); }

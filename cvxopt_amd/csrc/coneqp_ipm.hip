@@ -32,9 +32,13 @@ __device__ __forceinline__ void qp_store_result(const QpState& S, int status, in
 __global__ __launch_bounds__(256) void qp_unit_scaling_kernel(QpState S) {
     const int tid = threadIdx.x;
     for (int i = tid; i < S.ml; i += 256) { S.d[i] = 1.0; S.di[i] = 1.0; }
-    for (int i = tid; i < S.m - S.ml; i += 256) S.v[i] = 0.0;
+    for (int i = tid; i < S.lq - S.ml; i += 256) S.v[i] = 0.0;
     __syncthreads();
     for (int k = tid; k < S.nq; k += 256) { S.v[S.qoff[k] - S.ml] = 1.0; S.beta[k] = 1.0; }
+    for (int k = 0; k < S.ns; ++k) {                     // r_k = rti_k = I
+        const int mk = S.sdim[k], o = S.soff[k] - S.lq;
+        for (int e = tid; e < mk * mk; e += 256) S.r[o + e] = S.rti[o + e] = (e % mk == e / mk) ? 1.0 : 0.0;
+    }
 }
 
 __global__ __launch_bounds__(256) void qp_start_kernel(QpState S) {
@@ -130,13 +134,13 @@ __global__ __launch_bounds__(256) void qp_residual_kernel(QpState S, int it, int
     }
     if (tid == 0) atomicAdd(S.nactive, 1);
     if (it == 0) {
-        cv_compute_scaling(S, S.s, S.z, S.lmbda);
+        cv_compute_scaling(S, S.s, S.z, S.lmbda, sh);
         __syncthreads();
     }
     for (int i = tid; i < S.ml; i += 256) S.di[i] = 1.0 / S.d[i];
     cv_ssqr(S, S.lmbdasq, S.lmbda);
     if (tid == 0) {
-        sc[QP_MU] = gap / (double)(S.ml + S.nq);      // gap / (dims['l'] + len(dims['q']))
+        sc[QP_MU] = gap / (double)(S.ml + S.nq + (S.ldim - S.lq));   // gap / (dims['l'] + len(dims['q']) + sum(dims['s']))
         sc[QP_SIGMA] = 0.0;
     }
 }
@@ -154,10 +158,12 @@ __global__ __launch_bounds__(256) void qp_build_kernel(QpState S, QpBuf D, QpBuf
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     const double sigma = (i01 == 0) ? 0.0 : S.sc[QP_SIGMA];
     const double mu = S.sc[QP_MU];
+    cv_expand(S, D.s, S.lmbdasq);                   // 's' blocks: diag(lmbdasq_k) (:2386-2391)
+    __syncthreads();
     for (int i = tid; i < m; i += 256) {
         double v = 0.0;
         if (i01 == 1) v -= S.ws3[i];
-        v -= S.lmbdasq[i];
+        v -= D.s[i];
         D.s[i] = v;
         D.z[i] = -S.rz[i];
     }
@@ -188,12 +194,13 @@ __global__ __launch_bounds__(256) void qp_add_kernel(QpState S, QpBuf dst, QpBuf
 
 // f4_no_ir before the KKT solve (:2303-2309): s := lmbda o\ s; z := z - W's
 __global__ __launch_bounds__(256) void qp_f4pre_kernel(QpState S, QpBuf X) {
+    __shared__ double sh[4];
     const int tid = threadIdx.x, m = S.m;
-    cv_sinv(S, X.s, S.lmbda);
+    cv_sinv(S, X.s, S.lmbda, sh);
     __syncthreads();
     for (int i = tid; i < m; i += 256) S.t1[i] = X.s[i];
     __syncthreads();
-    cv_scale(S, S.t1, false);
+    cv_scale(S, S.t1, false, true, sh);             // misc.scale(ws3, W, trans = 'T')
     __syncthreads();
     for (int i = tid; i < m; i += 256) X.z[i] -= S.t1[i];
 }
@@ -204,12 +211,14 @@ __global__ __launch_bounds__(256) void qp_f4post_kernel(QpState S, QpBuf X) {
 
 // res() (:1930-1961), first half: wz3 = W^-1 uz (products with P, A', G', A, G launched by the host in between)
 __global__ __launch_bounds__(256) void qp_res_a_kernel(QpState S, QpBuf U) {
+    __shared__ double sh[4];
     for (int i = threadIdx.x; i < S.m; i += 256) S.wz3[i] = U.z[i];
     __syncthreads();
-    cv_scale(S, S.wz3, true);
+    cv_scale(S, S.wz3, true, false, sh);            // misc.scale(wz3, W, inverse = 'I')
 }
 // second half: S.Px = P ux, S.ATy = A' uy, S.GTz = G' wz3, S.Ax = A ux, S.Gx = G ux are in place
 __global__ __launch_bounds__(256) void qp_res_b_kernel(QpState S, QpBuf U, QpBuf V) {
+    __shared__ double sh[4];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     for (int i = tid; i < n; i += 256) {
         double v = V.x[i] - S.Px[i];
@@ -223,8 +232,8 @@ __global__ __launch_bounds__(256) void qp_res_b_kernel(QpState S, QpBuf U, QpBuf
         S.t2[i] = U.s[i] + U.z[i];                  // lmbda o (uz + us)
     }
     __syncthreads();
-    cv_scale(S, S.t1, false);
-    cv_sprod(S, S.t2, S.lmbda);
+    cv_scale(S, S.t1, false, true, sh);             // misc.scale(ws3, W, trans = 'T')
+    cv_sprod_diag(S, S.t2, S.lmbda, sh);            // misc.sprod(ws3, lmbda, dims, diag = 'D')
     __syncthreads();
     for (int i = tid; i < m; i += 256) {
         V.z[i] = V.z[i] - S.Gx[i] - S.t1[i];
@@ -240,14 +249,15 @@ __global__ __launch_bounds__(256) void qp_step_kernel(QpState S, QpBuf D, int i0
     if (i01 == 0) {
         for (int i = tid; i < m; i += 256) S.ws3[i] = D.s[i];
         __syncthreads();
-        cv_sprod(S, S.ws3, D.z);
+        cv_sprod(S, S.ws3, D.z, sh);
     }
     __syncthreads();
-    cv_scale2(S, S.lmbda, D.s, false);
-    cv_scale2(S, S.lmbda, D.z, false);
+    cv_scale2(S, S.lmbda, D.s, false, sh);
+    cv_scale2(S, S.lmbda, D.z, false, sh);
     __syncthreads();
-    const double ts = cv_maxstep(S, D.s, sh);
-    const double tz = cv_maxstep(S, D.z, sh);
+    // i01 == 1: also the eigenvalue decomposition of the 's' blocks of ds, dz (:2427-2437)
+    const double ts = (i01 == 0) ? cv_maxstep(S, D.s, sh) : cv_maxstep_sigma(S, D.s, S.sigs, sh);
+    const double tz = (i01 == 0) ? cv_maxstep(S, D.z, sh) : cv_maxstep_sigma(S, D.z, S.sigz, sh);
     if (tid == 0) {
         const double t = fmax(0.0, fmax(ts, tz));
         const double step = (t == 0.0) ? 1.0 : fmin(1.0, (i01 == 0 ? 1.0 : 0.99) / t);
@@ -267,31 +277,37 @@ __global__ __launch_bounds__(256) void qp_update_kernel(QpState S, QpBuf D) {
     const double step = S.sc[QP_STEP];
     for (int i = tid; i < S.n; i += 256) S.x[i] += step * D.x[i];
     for (int i = tid; i < S.p; i += 256) S.y[i] += step * D.y[i];
-    for (int i = tid; i < m; i += 256) {
+    // ('s' blocks: ds, dz hold the eigenvectors Qs, Qz; they become the factors Ls, Lz of the updated variables in the
+    // current scaling, :2459-2501)
+    for (int i = tid; i < S.lq; i += 256) {
         D.s[i] *= step;
         D.z[i] *= step;
     }
     __syncthreads();
-    cv_add_e(S, D.s, 1.0);
-    cv_add_e(S, D.z, 1.0);
+    cv_add_e(S, D.s, 1.0, false);
+    cv_add_e(S, D.z, 1.0, false);
     __syncthreads();
-    cv_scale2(S, S.lmbda, D.s, true);
-    cv_scale2(S, S.lmbda, D.z, true);
+    cv_scale2(S, S.lmbda, D.s, true, sh);
+    cv_scale2(S, S.lmbda, D.z, true, sh);
+    cv_s_factors(S, S.lmbda, D.s, S.sigs, step);
+    cv_s_factors(S, S.lmbda, D.z, S.sigz, step);
     __syncthreads();
-    cv_update_scaling(S, S.lmbda, D.s, D.z);
+    cv_update_scaling(S, S.lmbda, D.s, D.z, sh);
     __syncthreads();
-    for (int i = tid; i < m; i += 256) {
-        S.s[i] = S.lmbda[i];
-        S.z[i] = S.lmbda[i];
-    }
+    cv_expand(S, S.s, S.lmbda);
+    cv_expand(S, S.z, S.lmbda);
     __syncthreads();
-    cv_scale(S, S.s, false);
-    cv_scale(S, S.z, true);
-    const double g = lp_dot(S.lmbda, S.lmbda, m, sh);
+    cv_scale(S, S.s, false, true, sh);
+    cv_scale(S, S.z, true, false, sh);
+    const double g = lp_dot(S.lmbda, S.lmbda, S.ldim, sh);
     if (tid == 0) S.sc[QP_GAP] = g;
 }
 
+// upper triangles of the 's' blocks of a KKT-solve result := lower triangles
+__global__ __launch_bounds__(256) void qp_symm_kernel(QpState S, double* z) { cv_symm(S, z); }
+
 #define QP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(256), 0, st, __VA_ARGS__)
+void qp_launch_symm(const QpState& S, double* z, hipStream_t st) { if (S.ns > 0) QP1(qp_symm_kernel, S, z); }
 void qp_launch_unit_scaling(const QpState& S, hipStream_t st) { QP1(qp_unit_scaling_kernel, S); }
 void qp_launch_start(const QpState& S, hipStream_t st) { QP1(qp_start_kernel, S); }
 void qp_launch_residual(const QpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st) {

@@ -265,8 +265,14 @@ enum LpScalar {
 };
 struct LpBuf { double *x, *y, *z, *s; int itau, ikappa; };   // one (x, y, z, tau, s, kappa) sextuple of f6 / res
 struct LpState {
-    int n = 0, m = 0, p = 0, ml = 0, nq = 0;          // m = ml + sum(q)
+    int n = 0, m = 0, p = 0, ml = 0, nq = 0;          // m = ml + sum(q) + sum(s_k^2)
     const int *qoff = nullptr, *qdim = nullptr;       // per cone: offset into the cone vectors, dimension
+    // 's' blocks (cone_ops_s.h): block k is sdim[k] x sdim[k], full symmetric storage, at soff[k] of the cone vectors, at
+    // sloff[k] of lmbda (compact layout: sdim[k] entries), at soff[k] - lq of r / rti / sw1..3, at sloff[k] - lq of sigs / sigz
+    int ns = 0, lq = 0, ldim = 0;                     // lq = ml + sum(q); ldim = lq + sum(s) = length of lmbda
+    const int *sdim = nullptr, *soff = nullptr, *sloff = nullptr;
+    double *r = nullptr, *rti = nullptr, *sw1 = nullptr, *sw2 = nullptr, *sw3 = nullptr, *jw = nullptr, *sigs = nullptr,
+           *sigz = nullptr;
     double *c = nullptr, *x = nullptr, *dx = nullptr, *rx = nullptr, *x1 = nullptr, *GTz = nullptr, *ATy = nullptr,
            *x_out = nullptr, *wx = nullptr, *wx2 = nullptr;                          // [n]
     double *b = nullptr, *y = nullptr, *dy = nullptr, *ry = nullptr, *y1 = nullptr, *Ax = nullptr, *y_out = nullptr,
@@ -294,6 +300,7 @@ void lp_launch_res_a(const LpState& S, const LpBuf& U, hipStream_t st);
 void lp_launch_res_b(const LpState& S, const LpBuf& U, const LpBuf& V, hipStream_t st);
 void lp_launch_step(const LpState& S, const LpBuf& D, int i01, hipStream_t st);
 void lp_launch_update(const LpState& S, const LpBuf& D, hipStream_t st);
+void lp_launch_symm(const LpState& S, double* z, hipStream_t st);   // no-op without 's' blocks
 
 // ---- device-resident coneqp loop for one problem, 'l' + 'q' cones (coneqp_ipm.hip) ------------------------
 enum QpScalar {
@@ -302,8 +309,14 @@ enum QpScalar {
 };
 struct QpBuf { double *x, *y, *z, *s; };            // one (x, y, z, s) quadruple of f4 / res
 struct QpState {
-    int n = 0, m = 0, p = 0, ml = 0, nq = 0;          // m = ml + sum(q)
+    int n = 0, m = 0, p = 0, ml = 0, nq = 0;          // m = ml + sum(q) + sum(s_k^2)
     const int *qoff = nullptr, *qdim = nullptr;
+    // 's' blocks (cone_ops_s.h): block k is sdim[k] x sdim[k], full symmetric storage, at soff[k] of the cone vectors, at
+    // sloff[k] of lmbda (compact layout: sdim[k] entries), at soff[k] - lq of r / rti / sw1..3, at sloff[k] - lq of sigs / sigz
+    int ns = 0, lq = 0, ldim = 0;                     // lq = ml + sum(q); ldim = lq + sum(s) = length of lmbda
+    const int *sdim = nullptr, *soff = nullptr, *sloff = nullptr;
+    double *r = nullptr, *rti = nullptr, *sw1 = nullptr, *sw2 = nullptr, *sw3 = nullptr, *jw = nullptr, *sigs = nullptr,
+           *sigz = nullptr;
     double *q = nullptr, *x = nullptr, *dx = nullptr, *rx = nullptr, *Px = nullptr, *GTz = nullptr, *ATy = nullptr,
            *x_out = nullptr, *wx = nullptr, *wx2 = nullptr;                          // [n]
     double *b = nullptr, *y = nullptr, *dy = nullptr, *ry = nullptr, *Ax = nullptr, *y_out = nullptr, *wy = nullptr,
@@ -328,5 +341,6 @@ void qp_launch_res_a(const QpState& S, const QpBuf& U, hipStream_t st);
 void qp_launch_res_b(const QpState& S, const QpBuf& U, const QpBuf& V, hipStream_t st);
 void qp_launch_step(const QpState& S, const QpBuf& D, int i01, hipStream_t st);
 void qp_launch_update(const QpState& S, const QpBuf& D, hipStream_t st);
+void qp_launch_symm(const QpState& S, double* z, hipStream_t st);   // no-op without 's' blocks
 
 }  // namespace mi355kkt

@@ -444,19 +444,23 @@ class _Engine(object):
                 'iterations': iters.value}
 
     def _slack(self, v):
-        """-max_step(v) (misc.py:1018-1052): min over the 'l' entries and v0 - ||v1|| per second-order cone"""
+        """-max_step(v) (misc.py:1018-1052): min over the 'l' entries, v0 - ||v1|| per second-order cone, the smallest
+        eigenvalue per 's' block (a handful of small host eigenvalue problems on the RESULT; the loop itself ran on the device)"""
         t = [float(np.min(v[:self.dims['l']]))] if self.dims['l'] else []
         ind = self.dims['l']
         for mk in self.dims['q']:
             t.append(float(v[ind] - np.linalg.norm(v[ind + 1:ind + mk])))
             ind += mk
+        for mk in self.dims['s']:
+            if mk:
+                t.append(float(np.linalg.eigvalsh(v[ind:ind + mk * mk].reshape(mk, mk, order='F'), UPLO='L')[0]))
+            ind += mk * mk
         return min(t) if t else 0.0
 
     def coneqp_cones(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None):
-        """The reference coneqp loop (coneprog.py:2044-2547) for 'l' and 'q' cones resident on the device around this
-        handle (`mi355kkt_coneqp`; refinement 1 with second-order cones like the reference)."""
-        if self.dims['s']:
-            raise NotImplementedError("device-resident coneqp: 'l' and 'q' cones only (use cvxopt_amd.solvers.coneqp)")
+        """The reference coneqp loop (coneprog.py:2044-2547) for 'l', 'q' and 's' cones resident on the device around this
+        handle (`mi355kkt_coneqp`; refinement 1 with second-order or semidefinite cones like the reference).  'q' / 's' cones
+        run on the dense engine; the 's' blocks of h, s, z are in the reference's unpacked storage (s, z returned symmetric)."""
         self._set_H(P)
         n, m, p = self.n, self.cdim, self.p
         qv = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1))
@@ -481,14 +485,13 @@ class _Engine(object):
                 'dual slack': self._slack(z), 'iterations': iters.value}
 
     def conelp(self, c, h, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None, kktreg=None):
-        """The reference conelp loop (coneprog.py:586-1436; 'l' and 'q' cones, default starting point) resident on the
+        """The reference conelp loop (coneprog.py:586-1436; 'l', 'q' and 's' cones, default starting point) resident on the
         device around this handle (`mi355kkt_conelp`).  Returns a dict with the reference's keys and conventions
         (None entries for the infeasibility-certificate cases), vectors as NumPy arrays."""
-        if self.dims['s']:
-            raise NotImplementedError("device-resident conelp: 'l' and 'q' cones only (use cvxopt_amd.solvers.conelp)")
         self._set_H(None)
         n, m, p = self.n, self.cdim, self.p
-        if kktreg is None and (p > n or p + m < n):
+        cdim_pckd = self.dims['l'] + sum(self.dims['q']) + sum(k * (k + 1) // 2 for k in self.dims['s'])
+        if kktreg is None and (p > n or p + cdim_pckd < n):
             raise ValueError("Rank(A) < p or Rank([G; A]) < n")           # coneprog.py:572-573
         cv = np.ascontiguousarray(np.asarray(c, dtype=np.float64).reshape(-1))
         hv = np.ascontiguousarray(np.asarray(h, dtype=np.float64).reshape(-1))
@@ -571,14 +574,14 @@ def _factory(kind, G, dims, A, mnl=0, kktreg=None):
 
 def conelp_device(c, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters=100, abstol=1e-7, reltol=1e-6,
                   feastol=1e-7, refinement=None, kktreg=None, show_progress=False):
-    """min c'x  s.t.  Gx <=_K h, Ax = b,  K = R^l_+ x second-order cones (`solvers.conelp` / `lp` / `socp`) with the whole
-    self-dual interior-point loop on the MI355X.  Iterates match `solvers.conelp(c, G, h, dims[, A=A, b=b])`."""
+    """min c'x  s.t.  Gx <=_K h, Ax = b,  K = R^l_+ x second-order cones x positive semidefinite cones (`solvers.conelp` / `lp` /
+    `socp` / `sdp`) with the whole self-dual interior-point loop on the MI355X.  Iterates match `solvers.conelp(c, G, h, dims[, A=A, b=b])`."""
     kind = {'chol2': _capi.CHOL2, 'chol': _capi.CHOL, 'ldl': _capi.LDL, 'ldl2': _capi.LDL2, 'qr': _capi.CHOL}[kktsolver]
     m, n = _size(G)
     if dims is None:
         dims = {'l': m, 'q': [], 's': []}
     dims = {'l': int(dims['l']), 'q': [int(k) for k in dims['q']], 's': [int(k) for k in dims['s']]}
-    if kind == _capi.CHOL2 and dims['q']:
+    if kind == _capi.CHOL2 and (dims['q'] or dims['s']):
         kind = _capi.CHOL
     eng = _Engine(kind, G, dims, A if A is not None else _EmptyA(n), kktreg=kktreg if kind == _capi.LDL else None)
     try:
@@ -607,14 +610,14 @@ def _final_line(sol, maxiters):
 
 def coneqp_device(P, q, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters=100, abstol=1e-7, reltol=1e-6,
                   feastol=1e-7, refinement=None, kktreg=None, show_progress=False):
-    """min 1/2 x'Px + q'x  s.t.  Gx <=_K h, Ax = b,  K = R^l_+ x second-order cones, with the whole interior-point loop
-    on the MI355X.  Iterates match `solvers.coneqp(P, q, G, h, dims[, A, b])`."""
+    """min 1/2 x'Px + q'x  s.t.  Gx <=_K h, Ax = b,  K = R^l_+ x second-order cones x positive semidefinite cones, with the whole
+    interior-point loop on the MI355X.  Iterates match `solvers.coneqp(P, q, G, h, dims[, A, b])`."""
     kind = {'chol2': _capi.CHOL2, 'chol': _capi.CHOL, 'ldl': _capi.LDL, 'ldl2': _capi.LDL2}[kktsolver]
     m, n = _size(G)
     if dims is None:
         dims = {'l': m, 'q': [], 's': []}
     dims = {'l': int(dims['l']), 'q': [int(k) for k in dims['q']], 's': [int(k) for k in dims['s']]}
-    if kind == _capi.CHOL2 and dims['q']:
+    if kind == _capi.CHOL2 and (dims['q'] or dims['s']):
         kind = _capi.CHOL
     eng = _Engine(kind, G, dims, A if A is not None else _EmptyA(n), kktreg=kktreg if kind == _capi.LDL else None)
     try:

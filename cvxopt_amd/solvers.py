@@ -109,8 +109,8 @@ def _resolve_kktsolver(kktsolver, dims, lp):
 
 def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None, kktsolver=None, device_loop='auto',
            **kwargs):
-    """cvxopt.solvers.conelp on the MI355X, same signature and result dict.  Without 's' cones and with the default
-    starting point the whole loop runs on the device (`mi355kkt_conelp`); otherwise the reference driver runs on the
+    """cvxopt.solvers.conelp on the MI355X, same signature and result dict.  With the default starting point the whole
+    loop runs on the device (`mi355kkt_conelp`, all three cone types); otherwise the reference driver runs on the
     host with G, A as device operators and the GPU kktsolver ('chol' | 'chol2' | 'ldl' | 'ldl2')."""
     from cvxopt import solvers, spmatrix
     dims = _dims_of(h, dims)
@@ -123,8 +123,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
         ks_name = 'chol'
     extra = set(kwargs) - {'options'}
     o, kktreg, debug = _options(kwargs)
-    if device_loop and not dims['s'] and primalstart is None and dualstart is None and not extra \
-            and not debug and (dims['l'] + sum(dims['q'])) > 0:
+    if device_loop and primalstart is None and dualstart is None and not extra \
+            and not debug and (dims['l'] + sum(dims['q']) + sum(dims['s'])) > 0:
         return _as_cvxopt(_kkt.conelp_device(c, G, h, dims, A, b, kktsolver=ks_name, **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
     ks = _kkt.kktsolver_lp(G, dims, Am, kind={'qr': 'chol'}.get(ks_name, ks_name), kktreg=kktreg)
@@ -142,8 +142,8 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
 
 def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktsolver=None, device_loop='auto',
            **kwargs):
-    """cvxopt.solvers.coneqp on the MI355X, same signature and result dict.  Without 's' cones and initvals the whole loop
-    runs on the device (`mi355kkt_coneqp`); otherwise the reference driver runs with P, G, A as device operators."""
+    """cvxopt.solvers.coneqp on the MI355X, same signature and result dict.  Without initvals the whole loop runs on the
+    device (`mi355kkt_coneqp`, all three cone types); otherwise the reference driver runs with P, G, A as device operators."""
     from cvxopt import solvers, spmatrix, matrix
     n = q.size[0]
     if G is None:
@@ -156,8 +156,8 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
         ks_name = 'chol'                        # kkt_chol2 is LP-cone only (misc.py:1381-1384); the reference's own default here
     extra = set(kwargs) - {'options'}
     o, kktreg, debug = _options(kwargs)
-    if device_loop and not dims['s'] and initvals is None and not extra and not debug \
-            and (dims['l'] + sum(dims['q'])) > 0:
+    if device_loop and initvals is None and not extra and not debug \
+            and (dims['l'] + sum(dims['q']) + sum(dims['s'])) > 0:
         return _as_cvxopt(_kkt.coneqp_device(P, q, G, h, dims, A, b, kktsolver=ks_name, **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
     ks = _kkt.kktsolver_qp(G, dims, Am, P, kind=ks_name, kktreg=kktreg)
