@@ -147,14 +147,18 @@ struct SBlocks {
     explicit SBlocks(const std::vector<int>& s) : ns((int)s.size()) {
         for (int k : s) { sums += k; sums2 += k * k; maxs = std::max(maxs, k); }
     }
-    size_t doubles() const { return ns ? 5 * (size_t)sums2 + 2 * (size_t)sums + s_jw_doubles(maxs, 256) + 8 : 8; }
+    size_t doubles() const { return ns ? 5 * (size_t)sums2 + 2 * (size_t)sums + s_jw_doubles(maxs, 1024) + 8 : 8; }
 };
 template <class ST>
 static int sblocks_bind(ST& S, const SBlocks& sb, const std::vector<int>& s, int lq, double*& p, int* di) {
     S.ns = sb.ns; S.lq = lq; S.ldim = lq + sb.sums;
+    // with 's' blocks: 1024 threads (16 waves rotate 16 column pairs of a Jacobi round at a time) and as much of the 160 KB
+    // LDS as G and V of the largest block need
+    S.nthreads = sb.ns ? 1024 : 256;
+    S.lds_doubles = sb.ns ? (int)std::min<size_t>(20416, 2 * (size_t)sb.maxs * sb.maxs) : 0;
     auto take = [&](size_t k) { double* r = p; p += (k ? k : 1); return r; };
     S.r = take(sb.sums2); S.rti = take(sb.sums2); S.sw1 = take(sb.sums2); S.sw2 = take(sb.sums2); S.sw3 = take(sb.sums2);
-    S.sigs = take(sb.sums); S.sigz = take(sb.sums); S.jw = take(sb.ns ? s_jw_doubles(sb.maxs, 256) : 1);
+    S.sigs = take(sb.sums); S.sigz = take(sb.sums); S.jw = take(sb.ns ? s_jw_doubles(sb.maxs, 1024) : 1);
     S.sdim = di; S.soff = di + sb.ns; S.sloff = di + 2 * sb.ns;
     if (sb.ns) {
         std::vector<int> h(3 * (size_t)sb.ns);

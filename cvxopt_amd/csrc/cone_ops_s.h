@@ -31,45 +31,67 @@ struct ParHost {   // team of one (host tests)
     __host__ __device__ void sync() const {}
     __host__ __device__ double sum(double v) const { return v; }
     __host__ __device__ double max(double v) const { return v; }
+    template <class = void>
+    __host__ __device__ void jacobi(double* G, double* V, int m, double* jw) const;
 };
 
 // scratch doubles s_jacobi / s_sort need for blocks of order <= maxm with a team of nt threads
 __host__ __device__ inline size_t s_jw_doubles(int maxm, int nt) {
     const size_t np = (size_t)(maxm + 1) / 2 + 1;
     const size_t nw = np > (size_t)nt ? np : (size_t)nt;
-    return 3 * nw + 3 * np + 2 * (size_t)maxm + 16;
+    return 3 * nw + 3 * np + 3 * (size_t)maxm + 16;
 }
 
 // ---- small dense helpers ---------------------------------------------------------------------------------------
-// C := op(A) op(B), all m x m; C must not alias A or B
+// C := op(A) op(B), all m x m; C must not alias A or B.  4 x 4 register tiles per thread: a quarter of the loads per
+// multiply-add of the element-per-thread form (the single workgroup is bound by load latency, not by arithmetic).
+// sym: the result is known to be symmetric -- tiles strictly above the diagonal are skipped, the lower triangle mirrored.
 template <class P>
-__host__ __device__ inline void s_gemm(const P& par, double* C, const double* A, bool tA, const double* B, bool tB, int m) {
-    const int mm = m * m;
-    for (int e = par.tid(); e < mm; e += par.nt()) {
-        const int i = e % m, j = e / m;
-        double acc = 0.0;
+__host__ __device__ inline void s_gemm_tiles(const P& par, double* C, const double* A, bool tA, const double* B, bool tB, int m,
+                                             bool sym) {
+    const int tm = (m + 3) / 4, ntile = tm * tm;
+    for (int t = par.tid(); t < ntile; t += par.nt()) {
+        const int i0 = (t % tm) * 4, j0 = (t / tm) * 4;
+        if (sym && j0 > i0 + 3) continue;
+        double acc[4][4];
+        for (int ii = 0; ii < 4; ++ii)
+            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
+        const bool full = (i0 + 4 <= m) && (j0 + 4 <= m);
         for (int k = 0; k < m; ++k) {
-            const double a = tA ? A[k + i * m] : A[i + k * m];
-            const double b = tB ? B[j + k * m] : B[k + j * m];
-            acc += a * b;
+            double a[4], b[4];
+            if (full) {
+                for (int ii = 0; ii < 4; ++ii) a[ii] = tA ? A[k + (size_t)(i0 + ii) * m] : A[i0 + ii + (size_t)k * m];
+                for (int jj = 0; jj < 4; ++jj) b[jj] = tB ? B[j0 + jj + (size_t)k * m] : B[k + (size_t)(j0 + jj) * m];
+            } else {
+                for (int ii = 0; ii < 4; ++ii)
+                    a[ii] = (i0 + ii < m) ? (tA ? A[k + (size_t)(i0 + ii) * m] : A[i0 + ii + (size_t)k * m]) : 0.0;
+                for (int jj = 0; jj < 4; ++jj)
+                    b[jj] = (j0 + jj < m) ? (tB ? B[j0 + jj + (size_t)k * m] : B[k + (size_t)(j0 + jj) * m]) : 0.0;
+            }
+            for (int ii = 0; ii < 4; ++ii)
+                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += a[ii] * b[jj];
         }
-        C[e] = acc;
+        for (int ii = 0; ii < 4; ++ii)
+            for (int jj = 0; jj < 4; ++jj) {
+                const int i = i0 + ii, j = j0 + jj;
+                if (i >= m || j >= m) continue;
+                if (!sym) C[i + (size_t)j * m] = acc[ii][jj];
+                else if (i >= j) {
+                    C[i + (size_t)j * m] = acc[ii][jj];
+                    C[j + (size_t)i * m] = acc[ii][jj];
+                }
+            }
     }
     par.sync();
 }
-// C := op(A) B for a result known to be symmetric: the lower triangle is computed and mirrored
+template <class P>
+__host__ __device__ inline void s_gemm(const P& par, double* C, const double* A, bool tA, const double* B, bool tB, int m) {
+    s_gemm_tiles(par, C, A, tA, B, tB, m, false);
+}
+// C := op(A) B for a result known to be symmetric
 template <class P>
 __host__ __device__ inline void s_gemm_sym(const P& par, double* C, const double* A, bool tA, const double* B, int m) {
-    const int mm = m * m;
-    for (int e = par.tid(); e < mm; e += par.nt()) {
-        const int i = e % m, j = e / m;
-        if (i < j) continue;
-        double acc = 0.0;
-        for (int k = 0; k < m; ++k) acc += (tA ? A[k + i * m] : A[i + k * m]) * B[k + j * m];
-        C[i + j * m] = acc;
-        C[j + i * m] = acc;
-    }
-    par.sync();
+    s_gemm_tiles(par, C, A, tA, B, false, m, true);
 }
 template <class P>
 __host__ __device__ inline void s_copy(const P& par, double* dst, const double* src, int n) {
@@ -135,14 +157,98 @@ __host__ __device__ inline void s_pair(int i, int r, int M, int& p, int& q) {
     if (i == 0) {
         p = M - 1;
         q = r;
-    } else {
-        p = (r + i) % (M - 1);
-        q = (r + M - 1 - i) % (M - 1);
+    } else {                       // (r + i) mod (M - 1), (r - i) mod (M - 1): both operands < 2 (M - 1), no division
+        p = r + i;
+        if (p >= M - 1) p -= M - 1;
+        q = r + M - 1 - i;
+        if (q >= M - 1) q -= M - 1;
     }
 }
 
+// The rotations of the one-sided Jacobi iteration, generic team version (barrier-separated phases: partial dot products of
+// every pair over row chunks, one rotation per pair, rotation of the columns).  jw: s_jw_doubles(m, nt) doubles of scratch.
+template <class P>
+__host__ __device__ inline void s_jacobi_rotations(const P& par, double* G, double* V, int m, double* jw) {
+    const int M = m + (m & 1), np = M / 2;
+    int nchunk = par.nt() / np;
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > (m + 7) / 8) nchunk = (m + 7) / 8;      // at least ~8 rows per partial sum
+    const int nw = np * nchunk;
+    double* part = jw;                                   // [nw][3] partial (alpha, beta, gamma)
+    double* cs = jw + 3 * (size_t)(nw > par.nt() ? nw : par.nt());   // [np][3]: c, s, rotated
+    const double tol = fmax(1e-15, 4.5e-16 * sqrt((double)m));
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double myrot = 0.0;
+        for (int r = 0; r < M - 1; ++r) {
+            for (int w = par.tid(); w < nw; w += par.nt()) {
+                const int i = w / nchunk, c = w % nchunk;
+                int p, q;
+                s_pair(i, r, M, p, q);
+                double al = 0.0, be = 0.0, ga = 0.0;
+                if (p < m && q < m) {
+                    const int r0 = (int)((long long)m * c / nchunk), r1 = (int)((long long)m * (c + 1) / nchunk);
+                    const double *gp = G + (size_t)p * m, *gq = G + (size_t)q * m;
+                    for (int k = r0; k < r1; ++k) {
+                        const double a = gp[k], b = gq[k];
+                        al += a * a;
+                        be += b * b;
+                        ga += a * b;
+                    }
+                }
+                part[3 * w] = al;
+                part[3 * w + 1] = be;
+                part[3 * w + 2] = ga;
+            }
+            par.sync();
+            for (int i = par.tid(); i < np; i += par.nt()) {
+                double al = 0.0, be = 0.0, ga = 0.0;
+                for (int c = 0; c < nchunk; ++c) {
+                    al += part[3 * (i * nchunk + c)];
+                    be += part[3 * (i * nchunk + c) + 1];
+                    ga += part[3 * (i * nchunk + c) + 2];
+                }
+                double cc = 1.0, ss = 0.0;
+                if (fabs(ga) > tol * sqrt(al) * sqrt(be) && al > 0.0 && be > 0.0) {
+                    const double zeta = (be - al) / (2.0 * ga);
+                    const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    cc = 1.0 / sqrt(1.0 + t * t);
+                    ss = cc * t;
+                    myrot = 1.0;
+                }
+                cs[3 * i] = cc;
+                cs[3 * i + 1] = ss;
+            }
+            par.sync();
+            const int nwork = np * m;
+            for (int w = par.tid(); w < nwork; w += par.nt()) {
+                const int i = w / m, k = w % m;
+                const double cc = cs[3 * i], ss = cs[3 * i + 1];
+                if (ss == 0.0) continue;
+                int p, q;
+                s_pair(i, r, M, p, q);
+                const double a = G[k + (size_t)p * m], b = G[k + (size_t)q * m];
+                G[k + (size_t)p * m] = cc * a - ss * b;
+                G[k + (size_t)q * m] = ss * a + cc * b;
+                if (V) {
+                    const double va = V[k + (size_t)p * m], vb = V[k + (size_t)q * m];
+                    V[k + (size_t)p * m] = cc * va - ss * vb;
+                    V[k + (size_t)q * m] = ss * va + cc * vb;
+                }
+            }
+            par.sync();
+        }
+        if (par.max(myrot) == 0.0) break;
+    }
+}
+
+template <class>
+__host__ __device__ inline void ParHost::jacobi(double* G, double* V, int m, double* jw) const {
+    s_jacobi_rotations(*this, G, V, m, jw);
+}
+
 // On entry G = B (m x m).  On exit G = B V with mutually orthogonal columns (= U diag(sig)), V orthogonal (accumulated
-// when V != nullptr), sig[j] = ||G(:, j)||.  jw: s_jw_doubles(m, nt) doubles of scratch.
+// when V != nullptr), sig[j] = ||G(:, j)||.  The rotations are the team's own (P::jacobi): s_jacobi_rotations for the
+// generic team, one column pair per wave for a workgroup (cone_ops.h, s_jacobi_waves).
 template <class P>
 __host__ __device__ inline void s_jacobi(const P& par, double* G, double* V, double* sig, int m, double* jw) {
     const int mm = m * m;
@@ -150,78 +256,7 @@ __host__ __device__ inline void s_jacobi(const P& par, double* G, double* V, dou
         for (int e = par.tid(); e < mm; e += par.nt()) V[e] = (e % m == e / m) ? 1.0 : 0.0;
     }
     par.sync();
-    if (m > 1) {
-        const int M = m + (m & 1), np = M / 2;
-        int nchunk = par.nt() / np;
-        if (nchunk < 1) nchunk = 1;
-        if (nchunk > (m + 7) / 8) nchunk = (m + 7) / 8;      // at least ~8 rows per partial sum
-        const int nw = np * nchunk;
-        double* part = jw;                                   // [nw][3] partial (alpha, beta, gamma)
-        double* cs = jw + 3 * (size_t)(nw > par.nt() ? nw : par.nt());   // [np][3]: c, s, rotated
-        const double tol = fmax(1e-15, 4.5e-16 * sqrt((double)m));
-        for (int sweep = 0; sweep < 60; ++sweep) {
-            double myrot = 0.0;
-            for (int r = 0; r < M - 1; ++r) {
-                for (int w = par.tid(); w < nw; w += par.nt()) {
-                    const int i = w / nchunk, c = w % nchunk;
-                    int p, q;
-                    s_pair(i, r, M, p, q);
-                    double al = 0.0, be = 0.0, ga = 0.0;
-                    if (p < m && q < m) {
-                        const int r0 = (int)((long long)m * c / nchunk), r1 = (int)((long long)m * (c + 1) / nchunk);
-                        const double *gp = G + (size_t)p * m, *gq = G + (size_t)q * m;
-                        for (int k = r0; k < r1; ++k) {
-                            const double a = gp[k], b = gq[k];
-                            al += a * a;
-                            be += b * b;
-                            ga += a * b;
-                        }
-                    }
-                    part[3 * w] = al;
-                    part[3 * w + 1] = be;
-                    part[3 * w + 2] = ga;
-                }
-                par.sync();
-                for (int i = par.tid(); i < np; i += par.nt()) {
-                    double al = 0.0, be = 0.0, ga = 0.0;
-                    for (int c = 0; c < nchunk; ++c) {
-                        al += part[3 * (i * nchunk + c)];
-                        be += part[3 * (i * nchunk + c) + 1];
-                        ga += part[3 * (i * nchunk + c) + 2];
-                    }
-                    double cc = 1.0, ss = 0.0;
-                    if (fabs(ga) > tol * sqrt(al) * sqrt(be) && al > 0.0 && be > 0.0) {
-                        const double zeta = (be - al) / (2.0 * ga);
-                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                        cc = 1.0 / sqrt(1.0 + t * t);
-                        ss = cc * t;
-                        myrot = 1.0;
-                    }
-                    cs[3 * i] = cc;
-                    cs[3 * i + 1] = ss;
-                }
-                par.sync();
-                const int nwork = np * m;
-                for (int w = par.tid(); w < nwork; w += par.nt()) {
-                    const int i = w / m, k = w % m;
-                    const double cc = cs[3 * i], ss = cs[3 * i + 1];
-                    if (ss == 0.0) continue;
-                    int p, q;
-                    s_pair(i, r, M, p, q);
-                    const double a = G[k + (size_t)p * m], b = G[k + (size_t)q * m];
-                    G[k + (size_t)p * m] = cc * a - ss * b;
-                    G[k + (size_t)q * m] = ss * a + cc * b;
-                    if (V) {
-                        const double va = V[k + (size_t)p * m], vb = V[k + (size_t)q * m];
-                        V[k + (size_t)p * m] = cc * va - ss * vb;
-                        V[k + (size_t)q * m] = ss * va + cc * vb;
-                    }
-                }
-                par.sync();
-            }
-            if (par.max(myrot) == 0.0) break;
-        }
-    }
+    if (m > 1) par.jacobi(G, V, m, jw);
     for (int j = par.tid(); j < m; j += par.nt()) {
         double a = 0.0;
         for (int k = 0; k < m; ++k) a += G[k + (size_t)j * m] * G[k + (size_t)j * m];
@@ -268,20 +303,12 @@ __host__ __device__ inline void s_scale_blk(const P& par, double* X, const doubl
     s_gemm(par, T, X, false, M, !mt, m);           // T = X M  or  X M'
     s_gemm_sym(par, X, M, mt, T, m);               // X = M' T or  M T
 }
-// misc_solvers.sprod, diag = 'N' (misc_solvers.c:716-741): X := (X Y + Y X) / 2
+// misc_solvers.sprod, diag = 'N' (misc_solvers.c:716-741): X := (X Y + Y X) / 2 = (T + T') / 2 with T = X Y (X, Y symmetric)
 template <class P>
 __host__ __device__ inline void s_sprod_blk(const P& par, double* X, const double* Y, int m, double* T) {
     const int mm = m * m;
-    s_copy(par, T, X, mm);
-    for (int e = par.tid(); e < mm; e += par.nt()) {
-        const int i = e % m, j = e / m;
-        if (i < j) continue;
-        double acc = 0.0;
-        for (int k = 0; k < m; ++k) acc += T[i + k * m] * Y[k + j * m] + Y[i + k * m] * T[k + j * m];
-        acc *= 0.5;
-        X[i + j * m] = acc;
-        X[j + i * m] = acc;
-    }
+    s_gemm(par, T, X, false, Y, false, m);
+    for (int e = par.tid(); e < mm; e += par.nt()) X[e] = 0.5 * (T[e] + T[(e / m) + (size_t)(e % m) * m]);
     par.sync();
 }
 // sprod, diag = 'D' (misc_solvers.c:743-762): X_ij *= (y_i + y_j) / 2;   sinv (:858-876): X_ij /= (y_i + y_j) / 2
@@ -327,18 +354,29 @@ __host__ __device__ inline double s_min_eig_blk(const P& par, const double* X, i
     return -par.max(-lo);
 }
 // eigenvalue decomposition (max_step with sigma: dsyevd 'V', misc_solvers.c:1131-1136): X := eigenvectors (columns),
-// sig := eigenvalues, ascending.  T1, T2: m*m scratch each.
+// sig := eigenvalues, ascending.  T1: m*m scratch.  With the shift c = 2 ||X||_F the matrix X + c I is positive definite with
+// condition number <= 3, its one-sided Jacobi iteration ends with G = (X + c I) V = V diag(sigma), so the eigenvectors are the
+// normalised columns of G and no V has to be accumulated; eigenvalues sigma - c (absolute accuracy eps ||X||_F, LAPACK's).
 template <class P>
-__host__ __device__ inline void s_eig_blk(const P& par, double* X, double* sig, int m, double* T1, double* T2, double* jw) {
-    const double c = s_fro(par, X, m);
+__host__ __device__ inline void s_eig_blk(const P& par, double* X, double* sig, int m, double* T1, double* /*T2*/, double* jw) {
+    const double c = 2.0 * s_fro(par, X, m);
     const int mm = m * m;
+    double* sv = jw + s_jw_doubles(m, par.nt()) - 3 * (size_t)m - 8;      // [m] singular values, [m] ranks, [m] 1 / sigma
+    double* rank = sv + m;
+    double* inv = rank + m;
+    if (c == 0.0) {                                                       // X = 0: eigenvalues 0, eigenvectors I
+        for (int e = par.tid(); e < mm; e += par.nt()) X[e] = (e % m == e / m) ? 1.0 : 0.0;
+        for (int j = par.tid(); j < m; j += par.nt()) sig[j] = 0.0;
+        par.sync();
+        return;
+    }
     for (int e = par.tid(); e < mm; e += par.nt()) T1[e] = X[e] + ((e % m == e / m) ? c : 0.0);
     par.sync();
-    double* sv = jw + s_jw_doubles(m, par.nt()) - 2 * (size_t)m - 8;      // [m] singular values, [m] ranks
-    double* rank = sv + m;
-    s_jacobi(par, T1, T2, sv, m, jw);
+    s_jacobi(par, T1, (double*)nullptr, sv, m, jw);
     s_rank(par, sv, rank, m, false);
-    s_permute_cols(par, X, T2, rank, (const double*)nullptr, m);
+    for (int j = par.tid(); j < m; j += par.nt()) inv[j] = 1.0 / sv[j];
+    par.sync();
+    s_permute_cols(par, X, T1, rank, inv, m);
     for (int j = par.tid(); j < m; j += par.nt()) sig[(int)rank[j]] = sv[j] - c;
     par.sync();
 }
@@ -358,7 +396,7 @@ __host__ __device__ inline int s_compute_scaling_blk(const P& par, const double*
     const int f2 = s_potrf(par, T2, m);                    // T2 = Lz
     if (!fail) fail = f2;
     s_gemm(par, T3, T2, true, T1, false, m);               // T3 = Lz' Ls -> G = U diag(sigma)
-    double* sv = jw + s_jw_doubles(m, par.nt()) - 2 * (size_t)m - 8;
+    double* sv = jw + s_jw_doubles(m, par.nt()) - 3 * (size_t)m - 8;
     double* rank = sv + m;
     s_jacobi(par, T3, r /* V */, sv, m, jw);
     s_rank(par, sv, rank, m, true);
@@ -392,7 +430,7 @@ __host__ __device__ inline void s_update_scaling_blk(const P& par, double* Ls, d
     s_gemm(par, T1, rti, false, Lz, false, m);             // rti := rti Lz
     s_copy(par, rti, T1, mm);
     s_gemm(par, T1, Lz, true, Ls, false, m);               // T1 = Lz' Ls -> G = U diag(sigma), V in T2
-    double* sv = jw + s_jw_doubles(m, par.nt()) - 2 * (size_t)m - 8;
+    double* sv = jw + s_jw_doubles(m, par.nt()) - 3 * (size_t)m - 8;
     double* rank = sv + m;
     s_jacobi(par, T1, T2, sv, m, jw);
     s_rank(par, sv, rank, m, true);

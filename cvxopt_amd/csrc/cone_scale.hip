@@ -95,6 +95,7 @@ __global__ __launch_bounds__(256) void sdp_scale_pack_kernel(const double* __res
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int k = blockIdx.x, j = blockIdx.y, tid = threadIdx.x;
     const int nk = sdim[k];
+    if (nk > SDP_MAXN) return;             // large blocks of a mixed problem go through launch_sdp_congruence
     double* X = sm;
     double* T = sm + nk * nk;
     const double* __restrict__ x = in + soff[k] + (int64_t)j * ldi;
@@ -143,7 +144,8 @@ __global__ __launch_bounds__(256) void sdp_scale_pack_big_kernel(const double* _
     const double* __restrict__ Rm = rti + sroff[k];
     double* __restrict__ y = out + spoff[k] + (int64_t)j * ldo;
     const double r2 = 1.4142135623730951;
-    for (int b0 = 0; b0 < nk; b0 += SDP_PANEL) {
+    // blockIdx.z strides over the panels: a single vector (the right-hand side of a solve) still spreads over nk / 16 CUs
+    for (int b0 = blockIdx.z * SDP_PANEL; b0 < nk; b0 += gridDim.z * SDP_PANEL) {
         const int pw = min(SDP_PANEL, nk - b0);
         for (int e = tid; e < nk * pw; e += 256) {      // T[a][bb] = sum_c X[a][c] R[c][b0 + bb], X symmetric from its lower part
             const int a = e % nk, bb = e / nk;
@@ -207,6 +209,7 @@ int cone_layout_build_s(ConeLayout& cl, int lq_rows, const std::vector<int>& s) 
         if (!h.empty()) KKT_HIP_CHECK(hipMemcpy(*d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
         return 0;
     };
+    cl.h_sdim = sdim; cl.h_soff = soff; cl.h_spoff = spoff; cl.h_sroff = sroff;
     if (int e = up(&cl.d_sdim, sdim)) return e;
     if (int e = up(&cl.d_soff, soff)) return e;
     if (int e = up(&cl.d_spoff, spoff)) return e;
@@ -217,6 +220,45 @@ int cone_layout_build_s(ConeLayout& cl, int lq_rows, const std::vector<int>& s) 
 int launch_sdp_scale_pack(const ConeLayout& cl, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
                           const double* d_rti, double extra, hipStream_t st) {
     if (cl.ns == 0 || ncols <= 0) return 0;
+    static const bool no_mfma = getenv("MI355KKT_SDP_NO_MFMA") != nullptr;
+    if (cl.s_maxn > SDP_MAXN && ncols >= 16 && !no_mfma) {
+        // a whole matrix of columns (Gs = W^-T G): blocks > 80 as two batched FP64-MFMA products each (gemm_f64.hip),
+        // the smaller ones through the LDS-resident kernel
+        int small_max = 0;
+        size_t need = 0;
+        for (int k = 0; k < cl.ns; ++k) {
+            const int nk = cl.h_sdim[k];
+            if (nk <= SDP_MAXN) small_max = std::max(small_max, nk);
+            else need = std::max(need, (size_t)nk * nk * (1 + (size_t)std::min(ncols, std::max(1, (int)((size_t)(32 << 20) / ((size_t)nk * nk))))));
+        }
+        if (need > cl.cong_doubles) {
+            if (cl.d_cong) (void)hipFree(cl.d_cong);
+            cl.d_cong = nullptr;
+            cl.cong_doubles = 0;
+            KKT_HIP_CHECK(hipMalloc(&cl.d_cong, sizeof(double) * need));
+            cl.cong_doubles = need;
+        }
+        if (small_max > 0) {
+            static bool attr_s = false;
+            if (!attr_s) {
+                KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sdp_scale_pack_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)(sizeof(double) * 2 * SDP_MAXN * SDP_MAXN)));
+                attr_s = true;
+            }
+            hipLaunchKernelGGL(sdp_scale_pack_kernel, dim3(cl.ns, ncols), dim3(256), sizeof(double) * 2 * small_max * small_max, st,
+                               in, ldi, out, ldo, cl.d_sdim, cl.d_soff, cl.d_spoff, cl.d_sroff, d_rti, extra);
+        }
+        for (int k = 0; k < cl.ns; ++k) {
+            const int nk = cl.h_sdim[k];
+            if (nk <= SDP_MAXN) continue;
+            if (int e = launch_sdp_congruence(d_rti + cl.h_sroff[k], nk, in + cl.h_soff[k], ldi, out + cl.h_spoff[k], ldo, ncols, extra,
+                                              cl.d_cong, cl.cong_doubles, st))
+                return e;
+        }
+        KKT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
     if (cl.s_maxn > SDP_MAXN) {
         if ((size_t)cl.s_maxn * SDP_PANEL * sizeof(double) > 150 * 1024) {
             set_last_error("semidefinite blocks larger than %d x %d are not supported on the device", 150 * 1024 / 8 / SDP_PANEL,
@@ -229,7 +271,9 @@ int launch_sdp_scale_pack(const ConeLayout& cl, const double* in, int64_t ldi, d
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
             attr_big = true;
         }
-        hipLaunchKernelGGL(sdp_scale_pack_big_kernel, dim3(cl.ns, ncols), dim3(256), sizeof(double) * cl.s_maxn * SDP_PANEL, st, in,
+        const int npanels = (cl.s_maxn + SDP_PANEL - 1) / SDP_PANEL;
+        const int gz = std::max(1, std::min(npanels, 1024 / std::max(1, cl.ns * ncols)));
+        hipLaunchKernelGGL(sdp_scale_pack_big_kernel, dim3(cl.ns, ncols, gz), dim3(256), sizeof(double) * cl.s_maxn * SDP_PANEL, st, in,
                            ldi, out, ldo, cl.d_sdim, cl.d_soff, cl.d_spoff, cl.d_sroff, d_rti, extra);
         KKT_HIP_CHECK(hipGetLastError());
         return 0;
@@ -303,6 +347,7 @@ void cone_layout_free(ConeLayout& cl) {
     int* sp[] = {cl.d_sdim, cl.d_soff, cl.d_spoff, cl.d_sroff};
     for (int* p : sp)
         if (p) (void)hipFree(p);
+    if (cl.d_cong) (void)hipFree(cl.d_cong);
     cl = ConeLayout();
 }
 

@@ -22,9 +22,9 @@ namespace mi355kkt {
 // 5 dual infeasible
 __device__ __forceinline__ void lp_store_result(const LpState& S, int status, int it, double xs, double ys, double ss, double zs) {
     const int tid = threadIdx.x, n = S.n, m = S.m, p = S.p;
-    for (int i = tid; i < n; i += 256) S.x_out[i] = S.x[i] * xs;
-    for (int i = tid; i < p; i += 256) S.y_out[i] = S.y[i] * ys;
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < n; i += blockDim.x) S.x_out[i] = S.x[i] * xs;
+    for (int i = tid; i < p; i += blockDim.x) S.y_out[i] = S.y[i] * ys;
+    for (int i = tid; i < m; i += blockDim.x) {
         S.s_out[i] = S.s[i] * ss;
         S.z_out[i] = S.z[i] * zs;
     }
@@ -36,28 +36,28 @@ __device__ __forceinline__ void lp_store_result(const LpState& S, int status, in
 }
 
 // W = I: d = di = 1, v_k = e, beta_k = 1 (coneprog.py:676-688)
-__global__ __launch_bounds__(256) void lp_unit_scaling_kernel(LpState S) {
+__global__ __launch_bounds__(1024) void lp_unit_scaling_kernel(LpState S) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < S.ml; i += 256) { S.d[i] = 1.0; S.di[i] = 1.0; }
-    for (int i = tid; i < S.lq - S.ml; i += 256) S.v[i] = 0.0;
+    for (int i = tid; i < S.ml; i += blockDim.x) { S.d[i] = 1.0; S.di[i] = 1.0; }
+    for (int i = tid; i < S.lq - S.ml; i += blockDim.x) S.v[i] = 0.0;
     __syncthreads();
-    for (int k = tid; k < S.nq; k += 256) { S.v[S.qoff[k] - S.ml] = 1.0; S.beta[k] = 1.0; }
+    for (int k = tid; k < S.nq; k += blockDim.x) { S.v[S.qoff[k] - S.ml] = 1.0; S.beta[k] = 1.0; }
     for (int k = 0; k < S.ns; ++k) {                     // r_k = rti_k = I
         const int mk = S.sdim[k], o = S.soff[k] - S.lq;
-        for (int e = tid; e < mk * mk; e += 256) S.r[o + e] = S.rti[o + e] = (e % mk == e / mk) ? 1.0 : 0.0;
+        for (int e = tid; e < mk * mk; e += blockDim.x) S.r[o + e] = S.rti[o + e] = (e % mk == e / mk) ? 1.0 : 0.0;
     }
 }
 
-__global__ __launch_bounds__(256) void lp_init_primal_kernel(LpState S) {
-    __shared__ double sh[4];
-    for (int i = threadIdx.x; i < S.m; i += 256) S.s[i] = -S.s[i];
+__global__ __launch_bounds__(1024) void lp_init_primal_kernel(LpState S) {
+    __shared__ double sh[16];
+    for (int i = threadIdx.x; i < S.m; i += blockDim.x) S.s[i] = -S.s[i];
     __syncthreads();
     const double ts = cv_maxstep(S, S.s, sh);
     if (threadIdx.x == 0) S.sc[LP_TS] = ts;
 }
 
-__global__ __launch_bounds__(256) void lp_init_dual_kernel(LpState S, double abstol, double reltol) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void lp_init_dual_kernel(LpState S, double abstol, double reltol) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     double* sc = S.sc;
     const double tz = cv_maxstep(S, S.z, sh);
@@ -101,16 +101,16 @@ __global__ __launch_bounds__(256) void lp_init_dual_kernel(LpState S, double abs
     if (tid == 0) sc[LP_GAP] = g2;
 }
 
-__global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int maxiters, double abstol, double reltol,
+__global__ __launch_bounds__(1024) void lp_residual_kernel(LpState S, int it, int maxiters, double abstol, double reltol,
                                                           double feastol) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     double* sc = S.sc;
     if (S.active[0] == 0) return;
     const double tau = sc[LP_TAU], kappa = sc[LP_KAPPA], gap = sc[LP_GAP];
     // hrx = -A'y - G'z ; rx = hrx - c tau
     double hx2 = 0.0, rx2 = 0.0, cx = 0.0;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += blockDim.x) {
         double hr = 0.0;
         if (p > 0) hr = -S.ATy[i];
         hr -= S.GTz[i];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
     double hresy = 0.0, resy = 0.0, by = 0.0;
     if (p > 0) {
         double a2 = 0.0, r2 = 0.0, d = 0.0;
-        for (int i = tid; i < p; i += 256) {
+        for (int i = tid; i < p; i += blockDim.x) {
             const double hr = S.Ax[i];
             const double r = hr - S.b[i] * tau;
             S.ry[i] = r;
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
         by = lp_block_sum(d, sh);
     }
     double hz2 = 0.0, rz2 = 0.0, hz = 0.0;
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += blockDim.x) {
         const double hr = S.s[i] + S.Gx[i];
         const double r = hr - S.h[i] * tau;
         S.rz[i] = r;
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
         __syncthreads();
     }
     // scaling for the factorisation; right-hand side of the extra solve (x1, y1, z1) = (-c, b, h); th = W^-T h
-    for (int i = tid; i < S.ml; i += 256) S.di[i] = 1.0 / S.d[i];
-    for (int i = tid; i < n; i += 256) S.x1[i] = -S.c[i];
-    for (int i = tid; i < p; i += 256) S.y1[i] = S.b[i];
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < S.ml; i += blockDim.x) S.di[i] = 1.0 / S.d[i];
+    for (int i = tid; i < n; i += blockDim.x) S.x1[i] = -S.c[i];
+    for (int i = tid; i < p; i += blockDim.x) S.y1[i] = S.b[i];
+    for (int i = tid; i < m; i += blockDim.x) {
         S.z1[i] = S.h[i];
         S.th[i] = S.h[i];
     }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void lp_residual_kernel(LpState S, int it, int
 }
 
 // "Terminated (singular KKT matrix)" (:1076-1109)
-__global__ __launch_bounds__(256) void lp_singular_kernel(LpState S, const int* info, int it) {
+__global__ __launch_bounds__(1024) void lp_singular_kernel(LpState S, const int* info, int it) {
     if (!S.active[0] || info[0] <= 0) return;
     const double tau = S.sc[LP_TAU];
     __syncthreads();
@@ -225,32 +225,32 @@ __global__ __launch_bounds__(256) void lp_singular_kernel(LpState S, const int* 
     if (threadIdx.x == 0) atomicAdd(S.nactive, -1);
 }
 
-__global__ __launch_bounds__(256) void lp_scale1_kernel(LpState S) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void lp_scale1_kernel(LpState S) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x;
     const double dgi = S.sc[LP_DGI];
-    for (int i = tid; i < S.n; i += 256) S.x1[i] *= dgi;
-    for (int i = tid; i < S.p; i += 256) S.y1[i] *= dgi;
-    for (int i = tid; i < S.m; i += 256) S.z1[i] *= dgi;
+    for (int i = tid; i < S.n; i += blockDim.x) S.x1[i] *= dgi;
+    for (int i = tid; i < S.p; i += blockDim.x) S.y1[i] *= dgi;
+    for (int i = tid; i < S.m; i += blockDim.x) S.z1[i] *= dgi;
     __syncthreads();
     const double zz = lp_dot(S.z1, S.z1, S.m, sh);
     if (tid == 0) S.sc[LP_Z1Z1] = zz;
 }
 
 // right-hand side of the Newton system (:1259-1296), also saved in W for the refinement step
-__global__ __launch_bounds__(256) void lp_build_kernel(LpState S, LpBuf D, LpBuf W, int i01, int save) {
+__global__ __launch_bounds__(1024) void lp_build_kernel(LpState S, LpBuf D, LpBuf W, int i01, int save) {
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     double* sc = S.sc;
     const double sigma = (i01 == 0) ? 0.0 : sc[LP_SIGMA];
     const double mu = sc[LP_MU], lg = sc[LP_LG];
     cv_expand(S, D.s, S.lmbdasq);                   // ds := lmbdasq ('s' blocks: diag(lmbdasq_k), coneprog.py:1264-1273)
-    for (int i = tid; i < m; i += 256) D.z[i] = (1.0 - sigma) * S.rz[i];
+    for (int i = tid; i < m; i += blockDim.x) D.z[i] = (1.0 - sigma) * S.rz[i];
     if (i01 == 1) {
         __syncthreads();
-        for (int i = tid; i < m; i += 256) D.s[i] += S.ws3[i];
+        for (int i = tid; i < m; i += blockDim.x) D.s[i] += S.ws3[i];
     }
-    for (int i = tid; i < n; i += 256) D.x[i] = (1.0 - sigma) * S.rx[i];
-    for (int i = tid; i < p; i += 256) D.y[i] = (1.0 - sigma) * S.ry[i];
+    for (int i = tid; i < n; i += blockDim.x) D.x[i] = (1.0 - sigma) * S.rx[i];
+    for (int i = tid; i < p; i += blockDim.x) D.y[i] = (1.0 - sigma) * S.ry[i];
     __syncthreads();
     if (i01 == 1) cv_add_e(S, D.s, -sigma * mu);
     if (tid == 0) {
@@ -261,38 +261,38 @@ __global__ __launch_bounds__(256) void lp_build_kernel(LpState S, LpBuf D, LpBuf
     }
     if (save) {
         __syncthreads();
-        for (int i = tid; i < m; i += 256) { W.s[i] = D.s[i]; W.z[i] = D.z[i]; }
-        for (int i = tid; i < n; i += 256) W.x[i] = D.x[i];
-        for (int i = tid; i < p; i += 256) W.y[i] = D.y[i];
+        for (int i = tid; i < m; i += blockDim.x) { W.s[i] = D.s[i]; W.z[i] = D.z[i]; }
+        for (int i = tid; i < n; i += blockDim.x) W.x[i] = D.x[i];
+        for (int i = tid; i < p; i += blockDim.x) W.y[i] = D.y[i];
         if (tid == 0) { sc[W.itau] = sc[D.itau]; sc[W.ikappa] = sc[D.ikappa]; }
     }
 }
 
 // dst := src (all six components)
-__global__ __launch_bounds__(256) void lp_copy_kernel(LpState S, LpBuf dst, LpBuf src) {
+__global__ __launch_bounds__(1024) void lp_copy_kernel(LpState S, LpBuf dst, LpBuf src) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < S.m; i += 256) { dst.s[i] = src.s[i]; dst.z[i] = src.z[i]; }
-    for (int i = tid; i < S.n; i += 256) dst.x[i] = src.x[i];
-    for (int i = tid; i < S.p; i += 256) dst.y[i] = src.y[i];
+    for (int i = tid; i < S.m; i += blockDim.x) { dst.s[i] = src.s[i]; dst.z[i] = src.z[i]; }
+    for (int i = tid; i < S.n; i += blockDim.x) dst.x[i] = src.x[i];
+    for (int i = tid; i < S.p; i += blockDim.x) dst.y[i] = src.y[i];
     if (tid == 0) { S.sc[dst.itau] = S.sc[src.itau]; S.sc[dst.ikappa] = S.sc[src.ikappa]; }
 }
 // dst += src
-__global__ __launch_bounds__(256) void lp_add_kernel(LpState S, LpBuf dst, LpBuf src) {
+__global__ __launch_bounds__(1024) void lp_add_kernel(LpState S, LpBuf dst, LpBuf src) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < S.m; i += 256) { dst.s[i] += src.s[i]; dst.z[i] += src.z[i]; }
-    for (int i = tid; i < S.n; i += 256) dst.x[i] += src.x[i];
-    for (int i = tid; i < S.p; i += 256) dst.y[i] += src.y[i];
+    for (int i = tid; i < S.m; i += blockDim.x) { dst.s[i] += src.s[i]; dst.z[i] += src.z[i]; }
+    for (int i = tid; i < S.n; i += blockDim.x) dst.x[i] += src.x[i];
+    for (int i = tid; i < S.p; i += blockDim.x) dst.y[i] += src.y[i];
     if (tid == 0) { S.sc[dst.itau] += S.sc[src.itau]; S.sc[dst.ikappa] += S.sc[src.ikappa]; }
 }
 
 // f6_no_ir, part before the KKT solve (:1158-1174): y := -y; s := -lmbda o\ s; z := -(z + W's)
-__global__ __launch_bounds__(256) void lp_f6pre_kernel(LpState S, LpBuf X) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void lp_f6pre_kernel(LpState S, LpBuf X) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
-    for (int i = tid; i < S.p; i += 256) X.y[i] = -X.y[i];
+    for (int i = tid; i < S.p; i += blockDim.x) X.y[i] = -X.y[i];
     cv_sinv(S, X.s, S.lmbda, sh);
     __syncthreads();
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += blockDim.x) {
         const double v = -X.s[i];
         X.s[i] = v;
         S.t1[i] = v;
@@ -300,12 +300,12 @@ __global__ __launch_bounds__(256) void lp_f6pre_kernel(LpState S, LpBuf X) {
     __syncthreads();
     cv_scale(S, S.t1, false, true, sh);             // W' s
     __syncthreads();
-    for (int i = tid; i < m; i += 256) X.z[i] = -(X.z[i] + S.t1[i]);
+    for (int i = tid; i < m; i += blockDim.x) X.z[i] = -(X.z[i] + S.t1[i]);
 }
 
 // f6_no_ir, part after the KKT solve (:1187-1203)
-__global__ __launch_bounds__(256) void lp_f6post_kernel(LpState S, LpBuf X) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void lp_f6post_kernel(LpState S, LpBuf X) {
+    __shared__ double sh[16];
     __shared__ double tsh;
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     double* sc = S.sc;
@@ -323,9 +323,9 @@ __global__ __launch_bounds__(256) void lp_f6post_kernel(LpState S, LpBuf X) {
     }
     __syncthreads();
     const double t = tsh;
-    for (int i = tid; i < n; i += 256) X.x[i] += t * S.x1[i];
-    for (int i = tid; i < p; i += 256) X.y[i] += t * S.y1[i];
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < n; i += blockDim.x) X.x[i] += t * S.x1[i];
+    for (int i = tid; i < p; i += blockDim.x) X.y[i] += t * S.y1[i];
+    for (int i = tid; i < m; i += blockDim.x) {
         const double zz = X.z[i] + t * S.z1[i];
         X.z[i] = zz;
         X.s[i] -= zz;                               // s := s - z
@@ -333,15 +333,15 @@ __global__ __launch_bounds__(256) void lp_f6post_kernel(LpState S, LpBuf X) {
 }
 
 // res() (:596-634), first half: wz3 = W^-1 uz (the products with G', A', G, A are launched by the host in between)
-__global__ __launch_bounds__(256) void lp_res_a_kernel(LpState S, LpBuf U) {
-    __shared__ double sh[4];
-    for (int i = threadIdx.x; i < S.m; i += 256) S.wz3[i] = U.z[i];
+__global__ __launch_bounds__(1024) void lp_res_a_kernel(LpState S, LpBuf U) {
+    __shared__ double sh[16];
+    for (int i = threadIdx.x; i < S.m; i += blockDim.x) S.wz3[i] = U.z[i];
     __syncthreads();
     cv_scale(S, S.wz3, true, false, sh);            // misc.scale(wz3, W, inverse = 'I')
 }
 // second half: S.GTz = G' wz3, S.ATy = A' uy, S.Gx = G ux, S.Ax = A ux are in place
-__global__ __launch_bounds__(256) void lp_res_b_kernel(LpState S, LpBuf U, LpBuf V) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void lp_res_b_kernel(LpState S, LpBuf U, LpBuf V) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     double* sc = S.sc;
     const double dg = sc[LP_DG], lg = sc[LP_LG];
@@ -349,15 +349,15 @@ __global__ __launch_bounds__(256) void lp_res_b_kernel(LpState S, LpBuf U, LpBuf
     const double cux = lp_dot(S.c, U.x, n, sh);
     const double buy = p > 0 ? lp_dot(S.b, U.y, p, sh) : 0.0;
     const double hw = lp_dot(S.h, S.wz3, m, sh);
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += blockDim.x) {
         double v = V.x[i];
         if (p > 0) v -= S.ATy[i];
         v -= S.GTz[i];
         v -= S.c[i] * (utau / dg);
         V.x[i] = v;
     }
-    for (int i = tid; i < p; i += 256) V.y[i] = V.y[i] + S.Ax[i] - S.b[i] * (utau / dg);
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < p; i += blockDim.x) V.y[i] = V.y[i] + S.Ax[i] - S.b[i] * (utau / dg);
+    for (int i = tid; i < m; i += blockDim.x) {
         S.t1[i] = U.s[i];                           // W' us
         S.t2[i] = U.s[i] + U.z[i];                  // lmbda o (uz + us)
     }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void lp_res_b_kernel(LpState S, LpBuf U, LpBuf
     cv_scale(S, S.t1, false, true, sh);             // misc.scale(ws3, W, trans = 'T')
     cv_sprod_diag(S, S.t2, S.lmbda, sh);            // misc.sprod(ws3, lmbda, dims, diag = 'D')
     __syncthreads();
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += blockDim.x) {
         V.z[i] = V.z[i] + S.Gx[i] - S.h[i] * (utau / dg) + S.t1[i];
         V.s[i] += S.t2[i];
     }
@@ -376,12 +376,12 @@ __global__ __launch_bounds__(256) void lp_res_b_kernel(LpState S, LpBuf U, LpBuf
 }
 
 // Mehrotra products, scale2, step to the boundary, sigma (:1299-1331)
-__global__ __launch_bounds__(256) void lp_step_kernel(LpState S, LpBuf D, int i01) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void lp_step_kernel(LpState S, LpBuf D, int i01) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     double* sc = S.sc;
     if (i01 == 0) {
-        for (int i = tid; i < m; i += 256) S.ws3[i] = D.s[i];
+        for (int i = tid; i < m; i += blockDim.x) S.ws3[i] = D.s[i];
         __syncthreads();
         cv_sprod(S, S.ws3, D.z, sh);
     }
@@ -410,18 +410,18 @@ __global__ __launch_bounds__(256) void lp_step_kernel(LpState S, LpBuf D, int i0
     }
 }
 
-__global__ __launch_bounds__(256) void lp_update_kernel(LpState S, LpBuf D) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void lp_update_kernel(LpState S, LpBuf D) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     if (!S.active[0]) return;
     double* sc = S.sc;
     const double step = sc[LP_STEP];
-    for (int i = tid; i < n; i += 256) S.x[i] += step * D.x[i];
-    for (int i = tid; i < p; i += 256) S.y[i] += step * D.y[i];
+    for (int i = tid; i < n; i += blockDim.x) S.x[i] += step * D.x[i];
+    for (int i = tid; i < p; i += blockDim.x) S.y[i] += step * D.y[i];
     // ds := e + step ds, dz := e + step dz; then H(lambda)^{-1/2}: the updated variables in the current scaling
     // ('s' blocks: ds, dz hold the eigenvectors Qs, Qz; they become the factors Ls, Lz of the updated variables in the
     // current scaling, coneprog.py:1348-1395)
-    for (int i = tid; i < S.lq; i += 256) {
+    for (int i = tid; i < S.lq; i += blockDim.x) {
         D.s[i] *= step;
         D.z[i] *= step;
     }
@@ -461,15 +461,27 @@ __global__ __launch_bounds__(256) void lp_update_kernel(LpState S, LpBuf D) {
 }
 
 // upper triangles of the 's' blocks of a KKT-solve result := lower triangles
-__global__ __launch_bounds__(256) void lp_symm_kernel(LpState S, double* z) { cv_symm(S, z); }
+__global__ __launch_bounds__(1024) void lp_symm_kernel(LpState S, double* z) { cv_symm(S, z); }
 
-#define LP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(256), 0, st, __VA_ARGS__)
+// one workgroup of S.nthreads threads; kernels that run the Jacobi iteration get the dynamic LDS staging area (> 64 KB
+// needs the attribute once per kernel)
+#define LP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(S.nthreads), 0, st, __VA_ARGS__)
+#define LP1J(kernel, ...)                                                                                              \
+    do {                                                                                                               \
+        static bool attr_done = false;                                                                                 \
+        if (S.lds_doubles > 0 && !attr_done) {                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024 - 512);                                                               \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(S.nthreads), sizeof(double) * S.lds_doubles, st, __VA_ARGS__);         \
+    } while (0)
 void lp_launch_symm(const LpState& S, double* z, hipStream_t st) { if (S.ns > 0) LP1(lp_symm_kernel, S, z); }
 void lp_launch_unit_scaling(const LpState& S, hipStream_t st) { LP1(lp_unit_scaling_kernel, S); }
-void lp_launch_init_primal(const LpState& S, hipStream_t st) { LP1(lp_init_primal_kernel, S); }
-void lp_launch_init_dual(const LpState& S, double abstol, double reltol, hipStream_t st) { LP1(lp_init_dual_kernel, S, abstol, reltol); }
+void lp_launch_init_primal(const LpState& S, hipStream_t st) { LP1J(lp_init_primal_kernel, S); }
+void lp_launch_init_dual(const LpState& S, double abstol, double reltol, hipStream_t st) { LP1J(lp_init_dual_kernel, S, abstol, reltol); }
 void lp_launch_residual(const LpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st) {
-    LP1(lp_residual_kernel, S, it, maxiters, abstol, reltol, feastol);
+    LP1J(lp_residual_kernel, S, it, maxiters, abstol, reltol, feastol);
 }
 void lp_launch_singular(const LpState& S, const int* d_info, int it, hipStream_t st) { LP1(lp_singular_kernel, S, d_info, it); }
 void lp_launch_scale1(const LpState& S, hipStream_t st) { LP1(lp_scale1_kernel, S); }
@@ -480,7 +492,7 @@ void lp_launch_f6pre(const LpState& S, const LpBuf& X, hipStream_t st) { LP1(lp_
 void lp_launch_f6post(const LpState& S, const LpBuf& X, hipStream_t st) { LP1(lp_f6post_kernel, S, X); }
 void lp_launch_res_a(const LpState& S, const LpBuf& U, hipStream_t st) { LP1(lp_res_a_kernel, S, U); }
 void lp_launch_res_b(const LpState& S, const LpBuf& U, const LpBuf& V, hipStream_t st) { LP1(lp_res_b_kernel, S, U, V); }
-void lp_launch_step(const LpState& S, const LpBuf& D, int i01, hipStream_t st) { LP1(lp_step_kernel, S, D, i01); }
-void lp_launch_update(const LpState& S, const LpBuf& D, hipStream_t st) { LP1(lp_update_kernel, S, D); }
+void lp_launch_step(const LpState& S, const LpBuf& D, int i01, hipStream_t st) { LP1J(lp_step_kernel, S, D, i01); }
+void lp_launch_update(const LpState& S, const LpBuf& D, hipStream_t st) { LP1J(lp_update_kernel, S, D); }
 
 }  // namespace mi355kkt

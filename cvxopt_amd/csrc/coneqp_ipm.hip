@@ -15,9 +15,9 @@ namespace mi355kkt {
 
 __device__ __forceinline__ void qp_store_result(const QpState& S, int status, int it) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < S.n; i += 256) S.x_out[i] = S.x[i];
-    for (int i = tid; i < S.p; i += 256) S.y_out[i] = S.y[i];
-    for (int i = tid; i < S.m; i += 256) {
+    for (int i = tid; i < S.n; i += blockDim.x) S.x_out[i] = S.x[i];
+    for (int i = tid; i < S.p; i += blockDim.x) S.y_out[i] = S.y[i];
+    for (int i = tid; i < S.m; i += blockDim.x) {
         S.s_out[i] = S.s[i];
         S.z_out[i] = S.z[i];
     }
@@ -29,25 +29,25 @@ __device__ __forceinline__ void qp_store_result(const QpState& S, int status, in
 }
 
 // W = I (coneprog.py:2054-2063)
-__global__ __launch_bounds__(256) void qp_unit_scaling_kernel(QpState S) {
+__global__ __launch_bounds__(1024) void qp_unit_scaling_kernel(QpState S) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < S.ml; i += 256) { S.d[i] = 1.0; S.di[i] = 1.0; }
-    for (int i = tid; i < S.lq - S.ml; i += 256) S.v[i] = 0.0;
+    for (int i = tid; i < S.ml; i += blockDim.x) { S.d[i] = 1.0; S.di[i] = 1.0; }
+    for (int i = tid; i < S.lq - S.ml; i += blockDim.x) S.v[i] = 0.0;
     __syncthreads();
-    for (int k = tid; k < S.nq; k += 256) { S.v[S.qoff[k] - S.ml] = 1.0; S.beta[k] = 1.0; }
+    for (int k = tid; k < S.nq; k += blockDim.x) { S.v[S.qoff[k] - S.ml] = 1.0; S.beta[k] = 1.0; }
     for (int k = 0; k < S.ns; ++k) {                     // r_k = rti_k = I
         const int mk = S.sdim[k], o = S.soff[k] - S.lq;
-        for (int e = tid; e < mk * mk; e += 256) S.r[o + e] = S.rti[o + e] = (e % mk == e / mk) ? 1.0 : 0.0;
+        for (int e = tid; e < mk * mk; e += blockDim.x) S.r[o + e] = S.rti[o + e] = (e % mk == e / mk) ? 1.0 : 0.0;
     }
 }
 
-__global__ __launch_bounds__(256) void qp_start_kernel(QpState S) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void qp_start_kernel(QpState S) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     double* sc = S.sc;
     const double q2 = lp_dot(S.q, S.q, S.n, sh), h2 = lp_dot(S.h, S.h, m, sh);
     const double b2 = S.p > 0 ? lp_dot(S.b, S.b, S.p, sh) : 0.0;
-    for (int i = tid; i < m; i += 256) S.s[i] = -S.z[i];
+    for (int i = tid; i < m; i += blockDim.x) S.s[i] = -S.z[i];
     __syncthreads();
     const double ns = sqrt(lp_dot(S.s, S.s, m, sh));
     const double ts = cv_maxstep(S, S.s, sh);
@@ -69,14 +69,14 @@ __global__ __launch_bounds__(256) void qp_start_kernel(QpState S) {
 }
 
 // in place: S.Px = P x, S.ATy = A' y, S.GTz = G' z, S.Ax = A x, S.Gx = G x
-__global__ __launch_bounds__(256) void qp_residual_kernel(QpState S, int it, int maxiters, double abstol, double reltol,
+__global__ __launch_bounds__(1024) void qp_residual_kernel(QpState S, int it, int maxiters, double abstol, double reltol,
                                                           double feastol) {
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     double* sc = S.sc;
     if (S.active[0] == 0) return;
     double f0a = 0.0, f0b = 0.0, r2 = 0.0;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += blockDim.x) {
         const double t = S.q[i] + S.Px[i];
         f0a += S.x[i] * t;
         f0b += S.x[i] * S.q[i];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void qp_residual_kernel(QpState S, int it, int
     double resy = 0.0, yry = 0.0;
     if (p > 0) {
         double e2 = 0.0, d2 = 0.0;
-        for (int i = tid; i < p; i += 256) {
+        for (int i = tid; i < p; i += blockDim.x) {
             const double r = S.Ax[i] - S.b[i];
             S.ry[i] = r;
             e2 += r * r;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void qp_residual_kernel(QpState S, int it, int
         yry = lp_block_sum(d2, sh);
     }
     double z2 = 0.0, zr = 0.0;
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += blockDim.x) {
         const double r = S.s[i] + S.Gx[i] - S.h[i];
         S.rz[i] = r;
         z2 += r * r;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void qp_residual_kernel(QpState S, int it, int
         cv_compute_scaling(S, S.s, S.z, S.lmbda, sh);
         __syncthreads();
     }
-    for (int i = tid; i < S.ml; i += 256) S.di[i] = 1.0 / S.d[i];
+    for (int i = tid; i < S.ml; i += blockDim.x) S.di[i] = 1.0 / S.d[i];
     cv_ssqr(S, S.lmbdasq, S.lmbda);
     if (tid == 0) {
         sc[QP_MU] = gap / (double)(S.ml + S.nq + (S.ldim - S.lq));   // gap / (dims['l'] + len(dims['q']) + sum(dims['s']))
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void qp_residual_kernel(QpState S, int it, int
 }
 
 // "Terminated (singular KKT matrix)" (:2256-2275)
-__global__ __launch_bounds__(256) void qp_singular_kernel(QpState S, const int* info, int it) {
+__global__ __launch_bounds__(1024) void qp_singular_kernel(QpState S, const int* info, int it) {
     if (!S.active[0] || info[0] <= 0) return;
     __syncthreads();
     qp_store_result(S, 3, it);
@@ -154,80 +154,80 @@ __global__ __launch_bounds__(256) void qp_singular_kernel(QpState S, const int* 
 }
 
 // right-hand side (:2376-2399): ds = -lmbdasq [- ws3] + sigma mu e; (dx, dy, dz) = -(rx, ry, rz)
-__global__ __launch_bounds__(256) void qp_build_kernel(QpState S, QpBuf D, QpBuf W, int i01, int save) {
+__global__ __launch_bounds__(1024) void qp_build_kernel(QpState S, QpBuf D, QpBuf W, int i01, int save) {
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     const double sigma = (i01 == 0) ? 0.0 : S.sc[QP_SIGMA];
     const double mu = S.sc[QP_MU];
     cv_expand(S, D.s, S.lmbdasq);                   // 's' blocks: diag(lmbdasq_k) (:2386-2391)
     __syncthreads();
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += blockDim.x) {
         double v = 0.0;
         if (i01 == 1) v -= S.ws3[i];
         v -= D.s[i];
         D.s[i] = v;
         D.z[i] = -S.rz[i];
     }
-    for (int i = tid; i < n; i += 256) D.x[i] = -S.rx[i];
-    for (int i = tid; i < p; i += 256) D.y[i] = -S.ry[i];
+    for (int i = tid; i < n; i += blockDim.x) D.x[i] = -S.rx[i];
+    for (int i = tid; i < p; i += blockDim.x) D.y[i] = -S.ry[i];
     __syncthreads();
     cv_add_e(S, D.s, sigma * mu);
     if (save) {
         __syncthreads();
-        for (int i = tid; i < m; i += 256) { W.s[i] = D.s[i]; W.z[i] = D.z[i]; }
-        for (int i = tid; i < n; i += 256) W.x[i] = D.x[i];
-        for (int i = tid; i < p; i += 256) W.y[i] = D.y[i];
+        for (int i = tid; i < m; i += blockDim.x) { W.s[i] = D.s[i]; W.z[i] = D.z[i]; }
+        for (int i = tid; i < n; i += blockDim.x) W.x[i] = D.x[i];
+        for (int i = tid; i < p; i += blockDim.x) W.y[i] = D.y[i];
     }
 }
 
-__global__ __launch_bounds__(256) void qp_copy_kernel(QpState S, QpBuf dst, QpBuf src) {
+__global__ __launch_bounds__(1024) void qp_copy_kernel(QpState S, QpBuf dst, QpBuf src) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < S.m; i += 256) { dst.s[i] = src.s[i]; dst.z[i] = src.z[i]; }
-    for (int i = tid; i < S.n; i += 256) dst.x[i] = src.x[i];
-    for (int i = tid; i < S.p; i += 256) dst.y[i] = src.y[i];
+    for (int i = tid; i < S.m; i += blockDim.x) { dst.s[i] = src.s[i]; dst.z[i] = src.z[i]; }
+    for (int i = tid; i < S.n; i += blockDim.x) dst.x[i] = src.x[i];
+    for (int i = tid; i < S.p; i += blockDim.x) dst.y[i] = src.y[i];
 }
-__global__ __launch_bounds__(256) void qp_add_kernel(QpState S, QpBuf dst, QpBuf src) {
+__global__ __launch_bounds__(1024) void qp_add_kernel(QpState S, QpBuf dst, QpBuf src) {
     const int tid = threadIdx.x;
-    for (int i = tid; i < S.m; i += 256) { dst.s[i] += src.s[i]; dst.z[i] += src.z[i]; }
-    for (int i = tid; i < S.n; i += 256) dst.x[i] += src.x[i];
-    for (int i = tid; i < S.p; i += 256) dst.y[i] += src.y[i];
+    for (int i = tid; i < S.m; i += blockDim.x) { dst.s[i] += src.s[i]; dst.z[i] += src.z[i]; }
+    for (int i = tid; i < S.n; i += blockDim.x) dst.x[i] += src.x[i];
+    for (int i = tid; i < S.p; i += blockDim.x) dst.y[i] += src.y[i];
 }
 
 // f4_no_ir before the KKT solve (:2303-2309): s := lmbda o\ s; z := z - W's
-__global__ __launch_bounds__(256) void qp_f4pre_kernel(QpState S, QpBuf X) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void qp_f4pre_kernel(QpState S, QpBuf X) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     cv_sinv(S, X.s, S.lmbda, sh);
     __syncthreads();
-    for (int i = tid; i < m; i += 256) S.t1[i] = X.s[i];
+    for (int i = tid; i < m; i += blockDim.x) S.t1[i] = X.s[i];
     __syncthreads();
     cv_scale(S, S.t1, false, true, sh);             // misc.scale(ws3, W, trans = 'T')
     __syncthreads();
-    for (int i = tid; i < m; i += 256) X.z[i] -= S.t1[i];
+    for (int i = tid; i < m; i += blockDim.x) X.z[i] -= S.t1[i];
 }
 // ... and after it (:2316): s := s - z
-__global__ __launch_bounds__(256) void qp_f4post_kernel(QpState S, QpBuf X) {
-    for (int i = threadIdx.x; i < S.m; i += 256) X.s[i] -= X.z[i];
+__global__ __launch_bounds__(1024) void qp_f4post_kernel(QpState S, QpBuf X) {
+    for (int i = threadIdx.x; i < S.m; i += blockDim.x) X.s[i] -= X.z[i];
 }
 
 // res() (:1930-1961), first half: wz3 = W^-1 uz (products with P, A', G', A, G launched by the host in between)
-__global__ __launch_bounds__(256) void qp_res_a_kernel(QpState S, QpBuf U) {
-    __shared__ double sh[4];
-    for (int i = threadIdx.x; i < S.m; i += 256) S.wz3[i] = U.z[i];
+__global__ __launch_bounds__(1024) void qp_res_a_kernel(QpState S, QpBuf U) {
+    __shared__ double sh[16];
+    for (int i = threadIdx.x; i < S.m; i += blockDim.x) S.wz3[i] = U.z[i];
     __syncthreads();
     cv_scale(S, S.wz3, true, false, sh);            // misc.scale(wz3, W, inverse = 'I')
 }
 // second half: S.Px = P ux, S.ATy = A' uy, S.GTz = G' wz3, S.Ax = A ux, S.Gx = G ux are in place
-__global__ __launch_bounds__(256) void qp_res_b_kernel(QpState S, QpBuf U, QpBuf V) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void qp_res_b_kernel(QpState S, QpBuf U, QpBuf V) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = tid; i < n; i += blockDim.x) {
         double v = V.x[i] - S.Px[i];
         if (p > 0) v -= S.ATy[i];
         v -= S.GTz[i];
         V.x[i] = v;
     }
-    for (int i = tid; i < p; i += 256) V.y[i] -= S.Ax[i];
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < p; i += blockDim.x) V.y[i] -= S.Ax[i];
+    for (int i = tid; i < m; i += blockDim.x) {
         S.t1[i] = U.s[i];                           // W' us
         S.t2[i] = U.s[i] + U.z[i];                  // lmbda o (uz + us)
     }
@@ -235,19 +235,19 @@ __global__ __launch_bounds__(256) void qp_res_b_kernel(QpState S, QpBuf U, QpBuf
     cv_scale(S, S.t1, false, true, sh);             // misc.scale(ws3, W, trans = 'T')
     cv_sprod_diag(S, S.t2, S.lmbda, sh);            // misc.sprod(ws3, lmbda, dims, diag = 'D')
     __syncthreads();
-    for (int i = tid; i < m; i += 256) {
+    for (int i = tid; i < m; i += blockDim.x) {
         V.z[i] = V.z[i] - S.Gx[i] - S.t1[i];
         V.s[i] -= S.t2[i];
     }
 }
 
-__global__ __launch_bounds__(256) void qp_step_kernel(QpState S, QpBuf D, int i01) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void qp_step_kernel(QpState S, QpBuf D, int i01) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     double* sc = S.sc;
     const double dsdz = lp_dot(D.s, D.z, m, sh);
     if (i01 == 0) {
-        for (int i = tid; i < m; i += 256) S.ws3[i] = D.s[i];
+        for (int i = tid; i < m; i += blockDim.x) S.ws3[i] = D.s[i];
         __syncthreads();
         cv_sprod(S, S.ws3, D.z, sh);
     }
@@ -270,16 +270,16 @@ __global__ __launch_bounds__(256) void qp_step_kernel(QpState S, QpBuf D, int i0
     }
 }
 
-__global__ __launch_bounds__(256) void qp_update_kernel(QpState S, QpBuf D) {
-    __shared__ double sh[4];
+__global__ __launch_bounds__(1024) void qp_update_kernel(QpState S, QpBuf D) {
+    __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     if (!S.active[0]) return;
     const double step = S.sc[QP_STEP];
-    for (int i = tid; i < S.n; i += 256) S.x[i] += step * D.x[i];
-    for (int i = tid; i < S.p; i += 256) S.y[i] += step * D.y[i];
+    for (int i = tid; i < S.n; i += blockDim.x) S.x[i] += step * D.x[i];
+    for (int i = tid; i < S.p; i += blockDim.x) S.y[i] += step * D.y[i];
     // ('s' blocks: ds, dz hold the eigenvectors Qs, Qz; they become the factors Ls, Lz of the updated variables in the
     // current scaling, :2459-2501)
-    for (int i = tid; i < S.lq; i += 256) {
+    for (int i = tid; i < S.lq; i += blockDim.x) {
         D.s[i] *= step;
         D.z[i] *= step;
     }
@@ -304,14 +304,26 @@ __global__ __launch_bounds__(256) void qp_update_kernel(QpState S, QpBuf D) {
 }
 
 // upper triangles of the 's' blocks of a KKT-solve result := lower triangles
-__global__ __launch_bounds__(256) void qp_symm_kernel(QpState S, double* z) { cv_symm(S, z); }
+__global__ __launch_bounds__(1024) void qp_symm_kernel(QpState S, double* z) { cv_symm(S, z); }
 
-#define QP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(256), 0, st, __VA_ARGS__)
+// one workgroup of S.nthreads threads; kernels that run the Jacobi iteration get the dynamic LDS staging area (> 64 KB
+// needs the attribute once per kernel)
+#define QP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(S.nthreads), 0, st, __VA_ARGS__)
+#define QP1J(kernel, ...)                                                                                              \
+    do {                                                                                                               \
+        static bool attr_done = false;                                                                                 \
+        if (S.lds_doubles > 0 && !attr_done) {                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      160 * 1024 - 512);                                                               \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL(kernel, dim3(1), dim3(S.nthreads), sizeof(double) * S.lds_doubles, st, __VA_ARGS__);         \
+    } while (0)
 void qp_launch_symm(const QpState& S, double* z, hipStream_t st) { if (S.ns > 0) QP1(qp_symm_kernel, S, z); }
 void qp_launch_unit_scaling(const QpState& S, hipStream_t st) { QP1(qp_unit_scaling_kernel, S); }
-void qp_launch_start(const QpState& S, hipStream_t st) { QP1(qp_start_kernel, S); }
+void qp_launch_start(const QpState& S, hipStream_t st) { QP1J(qp_start_kernel, S); }
 void qp_launch_residual(const QpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st) {
-    QP1(qp_residual_kernel, S, it, maxiters, abstol, reltol, feastol);
+    QP1J(qp_residual_kernel, S, it, maxiters, abstol, reltol, feastol);
 }
 void qp_launch_singular(const QpState& S, const int* d_info, int it, hipStream_t st) { QP1(qp_singular_kernel, S, d_info, it); }
 void qp_launch_build(const QpState& S, const QpBuf& D, const QpBuf& W, int i01, int save, hipStream_t st) { QP1(qp_build_kernel, S, D, W, i01, save); }
@@ -321,7 +333,7 @@ void qp_launch_f4pre(const QpState& S, const QpBuf& X, hipStream_t st) { QP1(qp_
 void qp_launch_f4post(const QpState& S, const QpBuf& X, hipStream_t st) { QP1(qp_f4post_kernel, S, X); }
 void qp_launch_res_a(const QpState& S, const QpBuf& U, hipStream_t st) { QP1(qp_res_a_kernel, S, U); }
 void qp_launch_res_b(const QpState& S, const QpBuf& U, const QpBuf& V, hipStream_t st) { QP1(qp_res_b_kernel, S, U, V); }
-void qp_launch_step(const QpState& S, const QpBuf& D, int i01, hipStream_t st) { QP1(qp_step_kernel, S, D, i01); }
-void qp_launch_update(const QpState& S, const QpBuf& D, hipStream_t st) { QP1(qp_update_kernel, S, D); }
+void qp_launch_step(const QpState& S, const QpBuf& D, int i01, hipStream_t st) { QP1J(qp_step_kernel, S, D, i01); }
+void qp_launch_update(const QpState& S, const QpBuf& D, hipStream_t st) { QP1J(qp_update_kernel, S, D); }
 
 }  // namespace mi355kkt

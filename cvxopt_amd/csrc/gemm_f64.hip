@@ -751,6 +751,125 @@ int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, 
 }
 
 
+// ===================================================================================================
+// Congruence of a large 's' block, all columns of G at once:  Y_j = R' X_j R  (X_j = mat of column j of the block's rows,
+// symmetric, given by its lower triangle; R = rti_k), written as packed lower triangles with the off-diagonals scaled by
+// sqrt(2) -- misc.scale(trans = 'T', inverse = 'I') + misc.pack of the reference's kkt factories (misc_solvers.c:187-240,
+// :412-550) for blocks too large for the LDS-resident kernel of cone_scale.hip.  Two batched FP64-MFMA products with the
+// tile machinery of the "NT" update above (C = A B', A = R' for both):
+//     pass 1:  Tt_j = R' X_j          (B = X_j read through its lower triangle)
+//     pass 2:  Y_j  = R' Tt_j'        (B = Tt_j; lower triangle packed in the epilogue)
+// blockIdx.z = column j.
+// ===================================================================================================
+template <bool SYMB>
+__device__ __forceinline__ void cg_load(const double* __restrict__ X, int ld, int row0, int n, int k0, int tid, double (&reg)[8]) {
+    const int ip = (tid & 63) * 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = k0 + (tid >> 6) + 4 * r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = row0 + ip + h;
+            double v = 0.0;
+            if (k < n && row < n) {
+                if (SYMB && row < k) v = X[k + (int64_t)row * ld];
+                else v = X[row + (int64_t)k * ld];
+            }
+            reg[2 * r + h] = v;
+        }
+    }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256, 2) void sdp_congruence_kernel(const double* __restrict__ RT, int m,
+                                                                const double* __restrict__ Bbase, int64_t bstride,
+                                                                double* __restrict__ Cbase, int64_t cstride, double extra) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int ti = blockIdx.x, tj = blockIdx.y;
+    const int i0 = ti * TILE, j0 = tj * TILE;
+    if (PASS == 2 && i0 + TILE <= j0) return;                  // tile strictly above the diagonal: not stored
+    const double* __restrict__ B = Bbase + (int64_t)blockIdx.z * bstride;
+    double* __restrict__ C = Cbase + (int64_t)blockIdx.z * cstride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wj = wave >> 1, wi = wave & 1;
+    auto sJ = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES; };
+    auto sI = [&](int s) -> double* { return smem + s * 2 * STAGE_DOUBLES + STAGE_DOUBLES; };
+    const int nkt = (m + BK - 1) / BK;
+    double rJ[8], rI[8];
+    auto fetch = [&](int kt) {
+        cg_load<PASS == 1>(B, m, j0, m, kt * BK, tid, rJ);
+        cg_load<false>(RT, m, i0, m, kt * BK, tid, rI);
+    };
+    auto stash = [&](int s) {
+        nt_store(sJ(s), tid, rJ);
+        nt_store(sI(s), tid, rI);
+    };
+    d4 acc[4][4];
+    zero_acc(acc);
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) fetch(kt + 1);
+        wave_mma<1, LDT_M>(sJ(cur) + wj * 64, sI(cur) + wi * 64, acc, lane);
+        if (kt + 1 < nkt) stash(cur ^ 1);
+        __syncthreads();
+    }
+    const int li = lane & 15, lq = lane >> 4;
+    const double r2 = 1.4142135623730951;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + wi * 64 + u * 16 + li;
+                const int j = j0 + wj * 64 + t * 16 + lq + 4 * r;
+                if (i >= m || j >= m) continue;
+                if (PASS == 1) C[i + (int64_t)j * m] = acc[t][u][r];
+                else if (i >= j) {
+                    const int64_t idx = (int64_t)j * m - ((int64_t)j * (j - 1)) / 2 + (i - j);
+                    C[idx] = extra * ((i == j) ? acc[t][u][r] : r2 * acc[t][u][r]);
+                }
+            }
+}
+
+__global__ void cg_transpose_kernel(const double* __restrict__ R, double* __restrict__ RT, int m) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < m * m) RT[(e / m) + (int64_t)(e % m) * m] = R[e];
+}
+
+// in: rows of this block in column 0 of the input (column stride ldi); out: its packed rows in column 0 of the output (ldo).
+// scratch: m*m doubles for R' plus m*m per column of a chunk.
+int launch_sdp_congruence(const double* d_rti, int m, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
+                          double extra, double* scratch, size_t scratch_doubles, hipStream_t st) {
+    const size_t mm = (size_t)m * m;
+    if (scratch_doubles < 2 * mm) return -1;
+    static bool attr = false;
+    if (!attr) {
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sdp_congruence_kernel<1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sdp_congruence_kernel<2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        attr = true;
+    }
+    double* RT = scratch;
+    double* Tt = scratch + mm;
+    hipLaunchKernelGGL(cg_transpose_kernel, dim3((unsigned)((mm + 255) / 256)), dim3(256), 0, st, d_rti, RT, m);
+    const int chunk = (int)std::min<size_t>((scratch_doubles - mm) / mm, 65535);
+    const int nt = (m + TILE - 1) / TILE;
+    for (int c0 = 0; c0 < ncols; c0 += chunk) {
+        const int nc = std::min(chunk, ncols - c0);
+        hipLaunchKernelGGL(sdp_congruence_kernel<1>, dim3(nt, nt, nc), dim3(256), kGemmLds, st, RT, m, in + (int64_t)c0 * ldi, ldi, Tt,
+                           (int64_t)mm, 1.0);
+        hipLaunchKernelGGL(sdp_congruence_kernel<2>, dim3(nt, nt, nc), dim3(256), kGemmLds, st, RT, m, Tt, (int64_t)mm,
+                           out + (int64_t)c0 * ldo, ldo, extra);
+    }
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Microbenchmark: issue-bound v_mfma_f64_16x16x4_f64 rate (8 independent accumulators per wave,
 // 2 waves per SIMD).  Confirms the FP64 matrix peak that bench.py's roofline line divides by.

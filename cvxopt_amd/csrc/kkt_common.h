@@ -218,7 +218,12 @@ struct ConeLayout {
     // semidefinite blocks
     int ns = 0, lq_rows = 0, cdim_packed = 0, rlen = 0, s_maxn = 0;
     int *d_sdim = nullptr, *d_soff = nullptr, *d_spoff = nullptr, *d_sroff = nullptr;
+    std::vector<int> h_sdim, h_soff, h_spoff, h_sroff;                 // host copies (the MFMA path is launched per large block)
+    mutable double* d_cong = nullptr;                                  // scratch of launch_sdp_congruence, grown on demand
+    mutable size_t cong_doubles = 0;
 };
+int launch_sdp_congruence(const double* d_rti, int m, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
+                          double extra, double* scratch, size_t scratch_doubles, hipStream_t st);
 int cone_layout_build_s(ConeLayout& cl, int lq_rows, const std::vector<int>& s);
 // out(packed rows of the 's' blocks, ncols columns) = extra * pack(rti' mat(in) rti)
 int launch_sdp_scale_pack(const ConeLayout& cl, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
@@ -270,6 +275,7 @@ struct LpState {
     // 's' blocks (cone_ops_s.h): block k is sdim[k] x sdim[k], full symmetric storage, at soff[k] of the cone vectors, at
     // sloff[k] of lmbda (compact layout: sdim[k] entries), at soff[k] - lq of r / rti / sw1..3, at sloff[k] - lq of sigs / sigz
     int ns = 0, lq = 0, ldim = 0;                     // lq = ml + sum(q); ldim = lq + sum(s) = length of lmbda
+    int nthreads = 256, lds_doubles = 0;              // workgroup size of the loop kernels; dynamic LDS (Jacobi staging)
     const int *sdim = nullptr, *soff = nullptr, *sloff = nullptr;
     double *r = nullptr, *rti = nullptr, *sw1 = nullptr, *sw2 = nullptr, *sw3 = nullptr, *jw = nullptr, *sigs = nullptr,
            *sigz = nullptr;
@@ -314,6 +320,7 @@ struct QpState {
     // 's' blocks (cone_ops_s.h): block k is sdim[k] x sdim[k], full symmetric storage, at soff[k] of the cone vectors, at
     // sloff[k] of lmbda (compact layout: sdim[k] entries), at soff[k] - lq of r / rti / sw1..3, at sloff[k] - lq of sigs / sigz
     int ns = 0, lq = 0, ldim = 0;                     // lq = ml + sum(q); ldim = lq + sum(s) = length of lmbda
+    int nthreads = 256, lds_doubles = 0;              // workgroup size of the loop kernels; dynamic LDS (Jacobi staging)
     const int *sdim = nullptr, *soff = nullptr, *sloff = nullptr;
     double *r = nullptr, *rti = nullptr, *sw1 = nullptr, *sw2 = nullptr, *sw3 = nullptr, *jw = nullptr, *sigs = nullptr,
            *sigz = nullptr;

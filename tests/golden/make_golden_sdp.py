@@ -4,7 +4,7 @@ with 's' blocks, run in the build container and committed with this script (test
     python tests/golden/make_golden_sdp.py
 
   sdp_doc        the SDP of the reference's documentation, examples/doc/chap8/sdp.py (two blocks, 2 and 3)
-  sdp_mc20/60    the max-cut relaxation of examples/doc/chap8/mcsdp.py as a plain cone LP: min 1'x s.t. w + diag(x) >= 0
+  sdp_mc20/60/150 the max-cut relaxation of examples/doc/chap8/mcsdp.py as a plain cone LP: min 1'x s.t. w + diag(x) >= 0
                  (the example's own data generator: w = normal(n, n) symmetrised), solved with the default kktsolver
   sdp_mixed      a random feasible cone LP over R^l_+ x two second-order cones x three 's' blocks with equality constraints
   sdp_qp         a cone QP (solvers.coneqp) with an LP block, a second-order cone and two 's' blocks, equality constraints
@@ -172,6 +172,7 @@ if __name__ == "__main__":
     doc_sdp()
     maxcut(20, 0)
     maxcut(60, 1)
+    maxcut(150, 2)          # beyond the LDS-resident Jacobi of the device code (order <= 101 / 142)
     mixed()
     qp()
     pinf()

@@ -1,0 +1,12 @@
+#!/usr/bin/env bash
+export PYTHONPATH=.
+O=gpurun_out
+( timeout 600 python -m pytest tests/test_gpu_sdp.py -q -m gpu 2>&1 | tail -8 ) > $O/r2s_sdp.log 2>&1
+timeout 600 python tests/sdp_time_dev.py 20 60 100 200 > $O/r2s_time.log 2>&1
+( timeout 900 python -m pytest tests/test_gpu_resident.py tests/test_gpu_fullsize.py -q -m gpu 2>&1 | tail -8 ) > $O/r2s_regress.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_sdp -o sdp -- python $GRAFT_REPO_ROOT/tests/sdp_time_dev.py 100 > $GRAFT_REPO_ROOT/$O/r2s_prof.log 2>&1
+cd $GRAFT_REPO_ROOT
+DB=$(find /tmp/prof_sdp -name '*results.db' | head -1)
+python tools/rocpd_summary.py stats $DB $O/r02_sdp_mc100_kernel_stats.md > /dev/null 2>&1
+echo done
