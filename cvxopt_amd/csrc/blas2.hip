@@ -418,10 +418,23 @@ typedef unsigned long long u64;
 // iterative refinement, three 128 x 128 matrix-vector products spread over the 256 threads:
 //     x0 = M b,   e = b - L_kk x0,   x = x0 + M e        (backward stable like the substitution: Skeel 1980)
 // minv: per 128-block 2 x 16384 doubles, M column-major then M' column-major (the backward solve reads rows of M').
+// jobs (optional): several independent triangular systems in one launch, blockIdx.y = job (the wide supernodes of one level of
+// the sparse engine); every job has its own TRSV_JOB_STRIDE flags / granule blocks.
 template <bool TRANS, bool GRAN, bool INV>
 __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __restrict__ L, int64_t ldl, int n,
                                                               double* x, u32* flags, u32 epoch, int* err, u64* gran,
-                                                              const double* __restrict__ minv) {
+                                                              const double* __restrict__ minv,
+                                                              const TrsvJob* __restrict__ jobs) {
+    if (jobs) {
+        const TrsvJob jb = jobs[blockIdx.y];
+        L = jb.L;
+        ldl = jb.ld;
+        n = jb.n;
+        x = jb.x;
+        flags += (int64_t)blockIdx.y * TRSV_JOB_STRIDE;
+        gran += (int64_t)blockIdx.y * TRSV_JOB_STRIDE * 256;
+        if ((int)blockIdx.x * TB >= n) return;
+    }
     // 256 threads: two per row (forward) / column (backward) of the block row; each holds one 64-wide half of the strip
     // of every off-diagonal block in registers BEFORE waiting for that block's x, so that nothing but 64 FMAs, one
     // partial-sum exchange and the diagonal solve sits between "x_j published" and "x_k published".
@@ -617,26 +630,28 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
 }
 
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
-                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran, const double* minv) {
-    const int nblk = (n + TB - 1) / TB;
+                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran, const double* minv,
+                           const TrsvJob* jobs, int njobs) {
+    const int nblk = (n + TB - 1) / TB;      // with jobs: n = the largest order among them
     if (nblk <= 0) return 0;
+    if (jobs && (njobs <= 0 || nblk > TRSV_JOB_STRIDE || !gran)) return -1;
     static const bool use_flags = getenv("MI355KKT_TRSV") && !strcmp(getenv("MI355KKT_TRSV"), "flag");
     static const bool no_inv = getenv("MI355KKT_TRSV_NOINV") != nullptr;
-    const dim3 g(nblk), b(256);
+    const dim3 g(nblk, jobs ? njobs : 1), b(256);
     if (gran && !use_flags && minv && !no_inv) {
         if (trans)
-            hipLaunchKernelGGL((trsv_persistent_kernel<true, true, true>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
+            hipLaunchKernelGGL((trsv_persistent_kernel<true, true, true>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
         else
-            hipLaunchKernelGGL((trsv_persistent_kernel<false, true, true>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
+            hipLaunchKernelGGL((trsv_persistent_kernel<false, true, true>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
     } else if (gran && !use_flags) {
         if (trans)
-            hipLaunchKernelGGL((trsv_persistent_kernel<true, true, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
+            hipLaunchKernelGGL((trsv_persistent_kernel<true, true, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
         else
-            hipLaunchKernelGGL((trsv_persistent_kernel<false, true, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
+            hipLaunchKernelGGL((trsv_persistent_kernel<false, true, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
     } else if (trans)
-        hipLaunchKernelGGL((trsv_persistent_kernel<true, false, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
+        hipLaunchKernelGGL((trsv_persistent_kernel<true, false, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
     else
-        hipLaunchKernelGGL((trsv_persistent_kernel<false, false, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv);
+        hipLaunchKernelGGL((trsv_persistent_kernel<false, false, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

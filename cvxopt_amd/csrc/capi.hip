@@ -459,7 +459,7 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     if ((rc = alloc(&h->dwork, C + P + 8))) return fail(rc);   // grown to the dense GEMV workspace on first dense use
     if ((rc = alloc(&h->dWst, 2 * C + (size_t)nq + 8))) return fail(rc);
     {
-        const size_t nfl = N / 128 + 2;
+        const size_t nfl = N / 128 + 2 + 64 * TRSV_JOB_STRIDE;    // + room for 64 batched jobs of the sparse engine's wide supernodes
         if (hipMalloc(&h->dflags, sizeof(unsigned int) * nfl) != hipSuccess) return fail(MI355KKT_ENOMEM);
         if (hipMemset(h->dflags, 0, sizeof(unsigned int) * nfl) != hipSuccess) return fail(MI355KKT_EHIP);
         if (hipMalloc(&h->dgran, sizeof(unsigned long long) * nfl * 256) != hipSuccess) return fail(MI355KKT_ENOMEM);
@@ -647,6 +647,7 @@ int mi355kkt_set_sparse_problem_aug(mi355kkt_solver* h, const int64_t* gcolptr, 
         for (int64_t k = gcolptr[j]; k < gcolptr[j + 1]; ++k)
             if (growind[k] < 0 || growind[k] >= rows) { set_last_error("set_sparse_problem: G row index out of range"); return MI355KKT_EINVAL; }
     if (int e = sparse_engine_create(h->sp, h->n, rows, gcolptr, growind, gvalues, hcolptr, hrowind, hvalues)) return e;
+    h->sp.t_flags = h->dflags; h->sp.t_gran = h->dgran; h->sp.t_err = h->derr; h->sp.t_epoch = &h->epoch; h->sp.t_njobs_max = 64;
     h->sparse = true;
     h->firstcall = true;
     h->sp_extra = extra_rows;

@@ -111,7 +111,7 @@ int launch_syrk_nt_update_vb(double* base, const VbDesc* d_desc, int nfronts, in
 // linv_off: per front offsets into the level's progress words / 2048-double inverse blocks
 int launch_potrf_tiles_vb(double* base, const VbDesc* d_desc, int nfronts, const void* d_tickets, int ntickets,
                           const int* d_prog_off, const int* d_linv_off, void* d_ctl, unsigned* d_prog, int nprog, double* d_linv,
-                          int* d_info, hipStream_t st);
+                          int* d_info, hipStream_t st, bool prezeroed = false);
 size_t potrf_tile_ctl_bytes();
 // nbatch matrices `bstride` doubles apart; w.d_info / w.d_dinv must hold nbatch ints / nbatch*2048 doubles
 int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st);
@@ -134,9 +134,11 @@ int launch_mirror_lower(double* A, int64_t lda, int n, hipStream_t st);
 // trans != 0 solves L' x = b and REQUIRES the mirrored upper triangle (launch_mirror_lower after the factorisation)
 // gran != nullptr: data-tagged granule hand-off (256 u64 per 128-block, zeroed once) instead of flag + fences
 // minv != nullptr: inverses of the 128 x 128 diagonal blocks (per block M then M', 2 x 16384 doubles) from the tile Cholesky
+struct TrsvJob { const double* L; int64_t ld; int n; int pad; double* x; };   // one system of a batched launch
+constexpr int TRSV_JOB_STRIDE = 64;    // flags / granule blocks reserved per job (orders up to 8192)
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
                            unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran = nullptr,
-                           const double* minv = nullptr);
+                           const double* minv = nullptr, const TrsvJob* jobs = nullptr, int njobs = 0);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);
@@ -162,6 +164,7 @@ struct SparseSymbolic {
     int tv_prog_max = 0, tv_linv_max = 0;
     int vb_maxcount = 0;
     std::vector<int> heavy, heavy_ptr, heavy_maxhu, heavy_maxw;   // per level: supernodes with large off-diagonal panels
+    std::vector<int> wide, wide_ptr;                              // per level: supernodes wider than 256 columns (dense multi-workgroup solves)
     int64_t store_doubles = 0;
     std::vector<int> child_ptr, child_list, relmap;
     std::vector<int64_t> asm_slot, asm_ptr;       // numeric assembly: one entry per structural nonzero of S
@@ -178,6 +181,12 @@ struct SparseEngine {
     int *d_tv_tickets = nullptr, *d_tv_prog_off = nullptr, *d_tv_linv_off = nullptr;
     unsigned* d_tv_prog = nullptr;
     void* d_tv_ctl = nullptr;
+    // one zero-initialised state buffer per factorisation: per level a TileCtl, the progress words and the per-front info words
+    // of the persistent tile kernel (d_tv_ctl / d_tv_prog alias into it)
+    unsigned char* d_tv_state = nullptr;
+    size_t tv_state_bytes = 0;
+    std::vector<size_t> tv_ctl_at, tv_prog_at;      // byte offsets per level
+    size_t tv_info_at = 0;                          // byte offset of the info words (one per big front, all levels)
     double* d_tv_linv = nullptr;
     PotrfWork pw_vb;
     int64_t *d_sn_rowptr = nullptr, *d_panel_off = nullptr, *d_upd_off = nullptr, *d_relmap_off = nullptr,
@@ -186,6 +195,15 @@ struct SparseEngine {
     double *d_gv = nullptr, *d_hv = nullptr, *d_rem = nullptr, *d_panels = nullptr, *d_upd = nullptr, *d_xp = nullptr,
            *d_rem_multi = nullptr;
     int rem_multi_cols = 0;
+    // hand-off state of the persistent dense triangular solve (blas2.hip) used for the wide supernodes: borrowed from the handle
+    unsigned int* t_flags = nullptr;
+    unsigned long long* t_gran = nullptr;
+    int* t_err = nullptr;
+    unsigned int* t_epoch = nullptr;
+    int t_njobs_max = 0;                       // jobs the borrowed flags / granules have room for
+    TrsvJob* d_wide_jobs = nullptr;            // one per wide supernode, in the order of sym.wide (x = d_xp + first column)
+    int* d_wide = nullptr;                     // sym.wide on the device
+    std::vector<int> wide_maxw;                // per level
 };
 int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const int64_t* gri, const int64_t* hcp,
                      const int64_t* hri);

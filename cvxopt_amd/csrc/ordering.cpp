@@ -184,7 +184,9 @@ void cost_of(const std::vector<int64_t>& cc, int64_t& nnz, double& flops) {
 void relaxed_supernodes(const std::vector<int>& parent, const std::vector<int64_t>& cc, std::vector<int>& sn_first,
                         std::vector<int>& sn_of) {
     const int n = (int)parent.size();
-    const int MAXW = 256;
+    // widest supernode: wider ones (the top separators of a nested dissection) are factored and solved by the multi-workgroup
+    // dense kernels as ONE front instead of a chain of 256-column pieces, one level each ($MI355KKT_SN_MAXW: experiments)
+    static const int MAXW = getenv("MI355KKT_SN_MAXW") ? std::max(1, atoi(getenv("MI355KKT_SN_MAXW"))) : 8192;
     sn_first.clear();
     sn_of.assign(n, 0);
     int64_t true_nnz = 0;        // nonzeros of L in the columns of the current supernode

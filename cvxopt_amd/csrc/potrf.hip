@@ -1184,7 +1184,7 @@ void potrf_work_free(PotrfWork& w) {
 // all big fronts of one level of the supernodal tree (see potrf_tiles_vb_kernel); d_info: nfronts ints, zeroed here
 int launch_potrf_tiles_vb(double* base, const VbDesc* d_desc, int nfronts, const void* d_tickets, int ntickets,
                           const int* d_prog_off, const int* d_linv_off, void* d_ctl, unsigned* d_prog, int nprog, double* d_linv,
-                          int* d_info, hipStream_t st) {
+                          int* d_info, hipStream_t st, bool prezeroed) {
     if (nfronts <= 0 || ntickets <= 0) return 0;
     static int num_cus = 0;
     static bool attr_set = false;
@@ -1199,9 +1199,11 @@ int launch_potrf_tiles_vb(double* base, const VbDesc* d_desc, int nfronts, const
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    KKT_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int) * nfronts, st));
-    KKT_HIP_CHECK(hipMemsetAsync(d_ctl, 0, sizeof(TileCtl), st));
-    KKT_HIP_CHECK(hipMemsetAsync(d_prog, 0, sizeof(unsigned) * (nprog > 0 ? nprog : 1), st));
+    if (!prezeroed) {       // (the sparse engine zeroes the state of all its levels with one memset per factorisation)
+        KKT_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int) * nfronts, st));
+        KKT_HIP_CHECK(hipMemsetAsync(d_ctl, 0, sizeof(TileCtl), st));
+        KKT_HIP_CHECK(hipMemsetAsync(d_prog, 0, sizeof(unsigned) * (nprog > 0 ? nprog : 1), st));
+    }
     const int grid = ntickets < num_cus ? ntickets : num_cus;
     hipLaunchKernelGGL(potrf_tiles_vb_kernel, dim3(grid), dim3(PT_THREADS), lds, st, base, d_desc,
                        reinterpret_cast<const VbTicket*>(d_tickets), (unsigned)ntickets, d_prog_off, d_linv_off,

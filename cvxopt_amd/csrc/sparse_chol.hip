@@ -294,13 +294,22 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
             const int sn = S.level_sn[k];
             const int64_t h = S.sn_rowptr[sn + 1] - S.sn_rowptr[sn], w = S.sn_first[sn + 1] - S.sn_first[sn];
-            if ((h - w) * w > 32768) {      // == SP_HEAVY in the kernels
+            if ((h - w) * w > 32768 || (w > 256 && h > w)) {      // == SP_HEAVY / SP_WIDE in the kernels
                 S.heavy.push_back(sn);
                 S.heavy_maxhu[l] = std::max<int>(S.heavy_maxhu[l], (int)(h - w));
                 S.heavy_maxw[l] = std::max<int>(S.heavy_maxw[l], (int)w);
             }
         }
         S.heavy_ptr[l + 1] = (int)S.heavy.size();
+    }
+    // supernodes wider than one workgroup's LDS vector (256): their diagonal blocks are solved by the persistent dense
+    // triangular solve (blas2.hip), launched one by one (they are the few top separators of the tree)
+    S.wide.clear();
+    S.wide_ptr.assign(S.nlevels + 1, 0);
+    for (int l = 0; l < S.nlevels; ++l) {
+        for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k)
+            if (S.sn_first[S.level_sn[k] + 1] - S.sn_first[S.level_sn[k]] > 256) S.wide.push_back(S.level_sn[k]);
+        S.wide_ptr[l + 1] = (int)S.wide.size();
     }
     if (getenv("MI355KKT_SPARSE_DEBUG")) {
         fprintf(stderr, "[sparse] n=%d supernodes=%d levels=%d store=%.1f MB\n", n, ns, S.nlevels, off * 8.0 / 1e6);
@@ -560,11 +569,13 @@ __global__ __launch_bounds__(256) void sp_extend_add_vb_kernel(SpDev d, const Vb
         if (jb > ja && ib > ia) {
             const double* __restrict__ Uc = store + d.upd_off[c];
             const int ldc = d.upd_ld[c];
-            const int rows = ib - ia;
-            for (int64_t e = threadIdx.x; e < (int64_t)(jb - ja) * rows; e += 256) {
-                const int j = ja + (int)(e / rows), i = ia + (int)(e % rows);
-                if (i < j) continue;
-                F[rm[i] + (int64_t)rm[j] * h] += Uc[i + (int64_t)j * ldc];
+            // a thread owns a row of the child's update matrix (its target row is looked up once) and walks the tile's
+            // columns: consecutive threads read consecutive entries of a column, no integer division per entry
+            for (int i = ia + threadIdx.x; i < ib; i += 256) {
+                const int ri = rm[i];
+                const double* __restrict__ u = Uc + i;
+                const int jend = min(jb, i + 1);          // lower triangle: i >= j
+                for (int j = ja; j < jend; ++j) F[ri + (int64_t)rm[j] * h] += u[(int64_t)j * ldc];
             }
         }
         __syncthreads();
@@ -586,6 +597,7 @@ __global__ void sp_merge_info_kernel(const int* __restrict__ local, int offset, 
 // the block to the rest of the vector.
 constexpr int SPB = 32;
 constexpr int64_t SP_HEAVY = 32768;     // supernodes with more off-diagonal panel entries get the multi-workgroup kernels
+constexpr int SP_WIDE = 256;            // wider supernodes: gather / dense persistent trsv / multi-workgroup products
 
 __device__ __forceinline__ void sp_trsv_fwd_lds(const double* __restrict__ P, int h, int w, double* xs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -690,6 +702,7 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
     const int w = d.sn_first[s + 1] - f;
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
     const int hu = h - w;
+    if (w > SP_WIDE) return;                            // sp_fwd_wide_gather_kernel + launch_trsv_persistent + sp_fwd_rem_kernel
     const double* __restrict__ P = panels + d.panel_off[s];
     double* __restrict__ R = rem + rem_off[s];          // hu entries
     for (int i = tid; i < hu; i += 256) R[i] = 0.0;
@@ -725,12 +738,15 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
     }
 }
 
-// R_s -= L21 y_s for the heavy supernodes of a level: grid (row chunks of 256, heavy supernodes)
+// R_s -= L21 y_s for the heavy supernodes of a level: grid (row chunks of 64, heavy supernodes[, right-hand sides]).  A
+// workgroup owns 64 rows (one per lane); its four waves split the columns (j mod 4) and their partial sums are added in wave
+// order, so the result does not depend on the schedule.  Any width: the solved block goes through LDS 256 entries at a time.
 __global__ __launch_bounds__(256) void sp_fwd_rem_kernel(SpDev d, const int* __restrict__ heavy,
                                                          const double* __restrict__ panels, const double* __restrict__ x,
                                                          double* __restrict__ rem, const int64_t* __restrict__ rem_off,
                                                          int64_t xstride, int64_t remstride) {
     __shared__ double xs[256];
+    __shared__ double red[4][64];
     x += (int64_t)blockIdx.z * xstride;
     rem += (int64_t)blockIdx.z * remstride;
     const int s = heavy[blockIdx.y];
@@ -738,22 +754,56 @@ __global__ __launch_bounds__(256) void sp_fwd_rem_kernel(SpDev d, const int* __r
     const int w = d.sn_first[s + 1] - f;
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
     const int hu = h - w;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= hu) return;
-    if (threadIdx.x < w) xs[threadIdx.x] = x[f + threadIdx.x];
-    __syncthreads();
-    if (i >= hu) return;
-    const double* __restrict__ P = panels + d.panel_off[s] + w + i;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int j = 0;
-    for (; j + 4 <= w; j += 4) {
-        a0 += P[(int64_t)j * h] * xs[j];
-        a1 += P[(int64_t)(j + 1) * h] * xs[j + 1];
-        a2 += P[(int64_t)(j + 2) * h] * xs[j + 2];
-        a3 += P[(int64_t)(j + 3) * h] * xs[j + 3];
+    if ((int)blockIdx.x * 64 >= hu) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const double* __restrict__ P = panels + d.panel_off[s] + w + min(i, hu - 1);
+    double a0 = 0.0, a1 = 0.0;
+    for (int c0 = 0; c0 < w; c0 += 256) {
+        const int wc = min(256, w - c0);
+        __syncthreads();
+        if ((int)threadIdx.x < wc) xs[threadIdx.x] = x[f + c0 + threadIdx.x];
+        __syncthreads();
+        const double* __restrict__ Pc = P + (int64_t)c0 * h;
+        int j = wave;
+        for (; j + 4 < wc; j += 8) {                    // two loads in flight per thread
+            a0 += Pc[(int64_t)j * h] * xs[j];
+            a1 += Pc[(int64_t)(j + 4) * h] * xs[j + 4];
+        }
+        for (; j < wc; j += 4) a0 += Pc[(int64_t)j * h] * xs[j];
     }
-    for (; j < w; ++j) a0 += P[(int64_t)j * h] * xs[j];
-    rem[rem_off[s] + i] -= (a0 + a1) + (a2 + a3);
+    red[wave][lane] = a0 + a1;
+    __syncthreads();
+    if (wave == 0 && i < hu) rem[rem_off[s] + i] -= (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// children contributions of a wide supernode (w > SP_WIDE), straight in global memory: x_s += updates into its columns,
+// R_s = updates below them; one workgroup per right-hand side, children one after the other (deterministic, no atomics)
+__global__ __launch_bounds__(256) void sp_fwd_wide_gather_kernel(SpDev d, const int* __restrict__ wide, double* __restrict__ x,
+                                                                 double* __restrict__ rem, const int64_t* __restrict__ rem_off,
+                                                                 int64_t xstride, int64_t remstride) {
+    x += (int64_t)blockIdx.y * xstride;
+    rem += (int64_t)blockIdx.y * remstride;
+    const int s = wide[blockIdx.x];                     // the wide supernodes of a level, one workgroup each
+    const int tid = threadIdx.x;
+    const int f = d.sn_first[s];
+    const int w = d.sn_first[s + 1] - f;
+    const int hu = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]) - w;
+    double* __restrict__ R = rem + rem_off[s];
+    for (int i = tid; i < hu; i += 256) R[i] = 0.0;
+    __syncthreads();
+    for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
+        const int c = d.child_list[ci];
+        const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
+        const double* __restrict__ Rc = rem + rem_off[c];
+        const int* __restrict__ rm = d.relmap + d.relmap_off[c];
+        for (int i = tid; i < hc; i += 256) {
+            const int p = rm[i];
+            if (p < w) x[f + p] += Rc[i];
+            else R[p - w] += Rc[i];
+        }
+        __syncthreads();
+    }
 }
 
 // y_j -= sum_{i >= w} L[i][j] x[rows[i]] for `ncol` columns starting at j0: one wave per column, lanes along the
@@ -801,6 +851,7 @@ __global__ __launch_bounds__(256) void sp_bwd_kernel(SpDev d, int level_begin, c
     const int w = d.sn_first[s + 1] - f;
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
     const double* __restrict__ P = panels + d.panel_off[s];
+    if (w > SP_WIDE) return;                            // sp_bwd_gemv_kernel + launch_trsv_persistent (transposed)
     if (tid < w) xs[tid] = x[f + tid];
     __syncthreads();
     if ((int64_t)(h - w) * w <= SP_HEAVY && h > w) {
@@ -898,8 +949,21 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     if (int e = up(&E.d_tv_tickets, S.tv_tickets)) return e;
     if (int e = up(&E.d_tv_prog_off, S.tv_prog_off)) return e;
     if (int e = up(&E.d_tv_linv_off, S.tv_linv_off)) return e;
-    KKT_HIP_CHECK(hipMalloc(&E.d_tv_prog, sizeof(unsigned) * (size_t)std::max(1, S.tv_prog_max)));
-    KKT_HIP_CHECK(hipMalloc(&E.d_tv_ctl, potrf_tile_ctl_bytes()));
+    {   // state of the persistent tile kernel for every level, zeroed by ONE memset per factorisation
+        size_t at = 0;
+        E.tv_ctl_at.assign(S.nlevels, 0);
+        E.tv_prog_at.assign(S.nlevels, 0);
+        for (int l = 0; l < S.nlevels; ++l) {
+            E.tv_ctl_at[l] = at;
+            at += (potrf_tile_ctl_bytes() + 63) & ~(size_t)63;
+            E.tv_prog_at[l] = at;
+            at += (sizeof(unsigned) * (size_t)std::max(1, S.tv_nprog[l]) + 63) & ~(size_t)63;
+        }
+        E.tv_info_at = at;
+        at += sizeof(int) * std::max<size_t>(1, S.vb.size());
+        E.tv_state_bytes = at;
+        KKT_HIP_CHECK(hipMalloc(&E.d_tv_state, at));
+    }
     KKT_HIP_CHECK(hipMalloc(&E.d_tv_linv, sizeof(double) * 2048 * (size_t)std::max(1, S.tv_linv_max)));
     if (int e = potrf_work_init_batched(E.pw_vb, std::max(1, S.vb_maxcount))) return e;
     {   // G in CSC (values + int rows) and CSR (for G x)
@@ -960,6 +1024,21 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     KKT_HIP_CHECK(hipMalloc(&E.d_panels, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
     E.d_upd = nullptr;          // update matrices live in the same buffer (offsets are absolute)
     KKT_HIP_CHECK(hipMalloc(&E.d_xp, sizeof(double) * (n ? n : 1)));
+    {   // the wide supernodes as jobs of the batched persistent triangular solve (single right-hand side: x = d_xp)
+        std::vector<TrsvJob> jobs(S.wide.size());
+        for (size_t k = 0; k < S.wide.size(); ++k) {
+            const int s = S.wide[k];
+            jobs[k] = TrsvJob{E.d_panels + S.panel_off[s], S.sn_rowptr[s + 1] - S.sn_rowptr[s], S.sn_first[s + 1] - S.sn_first[s], 0,
+                              E.d_xp + S.sn_first[s]};
+        }
+        E.wide_maxw.assign(S.nlevels, 0);
+        for (int l = 0; l < S.nlevels; ++l)
+            for (int k = S.wide_ptr[l]; k < S.wide_ptr[l + 1]; ++k)
+                E.wide_maxw[l] = std::max(E.wide_maxw[l], S.sn_first[S.wide[k] + 1] - S.sn_first[S.wide[k]]);
+        KKT_HIP_CHECK(hipMalloc(&E.d_wide_jobs, sizeof(TrsvJob) * std::max<size_t>(1, jobs.size())));
+        if (!jobs.empty()) KKT_HIP_CHECK(hipMemcpy(E.d_wide_jobs, jobs.data(), sizeof(TrsvJob) * jobs.size(), hipMemcpyHostToDevice));
+        if (int e = up(&E.d_wide, S.wide)) return e;
+    }
     KKT_HIP_CHECK(hipMalloc(&E.d_info, sizeof(int)));
     KKT_HIP_CHECK(hipHostMalloc(&E.h_info, sizeof(int)));
     return 0;
@@ -970,7 +1049,7 @@ void sparse_engine_free(SparseEngine& E) {
                     E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
                     E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap, E.d_rem_multi, E.d_iperm,
-                    E.d_tv_tickets, E.d_tv_prog_off, E.d_tv_linv_off, E.d_tv_prog, E.d_tv_ctl, E.d_tv_linv};
+                    E.d_tv_tickets, E.d_tv_prog_off, E.d_tv_linv_off, E.d_tv_state, E.d_tv_linv, E.d_wide_jobs, E.d_wide};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
@@ -1006,6 +1085,8 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
         hipLaunchKernelGGL(sp_assemble_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, nt, E.d_asm_slot,
                            E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r, E.d_gv, E.d_hv, d_di, E.d_panels);
     const SpDev d = devview(E);
+    static const bool old_chain = getenv("MI355KKT_SPARSE_TILES") && !strcmp(getenv("MI355KKT_SPARSE_TILES"), "0");
+    if (!old_chain) KKT_HIP_CHECK(hipMemsetAsync(E.d_tv_state, 0, E.tv_state_bytes, st));
     for (int l = 0; l < S.nlevels; ++l) {
         const int nsmall = S.level_nsmall[l];
         if (nsmall > 0)
@@ -1017,21 +1098,72 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
             const VbDesc* dv = E.d_vb + S.vb_ptr[l];
             hipLaunchKernelGGL(sp_extend_add_vb_kernel, dim3((S.vb_maxh[l] + EA_COLS - 1) / EA_COLS, (S.vb_maxh[l] + EA_ROWS - 1) / EA_ROWS, nbig),
                                dim3(256), 0, st, d, dv, E.d_panels);
-            static const bool old_chain = getenv("MI355KKT_SPARSE_TILES") && !strcmp(getenv("MI355KKT_SPARSE_TILES"), "0");
             if (old_chain) {
                 if (int e = launch_potrf_partial_vb(E.d_panels, dv, nbig, S.vb_maxh[l], S.vb_maxw[l], E.pw_vb, st)) return e;
+                hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3((nbig + 255) / 256), dim3(256), 0, st, E.pw_vb.d_info, nbig, E.d_info);
             } else if (int e = launch_potrf_tiles_vb(E.d_panels, dv, nbig, E.d_tv_tickets + 4 * (size_t)S.tv_ptr[l],
                                                     S.tv_ptr[l + 1] - S.tv_ptr[l], E.d_tv_prog_off + S.vb_ptr[l],
-                                                    E.d_tv_linv_off + S.vb_ptr[l], E.d_tv_ctl, E.d_tv_prog, S.tv_nprog[l],
-                                                    E.d_tv_linv, E.pw_vb.d_info, st))
+                                                    E.d_tv_linv_off + S.vb_ptr[l], E.d_tv_state + E.tv_ctl_at[l],
+                                                    reinterpret_cast<unsigned*>(E.d_tv_state + E.tv_prog_at[l]), S.tv_nprog[l], E.d_tv_linv,
+                                                    reinterpret_cast<int*>(E.d_tv_state + E.tv_info_at) + S.vb_ptr[l], st, true))
                 return e;
-            hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3((nbig + 255) / 256), dim3(256), 0, st, E.pw_vb.d_info, nbig, E.d_info);
         }
+    }
+    if (!old_chain && !S.vb.empty())       // first failing pivot over the big fronts of all levels
+        hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3(((unsigned)S.vb.size() + 255) / 256), dim3(256), 0, st,
+                           reinterpret_cast<const int*>(E.d_tv_state + E.tv_info_at), (int)S.vb.size(), E.d_info);
+    // the transposed persistent solve of the wide supernodes streams L11' from the (unused) upper triangle of the front
+    for (int s : S.wide) {
+        const int w = S.sn_first[s + 1] - S.sn_first[s], h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+        if (int e = launch_mirror_lower(E.d_panels + S.panel_off[s], h, w, st)) return e;
     }
     KKT_HIP_CHECK(hipGetLastError());
     KKT_HIP_CHECK(hipMemcpyAsync(E.h_info, E.d_info, sizeof(int), hipMemcpyDeviceToHost, st));
     KKT_HIP_CHECK(hipStreamSynchronize(st));
     if (info) *info = (*E.h_info == imax) ? 0 : *E.h_info;
+    return 0;
+}
+
+// Wide supernodes of level l (w > SP_WIDE; the top separators): children contributions gathered in global memory, the dense
+// diagonal block through the persistent multi-workgroup triangular solve of the dense engine (one right-hand side) or the
+// blocked trsm (several).  Runs after the level's sp_fwd_kernel and before its sp_fwd_rem_kernel.
+static int sp_wide_forward(SparseEngine& E, const SpDev& d, int l, double* x, double* rem, int64_t xstride, int64_t remstride,
+                           int nrhs, hipStream_t st) {
+    const SparseSymbolic& S = E.sym;
+    const int k0 = S.wide_ptr[l], nw = S.wide_ptr[l + 1] - k0;
+    if (nw == 0) return 0;
+    hipLaunchKernelGGL(sp_fwd_wide_gather_kernel, dim3(nw, nrhs), dim3(256), 0, st, d, E.d_wide + k0, x, rem, E.d_rem_off, xstride,
+                       remstride);
+    if (nrhs == 1 && x == E.d_xp && E.t_flags && nw <= E.t_njobs_max)      // all of the level's systems in one launch
+        return launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 0, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran, nullptr,
+                                      E.d_wide_jobs + k0, nw);
+    for (int k = k0; k < k0 + nw; ++k) {
+        const int s = S.wide[k], f = S.sn_first[s], w = S.sn_first[s + 1] - f;
+        const int h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+        const double* P = E.d_panels + S.panel_off[s];
+        if (nrhs == 1 && E.t_flags) {
+            if (int e = launch_trsv_persistent(P, h, w, x + f, 0, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran)) return e;
+        } else if (int e = launch_trsm_lower(P, h, w, x + f, xstride, nrhs, 0, st))
+            return e;
+    }
+    return 0;
+}
+static int sp_wide_backward(SparseEngine& E, int l, double* x, hipStream_t st) {
+    const SparseSymbolic& S = E.sym;
+    const int k0 = S.wide_ptr[l], nw = S.wide_ptr[l + 1] - k0;
+    if (nw == 0) return 0;
+    if (x == E.d_xp && E.t_flags && nw <= E.t_njobs_max)
+        return launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 1, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran, nullptr,
+                                      E.d_wide_jobs + k0, nw);
+    for (int k = S.wide_ptr[l]; k < S.wide_ptr[l + 1]; ++k) {
+        const int s = S.wide[k], f = S.sn_first[s], w = S.sn_first[s + 1] - f;
+        const int h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+        const double* P = E.d_panels + S.panel_off[s];
+        if (E.t_flags) {      // (L' streamed from the mirrored upper triangle, see sparse_engine_factor)
+            if (int e = launch_trsv_persistent(P, h, w, x + f, 1, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran)) return e;
+        } else if (int e = launch_trsm_lower(P, h, w, x + f, w, 1, 1, st))
+            return e;
+    }
     return 0;
 }
 
@@ -1047,9 +1179,10 @@ int sparse_engine_forward(SparseEngine& E, const double* d_in, double* d_out_per
         if (cnt > 0)
             hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp, E.d_rem,
                                E.d_rem_off, (int64_t)0, (int64_t)0);
+        if (int e = sp_wide_forward(E, d, l, E.d_xp, E.d_rem, 0, 0, 1, st)) return e;
         const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
         if (nh > 0)
-            hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 255) / 256, nh), dim3(256), 0, st, d,
+            hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 63) / 64, nh), dim3(256), 0, st, d,
                                E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp, E.d_rem, E.d_rem_off, (int64_t)0, (int64_t)0);
     }
     if (d_out_perm) KKT_HIP_CHECK(hipMemcpyAsync(d_out_perm, E.d_xp, sizeof(double) * E.n, hipMemcpyDeviceToDevice, st));
@@ -1083,9 +1216,10 @@ int sparse_engine_forward_rows(SparseEngine& E, const double* d_A, int64_t lda, 
             if (cnt > 0)
                 hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt, nj), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, out, E.d_rem_multi,
                                    E.d_rem_off, (int64_t)E.n, remtot);
+            if (int e = sp_wide_forward(E, d, l, out, E.d_rem_multi, (int64_t)E.n, remtot, nj, st)) return e;
             const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
             if (nh > 0)
-                hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 255) / 256, nh, nj), dim3(256), 0, st, d,
+                hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 63) / 64, nh, nj), dim3(256), 0, st, d,
                                    E.d_heavy + S.heavy_ptr[l], E.d_panels, out, E.d_rem_multi, E.d_rem_off, (int64_t)E.n, remtot);
         }
     }
@@ -1131,9 +1265,10 @@ int sparse_engine_forward_rows_csr(SparseEngine& E, const int64_t* d_rp, const i
             if (cnt > 0)
                 hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt, nj), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, out, E.d_rem_multi,
                                    E.d_rem_off, (int64_t)E.n, remtot);
+            if (int e = sp_wide_forward(E, d, l, out, E.d_rem_multi, (int64_t)E.n, remtot, nj, st)) return e;
             const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
             if (nh > 0)
-                hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 255) / 256, nh, nj), dim3(256), 0, st, d,
+                hipLaunchKernelGGL(sp_fwd_rem_kernel, dim3((S.heavy_maxhu[l] + 63) / 64, nh, nj), dim3(256), 0, st, d,
                                    E.d_heavy + S.heavy_ptr[l], E.d_panels, out, E.d_rem_multi, E.d_rem_off, (int64_t)E.n, remtot);
         }
     }
@@ -1153,6 +1288,7 @@ int sparse_engine_backward(SparseEngine& E, double* d_out, hipStream_t st) {
             hipLaunchKernelGGL(sp_bwd_gemv_kernel, dim3((S.heavy_maxw[l] + 15) / 16, nh), dim3(256), 0, st, d,
                                E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp);
         if (cnt > 0) hipLaunchKernelGGL(sp_bwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp);
+        if (int e = sp_wide_backward(E, l, E.d_xp, st)) return e;
     }
     hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, E.d_xp, d_out, E.d_perm, E.n, 0);
     KKT_HIP_CHECK(hipGetLastError());

@@ -121,6 +121,17 @@ def test_conelp_device_loop_with_s_cones_vs_reference_fixture(name, kktsolver):
     check_table(tab, g['table'])
 
 
+def test_block_beyond_the_lds_resident_jacobi():
+    """order 150: the eigendecompositions / the SVD of the scaling update run out of global memory (the LDS-resident Jacobi
+    holds blocks up to 142 / 101), the KKT assembly takes the FP64-MFMA congruence path"""
+    g = gold("sdp_mc150")
+    dims = dims_of(g)
+    sol, tab = run_with_progress(lambda: cvxopt_amd.conelp_device(g['c'], np.asfortranarray(g['G']), g['h'], dims,
+                                                                  show_progress=True))
+    check_solution(sol, g, dims)
+    check_table(tab, g['table'])
+
+
 def test_only_the_lower_triangles_of_G_and_h_count():
     g = gold("sdp_mixed")
     dims = dims_of(g)

@@ -60,7 +60,7 @@ class Plan(object):
         n, ns = self.n, self.ns
         assert sorted(self.perm.tolist()) == list(range(n))
         assert self.sn_first[0] == 0 and self.sn_first[ns] == n and np.all(np.diff(self.sn_first) > 0)
-        assert np.all(np.diff(self.sn_first) <= 256)
+        assert np.all(np.diff(self.sn_first) <= 8192)
         ends = []
         for s in range(ns):
             f, l = self.sn_first[s], self.sn_first[s + 1]
@@ -94,7 +94,7 @@ class Plan(object):
             assert np.array_equal(vb[:, 0], self.panel_off[sl[k:]]) and np.array_equal(vb[:, 1], hgt[sl[k:]])
             assert np.array_equal(vb[:, 2], wid[sl[k:]]) and np.array_equal(vb[:, 3], self.sn_first[sl[k:]])
             heavy = self.heavy[self.heavy_ptr[l]:self.heavy_ptr[l + 1]]
-            expect = [int(s_) for s_ in sl if (hgt[s_] - wid[s_]) * wid[s_] > 32768]
+            expect = [int(s_) for s_ in sl if (hgt[s_] - wid[s_]) * wid[s_] > 32768 or (wid[s_] > 256 and hgt[s_] > wid[s_])]
             assert heavy.tolist() == expect
 
     def factor(self, di):
