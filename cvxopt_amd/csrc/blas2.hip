@@ -352,10 +352,17 @@ __global__ __launch_bounds__(64) void trsv_diag_bwd_kernel(const double* __restr
 // ===================================================================================================
 // A(upper) := A(lower)': the backward solve then streams L' with the same coalesced row-of-a-block-row pattern as the
 // forward solve streams L (32 x 32 tiles through LDS; diagonal tiles mirror themselves).
-__global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ A, int64_t lda, int n) {
+__global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ A, int64_t lda, int n,
+                                                           const TrsvJob* __restrict__ jobs) {
     __shared__ double t[32][33];
+    if (jobs) {                          // several matrices, blockIdx.z = job (the wide supernodes of the sparse engine)
+        const TrsvJob jb = jobs[blockIdx.z];
+        A = const_cast<double*>(jb.L);
+        lda = jb.ld;
+        n = jb.n;
+    }
     const int bi = blockIdx.x, bj = blockIdx.y;
-    if (bj > bi) return;
+    if (bj > bi || bi * 32 >= n) return;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
     const int i0 = bi * 32, j0 = bj * 32;
 #pragma unroll
@@ -374,7 +381,14 @@ __global__ __launch_bounds__(256) void mirror_lower_kernel(double* __restrict__ 
 int launch_mirror_lower(double* A, int64_t lda, int n, hipStream_t st) {
     if (n <= 1) return 0;
     const int nb = (n + 31) / 32;
-    hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb, nb), dim3(256), 0, st, A, lda, n);
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb, nb), dim3(256), 0, st, A, lda, n, nullptr);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+int launch_mirror_lower_jobs(const TrsvJob* d_jobs, int njobs, int nmax, hipStream_t st) {
+    if (njobs <= 0 || nmax <= 1) return 0;
+    const int nb = (nmax + 31) / 32;
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb, nb, njobs), dim3(256), 0, st, nullptr, (int64_t)0, 0, d_jobs);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -135,6 +135,7 @@ int launch_mirror_lower(double* A, int64_t lda, int n, hipStream_t st);
 // gran != nullptr: data-tagged granule hand-off (256 u64 per 128-block, zeroed once) instead of flag + fences
 // minv != nullptr: inverses of the 128 x 128 diagonal blocks (per block M then M', 2 x 16384 doubles) from the tile Cholesky
 struct TrsvJob { const double* L; int64_t ld; int n; int pad; double* x; };   // one system of a batched launch
+int launch_mirror_lower_jobs(const TrsvJob* d_jobs, int njobs, int nmax, hipStream_t st);   // the same for a list of matrices
 constexpr int TRSV_JOB_STRIDE = 64;    // flags / granule blocks reserved per job (orders up to 8192)
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
                            unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran = nullptr,
@@ -164,6 +165,8 @@ struct SparseSymbolic {
     int tv_prog_max = 0, tv_linv_max = 0;
     int vb_maxcount = 0;
     std::vector<int> heavy, heavy_ptr, heavy_maxhu, heavy_maxw;   // per level: supernodes with large off-diagonal panels
+    std::vector<int64_t> ea_off;                                  // extend-add tile-boundary tables of the children of big fronts
+    std::vector<int> ea_lb;
     std::vector<int> wide, wide_ptr;                              // per level: supernodes wider than 256 columns (dense multi-workgroup solves)
     int64_t store_doubles = 0;
     std::vector<int> child_ptr, child_list, relmap;
@@ -201,6 +204,8 @@ struct SparseEngine {
     int* t_err = nullptr;
     unsigned int* t_epoch = nullptr;
     int t_njobs_max = 0;                       // jobs the borrowed flags / granules have room for
+    int64_t* d_ea_off = nullptr;
+    int* d_ea_lb = nullptr;
     TrsvJob* d_wide_jobs = nullptr;            // one per wide supernode, in the order of sym.wide (x = d_xp + first column)
     int* d_wide = nullptr;                     // sym.wide on the device
     std::vector<int> wide_maxw;                // per level

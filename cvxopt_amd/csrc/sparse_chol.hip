@@ -356,6 +356,28 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
             for (int r : snrows[p]) where[r] = -1;
         }
     }
+    // extend-add of the big fronts works on 64-column x 256-row tiles of the parent: for every child of a big front the
+    // first child row that lands at or beyond each multiple of 64 of the parent's row positions (so a tile finds its share
+    // of a child with four table reads instead of four binary searches through global memory)
+    S.ea_off.assign(ns + 1, 0);
+    for (int p = 0; p < ns; ++p)
+        for (int c : snchild[p]) {
+            const int64_t hp = S.sn_rowptr[p + 1] - S.sn_rowptr[p];
+            S.ea_off[c + 1] = S.big[p] ? (hp + 63) / 64 + 1 : 0;
+        }
+    for (int s2 = 0; s2 < ns; ++s2) S.ea_off[s2 + 1] += S.ea_off[s2];
+    S.ea_lb.assign(S.ea_off[ns], 0);
+    for (int c = 0; c < ns; ++c) {
+        const int64_t nb = S.ea_off[c + 1] - S.ea_off[c];
+        if (nb == 0) continue;
+        const int* rm = S.relmap.data() + S.relmap_off[c];
+        const int hc = (int)(S.relmap_off[c + 1] - S.relmap_off[c]);
+        int k = 0;
+        for (int64_t t = 0; t < nb; ++t) {
+            while (k < hc && rm[k] < t * 64) ++k;
+            S.ea_lb[S.ea_off[c] + t] = k;
+        }
+    }
     lap("tree, levels, maps");
     // ---- numeric assembly lists: every structural nonzero of S in (permuted) column j, row i >= j, gets a slot in
     //      its supernode's panel; contributions: H entries and products G_ra G_rb di_r^2.
@@ -456,6 +478,8 @@ struct SpDev {   // device copies of the symbolic structure (plain pointers for 
     const int64_t* relmap_off;
     const int* relmap;
     const int* level_sn;
+    const int64_t* ea_off;     // per child of a big front: offset of its tile-boundary table in ea_lb
+    const int* ea_lb;
 };
 
 // One workgroup = one frontal matrix.  F = [ L-panel (h x w) | U (h-w x h-w) ]: the panel already holds the
@@ -540,7 +564,7 @@ __global__ __launch_bounds__(256) void sp_front_kernel(SpDev d, int level_begin,
 // blocks, fronts).  One workgroup owns its block of the target front, so the children can be added one after the
 // other (deterministic, no atomics); the child rows / columns that land in the block are contiguous ranges of its
 // sorted map.
-constexpr int EA_COLS = 64, EA_ROWS = 256;
+constexpr int EA_COLS = 64, EA_ROWS = 64;
 __global__ __launch_bounds__(256) void sp_extend_add_vb_kernel(SpDev d, const VbDesc* __restrict__ vb, double* store) {
     const VbDesc dd = vb[blockIdx.z];
     const int s = dd.pad;                      // supernode id
@@ -549,33 +573,42 @@ __global__ __launch_bounds__(256) void sp_extend_add_vb_kernel(SpDev d, const Vb
     const int r0 = blockIdx.y * EA_ROWS, r1 = min(r0 + EA_ROWS, h);
     if (c0 >= h || r0 >= h || r1 <= c0) return;            // outside the front / strictly above the diagonal
     double* __restrict__ F = store + dd.off;
-    __shared__ int range[4];
+    const int nbt = (h + 63) / 64;             // last entry of a child's boundary table (= its number of update rows)
     for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
         const int c = d.child_list[ci];
         const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
         if (hc <= 0) continue;
         const int* __restrict__ rm = d.relmap + d.relmap_off[c];
-        if (threadIdx.x < 4) {                 // first child index with rm >= c0, c1, r0, r1
-            const int target = threadIdx.x == 0 ? c0 : (threadIdx.x == 1 ? c1 : (threadIdx.x == 2 ? r0 : r1));
-            int lo = 0, hi = hc;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (rm[mid] < target) lo = mid + 1; else hi = mid;
-            }
-            range[threadIdx.x] = lo;
-        }
-        __syncthreads();
-        const int ja = range[0], jb = range[1], ia = max(range[2], ja), ib = range[3];
+        // first child index whose parent position is >= c0, c1, r0, r1 (tile boundaries are multiples of 64)
+        const int* __restrict__ lb = d.ea_lb + d.ea_off[c];
+        const int ja = lb[blockIdx.x], jb = lb[min((int)blockIdx.x + 1, nbt)];
+        const int ia = max(lb[min((int)blockIdx.y, nbt)], ja), ib = lb[min((int)blockIdx.y + 1, nbt)];
         if (jb > ja && ib > ia) {
             const double* __restrict__ Uc = store + d.upd_off[c];
             const int ldc = d.upd_ld[c];
-            // a thread owns a row of the child's update matrix (its target row is looked up once) and walks the tile's
-            // columns: consecutive threads read consecutive entries of a column, no integer division per entry
-            for (int i = ia + threadIdx.x; i < ib; i += 256) {
+            // a lane owns a row of the child's update matrix inside the tile (its target row is looked up once), the four
+            // waves split the tile's columns: consecutive lanes read consecutive entries of a column, short dependent chains
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            const int nj = jb - ja;
+            const int jq0 = ja + (nj * wave) / 4, jq1 = ja + (nj * (wave + 1)) / 4;
+            for (int i = ia + lane; i < ib; i += 64) {
                 const int ri = rm[i];
                 const double* __restrict__ u = Uc + i;
-                const int jend = min(jb, i + 1);          // lower triangle: i >= j
-                for (int j = ja; j < jend; ++j) F[ri + (int64_t)rm[j] * h] += u[(int64_t)j * ldc];
+                const int jend = min(jq1, i + 1);         // lower triangle: i >= j
+                int j = jq0;
+                for (; j + 8 <= jend; j += 8) {           // eight independent read-modify-writes in flight (distinct columns)
+                    int64_t at[8];
+                    double fv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) at[q] = ri + (int64_t)rm[j + q] * h;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) fv[q] = F[at[q]];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) fv[q] += u[(int64_t)(j + q) * ldc];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) F[at[q]] = fv[q];
+                }
+                for (; j < jend; ++j) F[ri + (int64_t)rm[j] * h] += u[(int64_t)j * ldc];
             }
         }
         __syncthreads();
@@ -1038,6 +1071,8 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
         KKT_HIP_CHECK(hipMalloc(&E.d_wide_jobs, sizeof(TrsvJob) * std::max<size_t>(1, jobs.size())));
         if (!jobs.empty()) KKT_HIP_CHECK(hipMemcpy(E.d_wide_jobs, jobs.data(), sizeof(TrsvJob) * jobs.size(), hipMemcpyHostToDevice));
         if (int e = up(&E.d_wide, S.wide)) return e;
+        if (int e = up(&E.d_ea_off, S.ea_off)) return e;
+        if (int e = up(&E.d_ea_lb, S.ea_lb)) return e;
     }
     KKT_HIP_CHECK(hipMalloc(&E.d_info, sizeof(int)));
     KKT_HIP_CHECK(hipHostMalloc(&E.h_info, sizeof(int)));
@@ -1049,7 +1084,7 @@ void sparse_engine_free(SparseEngine& E) {
                     E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
                     E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap, E.d_rem_multi, E.d_iperm,
-                    E.d_tv_tickets, E.d_tv_prog_off, E.d_tv_linv_off, E.d_tv_state, E.d_tv_linv, E.d_wide_jobs, E.d_wide};
+                    E.d_tv_tickets, E.d_tv_prog_off, E.d_tv_linv_off, E.d_tv_state, E.d_tv_linv, E.d_wide_jobs, E.d_wide, E.d_ea_off, E.d_ea_lb};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
@@ -1070,6 +1105,8 @@ static SpDev devview(const SparseEngine& E) {
     d.relmap_off = E.d_relmap_off;
     d.relmap = E.d_relmap;
     d.level_sn = E.d_level_sn;
+    d.ea_off = E.d_ea_off;
+    d.ea_lb = E.d_ea_lb;
     return d;
 }
 
@@ -1113,9 +1150,10 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
         hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3(((unsigned)S.vb.size() + 255) / 256), dim3(256), 0, st,
                            reinterpret_cast<const int*>(E.d_tv_state + E.tv_info_at), (int)S.vb.size(), E.d_info);
     // the transposed persistent solve of the wide supernodes streams L11' from the (unused) upper triangle of the front
-    for (int s : S.wide) {
-        const int w = S.sn_first[s + 1] - S.sn_first[s], h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
-        if (int e = launch_mirror_lower(E.d_panels + S.panel_off[s], h, w, st)) return e;
+    if (!S.wide.empty()) {
+        int wmax = 0;
+        for (int w : E.wide_maxw) wmax = std::max(wmax, w);
+        if (int e = launch_mirror_lower_jobs(E.d_wide_jobs, (int)S.wide.size(), wmax, st)) return e;
     }
     KKT_HIP_CHECK(hipGetLastError());
     KKT_HIP_CHECK(hipMemcpyAsync(E.h_info, E.d_info, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -8,3 +8,4 @@ MI355KKT_SN_MAXW=256 timeout 300 python bench.py --workload sparse --no-cpu-base
 timeout 300 python bench.py --workload sparse --mesh tet --grid 39 --no-cpu-baseline --steps 10 > $O/r2w_sparse_tet.json 2> $O/r2w_sparse_tet.err
 timeout 300 python bench.py --workload sparse --grid 64 --no-cpu-baseline --steps 5 > $O/r2w_sparse64.json 2> $O/r2w_sparse64.err
 echo done
+( timeout 600 python bench.py --workload sparse --grid 100 --no-cpu-baseline --steps 3 --warmup 1 > $O/r2w_sparse100.json 2> $O/r2w_sparse100.err ; echo "rc=$?" >> $O/r2w_sparse100.err )
