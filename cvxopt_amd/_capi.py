@@ -85,6 +85,12 @@ SIGNATURES = {
     "mi355kkt_batch_coneqp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_int_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, c_int_p]),
+    "mi355kkt_batch_create_eq": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi355kkt_batch_set_A": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "mi355kkt_batch_solve_eq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "mi355kkt_batch_coneqp_eq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                           C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_int_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, c_int_p]),
     "mi355kkt_op_syrk_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_int64, c_float_p]),
     "mi355kkt_op_symbolic": (C.c_int, [C.c_int, C.c_int, c_i64_p, c_i64_p, c_i64_p, c_i64_p, c_int_p, c_i64_p, c_int_p, c_int_p]),

@@ -27,9 +27,10 @@ from . import _capi
 # KKT back end: batched factor / solve on the GPU
 # ---------------------------------------------------------------------------------------------------
 class BatchKkt(object):
-    """B independent kkt_chol2-style solvers (p = 0, LP cone) behind the batched C ABI."""
+    """B independent kkt_chol2-style solvers (LP cone; optionally p equality constraints per problem, At: (B, n, p) = the
+    p x n blocks A_b column-major) behind the batched C ABI."""
 
-    def __init__(self, Gt, P=None, device=0):
+    def __init__(self, Gt, P=None, device=0, At=None):
         self.L = _capi.lib()
         if _capi.device_count() <= 0:
             raise RuntimeError("cvxopt_amd.batch: no HIP device visible (there is no CPU fallback)")
@@ -45,7 +46,8 @@ class BatchKkt(object):
             self.B, self.n, self.m = Gt.shape
             gptr = Gt.ctypes.data
         h = C.c_void_p()
-        _capi.check(self.L.mi355kkt_batch_create(C.byref(h), device, self.B, self.n, self.m), "batch_create")
+        self.p = 0 if At is None else int(At.shape[2])
+        _capi.check(self.L.mi355kkt_batch_create_eq(C.byref(h), device, self.B, self.n, self.m, self.p), "batch_create")
         self.h = h
         Pp = None
         if P is not None:
@@ -63,6 +65,17 @@ class BatchKkt(object):
             torch.cuda.synchronize(Gt.device)                     # the copies below run on the library's own stream
         _capi.check(self.L.mi355kkt_batch_set_problem(h, C.c_void_p(gptr), C.c_void_p(Pp) if Pp else None,
                                                       1 if on_device else 0), "batch_set_problem")
+        if self.p:
+            if on_device:
+                if not (hasattr(At, "data_ptr") and At.is_cuda and At.is_contiguous() and At.element_size() == 8):
+                    raise TypeError("At must be a contiguous float64 CUDA tensor when Gt is one")
+                assert tuple(At.shape) == (self.B, self.n, self.p)
+                aptr = At.data_ptr()
+            else:
+                At = np.ascontiguousarray(At, dtype=np.float64)
+                assert At.shape == (self.B, self.n, self.p)
+                aptr = At.ctypes.data
+            _capi.check(self.L.mi355kkt_batch_set_A(h, C.c_void_p(aptr), 1 if on_device else 0), "batch_set_A")
 
     def factor(self, di):
         di = np.ascontiguousarray(di, dtype=np.float64)
@@ -71,9 +84,13 @@ class BatchKkt(object):
                     "batch_factor")
         return info
 
-    def solve(self, x, z):
+    def solve(self, x, z, y=None):
         assert x.flags.c_contiguous and z.flags.c_contiguous and x.dtype == np.float64 and z.dtype == np.float64
-        _capi.check(self.L.mi355kkt_batch_solve(self.h, x.ctypes.data, z.ctypes.data, 0), "batch_solve")
+        if self.p:
+            assert y is not None and y.flags.c_contiguous and y.dtype == np.float64 and y.shape == (self.B, self.p)
+            _capi.check(self.L.mi355kkt_batch_solve_eq(self.h, x.ctypes.data, y.ctypes.data, z.ctypes.data, 0), "batch_solve")
+        else:
+            _capi.check(self.L.mi355kkt_batch_solve(self.h, x.ctypes.data, z.ctypes.data, 0), "batch_solve")
 
     def products(self, x, z):
         """(G x, G' z, P x) for every problem, computed next to the data in HBM."""
@@ -87,7 +104,7 @@ class BatchKkt(object):
     def factor_ms(self):
         return float(self.L.mi355kkt_batch_last_factor_ms(self.h))
 
-    def coneqp(self, q, h, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):
+    def coneqp(self, q, h, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, b=None):
         """The whole interior-point loop on the device (`mi355kkt_batch_coneqp`): same result dict as
         `coneqp_batch`; only the count of active problems crosses PCIe per iteration.  q, h may be float64 CUDA tensors
         (a sharded batch: they arrived over RCCL); the result arrays are then CUDA tensors too and nothing but the
@@ -104,32 +121,45 @@ class BatchKkt(object):
             assert tuple(q.shape) == (B, n) and tuple(h.shape) == (B, m)
             dev = q.device
             x, s, z = (torch.zeros((B, k), dtype=torch.float64, device=dev) for k in (n, m, m))
+            y = torch.zeros((B, max(1, self.p)), dtype=torch.float64, device=dev)
             status, iters = (torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(2))
             pc, dc, gap = (torch.zeros(B, dtype=torch.float64, device=dev) for _ in range(3))
+            if self.p:
+                if not (hasattr(b, "data_ptr") and b.is_cuda and b.dtype == torch.float64 and tuple(b.shape) == (B, self.p)):
+                    raise TypeError("b must be a float64 CUDA tensor of shape (B, p)")
+                b = b.contiguous()
             torch.cuda.synchronize(dev)                           # the loop runs on the library's own stream
             ptr = lambda t: C.c_void_p(t.data_ptr())
-            rc = self.L.mi355kkt_batch_coneqp(self.h, ptr(q), ptr(h), int(maxiters), float(abstol), float(reltol),
-                                              float(feastol), ptr(x), ptr(s), ptr(z), C.cast(ptr(status), ip),
-                                              C.cast(ptr(iters), ip), ptr(pc), ptr(dc), ptr(gap), C.byref(nrun))
+            rc = self.L.mi355kkt_batch_coneqp_eq(self.h, ptr(q), ptr(h), ptr(b) if self.p else None, int(maxiters), float(abstol),
+                                                 float(reltol), float(feastol), ptr(x), ptr(y), ptr(s), ptr(z),
+                                                 C.cast(ptr(status), ip), C.cast(ptr(iters), ip), ptr(pc), ptr(dc), ptr(gap),
+                                                 C.byref(nrun))
         else:
             q = np.ascontiguousarray(q, dtype=np.float64)
             h = np.ascontiguousarray(h, dtype=np.float64)
             assert q.shape == (B, n) and h.shape == (B, m)
             x, s, z = np.zeros((B, n)), np.zeros((B, m)), np.zeros((B, m))
+            y = np.zeros((B, max(1, self.p)))
+            bv = None
+            if self.p:
+                bv = np.ascontiguousarray(b, dtype=np.float64)
+                assert bv.shape == (B, self.p)
             status, iters = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
             pc, dc, gap = np.zeros(B), np.zeros(B), np.zeros(B)
-            rc = self.L.mi355kkt_batch_coneqp(self.h, q.ctypes.data, h.ctypes.data, int(maxiters), float(abstol),
-                                              float(reltol), float(feastol), x.ctypes.data, s.ctypes.data, z.ctypes.data,
-                                              status.ctypes.data_as(ip), iters.ctypes.data_as(ip), pc.ctypes.data,
-                                              dc.ctypes.data, gap.ctypes.data, C.byref(nrun))
+            rc = self.L.mi355kkt_batch_coneqp_eq(self.h, q.ctypes.data, h.ctypes.data, bv.ctypes.data if self.p else None,
+                                                 int(maxiters), float(abstol), float(reltol), float(feastol), x.ctypes.data,
+                                                 y.ctypes.data, s.ctypes.data, z.ctypes.data, status.ctypes.data_as(ip),
+                                                 iters.ctypes.data_as(ip), pc.ctypes.data, dc.ctypes.data, gap.ctypes.data,
+                                                 C.byref(nrun))
         if rc == 1:
             raise ValueError("Rank([P; A; G]) < n (%s)" % _capi.last_error())
         _capi.check(rc, "batch_coneqp")
+        y = y[:, :self.p]
         if on_device:        # status stays numeric on the device: 1 optimal, 2 / 3 unknown (see include/mi355kkt.h)
-            return {'x': x, 's': s, 'z': z, 'status_code': status, 'iterations': iters, 'primal objective': pc,
+            return {'x': x, 'y': y, 's': s, 'z': z, 'status_code': status, 'iterations': iters, 'primal objective': pc,
                     'dual objective': dc, 'gap': gap, 'lockstep iterations': nrun.value}
         names = np.array(['unknown', 'optimal', 'unknown', 'unknown'], dtype=object)
-        return {'x': x, 's': s, 'z': z, 'status': names[status], 'iterations': iters.astype(int),
+        return {'x': x, 'y': y, 's': s, 'z': z, 'status': names[status], 'iterations': iters.astype(int),
                 'primal objective': pc, 'dual objective': dc, 'gap': gap, 'lockstep iterations': nrun.value}
 
     def close(self):

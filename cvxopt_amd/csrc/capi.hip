@@ -32,6 +32,11 @@ void set_last_error(const char* fmt, ...) {
 }
 
 // ---- tiny element-wise helpers -------------------------------------------------------------------
+// per-problem info of the batched engine: a failing pivot of K_b (rank(A_b) < p) is reported as n + pivot
+__global__ void batch_merge_info_kernel(int* __restrict__ info, const int* __restrict__ infoK, int n, int nbatch) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nbatch && info[i] <= 0 && infoK[i] > 0) info[i] = n + infoK[i];
+}
 __global__ void scal_kernel(double* x, int n, double a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) x[i] *= a;
@@ -63,8 +68,11 @@ __global__ void symmetrize_kernel(double* A, int n, int64_t bstride) {
     if (i < n && j < n && i > j) A[j + (int64_t)i * n] = A[i + (int64_t)j * n];
 }
 // out (n x p, ld n) = A' where A is p x n (lda)
-__global__ void transpose_kernel(const double* __restrict__ A, int64_t lda, int p, int n, double* __restrict__ out) {
+__global__ void transpose_kernel(const double* __restrict__ A, int64_t lda, int p, int n, double* __restrict__ out,
+                                 int64_t sA = 0, int64_t sOut = 0) {      // blockIdx.z: batched problems
     __shared__ double t[32][33];
+    A += (int64_t)blockIdx.z * sA;
+    out += (int64_t)blockIdx.z * sOut;
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx over n (cols of A), by over p (rows of A)
     for (int r = threadIdx.y; r < 32; r += 8) {
         const int i = by + threadIdx.x, j = bx + r;   // A[i, j]
@@ -1183,6 +1191,12 @@ int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL) {
 
 struct mi355kkt_batch {
     int device = 0, nbatch = 0, n = 0, ml = 0, num_cus = 256;
+    // equality constraints A_b x = b_b (p rows each): Asct_b = L_b^-1 A_b', K_b = Asct_b' Asct_b per problem (misc.py:1464-1487)
+    int p = 0;
+    double *dA = nullptr, *dAsct = nullptr, *dK = nullptr, *dy = nullptr, *dtp = nullptr;
+    SyrkPlan planK, planAtA;
+    PotrfWork pwK;
+    bool singular = false, firstcall = true;      // S + A'A mode, decided for the whole batch at the first factorisation
     hipStream_t st = nullptr;
     hipEvent_t ev[2] = {};
     double *dG = nullptr, *dH = nullptr, *dS = nullptr, *dW = nullptr;
@@ -1198,10 +1212,15 @@ struct mi355kkt_batch {
 extern "C" {
 
 int mi355kkt_batch_create(mi355kkt_batch** out, int device, int nbatch, int n, int ml) {
-    if (!out || nbatch < 1 || n < 1 || ml < 0) { set_last_error("batch_create: invalid argument"); return MI355KKT_EINVAL; }
+    return mi355kkt_batch_create_eq(out, device, nbatch, n, ml, 0);
+}
+
+/* The same with p equality constraints per problem (A_b: p x n, set with mi355kkt_batch_set_A). */
+int mi355kkt_batch_create_eq(mi355kkt_batch** out, int device, int nbatch, int n, int ml, int p) {
+    if (!out || nbatch < 1 || n < 1 || ml < 0 || p < 0 || p > n) { set_last_error("batch_create: invalid argument"); return MI355KKT_EINVAL; }
     if (mi355kkt_device_count() <= device) { set_last_error("batch_create: HIP device %d not available", device); return MI355KKT_EHIP; }
     mi355kkt_batch* b = new mi355kkt_batch();
-    b->device = device; b->nbatch = nbatch; b->n = n; b->ml = ml;
+    b->device = device; b->nbatch = nbatch; b->n = n; b->ml = ml; b->p = p;
     auto fail = [&](int code) { mi355kkt_batch_destroy(b); return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(MI355KKT_EHIP);
     hipDeviceProp_t prop;
@@ -1224,6 +1243,17 @@ int mi355kkt_batch_create(mi355kkt_batch** out, int device, int nbatch, int n, i
     if ((rc = alloc(&b->dt2, B * dmax(N, M)))) return fail(rc);
     if ((rc = potrf_work_init_batched(b->pw, nbatch))) return fail(rc);
     if ((rc = build_syrk_plan(b->plan, n, ml, b->num_cus, /*allow_split=*/false))) return fail(rc);
+    if (p > 0) {
+        const size_t Pq = p;
+        if ((rc = alloc(&b->dA, B * Pq * N))) return fail(rc);
+        if ((rc = alloc(&b->dAsct, B * N * Pq))) return fail(rc);
+        if ((rc = alloc(&b->dK, B * Pq * Pq))) return fail(rc);
+        if ((rc = alloc(&b->dy, B * Pq))) return fail(rc);
+        if ((rc = alloc(&b->dtp, B * dmax(Pq, N)))) return fail(rc);
+        if ((rc = potrf_work_init_batched(b->pwK, nbatch))) return fail(rc);
+        if ((rc = build_syrk_plan(b->planK, p, n, b->num_cus, false))) return fail(rc);
+        if ((rc = build_syrk_plan(b->planAtA, n, p, b->num_cus, false))) return fail(rc);
+    }
     *out = b;
     return 0;
 }
@@ -1232,11 +1262,14 @@ void mi355kkt_batch_destroy(mi355kkt_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->st) (void)hipStreamSynchronize(b->st);
-    double* bufs[] = {b->dG, b->dH, b->dS, b->dW, b->dx, b->dz, b->dzs, b->dwork, b->dt1, b->dt2};
+    double* bufs[] = {b->dG, b->dH, b->dS, b->dW, b->dx, b->dz, b->dzs, b->dwork, b->dt1, b->dt2, b->dA, b->dAsct, b->dK, b->dy, b->dtp};
     for (double* p : bufs) if (p) (void)hipFree(p);
     ipm_free(b->ipm);
     potrf_work_free(b->pw);
+    potrf_work_free(b->pwK);
     free_syrk_plan(b->plan);
+    free_syrk_plan(b->planK);
+    free_syrk_plan(b->planAtA);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->st) (void)hipStreamDestroy(b->st);
     delete b;
@@ -1257,6 +1290,31 @@ int mi355kkt_batch_set_problem(mi355kkt_batch* b, const double* G, const double*
         hipLaunchKernelGGL(symmetrize_kernel, dim3((b->n + 15) / 16, (b->n + 15) / 16, b->nbatch), dim3(16, 16), 0, b->st,
                            b->dH, b->n, (int64_t)(N * N));
         KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+    }
+    return 0;
+}
+
+/* A: nbatch blocks of p x n (column-major, contiguous). */
+int mi355kkt_batch_set_A(mi355kkt_batch* b, const double* A, int is_device) {
+    if (!b || (b->p > 0 && !A)) { set_last_error("batch_set_A: null argument"); return MI355KKT_EINVAL; }
+    if (b->p == 0) return 0;
+    KKT_HIP_CHECK(hipSetDevice(b->device));
+    KKT_HIP_CHECK(hipMemcpy(b->dA, A, sizeof(double) * (size_t)b->nbatch * b->p * b->n, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    b->singular = false;
+    b->firstcall = true;
+    return 0;
+}
+
+// Ax[b] = A_b x_b, ATy[b] = A_b' y_b (device arrays; the fA of coneprog.py:2170-2186)
+static int batch_a_products(mi355kkt_batch* b, const double* dx, const double* dy, double* Ax, double* ATy) {
+    if (b->p <= 0) return 0;
+    const size_t B = b->nbatch, N = b->n, Pq = b->p;
+    const int64_t sA = (int64_t)(Pq * N);
+    if (Ax)
+        if (int e = launch_gemv_n_scaled(b->dA, (int64_t)Pq, b->p, b->n, nullptr, dx, Ax, Ax, 1.0, 0.0, b->dwork, b->st, b->nbatch, sA)) return e;
+    if (ATy) {
+        KKT_HIP_CHECK(hipMemsetAsync(ATy, 0, sizeof(double) * B * N, b->st));
+        if (int e = launch_gemv_t_scaled(b->dA, (int64_t)Pq, b->p, b->n, nullptr, dy, b->dtp, ATy, nullptr, b->st, b->nbatch, sA)) return e;
     }
     return 0;
 }
@@ -1307,13 +1365,49 @@ int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, in
     KKT_HIP_CHECK(hipSetDevice(b->device));
     const size_t B = b->nbatch, N = b->n, M = b->ml;
     KKT_HIP_CHECK(hipEventRecord(b->ev[0], b->st));
-    if (M) KKT_HIP_CHECK(hipMemcpyAsync(b->dW, di, sizeof(double) * B * M, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->st));
+    if (M && di != b->dW)
+        KKT_HIP_CHECK(hipMemcpyAsync(b->dW, di, sizeof(double) * B * M, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->st));
     BatchStrides bs;
     bs.a = (int64_t)(M * N); bs.b = (int64_t)M; bs.c = (int64_t)(N * N); bs.d = (int64_t)(N * N);
     if (int e = launch_syrk_scaled(b->plan, b->dG, M ? (int64_t)M : 1, M ? b->dW : nullptr, b->dS, (int64_t)N,
                                    b->hasH ? b->dH : nullptr, (int64_t)N, b->st, nullptr, b->nbatch, bs))
         return e;
+    if (b->singular && b->p > 0) {      // S + A'A mode (misc.py:1433-1447), decided at the first factorisation
+        BatchStrides ba;
+        ba.a = (int64_t)((size_t)b->p * N); ba.b = 0; ba.c = (int64_t)(N * N); ba.d = (int64_t)(N * N);
+        if (int e = launch_syrk_scaled(b->planAtA, b->dA, (int64_t)b->p, nullptr, b->dS, (int64_t)N, b->dS, (int64_t)N, b->st, nullptr,
+                                       b->nbatch, ba))
+            return e;
+    }
     if (int e = launch_potrf_batched(b->dS, (int64_t)N, b->n, b->nbatch, (int64_t)(N * N), b->pw, b->st)) return e;
+    if (b->p > 0) {
+        const size_t Pq = b->p;
+        if (b->firstcall && !b->singular) {       // a singular S in any problem of the batch at the first call: S + A'A for all
+            KKT_HIP_CHECK(hipMemcpyAsync(b->pw.h_info, b->pw.d_info, sizeof(int) * B, hipMemcpyDeviceToHost, b->st));
+            KKT_HIP_CHECK(hipStreamSynchronize(b->st));
+            bool bad = false;
+            for (size_t i = 0; i < B; ++i) bad = bad || b->pw.h_info[i] > 0;
+            b->firstcall = false;
+            if (bad) {
+                b->singular = true;
+                return mi355kkt_batch_factor(b, b->dW, 1, info);
+            }
+        }
+        b->firstcall = false;
+        // Asct_b = L_b^-1 A_b';  K_b = Asct_b' Asct_b;  K_b = L_K L_K'
+        hipLaunchKernelGGL(transpose_kernel, dim3((b->n + 31) / 32, (b->p + 31) / 32, b->nbatch), dim3(32, 8), 0, b->st, b->dA,
+                           (int64_t)Pq, b->p, b->n, b->dAsct, (int64_t)(Pq * N), (int64_t)(N * Pq));
+        if (int e = launch_trsm_lower(b->dS, (int64_t)N, b->n, b->dAsct, (int64_t)N, b->p, 0, b->st, b->nbatch, (int64_t)(N * N),
+                                      (int64_t)(N * Pq)))
+            return e;
+        BatchStrides bk;
+        bk.a = (int64_t)(N * Pq); bk.b = 0; bk.c = (int64_t)(Pq * Pq); bk.d = 0;
+        if (int e = launch_syrk_scaled(b->planK, b->dAsct, (int64_t)N, nullptr, b->dK, (int64_t)Pq, nullptr, 0, b->st, nullptr, b->nbatch, bk))
+            return e;
+        if (int e = launch_potrf_batched(b->dK, (int64_t)Pq, b->p, b->nbatch, (int64_t)(Pq * Pq), b->pwK, b->st)) return e;
+        // a failing K (rank(A_b) < p) is reported through the same per-problem info words
+        hipLaunchKernelGGL(batch_merge_info_kernel, g1(b->nbatch), dim3(256), 0, b->st, b->pw.d_info, b->pwK.d_info, b->n, b->nbatch);
+    }
     KKT_HIP_CHECK(hipEventRecord(b->ev[1], b->st));
     if (b->defer_sync) return 0;
     KKT_HIP_CHECK(hipMemcpyAsync(b->pw.h_info, b->pw.d_info, sizeof(int) * B, hipMemcpyDeviceToHost, b->st));
@@ -1325,23 +1419,41 @@ int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, in
 
 /* x: [nbatch][n], z: [nbatch][ml], in place: (bx, bz) -> (ux, W uz) per problem (p = 0). */
 int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device) {
-    if (!b || !x || (!z && b->ml)) { set_last_error("batch_solve: null argument"); return MI355KKT_EINVAL; }
+    if (b && b->p > 0) { set_last_error("batch_solve: the batch has equality constraints, use mi355kkt_batch_solve_eq"); return MI355KKT_EINVAL; }
+    return mi355kkt_batch_solve_eq(b, x, nullptr, z, is_device);
+}
+
+/* x: [nbatch][n], y: [nbatch][p], z: [nbatch][ml], in place: (bx, by, bz) -> (ux, uy, W uz) per problem (misc.py:1513-1563). */
+int mi355kkt_batch_solve_eq(mi355kkt_batch* b, double* x, double* y, double* z, int is_device) {
+    if (!b || !x || (!z && b->ml) || (!y && b->p)) { set_last_error("batch_solve: null argument"); return MI355KKT_EINVAL; }
     KKT_HIP_CHECK(hipSetDevice(b->device));
-    const size_t B = b->nbatch, N = b->n, M = b->ml;
-    double *dx = x, *dz = z;
+    const size_t B = b->nbatch, N = b->n, M = b->ml, Pq = b->p;
+    double *dx = x, *dz = z, *dy = y;
     if (!is_device) {
         KKT_HIP_CHECK(hipMemcpyAsync(b->dx, x, sizeof(double) * B * N, hipMemcpyHostToDevice, b->st));
         if (M) KKT_HIP_CHECK(hipMemcpyAsync(b->dz, z, sizeof(double) * B * M, hipMemcpyHostToDevice, b->st));
-        dx = b->dx; dz = b->dz;
+        if (Pq) KKT_HIP_CHECK(hipMemcpyAsync(b->dy, y, sizeof(double) * B * Pq, hipMemcpyHostToDevice, b->st));
+        dx = b->dx; dz = b->dz; dy = b->dy;
     }
-    const int64_t sG = (int64_t)(M * N), sL = (int64_t)(N * N);
+    const int64_t sG = (int64_t)(M * N), sL = (int64_t)(N * N), sA = (int64_t)(Pq * N), sK = (int64_t)(Pq * Pq);
     if (int e = launch_gemv_t_scaled(b->dG, M ? (int64_t)M : 1, b->ml, b->n, b->dW, dz, b->dzs, dx, b->dwork, b->st, b->nbatch, sG)) return e;
+    if (b->singular && Pq)                                             // x += A' by  (misc.py:1527)
+        if (int e = launch_gemv_t_scaled(b->dA, (int64_t)Pq, b->p, b->n, nullptr, dy, b->dtp, dx, nullptr, b->st, b->nbatch, sA)) return e;
     if (int e = launch_trsm_lower(b->dS, (int64_t)N, b->n, dx, (int64_t)N, 1, 0, b->st, b->nbatch, sL, (int64_t)N)) return e;
+    if (Pq) {
+        // y := K^-1 (Asct' x - y);  x := x - Asct y                 (misc.py:1541-1553)
+        hipLaunchKernelGGL(scal_kernel, g1((int)(B * Pq)), dim3(256), 0, b->st, dy, (int)(B * Pq), -1.0);
+        if (int e = launch_gemv_t_scaled(b->dAsct, (int64_t)N, b->n, b->p, nullptr, dx, b->dt1, dy, nullptr, b->st, b->nbatch, sA)) return e;
+        if (int e = launch_trsm_lower(b->dK, (int64_t)Pq, b->p, dy, (int64_t)Pq, 1, 0, b->st, b->nbatch, sK, (int64_t)Pq)) return e;
+        if (int e = launch_trsm_lower(b->dK, (int64_t)Pq, b->p, dy, (int64_t)Pq, 1, 1, b->st, b->nbatch, sK, (int64_t)Pq)) return e;
+        if (int e = launch_gemv_n_scaled(b->dAsct, (int64_t)N, b->n, b->p, nullptr, dy, dx, dx, -1.0, 1.0, b->dwork, b->st, b->nbatch, sA)) return e;
+    }
     if (int e = launch_trsm_lower(b->dS, (int64_t)N, b->n, dx, (int64_t)N, 1, 1, b->st, b->nbatch, sL, (int64_t)N)) return e;
     if (int e = launch_gemv_n_scaled(b->dG, M ? (int64_t)M : 1, b->ml, b->n, b->dW, dx, b->dzs, dz, 1.0, -1.0, b->dwork, b->st, b->nbatch, sG)) return e;
     if (!is_device) {
         KKT_HIP_CHECK(hipMemcpyAsync(x, b->dx, sizeof(double) * B * N, hipMemcpyDeviceToHost, b->st));
         if (M) KKT_HIP_CHECK(hipMemcpyAsync(z, b->dz, sizeof(double) * B * M, hipMemcpyDeviceToHost, b->st));
+        if (Pq) KKT_HIP_CHECK(hipMemcpyAsync(y, b->dy, sizeof(double) * B * Pq, hipMemcpyDeviceToHost, b->st));
     }
     if (!b->defer_sync) KKT_HIP_CHECK(hipStreamSynchronize(b->st));
     return 0;
@@ -1420,15 +1532,30 @@ extern "C" {
 int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, int maxiters, double abstol, double reltol,
                           double feastol, double* x, double* s, double* z, int* status, int* iters, double* pcost,
                           double* dcost, double* gap, int* iterations_run) {
-    if (!b || !q || (!h && b->ml) || !x || !status || !iters) { set_last_error("batch_coneqp: null argument"); return MI355KKT_EINVAL; }
+    if (b && b->p > 0) { set_last_error("batch_coneqp: the batch has equality constraints, use mi355kkt_batch_coneqp_eq"); return MI355KKT_EINVAL; }
+    return mi355kkt_batch_coneqp_eq(b, q, h, nullptr, maxiters, abstol, reltol, feastol, x, nullptr, s, z, status, iters, pcost, dcost,
+                                    gap, iterations_run);
+}
+
+/* The same with equality constraints A_b x = bvec_b (bvec, y: [nbatch][p]). */
+int mi355kkt_batch_coneqp_eq(mi355kkt_batch* b, const double* q, const double* h, const double* bvec, int maxiters, double abstol,
+                             double reltol, double feastol, double* x, double* y, double* s, double* z, int* status, int* iters,
+                             double* pcost, double* dcost, double* gap, int* iterations_run) {
+    if (!b || !q || (!h && b->ml) || !x || !status || !iters || (b->p > 0 && (!bvec || !y))) {
+        set_last_error("batch_coneqp: null argument");
+        return MI355KKT_EINVAL;
+    }
     if (b->ml < 1) { set_last_error("batch_coneqp: needs at least one inequality"); return MI355KKT_EINVAL; }
     KKT_HIP_CHECK(hipSetDevice(b->device));
-    if (int e = ipm_alloc(b->ipm, b->nbatch, b->n, b->ml, 0)) return e;
+    if (int e = ipm_alloc(b->ipm, b->nbatch, b->n, b->ml, b->p)) return e;
     const IpmState& S = b->ipm.S;
     struct Guard { mi355kkt_batch* b; ~Guard() { b->defer_sync = false; } } guard{b};
     b->defer_sync = true;
     IpmOps ops;
-    ops.products = [&]() { return mi355kkt_batch_products(b, S.x, S.z, S.Gx, S.GTz, S.Px, 1); };
+    ops.products = [&]() -> int {
+        if (int e = mi355kkt_batch_products(b, S.x, S.z, S.Gx, S.GTz, S.Px, 1)) return e;
+        return batch_a_products(b, S.x, S.y, S.Ax, S.ATy);
+    };
     ops.factor = [&](const double* di, int* d_info, int* first_bad) -> int {
         if (int e = mi355kkt_batch_factor(b, di, 1, nullptr)) return e;
         KKT_HIP_CHECK(hipMemcpyAsync(d_info, b->pw.d_info, sizeof(int) * b->nbatch, hipMemcpyDeviceToDevice, b->st));
@@ -1440,9 +1567,9 @@ int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, i
         }
         return 0;
     };
-    ops.solve = [&](double* dx, double*, double* dz) { return mi355kkt_batch_solve(b, dx, dz, 1); };
-    IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, iterations_run, nullptr};
-    return run_ipm(b->ipm, b->st, ops, q, h, nullptr, maxiters, abstol, reltol, feastol, o);
+    ops.solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_batch_solve_eq(b, dx, dy, dz, 1); };
+    IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, iterations_run, y};
+    return run_ipm(b->ipm, b->st, ops, q, h, bvec, maxiters, abstol, reltol, feastol, o);
 }
 
 // the mirrored copy of H (only tril(H) is meaningful on input, coneprog.py:1475-1477) for plain products H x

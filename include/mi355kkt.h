@@ -217,6 +217,16 @@ float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b);
 int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, int maxiters, double abstol, double reltol,
                           double feastol, double* x, double* s, double* z, int* status, int* iters, double* pcost,
                           double* dcost, double* gap, int* iterations_run);
+/* Batches with p equality constraints per problem, A_b x = b_b (reference misc.py:1464-1487, :1513-1563 per problem:
+ * Asct_b = L_b^-1 A_b', K_b = Asct_b' Asct_b = L_K L_K'; a singular S_b in any problem at the first factorisation switches the
+ * whole batch to S + A'A, misc.py:1433-1447).  A: [nbatch] blocks of p x n, column-major; bvec, y: [nbatch][p].  A failing pivot
+ * of K_b is reported as n + pivot in that problem's info word. */
+int mi355kkt_batch_create_eq(mi355kkt_batch** out, int device, int nbatch, int n, int ml, int p);
+int mi355kkt_batch_set_A(mi355kkt_batch* b, const double* A, int is_device);
+int mi355kkt_batch_solve_eq(mi355kkt_batch* b, double* x, double* y, double* z, int is_device);
+int mi355kkt_batch_coneqp_eq(mi355kkt_batch* b, const double* q, const double* h, const double* bvec, int maxiters, double abstol,
+                             double reltol, double feastol, double* x, double* y, double* s, double* z, int* status, int* iters,
+                             double* pcost, double* dcost, double* gap, int* iterations_run);
 
 /* ---- stand-alone device operators (each is one stage of factor()/solve(); used by the per-kernel
  * parity tests and by the profiler).  All pointers are DEVICE pointers; calls are synchronous. ---- */

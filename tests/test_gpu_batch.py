@@ -148,3 +148,65 @@ def test_sharded_batch_on_rccl():
                           os.path.join(here, "run_batch_sharded_nccl.py")], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "SHARDED_NCCL_OK" in out.stdout
+
+
+# ---- equality constraints in the batched engine (round 2) ------------------------------------------------------------------
+def _batch_eq(name):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    Gt = np.ascontiguousarray(np.transpose(g['G'], (0, 2, 1)))       # (B, n, m): the m x n blocks column-major
+    At = np.ascontiguousarray(np.transpose(g['A'], (0, 2, 1)))       # (B, n, p)
+    return g, Gt, At
+
+
+@pytest.mark.parametrize("name,singular", [("batch_eq", False), ("batch_eq_singular", True)])
+def test_batched_coneqp_with_equality_constraints_vs_reference_fixture(name, singular):
+    """`mi355kkt_batch_coneqp_eq` against solvers.coneqp(P, q, G, h, A=A, b=b) run problem by problem by the real reference
+    (tests/golden/make_golden_batch_eq.py); the second batch has a singular S in every problem: the S + A'A mode."""
+    g, Gt, At = _batch_eq(name)
+    bk = BatchKkt(Gt, np.ascontiguousarray(g['P']), At=At)
+    res = bk.coneqp(g['q'], g['h'], b=g['b'])
+    B = Gt.shape[0]
+    assert all(s == 'optimal' for s in res['status'])
+    assert np.array_equal(res['iterations'], g['iterations'])
+    for k in range(B):
+        assert abs(res['primal objective'][k] - g['pobj'][k]) <= 1e-8 * max(1.0, abs(g['pobj'][k])), k
+        assert abs(res['dual objective'][k] - g['dobj'][k]) <= 1e-8 * max(1.0, abs(g['dobj'][k])), k
+        assert relerr(res['x'][k], g['x'][k]) < 1e-6, k
+        assert relerr(res['y'][k], g['y'][k]) < 1e-5, k
+        assert relerr(res['z'][k], g['z'][k]) < 1e-5 and relerr(res['s'][k], g['s'][k]) < 1e-5, k
+    bk.close()
+
+
+def test_batched_solve_with_equality_constraints_solves_the_kkt_system():
+    """factor + solve of the batched engine at the hook level: residual of [P A' G'; A 0 0; G 0 -W'W][ux; uy; uz] = [bx; by; bz]"""
+    g, Gt, At = _batch_eq("batch_eq")
+    B, n, m = Gt.shape
+    p = At.shape[2]
+    rng = np.random.default_rng(3)
+    di = 10.0 ** rng.uniform(-1.0, 1.0, (B, m))
+    bk = BatchKkt(Gt, np.ascontiguousarray(g['P']), At=At)
+    assert np.all(bk.factor(di) == 0)
+    bx, by, bz = rng.standard_normal((B, n)), rng.standard_normal((B, p)), rng.standard_normal((B, m))
+    x, y, z = bx.copy(), by.copy(), bz.copy()
+    bk.solve(x, z, y)
+    for k in range(B):
+        P, G, A = g['P'][k], g['G'][k], g['A'][k]
+        uz = z[k] * di[k]                                        # returned z = W uz, W = diag(1 / di)
+        r1 = P @ x[k] + A.T @ y[k] + G.T @ uz - bx[k]
+        r2 = A @ x[k] - by[k]
+        r3 = G @ x[k] - uz / di[k] ** 2 - bz[k]
+        scale = max(np.linalg.norm(bx[k]), np.linalg.norm(bz[k]), 1.0) * np.linalg.norm(di[k]) ** 2
+        assert max(np.linalg.norm(r1), np.linalg.norm(r2), np.linalg.norm(r3)) <= 1e-10 * scale, k
+    bk.close()
+
+
+def test_batched_rank_deficient_A_is_reported_per_problem():
+    g, Gt, At = _batch_eq("batch_eq")
+    B, n, m = Gt.shape
+    At = At.copy()
+    At[2, :, 4] = 0.0                                           # problem 2: a zero row of A -> K_2 has an exactly zero pivot
+    bk = BatchKkt(Gt, np.ascontiguousarray(g['P']), At=At)
+    info = bk.factor(np.ones((B, m)))
+    assert info[2] == n + 5 and np.all(np.delete(info, 2) == 0)       # reported as n + pivot, like the single-problem engine
+    bk.close()
