@@ -27,4 +27,4 @@ cd "$ROOT"
 CVXOPT_AMD_LIB="$OUT/libmi355kkt.so" CVXOPT_AMD_NO_TORCH_PRELOAD=1 LD_PRELOAD="$RT" \
   ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
   python -m pytest -q -m "not gpu" tests/test_capi_load.py tests/test_ordering_cpu.py tests/test_sparse_symbolic_cpu.py \
-      tests/test_sparse_plan_cpu.py tests/test_syrk_plan_cpu.py tests/test_cone_ops_cpu.py "$@"
+      tests/test_sparse_plan_cpu.py tests/test_syrk_plan_cpu.py tests/test_cone_ops_cpu.py tests/test_sdp_ops_cpu.py "$@"
