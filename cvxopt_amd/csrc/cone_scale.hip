@@ -35,6 +35,34 @@ __global__ __launch_bounds__(64) void scale_q_small_kernel(const double* __restr
     const double* __restrict__ x = in + off[k] + (int64_t)j * ldi;
     double* __restrict__ y = out + off[k] + (int64_t)j * ldo;
     const double* __restrict__ vk = v + voff[k];
+    // cones of dimension 8 or 4 on 16-byte boundaries (the SOCP classes of BASELINE configs[2]): 16-byte requests, no
+    // per-row predicates.  (Staging the rows through LDS with fully coalesced 512-byte requests was measured SLOWER: one wave
+    // per block and two barriers per column hide less latency than this kernel's many independent threads.)
+    if ((m == 8 || m == 4) && ((off[k] | voff[k]) & 1) == 0 && ((ldi | ldo) & 1) == 0 &&
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        typedef double dv2 __attribute__((ext_vector_type(2)));
+        const dv2* __restrict__ x2 = reinterpret_cast<const dv2*>(x);
+        const dv2* __restrict__ v2 = reinterpret_cast<const dv2*>(vk);
+        dv2* __restrict__ y2 = reinterpret_cast<dv2*>(y);
+        const double s = extra / beta[k];
+        if (m == 8) {
+            const dv2 a0 = x2[0], a1 = x2[1], a2 = x2[2], a3 = x2[3];
+            const dv2 b0 = v2[0], b1 = v2[1], b2 = v2[2], b3 = v2[3];
+            const double w = b0.x * a0.x - b0.y * a0.y - (b1.x * a1.x + b1.y * a1.y) - (b2.x * a2.x + b2.y * a2.y) -
+                             (b3.x * a3.x + b3.y * a3.y);
+            y2[0] = dv2{s * (2.0 * b0.x * w - a0.x), s * (-2.0 * b0.y * w + a0.y)};
+            y2[1] = dv2{s * (-2.0 * b1.x * w + a1.x), s * (-2.0 * b1.y * w + a1.y)};
+            y2[2] = dv2{s * (-2.0 * b2.x * w + a2.x), s * (-2.0 * b2.y * w + a2.y)};
+            y2[3] = dv2{s * (-2.0 * b3.x * w + a3.x), s * (-2.0 * b3.y * w + a3.y)};
+        } else {
+            const dv2 a0 = x2[0], a1 = x2[1];
+            const dv2 b0 = v2[0], b1 = v2[1];
+            const double w = b0.x * a0.x - b0.y * a0.y - (b1.x * a1.x + b1.y * a1.y);
+            y2[0] = dv2{s * (2.0 * b0.x * w - a0.x), s * (-2.0 * b0.y * w + a0.y)};
+            y2[1] = dv2{s * (-2.0 * b1.x * w + a1.x), s * (-2.0 * b1.y * w + a1.y)};
+        }
+        return;
+    }
     double xv[32];
     double w = 0.0;
 #pragma unroll
@@ -55,7 +83,9 @@ __global__ __launch_bounds__(64) void scale_q_small_kernel(const double* __restr
     }
 }
 
-// large cones: one wave per (cone, column), lanes stride the cone's rows
+// large cones: one wave per (cone, SQL_COLS columns), lanes stride the cone's rows; the loads of all its columns are in flight
+// before the first butterfly (one column per wave left the kernel latency-bound at 2.2 TB/s)
+constexpr int SQL_COLS = 4;
 __global__ __launch_bounds__(256) void scale_q_large_kernel(const double* __restrict__ in, int64_t ldi,
                                                             double* __restrict__ out, int64_t ldo, int ncones,
                                                             const int* __restrict__ cone_ids,
@@ -64,22 +94,50 @@ __global__ __launch_bounds__(256) void scale_q_large_kernel(const double* __rest
                                                             const double* __restrict__ beta, int ncols, double extra) {
     const int lane = threadIdx.x & 63;
     const int kk = blockIdx.x;
-    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (kk >= ncones || j >= ncols) return;
+    const int j0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * SQL_COLS;
+    if (kk >= ncones || j0 >= ncols) return;
     const int k = cone_ids[kk];
     const int m = dim[k];
-    const double* __restrict__ x = in + off[k] + (int64_t)j * ldi;
-    double* __restrict__ y = out + off[k] + (int64_t)j * ldo;
     const double* __restrict__ vk = v + voff[k];
-    double w = 0.0;
-    for (int i = lane; i < m; i += 64) w += (i == 0 ? vk[0] : -vk[i]) * x[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
     const double s = extra / beta[k];
-    for (int i = lane; i < m; i += 64) {
-        const double jv = (i == 0 ? vk[0] : -vk[i]);
-        const double jx = (i == 0 ? x[0] : -x[i]);
-        y[i] = s * (2.0 * jv * w - jx);
+    const int nc = min(SQL_COLS, ncols - j0);
+    if (m <= 128 && nc == SQL_COLS) {                    // up to two rows per lane: everything in registers
+        const int i0 = lane, i1 = lane + 64;
+        const double jv0 = (i0 < m) ? (i0 == 0 ? vk[0] : -vk[i0]) : 0.0;
+        const double jv1 = (i1 < m) ? -vk[i1] : 0.0;
+        double xa[SQL_COLS], xb[SQL_COLS], w[SQL_COLS];
+#pragma unroll
+        for (int c = 0; c < SQL_COLS; ++c) {
+            const double* __restrict__ x = in + off[k] + (int64_t)(j0 + c) * ldi;
+            xa[c] = (i0 < m) ? x[i0] : 0.0;
+            xb[c] = (i1 < m) ? x[i1] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < SQL_COLS; ++c) w[c] = jv0 * xa[c] + jv1 * xb[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int c = 0; c < SQL_COLS; ++c) w[c] += __shfl_xor(w[c], o, 64);
+#pragma unroll
+        for (int c = 0; c < SQL_COLS; ++c) {
+            double* __restrict__ y = out + off[k] + (int64_t)(j0 + c) * ldo;
+            if (i0 < m) y[i0] = s * (2.0 * jv0 * w[c] - (i0 == 0 ? xa[c] : -xa[c]));
+            if (i1 < m) y[i1] = s * (2.0 * jv1 * w[c] + xb[c]);
+        }
+        return;
+    }
+    for (int c = 0; c < nc; ++c) {
+        const double* __restrict__ x = in + off[k] + (int64_t)(j0 + c) * ldi;
+        double* __restrict__ y = out + off[k] + (int64_t)(j0 + c) * ldo;
+        double w = 0.0;
+        for (int i = lane; i < m; i += 64) w += (i == 0 ? vk[0] : -vk[i]) * x[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+        for (int i = lane; i < m; i += 64) {
+            const double jv = (i == 0 ? vk[0] : -vk[i]);
+            const double jx = (i == 0 ? x[0] : -x[i]);
+            y[i] = s * (2.0 * jv * w - jx);
+        }
     }
 }
 
@@ -380,7 +438,7 @@ int launch_cone_scale(const ConeLayout& cl, const double* in, int64_t ldi, doubl
         KKT_HIP_CHECK(hipGetLastError());
     }
     if (cl.n_large > 0) {
-        hipLaunchKernelGGL(scale_q_large_kernel, dim3(cl.n_large, (ncols + 3) / 4), dim3(256), 0, st, in, ldi, out, ldo,
+        hipLaunchKernelGGL(scale_q_large_kernel, dim3(cl.n_large, (ncols + 4 * SQL_COLS - 1) / (4 * SQL_COLS)), dim3(256), 0, st, in, ldi, out, ldo,
                            cl.n_large, cl.d_large_ids, cl.d_off, cl.d_dim, cl.d_voff, d_v, d_beta, ncols, extra);
         KKT_HIP_CHECK(hipGetLastError());
     }
