@@ -100,6 +100,8 @@ SIGNATURES = {
     "mi355kkt_debug_hwid": (C.c_int, [C.c_void_p, C.c_int]),
     "mi355kkt_debug_cone_op_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355kkt_debug_sdp_op_host": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "mi355kkt_debug_sdp_op_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "mi355kkt_debug_sdp_op_host_team": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "mi355kkt_debug_syrk_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p]),
     "mi355kkt_debug_ordering": (C.c_int, [C.c_int, c_i64_p, c_i64_p, C.c_int, c_int_p, c_double_p]),
     "mi355kkt_debug_potf2_skip": (C.c_int, [C.c_int]),

@@ -151,11 +151,13 @@ static void lp_free(LpWork& w) {
 // 's' blocks of the device loops: sizes of the extra state (r, rti, three scratch matrices per block, the Jacobi scratch,
 // sigs, sigz) and the int descriptors sdim | soff | sloff
 struct SBlocks {
-    int ns = 0, sums = 0, sums2 = 0, maxs = 0;
+    int ns = 0, sums = 0, sums2 = 0, maxs = 0, mins = 0;
     explicit SBlocks(const std::vector<int>& s) : ns((int)s.size()) {
-        for (int k : s) { sums += k; sums2 += k * k; maxs = std::max(maxs, k); }
+        mins = ns ? s[0] : 0;
+        for (int k : s) { sums += k; sums2 += k * k; maxs = std::max(maxs, k); mins = std::min(mins, k); }
     }
-    size_t doubles() const { return ns ? 5 * (size_t)sums2 + 2 * (size_t)sums + s_jw_doubles(maxs, 1024) + 8 : 8; }
+    size_t jw_doubles() const { return s_jw_doubles(maxs, 1024) + 16 * s_jw_doubles(16, 64); }   // workgroup team + 16 wave teams
+    size_t doubles() const { return ns ? 5 * (size_t)sums2 + 2 * (size_t)sums + jw_doubles() + 8 : 8; }
 };
 template <class ST>
 static int sblocks_bind(ST& S, const SBlocks& sb, const std::vector<int>& s, int lq, double*& p, int* di) {
@@ -166,7 +168,10 @@ static int sblocks_bind(ST& S, const SBlocks& sb, const std::vector<int>& s, int
     S.lds_doubles = sb.ns ? (int)std::min<size_t>(20416, 2 * (size_t)sb.maxs * sb.maxs) : 0;
     auto take = [&](size_t k) { double* r = p; p += (k ? k : 1); return r; };
     S.r = take(sb.sums2); S.rti = take(sb.sums2); S.sw1 = take(sb.sums2); S.sw2 = take(sb.sums2); S.sw3 = take(sb.sums2);
-    S.sigs = take(sb.sums); S.sigz = take(sb.sums); S.jw = take(sb.ns ? s_jw_doubles(sb.maxs, 1024) : 1);
+    S.sigs = take(sb.sums); S.sigz = take(sb.sums); S.jw = take(sb.ns ? sb.jw_doubles() : 1);
+    S.jww = S.jw + (sb.ns ? s_jw_doubles(sb.maxs, 1024) : 0);
+    S.smin = sb.mins; S.smax = sb.maxs;
+    S.swmax = getenv("MI355KKT_SDP_WAVE_MAX") ? std::min(16, std::max(-16, atoi(getenv("MI355KKT_SDP_WAVE_MAX")))) : 16;
     S.sdim = di; S.soff = di + sb.ns; S.sloff = di + 2 * sb.ns;
     if (sb.ns) {
         std::vector<int> h(3 * (size_t)sb.ns);
@@ -2222,6 +2227,103 @@ int mi355kkt_debug_sdp_op_host(int op, int m, int arg, double* x, double* y, dou
         default: return MI355KKT_EINVAL;
     }
     return 0;
+}
+/* ... and on the DEVICE: one workgroup (team = 0: 1024 threads, the loops' configuration) or one wave (team = 1) runs the
+ * operation on copies of the host arrays (any may be NULL where the operation does not use it); results come back in place. */
+int mi355kkt_debug_sdp_op_device(int op, int m, int arg, int team, double* x, double* y, double* r, double* rti, double* lam) {
+    if (m < 1 || !x || mi355kkt_device_count() < 1) return MI355KKT_EINVAL;
+    const size_t mm = (size_t)m * m, nw = 3 * mm + mi355kkt::s_jw_doubles(m, 1024) + 64;
+    double* d = nullptr;
+    KKT_HIP_CHECK(hipMalloc(&d, sizeof(double) * (4 * mm + (size_t)m + nw + 8)));
+    double *dx = d, *dy = dx + mm, *dr = dy + mm, *drti = dr + mm, *dl = drti + mm, *dw = dl + m, *dout = dw + nw;
+    KKT_HIP_CHECK(hipMemset(d, 0, sizeof(double) * (4 * mm + (size_t)m + nw + 8)));
+    KKT_HIP_CHECK(hipMemcpy(dx, x, sizeof(double) * mm, hipMemcpyHostToDevice));
+    if (y) KKT_HIP_CHECK(hipMemcpy(dy, y, sizeof(double) * mm, hipMemcpyHostToDevice));
+    if (r) KKT_HIP_CHECK(hipMemcpy(dr, r, sizeof(double) * mm, hipMemcpyHostToDevice));
+    if (rti) KKT_HIP_CHECK(hipMemcpy(drti, rti, sizeof(double) * mm, hipMemcpyHostToDevice));
+    if (lam) KKT_HIP_CHECK(hipMemcpy(dl, lam, sizeof(double) * m, hipMemcpyHostToDevice));
+    if (int e = mi355kkt::sdp_op_debug_launch(op, m, arg, team, dx, dy, dr, drti, dl, dw, dout, nullptr)) { (void)hipFree(d); return e; }
+    KKT_HIP_CHECK(hipDeviceSynchronize());
+    KKT_HIP_CHECK(hipMemcpy(x, dx, sizeof(double) * mm, hipMemcpyDeviceToHost));
+    if (y) KKT_HIP_CHECK(hipMemcpy(y, dy, sizeof(double) * mm, hipMemcpyDeviceToHost));
+    if (r) KKT_HIP_CHECK(hipMemcpy(r, dr, sizeof(double) * mm, hipMemcpyDeviceToHost));
+    if (rti) KKT_HIP_CHECK(hipMemcpy(rti, drti, sizeof(double) * mm, hipMemcpyDeviceToHost));
+    double ret = 0.0;
+    KKT_HIP_CHECK(hipMemcpy(&ret, dout, sizeof(double), hipMemcpyDeviceToHost));
+    if (lam) {
+        KKT_HIP_CHECK(hipMemcpy(lam, dl, sizeof(double) * m, hipMemcpyDeviceToHost));
+        if (op == 4) lam[0] = ret;
+    }
+    (void)hipFree(d);
+    return (op == 6 || op == 8) ? (int)ret : 0;
+}
+
+/* The same operations run by a TEAM of nt host threads (pthread barrier as the team barrier): the SPMD form of cone_ops_s.h
+ * with real concurrency between the threads of a team, as on the device (workgroup teams of 1024, wave teams of 64), for the
+ * CPU tests -- a data race or a missing barrier shows up here (and under ThreadSanitizer) without a GPU. */
+}  // extern "C"
+#include <pthread.h>
+#include <thread>
+namespace {
+struct ParThreads {
+    int id, n;
+    pthread_barrier_t* bar;
+    double* red;
+    int tid() const { return id; }
+    int nt() const { return n; }
+    void sync() const { pthread_barrier_wait(bar); }
+    double sum(double v) const {
+        red[id] = v;
+        sync();
+        double a = 0.0;
+        for (int i = 0; i < n; ++i) a += red[i];
+        sync();
+        return a;
+    }
+    double max(double v) const {
+        red[id] = v;
+        sync();
+        double a = red[0];
+        for (int i = 1; i < n; ++i) a = a > red[i] ? a : red[i];
+        sync();
+        return a;
+    }
+    void jacobi(double* G, double* V, int m, double* jw) const { mi355kkt::s_jacobi_rotations(*this, G, V, m, jw); }
+};
+}  // namespace
+extern "C" {
+int mi355kkt_debug_sdp_op_host_team(int op, int m, int arg, int nt, double* x, double* y, double* r, double* rti, double* lam) {
+    if (m < 1 || !x || nt < 1 || nt > 1024) return MI355KKT_EINVAL;
+    const size_t mm = (size_t)m * m;
+    std::vector<double> w(3 * mm + mi355kkt::s_jw_doubles(m, nt) + m), red(nt);
+    double *T1 = w.data(), *T2 = T1 + mm, *T3 = T2 + mm, *jw = T3 + mm, *sg = jw + mi355kkt::s_jw_doubles(m, nt);
+    const bool inverse = arg & 1, trans = arg & 2;
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, (unsigned)nt);
+    std::vector<int> rc(nt, 0);
+    std::vector<double> ret(nt, 0.0);
+    auto body = [&](int id) {
+        const ParThreads par{id, nt, &bar, red.data()};
+        switch (op) {
+            case 0: mi355kkt::s_scale_blk(par, x, inverse ? rti : r, m, trans == inverse, T1); break;
+            case 1: mi355kkt::s_sprod_blk(par, x, y, m, T1); break;
+            case 2: mi355kkt::s_sprod_diag_blk(par, x, lam, m, inverse); break;
+            case 3: mi355kkt::s_scale2_blk(par, lam, x, m, inverse); break;
+            case 4: ret[id] = mi355kkt::s_min_eig_blk(par, x, m, T1, sg, jw); break;
+            case 5: mi355kkt::s_eig_blk(par, x, lam, m, T1, T2, jw); break;
+            case 6: rc[id] = mi355kkt::s_compute_scaling_blk(par, x, y, r, rti, lam, m, T1, T2, T3, jw); break;
+            case 7: mi355kkt::s_update_scaling_blk(par, x, y, r, rti, lam, m, T1, T2, jw); break;
+            case 8: rc[id] = mi355kkt::s_potrf(par, x, m); break;
+            default: rc[id] = MI355KKT_EINVAL;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int id = 1; id < nt; ++id) th.emplace_back(body, id);
+    body(0);
+    for (auto& t : th) t.join();
+    pthread_barrier_destroy(&bar);
+    if (op == 4) lam[0] = ret[0];
+    return rc[0];
 }
 /* The static SYRK schedule for an n x n result contracted over K on a device with num_cus compute units, as plain integers
  * (host only): out[8 * i + 0..7] = ti, tj, k0, k1, slot, first, nparts, 0 of work item i, in launch order.  For the CPU tests

@@ -164,6 +164,7 @@ __device__ __noinline__ void s_jacobi_waves(double* Gg, double* Vg, int m, doubl
 struct ParWG {
     double* sh;
     int lds_doubles;          // capacity of ipm_dyn_lds
+    double* jw;               // Jacobi / sorting scratch (s_jw_doubles(max order, 1024))
     __device__ __forceinline__ int tid() const { return threadIdx.x; }
     __device__ __forceinline__ int nt() const { return blockDim.x; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
@@ -178,6 +179,60 @@ __device__ __forceinline__ double lp_dot(const double* a, const double* b, int n
     double v = 0.0;
     for (int i = threadIdx.x; i < n; i += blockDim.x) v += a[i] * b[i];
     return lp_block_sum(v, sh);
+}
+
+// One WAVE as the team: blocks of order <= SW_SMALL are handled one per wave, 16 at a time (programs with many small
+// blocks), with wave-level "barriers" (memory fence + scheduling barrier; the lanes run in lock step) and the generic
+// barrier-phased Jacobi rotations of cone_ops_s.h.  Uses no workgroup barrier, so different waves may work on different
+// blocks of different orders at the same time.
+constexpr int SW_SMALL = 16;
+struct ParWave {
+    double* jw;               // this wave's own scratch (s_jw_doubles(SW_SMALL, 64))
+    __device__ __forceinline__ int tid() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ int nt() const { return 64; }
+    __device__ __forceinline__ void sync() const {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __device__ __forceinline__ double sum(double v) const {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+    __device__ __forceinline__ double max(double v) const {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        return v;
+    }
+    __device__ __forceinline__ void jacobi(double* G, double* V, int m, double* scratch) const {
+        s_jacobi_rotations(*this, G, V, m, scratch);
+    }
+};
+
+// op(team, k) for every 's' block k: the small ones one per wave, the others by the whole workgroup one after the other.
+// Contains workgroup barriers: uniform control flow only.
+template <class ST, class F>
+__device__ __forceinline__ void cv_for_sblocks(const ST& S, double* sh, F&& op) {
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const bool serial = S.swmax < 0;                     // (debug: the wave team, but one block at a time)
+    const int swmax = serial ? -S.swmax : S.swmax;       // blocks up to this order go one per wave (<= SW_SMALL; 0: none)
+    if (S.smin <= swmax) {
+        const ParWave pw{S.jww + (size_t)wave * s_jw_doubles(SW_SMALL, 64)};
+        if (!serial) {
+            for (int k = wave; k < S.ns; k += nwaves)
+                if (S.sdim[k] <= swmax) op(pw, k);
+        } else if (wave == 0) {
+            for (int k = 0; k < S.ns; ++k)
+                if (S.sdim[k] <= swmax) op(pw, k);
+        }
+        __syncthreads();
+    }
+    if (S.smax > swmax) {
+        const ParWG par{sh, S.lds_doubles, S.jw};
+        for (int k = 0; k < S.ns; ++k)
+            if (S.sdim[k] > swmax) op(par, k);
+    }
 }
 
 // ---- second-order-cone pieces, one cone (x: the cone's own entries, mk of them) -----------------------------
@@ -255,14 +310,11 @@ __device__ __forceinline__ double cv_maxstep(const ST& S, const double* x, doubl
     double t = -1e300;
     for (int i = threadIdx.x; i < S.ml; i += blockDim.x) t = fmax(t, -x[i]);
     for (int k = threadIdx.x; k < S.nq; k += blockDim.x) t = fmax(t, q_nrm1(x + S.qoff[k], S.qdim[k]) - x[S.qoff[k]]);
-    if (S.ns > 0) {                                      // max_step without sigma: -lambda_min of every block
-        const ParWG par{sh, S.lds_doubles};
-        __syncthreads();
-        for (int k = 0; k < S.ns; ++k) {
+    if (S.ns > 0)                                        // max_step without sigma: -lambda_min of every block
+        cv_for_sblocks(S, sh, [&](const auto& par, int k) {
             const int o = S.soff[k] - S.lq;
-            t = fmax(t, -s_min_eig_blk(par, x + S.soff[k], S.sdim[k], S.sw1 + o, S.sw2 + o, S.jw));
-        }
-    }
+            t = fmax(t, -s_min_eig_blk(par, x + S.soff[k], S.sdim[k], S.sw1 + o, S.sw2 + o, par.jw));
+        });
     return lp_block_max(t, sh);
 }
 // max_step with sigma (misc_solvers.c:1131-1136): the 's' blocks of x are replaced by their eigenvectors, sig (compact
@@ -272,16 +324,13 @@ __device__ __forceinline__ double cv_maxstep_sigma(const ST& S, double* x, doubl
     double t = -1e300;
     for (int i = threadIdx.x; i < S.ml; i += blockDim.x) t = fmax(t, -x[i]);
     for (int k = threadIdx.x; k < S.nq; k += blockDim.x) t = fmax(t, q_nrm1(x + S.qoff[k], S.qdim[k]) - x[S.qoff[k]]);
-    if (S.ns > 0) {
-        const ParWG par{sh, S.lds_doubles};
-        __syncthreads();
-        for (int k = 0; k < S.ns; ++k) {
+    if (S.ns > 0)
+        cv_for_sblocks(S, sh, [&](const auto& par, int k) {
             const int o = S.soff[k] - S.lq;
             double* sg = sig + (S.sloff[k] - S.lq);
-            s_eig_blk(par, x + S.soff[k], sg, S.sdim[k], S.sw1 + o, S.sw2 + o, S.jw);
+            s_eig_blk(par, x + S.soff[k], sg, S.sdim[k], S.sw1 + o, S.sw2 + o, par.jw);
             t = fmax(t, -sg[0]);
-        }
-    }
+        });
     return lp_block_max(t, sh);
 }
 template <class ST>
@@ -296,32 +345,26 @@ template <class ST>
 __device__ __forceinline__ void cv_sprod(const ST& S, double* x, const double* y, double* sh) {
     for (int i = threadIdx.x; i < S.ml; i += blockDim.x) x[i] *= y[i];
     for (int k = threadIdx.x; k < S.nq; k += blockDim.x) q_sprod(x + S.qoff[k], y + S.qoff[k], S.qdim[k]);
-    if (S.ns > 0) {
-        const ParWG par{sh, S.lds_doubles};
-        __syncthreads();
-        for (int k = 0; k < S.ns; ++k)
+    if (S.ns > 0)
+        cv_for_sblocks(S, sh, [&](const auto& par, int k) {
             s_sprod_blk(par, x + S.soff[k], y + S.soff[k], S.sdim[k], S.sw1 + (S.soff[k] - S.lq));
-    }
+        });
 }
 // x := x o lmbda, lmbda in its compact layout (sprod with diag = 'D')
 template <class ST>
 __device__ __forceinline__ void cv_sprod_diag(const ST& S, double* x, const double* l, double* sh) {
     for (int i = threadIdx.x; i < S.ml; i += blockDim.x) x[i] *= l[i];
     for (int k = threadIdx.x; k < S.nq; k += blockDim.x) q_sprod(x + S.qoff[k], l + S.qoff[k], S.qdim[k]);
-    if (S.ns > 0) {
-        const ParWG par{sh, S.lds_doubles};
-        for (int k = 0; k < S.ns; ++k) s_sprod_diag_blk(par, x + S.soff[k], l + S.sloff[k], S.sdim[k], false);
-    }
+    if (S.ns > 0)
+        cv_for_sblocks(S, sh, [&](const auto& par, int k) { s_sprod_diag_blk(par, x + S.soff[k], l + S.sloff[k], S.sdim[k], false); });
 }
 // x := lmbda o\ x (sinv: the second argument is always the compact lmbda)
 template <class ST>
 __device__ __forceinline__ void cv_sinv(const ST& S, double* x, const double* l, double* sh) {
     for (int i = threadIdx.x; i < S.ml; i += blockDim.x) x[i] /= l[i];
     for (int k = threadIdx.x; k < S.nq; k += blockDim.x) q_sinv(x + S.qoff[k], l + S.qoff[k], S.qdim[k]);
-    if (S.ns > 0) {
-        const ParWG par{sh, S.lds_doubles};
-        for (int k = 0; k < S.ns; ++k) s_sprod_diag_blk(par, x + S.soff[k], l + S.sloff[k], S.sdim[k], true);
-    }
+    if (S.ns > 0)
+        cv_for_sblocks(S, sh, [&](const auto& par, int k) { s_sprod_diag_blk(par, x + S.soff[k], l + S.sloff[k], S.sdim[k], true); });
 }
 // x := y o y for the compact lmbda layout (misc.ssqr, misc.py:945-972: the 's' part is diagonal)
 template <class ST>
@@ -334,10 +377,8 @@ template <class ST>
 __device__ __forceinline__ void cv_scale2(const ST& S, const double* l, double* x, bool inverse, double* sh) {
     for (int i = threadIdx.x; i < S.ml; i += blockDim.x) x[i] = inverse ? x[i] * l[i] : x[i] / l[i];
     for (int k = threadIdx.x; k < S.nq; k += blockDim.x) q_scale2(l + S.qoff[k], x + S.qoff[k], S.qdim[k], inverse);
-    if (S.ns > 0) {
-        const ParWG par{sh, S.lds_doubles};
-        for (int k = 0; k < S.ns; ++k) s_scale2_blk(par, l + S.sloff[k], x + S.soff[k], S.sdim[k], inverse);
-    }
+    if (S.ns > 0)
+        cv_for_sblocks(S, sh, [&](const auto& par, int k) { s_scale2_blk(par, l + S.sloff[k], x + S.soff[k], S.sdim[k], inverse); });
 }
 // misc.scale: x := W x (trans: W' x) or W^-1 x (trans: W^-T x).  'l' and 'q' blocks are symmetric; 's' blocks (misc.py:
 // 118-164): r' X r | r X r' (trans) | rti X rti' (inverse) | rti' X rti (inverse, trans)
@@ -346,14 +387,11 @@ __device__ __forceinline__ void cv_scale(const ST& S, double* x, bool inverse, b
     for (int i = threadIdx.x; i < S.ml; i += blockDim.x) x[i] = inverse ? x[i] / S.d[i] : x[i] * S.d[i];
     for (int k = threadIdx.x; k < S.nq; k += blockDim.x)
         q_scale(x + S.qoff[k], S.v + (S.qoff[k] - S.ml), S.beta[k], S.qdim[k], inverse);
-    if (S.ns > 0) {
-        const ParWG par{sh, S.lds_doubles};
-        __syncthreads();
-        for (int k = 0; k < S.ns; ++k) {
+    if (S.ns > 0)
+        cv_for_sblocks(S, sh, [&](const auto& par, int k) {
             const int o = S.soff[k] - S.lq;
             s_scale_blk(par, x + S.soff[k], (inverse ? S.rti : S.r) + o, S.sdim[k], trans == inverse, S.sw1 + o);
-        }
-    }
+        });
 }
 // x := the cone vector with the compact lmbda on it: copy for 'l' / 'q', diag(lmbda_k) for the 's' blocks
 // (coneprog.py:1264-1273, :1404-1413)
@@ -463,15 +501,12 @@ __device__ __forceinline__ void cv_compute_scaling(const ST& S, const double* s,
         const int o = S.qoff[k];
         q_compute_scaling(s + o, z + o, S.v + (o - S.ml), S.beta + k, lmbda + o, S.qdim[k]);
     }
-    if (S.ns > 0) {                                      // misc.py:374-417
-        const ParWG par{sh, S.lds_doubles};
-        __syncthreads();
-        for (int k = 0; k < S.ns; ++k) {
+    if (S.ns > 0)                                        // misc.py:374-417
+        cv_for_sblocks(S, sh, [&](const auto& par, int k) {
             const int o = S.soff[k] - S.lq;
             s_compute_scaling_blk(par, s + S.soff[k], z + S.soff[k], S.r + o, S.rti + o, lmbda + S.sloff[k], S.sdim[k], S.sw1 + o,
-                                  S.sw2 + o, S.sw3 + o, S.jw);
-        }
-    }
+                                  S.sw2 + o, S.sw3 + o, par.jw);
+        });
 }
 
 // misc.update_scaling, 'l' (misc.py:444-464) and 'q' (:503-573) blocks; ds, dz: the updated variables in the current
@@ -488,15 +523,12 @@ __device__ __forceinline__ void cv_update_scaling(const ST& S, double* lmbda, do
         const int o = S.qoff[k];
         q_update_scaling(ds + o, dz + o, S.v + (o - S.ml), S.beta + k, lmbda + o, S.qdim[k]);
     }
-    if (S.ns > 0) {                                      // misc.py:592-634; the 's' blocks of ds, dz hold Ls, Lz
-        const ParWG par{sh, S.lds_doubles};
-        __syncthreads();
-        for (int k = 0; k < S.ns; ++k) {
+    if (S.ns > 0)                                        // misc.py:592-634; the 's' blocks of ds, dz hold Ls, Lz
+        cv_for_sblocks(S, sh, [&](const auto& par, int k) {
             const int o = S.soff[k] - S.lq;
             s_update_scaling_blk(par, ds + S.soff[k], dz + S.soff[k], S.r + o, S.rti + o, lmbda + S.sloff[k], S.sdim[k], S.sw1 + o,
-                                 S.sw2 + o, S.jw);
-        }
-    }
+                                 S.sw2 + o, par.jw);
+        });
 }
 
 }  // namespace mi355kkt

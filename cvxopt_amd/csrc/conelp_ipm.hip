@@ -15,6 +15,7 @@
 // and the cone-vector operations sprod, sinv, ssqr, scale2, max_step, scale (src/C/misc_solvers.c:634, :775, :256, :1052,
 // :85; misc.py:945) for the 'l' and 'q' blocks.
 #include "cone_ops.h"
+#include <algorithm>
 
 namespace mi355kkt {
 
@@ -465,6 +466,50 @@ __global__ __launch_bounds__(1024) void lp_symm_kernel(LpState S, double* z) { c
 
 // one workgroup of S.nthreads threads; kernels that run the Jacobi iteration get the dynamic LDS staging area (> 64 KB
 // needs the attribute once per kernel)
+// One 's'-block operation of cone_ops_s.h on the device, with the workgroup team (1024 threads) or one wave team (64): the
+// device twin of mi355kkt_debug_sdp_op_host for the GPU unit tests.  w: 3 m^2 + jw scratch; out[0]: return value.
+__global__ __launch_bounds__(1024) void sdp_op_debug_kernel(int op, int m, int arg, int wave_team, int lds_doubles, double* x, double* y,
+                                                            double* r, double* rti, double* lam, double* w, double* out) {
+    __shared__ double sh[16];
+    const size_t mm = (size_t)m * m;
+    double *T1 = w, *T2 = T1 + mm, *T3 = T2 + mm, *jw = T3 + mm;
+    const bool inverse = arg & 1, trans = arg & 2;
+    auto run = [&](const auto& par) {
+        double ret = 0.0;
+        switch (op) {
+            case 0: s_scale_blk(par, x, inverse ? rti : r, m, trans == inverse, T1); break;
+            case 1: s_sprod_blk(par, x, y, m, T1); break;
+            case 2: s_sprod_diag_blk(par, x, lam, m, inverse); break;
+            case 3: s_scale2_blk(par, lam, x, m, inverse); break;
+            case 4: ret = s_min_eig_blk(par, x, m, T1, T2, jw); break;
+            case 5: s_eig_blk(par, x, lam, m, T1, T2, jw); break;
+            case 6: ret = s_compute_scaling_blk(par, x, y, r, rti, lam, m, T1, T2, T3, jw); break;
+            case 7: s_update_scaling_blk(par, x, y, r, rti, lam, m, T1, T2, jw); break;
+            case 8: ret = s_potrf(par, x, m); break;
+        }
+        if (par.tid() == 0) out[0] = ret;
+    };
+    if (wave_team) {
+        if (threadIdx.x < 64) run(ParWave{jw});
+    } else {
+        run(ParWG{sh, lds_doubles, jw});
+    }
+}
+int sdp_op_debug_launch(int op, int m, int arg, int wave_team, double* x, double* y, double* r, double* rti, double* lam, double* w,
+                        double* out, hipStream_t st) {
+    const int lds_doubles = wave_team ? 0 : (int)std::min<size_t>(20416, 2 * (size_t)m * m);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sdp_op_debug_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 512);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(sdp_op_debug_kernel, dim3(1), dim3(wave_team ? 64 : 1024), sizeof(double) * lds_doubles, st, op, m, arg, wave_team,
+                       lds_doubles, x, y, r, rti, lam, w, out);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 #define LP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(S.nthreads), 0, st, __VA_ARGS__)
 #define LP1J(kernel, ...)                                                                                              \
     do {                                                                                                               \

@@ -299,6 +299,8 @@ struct LpState {
     // sloff[k] of lmbda (compact layout: sdim[k] entries), at soff[k] - lq of r / rti / sw1..3, at sloff[k] - lq of sigs / sigz
     int ns = 0, lq = 0, ldim = 0;                     // lq = ml + sum(q); ldim = lq + sum(s) = length of lmbda
     int nthreads = 256, lds_doubles = 0;              // workgroup size of the loop kernels; dynamic LDS (Jacobi staging)
+    int smin = 0, smax = 0, swmax = 0;                // smallest / largest block order; largest order handled one block per wave
+    double* jww = nullptr;                            // 16 per-wave scratch areas for the blocks handled one per wave
     const int *sdim = nullptr, *soff = nullptr, *sloff = nullptr;
     double *r = nullptr, *rti = nullptr, *sw1 = nullptr, *sw2 = nullptr, *sw3 = nullptr, *jw = nullptr, *sigs = nullptr,
            *sigz = nullptr;
@@ -330,6 +332,8 @@ void lp_launch_res_b(const LpState& S, const LpBuf& U, const LpBuf& V, hipStream
 void lp_launch_step(const LpState& S, const LpBuf& D, int i01, hipStream_t st);
 void lp_launch_update(const LpState& S, const LpBuf& D, hipStream_t st);
 void lp_launch_symm(const LpState& S, double* z, hipStream_t st);   // no-op without 's' blocks
+int sdp_op_debug_launch(int op, int m, int arg, int wave_team, double* x, double* y, double* r, double* rti, double* lam, double* w,
+                        double* out, hipStream_t st);
 
 // ---- device-resident coneqp loop for one problem, 'l' + 'q' cones (coneqp_ipm.hip) ------------------------
 enum QpScalar {
@@ -344,6 +348,8 @@ struct QpState {
     // sloff[k] of lmbda (compact layout: sdim[k] entries), at soff[k] - lq of r / rti / sw1..3, at sloff[k] - lq of sigs / sigz
     int ns = 0, lq = 0, ldim = 0;                     // lq = ml + sum(q); ldim = lq + sum(s) = length of lmbda
     int nthreads = 256, lds_doubles = 0;              // workgroup size of the loop kernels; dynamic LDS (Jacobi staging)
+    int smin = 0, smax = 0, swmax = 0;                // smallest / largest block order; largest order handled one block per wave
+    double* jww = nullptr;                            // 16 per-wave scratch areas for the blocks handled one per wave
     const int *sdim = nullptr, *soff = nullptr, *sloff = nullptr;
     double *r = nullptr, *rti = nullptr, *sw1 = nullptr, *sw2 = nullptr, *sw3 = nullptr, *jw = nullptr, *sigs = nullptr,
            *sigz = nullptr;

@@ -249,6 +249,8 @@ int mi355kkt_debug_hwid(unsigned* out, int nblocks);
  * parity tests against misc.sprod / sinv / ssqr / scale2 / scale / jnrm2 / compute_scaling / update_scaling / max_step */
 int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w);
 int mi355kkt_debug_sdp_op_host(int op, int m, int arg, double* x, double* y, double* r, double* rti, double* lam);
+int mi355kkt_debug_sdp_op_device(int op, int m, int arg, int team, double* x, double* y, double* r, double* rti, double* lam);
+int mi355kkt_debug_sdp_op_host_team(int op, int m, int arg, int nt, double* x, double* y, double* r, double* rti, double* lam);
 /* the static work list of the scaled SYRK (host only): 8 ints per item = ti, tj, k0, k1, slot, first, nparts, 0; returns #items */
 int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit);
 /* fill-reducing ordering of a symmetric CSC pattern (host only; csrc/ordering.cpp -- the step cholmod.symbolic performs through

@@ -211,3 +211,42 @@ def test_many_small_and_one_larger_block():
     assert np.linalg.norm(G.T @ z + c) <= 1e-6 * max(1.0, np.linalg.norm(c))
     assert abs(c @ x + h @ z) <= 1e-5 * max(1.0, abs(c @ x))
     assert sol['primal slack'] > -1e-8 and sol['dual slack'] > -1e-8
+
+
+@pytest.mark.parametrize("nb,mk,extra", [(100, 3, []), (40, 5, [30]), (70, 12, [])])
+def test_many_blocks_one_per_wave(nb, mk, extra):
+    """programs with many small blocks: blocks of order <= 16 are handled one per WAVE, 16 at a time (cone_ops.h, ParWave), the
+    larger ones by the whole workgroup; checked through the optimality conditions of the returned point"""
+    rng = np.random.default_rng(nb)
+    dims = {'l': 2, 'q': [], 's': [mk] * nb + extra}
+    n = 14
+    cols = []
+    for _ in range(n):
+        parts = [rng.standard_normal(dims['l'])]
+        for m in dims['s']:
+            a = rng.standard_normal((m, m))
+            parts.append((0.5 * (a + a.T)).ravel(order='F'))
+        cols.append(np.concatenate(parts))
+    G = np.asfortranarray(np.array(cols).T)
+
+    def interior():
+        parts = [rng.random(dims['l']) + 0.5]
+        for m in dims['s']:
+            a = rng.standard_normal((m, m))
+            parts.append((a @ a.T / m + 0.5 * np.eye(m)).ravel(order='F'))
+        return np.concatenate(parts)
+    x0 = rng.standard_normal(n)
+    h = G @ x0 + interior()
+    c = -(G.T @ interior())
+    for rep in range(3):                                    # repeated: the wave teams run concurrently
+        sol = cvxopt_amd.conelp_device(c, G, h, dims)
+        assert sol['status'] == 'optimal'
+        x, s, z = sol['x'], sol['s'], sol['z']
+        assert np.linalg.norm(G @ x + s - h) <= 1e-6 * max(1.0, np.linalg.norm(h))
+        assert np.linalg.norm(G.T @ z + c) <= 1e-6 * max(1.0, np.linalg.norm(c))
+        assert abs(c @ x + h @ z) <= 1e-5 * max(1.0, abs(c @ x))
+        assert sol['primal slack'] > -1e-8 and sol['dual slack'] > -1e-8
+        if rep == 0:
+            first = x.copy()
+        else:
+            assert np.array_equal(first, x)                  # fixed-order arithmetic: bit-identical from run to run

@@ -200,3 +200,34 @@ def test_potrf_block_reports_the_failing_pivot():
     assert np.allclose(c, np.linalg.cholesky(a), atol=1e-13)
     a[4, 4] = -1.0
     assert _op(8, m, a.copy(order='F')) == 5
+
+
+@pytest.mark.parametrize("nt", [4, 64])
+@pytest.mark.parametrize("m", [2, 5, 16, 33])
+def test_operations_with_a_team_of_host_threads(m, nt):
+    """the same SPMD source run by nt host threads with a pthread barrier as the team barrier (`mi355kkt_debug_sdp_op_host_team`):
+    real concurrency inside a team, as on the device; results must be those of the team of one"""
+    L = _capi.lib()
+    p = lambda a: a.ctypes.data if a is not None else None
+    rng = np.random.default_rng(50 + m)
+    s, z, x, y = _spd(rng, m, 1e2), _spd(rng, m, 1e2), _sym(rng, m), _sym(rng, m)
+    r, rti, lam = _F(np.zeros((m, m))), _F(np.zeros((m, m))), np.zeros(m)
+    r1, rti1, lam1 = r.copy(order='F'), rti.copy(order='F'), lam.copy()
+    sc, zc = s.copy(order='F'), z.copy(order='F')
+    assert _op(6, m, sc, zc, r, rti, lam) == 0
+    sc, zc = s.copy(order='F'), z.copy(order='F')
+    assert L.mi355kkt_debug_sdp_op_host_team(6, m, 0, nt, p(sc), p(zc), p(r1), p(rti1), p(lam1)) == 0
+    assert np.allclose(lam, lam1, rtol=1e-12, atol=0)
+    assert np.allclose(r @ r.T, r1 @ r1.T, rtol=0, atol=1e-11 * np.linalg.norm(r) ** 2)
+    for op, arg, second in ((0, 0, None), (0, 3, None), (1, 0, y), (3, 1, None), (2, 0, None)):
+        a, b = x.copy(order='F'), x.copy(order='F')
+        yc = None if second is None else second.copy(order='F')
+        lam0 = rng.random(m) + 0.2
+        assert _op(op, m, a, yc, r, rti, lam0, arg=arg) == 0
+        yc = None if second is None else second.copy(order='F')
+        assert L.mi355kkt_debug_sdp_op_host_team(op, m, arg, nt, p(b), p(yc), p(r), p(rti), p(lam0)) == 0
+        assert np.allclose(a, b, rtol=1e-13, atol=1e-13 * np.abs(a).max()), (op, arg)
+    a, sig = x.copy(order='F'), np.zeros(m)
+    assert L.mi355kkt_debug_sdp_op_host_team(5, m, 0, nt, p(a), None, None, None, p(sig)) == 0
+    assert np.allclose(sig, np.linalg.eigvalsh(x), atol=1e-12 * np.linalg.norm(x))
+    assert np.allclose(a @ np.diag(sig) @ a.T, x, atol=1e-12 * np.linalg.norm(x))
