@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--m", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="auto", choices=["auto", "dense", "batch", "sharded", "sparse", "socp"],
+    ap.add_argument("--workload", default="auto", choices=["auto", "dense", "batch", "sharded", "sparse", "socp", "sdp"],
                     help="auto = dense at --gpus 1, sharded at --gpus N > 1; dense = BASELINE configs[1] (the headline line; "
                          "--n 256 --m 512 gives configs[0]); sharded = configs[4]: --total-batch problems scattered from the "
                          "root GPU over the ranks, solved, gathered; batch = configs[4] class with --batch problems generated "
@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--dry-run", action="store_true", help="--gpus N plumbing check on CPU (gloo, NumPy, tiny batch)")
     ap.add_argument("--grid", type=int, default=46, help="k for the k^3 Laplacian of --workload sparse")
     ap.add_argument("--cone-dim", type=int, default=8, help="--workload socp: dimension of each of the 1024 second-order cones")
+    ap.add_argument("--sdp-order", type=int, default=100, help="--workload sdp: order of the semidefinite block")
     ap.add_argument("--mesh", default="grid", choices=["grid", "tet"],
                     help="--workload sparse: structured 7-point grid (default) or an unstructured tetrahedral mesh of k^3 nodes")
     ap.add_argument("--cpu-iters", type=int, default=2, help="reference CPU iterations timed (bounded sample)")
@@ -500,6 +501,49 @@ def main_socp(args):
         dist.destroy_process_group()
 
 
+def main_sdp(args):
+    """'s' cones: the max-cut relaxation of the reference's examples/doc/chap8/mcsdp.py as a plain cone LP
+    (min 1'x s.t. w + diag(x) >= 0, one block of order --sdp-order) through the device-resident conelp loop; a step = one
+    interior-point iteration (1 factor with the 's'-block congruence of G, 5 solves, the Jacobi eigen / singular value
+    decompositions of the scaling update and the step-length search)."""
+    rank, world, local_rank, torch, dist = _dist_setup()
+    import numpy as np
+    from cvxopt_amd import kkt
+    import cvxopt_amd
+    kkt.options["device"] = local_rank
+    m = args.sdp_order
+    rng = np.random.default_rng(rank)
+    w = rng.standard_normal((m, m))
+    w = 0.5 * (w + w.T)
+    G = np.zeros((m * m, m), order='F')
+    for j in range(m):
+        G[j * (m + 1), j] = -1.0
+    c, h, dims = np.ones(m), w.ravel(order='F'), {'l': 0, 'q': [], 's': [m]}
+    for _ in range(max(1, args.warmup)):
+        sol = cvxopt_amd.conelp_device(c, G, h, dims)
+    if dist is not None:
+        dist.barrier()
+    t = time.perf_counter()
+    its = 0
+    for _ in range(max(1, args.steps // 5)):
+        sol = cvxopt_amd.conelp_device(c, G, h, dims)
+        its += sol['iterations']
+    t = time.perf_counter() - t
+    if rank == 0:
+        print(json.dumps({
+            "metric": "SDP interior-point iterations/s, device-resident conelp loop ('s' cone, order %d)" % m,
+            "value": round(world * its / t, 3), "unit": "IPM iterations/s", "n_gpus": world, "steps": its, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * t / its, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "max-cut SDP relaxation (examples/doc/chap8/mcsdp.py as a cone LP), one 's' block of order %d, "
+                                   "n = %d, whole solves timed (engine creation and upload of G included)" % (m, m), "replicas": world},
+            "roofline": None, "status": sol['status'], "iterations_per_solve": sol['iterations'],
+            "note": "latency-bound Jacobi sweeps (one workgroup, LDS-resident up to order 142): see DESIGN.md section 11"}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -514,6 +558,8 @@ def main():
         args.workload = "sharded" if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.dry_run) else "dense"
     if args.workload == "sharded":
         return main_sharded(args)
+    if args.workload == "sdp":
+        return main_sdp(args)
     if args.workload == "socp":
         return main_socp(args)
     if args.workload == "batch":

@@ -65,6 +65,8 @@ void build_graph(int n, int m, const int64_t* gcp, const int64_t* gri, const int
 
 }  // namespace
 
+int sp_wide_threshold();
+
 int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const int64_t* gri, const int64_t* hcp,
                      const int64_t* hri) {
     S = SparseSymbolic();
@@ -294,7 +296,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
             const int sn = S.level_sn[k];
             const int64_t h = S.sn_rowptr[sn + 1] - S.sn_rowptr[sn], w = S.sn_first[sn + 1] - S.sn_first[sn];
-            if ((h - w) * w > 32768 || (w > 256 && h > w)) {      // == SP_HEAVY / SP_WIDE in the kernels
+            if ((h - w) * w > 32768 || (w > sp_wide_threshold() && h > w)) {      // == SP_HEAVY / SP_WIDE in the kernels
                 S.heavy.push_back(sn);
                 S.heavy_maxhu[l] = std::max<int>(S.heavy_maxhu[l], (int)(h - w));
                 S.heavy_maxw[l] = std::max<int>(S.heavy_maxw[l], (int)w);
@@ -308,7 +310,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     S.wide_ptr.assign(S.nlevels + 1, 0);
     for (int l = 0; l < S.nlevels; ++l) {
         for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k)
-            if (S.sn_first[S.level_sn[k] + 1] - S.sn_first[S.level_sn[k]] > 256) S.wide.push_back(S.level_sn[k]);
+            if (S.sn_first[S.level_sn[k] + 1] - S.sn_first[S.level_sn[k]] > sp_wide_threshold()) S.wide.push_back(S.level_sn[k]);
         S.wide_ptr[l + 1] = (int)S.wide.size();
     }
     if (getenv("MI355KKT_SPARSE_DEBUG")) {
@@ -480,6 +482,7 @@ struct SpDev {   // device copies of the symbolic structure (plain pointers for 
     const int* level_sn;
     const int64_t* ea_off;     // per child of a big front: offset of its tile-boundary table in ea_lb
     const int* ea_lb;
+    int wide;                  // sp_wide_threshold()
 };
 
 // One workgroup = one frontal matrix.  F = [ L-panel (h x w) | U (h-w x h-w) ]: the panel already holds the
@@ -630,7 +633,13 @@ __global__ void sp_merge_info_kernel(const int* __restrict__ local, int offset, 
 // the block to the rest of the vector.
 constexpr int SPB = 32;
 constexpr int64_t SP_HEAVY = 32768;     // supernodes with more off-diagonal panel entries get the multi-workgroup kernels
-constexpr int SP_WIDE = 256;            // wider supernodes: gather / dense persistent trsv / multi-workgroup products
+// supernodes wider than this leave the one-workgroup solve kernels: gather / dense persistent trsv / multi-workgroup products
+// (128; at most 256, the capacity of the kernels' LDS vector; $MI355KKT_SP_WIDE: experiments.  46^3: solve 1.98 ms at 256,
+// 1.76 ms at 128, 1.74 ms at 64)
+int sp_wide_threshold() {
+    static const int v = getenv("MI355KKT_SP_WIDE") ? std::min(256, std::max(32, atoi(getenv("MI355KKT_SP_WIDE")))) : 128;
+    return v;
+}
 
 __device__ __forceinline__ void sp_trsv_fwd_lds(const double* __restrict__ P, int h, int w, double* xs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -735,7 +744,7 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
     const int w = d.sn_first[s + 1] - f;
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
     const int hu = h - w;
-    if (w > SP_WIDE) return;                            // sp_fwd_wide_gather_kernel + launch_trsv_persistent + sp_fwd_rem_kernel
+    if (w > d.wide) return;                             // sp_fwd_wide_gather_kernel + launch_trsv_persistent + sp_fwd_rem_kernel
     const double* __restrict__ P = panels + d.panel_off[s];
     double* __restrict__ R = rem + rem_off[s];          // hu entries
     for (int i = tid; i < hu; i += 256) R[i] = 0.0;
@@ -884,7 +893,7 @@ __global__ __launch_bounds__(256) void sp_bwd_kernel(SpDev d, int level_begin, c
     const int w = d.sn_first[s + 1] - f;
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
     const double* __restrict__ P = panels + d.panel_off[s];
-    if (w > SP_WIDE) return;                            // sp_bwd_gemv_kernel + launch_trsv_persistent (transposed)
+    if (w > d.wide) return;                             // sp_bwd_gemv_kernel + launch_trsv_persistent (transposed)
     if (tid < w) xs[tid] = x[f + tid];
     __syncthreads();
     if ((int64_t)(h - w) * w <= SP_HEAVY && h > w) {
@@ -1107,6 +1116,7 @@ static SpDev devview(const SparseEngine& E) {
     d.level_sn = E.d_level_sn;
     d.ea_off = E.d_ea_off;
     d.ea_lb = E.d_ea_lb;
+    d.wide = sp_wide_threshold();
     return d;
 }
 
@@ -1172,9 +1182,13 @@ static int sp_wide_forward(SparseEngine& E, const SpDev& d, int l, double* x, do
     if (nw == 0) return 0;
     hipLaunchKernelGGL(sp_fwd_wide_gather_kernel, dim3(nw, nrhs), dim3(256), 0, st, d, E.d_wide + k0, x, rem, E.d_rem_off, xstride,
                        remstride);
-    if (nrhs == 1 && x == E.d_xp && E.t_flags && nw <= E.t_njobs_max)      // all of the level's systems in one launch
-        return launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 0, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran, nullptr,
-                                      E.d_wide_jobs + k0, nw);
+    if (nrhs == 1 && x == E.d_xp && E.t_flags && E.t_njobs_max > 0) {      // the level's systems, up to t_njobs_max per launch
+        for (int c0 = 0; c0 < nw; c0 += E.t_njobs_max)
+            if (int e = launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 0, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran,
+                                               nullptr, E.d_wide_jobs + k0 + c0, std::min(E.t_njobs_max, nw - c0)))
+                return e;
+        return 0;
+    }
     for (int k = k0; k < k0 + nw; ++k) {
         const int s = S.wide[k], f = S.sn_first[s], w = S.sn_first[s + 1] - f;
         const int h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
@@ -1190,9 +1204,13 @@ static int sp_wide_backward(SparseEngine& E, int l, double* x, hipStream_t st) {
     const SparseSymbolic& S = E.sym;
     const int k0 = S.wide_ptr[l], nw = S.wide_ptr[l + 1] - k0;
     if (nw == 0) return 0;
-    if (x == E.d_xp && E.t_flags && nw <= E.t_njobs_max)
-        return launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 1, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran, nullptr,
-                                      E.d_wide_jobs + k0, nw);
+    if (x == E.d_xp && E.t_flags && E.t_njobs_max > 0) {
+        for (int c0 = 0; c0 < nw; c0 += E.t_njobs_max)
+            if (int e = launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 1, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran,
+                                               nullptr, E.d_wide_jobs + k0 + c0, std::min(E.t_njobs_max, nw - c0)))
+                return e;
+        return 0;
+    }
     for (int k = S.wide_ptr[l]; k < S.wide_ptr[l + 1]; ++k) {
         const int s = S.wide[k], f = S.sn_first[s], w = S.sn_first[s + 1] - f;
         const int h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);

@@ -94,7 +94,7 @@ class Plan(object):
             assert np.array_equal(vb[:, 0], self.panel_off[sl[k:]]) and np.array_equal(vb[:, 1], hgt[sl[k:]])
             assert np.array_equal(vb[:, 2], wid[sl[k:]]) and np.array_equal(vb[:, 3], self.sn_first[sl[k:]])
             heavy = self.heavy[self.heavy_ptr[l]:self.heavy_ptr[l + 1]]
-            expect = [int(s_) for s_ in sl if (hgt[s_] - wid[s_]) * wid[s_] > 32768 or (wid[s_] > 256 and hgt[s_] > wid[s_])]
+            expect = [int(s_) for s_ in sl if (hgt[s_] - wid[s_]) * wid[s_] > 32768 or (wid[s_] > 128 and hgt[s_] > wid[s_])]       # 128 = sp_wide_threshold()
             assert heavy.tolist() == expect
 
     def factor(self, di):
