@@ -186,7 +186,7 @@ void relaxed_supernodes(const std::vector<int>& parent, const std::vector<int64_
     const int n = (int)parent.size();
     // widest supernode: wider ones (the top separators of a nested dissection) are factored and solved by the multi-workgroup
     // dense kernels as ONE front instead of a chain of 256-column pieces, one level each ($MI355KKT_SN_MAXW: experiments)
-    static const int MAXW = getenv("MI355KKT_SN_MAXW") ? std::max(1, atoi(getenv("MI355KKT_SN_MAXW"))) : 8192;
+    const int MAXW = getenv("MI355KKT_SN_MAXW") ? std::max(1, atoi(getenv("MI355KKT_SN_MAXW"))) : 8192;   // (read per analysis)
     sn_first.clear();
     sn_of.assign(n, 0);
     int64_t true_nnz = 0;        // nonzeros of L in the columns of the current supernode

@@ -252,3 +252,32 @@ def test_structure_of_a_larger_plan_with_heavy_supernodes():
     plan.check_structure()
     assert len(plan.heavy) > 0 and plan.big.any() and not plan.big.all()
     assert plan.nlevels < 40
+
+
+@pytest.mark.parametrize("maxw", ["8", "256", None])
+def test_supernode_width_cap_changes_the_partition_not_the_factor(maxw, monkeypatch):
+    """$MI355KKT_SN_MAXW: chains of narrow pieces (8), the round-1 cap (256), the default (8192: the 16^3 grid's root separator
+    of 256 columns and its children become single wide supernodes, more than the 128 columns of sp_wide_threshold()): the
+    executed plan is the same Cholesky factor, with fewer levels the wider the supernodes may be"""
+    monkeypatch.setenv('MI355KKT_ORDERING', 'nd')
+    if maxw is not None:
+        monkeypatch.setenv('MI355KKT_SN_MAXW', maxw)
+    G, H = box(4096), lap3(16)
+    plan = Plan(G, H)
+    plan.check_structure()
+    wid = np.diff(plan.sn_first)
+    di = np.ones(G.shape[0])
+    L = plan.factor(di)
+    Sp = plan.S(di).toarray()[np.ix_(plan.perm, plan.perm)]
+    assert np.linalg.norm(L @ L.T - Sp) <= 1e-12 * np.linalg.norm(Sp)
+    if maxw is None:
+        assert 128 < wid.max() <= 8192                        # the root separator in one piece
+    else:
+        assert wid.max() <= int(maxw)
+    test_supernode_width_cap_changes_the_partition_not_the_factor.levels[maxw] = plan.nlevels
+    lv = test_supernode_width_cap_changes_the_partition_not_the_factor.levels
+    if len(lv) == 3:
+        assert lv["8"] > lv["256"] >= lv[None]
+
+
+test_supernode_width_cap_changes_the_partition_not_the_factor.levels = {}
