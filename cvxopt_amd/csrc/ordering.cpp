@@ -16,6 +16,7 @@
 #include <cstring>
 #include <cstdio>
 #include <chrono>
+#include <functional>
 #include <future>
 #include <memory>
 #include <numeric>
@@ -643,6 +644,7 @@ struct Dissector {
     bool amd_leaves;
     int nd_mode = 3;                              // 1 level sets, 2 multilevel bisection, 3 level sets + multilevel where they are jagged, 7 always both
     bool norefine = false;
+    std::function<void(size_t, size_t)> on_top;   // called with (separator size, part size) for every split at depth 0
     std::vector<signed char> where;               // separator refinement: 0 left, 1 right, 2 separator
     std::vector<int> lock_stamp, version;
     std::atomic<int> next_pass{1};
@@ -926,6 +928,7 @@ struct Dissector {
             }
         }
         for (int v : sep) part[v].store(-1, std::memory_order_relaxed);
+        if (depth == 0 && on_top) on_top(sep.size(), nodes.size());
         if (depth < 3 && getenv("MI355KKT_ND_DEBUG"))
             fprintf(stderr, "[nd] depth %d: %zu nodes -> left %zu right %zu separator %zu (level %zu of %zu, raw %zu, thinned %zu)\n", depth, nodes.size(),
                     left.size(), right.size(), sep.size(), best_l, levels.size(), levels[best_l].size(), sep0);
@@ -989,14 +992,26 @@ void fill_reducing_ordering(const Graph& adj, std::vector<int>& order, int metho
         etree_and_counts(adj, oamd, par_amd, cc_amd);
         cost_of(cc_amd, I.nnz_amd, I.flops_amd);
     };
+    // The minimum-degree candidate runs beside the dissection, on its own thread -- but only when it can win.  It wins on
+    // graphs without small separators (random / small-world graphs: top separator of 0.2 n nodes); on mesh-like graphs, whose
+    // top separator is O(n^(2/3)) or smaller, the dissection is better in arithmetic AND in tree height in every case measured
+    // (2-D / 3-D grids, Delaunay meshes, band matrices: cost ratio 1.35 .. 90), and the candidate cost 4/5 of the ordering time
+    // (46^3: 130 ms beside the dissection's 28 ms).  So the candidate is started when the first split at depth 0 shows a
+    // separator above 1.5 |part|^(2/3) -- a structural, deterministic test -- and always for small graphs.
     std::future<void> amd_future;
-    if (method == 0) {
+    bool amd_started = false, top_seen = false;
+    auto start_amd = [&]() {
+        if (amd_started) return;
+        amd_started = true;
         try {
-            amd_future = std::async(std::launch::async, run_amd);               // beside the dissection, on its own thread
+            amd_future = std::async(std::launch::async, run_amd);
         } catch (const std::system_error&) {
             run_amd();
         }
-    } else if (method == 2) run_amd();
+    };
+    static const bool amd_always = getenv("MI355KKT_ORDERING_BOTH") != nullptr;
+    if (method == 0 && (n < 2000 || amd_always)) start_amd();
+    else if (method == 2) run_amd();
     if (method != 2) {
         ond.assign(n, -1);
         std::vector<int> nodes(n);
@@ -1004,7 +1019,13 @@ void fill_reducing_ordering(const Graph& adj, std::vector<int>& order, int metho
         Dissector nd(adj, ond, leaf, amd_leaves);
         if (const char* e = getenv("MI355KKT_ND_MODE")) nd.nd_mode = atoi(e);
         nd.norefine = getenv("MI355KKT_ND_NOREFINE") != nullptr;
+        if (method == 0)
+            nd.on_top = [&](size_t sep, size_t part) {
+                top_seen = true;
+                if ((double)sep > 1.5 * std::pow((double)part, 2.0 / 3.0)) start_amd();
+            };
         nd.run(nodes, 0, 0);
+        if (method == 0 && !top_seen) start_amd();        // nothing was split (dense / tiny parts): both candidates
         lap("dissection");
         etree_and_counts(adj, ond, par_nd, cc_nd);
         cost_of(cc_nd, I.nnz_nd, I.flops_nd);
@@ -1031,12 +1052,13 @@ void fill_reducing_ordering(const Graph& adj, std::vector<int>& order, int metho
     std::vector<int> fnd, famd, p2nd, p2amd;
     std::vector<int64_t> c2nd, c2amd;
     if (method != 2) finish(ond, par_nd, cc_nd, fnd, I.levels_nd, p2nd, c2nd);
-    if (method != 1) finish(oamd, par_amd, cc_amd, famd, I.levels_amd, p2amd, c2amd);
+    const bool have_amd = method == 2 || (method == 0 && amd_started);
+    if (have_amd) finish(oamd, par_amd, cc_amd, famd, I.levels_amd, p2amd, c2amd);
     // cost model of the device engine: the arithmetic at the rate the front kernels sustain + a fixed cost per level of
     // the supernodal tree (one factor step and two solve steps are launched per level)
     auto seconds = [](double flops, int levels) { return flops / 2.0e12 + 1.5e-4 * (double)levels; };
     bool use_amd = method == 2;
-    if (method == 0) use_amd = seconds(I.flops_amd, I.levels_amd) < 0.9 * seconds(I.flops_nd, I.levels_nd);
+    if (method == 0 && have_amd) use_amd = seconds(I.flops_amd, I.levels_amd) < 0.9 * seconds(I.flops_nd, I.levels_nd);
     I.method = use_amd ? 2 : 1;
     order.swap(use_amd ? famd : fnd);
     I.parent.swap(use_amd ? p2amd : p2nd);

@@ -402,17 +402,32 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         return S.panel_off[s] + (int64_t)col * h + pos;
     };
     {
-        std::vector<std::vector<std::pair<int, int>>> rows(m);   // (column, nz index)
-        for (int j = 0; j < n; ++j)
-            for (int64_t k = gcp[j]; k < gcp[j + 1]; ++k) rows[gri[k]].push_back({j, (int)k});
+        // G by rows (CSR: column, nz index), columns ascending inside a row like the column-major input
+        const int64_t gnz = gcp[n];
+        std::vector<int64_t> rp((size_t)m + 1, 0);
+        for (int64_t k = 0; k < gnz; ++k) rp[gri[k] + 1]++;
+        for (int r = 0; r < m; ++r) rp[r + 1] += rp[r];
+        std::vector<int> rcol((size_t)gnz), rnz((size_t)gnz);
+        {
+            std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+            for (int j = 0; j < n; ++j)
+                for (int64_t k = gcp[j]; k < gcp[j + 1]; ++k) {
+                    const int64_t q = fill[gri[k]]++;
+                    rcol[q] = j;
+                    rnz[q] = (int)k;
+                }
+        }
+        size_t total = 0;
+        for (int r = 0; r < m; ++r) total += (size_t)((rp[r + 1] - rp[r]) * (rp[r + 1] - rp[r] + 1) / 2);
+        cs.reserve(total + (hcp ? (size_t)hcp[n] : 0));
         for (int r = 0; r < m; ++r)
-            for (auto& pa : rows[r])
-                for (auto& pb : rows[r]) {
-                    const int ia = S.iperm[pa.first], ib = S.iperm[pb.first];
+            for (int64_t qa = rp[r]; qa < rp[r + 1]; ++qa)
+                for (int64_t qb = rp[r]; qb < rp[r + 1]; ++qb) {
+                    const int ia = S.iperm[rcol[qa]], ib = S.iperm[rcol[qb]];
                     if (ia < ib) continue;
                     const int64_t sl = slot_of(ia, ib);
                     if (sl < 0) { set_last_error("symbolic_analyze: G'G entry outside the symbolic pattern"); return -1; }
-                    cs.push_back({sl, pa.second, pb.second, r});
+                    cs.push_back({sl, rnz[qa], rnz[qb], r});
                 }
         if (hcp)
             for (int j = 0; j < n; ++j)
@@ -426,7 +441,43 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
                     cs.push_back({sl, (int)k, -1, 0});
                 }
     }
-    std::stable_sort(cs.begin(), cs.end(), [](const Contrib& x, const Contrib& y) { return x.slot < y.slot; });
+    lap("assembly contributions");
+    {   // by target slot, ties in generation order (the summation order of sp_assemble_kernel is part of the plan): a sort
+        // of (slot, sequence number) keys -- unique, so no stable sort of the 24-byte records -- in four chunks on their own
+        // threads, merged pairwise, then one gather
+        const size_t N = cs.size();
+        std::vector<std::pair<int64_t, uint32_t>> key(N);
+        for (size_t k = 0; k < N; ++k) key[k] = {cs[k].slot, (uint32_t)k};
+        if (N >= ((size_t)1 << 32)) { set_last_error("symbolic_analyze: more than 2^32 assembly contributions"); return -1; }
+        const size_t q1 = N / 4, q2 = N / 2, q3 = N - N / 4;
+        auto srt = [&](size_t a, size_t b) { std::sort(key.begin() + a, key.begin() + b); };
+        if (N > 100000) {
+            std::future<void> f1, f2, f3;
+            try {
+                f1 = std::async(std::launch::async, srt, (size_t)0, q1);
+                f2 = std::async(std::launch::async, srt, q1, q2);
+                f3 = std::async(std::launch::async, srt, q2, q3);
+            } catch (const std::system_error&) {
+            }
+            srt(q3, N);
+            if (f1.valid()) f1.get(); else srt(0, q1);
+            if (f2.valid()) f2.get(); else srt(q1, q2);
+            if (f3.valid()) f3.get(); else srt(q2, q3);
+            std::future<void> m1;
+            try {
+                m1 = std::async(std::launch::async, [&]() { std::inplace_merge(key.begin(), key.begin() + q1, key.begin() + q2); });
+            } catch (const std::system_error&) {
+            }
+            std::inplace_merge(key.begin() + q2, key.begin() + q3, key.end());
+            if (m1.valid()) m1.get(); else std::inplace_merge(key.begin(), key.begin() + q1, key.begin() + q2);
+            std::inplace_merge(key.begin(), key.begin() + q2, key.end());
+        } else {
+            srt(0, N);
+        }
+        std::vector<Contrib> sorted(N);
+        for (size_t k = 0; k < N; ++k) sorted[k] = cs[key[k].second];
+        cs.swap(sorted);
+    }
     for (size_t k = 0; k < cs.size();) {
         size_t e = k;
         while (e < cs.size() && cs[e].slot == cs[k].slot) ++e;

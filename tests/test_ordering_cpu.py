@@ -102,8 +102,11 @@ def test_fill_is_competitive_with_superlu_minimum_degree(name):
 
 def test_choice_follows_the_cost_model():
     # regular grid: dissection (less arithmetic and the shallower tree); hubs / small-world graphs: minimum degree
+    # (the minimum-degree candidate is only computed when the first split shows a separator above 1.5 |part|^(2/3):
+    #  on the grid its statistics come from an explicit method = 2 run)
     _, st = ordering(grid(60, 60), 0)
-    assert st['method'] == 1 and st['levels_nd'] < st['levels_amd']
+    _, amd = ordering(grid(60, 60), 2)
+    assert st['method'] == 1 and st['levels_amd'] == 0 and st['levels_nd'] < amd['levels_amd']
     _, st = ordering(preferential_attachment(3000), 0)
     assert st['method'] == 2 and st['flops_amd'] < 0.7 * st['flops_nd']
     # a band matrix: minimum degree keeps the natural order, a path of n supernodes -- n dependent launches on the device;
@@ -111,7 +114,8 @@ def test_choice_follows_the_cost_model():
     n = 4000
     B = sp.diags([np.ones(n - 2), np.ones(n - 1), 4 * np.ones(n), np.ones(n - 1), np.ones(n - 2)], [-2, -1, 0, 1, 2]).tocsc()
     _, st = ordering(B, 0)
-    assert st['levels_amd'] > 500 and st['levels_nd'] < 40 and st['method'] == 1
+    _, amd = ordering(B, 2)
+    assert amd['levels_amd'] > 500 and st['levels_nd'] < 40 and st['method'] == 1
 
 
 def test_dissection_beats_natural_and_bfs_orderings_on_an_unstructured_mesh(monkeypatch):
@@ -162,8 +166,22 @@ def test_multilevel_dissection_on_a_tetrahedral_mesh(monkeypatch):
     factorisation work well below both minimum degree and the plain level-set dissection"""
     S = delaunay3d(8000, seed=1)
     _, st = ordering(S, 0)
+    _, amd = ordering(S, 2)
     assert st['method'] == 1
-    assert st['flops_nd'] < 0.6 * st['flops_amd'] and st['nnz_nd'] < 0.85 * st['nnz_amd']
+    assert st['flops_nd'] < 0.6 * amd['flops_amd'] and st['nnz_nd'] < 0.85 * amd['nnz_amd']
     monkeypatch.setenv('MI355KKT_ND_MODE', '1')
     _, levelset = ordering(S, 1)
     assert st['flops_nd'] < 0.5 * levelset['flops_nd']
+
+
+def test_minimum_degree_candidate_runs_only_without_small_separators(monkeypatch):
+    """structural, deterministic rule of fill_reducing_ordering: mesh-like graphs (top separator <= 1.5 |part|^(2/3)) skip the
+    minimum-degree candidate -- 4/5 of the ordering time at 46^3 -- and keep the choice they had with both candidates;
+    graphs without small separators still get both; $MI355KKT_ORDERING_BOTH restores the two-candidate run"""
+    from cvxopt_amd import synth
+    for S in (grid(80, 80), synth.grid_laplacian(14), delaunay(5000, seed=2)):
+        _, st = ordering(S, 0)
+        assert st['method'] == 1 and st['nnz_amd'] == 0
+    for S in (random_graph(4000, 2, seed=3), preferential_attachment(3000, seed=1)):
+        _, st = ordering(S, 0)
+        assert st['nnz_amd'] > 0 and st['nnz_nd'] > 0
