@@ -362,9 +362,12 @@ __device__ __forceinline__ int potf2_panel16(double (&a)[16], double (&b)[16], d
 // already sits at the start of `smem` (the persistent tile kernel dumps its accumulators there); otherwise it is read
 // from A.  L goes to A (lower triangle only), the inverses of the 16x16 diagonal blocks to linv_out (may be null).
 // Returns 0 or the 1-based column of the first non-positive pivot (uniform over the workgroup).  All P2T threads call it.
+// half_word (tile kernel, full 128 x 128 blocks only): as soon as columns 0..63 of L and the inverses of the diagonal blocks
+// 0..3 are in global memory, *half_word = 1 is published (agent scope) -- the triangular solve of the tile below starts on
+// its first four column blocks while this block's second half is still being factored.
 template <bool FROM_LDS>
 __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda, int nb, double* __restrict__ linv_out,
-                                             double* __restrict__ smem, long long* ts) {
+                                             double* __restrict__ smem, long long* ts, unsigned* half_word = nullptr) {
     double* As = smem;                           // NB x PLD, column-major
     double* dinv = smem + NB * PLD;              // 128 reciprocal pivots
     double* dummy = dinv + NB;                   // 80 doubles: sink of the non-leader lanes' reciprocal-pivot stores
@@ -374,6 +377,7 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int lane = tid & 63;
     const int nt = (nb + 15) >> 4;
+    const bool halfp = half_word != nullptr && nb == NB && linv_out != nullptr;
     P2_TS(0);
     if (tid == 0) *flag = 0;
     double a[16], b[16];
@@ -439,6 +443,24 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
                     if (e < 16 * NB && r >= c && r < nb && c < nb) A[r + (int64_t)c * lda] = As[c * PLD + r];
                 }
             }
+            if (halfp && wave == 7 && pjb < 64) {
+                // inverse of the 16 x 16 diagonal block of micro panel pjb (final since the last barrier), column-oriented
+                // substitution as at the end of this function; the look-ahead waves have slack behind the panel wave
+                const int j = lane & 15;
+                double x[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) x[i] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    x[k] *= dinv[pjb + k];
+#pragma unroll
+                    for (int i = k + 1; i < 16; ++i) x[i] = fma(-As[(pjb + k) * PLD + pjb + i], x[k], x[i]);
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) linv_out[(pjb >> 4) * 256 + j * 16 + i] = (i >= j) ? x[i] : 0.0;
+                }
+            }
             const int ntr = nt - t1;
             const int ntiles = ntr > 0 ? ntr * (ntr + 1) / 2 : 0;
             for (int t = wave - 1; t < ntiles; t += 7) {
@@ -451,9 +473,15 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
             }
         }
         P2_TS(4 + (jb >> 4) * 5);
+        if (halfp && jb == 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // columns 0..63 + inverses 0..3: stores drained
         __syncthreads();                         // micro panel jb is in LDS; update jb-16 is complete
         P2_TS(5 + (jb >> 4) * 5);
         if (*flag) break;
+        if (halfp && jb == 64 && tid == P2T - 64) {          // wave 7 has no tile of the next column block: off the chain
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(half_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (jb + 16 >= nb) break;
         {   // column block jb/16 + 1 (the next micro panel): one tile per wave
             const int t0 = jb / 16 + 1;
@@ -474,7 +502,7 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
         }
     }
     // inverses of the 16x16 diagonal blocks (trsm_panel_kernel): wave w <-> block w, lane j <-> column j of inv(L_d)
-    if (linv_out && wave < nt) {
+    if (linv_out && wave < nt && !(halfp && wave < 4)) {      // (blocks 0..3 were done on the way when half_word is set)
         const int jb = wave * 16, pw = min(16, nb - jb);
         const int j = lane & 15;
         double x[16];
@@ -626,6 +654,7 @@ __device__ long long* g_tile_ts = nullptr;    // developer aid: 8 stamps per til
 struct TileCtl {
     unsigned ticket, abort_flag, pad0, pad1;
     unsigned prog[252];          // up to 252 block rows (n <= 32256); zeroed before every launch
+    unsigned half[252];          // dense factorisation: 1 once columns 0..63 of L(j,j) and their inverses are published
 };
 #define RLX_AGENT_ __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
@@ -842,6 +871,7 @@ struct TileJob {
     int nk;                  // number of factored tile columns left of the tile to accumulate over
     int q, w;                // k-tile boundaries: column 128 kt for kt <= q, w beyond (fronts: ragged last factored tile)
     bool factored;           // true: the tile belongs to the factored columns (potf2 / trsm + publish); false: Schur part, store
+    unsigned* half_j;        // dense only: half word of the diagonal tile of column j (nullptr: not used)
     unsigned* prog_i;        // progress word of the tile's block row (published to when factored)
     unsigned* prog_j;        // progress word of block row j (the tile's column index); == prog_i on diagonal tiles
     unsigned pub;            // value published / waited for once column j is final: j + 1
@@ -919,7 +949,7 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
         for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) As[(tt * 16 + lq + 4 * r) * PLD + row] = acc[tt][r];
-        const int failed = potf2_la_body<true>(A + j0 + (int64_t)j0 * lda, lda, mj, J.linv, smem, nullptr);
+        const int failed = potf2_la_body<true>(A + j0 + (int64_t)j0 * lda, lda, mj, J.linv, smem, nullptr, VB ? nullptr : J.half_j);
         if (failed) {
             if (tid == 0) atomicCAS(J.info, 0, J.info_base + failed);
             if (J.abort_on_fail) {
@@ -938,18 +968,21 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
         }
         return true;
     }
-    if (tid == 0) ctlw[1] = tile_wait(J.prog_j, nullptr, J.pub, ctl, err);
+    // halfmode (dense, full tiles): the diagonal tile publishes its columns 0..63 (+ the inverses of the diagonal blocks
+    // 0..3) while its second half is still being factored; the first four column blocks of this solve need nothing else
+    const bool halfmode = !VB && J.half_j != nullptr && mj == NB;
+    if (tid == 0) ctlw[1] = halfmode ? tile_wait(J.half_j, nullptr, 1u, ctl, err) : tile_wait(J.prog_j, nullptr, J.pub, ctl, err);
     __syncthreads();
     if (ctlw[1] == 0xffffffffu) return false;
     PT_TS(2);
     // ---- L(j,j) (tiles on / below the diagonal) and the inverses of its 16 x 16 diagonal blocks -> LDS, once for
     //      the eight waves: one coalesced sweep instead of strided global loads in front of every MFMA group.  The
     //      inverses ride in the 16 padding rows of the image: element (block cb, column k, row g) at As[(16cb+k) PLD + 128 + g].
-    {
+    //      Pass 0 = columns 0..63 (all rows) and the inverses 0..3, pass 1 = columns 64..127 and the inverses 4..7.
+    auto stage = [&](int half) {
         const double* __restrict__ Lg = A + j0 + (int64_t)j0 * lda;
         const double* __restrict__ linv = J.linv;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {        // two passes: 18 values in flight per thread (register budget)
+        {                                             // 18 values in flight per thread (register budget)
             double v[18];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -970,12 +1003,21 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
                 As[(e >> 4) * PLD + NB + (e & 15)] = v[16 + q];
             }
         }
-    }
+    };
+    stage(0);
+    if (!halfmode) stage(1);
     __syncthreads();
     // ---- X L(j,j)' = B on the accumulators (transposed tiles, diagonal blocks by inverse + one refinement step,
     //      as trsm_panel_kernel), operands from LDS
 #pragma unroll
     for (int cb = 0; cb < 8; ++cb) {
+        if (cb == 4 && halfmode) {                    // the second half of L(j,j): wait for the tile's final publish
+            if (tid == 0) ctlw[1] = tile_wait(J.prog_j, nullptr, J.pub, ctl, err);
+            __syncthreads();
+            if (ctlw[1] == 0xffffffffu) return false;
+            stage(1);
+            __syncthreads();
+        }
         d4 a4 = acc[cb], a5 = d4{0.0, 0.0, 0.0, 0.0};     // two chains: the matrix pipe is not left waiting on one accumulator
 #pragma unroll
         for (int c = 0; c < cb; ++c) {
@@ -1030,7 +1072,8 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
 
 __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int n, TileCtl* ctl,
                                                                  double* __restrict__ linv_all, int* __restrict__ info,
-                                                                 int* __restrict__ err, double* __restrict__ minv_all) {
+                                                                 int* __restrict__ err, double* __restrict__ minv_all,
+                                                                 int use_half) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // the control words of the workgroup live behind the potf2 image (all LDS in the dynamic region, guide G17)
     unsigned* ctlw = reinterpret_cast<unsigned*>(smem + NB * PLD + NB + 80 + 2);
@@ -1060,6 +1103,7 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
         J.nk = j; J.q = 0x3fffffff; J.w = 0;
         J.factored = true;
         J.prog_i = &ctl->prog[i]; J.prog_j = &ctl->prog[j];
+        J.half_j = use_half ? &ctl->half[j] : nullptr;
         J.pub = (unsigned)j + 1;
         J.linv = linv_all + (int64_t)j * 2048;
         J.minv = minv_all ? minv_all + (int64_t)j * 2 * NB * NB : nullptr;
@@ -1112,6 +1156,7 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_vb_kernel(double* __re
         J.nk = J.factored ? tk.j : ntf;
         J.q = q; J.w = dd.w;
         J.prog_i = fprog + tk.i; J.prog_j = fprog + tk.j;
+        J.half_j = nullptr;
         J.pub = (unsigned)tk.j + 1;
         J.linv = linv_all + (int64_t)(linv_off[tk.front] + (J.factored ? tk.j : 0)) * 2048;
         J.minv = nullptr;
@@ -1252,8 +1297,9 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
     const int ntiles = NT * (NT + 1) / 2;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
     static const bool no_minv = getenv("MI355KKT_NO_MINV") != nullptr;
+    static const int use_half = getenv("MI355KKT_POTRF_HALF") ? atoi(getenv("MI355KKT_POTRF_HALF")) : 1;
     hipLaunchKernelGGL(potrf_tiles_kernel, dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n, reinterpret_cast<TileCtl*>(w.d_ctl),
-                       w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv);
+                       w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
     KKT_HIP_CHECK(hipGetLastError());
     w.minv_n = no_minv ? 0 : n;          // the 128 x 128 inverses of this factor's diagonal blocks are valid
     w.minv_of = A;
