@@ -191,7 +191,8 @@ struct ParWave {
     __device__ __forceinline__ int tid() const { return threadIdx.x & 63; }
     __device__ __forceinline__ int nt() const { return 64; }
     __device__ __forceinline__ void sync() const {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        // workgroup scope: what __syncthreads() gives the workgroup team (the lanes of a wave share the compute unit's L1)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
     __device__ __forceinline__ double sum(double v) const {
