@@ -452,8 +452,9 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
     // 256 threads: two per row (forward) / column (backward) of the block row; each holds one 64-wide half of the strip
     // of every off-diagonal block in registers BEFORE waiting for that block's x, so that nothing but 64 FMAs, one
     // partial-sum exchange and the diagonal solve sits between "x_j published" and "x_k published".
-    __shared__ double xs[TB];
-    __shared__ double ps[TB];
+    // xs / ps are double buffered: consecutive stages alternate, so no barrier is needed just to make a buffer writable again
+    __shared__ double xs2[2][TB];
+    __shared__ double ps2[2][TB];
     __shared__ int ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = tid >> 7, r = tid & (TB - 1);
@@ -509,6 +510,7 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
         const int j = TRANS ? (nblk - 1 - s) : s;      // block whose solution we consume
         const int j0 = j * TB;
         const int jb = min(TB, n - j0);
+        double* xs = xs2[s & 1];
         // prefetch my half of my strip of block (k,j) before waiting
         double l0[64];
         const int ch = 64 * half;
@@ -543,10 +545,24 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
             if (tid < TB) xs[tid] = (tid < jb) ? x[j0 + tid] : 0.0;
             __syncthreads();
         }
+        {   // four independent chains of 16 instead of one of 64 dependent FMAs (this sits on the hop's critical path)
+            double a0 = acc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-        for (int c = 0; c < 64; ++c) acc = fma(-l0[c], xs[ch + c], acc);
-        __syncthreads();                               // xs is reused by the next step
+            for (int c = 0; c < 64; c += 4) {
+                a0 = fma(-l0[c], xs[ch + c], a0);
+                a1 = fma(-l0[c + 1], xs[ch + c + 1], a1);
+                a2 = fma(-l0[c + 2], xs[ch + c + 2], a2);
+                a3 = fma(-l0[c + 3], xs[ch + c + 3], a3);
+            }
+            acc = (a0 + a1) + (a2 + a3);
+        }
+        if (!GRAN) __syncthreads();                    // (flag path: xs is filled before the barrier of the next step)
     }
+    // the buffer NOT read by the last step: free to write at once
+    double* xs = xs2[nsteps & 1];
+    double* xo = xs2[(nsteps & 1) ^ 1];
+    double* ps = ps2[0];
+    double* po = ps2[1];
     // ---- combine the two partial sums of every row / column
     if (half == 1) ps[r] = acc;
     __syncthreads();
@@ -555,36 +571,39 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
     const double dinv = 1.0 / dg;
     if (INV) {
         const int ch2 = 64 * half;
+        // 64-term dot product of my register strip with one half of an LDS vector, as four independent chains
+        auto dot64 = [&](const double (&a)[64], const double* v) {
+            double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+            for (int c = 0; c < 64; c += 4) {
+                d0 = fma(a[c], v[ch2 + c], d0);
+                d1 = fma(a[c + 1], v[ch2 + c + 1], d1);
+                d2 = fma(a[c + 2], v[ch2 + c + 2], d2);
+                d3 = fma(a[c + 3], v[ch2 + c + 3], d3);
+            }
+            return (d0 + d1) + (d2 + d3);
+        };
         // x0 = M b
-        __syncthreads();
         if (half == 0) xs[r] = acc;                      // b (rows beyond nb carry zeros)
         __syncthreads();
-        double p0 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 64; ++c) p0 = fma(ra[c], xs[ch2 + c], p0);
-        if (half == 1) ps[r] = p0;
+        const double p0 = dot64(ra, xs);
+        if (half == 1) po[r] = p0;
         __syncthreads();
-        const double x0 = p0 + ps[r];                    // (meaningful in half 0)
+        const double x0 = p0 + po[r];                    // (meaningful in half 0)
         // e = b - L x0
+        if (half == 0) xo[r] = x0;
         __syncthreads();
-        if (half == 0) xs[r] = x0;
-        __syncthreads();
-        double q0 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 64; ++c) q0 = fma(rb[c], xs[ch2 + c], q0);
+        const double q0 = dot64(rb, xo);
         if (half == 1) ps[r] = q0;
         __syncthreads();
         const double e = acc - (q0 + ps[r]);
         // x = x0 + M e
-        __syncthreads();
         if (half == 0) xs[r] = e;
         __syncthreads();
-        double p1 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 64; ++c) p1 = fma(ra[c], xs[ch2 + c], p1);
-        if (half == 1) ps[r] = p1;
+        const double p1 = dot64(ra, xs);
+        if (half == 1) po[r] = p1;
         __syncthreads();
-        acc = x0 + (p1 + ps[r]);
+        acc = x0 + (p1 + po[r]);
     } else if (!TRANS) {
         if (wave == 0) {
 #pragma unroll
