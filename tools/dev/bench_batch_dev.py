@@ -1,7 +1,7 @@
 """Developer probe: batched config-5 timing on one GPU (B problems of n=512, m=1024)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cvxopt_amd import synth
 from cvxopt_amd.batch import BatchKkt, coneqp_batch, pack_problems
 

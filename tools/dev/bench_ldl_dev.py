@@ -2,8 +2,8 @@
 behind the same factory name, at a size where the (n+m)^2 KKT matrix fits comfortably (n=512, m=1024)."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
 from cvxopt_amd import kkt, synth
 n, m = 512, 1024
 pr = synth.dense_qp(n, m, seed=0)

@@ -2,7 +2,7 @@
 import ctypes as C, sys, time
 import numpy as np
 import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cvxopt_amd import _capi, kkt, synth
 
 def main(n, m, reps=3):

@@ -1,7 +1,7 @@
 """Developer probe: dense potrf timing only (n = 8192 by default), for A/B runs of env-selected variants."""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cvxopt_amd import _capi
 L = _capi.lib()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192

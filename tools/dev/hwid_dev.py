@@ -1,7 +1,7 @@
 """Developer probe: where do workgroups land?  HW_ID fields (gfx9: CU_ID [11:8], SH_ID [12], SE_ID [15:13]) and XCC_ID."""
 import os, sys, collections
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cvxopt_amd import _capi
 L = _capi.lib()
 n = 4096

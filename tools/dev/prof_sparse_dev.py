@@ -2,8 +2,8 @@
 import os, sys, time
 import numpy as np
 import scipy.sparse as sp
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cvxopt_amd import kkt, synth
 from test_gpu_sparse import FakeSp, laplace2d, laplace3d, box
 

@@ -1,7 +1,7 @@
 """Developer probe: per-tile timeline of the persistent tile Cholesky (shader-clock stamps)."""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cvxopt_amd import _capi
 L = _capi.lib()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024

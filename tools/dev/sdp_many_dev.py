@@ -1,6 +1,6 @@
 """Developer probe: cone LPs over nb 's' blocks of order mk through the device loop; residual of the returned point."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import cvxopt_amd
 

@@ -1,6 +1,6 @@
 """Developer probe: every 's'-block operation on the device with the workgroup team and the wave team against the host twin."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from cvxopt_amd import _capi
 L = _capi.lib()

@@ -1,7 +1,7 @@
 """Developer probe: wall time of the device-resident conelp loop on max-cut relaxations min 1'x s.t. w + diag(x) >= 0."""
 import sys, time, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import cvxopt_amd
 
 

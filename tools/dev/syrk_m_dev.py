@@ -1,7 +1,7 @@
 """Developer probe: scaled SYRK rate vs the contraction length m (operand footprint vs the 256 MB Infinity Cache)."""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cvxopt_amd import _capi
 L = _capi.lib()
 n = 8192

@@ -1,7 +1,7 @@
 """Developer probe: static wave-priority modes of the scaled SYRK main loop (g_syrk_skip bits 4..5)."""
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cvxopt_amd import _capi
 L = _capi.lib()
 n, m = 8192, 16384

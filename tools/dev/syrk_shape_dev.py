@@ -1,6 +1,6 @@
 import ctypes as C, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from cvxopt_amd import _capi
 L = _capi.lib()
 for n, m in [(2048, 65536), (1024, 131072), (4096, 32768), (8192, 16384), (8192, 4096)]:

@@ -6,11 +6,11 @@ mkdir -p $O
 ( timeout 600 python -m pytest tests/test_gpu_ops.py -x -q -m gpu 2>&1 | tail -15 ) > $O/r2a_ops.log 2>&1
 {
 for v in "old 2" "new 2" "new 3"; do set -- $v
-  MI355KKT_POTF2=$1 MI355KKT_POTRF_STREAMS=$2 timeout 300 python tests/bench_potrf_dev.py 8192
+  MI355KKT_POTF2=$1 MI355KKT_POTRF_STREAMS=$2 timeout 300 python tools/dev/bench_potrf_dev.py 8192
 done
 for n in 4096 2048 1024; do
-  MI355KKT_POTF2=old timeout 300 python tests/bench_potrf_dev.py $n
-  MI355KKT_POTF2=new timeout 300 python tests/bench_potrf_dev.py $n
+  MI355KKT_POTF2=old timeout 300 python tools/dev/bench_potrf_dev.py $n
+  MI355KKT_POTF2=new timeout 300 python tools/dev/bench_potrf_dev.py $n
 done
 } > $O/r2a_potrf.log 2>&1
 timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/r2a_bench_new.json 2> $O/r2a_bench_new.err

@@ -2,9 +2,9 @@
 export PYTHONPATH=.
 O=gpurun_out
 ( MI355KKT_TILES_MIN_N=1 timeout 300 python -m pytest tests/test_gpu_ops.py -x -q -m gpu -k potrf 2>&1 | tail -3 ) > $O/r2l.log 2>&1
-for n in 8192 4096 2048 1024 512 256; do MI355KKT_TILES_MIN_N=1 timeout 120 python tests/bench_potrf_dev.py $n 2>&1 | tail -1 >> $O/r2l.log; done
-for n in 512 256; do MI355KKT_POTRF=streams timeout 120 python tests/bench_potrf_dev.py $n 2>&1 | tail -1 >> $O/r2l.log; done
-MI355KKT_TILES_MIN_N=1 timeout 120 python tests/prof_tiles_dev.py 2048 2>&1 | tail -8 >> $O/r2l.log
+for n in 8192 4096 2048 1024 512 256; do MI355KKT_TILES_MIN_N=1 timeout 120 python tools/dev/bench_potrf_dev.py $n 2>&1 | tail -1 >> $O/r2l.log; done
+for n in 512 256; do MI355KKT_POTRF=streams timeout 120 python tools/dev/bench_potrf_dev.py $n 2>&1 | tail -1 >> $O/r2l.log; done
+MI355KKT_TILES_MIN_N=1 timeout 120 python tools/dev/prof_tiles_dev.py 2048 2>&1 | tail -8 >> $O/r2l.log
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # step timeline + kernel stats of the headline workload
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_r02_dense -o r02 -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > $O/r2l_prof_dense.log 2>&1
