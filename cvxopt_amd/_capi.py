@@ -86,6 +86,8 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_int_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, c_int_p]),
     "mi355kkt_batch_create_eq": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mi355kkt_batch_create_cones": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int]),
+    "mi355kkt_batch_factor_cones": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_int_p]),
     "mi355kkt_batch_set_A": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "mi355kkt_batch_solve_eq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "mi355kkt_batch_coneqp_eq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,

@@ -1,6 +1,7 @@
-"""Batched mode: many independent dense LP-cone QPs of one shape (BASELINE configs[4]).
+"""Batched mode: many independent dense cone QPs of one shape (BASELINE configs[4]: the LP cone).
 
-    min 1/2 x'P_b x + q_b'x   s.t.  G_b x <= h_b            b = 0 .. B-1,  no equalities
+    min 1/2 x'P_b x + q_b'x   s.t.  G_b x <= h_b  [A_b x = b_b]          b = 0 .. B-1
+    ('<=' in the cone of dims = {'l': .., 'q': [..]}; `BatchKkt(..., At=, dims=)`; the NumPy twin below is LP-cone only)
 
 There is no reference API for a batch; parity is per problem against individual
 `solvers.coneqp` calls.  The KKT work (the hot path: S_b = P_b + G_b'D_b^2 G_b, Cholesky, two solves per
@@ -28,9 +29,11 @@ from . import _capi
 # ---------------------------------------------------------------------------------------------------
 class BatchKkt(object):
     """B independent kkt_chol2-style solvers (LP cone; optionally p equality constraints per problem, At: (B, n, p) = the
-    p x n blocks A_b column-major) behind the batched C ABI."""
+    p x n blocks A_b column-major) behind the batched C ABI.  dims = {'l': nl, 'q': [...]} (the same for every problem) adds
+    second-order cones: Gt is then (B, n, cdim), cdim = nl + sum(q), and the engine works like the reference's kkt_chol
+    per problem (Gs_b = W_b^-T G_b materialised)."""
 
-    def __init__(self, Gt, P=None, device=0, At=None):
+    def __init__(self, Gt, P=None, device=0, At=None, dims=None):
         self.L = _capi.lib()
         if _capi.device_count() <= 0:
             raise RuntimeError("cvxopt_amd.batch: no HIP device visible (there is no CPU fallback)")
@@ -47,7 +50,19 @@ class BatchKkt(object):
             gptr = Gt.ctypes.data
         h = C.c_void_p()
         self.p = 0 if At is None else int(At.shape[2])
-        _capi.check(self.L.mi355kkt_batch_create_eq(C.byref(h), device, self.B, self.n, self.m, self.p), "batch_create")
+        self.q = [int(k) for k in (dims or {}).get('q', [])]
+        self.nl = int(dims['l']) if dims is not None else self.m
+        if dims is not None:
+            if dims.get('s'):
+                raise NotImplementedError("batched mode: 's' blocks are not supported")
+            if self.nl + sum(self.q) != self.m:
+                raise TypeError("Gt must have shape (B, n, %d) for these dims" % (self.nl + sum(self.q)))
+        if self.q:
+            qa = (C.c_int * len(self.q))(*self.q)
+            _capi.check(self.L.mi355kkt_batch_create_cones(C.byref(h), device, self.B, self.n, self.nl, len(self.q), qa, self.p),
+                        "batch_create_cones")
+        else:
+            _capi.check(self.L.mi355kkt_batch_create_eq(C.byref(h), device, self.B, self.n, self.m, self.p), "batch_create")
         self.h = h
         Pp = None
         if P is not None:
@@ -82,6 +97,20 @@ class BatchKkt(object):
         info = np.zeros(self.B, dtype=np.int32)
         _capi.check(self.L.mi355kkt_batch_factor(self.h, di.ctypes.data, 0, info.ctypes.data_as(_capi.c_int_p)),
                     "batch_factor")
+        return info
+
+    def factor_cones(self, di, v, beta):
+        """Batches with second-order cones: di (B, nl) = W['di'], v (B, sum(q)) = the cones' W['v'][k] back to back, beta (B, nq)
+        = W['beta'] of every problem."""
+        B, m = self.B, self.m
+        dfull = np.zeros((B, m))
+        if self.nl:
+            dfull[:, :self.nl] = np.asarray(di, dtype=np.float64).reshape(B, self.nl)
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(B, sum(self.q))
+        beta = np.ascontiguousarray(beta, dtype=np.float64).reshape(B, len(self.q))
+        info = np.zeros(B, dtype=np.int32)
+        _capi.check(self.L.mi355kkt_batch_factor_cones(self.h, dfull.ctypes.data, v.ctypes.data, beta.ctypes.data, 0,
+                                                       info.ctypes.data_as(_capi.c_int_p)), "batch_factor_cones")
         return info
 
     def solve(self, x, z, y=None):

@@ -9,6 +9,7 @@
 //           x = L^-T (x - Asct y);  z = Gs x - zs
 // G and A stay resident in HBM; per factor() only W (O(cdim) doubles) crosses PCIe, per solve() only
 // x, y, z.
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
@@ -236,23 +237,25 @@ static void qp_free(QpWork& w) {
     if (w.pinned) (void)hipHostFree(w.pinned);
     w = QpWork();
 }
-static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, const std::vector<int>& sd, int np) {
+static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, const std::vector<int>& sd, int np, int nbatch = 1) {
     if (w.f64) return 0;
     int sumq = 0;
     for (int k : q) sumq += k;
     const SBlocks sb(sd);
     const int m = ml + sumq + sb.sums2, nq = (int)q.size();
     const size_t N = n ? n : 1, M = m ? m : 1, Pq = np ? np : 1;
-    const size_t nd = 10 * N + 8 * Pq + 21 * M + (size_t)sumq + nq + QP_NSC + 8 + sb.doubles();
+    const size_t B = nbatch > 1 ? nbatch : 1;          // batched mode: every per-problem array holds B slices (QpState::nbatch)
+    if (B > 1 && sb.ns > 0) return MI355KKT_ENOTIMPL;
+    const size_t nd = B * (10 * N + 8 * Pq + 21 * M + (size_t)(sumq ? sumq : 1) + (nq ? nq : 1) + QP_NSC) + 8 + sb.doubles();
     // all or nothing: a partially allocated state must not look complete to the next call
     if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
-    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq + 3 * (size_t)sb.ns)) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
+    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq + 3 * (size_t)sb.ns + 4 * B)) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
     if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
     QpState& S = w.S;
-    S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq;
+    S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq; S.nbatch = (int)B;
     double* p = w.f64;
     if (int e = sblocks_bind(S, sb, sd, ml + sumq, p, w.i32 + 8 + 2 * nq)) { qp_free(w); return e; }
-    auto take = [&](size_t k) { double* r = p; p += k; return r; };
+    auto take = [&](size_t k) { double* r = p; p += B * k; return r; };
     S.q = take(N); S.x = take(N); S.dx = take(N); S.rx = take(N); S.Px = take(N); S.GTz = take(N); S.ATy = take(N); S.x_out = take(N);
     S.wx = take(N); S.wx2 = take(N);
     S.b = take(Pq); S.y = take(Pq); S.dy = take(Pq); S.ry = take(Pq); S.Ax = take(Pq); S.y_out = take(Pq); S.wy = take(Pq);
@@ -264,6 +267,10 @@ static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, const s
     S.sc = take(QP_NSC);
     int* qi = w.i32;
     S.active = qi; S.status = qi + 1; S.iters = qi + 2; S.nactive = qi + 3;
+    if (B > 1) {          // active | status | iters | info, B words each, behind the cone descriptors
+        int* bi = qi + 8 + 2 * (size_t)nq + 3 * (size_t)sb.ns;
+        S.active = bi; S.status = bi + B; S.iters = bi + 2 * B;
+    }
     if (nq) {
         std::vector<int> hq(2 * (size_t)nq);
         int off = ml;
@@ -1212,6 +1219,15 @@ struct mi355kkt_batch {
     float t_factor = 0;
     bool defer_sync = false;          // set by the device-resident loop: the public calls then only enqueue
     IpmWork ipm;                      // allocated on the first mi355kkt_batch_coneqp call
+    // second-order cones (mi355kkt_batch_create_cones): dims = {'l': nl, 'q': q} for every problem; `ml` above is then the
+    // number of ROWS of G (cdim = nl + sum(q)), which is all the LP-cone code paths need to know.  Gs_b = W_b^-T G_b is
+    // materialised (the cone transform is not diagonal), like the single-problem engine does.
+    int nl = 0, sumq = 0;
+    std::vector<int> q;
+    int *d_qoff = nullptr, *d_qdim = nullptr;
+    double *dGs = nullptr, *dV = nullptr, *dBeta = nullptr;
+    bool w_set = false;               // v, beta of the current factorisation are in dV, dBeta
+    QpWork qp;                        // state of the device-resident loop with cones (coneqp_ipm.hip, one workgroup per problem)
 };
 
 extern "C" {
@@ -1225,7 +1241,7 @@ int mi355kkt_batch_create_eq(mi355kkt_batch** out, int device, int nbatch, int n
     if (!out || nbatch < 1 || n < 1 || ml < 0 || p < 0 || p > n) { set_last_error("batch_create: invalid argument"); return MI355KKT_EINVAL; }
     if (mi355kkt_device_count() <= device) { set_last_error("batch_create: HIP device %d not available", device); return MI355KKT_EHIP; }
     mi355kkt_batch* b = new mi355kkt_batch();
-    b->device = device; b->nbatch = nbatch; b->n = n; b->ml = ml; b->p = p;
+    b->device = device; b->nbatch = nbatch; b->n = n; b->ml = ml; b->nl = ml; b->p = p;
     auto fail = [&](int code) { mi355kkt_batch_destroy(b); return code; };
     if (hipSetDevice(device) != hipSuccess) return fail(MI355KKT_EHIP);
     hipDeviceProp_t prop;
@@ -1263,10 +1279,42 @@ int mi355kkt_batch_create_eq(mi355kkt_batch** out, int device, int nbatch, int n
     return 0;
 }
 
+/* The same for problems with dims = {'l': nl, 'q': q[0..nq)}: G_b is cdim x n, cdim = nl + sum(q) (see include/mi355kkt.h). */
+int mi355kkt_batch_create_cones(mi355kkt_batch** out, int device, int nbatch, int n, int nl, int nq, const int* q, int p) {
+    if (!out || nl < 0 || nq < 0 || (nq > 0 && !q)) { set_last_error("batch_create_cones: invalid argument"); return MI355KKT_EINVAL; }
+    int64_t cdim = nl;
+    for (int k = 0; k < nq; ++k) {
+        if (q[k] < 1) { set_last_error("batch_create_cones: cone dimensions must be positive"); return MI355KKT_EINVAL; }
+        cdim += q[k];
+    }
+    if (cdim > INT_MAX) { set_last_error("batch_create_cones: too many cone rows"); return MI355KKT_EINVAL; }
+    if (int e = mi355kkt_batch_create_eq(out, device, nbatch, n, (int)cdim, p)) return e;
+    mi355kkt_batch* b = *out;
+    b->nl = nl;
+    if (nq == 0) return 0;
+    auto fail = [&](int code) { mi355kkt_batch_destroy(b); *out = nullptr; return code; };
+    b->q.assign(q, q + nq);
+    b->sumq = (int)(cdim - nl);
+    std::vector<int> hq(2 * (size_t)nq);
+    int off = nl;
+    for (int k = 0; k < nq; ++k) { hq[k] = off; hq[nq + k] = q[k]; off += q[k]; }
+    if (hipMalloc(&b->d_qoff, sizeof(int) * 2 * (size_t)nq) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    b->d_qdim = b->d_qoff + nq;
+    if (hipMemcpy(b->d_qoff, hq.data(), sizeof(int) * hq.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355KKT_EHIP);
+    const size_t B = nbatch;
+    if (hipMalloc(&b->dGs, sizeof(double) * B * (size_t)cdim * n) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    if (hipMalloc(&b->dV, sizeof(double) * B * b->sumq) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    if (hipMalloc(&b->dBeta, sizeof(double) * B * nq) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    return 0;
+}
+
 void mi355kkt_batch_destroy(mi355kkt_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->st) (void)hipStreamSynchronize(b->st);
+    if (b->d_qoff) (void)hipFree(b->d_qoff);
+    { double* cb[] = {b->dGs, b->dV, b->dBeta}; for (double* p : cb) if (p) (void)hipFree(p); }
+    qp_free(b->qp);
     double* bufs[] = {b->dG, b->dH, b->dS, b->dW, b->dx, b->dz, b->dzs, b->dwork, b->dt1, b->dt2, b->dA, b->dAsct, b->dK, b->dy, b->dtp};
     for (double* p : bufs) if (p) (void)hipFree(p);
     ipm_free(b->ipm);
@@ -1374,7 +1422,17 @@ int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, in
         KKT_HIP_CHECK(hipMemcpyAsync(b->dW, di, sizeof(double) * B * M, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, b->st));
     BatchStrides bs;
     bs.a = (int64_t)(M * N); bs.b = (int64_t)M; bs.c = (int64_t)(N * N); bs.d = (int64_t)(N * N);
-    if (int e = launch_syrk_scaled(b->plan, b->dG, M ? (int64_t)M : 1, M ? b->dW : nullptr, b->dS, (int64_t)N,
+    const double* Gk = b->dG;
+    const double* wk = M ? b->dW : nullptr;
+    if (!b->q.empty()) {              // second-order cones: Gs_b = W_b^-T G_b (misc.py:1271), then the plain SYRK
+        if (!b->w_set) { set_last_error("batch_factor: the batch has second-order cones, use mi355kkt_batch_factor_cones"); return MI355KKT_EINVAL; }
+        if (int e = launch_batch_cone_scale(b->dG, (int64_t)M, (int64_t)(M * N), b->dGs, (int64_t)M, (int64_t)(M * N), b->n, b->nbatch,
+                                            b->ml, b->nl, (int)b->q.size(), b->sumq, b->d_qoff, b->d_qdim, b->dW, b->dV, b->dBeta, b->st))
+            return e;
+        Gk = b->dGs;
+        wk = nullptr;
+    }
+    if (int e = launch_syrk_scaled(b->plan, Gk, M ? (int64_t)M : 1, wk, b->dS, (int64_t)N,
                                    b->hasH ? b->dH : nullptr, (int64_t)N, b->st, nullptr, b->nbatch, bs))
         return e;
     if (b->singular && b->p > 0) {      // S + A'A mode (misc.py:1433-1447), decided at the first factorisation
@@ -1422,6 +1480,25 @@ int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, in
     return 0;
 }
 
+/* Factorisation for a batch with second-order cones: di [nbatch][cdim] (the first nl entries of every slice: 1 / d of the 'l'
+ * block), v [nbatch][sum(q)] (the cones' v_k back to back), beta [nbatch][nq] — the W of misc.py:307-354 per problem. */
+int mi355kkt_batch_factor_cones(mi355kkt_batch* b, const double* di, const double* v, const double* beta, int is_device, int* info) {
+    if (!b || (!di && b->nl) || (!b->q.empty() && (!v || !beta))) { set_last_error("batch_factor_cones: null argument"); return MI355KKT_EINVAL; }
+    KKT_HIP_CHECK(hipSetDevice(b->device));
+    if (!b->q.empty()) {
+        const hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        const size_t B = b->nbatch;
+        if (v != b->dV) KKT_HIP_CHECK(hipMemcpyAsync(b->dV, v, sizeof(double) * B * b->sumq, kind, b->st));
+        if (beta != b->dBeta) KKT_HIP_CHECK(hipMemcpyAsync(b->dBeta, beta, sizeof(double) * B * b->q.size(), kind, b->st));
+        b->w_set = true;
+        if (!di) {                     // no 'l' rows: the scaling kernel never reads di, the LP path wants a valid pointer
+            KKT_HIP_CHECK(hipMemsetAsync(b->dW, 0, sizeof(double) * B * b->ml, b->st));
+            return mi355kkt_batch_factor(b, b->dW, 1, info);
+        }
+    }
+    return mi355kkt_batch_factor(b, di, is_device, info);
+}
+
 /* x: [nbatch][n], z: [nbatch][ml], in place: (bx, bz) -> (ux, W uz) per problem (p = 0). */
 int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device) {
     if (b && b->p > 0) { set_last_error("batch_solve: the batch has equality constraints, use mi355kkt_batch_solve_eq"); return MI355KKT_EINVAL; }
@@ -1441,7 +1518,15 @@ int mi355kkt_batch_solve_eq(mi355kkt_batch* b, double* x, double* y, double* z, 
         dx = b->dx; dz = b->dz; dy = b->dy;
     }
     const int64_t sG = (int64_t)(M * N), sL = (int64_t)(N * N), sA = (int64_t)(Pq * N), sK = (int64_t)(Pq * Pq);
-    if (int e = launch_gemv_t_scaled(b->dG, M ? (int64_t)M : 1, b->ml, b->n, b->dW, dz, b->dzs, dx, b->dwork, b->st, b->nbatch, sG)) return e;
+    const bool cones = !b->q.empty();
+    if (cones) {                      // zs = W^-T bz;  x += Gs' zs     (misc.py:1306-1311)
+        if (int e = launch_batch_cone_scale(dz, (int64_t)M, (int64_t)M, b->dzs, (int64_t)M, (int64_t)M, 1, b->nbatch, b->ml, b->nl,
+                                            (int)b->q.size(), b->sumq, b->d_qoff, b->d_qdim, b->dW, b->dV, b->dBeta, b->st))
+            return e;
+        if (int e = launch_gemv_t_scaled(b->dGs, (int64_t)M, b->ml, b->n, nullptr, b->dzs, b->dzs, dx, b->dwork, b->st, b->nbatch, sG)) return e;
+    } else if (int e = launch_gemv_t_scaled(b->dG, M ? (int64_t)M : 1, b->ml, b->n, b->dW, dz, b->dzs, dx, b->dwork, b->st, b->nbatch, sG)) {
+        return e;
+    }
     if (b->singular && Pq)                                             // x += A' by  (misc.py:1527)
         if (int e = launch_gemv_t_scaled(b->dA, (int64_t)Pq, b->p, b->n, nullptr, dy, b->dtp, dx, nullptr, b->st, b->nbatch, sA)) return e;
     if (int e = launch_trsm_lower(b->dS, (int64_t)N, b->n, dx, (int64_t)N, 1, 0, b->st, b->nbatch, sL, (int64_t)N)) return e;
@@ -1454,7 +1539,9 @@ int mi355kkt_batch_solve_eq(mi355kkt_batch* b, double* x, double* y, double* z, 
         if (int e = launch_gemv_n_scaled(b->dAsct, (int64_t)N, b->n, b->p, nullptr, dy, dx, dx, -1.0, 1.0, b->dwork, b->st, b->nbatch, sA)) return e;
     }
     if (int e = launch_trsm_lower(b->dS, (int64_t)N, b->n, dx, (int64_t)N, 1, 1, b->st, b->nbatch, sL, (int64_t)N)) return e;
-    if (int e = launch_gemv_n_scaled(b->dG, M ? (int64_t)M : 1, b->ml, b->n, b->dW, dx, b->dzs, dz, 1.0, -1.0, b->dwork, b->st, b->nbatch, sG)) return e;
+    if (int e = launch_gemv_n_scaled(cones ? b->dGs : b->dG, M ? (int64_t)M : 1, b->ml, b->n, cones ? nullptr : b->dW, dx, b->dzs, dz, 1.0, -1.0,
+                                     b->dwork, b->st, b->nbatch, sG))
+        return e;
     if (!is_device) {
         KKT_HIP_CHECK(hipMemcpyAsync(x, b->dx, sizeof(double) * B * N, hipMemcpyDeviceToHost, b->st));
         if (M) KKT_HIP_CHECK(hipMemcpyAsync(z, b->dz, sizeof(double) * B * M, hipMemcpyDeviceToHost, b->st));
@@ -1529,6 +1616,104 @@ static int run_ipm(IpmWork& w, hipStream_t st, IpmOps& ops, const double* q, con
     return 0;
 }
 
+// The coneqp loop for a batch with second-order cones: the single-problem kernels of coneqp_ipm.hip, one workgroup per
+// problem (QpState::nbatch), around the batched factor / solve / products.  Finished problems keep their last scaling (their
+// factorisation is repeated with it, harmlessly), their iterates and results are frozen (qp_residual_kernel / qp_update_kernel
+// return at once for them).  Same control flow as mi355kkt_coneqp below; status codes as the LP-cone batch.
+static int batch_coneqp_cones(mi355kkt_batch* b, const double* q, const double* hv, const double* bvec, int maxiters, double abstol,
+                              double reltol, double feastol, double* x, double* y, double* s, double* z, int* status, int* iters,
+                              double* pcost, double* dcost, double* gap, int* iterations_run) {
+    const int n = b->n, m = b->ml, np = b->p, nb = b->nbatch;
+    const size_t B = nb, N = n, M = m, Pq = np;
+    if (int e = qp_alloc(b->qp, n, b->nl, b->q, std::vector<int>(), np, nb)) return e;
+    QpWork& w = b->qp;
+    QpState& S0 = w.S;
+    S0.nbatch = nb;                    // (a batch of one problem still runs the batched control flow below)
+    const QpState& S = S0;
+    hipStream_t st = b->st;
+    struct Guard { mi355kkt_batch* b; ~Guard() { b->defer_sync = false; } } guard{b};
+    b->defer_sync = true;
+    int* d_info = (nb > 1) ? S.active + 3 * B : w.i32 + 4;
+    const int refinement = 1;          // coneprog.py:1862-1865: the default with second-order cones
+    auto products = [&](const double* xin, const double* yin, const double* zin) -> int {
+        if (int e = mi355kkt_batch_products(b, xin, zin, S.Gx, S.GTz, S.Px, 1)) return e;
+        return batch_a_products(b, xin, yin, S.Ax, S.ATy);
+    };
+    auto factor = [&](int* first_bad) -> int {
+        if (int e = mi355kkt_batch_factor_cones(b, S.di, S.v, S.beta, 1, nullptr)) return e;
+        KKT_HIP_CHECK(hipMemcpyAsync(d_info, b->pw.d_info, sizeof(int) * B, hipMemcpyDeviceToDevice, st));
+        if (first_bad) {
+            KKT_HIP_CHECK(hipMemcpyAsync(b->pw.h_info, b->pw.d_info, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+            KKT_HIP_CHECK(hipStreamSynchronize(st));
+            for (int i = 0; i < nb; ++i)
+                if (b->pw.h_info[i] > 0) { *first_bad = i; break; }
+        }
+        return 0;
+    };
+    auto solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_batch_solve_eq(b, dx, dy, dz, 1); };
+    const QpBuf D{S.dx, S.dy, S.dz, S.ds};
+    const QpBuf Wsave{S.wx, S.wy, S.wz, S.ws};
+    const QpBuf W2{S.wx2, S.wy2, S.wz2, S.ws2};
+    KKT_HIP_CHECK(hipMemcpyAsync(S.q, q, sizeof(double) * B * N, hipMemcpyDefault, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.h, hv, sizeof(double) * B * M, hipMemcpyDefault, st));
+    if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bvec, sizeof(double) * B * Pq, hipMemcpyDefault, st));
+    KKT_HIP_CHECK(hipMemsetAsync(w.i32, 0, sizeof(int) * 8, st));
+    if (nb > 1) KKT_HIP_CHECK(hipMemsetAsync(S.active, 0, sizeof(int) * 4 * B, st));
+    KKT_HIP_CHECK(hipMemsetAsync(S.sc, 0, sizeof(double) * B * QP_NSC, st));
+    // ---- starting point with W = I (coneprog.py:2054-2106)
+    qp_launch_unit_scaling(S, st);
+    int first_bad = -1;
+    if (int e = factor(&first_bad)) return e;
+    if (first_bad >= 0) { set_last_error("coneqp: Rank(A) < p or Rank([P; A; G]) < n (problem %d)", first_bad); return 1; }
+    hipLaunchKernelGGL(axpby_kernel, dim3((unsigned)((B * N + 255) / 256)), dim3(256), 0, st, S.x, S.q, -1.0, (int64_t)(B * N));
+    if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.y, S.b, sizeof(double) * B * Pq, hipMemcpyDeviceToDevice, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(S.z, S.h, sizeof(double) * B * M, hipMemcpyDeviceToDevice, st));
+    if (int e = solve(S.x, S.y, S.z)) return e;
+    qp_launch_start(S, st);
+    int it = 0;
+    for (; it <= maxiters; ++it) {
+        if (int e = products(S.x, S.y, S.z)) return e;
+        KKT_HIP_CHECK(hipMemsetAsync(S.nactive, 0, sizeof(int), st));
+        qp_launch_residual(S, it, maxiters, abstol, reltol, feastol, st);
+        KKT_HIP_CHECK(hipMemcpyAsync(w.pinned, S.nactive, sizeof(int), hipMemcpyDeviceToHost, st));
+        KKT_HIP_CHECK(hipStreamSynchronize(st));
+        if (w.pinned[0] == 0) break;
+        if (int e = factor(nullptr)) return e;
+        qp_launch_singular(S, d_info, it, st);
+        for (int i01 = 0; i01 < 2; ++i01) {
+            qp_launch_build(S, D, Wsave, i01, refinement > 0 ? 1 : 0, st);
+            qp_launch_f4pre(S, D, st);
+            if (int e = solve(D.x, D.y, D.z)) return e;
+            qp_launch_f4post(S, D, st);
+            for (int r = 0; r < refinement; ++r) {                       // coneprog.py:2330-2345
+                qp_launch_copy(S, W2, Wsave, st);
+                qp_launch_res_a(S, D, st);
+                if (int e = products(D.x, D.y, S.wz3)) return e;
+                qp_launch_res_b(S, D, W2, st);
+                qp_launch_f4pre(S, W2, st);
+                if (int e = solve(W2.x, W2.y, W2.z)) return e;
+                qp_launch_f4post(S, W2, st);
+                qp_launch_add(S, D, W2, st);
+            }
+            qp_launch_step(S, D, i01, st);
+        }
+        qp_launch_update(S, D, st);
+    }
+    KKT_HIP_CHECK(hipMemcpyAsync(x, S.x_out, sizeof(double) * B * N, hipMemcpyDefault, st));
+    if (y && np > 0) KKT_HIP_CHECK(hipMemcpyAsync(y, S.y_out, sizeof(double) * B * Pq, hipMemcpyDefault, st));
+    if (s) KKT_HIP_CHECK(hipMemcpyAsync(s, S.s_out, sizeof(double) * B * M, hipMemcpyDefault, st));
+    if (z) KKT_HIP_CHECK(hipMemcpyAsync(z, S.z_out, sizeof(double) * B * M, hipMemcpyDefault, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(status, S.status, sizeof(int) * B, hipMemcpyDefault, st));
+    KKT_HIP_CHECK(hipMemcpyAsync(iters, S.iters, sizeof(int) * B, hipMemcpyDefault, st));
+    // pcost / dcost / gap: column QP_PCOST / QP_DCOST / QP_GAP_OUT of the [B][QP_NSC] scalar table
+    if (pcost) KKT_HIP_CHECK(hipMemcpy2DAsync(pcost, sizeof(double), S.sc + QP_PCOST, sizeof(double) * QP_NSC, sizeof(double), B, hipMemcpyDefault, st));
+    if (dcost) KKT_HIP_CHECK(hipMemcpy2DAsync(dcost, sizeof(double), S.sc + QP_DCOST, sizeof(double) * QP_NSC, sizeof(double), B, hipMemcpyDefault, st));
+    if (gap) KKT_HIP_CHECK(hipMemcpy2DAsync(gap, sizeof(double), S.sc + QP_GAP_OUT, sizeof(double) * QP_NSC, sizeof(double), B, hipMemcpyDefault, st));
+    KKT_HIP_CHECK(hipStreamSynchronize(st));
+    if (iterations_run) *iterations_run = it;
+    return 0;
+}
+
 extern "C" {
 
 /* The whole LP-cone coneqp loop (reference coneprog.py:2044-2547 with dims = {'l': ml}, no equalities) for every problem
@@ -1552,6 +1737,9 @@ int mi355kkt_batch_coneqp_eq(mi355kkt_batch* b, const double* q, const double* h
     }
     if (b->ml < 1) { set_last_error("batch_coneqp: needs at least one inequality"); return MI355KKT_EINVAL; }
     KKT_HIP_CHECK(hipSetDevice(b->device));
+    if (!b->q.empty())
+        return batch_coneqp_cones(b, q, h, bvec, maxiters, abstol, reltol, feastol, x, y, s, z, status, iters, pcost, dcost, gap,
+                                  iterations_run);
     if (int e = ipm_alloc(b->ipm, b->nbatch, b->n, b->ml, b->p)) return e;
     const IpmState& S = b->ipm.S;
     struct Guard { mi355kkt_batch* b; ~Guard() { b->defer_sync = false; } } guard{b};

@@ -445,4 +445,96 @@ int launch_cone_scale(const ConeLayout& cl, const double* in, int64_t ldi, doubl
     return 0;
 }
 
+// ---- batched problems (mi355kkt_batch_* with second-order cones): every problem has its own (di, v, beta) ----------------
+// cones of dimension <= 32: one thread per (cone, column, problem), the cone's rows in registers
+__global__ __launch_bounds__(64) void batch_scale_q_small_kernel(const double* in, int64_t ldi, int64_t sIn,
+                                                                 double* out, int64_t ldo, int64_t sOut, int nq,
+                                                                 const int* __restrict__ qoff, const int* __restrict__ qdim,
+                                                                 int ml, int vstride, int bstride,
+                                                                 const double* __restrict__ v, const double* __restrict__ beta,
+                                                                 int ncols) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    const int j = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    if (k >= nq || j >= ncols) return;
+    const int m = qdim[k];
+    if (m > 32) return;                                  // (batch_scale_wave_kernel)
+    const double* x = in + b * sIn + qoff[k] + (int64_t)j * ldi;
+    double* y = out + b * sOut + qoff[k] + (int64_t)j * ldo;
+    const double* __restrict__ vk = v + b * vstride + (qoff[k] - ml);
+    double xv[32];
+    double w = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < m) {
+            xv[i] = x[i];
+            w += (i == 0 ? vk[0] : -vk[i]) * xv[i];       // w = (Jv)' x
+        }
+    }
+    const double s = 1.0 / beta[b * bstride + k];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (i < m) {
+            const double jv = (i == 0 ? vk[0] : -vk[i]);
+            const double jx = (i == 0 ? xv[0] : -xv[i]);
+            y[i] = s * (2.0 * jv * w - jx);
+        }
+    }
+}
+// one wave per (unit, column, problem): units 0 .. nq-1 are the cones of dimension > 32 (lanes stride the rows), the units
+// after them 64-row pieces of the 'l' block
+__global__ __launch_bounds__(256) void batch_scale_wave_kernel(const double* in, int64_t ldi, int64_t sIn,
+                                                              double* out, int64_t ldo, int64_t sOut, int nq,
+                                                              const int* __restrict__ qoff, const int* __restrict__ qdim,
+                                                              int ml, int cdim, int vstride, int bstride,
+                                                              const double* __restrict__ di, const double* __restrict__ v,
+                                                              const double* __restrict__ beta, int ncols) {
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x;
+    const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int64_t b = blockIdx.z;
+    if (j >= ncols) return;
+    const double* x = in + b * sIn + (int64_t)j * ldi;
+    double* y = out + b * sOut + (int64_t)j * ldo;
+    if (u >= nq) {
+        const int i = (u - nq) * 64 + lane;
+        if (i < ml) y[i] = di[b * cdim + i] * x[i];
+        return;
+    }
+    const int m = qdim[u];
+    if (m <= 32) return;                                 // (batch_scale_q_small_kernel)
+    x += qoff[u];
+    y += qoff[u];
+    const double* __restrict__ vk = v + b * vstride + (qoff[u] - ml);
+    double w = 0.0;
+    for (int i = lane; i < m; i += 64) w += (i == 0 ? vk[0] : -vk[i]) * x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
+    const double s = 1.0 / beta[b * bstride + u];
+    for (int i = lane; i < m; i += 64) {
+        const double jv = (i == 0 ? vk[0] : -vk[i]);
+        const double jx = (i == 0 ? x[0] : -x[i]);
+        y[i] = s * (2.0 * jv * w - jx);
+    }
+}
+
+int launch_batch_cone_scale(const double* in, int64_t ldi, int64_t sIn, double* out, int64_t ldo, int64_t sOut, int ncols,
+                            int nbatch, int cdim, int ml, int nq, int sumq, const int* d_qoff, const int* d_qdim,
+                            const double* d_di, const double* d_v, const double* d_beta, hipStream_t st) {
+    if (ncols <= 0 || nbatch <= 0 || cdim <= 0) return 0;
+    const int vstride = sumq > 0 ? sumq : 1, bstride = nq > 0 ? nq : 1;
+    if (nq > 0) {
+        hipLaunchKernelGGL(batch_scale_q_small_kernel, dim3((nq + 63) / 64, ncols, nbatch), dim3(64), 0, st, in, ldi, sIn, out, ldo,
+                           sOut, nq, d_qoff, d_qdim, ml, vstride, bstride, d_v, d_beta, ncols);
+        KKT_HIP_CHECK(hipGetLastError());
+    }
+    const int units = nq + (ml + 63) / 64;
+    if (units > 0) {
+        hipLaunchKernelGGL(batch_scale_wave_kernel, dim3(units, (ncols + 3) / 4, nbatch), dim3(256), 0, st, in, ldi, sIn, out, ldo,
+                           sOut, nq, d_qoff, d_qdim, ml, cdim, vstride, bstride, d_di, d_v, d_beta, ncols);
+        KKT_HIP_CHECK(hipGetLastError());
+    }
+    return 0;
+}
+
 }  // namespace mi355kkt

@@ -13,6 +13,27 @@
 
 namespace mi355kkt {
 
+// batched mode: workgroup b works on problem b — shift every per-problem pointer of (its copy of) the state
+__device__ __forceinline__ void qp_select(QpState& S) {
+    const int64_t b = blockIdx.x;
+    if (S.nbatch <= 1 || b == 0) return;
+    const int64_t on = b * S.n, op = b * (S.p > 0 ? S.p : 1), om = b * S.m;
+    const int64_t ov = b * (S.lq > S.ml ? S.lq - S.ml : 1), ob = b * (S.nq > 0 ? S.nq : 1);
+    S.q += on; S.x += on; S.dx += on; S.rx += on; S.Px += on; S.GTz += on; S.ATy += on; S.x_out += on; S.wx += on; S.wx2 += on;
+    S.b += op; S.y += op; S.dy += op; S.ry += op; S.Ax += op; S.y_out += op; S.wy += op; S.wy2 += op;
+    S.h += om; S.s += om; S.z += om; S.ds += om; S.dz += om; S.rz += om; S.lmbda += om; S.lmbdasq += om; S.d += om; S.di += om;
+    S.ws3 += om; S.Gx += om; S.s_out += om; S.z_out += om; S.t1 += om; S.t2 += om; S.wz3 += om; S.ws += om; S.wz += om;
+    S.ws2 += om; S.wz2 += om;
+    S.v += ov; S.beta += ob;
+    S.sc += b * QP_NSC;
+    S.active += b; S.status += b; S.iters += b;
+}
+__device__ __forceinline__ void qp_select(const QpState& S, QpBuf& X) {
+    const int64_t b = blockIdx.x;
+    if (S.nbatch <= 1 || b == 0) return;
+    X.x += b * S.n; X.y += b * (S.p > 0 ? S.p : 1); X.z += b * S.m; X.s += b * S.m;
+}
+
 __device__ __forceinline__ void qp_store_result(const QpState& S, int status, int it) {
     const int tid = threadIdx.x;
     for (int i = tid; i < S.n; i += blockDim.x) S.x_out[i] = S.x[i];
@@ -30,6 +51,7 @@ __device__ __forceinline__ void qp_store_result(const QpState& S, int status, in
 
 // W = I (coneprog.py:2054-2063)
 __global__ __launch_bounds__(1024) void qp_unit_scaling_kernel(QpState S) {
+    qp_select(S);
     const int tid = threadIdx.x;
     for (int i = tid; i < S.ml; i += blockDim.x) { S.d[i] = 1.0; S.di[i] = 1.0; }
     for (int i = tid; i < S.lq - S.ml; i += blockDim.x) S.v[i] = 0.0;
@@ -42,6 +64,7 @@ __global__ __launch_bounds__(1024) void qp_unit_scaling_kernel(QpState S) {
 }
 
 __global__ __launch_bounds__(1024) void qp_start_kernel(QpState S) {
+    qp_select(S);
     __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     double* sc = S.sc;
@@ -71,6 +94,7 @@ __global__ __launch_bounds__(1024) void qp_start_kernel(QpState S) {
 // in place: S.Px = P x, S.ATy = A' y, S.GTz = G' z, S.Ax = A x, S.Gx = G x
 __global__ __launch_bounds__(1024) void qp_residual_kernel(QpState S, int it, int maxiters, double abstol, double reltol,
                                                           double feastol) {
+    qp_select(S);
     __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     double* sc = S.sc;
@@ -147,6 +171,8 @@ __global__ __launch_bounds__(1024) void qp_residual_kernel(QpState S, int it, in
 
 // "Terminated (singular KKT matrix)" (:2256-2275)
 __global__ __launch_bounds__(1024) void qp_singular_kernel(QpState S, const int* info, int it) {
+    if (S.nbatch > 1) info += blockIdx.x;
+    qp_select(S);
     if (!S.active[0] || info[0] <= 0) return;
     __syncthreads();
     qp_store_result(S, 3, it);
@@ -155,6 +181,7 @@ __global__ __launch_bounds__(1024) void qp_singular_kernel(QpState S, const int*
 
 // right-hand side (:2376-2399): ds = -lmbdasq [- ws3] + sigma mu e; (dx, dy, dz) = -(rx, ry, rz)
 __global__ __launch_bounds__(1024) void qp_build_kernel(QpState S, QpBuf D, QpBuf W, int i01, int save) {
+    qp_select(S, D); qp_select(S, W); qp_select(S);
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     const double sigma = (i01 == 0) ? 0.0 : S.sc[QP_SIGMA];
     const double mu = S.sc[QP_MU];
@@ -180,12 +207,14 @@ __global__ __launch_bounds__(1024) void qp_build_kernel(QpState S, QpBuf D, QpBu
 }
 
 __global__ __launch_bounds__(1024) void qp_copy_kernel(QpState S, QpBuf dst, QpBuf src) {
+    qp_select(S, dst); qp_select(S, src); qp_select(S);
     const int tid = threadIdx.x;
     for (int i = tid; i < S.m; i += blockDim.x) { dst.s[i] = src.s[i]; dst.z[i] = src.z[i]; }
     for (int i = tid; i < S.n; i += blockDim.x) dst.x[i] = src.x[i];
     for (int i = tid; i < S.p; i += blockDim.x) dst.y[i] = src.y[i];
 }
 __global__ __launch_bounds__(1024) void qp_add_kernel(QpState S, QpBuf dst, QpBuf src) {
+    qp_select(S, dst); qp_select(S, src); qp_select(S);
     const int tid = threadIdx.x;
     for (int i = tid; i < S.m; i += blockDim.x) { dst.s[i] += src.s[i]; dst.z[i] += src.z[i]; }
     for (int i = tid; i < S.n; i += blockDim.x) dst.x[i] += src.x[i];
@@ -194,6 +223,7 @@ __global__ __launch_bounds__(1024) void qp_add_kernel(QpState S, QpBuf dst, QpBu
 
 // f4_no_ir before the KKT solve (:2303-2309): s := lmbda o\ s; z := z - W's
 __global__ __launch_bounds__(1024) void qp_f4pre_kernel(QpState S, QpBuf X) {
+    qp_select(S, X); qp_select(S);
     __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     cv_sinv(S, X.s, S.lmbda, sh);
@@ -206,11 +236,13 @@ __global__ __launch_bounds__(1024) void qp_f4pre_kernel(QpState S, QpBuf X) {
 }
 // ... and after it (:2316): s := s - z
 __global__ __launch_bounds__(1024) void qp_f4post_kernel(QpState S, QpBuf X) {
+    qp_select(S, X); qp_select(S);
     for (int i = threadIdx.x; i < S.m; i += blockDim.x) X.s[i] -= X.z[i];
 }
 
 // res() (:1930-1961), first half: wz3 = W^-1 uz (products with P, A', G', A, G launched by the host in between)
 __global__ __launch_bounds__(1024) void qp_res_a_kernel(QpState S, QpBuf U) {
+    qp_select(S, U); qp_select(S);
     __shared__ double sh[16];
     for (int i = threadIdx.x; i < S.m; i += blockDim.x) S.wz3[i] = U.z[i];
     __syncthreads();
@@ -218,6 +250,7 @@ __global__ __launch_bounds__(1024) void qp_res_a_kernel(QpState S, QpBuf U) {
 }
 // second half: S.Px = P ux, S.ATy = A' uy, S.GTz = G' wz3, S.Ax = A ux, S.Gx = G ux are in place
 __global__ __launch_bounds__(1024) void qp_res_b_kernel(QpState S, QpBuf U, QpBuf V) {
+    qp_select(S, U); qp_select(S, V); qp_select(S);
     __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     for (int i = tid; i < n; i += blockDim.x) {
@@ -242,6 +275,7 @@ __global__ __launch_bounds__(1024) void qp_res_b_kernel(QpState S, QpBuf U, QpBu
 }
 
 __global__ __launch_bounds__(1024) void qp_step_kernel(QpState S, QpBuf D, int i01) {
+    qp_select(S, D); qp_select(S);
     __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     double* sc = S.sc;
@@ -271,6 +305,7 @@ __global__ __launch_bounds__(1024) void qp_step_kernel(QpState S, QpBuf D, int i
 }
 
 __global__ __launch_bounds__(1024) void qp_update_kernel(QpState S, QpBuf D) {
+    qp_select(S, D); qp_select(S);
     __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     if (!S.active[0]) return;
@@ -306,9 +341,9 @@ __global__ __launch_bounds__(1024) void qp_update_kernel(QpState S, QpBuf D) {
 // upper triangles of the 's' blocks of a KKT-solve result := lower triangles
 __global__ __launch_bounds__(1024) void qp_symm_kernel(QpState S, double* z) { cv_symm(S, z); }
 
-// one workgroup of S.nthreads threads; kernels that run the Jacobi iteration get the dynamic LDS staging area (> 64 KB
+// one workgroup of S.nthreads threads per problem; kernels that run the Jacobi iteration get the dynamic LDS staging area (> 64 KB
 // needs the attribute once per kernel)
-#define QP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(1), dim3(S.nthreads), 0, st, __VA_ARGS__)
+#define QP1(kernel, ...) hipLaunchKernelGGL(kernel, dim3(S.nbatch > 1 ? S.nbatch : 1), dim3(S.nthreads), 0, st, __VA_ARGS__)
 #define QP1J(kernel, ...)                                                                                              \
     do {                                                                                                               \
         static bool attr_done = false;                                                                                 \
@@ -317,7 +352,8 @@ __global__ __launch_bounds__(1024) void qp_symm_kernel(QpState S, double* z) { c
                                       160 * 1024 - 512);                                                               \
             attr_done = true;                                                                                          \
         }                                                                                                              \
-        hipLaunchKernelGGL(kernel, dim3(1), dim3(S.nthreads), sizeof(double) * S.lds_doubles, st, __VA_ARGS__);         \
+        hipLaunchKernelGGL(kernel, dim3(S.nbatch > 1 ? S.nbatch : 1), dim3(S.nthreads), sizeof(double) * S.lds_doubles, st,     \
+                           __VA_ARGS__);         \
     } while (0)
 void qp_launch_symm(const QpState& S, double* z, hipStream_t st) { if (S.ns > 0) QP1(qp_symm_kernel, S, z); }
 void qp_launch_unit_scaling(const QpState& S, hipStream_t st) { QP1(qp_unit_scaling_kernel, S); }

@@ -258,6 +258,12 @@ int cone_layout_set_beta(ConeLayout& cl, const double* d_beta, hipStream_t st);
 // out = extra * W^-T in on the l + q rows, for ncols columns (in/out may alias)
 int launch_cone_scale(const ConeLayout& cl, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
                       const double* d_di, const double* d_v, const double* d_beta, double extra, hipStream_t st);
+// The same for a batch of problems of one shape, each with its own scaling: problem b reads in + b sIn, writes out + b sOut
+// (in == out allowed), with di + b cdim ('l' rows: the first ml entries), v + b max(sumq, 1), beta + b max(nq, 1).
+// qoff / qdim: device arrays, row offset and dimension of every second-order cone (shared by all problems).
+int launch_batch_cone_scale(const double* in, int64_t ldi, int64_t sIn, double* out, int64_t ldo, int64_t sOut, int ncols,
+                            int nbatch, int cdim, int ml, int nq, int sumq, const int* d_qoff, const int* d_qdim,
+                            const double* d_di, const double* d_v, const double* d_beta, hipStream_t st);
 
 // ---- device-resident LP-cone coneqp loop for a batch (batch_ipm.hip) --------------------------------
 struct IpmState {
@@ -343,6 +349,11 @@ enum QpScalar {
 struct QpBuf { double *x, *y, *z, *s; };            // one (x, y, z, s) quadruple of f4 / res
 struct QpState {
     int n = 0, m = 0, p = 0, ml = 0, nq = 0;          // m = ml + sum(q) + sum(s_k^2)
+    // batched mode (mi355kkt_batch_* with second-order cones): nbatch problems of one shape in lock step, one workgroup each
+    // (blockIdx.x); every per-problem array below then holds nbatch slices back to back — [n] fields with stride n, [p] with
+    // max(p, 1), [m] with m, v with max(sum(q), 1), beta with max(nq, 1), sc with QP_NSC, active / status / iters with 1 — and
+    // the kernels shift their copy of the state to their problem first (qp_select, coneqp_ipm.hip).  'l' + 'q' cones only.
+    int nbatch = 1;
     const int *qoff = nullptr, *qdim = nullptr;
     // 's' blocks (cone_ops_s.h): block k is sdim[k] x sdim[k], full symmetric storage, at soff[k] of the cone vectors, at
     // sloff[k] of lmbda (compact layout: sdim[k] entries), at soff[k] - lq of r / rti / sw1..3, at sloff[k] - lq of sigs / sigz

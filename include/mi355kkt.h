@@ -227,6 +227,16 @@ int mi355kkt_batch_solve_eq(mi355kkt_batch* b, double* x, double* y, double* z, 
 int mi355kkt_batch_coneqp_eq(mi355kkt_batch* b, const double* q, const double* h, const double* bvec, int maxiters, double abstol,
                              double reltol, double feastol, double* x, double* y, double* s, double* z, int* status, int* iters,
                              double* pcost, double* dcost, double* gap, int* iterations_run);
+/* Batches with second-order cones: dims = {'l': nl, 'q': q[0..nq)} for every problem, G_b is cdim x n with
+ * cdim = nl + sum(q) (wherever the functions above say ml, read cdim), p equality constraints (0: none).  Per problem this is
+ * the reference's kkt_chol with p = 0 / its Schur-complement twin (misc.py:1213-1349): Gs_b = W_b^-T G_b
+ * (misc_solvers.c:144-183 per cone), S_b = H_b + Gs_b' Gs_b.  factor_cones: di [nbatch][cdim] (the first nl entries of every
+ * slice), v [nbatch][sum(q)], beta [nbatch][nq] — W['di'], W['v'], W['beta'] of every problem; solve_eq / products / set_A as
+ * above.  mi355kkt_batch_coneqp[_eq] on such a batch runs the reference's coneqp loop with the 'q' branches of
+ * compute_scaling / update_scaling / max_step / sprod / sinv (misc.py:307-354, :503-573) and the default refinement step
+ * (coneprog.py:1862-1865, :2330-2345), one workgroup per problem, h / s / z: [nbatch][cdim]. */
+int mi355kkt_batch_create_cones(mi355kkt_batch** out, int device, int nbatch, int n, int nl, int nq, const int* q, int p);
+int mi355kkt_batch_factor_cones(mi355kkt_batch* b, const double* di, const double* v, const double* beta, int is_device, int* info);
 
 /* ---- stand-alone device operators (each is one stage of factor()/solve(); used by the per-kernel
  * parity tests and by the profiler).  All pointers are DEVICE pointers; calls are synchronous. ---- */

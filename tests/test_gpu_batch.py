@@ -210,3 +210,81 @@ def test_batched_rank_deficient_A_is_reported_per_problem():
     info = bk.factor(np.ones((B, m)))
     assert info[2] == n + 5 and np.all(np.delete(info, 2) == 0)       # reported as n + pivot, like the single-problem engine
     bk.close()
+
+
+# ---- second-order cones in the batched engine (round 2) ----------------------------------------------------------------------
+def _batch_q(name):
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    Gt = np.ascontiguousarray(np.transpose(g['G'], (0, 2, 1)))       # (B, n, cdim): the cdim x n blocks column-major
+    At = np.ascontiguousarray(np.transpose(g['A'], (0, 2, 1)))       # (B, n, p)
+    dims = {'l': int(g['dims_l']), 'q': [int(k) for k in g['dims_q']], 's': []}
+    return g, Gt, At, dims
+
+
+def test_batched_factor_solve_with_second_order_cones_vs_reference_kkt_chol():
+    """`mi355kkt_batch_factor_cones` + `mi355kkt_batch_solve` against the reference's misc.kkt_chol(G, dims, A)(W, P)(x, y, z)
+    problem by problem, each with its own Nesterov-Todd scaling from misc.compute_scaling
+    (tests/golden/make_golden_batch_q.py): cones of 3, 5, 12 and 40 rows next to an 'l' block."""
+    g, Gt, _At, dims = _batch_q("batch_q")
+    bk = BatchKkt(Gt, np.ascontiguousarray(g['P']), dims=dims)
+    info = bk.factor_cones(g['Wdi'], g['Wv'], g['Wbeta'])
+    assert np.all(info == 0)
+    x, z = np.ascontiguousarray(g['bx']).copy(), np.ascontiguousarray(g['bz']).copy()
+    bk.solve(x, z)
+    for k in range(Gt.shape[0]):
+        assert relerr(x[k], g['ux'][k]) < 1e-10, k
+        assert relerr(z[k], g['uz'][k]) < 1e-10, k
+    # a second factorisation with other scalings on the same handle, then the first ones again: nothing is cached
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(Gt.shape[0])
+    bk.factor_cones(g['Wdi'][perm], g['Wv'][perm], g['Wbeta'][perm])
+    bk.factor_cones(g['Wdi'], g['Wv'], g['Wbeta'])
+    x2, z2 = np.ascontiguousarray(g['bx']).copy(), np.ascontiguousarray(g['bz']).copy()
+    bk.solve(x2, z2)
+    assert np.array_equal(x, x2) and np.array_equal(z, z2)
+    bk.close()
+
+
+@pytest.mark.parametrize("name", ["batch_q", "batch_q_eq"])
+def test_batched_coneqp_with_second_order_cones_vs_reference_fixture(name):
+    """`mi355kkt_batch_coneqp_eq` on a batch with second-order cones against solvers.coneqp(P, q, G, h, dims[, A, b]) run
+    problem by problem by the real reference (default refinement 1 with 'q' blocks): the problems stop after different
+    numbers of iterations (10 .. 13), so the freeze of finished problems is exercised too."""
+    g, Gt, At, dims = _batch_q(name)
+    p = At.shape[2]
+    bk = BatchKkt(Gt, np.ascontiguousarray(g['P']), At=At if p else None, dims=dims)
+    res = bk.coneqp(g['q'], g['h'], b=g['b'] if p else None)
+    B = Gt.shape[0]
+    assert all(s == 'optimal' for s in res['status'])
+    assert np.array_equal(res['iterations'], g['iterations'])
+    for k in range(B):
+        assert abs(res['primal objective'][k] - g['pobj'][k]) <= 1e-8 * max(1.0, abs(g['pobj'][k])), k
+        assert abs(res['dual objective'][k] - g['dobj'][k]) <= 1e-8 * max(1.0, abs(g['dobj'][k])), k
+        assert relerr(res['x'][k], g['x'][k]) < 1e-6, k
+        if p:
+            assert relerr(res['y'][k], g['y'][k]) < 1e-5, k
+        assert relerr(res['z'][k], g['z'][k]) < 1e-5 and relerr(res['s'][k], g['s'][k]) < 1e-5, k
+    # the same batch again on the same handle (state reuse), and a batch of ONE problem (the single-problem control flow)
+    res2 = bk.coneqp(g['q'], g['h'], b=g['b'] if p else None)
+    assert np.array_equal(res2['iterations'], res['iterations']) and np.array_equal(res2['x'], res['x'])
+    bk.close()
+    b1 = BatchKkt(Gt[:1].copy(), np.ascontiguousarray(g['P'][:1]), At=At[:1].copy() if p else None, dims=dims)
+    r1 = b1.coneqp(g['q'][:1], g['h'][:1], b=g['b'][:1] if p else None)
+    assert r1['status'][0] == 'optimal' and r1['iterations'][0] == g['iterations'][0]
+    assert relerr(r1['x'][0], g['x'][0]) < 1e-6
+    b1.close()
+
+
+def test_batched_cones_match_the_single_problem_device_loop():
+    """every problem of the cone batch through `cvxopt_amd.coneqp_device` (the single-problem loop: same kernels, one
+    workgroup, other factorisation kernels): same iteration counts, iterates to rounding"""
+    import cvxopt_amd
+    g, Gt, _At, dims = _batch_q("batch_q")
+    bk = BatchKkt(Gt, np.ascontiguousarray(g['P']), dims=dims)
+    res = bk.coneqp(g['q'], g['h'])
+    bk.close()
+    for k in range(3):
+        sol = cvxopt_amd.coneqp_device(g['P'][k], g['q'][k], g['G'][k], g['h'][k], dims)
+        assert sol['status'] == 'optimal' and sol['iterations'] == res['iterations'][k]
+        assert relerr(np.asarray(sol['x']).ravel(), res['x'][k]) < 1e-8, k
