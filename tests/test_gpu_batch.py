@@ -11,7 +11,8 @@ from helpers import load_golden, relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,n,m", [(1, 64, 128), (5, 100, 230), (16, 256, 512), (3, 130, 61), (64, 512, 1024)])
+@pytest.mark.parametrize("B,n,m", [(1, 64, 128), (5, 100, 230), (16, 256, 512), (3, 130, 61), (64, 512, 1024), (6, 300, 450),
+                                   (2, 1100, 1300)])
 def test_batched_factor_solve_matches_cpu(B, n, m):
     probs = [synth.dense_qp(n, m, seed=100 + i) for i in range(B)]
     P, q, Gt, h = pack_problems(probs)
@@ -40,6 +41,28 @@ def test_batched_factor_reports_per_problem_failures():
     ref = NumpyBatchKkt(Gt, P).factor(np.ones((B, m)))
     # S is exactly rank 20: the first non-positive pivot is a rounding-level quantity (21 or 22)
     assert abs(int(info[1]) - int(ref[1])) <= 2 and abs(int(info[3]) - int(ref[3])) <= 2 and info[1] > 20
+    g.close()
+
+
+def test_batched_factor_reports_per_problem_failures_several_panels():
+    """n = 270 (three 128-column panels, the last one narrow): a failing problem reports its first non-positive pivot and
+    does not disturb the others"""
+    B, n, m = 3, 270, 100                     # rank(G) = 100 < 270 and P = 0 for problem 1
+    probs = [synth.dense_qp(n, m, seed=i) for i in range(B)]
+    P, q, Gt, h = pack_problems(probs)
+    P[1] = 0.0
+    g = BatchKkt(Gt, P)
+    rng = np.random.default_rng(0)
+    info = g.factor(np.ones((B, m)))
+    assert info[0] == 0 and info[2] == 0 and 100 < info[1] <= 103
+    x, z = rng.standard_normal((B, n)), rng.standard_normal((B, m))
+    xg, zg = x.copy(), z.copy()
+    g.solve(xg, zg)
+    c = NumpyBatchKkt(Gt[[0, 2]], P[[0, 2]])
+    assert np.all(c.factor(np.ones((2, m))) == 0)
+    xc, zc = x[[0, 2]].copy(), z[[0, 2]].copy()
+    c.solve(xc, zc)
+    assert relerr(xg[0], xc[0]) < 1e-8 and relerr(xg[2], xc[1]) < 1e-8 and relerr(zg[2], zc[1]) < 1e-8
     g.close()
 
 
