@@ -1224,7 +1224,8 @@ struct mi355kkt_batch {
     // materialised (the cone transform is not diagonal), like the single-problem engine does.
     int nl = 0, sumq = 0;
     std::vector<int> q;
-    int *d_qoff = nullptr, *d_qdim = nullptr;
+    int *d_qoff = nullptr, *d_qdim = nullptr, *d_large = nullptr;   // cone offsets / dimensions / ids of the cones > 32 rows
+    int nlarge = 0;
     double *dGs = nullptr, *dV = nullptr, *dBeta = nullptr;
     bool w_set = false;               // v, beta of the current factorisation are in dV, dBeta
     QpWork qp;                        // state of the device-resident loop with cones (coneqp_ipm.hip, one workgroup per problem)
@@ -1298,8 +1299,12 @@ int mi355kkt_batch_create_cones(mi355kkt_batch** out, int device, int nbatch, in
     std::vector<int> hq(2 * (size_t)nq);
     int off = nl;
     for (int k = 0; k < nq; ++k) { hq[k] = off; hq[nq + k] = q[k]; off += q[k]; }
-    if (hipMalloc(&b->d_qoff, sizeof(int) * 2 * (size_t)nq) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    for (int k = 0; k < nq; ++k)
+        if (q[k] > 32) hq.push_back(k);
+    b->nlarge = (int)hq.size() - 2 * nq;
+    if (hipMalloc(&b->d_qoff, sizeof(int) * hq.size()) != hipSuccess) return fail(MI355KKT_ENOMEM);
     b->d_qdim = b->d_qoff + nq;
+    b->d_large = b->d_qoff + 2 * nq;
     if (hipMemcpy(b->d_qoff, hq.data(), sizeof(int) * hq.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355KKT_EHIP);
     const size_t B = nbatch;
     if (hipMalloc(&b->dGs, sizeof(double) * B * (size_t)cdim * n) != hipSuccess) return fail(MI355KKT_ENOMEM);
@@ -1427,7 +1432,7 @@ int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, in
     if (!b->q.empty()) {              // second-order cones: Gs_b = W_b^-T G_b (misc.py:1271), then the plain SYRK
         if (!b->w_set) { set_last_error("batch_factor: the batch has second-order cones, use mi355kkt_batch_factor_cones"); return MI355KKT_EINVAL; }
         if (int e = launch_batch_cone_scale(b->dG, (int64_t)M, (int64_t)(M * N), b->dGs, (int64_t)M, (int64_t)(M * N), b->n, b->nbatch,
-                                            b->ml, b->nl, (int)b->q.size(), b->sumq, b->d_qoff, b->d_qdim, b->dW, b->dV, b->dBeta, b->st))
+                                            b->ml, b->nl, (int)b->q.size(), b->sumq, b->d_qoff, b->d_qdim, b->d_large, b->nlarge, b->dW, b->dV, b->dBeta, b->st))
             return e;
         Gk = b->dGs;
         wk = nullptr;
@@ -1521,7 +1526,7 @@ int mi355kkt_batch_solve_eq(mi355kkt_batch* b, double* x, double* y, double* z, 
     const bool cones = !b->q.empty();
     if (cones) {                      // zs = W^-T bz;  x += Gs' zs     (misc.py:1306-1311)
         if (int e = launch_batch_cone_scale(dz, (int64_t)M, (int64_t)M, b->dzs, (int64_t)M, (int64_t)M, 1, b->nbatch, b->ml, b->nl,
-                                            (int)b->q.size(), b->sumq, b->d_qoff, b->d_qdim, b->dW, b->dV, b->dBeta, b->st))
+                                            (int)b->q.size(), b->sumq, b->d_qoff, b->d_qdim, b->d_large, b->nlarge, b->dW, b->dV, b->dBeta, b->st))
             return e;
         if (int e = launch_gemv_t_scaled(b->dGs, (int64_t)M, b->ml, b->n, nullptr, b->dzs, b->dzs, dx, b->dwork, b->st, b->nbatch, sG)) return e;
     } else if (int e = launch_gemv_t_scaled(b->dG, M ? (int64_t)M : 1, b->ml, b->n, b->dW, dz, b->dzs, dx, b->dwork, b->st, b->nbatch, sG)) {

@@ -462,6 +462,33 @@ __global__ __launch_bounds__(64) void batch_scale_q_small_kernel(const double* i
     const double* x = in + b * sIn + qoff[k] + (int64_t)j * ldi;
     double* y = out + b * sOut + qoff[k] + (int64_t)j * ldo;
     const double* __restrict__ vk = v + b * vstride + (qoff[k] - ml);
+    // cones of 8 or 4 rows on 16-byte boundaries: 16-byte requests like scale_q_small_kernel (1.7 -> TB/s class of the
+    // single-problem kernel); in == out is fine, every thread reads its cone before it writes it
+    if ((m == 8 || m == 4) && ((qoff[k] | (qoff[k] - ml) | vstride) & 1) == 0 && ((ldi | ldo | sIn | sOut) & 1) == 0 &&
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        typedef double dv2 __attribute__((ext_vector_type(2)));
+        const dv2* x2 = reinterpret_cast<const dv2*>(x);
+        const dv2* __restrict__ v2 = reinterpret_cast<const dv2*>(vk);
+        dv2* y2 = reinterpret_cast<dv2*>(y);
+        const double s = 1.0 / beta[b * bstride + k];
+        if (m == 8) {
+            const dv2 a0 = x2[0], a1 = x2[1], a2 = x2[2], a3 = x2[3];
+            const dv2 b0 = v2[0], b1 = v2[1], b2 = v2[2], b3 = v2[3];
+            const double w = b0.x * a0.x - b0.y * a0.y - (b1.x * a1.x + b1.y * a1.y) - (b2.x * a2.x + b2.y * a2.y) -
+                             (b3.x * a3.x + b3.y * a3.y);
+            y2[0] = dv2{s * (2.0 * b0.x * w - a0.x), s * (-2.0 * b0.y * w + a0.y)};
+            y2[1] = dv2{s * (-2.0 * b1.x * w + a1.x), s * (-2.0 * b1.y * w + a1.y)};
+            y2[2] = dv2{s * (-2.0 * b2.x * w + a2.x), s * (-2.0 * b2.y * w + a2.y)};
+            y2[3] = dv2{s * (-2.0 * b3.x * w + a3.x), s * (-2.0 * b3.y * w + a3.y)};
+        } else {
+            const dv2 a0 = x2[0], a1 = x2[1];
+            const dv2 b0 = v2[0], b1 = v2[1];
+            const double w = b0.x * a0.x - b0.y * a0.y - (b1.x * a1.x + b1.y * a1.y);
+            y2[0] = dv2{s * (2.0 * b0.x * w - a0.x), s * (-2.0 * b0.y * w + a0.y)};
+            y2[1] = dv2{s * (-2.0 * b1.x * w + a1.x), s * (-2.0 * b1.y * w + a1.y)};
+        }
+        return;
+    }
     double xv[32];
     double w = 0.0;
 #pragma unroll
@@ -481,10 +508,11 @@ __global__ __launch_bounds__(64) void batch_scale_q_small_kernel(const double* i
         }
     }
 }
-// one wave per (unit, column, problem): units 0 .. nq-1 are the cones of dimension > 32 (lanes stride the rows), the units
-// after them 64-row pieces of the 'l' block
+// one wave per (unit, column, problem): units 0 .. nlarge-1 are the cones of dimension > 32 (large_ids; lanes stride the
+// rows), the units after them 64-row pieces of the 'l' block
 __global__ __launch_bounds__(256) void batch_scale_wave_kernel(const double* in, int64_t ldi, int64_t sIn,
-                                                              double* out, int64_t ldo, int64_t sOut, int nq,
+                                                              double* out, int64_t ldo, int64_t sOut, int nlarge,
+                                                              const int* __restrict__ large_ids,
                                                               const int* __restrict__ qoff, const int* __restrict__ qdim,
                                                               int ml, int cdim, int vstride, int bstride,
                                                               const double* __restrict__ di, const double* __restrict__ v,
@@ -496,21 +524,21 @@ __global__ __launch_bounds__(256) void batch_scale_wave_kernel(const double* in,
     if (j >= ncols) return;
     const double* x = in + b * sIn + (int64_t)j * ldi;
     double* y = out + b * sOut + (int64_t)j * ldo;
-    if (u >= nq) {
-        const int i = (u - nq) * 64 + lane;
+    if (u >= nlarge) {
+        const int i = (u - nlarge) * 64 + lane;
         if (i < ml) y[i] = di[b * cdim + i] * x[i];
         return;
     }
-    const int m = qdim[u];
-    if (m <= 32) return;                                 // (batch_scale_q_small_kernel)
-    x += qoff[u];
-    y += qoff[u];
-    const double* __restrict__ vk = v + b * vstride + (qoff[u] - ml);
+    const int k = large_ids[u];
+    const int m = qdim[k];
+    x += qoff[k];
+    y += qoff[k];
+    const double* __restrict__ vk = v + b * vstride + (qoff[k] - ml);
     double w = 0.0;
     for (int i = lane; i < m; i += 64) w += (i == 0 ? vk[0] : -vk[i]) * x[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o, 64);
-    const double s = 1.0 / beta[b * bstride + u];
+    const double s = 1.0 / beta[b * bstride + k];
     for (int i = lane; i < m; i += 64) {
         const double jv = (i == 0 ? vk[0] : -vk[i]);
         const double jx = (i == 0 ? x[0] : -x[i]);
@@ -520,18 +548,19 @@ __global__ __launch_bounds__(256) void batch_scale_wave_kernel(const double* in,
 
 int launch_batch_cone_scale(const double* in, int64_t ldi, int64_t sIn, double* out, int64_t ldo, int64_t sOut, int ncols,
                             int nbatch, int cdim, int ml, int nq, int sumq, const int* d_qoff, const int* d_qdim,
-                            const double* d_di, const double* d_v, const double* d_beta, hipStream_t st) {
+                            const int* d_large_ids, int nlarge, const double* d_di, const double* d_v, const double* d_beta,
+                            hipStream_t st) {
     if (ncols <= 0 || nbatch <= 0 || cdim <= 0) return 0;
     const int vstride = sumq > 0 ? sumq : 1, bstride = nq > 0 ? nq : 1;
-    if (nq > 0) {
+    if (nq > nlarge) {
         hipLaunchKernelGGL(batch_scale_q_small_kernel, dim3((nq + 63) / 64, ncols, nbatch), dim3(64), 0, st, in, ldi, sIn, out, ldo,
                            sOut, nq, d_qoff, d_qdim, ml, vstride, bstride, d_v, d_beta, ncols);
         KKT_HIP_CHECK(hipGetLastError());
     }
-    const int units = nq + (ml + 63) / 64;
+    const int units = nlarge + (ml + 63) / 64;
     if (units > 0) {
         hipLaunchKernelGGL(batch_scale_wave_kernel, dim3(units, (ncols + 3) / 4, nbatch), dim3(256), 0, st, in, ldi, sIn, out, ldo,
-                           sOut, nq, d_qoff, d_qdim, ml, cdim, vstride, bstride, d_di, d_v, d_beta, ncols);
+                           sOut, nlarge, d_large_ids, d_qoff, d_qdim, ml, cdim, vstride, bstride, d_di, d_v, d_beta, ncols);
         KKT_HIP_CHECK(hipGetLastError());
     }
     return 0;

@@ -260,10 +260,12 @@ int launch_cone_scale(const ConeLayout& cl, const double* in, int64_t ldi, doubl
                       const double* d_di, const double* d_v, const double* d_beta, double extra, hipStream_t st);
 // The same for a batch of problems of one shape, each with its own scaling: problem b reads in + b sIn, writes out + b sOut
 // (in == out allowed), with di + b cdim ('l' rows: the first ml entries), v + b max(sumq, 1), beta + b max(nq, 1).
-// qoff / qdim: device arrays, row offset and dimension of every second-order cone (shared by all problems).
+// qoff / qdim: device arrays, row offset and dimension of every second-order cone (shared by all problems); large_ids: the
+// nlarge cones of more than 32 rows.
 int launch_batch_cone_scale(const double* in, int64_t ldi, int64_t sIn, double* out, int64_t ldo, int64_t sOut, int ncols,
                             int nbatch, int cdim, int ml, int nq, int sumq, const int* d_qoff, const int* d_qdim,
-                            const double* d_di, const double* d_v, const double* d_beta, hipStream_t st);
+                            const int* d_large_ids, int nlarge, const double* d_di, const double* d_v, const double* d_beta,
+                            hipStream_t st);
 
 // ---- device-resident LP-cone coneqp loop for a batch (batch_ipm.hip) --------------------------------
 struct IpmState {

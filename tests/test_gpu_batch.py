@@ -311,3 +311,58 @@ def test_batched_cones_match_the_single_problem_device_loop():
         sol = cvxopt_amd.coneqp_device(g['P'][k], g['q'][k], g['G'][k], g['h'][k], dims)
         assert sol['status'] == 'optimal' and sol['iterations'] == res['iterations'][k]
         assert relerr(np.asarray(sol['x']).ravel(), res['x'][k]) < 1e-8, k
+
+
+def test_batched_cones_of_8_and_4_rows_vector_path_vs_oracle_and_single_loop():
+    """cones of 8 and 4 rows on even offsets with an even cdim take the 16-byte path of the batched scaling kernel
+    (the SOCP class of BASELINE configs[2]): hook level against the NumPy oracle of misc.kkt_chol with a different
+    Nesterov-Todd scaling per problem, whole loop against the single-problem device loop"""
+    import cvxopt_amd
+    from oracle import kkt_oracle as ko
+    B, n = 5, 14
+    dims = {'l': 4, 'q': [8, 4, 8, 4], 's': []}
+    m = 28
+    rng = np.random.default_rng(11)
+
+    def interior():
+        u = np.empty(m)
+        u[:4] = rng.uniform(0.5, 1.5, 4)
+        o = 4
+        for k in dims['q']:
+            t = rng.standard_normal(k - 1)
+            u[o] = np.linalg.norm(t) + rng.uniform(0.5, 1.5)
+            u[o + 1:o + k] = t
+            o += k
+        return u
+    P, q, G, h = [], [], [], []
+    for _ in range(B):
+        Bm = rng.standard_normal((n, n))
+        Pk = Bm @ Bm.T / n + 0.1 * np.eye(n)
+        Gk = rng.standard_normal((m, n))
+        x0 = rng.standard_normal(n)
+        P.append(Pk)
+        G.append(Gk)
+        q.append(-(Pk @ x0 + Gk.T @ interior()))
+        h.append(Gk @ x0 + interior())
+    P, q, G, h = np.array(P), np.array(q), np.array(G), np.array(h)
+    Gt = np.ascontiguousarray(np.transpose(G, (0, 2, 1)))
+    bk = BatchKkt(Gt, P, dims=dims)
+    Ws = [synth.random_scaling(dims, seed=50 + k, spread=1.0) for k in range(B)]
+    di = np.array([W['di'] for W in Ws])
+    v = np.array([np.concatenate(W['v']) for W in Ws])
+    beta = np.array([W['beta'] for W in Ws])
+    assert np.all(bk.factor_cones(di, v, beta) == 0)
+    bx, bz = rng.standard_normal((B, n)), rng.standard_normal((B, m))
+    x, z = bx.copy(), bz.copy()
+    bk.solve(x, z)
+    for k in range(B):
+        xo, yo, zo = bx[k].copy(), np.zeros(0), bz[k].copy()
+        ko.KktChol(G[k], dims, np.zeros((0, n))).factor(Ws[k], P[k])(xo, yo, zo)
+        assert relerr(x[k], xo) < 1e-10 and relerr(z[k], zo) < 1e-10, k
+    res = bk.coneqp(q, h)
+    bk.close()
+    assert all(s == 'optimal' for s in res['status'])
+    for k in range(B):
+        sol = cvxopt_amd.coneqp_device(P[k], q[k], np.asfortranarray(G[k]), h[k], dims)
+        assert sol['status'] == 'optimal' and sol['iterations'] == res['iterations'][k], k
+        assert relerr(np.asarray(sol['x']).ravel(), res['x'][k]) < 1e-8, k
