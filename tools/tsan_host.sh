@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Host-side ThreadSanitizer build of libmi355kkt: the SPMD 's'-block operations of csrc/cone_ops_s.h run by teams of host
 # threads (mi355kkt_debug_sdp_op_host_team, a pthread barrier as the team barrier) under TSan -- a missing barrier or a data
-# race between the threads of a team shows up here without a GPU.
+# race between the threads of a team shows up here without a GPU.  Second part: the threaded host analysis of the sparse engine.
 #     bash tools/tsan_host.sh
 set -euo pipefail
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
@@ -25,3 +25,10 @@ cd "$ROOT"
 CVXOPT_AMD_LIB="$OUT/libmi355kkt.so" CVXOPT_AMD_NO_TORCH_PRELOAD=1 LD_PRELOAD="$RT" \
   TSAN_OPTIONS="halt_on_error=1 report_signal_unsafe=0 exitcode=66" \
   python -m pytest -q -m "not gpu" tests/test_sdp_ops_cpu.py -k "team" "$@"
+# the multi-threaded host analysis of the sparse engine (the two sides of every separator of the nested dissection on separate
+# threads, the two ordering candidates side by side, the parallel key sort of the assembly lists).  NumPy's own OpenBLAS
+# threads are not instrumented and would be reported as races: one BLAS thread.  (-s: TSan writes to fd 2.)
+OPENBLAS_NUM_THREADS=1 MKL_NUM_THREADS=1 OMP_NUM_THREADS=1 \
+CVXOPT_AMD_LIB="$OUT/libmi355kkt.so" CVXOPT_AMD_NO_TORCH_PRELOAD=1 LD_PRELOAD="$RT" \
+  TSAN_OPTIONS="halt_on_error=1 report_signal_unsafe=0 exitcode=66" \
+  python -m pytest -q -s -m "not gpu" tests/test_ordering_cpu.py tests/test_sparse_plan_cpu.py "$@"
