@@ -69,6 +69,31 @@ def test_argument_errors_mirror_the_reference():
         _capi.check(7, "factor")
 
 
+def test_batch_entry_points_validate_their_arguments_before_touching_the_device():
+    """bad shapes are refused with MI355KKT_EINVAL (no GPU needed); well-formed calls fail loudly with MI355KKT_EHIP here"""
+    import ctypes as C
+    from cvxopt_amd import _capi
+    L = _capi.lib()
+    h = C.c_void_p()
+    EINVAL = -1
+    q = (C.c_int * 3)(4, 0, 5)                            # a cone of dimension 0
+    assert L.mi355kkt_batch_create_cones(C.byref(h), 0, 4, 8, 2, 3, q, 0) == EINVAL and not h.value
+    assert b"positive" in L.mi355kkt_last_error()
+    q = (C.c_int * 2)(4, 5)
+    assert L.mi355kkt_batch_create_cones(C.byref(h), 0, 4, 8, -1, 2, q, 0) == EINVAL             # negative 'l'
+    assert L.mi355kkt_batch_create_cones(C.byref(h), 0, 4, 8, 2, 2, None, 0) == EINVAL           # nq > 0 without q
+    assert L.mi355kkt_batch_create_cones(C.byref(h), 0, 0, 8, 2, 2, q, 0) == EINVAL              # empty batch
+    assert L.mi355kkt_batch_create_cones(C.byref(h), 0, 4, 8, 2, 2, q, 9) == EINVAL              # p > n
+    assert L.mi355kkt_batch_create_eq(C.byref(h), 0, 4, 0, 5, 0) == EINVAL                       # n = 0
+    assert L.mi355kkt_batch_factor_cones(None, None, None, None, 0, None) == EINVAL
+    assert L.mi355kkt_batch_solve_eq(None, None, None, None, 0) == EINVAL
+    if _capi.device_count() <= 0:
+        assert L.mi355kkt_batch_create_cones(C.byref(h), 0, 4, 8, 2, 2, q, 0) == _capi.EHIP and not h.value
+        from cvxopt_amd.batch import BatchKkt
+        with pytest.raises(RuntimeError):                  # there is no CPU fallback
+            BatchKkt(np.zeros((2, 8, 11)), dims={'l': 2, 'q': [4, 5], 's': []})
+
+
 def test_install_and_uninstall_rebind_factories():
     import types
     import cvxopt_amd
