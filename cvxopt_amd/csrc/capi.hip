@@ -602,17 +602,46 @@ int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t*
 
 /* A (p x n) in CSR: rowptr[p + 1], colind[nnz] (int64, like the CCS arrays of cvxopt), values[nnz].  The handle keeps A sparse
  * on the device (CSR + its transpose) -- reference misc.py:1483-1487 / cholmod.spsolve keep A' sparse too.  Sparse engine only. */
-int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr, const int64_t* colind, const double* values) {
-    if (!h || (h->p > 0 && !rowptr)) { set_last_error("set_A_csr: null argument"); return MI355KKT_EINVAL; }
-    if (int e = bind(h)) return e;
+int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr_in, const int64_t* colind_in, const double* values_in) {
+    if (!h || (h->p > 0 && !rowptr_in)) { set_last_error("set_A_csr: null argument"); return MI355KKT_EINVAL; }
     const int p = h->p, n = h->n;
     if (p == 0) { h->A_sparse = true; return 0; }
-    const int64_t nnz = rowptr[p];
+    // validation first (no device needed): rowptr[0] == 0 and monotone, column indices in range
+    if (rowptr_in[0] != 0) { set_last_error("set_A_csr: rowptr[0] must be 0"); return MI355KKT_EINVAL; }
+    for (int r = 0; r < p; ++r)
+        if (rowptr_in[r + 1] < rowptr_in[r]) { set_last_error("set_A_csr: rowptr must be non-decreasing"); return MI355KKT_EINVAL; }
+    const int64_t nnz_in = rowptr_in[p];
+    if (nnz_in > 0 && (!colind_in || !values_in)) { set_last_error("set_A_csr: null argument"); return MI355KKT_EINVAL; }
+    for (int64_t k = 0; k < nnz_in; ++k)
+        if (colind_in[k] < 0 || colind_in[k] >= n) { set_last_error("set_A_csr: column index out of range"); return MI355KKT_EINVAL; }
+    // canonical form: columns ascending within a row, repeated (row, column) entries summed in input order -- what the dense
+    // upload does with repeated triplets; the scatter kernels of the sparse engine assume one entry per (row, column)
+    std::vector<int64_t> rp((size_t)p + 1, 0), colind;
+    std::vector<double> values;
+    colind.reserve((size_t)nnz_in);
+    values.reserve((size_t)nnz_in);
+    {
+        std::vector<int64_t> ord;
+        for (int r = 0; r < p; ++r) {
+            const int64_t a = rowptr_in[r], b = rowptr_in[r + 1];
+            ord.resize((size_t)(b - a));
+            for (int64_t k = a; k < b; ++k) ord[(size_t)(k - a)] = k;
+            std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return colind_in[x] < colind_in[y]; });
+            for (size_t t = 0; t < ord.size(); ++t) {
+                const int64_t k = ord[t];
+                if (t > 0 && colind_in[k] == colind.back() && (int64_t)colind.size() > rp[r]) values.back() += values_in[k];
+                else { colind.push_back(colind_in[k]); values.push_back(values_in[k]); }
+            }
+            rp[(size_t)r + 1] = (int64_t)colind.size();
+        }
+    }
+    const int64_t* rowptr = rp.data();
+    const int64_t nnz = rp[p];
+    if (int e = bind(h)) return e;
     std::vector<int> ci((size_t)nnz), ri((size_t)nnz);
-    std::vector<int64_t> cp((size_t)n + 1, 0), rp(rowptr, rowptr + p + 1);
+    std::vector<int64_t> cp((size_t)n + 1, 0);
     std::vector<double> vc((size_t)nnz);
     for (int64_t k = 0; k < nnz; ++k) {
-        if (colind[k] < 0 || colind[k] >= n) { set_last_error("set_A_csr: column index out of range"); return MI355KKT_EINVAL; }
         ci[k] = (int)colind[k];
         ++cp[colind[k] + 1];
     }
@@ -641,7 +670,7 @@ int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr, const int64_t*
     if (nnz > 0) {
         KKT_HIP_CHECK(hipMemcpy(h->dAci, ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
         KKT_HIP_CHECK(hipMemcpy(h->dAri, ri.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
-        KKT_HIP_CHECK(hipMemcpy(h->dAv, values, sizeof(double) * nnz, hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(hipMemcpy(h->dAv, values.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
         KKT_HIP_CHECK(hipMemcpy(h->dAvc, vc.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
     }
     h->A_sparse = true;
@@ -728,6 +757,7 @@ int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) {
         KKT_HIP_CHECK(hipStreamSynchronize(h->cst));
         h->h_pending = false;
     }
+    h_unregister(h);                                       // the caller may free the buffer an earlier async call pinned
     if (!H) {
         h->dH = nullptr;
         return 0;
@@ -784,7 +814,9 @@ int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH)
 }
 int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH) {
     if (!h) return MI355KKT_EINVAL;
+    if (h->h_pending && h->cst) (void)hipStreamSynchronize(h->cst);
     h->h_pending = false;
+    h_unregister(h);                                       // header contract: a pinned host H is released by the next set_H_*
     h->dH = dH;
     h->ldH = ldH;
     h->hsym_valid = false;

@@ -301,7 +301,8 @@ class _Engine(object):
             return
         if H is None:
             _capi.check(self.L.mi355kkt_set_H_dense(self.h, None, 1), "set_H_dense")
-            self._H_ref = self._H_view = None
+            # the device holds no H now: the sparse-H shortcut below must not match the image uploaded before
+            self._H_tag = self._H_ref = self._H_view = None
             return
         hm, hn = _size(H)
         if hm != self.n or hn != self.n:

@@ -93,7 +93,8 @@ def _options(kwargs):
 
 
 def _resolve_kktsolver(kktsolver, dims, lp):
-    """None -> the reference's default (coneprog.py:458-462 / :1805-1809); strings are validated like :463-466 / :1810-1813;
+    """None -> the reference's default (coneprog.py:458-462 / :1805-1809); strings are validated like :463-466 / :1810-1813,
+    an explicit 'chol2' with second-order or semidefinite cones raises like misc.kkt_chol2 (misc.py:1381-1384);
     a callable is the documented plug-in API and is handed to the reference driver untouched (returns None here)."""
     if kktsolver is None:
         if dims['q'] or dims['s']:
@@ -103,6 +104,9 @@ def _resolve_kktsolver(kktsolver, dims, lp):
         valid = ('ldl', 'ldl2', 'qr', 'chol', 'chol2') if lp else ('ldl', 'ldl2', 'chol', 'chol2')
         if kktsolver not in valid:
             raise ValueError("'%s' is not a valid value for kktsolver" % kktsolver)
+        if kktsolver == 'chol2' and (dims['q'] or dims['s']):
+            raise ValueError("kktsolver option 'kkt_chol2' is implemented only for problems with no second-order or "
+                             "semidefinite cone constraints")
         return kktsolver
     return None
 
@@ -119,8 +123,6 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
     if ks_name is None:                        # a user kktsolver(W): the reference driver and the user's code, nothing of ours
         return solvers.conelp(c, G, h, dims, A=A, b=b, primalstart=primalstart, dualstart=dualstart, kktsolver=kktsolver,
                               **kwargs)
-    if ks_name == 'chol2' and (dims['q'] or dims['s']):
-        ks_name = 'chol'
     extra = set(kwargs) - {'options'}
     o, kktreg, debug = _options(kwargs)
     if device_loop and primalstart is None and dualstart is None and not extra \
@@ -152,8 +154,6 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
     ks_name = _resolve_kktsolver(kktsolver, dims, lp=False)
     if ks_name is None:                        # a user kktsolver(W): the reference driver and the user's code, nothing of ours
         return solvers.coneqp(P, q, G, h, dims, A=A, b=b, initvals=initvals, kktsolver=kktsolver, **kwargs)
-    if (dims['q'] or dims['s']) and ks_name == 'chol2':
-        ks_name = 'chol'                        # kkt_chol2 is LP-cone only (misc.py:1381-1384); the reference's own default here
     extra = set(kwargs) - {'options'}
     o, kktreg, debug = _options(kwargs)
     if device_loop and initvals is None and not extra and not debug \
@@ -162,6 +162,9 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
     Am = A if A is not None else spmatrix([], [], [], (0, n))
     ks = _kkt.kktsolver_qp(G, dims, Am, P, kind=ks_name, kktreg=kktreg)
     eng = ks.engine
+    # P is constant by the contract of coneqp (coneprog.py:1440-1477): the hook need not re-upload it at every factor(W, P)
+    const_H = _kkt.options.get('assume_constant_H')
+    _kkt.options['assume_constant_H'] = True
     try:
         eng._set_H(P)
         Gop, Aop, Pop = _operators(eng, dims)
@@ -170,6 +173,7 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
             kw = {'A': Aop, 'b': b}
         return solvers.coneqp(Pop, q, Gop, h, dims, initvals=initvals, kktsolver=ks, **kw, **kwargs)
     finally:
+        _kkt.options['assume_constant_H'] = const_H
         eng.close()
 
 

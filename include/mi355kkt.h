@@ -100,7 +100,9 @@ int mi355kkt_set_sparse_problem_aug(mi355kkt_solver* h, const int64_t* gcolptr, 
                                     const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues, int extra_rows);
 /* A (p x n) in CSR (rowptr[p+1], colind[nnz], values[nnz]) for the sparse engine: kept sparse on the device (CSR + its
  * transpose); the Schur complement K = A S^-1 A' (misc.py:1464-1487, cholmod.spsolve src/C/cholmod.c:583-654) is formed from
- * sparse right-hand sides, 256 rows of A per pass of the supernodal forward solve.  No dense copy of A exists. */
+ * sparse right-hand sides, 256 rows of A per pass of the supernodal forward solve.  No dense copy of A exists.
+ * rowptr[0] must be 0 and rowptr non-decreasing, column indices in [0, n) (else MI355KKT_EINVAL); columns of a row may come in
+ * any order, repeated (row, column) entries are summed -- the same matrix as the dense upload of the same triplets. */
 int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr, const int64_t* colind, const double* values);
 int mi355kkt_sparse_stats(const mi355kkt_solver* h, int64_t* nnzL, int* nsupernodes, int* nlevels, double* flops);
 /* the fill-reducing ordering chosen by the symbolic analysis (csrc/ordering.cpp): 1 nested dissection, 2 approximate

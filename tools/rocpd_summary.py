@@ -51,8 +51,25 @@ def pmc(fetch_db, write_db, substr, out, n, m):
     print(json.dumps(rec))
 
 
+def pmc_any(db, substr):
+    """every counter of a --pmc pass, summed over the dimensions of a dispatch, averaged over the dispatches of the kernel"""
+    cur = sqlite3.connect(db).cursor()
+    cols = [c[1] for c in cur.execute("pragma table_info('counters_collection')")]
+    namecol = "kernel_name" if "kernel_name" in cols else "name"
+    per = {}
+    for kname, cname, val, did in cur.execute("select %s, counter_name, value, dispatch_id from counters_collection" % namecol):
+        if substr in kname:
+            per.setdefault(cname, {}).setdefault(did, 0.0)
+            per[cname][did] += float(val)
+    out = {c: sum(v.values()) / max(1, len(v)) for c, v in per.items()}
+    out["_dispatches"] = max([len(v) for v in per.values()] or [0])
+    print(json.dumps({"kernel": substr, "db": db, "avg_per_dispatch": out}))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "pmcany":
+        pmc_any(sys.argv[2], sys.argv[3])
     else:
         pmc(*sys.argv[2:9])
