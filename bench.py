@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--mesh", default="grid", choices=["grid", "tet"],
                     help="--workload sparse: structured 7-point grid (default) or an unstructured tetrahedral mesh of k^3 nodes")
     ap.add_argument("--cpu-iters", type=int, default=2, help="reference CPU iterations timed (bounded sample)")
+    ap.add_argument("--no-side-workloads", action="store_true",
+                    help="headline line only: skip the short runs of BASELINE configs[2], [3]-class and [4] (one GPU) that the default "
+                         "N=1 line carries under `side_workloads`")
     return ap.parse_args()
 
 
@@ -126,6 +129,102 @@ def cpu_baseline(pr, W_np, n, m, iters):
             "host_cpus": ncpu, "iters_per_s": round(1e3 / ms, 4)}
 
 
+def _ref_modules():
+    """the real reference from oracle/_ref (cpu_baseline legs only)"""
+    from oracle import refloader
+    refloader.load()
+    from cvxopt import matrix, spmatrix, misc, solvers
+    solvers.options['show_progress'] = False
+    return matrix, spmatrix, misc, solvers
+
+
+def _set_host_threads(t):
+    import ctypes
+    mkl = _mkl()
+    if mkl is not None:
+        mkl.MKL_Set_Num_Threads(ctypes.c_int(int(t)))
+    os.environ["OMP_NUM_THREADS"] = str(int(t))
+
+
+def _best_threads():
+    return max(1, min(16, os.cpu_count() or 1))        # the dense thread sweep's optimum on the GPU boxes (16 of 256)
+
+
+def cpu_socp(pr, W_np, n, cdim):
+    """reference misc.kkt_chol (QR of A + dense potrf, misc.py:1213-1349) on the host: 1 factor(W) + 5 solves, same inputs"""
+    import numpy as np
+    matrix, spmatrix, misc, _ = _ref_modules()
+    t = _best_threads()
+    _set_host_threads(t)
+    G, A = matrix(pr['G']), spmatrix([], [], [], (0, n))
+    W = {'d': matrix(0.0, (0, 1)), 'di': matrix(0.0, (0, 1)), 'v': [matrix(np.asarray(v, dtype=float)) for v in W_np['v']],
+         'beta': [float(b) for b in W_np['beta']], 'r': [], 'rti': []}
+    factor = misc.kkt_chol(G, pr['dims'], A)
+    rng = np.random.default_rng(1)
+
+    def one():
+        t0 = time.perf_counter()
+        solve = factor(W)
+        for _ in range(5):
+            solve(matrix(rng.standard_normal(n)), matrix(0.0, (0, 1)), matrix(rng.standard_normal(cdim)))
+        return time.perf_counter() - t0
+    one()
+    ms = 1e3 * min(one(), one())
+    return {"value": round(ms, 2), "unit": "ms/iter (factor + 5 solves)", "cores": t, "kind": "reference",
+            "sample": "2 KKT iterations (best) of the same SOCP workload through the reference's misc.kkt_chol + MKL, same W",
+            "iters_per_s": round(1e3 / ms, 4)}
+
+
+def cpu_sparse(P_csc, G_csc, W_np, n):
+    """the reference's sparse branch of misc.kkt_chol2 (misc.py:1389-1487: its own sparse S assembly, cholmod.symbolic once,
+    cholmod.numeric + solves per iteration) on the host.  SuiteSparse is absent from the reference tree and this image: the
+    `cholmod` module is oracle/cholmod_shim.py (SuperLU in symmetric mode) -- said in the record."""
+    import numpy as np
+    import scipy.sparse as sp
+    matrix, spmatrix, misc, _ = _ref_modules()
+    t = _best_threads()
+    _set_host_threads(t)
+
+    def spm(M):
+        M = sp.coo_matrix(M)
+        return spmatrix(M.data.tolist(), M.row.tolist(), M.col.tolist(), M.shape)
+    G, H, A = spm(G_csc), spm(sp.tril(P_csc)), spmatrix([], [], [], (0, n))
+    dims = {'l': 2 * n, 'q': [], 's': []}
+    W = {'d': matrix(W_np['d']), 'di': matrix(W_np['di']), 'v': [], 'beta': [], 'r': [], 'rti': []}
+    factor = misc.kkt_chol2(G, dims, A)
+    rng = np.random.default_rng(1)
+    t0 = time.perf_counter()
+    solve = factor(W, H)     # ONE call (bounded sample): the shim's symbolic step is a no-op, so this is assembly + numeric factor
+    t_fac = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(2):
+        solve(matrix(rng.standard_normal(n)), matrix(0.0, (0, 1)), matrix(rng.standard_normal(2 * n)))
+    t_sol = time.perf_counter() - t0
+    ms = 1e3 * (t_fac + t_sol)
+    return {"value": round(ms, 1), "unit": "ms/iter (factor + 2 solves)", "cores": t, "kind": "reference",
+            "sample": "1 KKT iteration of the same box-QP through the reference's sparse kkt_chol2 branch; its cholmod module "
+                      "is the SciPy/SuperLU shim oracle/cholmod_shim.py (SuiteSparse CHOLMOD is not in the reference tree): "
+                      "an upper bound for what CHOLMOD's supernodal code would take on the same cores",
+            "factor_ms": round(1e3 * t_fac, 1), "solve_ms": round(1e3 * t_sol / 2, 1),
+            "iters_per_s": round(1e3 / ms, 4)}
+
+
+def cpu_batch(probs):
+    """reference solvers.coneqp (kktsolver default = chol2 + MKL) on a few problems of the batch, one after the other"""
+    import numpy as np
+    matrix, _, _, solvers = _ref_modules()
+    t = _best_threads()
+    _set_host_threads(t)
+    its, t0 = 0, time.perf_counter()
+    for pr in probs:
+        sol = solvers.coneqp(matrix(pr['P']), matrix(pr['q']), matrix(pr['G']), matrix(pr['h']))
+        its += sol['iterations']
+    el = time.perf_counter() - t0
+    return {"value": round(its / el, 2), "unit": "problem-iterations/s", "cores": t, "kind": "reference",
+            "sample": "%d of the batch's problems solved one after the other by the reference solvers.coneqp (chol2 + MKL): "
+                      "%d interior-point iterations in %.2f s" % (len(probs), its, el)}
+
+
 def _dist_setup(dry=False):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -182,10 +281,9 @@ def _timed(step, args, torch, dist):
     return elapsed
 
 
-def main_batch(args):
+def measure_batch(args, rank, world, local_rank, torch, dist, cpu=False):
     """configs[4] class: every rank owns `--batch` independent dense QPs (n=512, m=1024); a step = the whole
     device-resident coneqp solve of the rank's shard (no collective in the data path); value = problem-IPM-iterations/s."""
-    rank, world, local_rank, torch, dist = _dist_setup()
     import numpy as np
     from cvxopt_amd import synth
     from cvxopt_amd.batch import BatchKkt, pack_problems
@@ -199,18 +297,45 @@ def main_batch(args):
         res['r'] = k.coneqp(q, h)
     elapsed = _timed(step, args, torch, dist)
     its = int(res['r']['iterations'].sum())
+    lock = int(res['r'].get('lockstep iterations', 0)) if hasattr(res['r'], 'get') else 0
     if dist is not None:
         t = torch.tensor([its], dtype=torch.float64, device="cuda")
         dist.all_reduce(t)
         its = int(t.item())
+    k.close()
+    if rank != 0:
+        return None
+    # algorithmic work of one interior-point iteration of one problem: m n^2 (SYRK) + n^3 / 3 (Cholesky) +
+    # 2 solves x (4 m n + 2 n^2); finished problems are frozen, so only the problem-iterations actually taken count
+    flop_it = float(m) * n * n + float(n) ** 3 / 3.0 + 2.0 * (4.0 * m * n + 2.0 * n * n)
+    tf = its * args.steps * flop_it / elapsed / 1e12
+    out = {
+        "metric": "batched coneqp: problem-IPM-iterations/s (BASELINE configs[4] class)", "value": round(its * args.steps / elapsed, 1),
+        "unit": "problem-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%d independent dense QPs per GPU, n=%d, m=%d, whole coneqp solve resident on the device"
+                               % (B, n, m), "all_optimal": bool(np.all(res['r']['status'] == 'optimal')),
+                   "problem_iterations_per_step": its // max(1, world), "lockstep_iterations": lock},
+        "roofline": {"kernel": "whole lock-step interior-point iteration of the batch (batched SYRK + Cholesky + solves + residual "
+                               "products)", "bound": "mfma", "achieved": round(tf / max(1, world), 2), "peak": FP64_MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(tf / max(1, world) / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "flops_per_problem_iteration": flop_it,
+                     "note": "useful flops only: m n^2 + n^3/3 + 2 (4 m n + 2 n^2) per problem-iteration taken; per GPU"}}
+    if cpu:
+        try:
+            out["cpu_baseline"] = cpu_batch(probs[:4])
+            out["speedup_vs_cpu"] = round(out["value"] / max(1, world) / out["cpu_baseline"]["value"], 1)
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)}
+    return out
+
+
+def main_batch(args):
+    rank, world, local_rank, torch, dist = _dist_setup()
+    out = measure_batch(args, rank, world, local_rank, torch, dist, cpu=(not args.no_cpu_baseline and world == 1))
     if rank == 0:
-        print(json.dumps({
-            "metric": "batched coneqp: problem-IPM-iterations/s (BASELINE configs[4] class)", "value": round(its * args.steps / elapsed, 1),
-            "unit": "problem-iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d independent dense QPs per GPU, n=%d, m=%d, whole coneqp solve resident on the device"
-                                   % (B, n, m), "all_optimal": bool(np.all(res['r']['status'] == 'optimal'))}}))
+        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -359,10 +484,9 @@ def main_sharded(args):
         dist.destroy_process_group()
 
 
-def main_sparse(args):
+def measure_sparse(args, rank, world, local_rank, torch, dist, cpu=False):
     """configs[3] class stand-in: P = 3-D 7-point Laplacian + 1e-2 I, box constraints; a step = 1 sparse
     factor + 2 solves through the hook-level engine with inputs resident; replicas over ranks."""
-    rank, world, local_rank, torch, dist = _dist_setup()
     import numpy as np
     import scipy.sparse as sp
     from cvxopt_amd import kkt, synth, _capi
@@ -402,6 +526,7 @@ def main_sparse(args):
             eng.solve_device(dx.ptr, d_y.ptr, dz.ptr)
         eng.sync()
     elapsed = _timed(step, args, torch, dist)
+    out = None
     if rank == 0:
         st = eng.sparse_stats()
         tm = eng.timings()
@@ -414,7 +539,7 @@ def main_sparse(args):
                     "solve": {"bound": "hbm", "achieved": round(s_gb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(s_gb / HBM_PEAK_GBS, 4), "ms": round(tm["solve_ms"], 3),
                               "bytes": 2.0 * st["nnzL"] * 8.0}}
-        print(json.dumps({
+        out = {
             "roofline": roofline, "phases_ms": {k: round(v, 3) for k, v in tm.items()},
             "parity_note": "CHOLMOD (SuiteSparse, absent from the reference tree) is the reference's sparse factor: its entries are "
                            "ordering-dependent and unpinned; parity for this class is on solutions / iterates (tests/test_gpu_sparse.py)",
@@ -426,16 +551,31 @@ def main_sparse(args):
                                    "the ssget-1288 class (no network)" % (what, n, 2 * n), "replicas": world,
                        "ordering": {1: "nested dissection", 2: "approximate minimum degree"}.get(st.get("ordering"), "?"),
                        "nnzL": st["nnzL"], "supernodes": st["supernodes"], "levels": st["levels"], "flops_estimate": st["flops"],
-                       "symbolic_plus_first_factor_s": round(t_sym, 3)}}))
+                       "symbolic_plus_first_factor_s": round(t_sym, 3)}}
+        if cpu:
+            try:
+                out["cpu_baseline"] = cpu_sparse(P, G, W, n)
+                out["speedup_vs_cpu"] = round(out["cpu_baseline"]["value"] / out["ms_per_step"], 1)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+    eng.close()
+    return out
+
+
+def main_sparse(args):
+    rank, world, local_rank, torch, dist = _dist_setup()
+    out = measure_sparse(args, rank, world, local_rank, torch, dist, cpu=(not args.no_cpu_baseline and world == 1))
+    if rank == 0:
+        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main_socp(args):
+def measure_socp(args, rank, world, local_rank, torch, dist, cpu=False, e2e=True):
     """configs[2]: SOCP, n=2048, 1024 cones of dimension 8 (cdim 8192); a step = what one conelp iteration asks of the
     kktsolver hook with second-order cones: 1 factor(W) + 5 solves (refinement 1: (x1,y1,z1) + 2 right-hand sides x 2)."""
-    rank, world, local_rank, torch, dist = _dist_setup()
+    import ctypes as C
     import numpy as np
     from cvxopt_amd import kkt, synth, _capi
     import cvxopt_amd
@@ -462,40 +602,64 @@ def main_socp(args):
         eng.sync()
     elapsed = _timed(step, args, torch, dist)
     tm = eng.timings()
-    e2e = None
-    scale_rl = None
+    out = None
     if rank == 0:
-        try:        # the Nesterov-Todd scaling step alone (W^-T G on the cone rows): HBM-bound, 2 * 8 * cdim * n algorithmic bytes
-            import ctypes as C
-            dG = _capi.DeviceBuffer.from_array(pr['G'])
+        def scale_roofline(ncols, note):
+            # the Nesterov-Todd scaling step alone (Gs = W^-T G on the cone rows): HBM-bound, 2 * 8 * cdim * ncols algorithmic bytes
+            Gd = _capi.DeviceBuffer(8 * cdim * ncols)
+            for c0 in range(0, ncols, n):                  # the workload's G, repeated along the columns
+                _capi.check(_capi.lib().mi355kkt_memcpy_h2d(Gd.ptr + 8 * cdim * c0, pr['G'].ctypes.data,
+                                                            8 * cdim * min(n, ncols - c0)), "memcpy_h2d")
             qarr = (C.c_int * ncones)(*([r] * ncones))
             ms = C.c_float()
             best = 1e30
-            for _ in range(5):
-                _capi.check(_capi.lib().mi355kkt_op_cone_scale(0, ncones, qarr, C.c_void_p(dG.ptr), cdim, n, None,
+            for _ in range(4):                             # in place: W^-T applied four times over (magnitudes stay far from overflow)
+                _capi.check(_capi.lib().mi355kkt_op_cone_scale(0, ncones, qarr, C.c_void_p(Gd.ptr), cdim, ncols, None,
                                                                 C.c_void_p(d_v.ptr), C.c_void_p(d_beta.ptr), C.byref(ms)), "cone_scale")
                 best = min(best, ms.value)
-            byts = 2.0 * 8.0 * cdim * n
+            byts = 2.0 * 8.0 * cdim * ncols
             gbs = byts / (best * 1e-3) / 1e9
-            scale_rl = {"kernel": "scale_q_* (Gs = W^-T G, second-order cones, in HBM)", "bound": "hbm", "achieved": round(gbs, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel_ms": round(best, 4), "bytes_per_launch": byts}
+            return {"kernel": "scale_q_* (Gs = W^-T G, second-order cones, in HBM)", "bound": "hbm", "achieved": round(gbs, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel_ms": round(best, 4), "bytes_per_launch": byts, "columns": ncols, "note": note}
+        try:
+            # 8 x the workload's column count: 2 x 1.07 GB through the kernel, far beyond the 256 MB Infinity Cache -- the HBM figure
+            scale_rl = scale_roofline(8 * n, "same cones, %d columns: 2.1 GB of traffic per launch, past the 256 MB Infinity Cache" % (8 * n))
+            scale_rl["at_workload_size"] = scale_roofline(n, "the workload's own G (%d columns, 268 MB in + out): Infinity-Cache "
+                                                             "assisted, not an HBM figure" % n)
         except Exception as e:
             scale_rl = {"error": repr(e)}
-        for _ in range(2):
-            t1 = time.perf_counter()
-            sol = cvxopt_amd.conelp_device(pr['c'], pr['G'], pr['h'], pr['dims'])
-            t1 = time.perf_counter() - t1
-        e2e = {"solver": "device-resident conelp loop (mi355kkt_conelp)", "status": sol['status'], "iterations": sol['iterations'],
-               "seconds": round(t1, 4)}
-        print(json.dumps({
+        ipm = None
+        if e2e:
+            for _ in range(2):
+                t1 = time.perf_counter()
+                sol = cvxopt_amd.conelp_device(pr['c'], pr['G'], pr['h'], pr['dims'])
+                t1 = time.perf_counter() - t1
+            ipm = {"solver": "device-resident conelp loop (mi355kkt_conelp)", "status": sol['status'], "iterations": sol['iterations'],
+                   "seconds": round(t1, 4)}
+        out = {
             "metric": "SOCP KKT factor+solve ms/iter (BASELINE configs[2])", "value": round(world * args.steps / elapsed, 3),
             "unit": "KKT iterations/s (1 factor + 5 solves each)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "conelp SOCP n=%d, %d second-order cones of dimension %d (cdim %d); hook = 1 factor(W) + 5 "
                                    "solve(x,y,z) per step, inputs resident in HBM" % (n, ncones, r, cdim), "replicas": world},
-            "roofline": scale_rl, "phases_ms": {k: round(v, 3) for k, v in tm.items()}, "ipm_end_to_end": e2e}))
+            "roofline": scale_rl, "phases_ms": {k: round(v, 3) for k, v in tm.items()}, "ipm_end_to_end": ipm}
+        if cpu:
+            try:
+                out["cpu_baseline"] = cpu_socp(pr, W, n, cdim)
+                out["speedup_vs_cpu"] = round(out["cpu_baseline"]["value"] / out["ms_per_step"], 1)
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+    eng.close()
+    return out
+
+
+def main_socp(args):
+    rank, world, local_rank, torch, dist = _dist_setup()
+    out = measure_socp(args, rank, world, local_rank, torch, dist, cpu=(not args.no_cpu_baseline and world == 1))
+    if rank == 0:
+        print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -730,6 +894,27 @@ def main():
                     out["speedup_vs_cpu_at_hook"] = round(out["cpu_baseline"]["value"] / hook["ms_per_step"], 2)
             except Exception as e:                     # the baseline must never take the GPU number down
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and not args.no_side_workloads and (n, m) == (8192, 16384):
+            # the other BASELINE configs on this GPU, short runs outside the headline's timed region: each record is the line
+            # `--workload socp|sparse|batch` prints (ms_per_step, roofline, phases) + a bounded cpu_baseline of the reference
+            eng.close()
+            del dP, d_di, rhs
+            side = {}
+            sa = argparse.Namespace(**vars(args))
+            sa.steps, sa.warmup = 8, 2
+            want_cpu = not args.no_cpu_baseline
+            for name, fn, kw in (("socp_configs2", measure_socp, {"e2e": True}), ("sparse_configs3_class", measure_sparse, {}),
+                                 ("batch_configs4_one_gpu", measure_batch, {})):
+                t1 = time.perf_counter()
+                try:
+                    if name.startswith("batch"):
+                        sa.steps, sa.warmup = 3, 1
+                    side[name] = fn(sa, 0, 1, local_rank, torch, None, cpu=want_cpu, **kw)
+                except Exception as e:                 # a side workload must never take the headline down
+                    side[name] = {"error": repr(e)}
+                if isinstance(side[name], dict):
+                    side[name]["wall_s"] = round(time.perf_counter() - t1, 2)
+            out["side_workloads"] = side
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -256,6 +256,221 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
     }
 }
 
+// ===================================================================================================
+// The same SYRK with NO LDS and NO barrier: every wave loads the MFMA operand fragments of its 64 x 64 tile
+// straight from global memory (L1 / L2) into registers, a few 8-deep chunks of k ahead of their use.
+//
+//   v_mfma_f64_16x16x4_f64 wants lane (li = lane & 15, lk = lane >> 4) to hold X[row li][k lk].  Which k the four lane
+//   groups stand for is free as long as both operands agree, so a chunk of 8 k is mapped  k = kc + 2 lk + g  (g = 0, 1: the
+//   chunk's two MFMA groups): lane (li, lk) needs 16 contiguous bytes G[kc + 2 lk .. + 1][column li] per 16-column block —
+//   ONE global_load_dwordx4 per block and chunk, and the four lk groups of a column read one contiguous 64-byte piece.
+//   Per wave and chunk: 4 + 4 operand loads (+ 1 for di) against 32 MFMAs (2048 matrix-pipe cycles); no ds_write, no
+//   ds_read, no s_barrier — the waves of a workgroup never wait for each other, so nothing but a late load can idle the
+//   matrix pipe.  The price is register space (PF + 1 chunks of fragments next to the 128 accumulator registers) and twice
+//   the L1 requests of the LDS version (each operand panel is loaded by the two waves that share it).
+//   di rides on the fragments (both operands are multiplied, like the reference's (di G)'(di G), misc.py:1418-1422).
+//   Columns beyond n are clamped to n - 1 (their results are never stored), a last partial chunk is loaded from clamped
+//   addresses with zero weights.
+// ===================================================================================================
+template <bool SCALED, int TA, int NS, int SC, int SN, int LPQ>
+__device__ __forceinline__ void direct_chunk(d4 (&acc)[TA][4], d2 (&fa)[NS][TA], d2 (&fb)[NS][4], d2 (&fw)[NS],
+                                             const char* __restrict__ pJ, const char* __restrict__ pI,
+                                             const char* __restrict__ pw, const uint32_t (&offJ)[TA],
+                                             const uint32_t (&offI)[4], uint32_t offw) {
+    if (SCALED) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fb[SC][u] *= fw[SC];
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int t = 0; t < TA; ++t) {
+            if (SCALED && g == 0) fa[SC][t] *= fw[SC];       // J block t is first needed here (its load was issued last)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[t][u] = MFMA_F64(fa[SC][t][g], fb[SC][u][g], acc[t][u]);
+            // LPQ loads of the chunk PF ahead after every MFMA quad (front-loaded for LPQ > 1: the later a load is issued, the
+            // closer its first use), in the order of first use: the four I blocks (every quad needs them all), the weights,
+            // then the J blocks (block t is first used by quad t)
+            const int q0 = (g * TA + t) * LPQ;
+#pragma unroll
+            for (int q = q0; q < q0 + LPQ; ++q) {
+                if (q < 4) {
+                    const d2u v = *reinterpret_cast<const d2u*>(pI + offI[q]);
+                    fb[SN][q] = d2{v.x, v.y};
+                    if (q == 0 && SCALED) {
+                        const d2u w = *reinterpret_cast<const d2u*>(pw + offw);
+                        fw[SN] = d2{w.x, w.y};
+                    }
+                } else if (q - 4 < TA) {
+                    const d2u v = *reinterpret_cast<const d2u*>(pJ + offJ[q - 4]);
+                    fa[SN][q - 4] = d2{v.x, v.y};
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
+template <int TA>
+__device__ __forceinline__ void syrk_store_tile(const SyrkItem& it, const d4 (&acc)[TA][4], int n, int i0, int j0, int wi,
+                                                int wj, int lane, double* __restrict__ C, int64_t ldc,
+                                                const double* __restrict__ P, int64_t ldp, double* __restrict__ slabs) {
+    // lane holds D[row=(lane>>4)+4r -> j][col=lane&15 -> i]
+    const int li = lane & 15, lq = lane >> 4;
+    if (it.slot < 0) {
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = i0 + wi * 64 + u * 16 + li;
+                    const int j = j0 + wj * 64 + t * 16 + lq + 4 * r;
+                    if (i < n && j < n && i >= j) {
+                        double v = acc[t][u][r];
+                        if (P) v += P[i + (int64_t)j * ldp];
+                        C[i + (int64_t)j * ldc] = v;
+                    }
+                }
+    } else {
+        double* S = slabs + (int64_t)it.slot * TILE * TILE;
+#pragma unroll
+        for (int t = 0; t < TA; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int il = wi * 64 + u * 16 + li;
+                    const int jl = wj * 64 + t * 16 + lq + 4 * r;
+                    S[il + jl * TILE] = acc[t][u][r];
+                }
+    }
+}
+
+// TA = 4: 256 threads, four waves of 64 x 64 (two waves per SIMD).  (TA = 8 — 128 threads, two waves of 64 rows x 128 columns, ONE
+// wave per SIMD with the whole 512-entry register file — compiles, but hipcc's register allocator answers the 256 accumulator
+// registers with ~800 accvgpr moves and 86 scratch accesses per 192 MFMAs in the loop: not instantiated.)
+template <bool SCALED, int TA, int PF, int LPQ>
+__global__ __launch_bounds__(TA == 4 ? 256 : 128, TA == 4 ? 2 : 1) void syrk_tn_direct_kernel(
+    const double* __restrict__ G, int64_t ldg, const double* __restrict__ di, int n,
+    const SyrkItem* __restrict__ items, double* __restrict__ C, int64_t ldc, const double* __restrict__ P, int64_t ldp,
+    double* __restrict__ slabs, BatchStrides bs) {
+    constexpr int NS = PF + 1;
+    const SyrkItem it = items[blockIdx.x];
+    {
+        const int64_t bz = blockIdx.z;
+        G += bz * bs.a;
+        if (SCALED) di += bz * bs.b;
+        C += bz * bs.c;
+        if (P) P += bz * bs.d;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wj = TA == 4 ? (wave >> 1) : 0, wi = wave & 1;
+    const int li = lane & 15, lk = lane >> 4;
+    const int i0 = it.ti * TILE, j0 = it.tj * TILE;
+
+    d4 acc[TA][4];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = d4{0.0, 0.0, 0.0, 0.0};
+
+    const int klen = it.k1 - it.k0;
+    const int nfull = klen >> 3, ktail = klen & 7;
+    const char* baseJ = reinterpret_cast<const char*>(G + (int64_t)j0 * ldg + it.k0);
+    const char* baseI = reinterpret_cast<const char*>(G + (int64_t)i0 * ldg + it.k0);
+    const char* basew = SCALED ? reinterpret_cast<const char*>(di + it.k0) : nullptr;
+    uint32_t offJ[TA], offI[4];
+#pragma unroll
+    for (int t = 0; t < TA; ++t) {
+        const int cj = min(j0 + wj * 64 + t * 16 + li, n - 1) - j0;
+        offJ[t] = (uint32_t)(((int64_t)cj * ldg + 2 * lk) * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int ci = min(i0 + wi * 64 + u * 16 + li, n - 1) - i0;
+        offI[u] = (uint32_t)(((int64_t)ci * ldg + 2 * lk) * 8);
+    }
+    const uint32_t offw = (uint32_t)(2 * lk * 8);
+
+    d2 fa[NS][TA], fb[NS][4], fw[NS];
+    if (nfull > 0) {
+        // prologue: chunks 0 .. PF-1 (indices clamped: a short tile reloads its last chunk, harmless)
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int64_t cb = (int64_t)min(s, nfull - 1) * 64;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const d2u b = *reinterpret_cast<const d2u*>(baseI + cb + offI[u]);
+                fb[s][u] = d2{b.x, b.y};
+            }
+#pragma unroll
+            for (int t = 0; t < TA; ++t) {
+                const d2u a = *reinterpret_cast<const d2u*>(baseJ + cb + offJ[t]);
+                fa[s][t] = d2{a.x, a.y};
+            }
+            if (SCALED) {
+                const d2u w = *reinterpret_cast<const d2u*>(basew + cb + offw);
+                fw[s] = d2{w.x, w.y};
+            }
+        }
+        const int last = nfull - 1;
+        int c = 0;
+#define DIRECT_STEP(SC)                                                                                           \
+        {                                                                                                         \
+            const int64_t cb = (int64_t)min(c + (SC) + PF, last) * 64;                                            \
+            direct_chunk<SCALED, TA, NS, (SC), ((SC) + PF) % NS, LPQ>(acc, fa, fb, fw, baseJ + cb, baseI + cb,         \
+                                                                 SCALED ? basew + cb : nullptr, offJ, offI, offw); \
+        }
+        for (; c + NS <= nfull; c += NS) {
+            DIRECT_STEP(0)
+            DIRECT_STEP(1)
+            if (NS > 2) DIRECT_STEP(2 % NS)
+            if (NS > 3) DIRECT_STEP(3 % NS)
+        }
+        if (c < nfull) DIRECT_STEP(0)
+        if (c + 1 < nfull) DIRECT_STEP(1)
+        if (NS > 3 && c + 2 < nfull) DIRECT_STEP(2 % NS)
+#undef DIRECT_STEP
+    }
+    if (ktail) {
+        // last partial chunk: addresses clamped into the range, rows >= k1 get weight zero
+        const int kc = nfull * 8 + 2 * lk;                    // this lane's first k inside [0, klen)
+        const bool v0 = kc < klen, v1 = kc + 1 < klen;
+        const int64_t kb = (int64_t)max(0, min(kc, klen - 2)) * 8 - (int64_t)(2 * lk) * 8;   // the offsets already carry 2 lk
+        const bool shifted = v0 && !v1;                      // the pair was moved down by one row: its .y is row kc
+        d2 w = {0.0, 0.0};
+        if (SCALED) {
+            if (v0) w.x = di[it.k0 + kc];
+            if (v1) w.y = di[it.k0 + kc + 1];
+        } else {
+            w.x = v0 ? 1.0 : 0.0;
+            w.y = v1 ? 1.0 : 0.0;
+        }
+        auto fetch = [&](const char* base, uint32_t off) -> d2 {
+            d2u a;
+            if (klen >= 2) {
+                a = *reinterpret_cast<const d2u*>(base + kb + off);
+                if (shifted) a.x = a.y;
+            } else {                                          // a single row in the range
+                a.x = a.y = *reinterpret_cast<const double*>(base + off - (int64_t)(2 * lk) * 8);
+            }
+            return d2{a.x * w.x, a.y * w.y};
+        };
+        d2 ta[TA], tb[4];
+#pragma unroll
+        for (int t = 0; t < TA; ++t) ta[t] = fetch(baseJ, offJ[t]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tb[u] = fetch(baseI, offI[u]);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int t = 0; t < TA; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[t][u] = MFMA_F64(ta[t][g], tb[u][g], acc[t][u]);
+    }
+    syrk_store_tile<TA>(it, acc, n, i0, j0, wi, wj, lane, C, ldc, P, ldp, slabs);
+}
+
 // Deterministic fix-up for split tiles: C = P + slab[first] + slab[first+1] + ...  (fixed order)
 __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkItem* __restrict__ tiles, int n,
                                                           const double* __restrict__ slabs,
@@ -376,6 +591,19 @@ void free_syrk_plan(SyrkPlan& plan) {
 }
 
 static constexpr size_t kGemmLds = sizeof(double) * 4 * STAGE_DOUBLES;   // 73,728 B
+
+// 0: LDS-staged syrk_tn_kernel, otherwise a syrk_tn_direct_kernel variant (waves' tile shape, chunks of look-ahead)
+static int syrk_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MI355KKT_SYRK");
+        v = 0;
+        if (e && !strcmp(e, "direct411")) v = 411;   // one chunk ahead, one load after every MFMA quad
+        if (e && !strcmp(e, "direct412")) v = 412;   // one chunk ahead, the loads front-loaded two per quad
+        if (e && !strcmp(e, "direct414")) v = 414;   // one chunk ahead, four loads per quad (all nine within the first three quads)
+    }
+    return v;
+}
 static constexpr size_t kGemmLdsWide = 84 * 1024;                        // > 80 KiB: one workgroup per CU
 
 int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const double* di, double* C,
@@ -394,8 +622,32 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
         set_last_error("launch_syrk_scaled: batched launch needs an unsplit plan");
         return -1;
     }
-    hipLaunchKernelGGL(syrk_tn_kernel, dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di, plan.n,
-                       fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs);
+    // $MI355KKT_SYRK: "lds" = the LDS-staged kernel, "direct411" / "direct412" / "direct414" = the barrier-free register kernels
+    const int variant = syrk_variant();
+    const bool off_ok = (int64_t)(TILE - 1) * ldg * 8 + 64 < (int64_t)UINT32_MAX;   // 32-bit lane offsets inside a tile
+    if (variant != 0 && off_ok) {
+        const dim3 grid(plan.nitems, 1, nbatch);
+#define LAUNCH_DIRECT(SC_, PF_, LPQ_)                                                                                     \
+        hipLaunchKernelGGL((syrk_tn_direct_kernel<SC_, 4, PF_, LPQ_>), grid, dim3(256), 0, st, G, ldg, di, plan.n, plan.d_items, C, \
+                           ldc, P, ldp, plan.d_slabs, bs)
+        if (di) {
+            switch (variant) {
+                case 411: LAUNCH_DIRECT(true, 1, 1); break;
+                case 414: LAUNCH_DIRECT(true, 1, 4); break;
+                default: LAUNCH_DIRECT(true, 1, 2); break;
+            }
+        } else {
+            switch (variant) {
+                case 411: LAUNCH_DIRECT(false, 1, 1); break;
+                case 414: LAUNCH_DIRECT(false, 1, 4); break;
+                default: LAUNCH_DIRECT(false, 1, 2); break;
+            }
+        }
+#undef LAUNCH_DIRECT
+    } else {
+        hipLaunchKernelGGL(syrk_tn_kernel, dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di, plan.n,
+                           fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs);
+    }
     KKT_HIP_CHECK(hipGetLastError());
     if (kernel_events) KKT_HIP_CHECK(hipEventRecord(kernel_events[1], st));
     if (plan.nsplit_tiles) {

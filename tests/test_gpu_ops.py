@@ -18,6 +18,10 @@ def dev(capi, a):
 @pytest.mark.parametrize("n,m,use_di,use_H", [
     (128, 256, True, True), (200, 333, True, True), (129, 17, True, False), (384, 1000, False, True),
     (1000, 2048, True, True), (64, 5000, True, False), (1, 7, True, True), (300, 0, True, True),
+    # contraction lengths around the 8-deep chunks of the register-staged kernel: a single row, one chunk exactly, one chunk
+    # plus one row, even / odd chunk counts with and without a remainder
+    (5, 1, True, True), (70, 8, True, False), (130, 9, False, True), (70, 16, True, True), (70, 24, True, False),
+    (260, 31, True, True), (140, 2, False, False),
 ])
 def test_syrk_scaled_matches_numpy(capi, n, m, use_di, use_H):
     rng = np.random.default_rng(n * 7 + m)

@@ -194,3 +194,16 @@ def test_cvxprog_wrappers_bind_the_gpu_factories_for_the_call_only(ref_cvxopt, m
     with pytest.raises(ArithmeticError):
         gs.cp('F')
     assert {n: getattr(misc, n) for n in before} == before
+
+
+def test_explicit_chol2_with_second_order_or_semidefinite_cones_raises_like_the_reference():
+    """misc.kkt_chol2 raises ValueError for q / s cones (misc.py:1381-1384); only the DEFAULT resolves to qr / chol"""
+    from cvxopt_amd import solvers as S
+    for dims in ({'l': 2, 'q': [3], 's': []}, {'l': 0, 'q': [], 's': [2]}):
+        for lp in (True, False):
+            with pytest.raises(ValueError):
+                S._resolve_kktsolver('chol2', dims, lp)
+            assert S._resolve_kktsolver(None, dims, lp) == ('qr' if lp else 'chol')
+    assert S._resolve_kktsolver('chol2', {'l': 3, 'q': [], 's': []}, True) == 'chol2'
+    with pytest.raises(ValueError):
+        S._resolve_kktsolver('qr', {'l': 3, 'q': [], 's': []}, False)
