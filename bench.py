@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=512, help="problems per GPU for --workload batch")
     ap.add_argument("--total-batch", type=int, default=4096, help="problems in the whole job for --workload sharded")
     ap.add_argument("--dry-run", action="store_true", help="--gpus N plumbing check on CPU (gloo, NumPy, tiny batch)")
+    ap.add_argument("--nsub", type=int, default=4, help="--workload sharded: sub-batches per rank the scatter / solve / gather is "
+                                                        "pipelined over (1 = scatter everything, then solve, then gather)")
     ap.add_argument("--grid", type=int, default=46, help="k for the k^3 Laplacian of --workload sparse")
     ap.add_argument("--cone-dim", type=int, default=8, help="--workload socp: dimension of each of the 1024 second-order cones")
     ap.add_argument("--sdp-order", type=int, default=100, help="--workload sdp: order of the semidefinite block")
@@ -383,7 +385,7 @@ def main_sharded(args):
     gather of x, s, z, objectives, status (RCCL), everything inside the timed region.  Strong scaling: the batch is fixed."""
     rank, world, local_rank, torch, dist = _dist_setup(dry=args.dry_run)
     import numpy as np
-    from cvxopt_amd.batch import coneqp_batch_sharded, coneqp_batch, BatchKkt
+    from cvxopt_amd.batch import ShardedBatch, coneqp_batch, BatchKkt
     dry = args.dry_run
     B = args.total_batch if not dry else max(world * 2, 6)
     n, m = (512, 1024) if not dry else (12, 20)
@@ -419,9 +421,13 @@ def main_sharded(args):
     if dry:
         HostKkt = _host_kkt_for_dry_run()
         local = lambda P_, q_, G_, h_, **kw: coneqp_batch(P_, q_, G_, h_, kkt=HostKkt(G_, P_))
+    # persistent per-rank state (receive buffers, one engine per sub-batch): created once, OUTSIDE the timed steps
+    sb = ShardedBatch(B, n, m, True, root=0, nsub=args.nsub, local_solver=local)
+    phase = []
 
     def step():
-        res['r'] = coneqp_batch_sharded(P, q, Gt, h, root=0, local_solver=local, return_device=not dry)
+        res['r'] = sb.solve(P, q, Gt, h, return_device=not dry)
+        phase.append(dict(sb.last_timings))
 
     def sync():
         if not dry:
@@ -431,6 +437,7 @@ def main_sharded(args):
     for _ in range(args.warmup):
         step()
     sync()
+    del phase[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -440,6 +447,13 @@ def main_sharded(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dry else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # per-phase wall time of the step on every rank (mean over the timed steps), gathered as plain objects outside the timing
+    keys = ("scatter_exposed", "scatter_all", "upload", "solve", "gather_exposed", "total")
+    mine = {k: (sum(p_[k] for p_ in phase) / max(1, len(phase))) for k in keys}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     if rank == 0:
         r = res['r']
         its = int(np.asarray(r['iterations']).sum())
@@ -456,25 +470,40 @@ def main_sharded(args):
                                    % (B, n, m, "gloo" if dry else "RCCL", "gloo" if dry else "RCCL"),
                        "problems": B, "problems_per_rank": [b - a for a, b in __import__("cvxopt_amd.batch", fromlist=["x"]).shard_bounds(B, world)],
                        "problem_iterations": its, "all_optimal": all_opt,
-                       "lockstep_iterations_root": int(r.get('lockstep iterations', 0))},
+                       "lockstep_iterations_root": int(r.get('lockstep iterations', 0)), "sub_batches": sb.nsub},
+            # where a step spends its time (ms, mean over the timed steps): scatter_ms = until the first sub-batch was complete on
+            # the slowest rank (the exposed part of the pipelined scatter), solve_ms = the slowest rank's solves (+ the device-to-
+            # device upload into its engines), gather_ms = after the last solve until the root holds everything
+            "scatter_ms": round(max(p_["scatter_exposed"] for p_ in per_rank), 3),
+            "solve_ms": round(max(p_["solve"] + p_["upload"] for p_ in per_rank), 3),
+            "gather_ms": round(per_rank[0]["gather_exposed"], 3),
+            "phases_ms_per_rank": [{k: round(v, 3) for k, v in p_.items()} for p_ in per_rank],
         }
         if dry:
             out["dry_run"] = True
             out["note"] = "no GPU visible: gloo/NumPy plumbing check of the N-rank scatter-solve-gather path, NOT a measurement"
         else:
-            # the single-GPU point of the same curve, measured in this run on the root (outside the timed region)
+            # the single-GPU point of the same curve, measured in this run on the root (outside the timed region) and paying the
+            # same per-step costs as a rank of the sharded run: a persistent engine, the device-to-device upload of the problem
+            # data into it, the device-resident solve -- only the collectives are missing
             try:
-                kk = BatchKkt(Gt, P, device=local_rank)
-                kk.coneqp(q, h)
+                sb.close()
+                kk = BatchKkt(shape=(B, n, m), device=local_rank)
+
+                def one():
+                    kk.set_problem(Gt, P)
+                    return kk.coneqp(q, h)
+                one()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                r1 = kk.coneqp(q, h)
+                r1 = one()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter() - t1
                 kk.close()
                 its1 = int(r1['iterations'].sum().item())
                 out["single_gpu_reference"] = {"ms_per_step": round(1e3 * t1, 3), "value": round(its1 / t1, 1),
-                                               "note": "the same %d problems solved by the root GPU alone (already resident, no scatter)" % B}
+                                               "note": "the same %d problems solved by the root GPU alone: persistent engine, upload "
+                                                       "of the resident problem data into it + solve per step (no collectives)" % B}
                 out["speedup_vs_1gpu"] = round((1e3 * t1) / ms, 3)
             except Exception as e:
                 out["single_gpu_reference"] = {"error": repr(e)}

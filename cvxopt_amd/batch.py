@@ -33,23 +33,26 @@ class BatchKkt(object):
     second-order cones: Gt is then (B, n, cdim), cdim = nl + sum(q), and the engine works like the reference's kkt_chol
     per problem (Gs_b = W_b^-T G_b materialised)."""
 
-    def __init__(self, Gt, P=None, device=0, At=None, dims=None):
+    def __init__(self, Gt=None, P=None, device=0, At=None, dims=None, shape=None, p=None):
+        """Gt (B, n, m) [+ P (B, n, n), At (B, n, p)]: create the handle and upload the problems.  Gt = None with shape = (B, n, m)
+        [and p]: create the handle only -- a persistent engine whose problem data arrives later through `set_problem` (the
+        sharded batch: one handle per rank for the lifetime of the job, the ~GB allocations happen once)."""
         self.L = _capi.lib()
         if _capi.device_count() <= 0:
             raise RuntimeError("cvxopt_amd.batch: no HIP device visible (there is no CPU fallback)")
-        on_device = hasattr(Gt, "data_ptr")                       # torch CUDA tensors: the data is already in HBM
-        if on_device:
-            if not (Gt.is_cuda and Gt.is_contiguous() and Gt.dtype.is_floating_point and Gt.element_size() == 8):
-                raise TypeError("Gt must be a contiguous float64 CUDA tensor")
+        if Gt is None:
+            if shape is None:
+                raise TypeError("BatchKkt: Gt or shape = (B, n, m) is required")
+            self.B, self.n, self.m = (int(v) for v in shape)
+        elif hasattr(Gt, "data_ptr"):
             device = Gt.device.index if Gt.device.index is not None else device
             self.B, self.n, self.m = (int(v) for v in Gt.shape)
-            gptr = Gt.data_ptr()
         else:
             Gt = np.ascontiguousarray(Gt, dtype=np.float64)
             self.B, self.n, self.m = Gt.shape
-            gptr = Gt.ctypes.data
+        self.device = device
         h = C.c_void_p()
-        self.p = 0 if At is None else int(At.shape[2])
+        self.p = int(p) if p is not None else (0 if At is None else int(At.shape[2]))
         self.q = [int(k) for k in (dims or {}).get('q', [])]
         self.nl = int(dims['l']) if dims is not None else self.m
         if dims is not None:
@@ -64,6 +67,25 @@ class BatchKkt(object):
         else:
             _capi.check(self.L.mi355kkt_batch_create_eq(C.byref(h), device, self.B, self.n, self.m, self.p), "batch_create")
         self.h = h
+        if Gt is not None:
+            self.set_problem(Gt, P, At)
+
+    def set_problem(self, Gt, P=None, At=None):
+        """(Re)load the problem data of this handle: NumPy arrays, or contiguous float64 CUDA tensors already in this GPU's HBM
+        (copied device to device into the handle's own buffers).  Same shapes as at creation."""
+        h = self.h
+        on_device = hasattr(Gt, "data_ptr")                       # torch CUDA tensors: the data is already in HBM
+        if on_device:
+            if not (Gt.is_cuda and Gt.is_contiguous() and Gt.dtype.is_floating_point and Gt.element_size() == 8):
+                raise TypeError("Gt must be a contiguous float64 CUDA tensor")
+            if tuple(int(v) for v in Gt.shape) != (self.B, self.n, self.m):
+                raise TypeError("Gt must have shape %r" % ((self.B, self.n, self.m),))
+            gptr = Gt.data_ptr()
+        else:
+            Gt = np.ascontiguousarray(Gt, dtype=np.float64)
+            if Gt.shape != (self.B, self.n, self.m):
+                raise TypeError("Gt must have shape %r" % ((self.B, self.n, self.m),))
+            gptr = Gt.ctypes.data
         Pp = None
         if P is not None:
             if on_device:
@@ -77,10 +99,14 @@ class BatchKkt(object):
                 Pp = P.ctypes.data
         if on_device:
             import torch
-            torch.cuda.synchronize(Gt.device)                     # the copies below run on the library's own stream
+            # the copies below run on the library's own stream: the producer of the tensors (the current torch stream -- e.g. the
+            # wait on a scatter) must be done, NOT the whole device (later collectives of a pipelined scatter keep flying)
+            torch.cuda.current_stream(Gt.device).synchronize()
         _capi.check(self.L.mi355kkt_batch_set_problem(h, C.c_void_p(gptr), C.c_void_p(Pp) if Pp else None,
                                                       1 if on_device else 0), "batch_set_problem")
         if self.p:
+            if At is None:
+                raise TypeError("At is required for a handle with p > 0")
             if on_device:
                 if not (hasattr(At, "data_ptr") and At.is_cuda and At.is_contiguous() and At.element_size() == 8):
                     raise TypeError("At must be a contiguous float64 CUDA tensor when Gt is one")
@@ -157,7 +183,7 @@ class BatchKkt(object):
                 if not (hasattr(b, "data_ptr") and b.is_cuda and b.dtype == torch.float64 and tuple(b.shape) == (B, self.p)):
                     raise TypeError("b must be a float64 CUDA tensor of shape (B, p)")
                 b = b.contiguous()
-            torch.cuda.synchronize(dev)                           # the loop runs on the library's own stream
+            torch.cuda.current_stream(dev).synchronize()          # the loop runs on the library's own stream (see set_problem)
             ptr = lambda t: C.c_void_p(t.data_ptr())
             rc = self.L.mi355kkt_batch_coneqp_eq(self.h, ptr(q), ptr(h), ptr(b) if self.p else None, int(maxiters), float(abstol),
                                                  float(reltol), float(feastol), ptr(x), ptr(y), ptr(s), ptr(z),
@@ -385,111 +411,236 @@ def shard_bounds(B, world):
 _STATUS_NAMES = np.array(['unknown', 'optimal', 'unknown', 'unknown'], dtype=object)
 
 
-def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, device_of_rank=None, return_device=False, **opts):
+class ShardedBatch(object):
+    """Persistent per-rank state of the sharded batch solve (BASELINE configs[4]).
+
+    Everything that costs allocation time lives as long as this object: the rank's receive buffers for its shard of (q, h, Gt, P),
+    the packed result buffer, and -- on GPUs -- one `BatchKkt` engine per SUB-BATCH of the shard (the ~GB of engine state per
+    512 problems is allocated once, not inside a timed step).
+
+    A `solve()` is pipelined over `nsub` sub-batches of every rank's shard: all scatters are enqueued at once (async, in sub-batch
+    order), sub-batch k is solved as soon as ITS pieces have arrived while the pieces of k+1.. are still on the wire, and its
+    packed results go back with an async gather that overlaps the next solve.  Data path per sub-batch: `dist.scatter` of
+    contiguous row ranges (RCCL: grouped send/recv, one xGMI link per peer) -> device-to-device copy into the engine
+    (`set_problem`) -> device-resident coneqp loop -> ONE packed float64 tensor [x | s | z | pcost dcost gap status iters] ->
+    `dist.gather`.  No collective inside the interior-point loop.
+    """
+
+    def __init__(self, B, n, m, hasP, group=None, root=0, nsub=4, local_solver=None, device_of_rank=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.group, self.root = group, root
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+        self.B, self.n, self.m, self.hasP = int(B), int(n), int(m), bool(hasP)
+        self.local_solver, self.device_of_rank = local_solver, device_of_rank
+        self.bounds = shard_bounds(self.B, self.world)
+        self.lo, self.hi = self.bounds[self.rank]
+        self.nloc = self.hi - self.lo
+        self.mx = max(b - a for a, b in self.bounds)
+        self.nsub = max(1, min(int(nsub), self.mx))
+        # sub-batch k covers rows [sb[k], sb[k+1]) of every rank's shard (a short shard simply has fewer rows in the last ones)
+        self.sb = [k * self.mx // self.nsub for k in range(self.nsub + 1)]
+        self.width = self.n + 2 * self.m + 5
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        self.q_l = torch.empty((self.mx, self.n), **f64)
+        self.h_l = torch.empty((self.mx, self.m), **f64)
+        self.G_l = torch.empty((self.mx, self.n, self.m), **f64)
+        self.P_l = torch.empty((self.mx, self.n, self.n), **f64) if self.hasP else None
+        self.pack = torch.zeros((self.mx, self.width), **f64)
+        self.gathered = None
+        if self.rank == root:
+            self.gathered = [[torch.empty((self.sb[k + 1] - self.sb[k], self.width), **f64) for _ in range(self.world)]
+                             for k in range(self.nsub)]
+        self.on_device = (self.backend == "nccl" and local_solver is None)
+        self.engines = [None] * self.nsub          # BatchKkt per sub-batch, created at the first solve and kept
+        self.last_timings = {}
+
+    def close(self):
+        for e in self.engines:
+            if e is not None:
+                e.close()
+        self.engines = [None] * self.nsub
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _rows(self, k):
+        """rows of MY shard in sub-batch k"""
+        a = min(self.sb[k], self.nloc)
+        return a, min(self.sb[k + 1], self.nloc)
+
+    def _as_tensor(self, arr):
+        torch = self.torch
+        if hasattr(arr, "data_ptr"):
+            return arr if arr.device == self.dev else arr.to(self.dev)
+        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(self.dev)
+
+    def _scatter_sub(self, k, full, buf):
+        """rows [sb[k], sb[k+1]) of every rank's shard of `full` (root only) -> buf[sb[k]:sb[k+1]] on every rank, async"""
+        torch, dist = self.torch, self.dist
+        a, b = self.sb[k], self.sb[k + 1]
+        out = buf[a:b]
+        if self.rank != self.root:
+            return dist.scatter(out, None, src=self.root, group=self.group, async_op=True)
+        chunks = []
+        for lo, hi in self.bounds:
+            ra, rb = min(lo + a, hi), min(lo + b, hi)
+            c = full[ra:rb]                      # a view: whole pieces go out without a copy
+            if rb - ra < b - a:                  # dist.scatter needs equal sizes: only the short tail pieces are padded
+                c = torch.cat([c, torch.zeros((b - a - (rb - ra),) + tuple(full.shape[1:]), dtype=torch.float64, device=self.dev)])
+            chunks.append(c.contiguous())
+        return dist.scatter(out, chunks, src=self.root, group=self.group, async_op=True)
+
+    def _wait(self, works):
+        for w in works:
+            w.wait()
+        if self.backend == "nccl":               # host waits for THESE collectives only (later ones keep flying)
+            self.torch.cuda.current_stream(self.dev).synchronize()
+
+    def solve(self, P, q, Gt, h, return_device=False, **opts):
+        """P, q, Gt, h are only read on the root (other ranks may pass None).  The root returns the FULL gathered result dict,
+        the other ranks their local shard's.  `self.last_timings` (ms, this rank): scatter_exposed (until the first sub-batch
+        was complete here), scatter_all (until the last one was), upload, solve (sum over sub-batches), gather_exposed (after the
+        last solve), total."""
+        import time
+        torch, dist = self.torch, self.dist
+        n, m, root = self.n, self.m, self.root
+        t0 = time.perf_counter()
+        fulls = None
+        if self.rank == root:
+            fulls = (self._as_tensor(q), self._as_tensor(h), self._as_tensor(Gt), self._as_tensor(P) if self.hasP else None)
+        works = []
+        for k in range(self.nsub):                # everything is enqueued up front, in the order it will be consumed
+            wk = [self._scatter_sub(k, fulls[0] if fulls else None, self.q_l),
+                  self._scatter_sub(k, fulls[1] if fulls else None, self.h_l),
+                  self._scatter_sub(k, fulls[2] if fulls else None, self.G_l)]
+            if self.hasP:
+                wk.append(self._scatter_sub(k, fulls[3] if fulls else None, self.P_l))
+            works.append(wk)
+        tm = {"scatter_exposed": 0.0, "scatter_all": 0.0, "upload": 0.0, "solve": 0.0, "gather_exposed": 0.0}
+        gworks, lockstep = [], 0
+        sopts = {k_: v for k_, v in opts.items() if k_ != "resident"}
+        for k in range(self.nsub):
+            self._wait(works[k])
+            t1 = time.perf_counter()
+            if k == 0:
+                tm["scatter_exposed"] = 1e3 * (t1 - t0)
+            tm["scatter_all"] = 1e3 * (t1 - t0)
+            a, b = self._rows(k)
+            cnt = b - a
+            if cnt > 0:
+                G_k, P_k = self.G_l[a:b], (self.P_l[a:b] if self.hasP else None)
+                q_k, h_k = self.q_l[a:b], self.h_l[a:b]
+                if self.on_device and opts.get("resident", True):
+                    if self.engines[k] is None:
+                        self.engines[k] = BatchKkt(shape=(cnt, n, m), device=self.dev.index)
+                    eng = self.engines[k]
+                    t2 = time.perf_counter()
+                    eng.set_problem(G_k, P_k)
+                    t3 = time.perf_counter()
+                    res = eng.coneqp(q_k, h_k, **sopts)
+                    tm["upload"] += 1e3 * (t3 - t2)
+                    tm["solve"] += 1e3 * (time.perf_counter() - t3)
+                    pk = self.pack[a:b]
+                    pk[:, :n] = res['x']
+                    pk[:, n:n + m] = res['s']
+                    pk[:, n + m:n + 2 * m] = res['z']
+                    pk[:, n + 2 * m] = res['primal objective']
+                    pk[:, n + 2 * m + 1] = res['dual objective']
+                    pk[:, n + 2 * m + 2] = res['gap']
+                    pk[:, n + 2 * m + 3] = res['status_code'].to(torch.float64)
+                    pk[:, n + 2 * m + 4] = res['iterations'].to(torch.float64)
+                    lockstep = max(lockstep, int(res['lockstep iterations']))
+                else:
+                    t3 = time.perf_counter()
+                    Pn = P_k.cpu().numpy() if P_k is not None else None
+                    qn, Gn, hn = q_k.cpu().numpy(), G_k.cpu().numpy(), h_k.cpu().numpy()
+                    if self.local_solver is None:
+                        device = self.device_of_rank(self.rank) if self.device_of_rank else (
+                            torch.cuda.current_device() if self.backend == "nccl" else 0)
+                        res = coneqp_batch(Pn, qn, Gn, hn, device=device, **sopts)
+                    else:
+                        res = self.local_solver(Pn, qn, Gn, hn, **sopts)
+                    host = np.zeros((cnt, self.width))
+                    host[:, :n], host[:, n:n + m], host[:, n + m:n + 2 * m] = res['x'], res['s'], res['z']
+                    host[:, n + 2 * m], host[:, n + 2 * m + 1] = res['primal objective'], res['dual objective']
+                    host[:, n + 2 * m + 2] = res['gap']
+                    st_ = np.asarray(res['status'])
+                    host[:, n + 2 * m + 3] = (st_ == 'optimal').astype(float) + 2.0 * (st_ != 'optimal')
+                    host[:, n + 2 * m + 4] = res['iterations']
+                    self.pack[a:b] = torch.from_numpy(host).to(self.dev)
+                    lockstep = max(lockstep, int(res.get('lockstep iterations', 0)))
+                    tm["solve"] += 1e3 * (time.perf_counter() - t3)
+            # this sub-batch's results travel while the next one is solved
+            sa, sbk = self.sb[k], self.sb[k + 1]
+            gworks.append(dist.gather(self.pack[sa:sbk], self.gathered[k] if self.rank == root else None, dst=root,
+                                      group=self.group, async_op=True))
+        t4 = time.perf_counter()
+        self._wait(gworks)
+        t5 = time.perf_counter()
+        tm["gather_exposed"] = 1e3 * (t5 - t4)
+        tm["total"] = 1e3 * (t5 - t0)
+        self.last_timings = tm
+
+        def unpack(t, ls):
+            sc = t[:, n + 2 * m:].cpu().numpy()                    # pcost dcost gap status iters: O(B) doubles
+            if return_device:
+                vec = {'x': t[:, :n], 's': t[:, n:n + m], 'z': t[:, n + m:n + 2 * m]}
+            else:
+                a_ = t[:, :n + 2 * m].cpu().numpy()
+                vec = {'x': a_[:, :n].copy(), 's': a_[:, n:n + m].copy(), 'z': a_[:, n + m:n + 2 * m].copy()}
+            vec.update({'primal objective': sc[:, 0].copy(), 'dual objective': sc[:, 1].copy(), 'gap': sc[:, 2].copy(),
+                        'status': _STATUS_NAMES[sc[:, 3].astype(int)], 'iterations': sc[:, 4].astype(int),
+                        'lockstep iterations': ls})
+            return vec
+        if self.rank != root:
+            return unpack(self.pack[:self.nloc], lockstep)
+        # rank r's shard = its rows of every sub-batch, in order
+        pieces = []
+        for r, (lo, hi) in enumerate(self.bounds):
+            cnt_r = hi - lo
+            for k in range(self.nsub):
+                a, b = min(self.sb[k], cnt_r), min(self.sb[k + 1], cnt_r)
+                if b > a:
+                    pieces.append(self.gathered[k][r][:b - a])
+        full = unpack(torch.cat(pieces), lockstep)           # the root's own lock-step count (shards stop independently)
+        return full
+
+
+_SHARDED_CACHE = {}
+
+
+def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, device_of_rank=None, return_device=False, nsub=4,
+                         **opts):
     """P, q, Gt, h are only read on `root` (other ranks may pass None): NumPy arrays, or -- with RCCL -- float64 CUDA
     tensors already resident in the root's HBM (then the scatter sends views of them, nothing is staged or copied).
     Root returns the FULL gathered result dict (NumPy), the other ranks their local shard's.
 
-    Data path: `dist.scatter` of contiguous shards (RCCL: grouped send/recv, one xGMI link per peer, concurrently) ->
-    local device-resident solve -> ONE packed float64 tensor per rank [x | s | z | pcost dcost gap status iters]
-    -> `dist.gather`.  No collective inside the interior-point loop; with RCCL nothing but the per-iteration "still active"
-    word of the local loop touches a host.  return_device=True leaves x, s, z of the result as tensors on the gathering
-    device (only the O(B) scalars are copied to the host)."""
-    import torch
+    Thin wrapper around a cached `ShardedBatch` (one per group / problem shape): receive buffers and the per-rank engines are
+    created on the first call and reused, so a repeated call costs the data path only -- pipelined scatter of `nsub` sub-batches
+    -> local device-resident solve of each as it arrives -> async gather of its packed results.  No collective inside the
+    interior-point loop; with RCCL nothing but the per-iteration "still active" word of the local loop touches a host.
+    return_device=True leaves x, s, z of the result as tensors on the gathering device."""
     import torch.distributed as dist
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    rank = dist.get_rank(group)
     meta = [None]
     if rank == root:
         meta = [(int(q.shape[0]), int(q.shape[1]), int(h.shape[1]), P is not None)]
     dist.broadcast_object_list(meta, src=root, group=group)
     B, n, m, hasP = meta[0]
-    bounds = shard_bounds(B, world)
-    lo, hi = bounds[rank]
-    mx = max(b - a for a, b in bounds)
-
-    def as_tensor(arr):
-        if hasattr(arr, "data_ptr"):
-            return arr if arr.device == dev else arr.to(dev)
-        return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64)).to(dev)
-
-    def scatter(arr, tail_shape):
-        buf = torch.empty((mx,) + tail_shape, dtype=torch.float64, device=dev)
-        if rank == root:
-            full = as_tensor(arr)
-            chunks = []
-            for a, b in bounds:
-                c = full[a:b]                     # a view: equal shards go out without a copy
-                if b - a < mx:                    # dist.scatter needs equal sizes: only the short shards are padded
-                    c = torch.cat([c, torch.zeros((mx - (b - a),) + tail_shape, dtype=torch.float64, device=dev)])
-                chunks.append(c.contiguous())
-            dist.scatter(buf, chunks, src=root, group=group)
-        else:
-            dist.scatter(buf, None, src=root, group=group)
-        return buf[:hi - lo]
-
-    q_l = scatter(q, (n,))
-    h_l = scatter(h, (m,))
-    G_l = scatter(Gt, (n, m))
-    P_l = scatter(P, (n, n)) if hasP else None
-    # with RCCL the shard landed in this rank's HBM over xGMI and STAYS there (BatchKkt borrows the device pointers)
-    on_device = (backend == "nccl" and local_solver is None and opts.get("resident", True))
-    width = n + 2 * m + 5
-    pack = torch.zeros((mx, width), dtype=torch.float64, device=dev)
-    nloc = hi - lo
-    lockstep = 0
-    if nloc > 0:
-        if on_device:
-            kk = BatchKkt(G_l.contiguous(), P_l.contiguous() if P_l is not None else None, device=dev.index)
-            try:
-                res = kk.coneqp(q_l, h_l, **{k: v for k, v in opts.items() if k != "resident"})
-            finally:
-                kk.close()
-            pack[:nloc, :n] = res['x']
-            pack[:nloc, n:n + m] = res['s']
-            pack[:nloc, n + m:n + 2 * m] = res['z']
-            pack[:nloc, n + 2 * m] = res['primal objective']
-            pack[:nloc, n + 2 * m + 1] = res['dual objective']
-            pack[:nloc, n + 2 * m + 2] = res['gap']
-            pack[:nloc, n + 2 * m + 3] = res['status_code'].to(torch.float64)
-            pack[:nloc, n + 2 * m + 4] = res['iterations'].to(torch.float64)
-            lockstep = res['lockstep iterations']
-        else:
-            Pn = P_l.cpu().numpy() if P_l is not None else None
-            qn, Gn, hn = q_l.cpu().numpy(), G_l.cpu().numpy(), h_l.cpu().numpy()
-            if local_solver is None:
-                device = device_of_rank(rank) if device_of_rank else (torch.cuda.current_device() if backend == "nccl" else 0)
-                res = coneqp_batch(Pn, qn, Gn, hn, device=device, **opts)
-            else:
-                res = local_solver(Pn, qn, Gn, hn, **opts)
-            host = np.zeros((nloc, width))
-            host[:, :n], host[:, n:n + m], host[:, n + m:n + 2 * m] = res['x'], res['s'], res['z']
-            host[:, n + 2 * m], host[:, n + 2 * m + 1] = res['primal objective'], res['dual objective']
-            host[:, n + 2 * m + 2] = res['gap']
-            host[:, n + 2 * m + 3] = (np.asarray(res['status']) == 'optimal').astype(float) + 2.0 * (np.asarray(res['status']) != 'optimal')
-            host[:, n + 2 * m + 4] = res['iterations']
-            pack[:nloc] = torch.from_numpy(host).to(dev)
-            lockstep = int(res.get('lockstep iterations', 0))
-    gathered = [torch.empty_like(pack) for _ in range(world)] if rank == root else None
-    dist.gather(pack, gathered, dst=root, group=group)
-
-    def unpack(t, cnt, ls):
-        t = t[:cnt]
-        sc = t[:, n + 2 * m:].cpu().numpy()                    # pcost dcost gap status iters: O(B) doubles
-        if return_device:
-            vec = {'x': t[:, :n], 's': t[:, n:n + m], 'z': t[:, n + m:n + 2 * m]}
-        else:
-            a = t[:, :n + 2 * m].cpu().numpy()
-            vec = {'x': a[:, :n].copy(), 's': a[:, n:n + m].copy(), 'z': a[:, n + m:n + 2 * m].copy()}
-        vec.update({'primal objective': sc[:, 0].copy(), 'dual objective': sc[:, 1].copy(), 'gap': sc[:, 2].copy(),
-                    'status': _STATUS_NAMES[sc[:, 3].astype(int)], 'iterations': sc[:, 4].astype(int),
-                    'lockstep iterations': ls})
-        return vec
-    if rank != root:
-        return unpack(pack, nloc, lockstep)
-    parts = [unpack(g, b - a, 0) for g, (a, b) in zip(gathered, bounds)]
-    cat = lambda xs: torch.cat(list(xs)) if hasattr(xs[0], "data_ptr") else np.concatenate(xs)
-    full = {k: cat([pp[k] for pp in parts]) for k in parts[0] if k != 'lockstep iterations'}
-    full['lockstep iterations'] = lockstep          # the root's own count (shards stop independently)
-    return full
+    key = (id(group), root, B, n, m, hasP, int(nsub), id(local_solver), dist.get_backend(group), dist.get_world_size(group))
+    sb = _SHARDED_CACHE.get(key)
+    if sb is None:
+        for old in list(_SHARDED_CACHE.values()):    # one shape at a time: the engines hold GBs
+            old.close()
+        _SHARDED_CACHE.clear()
+        sb = _SHARDED_CACHE[key] = ShardedBatch(B, n, m, hasP, group=group, root=root, nsub=nsub, local_solver=local_solver,
+                                                device_of_rank=device_of_rank)
+    sb.local_solver = local_solver
+    return sb.solve(P, q, Gt, h, return_device=return_device, **opts)

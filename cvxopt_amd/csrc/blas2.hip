@@ -689,6 +689,200 @@ int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int t
     return 0;
 }
 
+// ===================================================================================================
+// Round 3: the same persistent solve with the hop's critical path cut to ONE matrix-vector stage.
+//
+//   forward:  x_k = L_kk^-1 (b_k - sum_{j<k} L_kj x_j)
+//                 = [ L_kk^-1 (b_k - sum_{j<=k-3} L_kj x_j) ]  -  Z2_k x_{k-2}  -  Z1_k x_{k-1},     Zq_k = L_kk^-1 L_{k,k-q}
+//
+//   The two blocks next to the diagonal are pre-multiplied by L_kk^-1 ONCE per factorisation (trsv_z_prepare: a backward
+//   stable multi-right-hand-side solve, 2 x 128 columns per block row and direction).  In the solve, workgroup k
+//     A  accumulates b_k - L_kj x_j for j <= k-3 as those x_j arrive (strips prefetched before each wait, as before),
+//     B  solves the diagonal block for that partial sum (M = L_kk^-1 from the tile Cholesky + one step of fixed-precision
+//        refinement against L_kk, three matrix-vector stages) -- this needs x_{k-3} only, so it runs while x_{k-2}, x_{k-1} are
+//        still being produced two and one hops up the chain,
+//     C  subtracts Z2_k x_{k-2},
+//     D  subtracts Z1_k x_{k-1} and publishes: between "x_{k-1} arrived" and "x_k published" sit one 64-term dot product per
+//        thread, one lane-pair exchange (DPP, no LDS) and the granule stores.
+//   256 threads = two ADJACENT lanes per row (columns 0..63 / 64..127 of the strip): the pair sum is a DPP move, every stage has
+//   one barrier (vector -> LDS -> all threads).  Requires n % 128 == 0 (the callers fall back to trsv_persistent_kernel).
+//   The backward solve is the mirror image on L' (read from the mirrored upper triangle), Zq_k = L_kk^-T L_{k+q,k}'.
+// ===================================================================================================
+__device__ __forceinline__ double pair_sum(double v) {           // v(lane) + v(lane ^ 1), identical bits in both lanes
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return v + __hiloint2double(hi, lo);
+}
+
+constexpr int ZV = TB + 2;       // LDS vector: entries 64..127 sit 2 doubles further (the two lanes of a pair read different banks)
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ L, int64_t ldl, int n, double* x, u32 epoch,
+                                                     int* err, u64* gran, const double* __restrict__ minv,
+                                                     const double* __restrict__ zmat) {
+    __shared__ __attribute__((aligned(16))) double vb[4][ZV + 2];
+    const int tid = threadIdx.x;
+    const int r = tid >> 1, half = tid & 1, ch = 64 * half;
+    const int nblk = n / TB;
+    const int k = TRANS ? (nblk - 1 - (int)blockIdx.x) : (int)blockIdx.x;   // dispatch order ~ dependency order
+    const int k0 = k * TB, idx = k0 + r;
+    const int vpos = r + ((r >> 6) << 1);                  // my row's slot in an LDS vector
+    const int vh = ch + 2 * half;                          // first slot of my half of a vector
+    int vi = 0;                                            // running stage counter: stage t uses vb[t & 3]
+    double acc = half == 0 ? x[idx] : 0.0;
+
+    // receive block j of the solution into an LDS vector: thread tid polls granule tid (word `half` of row r)
+    auto recv = [&](int j, double* buf) -> bool {
+        const u64* g = gran + (int64_t)j * 256 + tid;
+        u64 v = 0;
+        bool got = false;
+        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+            v = __hip_atomic_load(g, RLX_AGENT);
+            if ((u32)(v >> 32) == epoch) { got = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        reinterpret_cast<u32*>(buf)[2 * vpos + half] = (u32)v;
+        if (__syncthreads_or(got ? 0 : 1)) {
+            if (tid == 0) atomicExch(err, 1);
+            return false;                                  // timeout: give up (err is set)
+        }
+        return true;
+    };
+    // 64-term dot product of a register strip with my half of an LDS vector, four independent chains
+    auto dot64 = [&](const double (&a)[64], const double* v) {
+        const double* w = v + vh;
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+            d0 = fma(a[c], w[c], d0);
+            d1 = fma(a[c + 1], w[c + 1], d1);
+            d2 = fma(a[c + 2], w[c + 2], d2);
+            d3 = fma(a[c + 3], w[c + 3], d3);
+        }
+        return (d0 + d1) + (d2 + d3);
+    };
+
+    // Strip loads: element c of a thread's strip = column (first + c) of a column-major block, row r.  Addressed as a WAVE-UNIFORM
+    // column base (scalar registers, bumped by scalar adds) + one 32-bit lane offset: no per-load address registers (with 64-bit
+    // lane addresses hipcc formed the 64 addresses of a strip up front and spilled ~90 registers around every strip).
+    auto ldu = [](const double* ubase, uint32_t voff) -> double {
+        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ubase) + (uint64_t)voff);
+    };
+    const uint32_t voffM = (uint32_t)((r + ch * TB) * 8);                       // inside a 128 x 128 block with ld 128
+    const uint32_t voffL = (uint32_t)(((int64_t)r + (int64_t)ch * ldl) * 8);    // inside a block of L (ld = ldl)
+    // ---- diagonal block operands (M strip, L_kk strip): loaded now, used in phase B
+    double ra[64], rb[64];
+    {
+        const double* Mk = minv + (int64_t)k * (2 * TB * TB) + (TRANS ? TB * TB : 0);
+        const double* Lkk = L + k0 + (int64_t)k0 * ldl;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) ra[j] = ldu(Mk + j * TB, voffM);
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const int c = ch + j;
+            const double v = ldu(Lkk + (int64_t)j * ldl, voffL);   // unconditional (the other triangle holds the mirrored copy)
+            rb[j] = (TRANS ? c >= r : c <= r) ? v : 0.0;
+        }
+    }
+    // ---- phase A: the blocks three and more hops up the chain
+    const int nsteps = TRANS ? (nblk - 1 - k) : k;
+    const int nfar = nsteps > 2 ? nsteps - 2 : 0;
+    for (int s = 0; s < nfar; ++s) {
+        const int j = TRANS ? (nblk - 1 - s) : s;
+        double l0[64];
+        const double* Lkj = L + k0 + (int64_t)j * TB * ldl;          // block (k, j)  (TRANS: of the mirrored L')
+#pragma unroll
+        for (int c = 0; c < 64; ++c) l0[c] = ldu(Lkj + (int64_t)c * ldl, voffL);
+        double* buf = vb[vi++ & 3];
+        if (!recv(j, buf)) return;
+        acc -= dot64(l0, buf);
+    }
+    // ---- phase B: c' = L_kk^-1 (b_k - sum of phase A), x0 = M b, e = b - L_kk x0, c' = x0 + M e
+    const double b = pair_sum(acc);
+    double* buf = vb[vi++ & 3];
+    if (half == 0) buf[vpos] = b;
+    __syncthreads();
+    const double x0 = pair_sum(dot64(ra, buf));
+    buf = vb[vi++ & 3];
+    if (half == 0) buf[vpos] = x0;
+    __syncthreads();
+    const double e = b - pair_sum(dot64(rb, buf));
+    // the strips of the two pre-multiplied blocks take over the registers of the L_kk / M strips as those die
+    const double* Zk = zmat + (int64_t)k * (2 * TB * TB);
+    if (nsteps >= 2) {                                     // Z2 strip -> rb
+#pragma unroll
+        for (int c = 0; c < 64; ++c) rb[c] = ldu(Zk + TB * TB + c * TB, voffM);
+    }
+    buf = vb[vi++ & 3];
+    if (half == 0) buf[vpos] = e;
+    __syncthreads();
+    double xk = x0 + pair_sum(dot64(ra, buf));
+    if (nsteps >= 1) {                                     // Z1 strip -> ra
+#pragma unroll
+        for (int c = 0; c < 64; ++c) ra[c] = ldu(Zk + c * TB, voffM);
+    }
+    // ---- phase C: the block two hops up
+    if (nsteps >= 2) {
+        buf = vb[vi++ & 3];
+        if (!recv(TRANS ? k + 2 : k - 2, buf)) return;
+        xk -= pair_sum(dot64(rb, buf));
+    }
+    // ---- phase D: the block one hop up -- the only stage between its arrival and my publication
+    if (nsteps >= 1) {
+        buf = vb[vi++ & 3];
+        if (!recv(TRANS ? k + 1 : k - 1, buf)) return;
+        xk -= pair_sum(dot64(ra, buf));
+    }
+    // publish: every thread one granule (its word of x_r), then the plain copy for the caller
+    {
+        const u64 tag = (u64)epoch << 32;
+        const u32 word = half ? (u32)__double2hiint(xk) : (u32)__double2loint(xk);
+        __hip_atomic_store(gran + (int64_t)k * 256 + tid, tag | word, RLX_AGENT);
+        if (half == 0) x[idx] = xk;
+    }
+}
+
+// block (k, k -+ q) of the factor (forward: the lower block; backward: the mirrored upper block = L_{k+q,k}') -> Z storage
+__global__ __launch_bounds__(256) void trsv_z_gather_kernel(const double* __restrict__ L, int64_t ldl, int nblk,
+                                                            double* __restrict__ zmat) {
+    const int k = blockIdx.x, q = 1 + (int)blockIdx.y, dir = blockIdx.z;
+    double* Z = zmat + ((int64_t)dir * nblk + k) * (2 * TB * TB) + (int64_t)(q - 1) * TB * TB;
+    const int j = dir ? k + q : k - q;
+    const bool have = j >= 0 && j < nblk;
+    const double* B = L + (int64_t)k * TB + (int64_t)(have ? j : 0) * TB * ldl;
+    for (int e = threadIdx.x; e < TB * TB; e += 256) {
+        const int i = e & (TB - 1), c = e >> 7;
+        Z[e] = have ? B[i + (int64_t)c * ldl] : 0.0;
+    }
+}
+
+size_t trsv_z_doubles(int n) { return (size_t)2 * (n / TB) * 2 * TB * TB; }
+
+// Z1, Z2 of every block row for both directions; L must hold the factor AND its mirrored upper triangle (launch_mirror_lower)
+int trsv_z_prepare(const double* L, int64_t ldl, int n, double* zmat, hipStream_t st) {
+    if (n <= 0 || n % TB) return -1;
+    const int nblk = n / TB;
+    hipLaunchKernelGGL(trsv_z_gather_kernel, dim3(nblk, 2, 2), dim3(256), 0, st, L, ldl, nblk, zmat);
+    KKT_HIP_CHECK(hipGetLastError());
+    const int64_t sL = (int64_t)TB * (ldl + 1), sX = 2 * TB * TB;
+    if (int e = launch_trsm_lower(L, ldl, TB, zmat, TB, 2 * TB, 0, st, nblk, sL, sX)) return e;
+    if (int e = launch_trsm_lower(L, ldl, TB, zmat + (int64_t)nblk * sX, TB, 2 * TB, 1, st, nblk, sL, sX)) return e;
+    return 0;
+}
+
+int launch_trsv_z(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
+                  unsigned long long* gran, const double* minv, const double* zmat) {
+    if (n <= 0 || n % TB || !gran || !minv || !zmat) return -1;
+    const int nblk = n / TB;
+    if (trans)
+        hipLaunchKernelGGL((trsv_z_kernel<true>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, epoch, err, gran, minv,
+                           zmat + (int64_t)nblk * 2 * TB * TB);
+    else
+        hipLaunchKernelGGL((trsv_z_kernel<false>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, epoch, err, gran, minv, zmat);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs, int trans,
                       hipStream_t st, int nbatch, int64_t sL, int64_t sX) {
     if (n <= 0 || nrhs <= 0) return 0;

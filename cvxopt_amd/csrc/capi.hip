@@ -337,6 +337,8 @@ struct mi355kkt_solver {
     IpmWork ipm;               // device-resident coneqp loop (mi355kkt_coneqp_lp), allocated on first use
     LpWork lp;                 // device-resident conelp loop (mi355kkt_conelp)
     QpWork qp;                 // device-resident coneqp loop with second-order cones (mi355kkt_coneqp)
+    double* dZ = nullptr;      // trsv_z: L_kk^-1 L_{k,k-1}, L_kk^-1 L_{k,k-2} (and the mirrored pair) of every 128-block row, per factor
+    bool z_valid = false;
     double* dHsym = nullptr;   // full symmetric copy of H for the residual product P x
     bool hsym_valid = false;
     double* dIpmWork = nullptr;
@@ -536,6 +538,7 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
     if (h->ev_h) (void)hipEventDestroy(h->ev_h);
     if (h->dflags) (void)hipFree(h->dflags);
     if (h->dgran) (void)hipFree(h->dgran);
+    if (h->dZ) (void)hipFree(h->dZ);
     if (h->derr) (void)hipFree(h->derr);
     if (h->herr) (void)hipHostFree(h->herr);
     for (double* b : bufs)
@@ -1035,8 +1038,18 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
         if (int e = launch_potrf(h->dK, h->p, h->p, h->pw, h->st)) return e;
     }
     // L' into the (otherwise unused) upper triangle of S: the transposed persistent solve streams it coalesced
-    if ((h->n + 127) / 128 <= h->num_cus && !getenv("MI355KKT_NO_PERSISTENT_TRSV"))
+    h->z_valid = false;
+    if ((h->n + 127) / 128 <= h->num_cus && !getenv("MI355KKT_NO_PERSISTENT_TRSV")) {
         if (int e = launch_mirror_lower(h->dS, h->n, h->n, h->st)) return e;
+        // round 3: the two blocks next to the diagonal pre-multiplied by L_kk^-1 (blas2.hip: trsv_z_kernel) -- needs the 128 x 128
+        // inverses of the tile Cholesky of THIS matrix and whole 128-blocks; experimental, $MI355KKT_TRSV=z switches it on
+        static const bool use_z = getenv("MI355KKT_TRSV") && !strcmp(getenv("MI355KKT_TRSV"), "z");   // opt-in (see DESIGN: not faster yet)
+        if (use_z && h->n % 128 == 0 && h->n >= 256 && h->pw.minv_n == h->n && h->pw.minv_of == h->dS && h->dgran) {
+            if (!h->dZ) KKT_HIP_CHECK(hipMalloc(&h->dZ, sizeof(double) * trsv_z_doubles(h->n)));
+            if (int e = trsv_z_prepare(h->dS, h->n, h->n, h->dZ, h->st)) return e;
+            h->z_valid = true;
+        }
+    }
     KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
     if (int e = fetch_info(h, &info)) return e;
     (void)hipEventElapsedTime(&h->t_syrk, h->ev[0], h->ev[1]);
@@ -1128,6 +1141,8 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     // triangular solves with L: one persistent launch each when every 128-block can own a resident workgroup
     const bool persistent = (n + 127) / 128 <= h->num_cus && !getenv("MI355KKT_NO_PERSISTENT_TRSV");
     auto tri_solve = [&](int trans) -> int {
+        if (persistent && h->z_valid && h->pw.minv_n == n && h->pw.minv_of == h->dS)
+            return launch_trsv_z(h->dS, n, n, dx, trans, ++h->epoch, h->derr, st, h->dgran, h->pw.d_minv, h->dZ);
         if (persistent) return launch_trsv_persistent(h->dS, n, n, dx, trans, h->dflags, ++h->epoch, h->derr, st, h->dgran,
                                                       (h->pw.minv_n == n && h->pw.minv_of == h->dS) ? h->pw.d_minv : nullptr);
         return launch_trsm_lower(h->dS, n, n, dx, n, 1, trans, st);

@@ -140,6 +140,12 @@ constexpr int TRSV_JOB_STRIDE = 64;    // flags / granule blocks reserved per jo
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
                            unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran = nullptr,
                            const double* minv = nullptr, const TrsvJob* jobs = nullptr, int njobs = 0);
+// round 3: the persistent solve with the two blocks next to the diagonal pre-multiplied by L_kk^-1 (blas2.hip, trsv_z_kernel):
+// trsv_z_prepare once per factorisation (after launch_mirror_lower), zmat holds trsv_z_doubles(n) doubles; n % 128 == 0
+size_t trsv_z_doubles(int n);
+int trsv_z_prepare(const double* L, int64_t ldl, int n, double* zmat, hipStream_t st);
+int launch_trsv_z(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
+                  unsigned long long* gran, const double* minv, const double* zmat);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);

@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "kkt_common.h"
+#include <type_traits>
 
 namespace mi355kkt {
 
@@ -251,6 +252,12 @@ __global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int6
 // block (column-oriented forward substitution with LDS broadcasts).
 // ---------------------------------------------------------------------------------------------------
 constexpr int P2T = 512;
+// Write-through (sc1) store / L1-bypassing (sc1) load of a double: data handed from one compute unit to another inside a launch
+// WITHOUT fences -- the producer drains its sc1 stores (s_waitcnt vmcnt(0)) before a relaxed agent-scope flag store, the consumer
+// polls the flag and reads with sc1 loads (guide G16: "sc1 stores and loads both sides").  A release fence would write back every
+// dirty line of the XCD's L2 (~2-6 us with a freshly written tile), an acquire fence costs ~1.7 us: too much for 16-column steps.
+__device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_l2(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ long long* g_potf2_ts = nullptr;   // developer aid: when set, wave 0 / lane 0 logs s_memtime at phase boundaries
 #define P2_TS(i_) do { if (ts && tid == 0) ts[(i_)] = (long long)__builtin_readcyclecounter(); } while (0)
 
@@ -365,9 +372,13 @@ __device__ __forceinline__ int potf2_panel16(double (&a)[16], double (&b)[16], d
 // half_word (tile kernel, full 128 x 128 blocks only): as soon as columns 0..63 of L and the inverses of the diagonal blocks
 // 0..3 are in global memory, *half_word = 1 is published (agent scope) -- the triangular solve of the tile below starts on
 // its first four column blocks while this block's second half is still being factored.
+// stream (tile kernel, round 3): every finished 16-column micro panel (and the inverse of its diagonal block) goes to memory with
+// write-through stores and *half_word = number of micro panels in memory is published one step behind, without fences: the tiles
+// below consume L(j,j) panel by panel (tile_process).  The caller publishes the final count (8) after this function returns.
 template <bool FROM_LDS>
 __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda, int nb, double* __restrict__ linv_out,
-                                             double* __restrict__ smem, long long* ts, unsigned* half_word = nullptr) {
+                                             double* __restrict__ smem, long long* ts, unsigned* half_word = nullptr,
+                                             bool stream = false) {
     double* As = smem;                           // NB x PLD, column-major
     double* dinv = smem + NB * PLD;              // 128 reciprocal pivots
     double* dummy = dinv + NB;                   // 80 doubles: sink of the non-leader lanes' reciprocal-pivot stores
@@ -440,10 +451,13 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
                 for (int i = 0; i < 5; ++i) {
                     const int e = tt + (P2T - 64) * i;
                     const int r = e & (NB - 1), c = pjb + (e >> 7);
-                    if (e < 16 * NB && r >= c && r < nb && c < nb) A[r + (int64_t)c * lda] = As[c * PLD + r];
+                    if (e < 16 * NB && r >= c && r < nb && c < nb) {
+                        if (stream) st_wt(A + r + (int64_t)c * lda, As[c * PLD + r]);
+                        else A[r + (int64_t)c * lda] = As[c * PLD + r];
+                    }
                 }
             }
-            if (halfp && wave == 7 && pjb < 64) {
+            if (halfp && wave == 7 && (stream || pjb < 64)) {
                 // inverse of the 16 x 16 diagonal block of micro panel pjb (final since the last barrier), column-oriented
                 // substitution as at the end of this function; the look-ahead waves have slack behind the panel wave
                 const int j = lane & 15;
@@ -458,7 +472,11 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
                 }
                 if (lane < 16) {
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) linv_out[(pjb >> 4) * 256 + j * 16 + i] = (i >= j) ? x[i] : 0.0;
+                    for (int i = 0; i < 16; ++i) {
+                        const double v = (i >= j) ? x[i] : 0.0;
+                        if (stream) st_wt(linv_out + (pjb >> 4) * 256 + j * 16 + i, v);
+                        else linv_out[(pjb >> 4) * 256 + j * 16 + i] = v;
+                    }
                 }
             }
             const int ntr = nt - t1;
@@ -473,11 +491,15 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
             }
         }
         P2_TS(4 + (jb >> 4) * 5);
-        if (halfp && jb == 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // columns 0..63 + inverses 0..3: stores drained
+        if (halfp && (stream ? jb >= 16 : jb == 64))            // (the stores were issued a micro step ago: nothing to wait for)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // half: columns 0..63 + inverses 0..3; stream: micro panel jb - 16
         __syncthreads();                         // micro panel jb is in LDS; update jb-16 is complete
         P2_TS(5 + (jb >> 4) * 5);
         if (*flag) break;
-        if (halfp && jb == 64 && tid == P2T - 64) {          // wave 7 has no tile of the next column block: off the chain
+        if (halfp && stream) {
+            if (jb >= 16 && tid == P2T - 64)     // micro panels 0 .. jb/16 - 1 and their inverses are in memory (sc1 stores, drained)
+                __hip_atomic_store(half_word, (unsigned)(jb >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (halfp && jb == 64 && tid == P2T - 64) {   // wave 7 has no tile of the next column block: off the chain
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(half_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -498,11 +520,15 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
         for (int i = 0; i < 4; ++i) {
             const int e = tid + P2T * i;
             const int r = e & (NB - 1), c = ljb + (e >> 7);
-            if (r >= c && r < nb && c < nb) A[r + (int64_t)c * lda] = As[c * PLD + r];
+            if (r >= c && r < nb && c < nb) {
+                if (stream) st_wt(A + r + (int64_t)c * lda, As[c * PLD + r]);
+                else A[r + (int64_t)c * lda] = As[c * PLD + r];
+            }
         }
     }
     // inverses of the 16x16 diagonal blocks (trsm_panel_kernel): wave w <-> block w, lane j <-> column j of inv(L_d)
-    if (linv_out && wave < nt && !(halfp && wave < 4)) {      // (blocks 0..3 were done on the way when half_word is set)
+    // (blocks 0..3 were done on the way when half_word is set; all but the last one in stream mode)
+    if (linv_out && wave < nt && !(halfp && (stream ? wave < nt - 1 : wave < 4))) {
         const int jb = wave * 16, pw = min(16, nb - jb);
         const int j = lane & 15;
         double x[16];
@@ -516,7 +542,11 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
         }
         if (lane < 16) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) linv_out[wave * 256 + j * 16 + i] = (i < pw && j < pw && i >= j) ? x[i] : 0.0;
+            for (int i = 0; i < 16; ++i) {
+                const double v = (i < pw && j < pw && i >= j) ? x[i] : 0.0;
+                if (stream) st_wt(linv_out + wave * 256 + j * 16 + i, v);
+                else linv_out[wave * 256 + j * 16 + i] = v;
+            }
         }
     }
     P2_TS(42);
@@ -654,7 +684,9 @@ __device__ long long* g_tile_ts = nullptr;    // developer aid: 8 stamps per til
 struct TileCtl {
     unsigned ticket, abort_flag, pad0, pad1;
     unsigned prog[252];          // up to 252 block rows (n <= 32256); zeroed before every launch
-    unsigned half[252];          // dense factorisation: 1 once columns 0..63 of L(j,j) and their inverses are published
+    unsigned half[252];          // dense factorisation: 1 once columns 0..63 of L(j,j) and their inverses are published;
+                                 // stream mode: the number of 16-column micro panels of L(j,j) (and inverses) in memory, 0..8
+    unsigned micro[252];         // stream mode: the number of 16-column blocks of tile (i, i-1) in memory, 0..8
 };
 #define RLX_AGENT_ __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
@@ -668,7 +700,9 @@ struct TileCtl {
 constexpr int TILE_PF = 2;
 // TAIL: K need not be a multiple of TILE_PF * BK (the ragged last factored tile of a frontal matrix); the dense factorisation always
 // runs the TAIL = false instance, whose inner loop carries no extra checks.
-template <bool diag, bool TAIL>
+// L2: the operands are read with sc1 loads (written a moment ago with write-through stores by another compute unit and announced
+// without fences: the streamed last 128 columns of a diagonal tile).
+template <bool diag, bool TAIL, bool L2 = false>
 __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __restrict__ Xi, const double* __restrict__ Xj,
                                                 int64_t lda, int K, int mi, int mj, double* __restrict__ smem, int tid, int rt) {
     constexpr int PF = TILE_PF;                               // k-steps of operands in flight (global -> registers)
@@ -688,16 +722,19 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
             const double* pj = Xj + k * lda + ip;
             if (ktail) {
                 const bool kin = k < K;
-                J[2 * r] = (kin && ip < mj) ? pj[0] : 0.0;
-                J[2 * r + 1] = (kin && ip + 1 < mj) ? pj[1] : 0.0;
+                J[2 * r] = (kin && ip < mj) ? (L2 ? ld_l2(pj) : pj[0]) : 0.0;
+                J[2 * r + 1] = (kin && ip + 1 < mj) ? (L2 ? ld_l2(pj + 1) : pj[1]) : 0.0;
                 if (!diag) {
                     const double* pi = Xi + k * lda + ip;
-                    I[2 * r] = (kin && ip < mi) ? pi[0] : 0.0;
-                    I[2 * r + 1] = (kin && ip + 1 < mi) ? pi[1] : 0.0;
+                    I[2 * r] = (kin && ip < mi) ? (L2 ? ld_l2(pi) : pi[0]) : 0.0;
+                    I[2 * r + 1] = (kin && ip + 1 < mi) ? (L2 ? ld_l2(pi + 1) : pi[1]) : 0.0;
                 }
                 continue;
             }
-            if (fullJ) {
+            if (L2) {
+                J[2 * r] = (ip < mj) ? ld_l2(pj) : 0.0;
+                J[2 * r + 1] = (ip + 1 < mj) ? ld_l2(pj + 1) : 0.0;
+            } else if (fullJ) {
                 const d2u_ v = *reinterpret_cast<const d2u_*>(pj);
                 J[2 * r] = v.x;
                 J[2 * r + 1] = v.y;
@@ -707,7 +744,10 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
             }
             if (!diag) {
                 const double* pi = Xi + k * lda + ip;
-                if (fullI) {
+                if (L2) {
+                    I[2 * r] = (ip < mi) ? ld_l2(pi) : 0.0;
+                    I[2 * r + 1] = (ip + 1 < mi) ? ld_l2(pi + 1) : 0.0;
+                } else if (fullI) {
                     const d2u_ v = *reinterpret_cast<const d2u_*>(pi);
                     I[2 * r] = v.x;
                     I[2 * r + 1] = v.y;
@@ -774,7 +814,9 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
 }
 
 // one lane: wait until *p >= need (or abort); returns the value seen, 0xffffffff on abort / timeout
-__device__ __forceinline__ unsigned tile_wait(const unsigned* p, const unsigned* p2, unsigned need, TileCtl* ctl, int* err) {
+// acquire = false: the data behind the word was stored write-through and is read with sc1 loads (no L1 invalidate needed)
+__device__ __forceinline__ unsigned tile_wait(const unsigned* p, const unsigned* p2, unsigned need, TileCtl* ctl, int* err,
+                                              bool acquire = true) {
     for (unsigned spins = 0; spins < (1u << 24); ++spins) {
         unsigned v = __hip_atomic_load(p, RLX_AGENT_);
         if (p2) {
@@ -782,7 +824,7 @@ __device__ __forceinline__ unsigned tile_wait(const unsigned* p, const unsigned*
             v = v < v2 ? v : v2;
         }
         if (v >= need) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             return v;
         }
         if (__hip_atomic_load(&ctl->abort_flag, RLX_AGENT_)) return 0xffffffffu;
@@ -872,6 +914,8 @@ struct TileJob {
     int q, w;                // k-tile boundaries: column 128 kt for kt <= q, w beyond (fronts: ragged last factored tile)
     bool factored;           // true: the tile belongs to the factored columns (potf2 / trsm + publish); false: Schur part, store
     unsigned* half_j;        // dense only: half word of the diagonal tile of column j (nullptr: not used)
+    unsigned* micro_i;       // dense only (round 3, tile_process<.., STREAM>): 16-column streaming of L(j,j) to the tiles below (half_j
+                             //   counts micro panels) and of tile (i, i-1) to the diagonal tile (i, i): micro word of block row i
     unsigned* prog_i;        // progress word of the tile's block row (published to when factored)
     unsigned* prog_j;        // progress word of block row j (the tile's column index); == prog_i on diagonal tiles
     unsigned pub;            // value published / waited for once column j is final: j + 1
@@ -885,7 +929,7 @@ struct TileJob {
 __device__ __forceinline__ int tile_kcol(const TileJob& J, int kt) { return kt <= J.q ? kt * NB : J.w; }
 
 // returns false when the workgroup has to leave the kernel (abort / timeout).  VB: batched fronts (ragged k ranges possible)
-template <bool VB>
+template <bool VB, bool STREAM = false>
 __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int* err, double* __restrict__ smem,
                                              unsigned* ctlw, int tid, unsigned t, long long* tts) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -908,11 +952,15 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
             acc[tt][r] = (row < mi && col < mj && (!diag || row >= col)) ? A[i0 + row + (int64_t)(j0 + col) * lda] : 0.0;
         }
     // ---- left-looking accumulation over the columns that are final, as they become final
+    // sdiag (stream mode): the last 128 columns of a diagonal tile -- tile (i, i-1), the one the chain waits for -- are consumed
+    // as 16-column blocks while the triangular solve that produces them is still running (micro word of block row i)
+    const bool sdiag = !VB && STREAM && diag && J.nk >= 1;       // (STREAM: n is a multiple of 128, every tile is whole)
+    const int nk_plain = sdiag ? J.nk - 1 : J.nk;
     int kdone = 0;
-    while (kdone < J.nk) {
+    while (kdone < nk_plain) {
         if (tid == 0) {
             const unsigned v = tile_wait(J.prog_i, diag ? nullptr : J.prog_j, (unsigned)kdone + 1, ctl, err);
-            ctlw[1] = (v == 0xffffffffu) ? v : (v < (unsigned)J.nk ? v : (unsigned)J.nk);
+            ctlw[1] = (v == 0xffffffffu) ? v : (v < (unsigned)nk_plain ? v : (unsigned)nk_plain);
         }
         __syncthreads();
         const unsigned ka = ctlw[1];
@@ -929,6 +977,21 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
         else
             tile_accumulate<false, false>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
         kdone = (int)ka;                                  // (tile_accumulate ends with a barrier: ctlw[1] is free again)
+    }
+    if (sdiag) {
+        const int c0 = tile_kcol(J, J.nk - 1);
+        int kb = 0;
+        while (kb < 8) {
+            if (tid == 0) ctlw[1] = tile_wait(J.micro_i, nullptr, (unsigned)kb + 1, ctl, err, false);
+            __syncthreads();
+            const unsigned v = ctlw[1];
+            if (v == 0xffffffffu) return false;
+            const int kb1 = v < 8u ? (int)v : 8;
+            if (kb1 == 8) PT_TS(5);                           // the last block has arrived
+            const double* X = A + i0 + (int64_t)(c0 + 16 * kb) * lda;
+            tile_accumulate<true, true, true>(acc, X, X, lda, 16 * (kb1 - kb), mi, mj, smem, tid, rt);
+            kb = kb1;                                         // (ends with a barrier: ctlw[1] is free again)
+        }
     }
     PT_TS(1);
     if (!J.factored) {
@@ -949,7 +1012,9 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
         for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) As[(tt * 16 + lq + 4 * r) * PLD + row] = acc[tt][r];
-        const int failed = potf2_la_body<true>(A + j0 + (int64_t)j0 * lda, lda, mj, J.linv, smem, nullptr, VB ? nullptr : J.half_j);
+        constexpr bool dstream = !VB && STREAM;
+        const int failed = potf2_la_body<true>(A + j0 + (int64_t)j0 * lda, lda, mj, J.linv, smem, nullptr, VB ? nullptr : J.half_j,
+                                               dstream);
         if (failed) {
             if (tid == 0) atomicCAS(J.info, 0, J.info_base + failed);
             if (J.abort_on_fail) {
@@ -960,12 +1025,112 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
             return true;
         }
         PT_TS(3);
+        if (dstream) {            // the last micro panel and inverse (write-through stores): drained -> all eight are announced
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(J.half_j, 8u, RLX_AGENT_);
+        }
         tile_publish(J.prog_i, J.pub, tid);
         PT_TS(4);
         if (J.minv) {             // after the publish: nobody on the factorisation's chain waits for this
             __syncthreads();
             tile_invert_diag(As, J.linv, mj, J.minv, tid);
         }
+        return true;
+    }
+    // ---- X L(j,j)' = B on the accumulators (transposed tiles, diagonal blocks by inverse + one refinement step, as
+    //      trsm_panel_kernel), operands from the LDS image of L(j,j); column block cb needs row block cb of L(j,j) (its columns
+    //      0 .. 16 cb + 15) and the inverse of the diagonal block cb
+    auto solve_block = [&](auto cbc) {
+        constexpr int cb = decltype(cbc)::value;
+        d4 a4 = acc[cb], a5 = d4{0.0, 0.0, 0.0, 0.0};     // two chains: the matrix pipe is not left waiting on one accumulator
+#pragma unroll
+        for (int c = 0; c < cb; ++c) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4 += 2) {
+                const double lv0 = As[(16 * c + 4 * s4 + lq) * PLD + 16 * cb + li];
+                const double lv1 = As[(16 * c + 4 * (s4 + 1) + lq) * PLD + 16 * cb + li];
+                a4 = MFMA_F64(-lv0, acc[c][s4], a4);
+                a5 = MFMA_F64(-lv1, acc[c][s4 + 1], a5);
+            }
+        }
+        if (cb > 0) a4 += a5;
+        double mi4[4], ld4[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            mi4[s4] = As[(16 * cb + 4 * s4 + lq) * PLD + NB + li];
+            const double lv = As[(16 * cb + 4 * s4 + lq) * PLD + 16 * cb + li];
+            ld4[s4] = (4 * s4 + lq <= li) ? -lv : 0.0;
+        }
+        d4 x0 = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) x0 = MFMA_F64(mi4[s4], a4[s4], x0);
+        d4 e4 = a4;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) e4 = MFMA_F64(ld4[s4], x0[s4], e4);
+        d4 xx = x0;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) xx = MFMA_F64(mi4[s4], e4[s4], xx);
+        acc[cb] = xx;
+        __builtin_amdgcn_sched_barrier(0);            // operand reads run ahead inside one column block only (register budget)
+    };
+    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+    using C4 = std::integral_constant<int, 4>; using C5 = std::integral_constant<int, 5>;
+    using C6 = std::integral_constant<int, 6>; using C7 = std::integral_constant<int, 7>;
+    if constexpr (!VB && STREAM) {
+        // ---- stream mode (round 3): L(j,j) arrives as 16-column micro panels (write-through stores of the diagonal tile's owner,
+        //      half word = panels in memory, no fences): every look takes what has been announced, row block by row block, with
+        //      sc1 loads; the finished column blocks of this tile go back to memory the same way.  Tile (j+1, j) -- the one the next
+        //      diagonal tile waits for -- announces its column blocks through the micro word of its block row, one block behind.
+        const double* __restrict__ Lg = A + j0 + (int64_t)j0 * lda;
+        const bool announce = J.micro_i != nullptr;
+        int staged = 0;                                   // row blocks of L(j,j) in the LDS image
+        auto step = [&](auto cbc) -> bool {
+            constexpr int cb = decltype(cbc)::value;
+            if (staged <= cb) {
+                if (tid == 0) ctlw[1] = tile_wait(J.half_j, nullptr, (unsigned)cb + 1, ctl, err, false);
+                __syncthreads();
+                const unsigned v = ctlw[1];
+                if (v == 0xffffffffu) return false;
+                const int upto = v < 8u ? (int)v : 8;
+                if (cb == 0) PT_TS(2);
+                for (int b = staged; b < upto; ++b) {     // row block b: rows 16 b .. + 15, columns 0 .. 16 b + 15, and D_b
+                    const int nel = 256 * (b + 1);
+                    for (int e = tid; e < nel; e += PT_THREADS) {
+                        const int r = 16 * b + (e & 15), c = e >> 4;
+                        As[c * PLD + r] = (r >= (c & ~15)) ? ld_l2(Lg + r + (int64_t)c * lda) : 0.0;
+                    }
+                    if (tid < 256) As[(16 * b + (tid >> 4)) * PLD + NB + (tid & 15)] = ld_l2(J.linv + 256 * b + tid);
+                }
+                staged = upto;
+                __syncthreads();
+            }
+            solve_block(cbc);
+            // column block cb of the tile is final: to memory (write-through)
+            if (row < mi) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_wt(A + i0 + row + (int64_t)(j0 + 16 * cb + lq + 4 * r) * lda, acc[cb][r]);
+            }
+            if (announce && cb > 0) {                     // blocks 0 .. cb-1 were stored a block ago: drained by now
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (all but this block's four stores)
+                __syncthreads();
+                if (tid == 0) __hip_atomic_store(J.micro_i, (unsigned)cb, RLX_AGENT_);
+            }
+            return true;
+        };
+        if (!step(C0{}) || !step(C1{}) || !step(C2{}) || !step(C3{}) || !step(C4{}) || !step(C5{}) || !step(C6{}) || !step(C7{}))
+            return false;
+        PT_TS(3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            if (announce) __hip_atomic_store(J.micro_i, 8u, RLX_AGENT_);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // (nothing dirty to write back: the tile went out write-through)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(J.prog_i, J.pub, RLX_AGENT_);
+        }
+        PT_TS(4);
         return true;
     }
     // halfmode (dense, full tiles): the diagonal tile publishes its columns 0..63 (+ the inverses of the diagonal blocks
@@ -1007,47 +1172,22 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
     stage(0);
     if (!halfmode) stage(1);
     __syncthreads();
-    // ---- X L(j,j)' = B on the accumulators (transposed tiles, diagonal blocks by inverse + one refinement step,
-    //      as trsm_panel_kernel), operands from LDS
-#pragma unroll
-    for (int cb = 0; cb < 8; ++cb) {
-        if (cb == 4 && halfmode) {                    // the second half of L(j,j): wait for the tile's final publish
+    {
+        solve_block(C0{});
+        solve_block(C1{});
+        solve_block(C2{});
+        solve_block(C3{});
+        if (halfmode) {                               // the second half of L(j,j): wait for the tile's final publish
             if (tid == 0) ctlw[1] = tile_wait(J.prog_j, nullptr, J.pub, ctl, err);
             __syncthreads();
             if (ctlw[1] == 0xffffffffu) return false;
             stage(1);
             __syncthreads();
         }
-        d4 a4 = acc[cb], a5 = d4{0.0, 0.0, 0.0, 0.0};     // two chains: the matrix pipe is not left waiting on one accumulator
-#pragma unroll
-        for (int c = 0; c < cb; ++c) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4 += 2) {
-                const double lv0 = As[(16 * c + 4 * s4 + lq) * PLD + 16 * cb + li];
-                const double lv1 = As[(16 * c + 4 * (s4 + 1) + lq) * PLD + 16 * cb + li];
-                a4 = MFMA_F64(-lv0, acc[c][s4], a4);
-                a5 = MFMA_F64(-lv1, acc[c][s4 + 1], a5);
-            }
-        }
-        if (cb > 0) a4 += a5;
-        double mi4[4], ld4[4];
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) {
-            mi4[s4] = As[(16 * cb + 4 * s4 + lq) * PLD + NB + li];
-            const double lv = As[(16 * cb + 4 * s4 + lq) * PLD + 16 * cb + li];
-            ld4[s4] = (4 * s4 + lq <= li) ? -lv : 0.0;
-        }
-        d4 x0 = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) x0 = MFMA_F64(mi4[s4], a4[s4], x0);
-        d4 e4 = a4;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) e4 = MFMA_F64(ld4[s4], x0[s4], e4);
-        d4 xx = x0;
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) xx = MFMA_F64(mi4[s4], e4[s4], xx);
-        acc[cb] = xx;
-        __builtin_amdgcn_sched_barrier(0);            // operand reads run ahead inside one column block only (register budget)
+        solve_block(C4{});
+        solve_block(C5{});
+        solve_block(C6{});
+        solve_block(C7{});
     }
     // (stores after the branch-free solve: the compiler can then run the LDS operand reads ahead of the MFMAs)
     if (mi == NB && mj == NB) {
@@ -1070,6 +1210,7 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
     return true;
 }
 
+template <bool STREAM>
 __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int n, TileCtl* ctl,
                                                                  double* __restrict__ linv_all, int* __restrict__ info,
                                                                  int* __restrict__ err, double* __restrict__ minv_all,
@@ -1104,12 +1245,14 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
         J.factored = true;
         J.prog_i = &ctl->prog[i]; J.prog_j = &ctl->prog[j];
         J.half_j = use_half ? &ctl->half[j] : nullptr;
+        // the micro word of block row i: written by tile (i, i-1), read by the diagonal tile (i, i)
+        J.micro_i = (STREAM && (i == j || i == j + 1)) ? &ctl->micro[i] : nullptr;
         J.pub = (unsigned)j + 1;
         J.linv = linv_all + (int64_t)j * 2048;
         J.minv = minv_all ? minv_all + (int64_t)j * 2 * NB * NB : nullptr;
         J.info = info; J.info_base = J.j0;
         J.abort_on_fail = true;
-        if (!tile_process<false>(J, ctl, err, smem, ctlw, tid, t, g_tile_ts)) return;
+        if (!tile_process<false, STREAM>(J, ctl, err, smem, ctlw, tid, t, g_tile_ts)) return;
         __syncthreads();                                      // LDS (image, control words) is reused by the next tile
     }
 }
@@ -1157,6 +1300,7 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_vb_kernel(double* __re
         J.q = q; J.w = dd.w;
         J.prog_i = fprog + tk.i; J.prog_j = fprog + tk.j;
         J.half_j = nullptr;
+        J.micro_i = nullptr;
         J.pub = (unsigned)tk.j + 1;
         J.linv = linv_all + (int64_t)(linv_off[tk.front] + (J.factored ? tk.j : 0)) * 2048;
         J.minv = nullptr;
@@ -1287,7 +1431,9 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
         hipDeviceProp_t prop;
         KKT_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel),
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -1297,9 +1443,15 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
     const int ntiles = NT * (NT + 1) / 2;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
     static const bool no_minv = getenv("MI355KKT_NO_MINV") != nullptr;
-    static const int use_half = getenv("MI355KKT_POTRF_HALF") ? atoi(getenv("MI355KKT_POTRF_HALF")) : 1;
-    hipLaunchKernelGGL(potrf_tiles_kernel, dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n, reinterpret_cast<TileCtl*>(w.d_ctl),
-                       w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
+    // 0: whole tiles only; 1: half-tile hand-off of L(j,j) (round 2); 2: 16-column streaming (round 3).  Streaming needs whole tiles
+    static const int half_env = getenv("MI355KKT_POTRF_HALF") ? atoi(getenv("MI355KKT_POTRF_HALF")) : 2;
+    const int use_half = (half_env == 2 && n % NB) ? 1 : half_env;
+    if (use_half == 2)
+        hipLaunchKernelGGL(potrf_tiles_kernel<true>, dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
+                           reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
+    else
+        hipLaunchKernelGGL(potrf_tiles_kernel<false>, dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
+                           reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
     KKT_HIP_CHECK(hipGetLastError());
     w.minv_n = no_minv ? 0 : n;          // the 128 x 128 inverses of this factor's diagonal blocks are valid
     w.minv_of = A;

@@ -58,33 +58,49 @@ def test_lockstep_batch_matches_individual_reference_runs(ref_cvxopt):
     assert len(set(its)) > 1, "test should exercise the per-problem active mask"
 
 
-def _worker(rank, world, port, tmp):
+def _worker(rank, world, port, tmp, nprob, nsub):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
-    from cvxopt_amd.batch import coneqp_batch_sharded
+    from cvxopt_amd import batch
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = {}
+    for rep in range(2):                             # the second call reuses the cached ShardedBatch (buffers, sub-batch plan)
+        if rank == 0:
+            probs = make_batch(nprob, 16, 40, seed0=3 + 100 * rep)
+            P, q, Gt, h = pack_problems(probs)
+        else:
+            P = q = Gt = h = None
+        res = batch.coneqp_batch_sharded(P, q, Gt, h, local_solver=numpy_local_solver, nsub=nsub)
+        if rank == 0:
+            out.update({"x%d" % rep: res['x'], "it%d" % rep: res['iterations'], "pobj%d" % rep: res['primal objective'],
+                        "z%d" % rep: res['z']})
+        else:                                        # the other ranks get their own shard back
+            lo, hi = batch.shard_bounds(nprob, world)[rank]
+            assert res['x'].shape[0] == hi - lo
+    assert len(batch._SHARDED_CACHE) == 1
+    sb = next(iter(batch._SHARDED_CACHE.values()))
+    assert set(sb.last_timings) >= {"scatter_exposed", "scatter_all", "solve", "gather_exposed", "total"}
     if rank == 0:
-        probs = make_batch(5, 16, 40, seed0=3)       # 5 problems over 2 ranks: shards of 3 and 2
-        P, q, Gt, h = pack_problems(probs)
-    else:
-        P = q = Gt = h = None
-    res = coneqp_batch_sharded(P, q, Gt, h, local_solver=numpy_local_solver)
-    if rank == 0:
-        np.savez(tmp, x=res['x'], it=res['iterations'], pobj=res['primal objective'])
+        np.savez(tmp, **out)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_batch_on_gloo_world_size_2(tmp_path):
+@pytest.mark.parametrize("world,nprob,nsub", [(2, 5, 4), (3, 7, 4), (3, 8, 2), (2, 6, 1)])
+def test_sharded_batch_on_gloo(tmp_path, world, nprob, nsub):
+    """unequal shards (5 over 2, 7 over 3), sub-batches that are empty on the short ranks, the un-pipelined path (nsub = 1),
+    two solves through one persistent ShardedBatch: per-problem equality with the single-process solve"""
     import torch.multiprocessing as mp
     tmp = str(tmp_path / "out.npz")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, tmp), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 * world + nprob
+    mp.spawn(_worker, args=(world, port, tmp, nprob, nsub), nprocs=world, join=True)
     got = np.load(tmp)
-    probs = make_batch(5, 16, 40, seed0=3)
-    P, q, Gt, h = pack_problems(probs)
-    ref = coneqp_batch(P, q, Gt, h, kkt=NumpyBatchKkt(Gt, P))
-    assert np.array_equal(got['it'], ref['iterations'])
-    assert np.allclose(got['x'], ref['x'], rtol=0, atol=1e-12)
-    assert np.allclose(got['pobj'], ref['primal objective'], rtol=1e-13)
+    for rep in range(2):
+        probs = make_batch(nprob, 16, 40, seed0=3 + 100 * rep)
+        P, q, Gt, h = pack_problems(probs)
+        ref = coneqp_batch(P, q, Gt, h, kkt=NumpyBatchKkt(Gt, P))
+        assert np.array_equal(got['it%d' % rep], ref['iterations'])
+        assert np.allclose(got['x%d' % rep], ref['x'], rtol=0, atol=1e-12)
+        assert np.allclose(got['z%d' % rep], ref['z'], rtol=0, atol=1e-12)
+        assert np.allclose(got['pobj%d' % rep], ref['primal objective'], rtol=1e-13)

@@ -166,7 +166,9 @@ def test_sharded_batch_on_rccl():
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+    from cvxopt_amd import _capi
+    nproc = max(1, min(8, _capi.device_count()))             # every visible GPU (the round's box has one)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
                           "--master-addr", "127.0.0.1", "--master-port", "29531",
                           os.path.join(here, "run_batch_sharded_nccl.py")], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
