@@ -714,6 +714,9 @@ __device__ __forceinline__ double pair_sum(double v) {           // v(lane) + v(
     return v + __hiloint2double(hi, lo);
 }
 
+__device__ long long* g_trsvz_ts = nullptr;   // developer aid: 8 stamps (shader clock) per block of the last trsv_z launch when set
+int set_trsvz_ts(long long* dptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_trsvz_ts), &dptr, sizeof(dptr)) == hipSuccess ? 0 : -2; }
+#define TZ_TS(i_) do { if (tts && tid == 0) tts[(int64_t)k * 8 + (i_)] = (long long)__builtin_readcyclecounter(); } while (0)
 constexpr int ZV = TB + 2;       // LDS vector: entries 64..127 sit 2 doubles further (the two lanes of a pair read different banks)
 
 template <bool TRANS>
@@ -721,6 +724,11 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
                                                      int* err, u64* gran, const double* __restrict__ minv,
                                                      const double* __restrict__ zmat) {
     __shared__ __attribute__((aligned(16))) double vb[4][ZV + 2];
+    __shared__ int bad;
+    // LDS-only barrier: `s_waitcnt lgkmcnt(0); s_barrier`.  __syncthreads() also waits for every outstanding GLOBAL load
+    // (vmcnt(0)): the strips of the pre-multiplied blocks are fetched while phase B runs, and with __syncthreads() each of its
+    // barriers stalled for those 64 loads per thread (measured: phase B 10 us instead of ~1.5).
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     const int tid = threadIdx.x;
     const int r = tid >> 1, half = tid & 1, ch = 64 * half;
     const int nblk = n / TB;
@@ -728,8 +736,12 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
     const int k0 = k * TB, idx = k0 + r;
     const int vpos = r + ((r >> 6) << 1);                  // my row's slot in an LDS vector
     const int vh = ch + 2 * half;                          // first slot of my half of a vector
+    if (tid == 0) bad = 0;
+    lds_barrier();
     int vi = 0;                                            // running stage counter: stage t uses vb[t & 3]
     double acc = half == 0 ? x[idx] : 0.0;
+    long long* tts = g_trsvz_ts;
+    TZ_TS(0);
 
     // receive block j of the solution into an LDS vector: thread tid polls granule tid (word `half` of row r)
     auto recv = [&](int j, double* buf) -> bool {
@@ -742,7 +754,9 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
             __builtin_amdgcn_s_sleep(1);
         }
         reinterpret_cast<u32*>(buf)[2 * vpos + half] = (u32)v;
-        if (__syncthreads_or(got ? 0 : 1)) {
+        if (!got) bad = 1;
+        lds_barrier();
+        if (bad) {
             if (tid == 0) atomicExch(err, 1);
             return false;                                  // timeout: give up (err is set)
         }
@@ -797,42 +811,50 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
         if (!recv(j, buf)) return;
         acc -= dot64(l0, buf);
     }
+    TZ_TS(1);
+    // the strip of the block two hops up: fetched now (the registers of phase A's strips are free), it lands while phase B runs
+    const double* Zk = zmat + (int64_t)k * (2 * TB * TB);
+    double z2[64];
+    if (nsteps >= 2) {
+#pragma unroll
+        for (int c = 0; c < 64; ++c) z2[c] = ldu(Zk + TB * TB + c * TB, voffM);
+    }
     // ---- phase B: c' = L_kk^-1 (b_k - sum of phase A), x0 = M b, e = b - L_kk x0, c' = x0 + M e
     const double b = pair_sum(acc);
     double* buf = vb[vi++ & 3];
     if (half == 0) buf[vpos] = b;
-    __syncthreads();
+    lds_barrier();
     const double x0 = pair_sum(dot64(ra, buf));
     buf = vb[vi++ & 3];
     if (half == 0) buf[vpos] = x0;
-    __syncthreads();
+    lds_barrier();
     const double e = b - pair_sum(dot64(rb, buf));
-    // the strips of the two pre-multiplied blocks take over the registers of the L_kk / M strips as those die
-    const double* Zk = zmat + (int64_t)k * (2 * TB * TB);
-    if (nsteps >= 2) {                                     // Z2 strip -> rb
+    // the strip of the block one hop up takes over the registers of the L_kk strip (dead now); it lands behind phase C
+    if (nsteps >= 1) {                                     // Z1 strip -> rb
 #pragma unroll
-        for (int c = 0; c < 64; ++c) rb[c] = ldu(Zk + TB * TB + c * TB, voffM);
+        for (int c = 0; c < 64; ++c) rb[c] = ldu(Zk + c * TB, voffM);
     }
     buf = vb[vi++ & 3];
     if (half == 0) buf[vpos] = e;
-    __syncthreads();
+    lds_barrier();
     double xk = x0 + pair_sum(dot64(ra, buf));
-    if (nsteps >= 1) {                                     // Z1 strip -> ra
-#pragma unroll
-        for (int c = 0; c < 64; ++c) ra[c] = ldu(Zk + c * TB, voffM);
-    }
+    TZ_TS(2);
     // ---- phase C: the block two hops up
     if (nsteps >= 2) {
         buf = vb[vi++ & 3];
         if (!recv(TRANS ? k + 2 : k - 2, buf)) return;
-        xk -= pair_sum(dot64(rb, buf));
+        TZ_TS(3);
+        xk -= pair_sum(dot64(z2, buf));
     }
+    TZ_TS(4);
     // ---- phase D: the block one hop up -- the only stage between its arrival and my publication
     if (nsteps >= 1) {
         buf = vb[vi++ & 3];
         if (!recv(TRANS ? k + 1 : k - 1, buf)) return;
-        xk -= pair_sum(dot64(ra, buf));
+        TZ_TS(5);
+        xk -= pair_sum(dot64(rb, buf));
     }
+    TZ_TS(6);
     // publish: every thread one granule (its word of x_r), then the plain copy for the caller
     {
         const u64 tag = (u64)epoch << 32;
@@ -840,6 +862,7 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
         __hip_atomic_store(gran + (int64_t)k * 256 + tid, tag | word, RLX_AGENT);
         if (half == 0) x[idx] = xk;
     }
+    TZ_TS(7);
 }
 
 // block (k, k -+ q) of the factor (forward: the lower block; backward: the mirrored upper block = L_{k+q,k}') -> Z storage

@@ -9,7 +9,7 @@ OBJ="$HERE/.obj"; mkdir -p "$OBJ"
 pids=()
 for f in gemm_f64 potrf blas2 cone_scale sparse_chol batch_ipm conelp_ipm coneqp_ipm capi; do
   src="$HERE/$f.hip"; obj="$OBJ/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/kkt_common.h" -nt "$obj" ] || [ "$HERE/cone_ops.h" -nt "$obj" ] || [ "$HERE/ordering.h" -nt "$obj" ] || [ "$HERE/../../include/mi355kkt.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/kkt_common.h" -nt "$obj" ] || [ "$HERE/cone_ops.h" -nt "$obj" ] || [ "$HERE/cone_ops_s.h" -nt "$obj" ] || [ "$HERE/ordering.h" -nt "$obj" ] || [ "$HERE/../../include/mi355kkt.h" -nt "$obj" ]; then
     ( "$HIPCC" $FLAGS -c "$src" -o "$obj" ) &
     pids+=($!)
   fi

@@ -143,6 +143,7 @@ int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int t
 // round 3: the persistent solve with the two blocks next to the diagonal pre-multiplied by L_kk^-1 (blas2.hip, trsv_z_kernel):
 // trsv_z_prepare once per factorisation (after launch_mirror_lower), zmat holds trsv_z_doubles(n) doubles; n % 128 == 0
 size_t trsv_z_doubles(int n);
+int set_trsvz_ts(long long* dptr);   // developer aid: 8 stamps per 128-block of the next trsv_z launches (nullptr: off)
 int trsv_z_prepare(const double* L, int64_t ldl, int n, double* zmat, hipStream_t st);
 int launch_trsv_z(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
                   unsigned long long* gran, const double* minv, const double* zmat);

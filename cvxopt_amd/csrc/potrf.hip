@@ -702,23 +702,26 @@ constexpr int TILE_PF = 2;
 // runs the TAIL = false instance, whose inner loop carries no extra checks.
 // L2: the operands are read with sc1 loads (written a moment ago with write-through stores by another compute unit and announced
 // without fences: the streamed last 128 columns of a diagonal tile).
-template <bool diag, bool TAIL, bool L2 = false>
+// TBK: k-depth of one LDS stage (16, or 32: half the barriers per MFMA -- the dense factorisation's bulk; K a multiple of TBK)
+template <bool diag, bool TAIL, bool L2 = false, int TBK = BK>
 __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __restrict__ Xi, const double* __restrict__ Xj,
                                                 int64_t lda, int K, int mi, int mj, double* __restrict__ smem, int tid, int rt) {
-    constexpr int PF = TILE_PF;                               // k-steps of operands in flight (global -> registers)
+    constexpr int PF = TBK == 32 ? 1 : TILE_PF;               // k-steps of operands in flight (global -> registers); same depth in k
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int ip = (tid & 63) * 2, kq = tid >> 6;            // staging: index pair, k = kq + 8 r
-    auto sJ = [&](int s_) -> double* { return smem + s_ * 2 * STAGE_DOUBLES; };
-    auto sI = [&](int s_) -> double* { return smem + s_ * 2 * STAGE_DOUBLES + STAGE_DOUBLES; };
-    const int nkt = (K + BK - 1) / BK;                        // dense potrf: K is a multiple of 128; fronts: any K > 0
-    double rJ[PF][4], rI[PF][4];
+    constexpr int STG = TBK * LDT_M;                           // doubles per operand per stage
+    constexpr int NR = TBK / 8;                                // k rows per thread and stage (8 waves)
+    auto sJ = [&](int s_) -> double* { return smem + s_ * 2 * STG; };
+    auto sI = [&](int s_) -> double* { return smem + s_ * 2 * STG + STG; };
+    const int nkt = (K + TBK - 1) / TBK;                        // dense potrf: K is a multiple of 128; fronts: any K > 0
+    double rJ[PF][2 * NR], rI[PF][2 * NR];
     const bool fullJ = (mj == 128), fullI = (mi == 128);
-    auto fetch = [&](int kt, double (&J)[4], double (&I)[4]) {
-        const bool ktail = TAIL && (kt + 1) * BK > K;         // last step of a ragged k range: rows k >= K read as zero
+    auto fetch = [&](int kt, double (&J)[2 * NR], double (&I)[2 * NR]) {
+        const bool ktail = TAIL && (kt + 1) * TBK > K;         // last step of a ragged k range: rows k >= K read as zero
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int64_t k = (int64_t)kt * BK + kq + 8 * r;
+        for (int r = 0; r < NR; ++r) {
+            const int64_t k = (int64_t)kt * TBK + kq + 8 * r;
             const double* pj = Xj + k * lda + ip;
             if (ktail) {
                 const bool kin = k < K;
@@ -758,9 +761,9 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
             }
         }
     };
-    auto stash = [&](int s_, const double (&J)[4], const double (&I)[4]) {   // J stored negated: the MFMAs accumulate C - A B'
+    auto stash = [&](int s_, const double (&J)[2 * NR], const double (&I)[2 * NR]) {   // J stored negated: the MFMAs accumulate C - A B'
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int k = kq + 8 * r;
             d2_ vj = {-J[2 * r], -J[2 * r + 1]};
             *reinterpret_cast<d2_*>(sJ(s_) + k * LDT_M + ip) = vj;
@@ -782,11 +785,11 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
             const int kt = kt0 + u;
             if (TAIL && kt >= nkt) break;                     // (uniform) odd number of steps
             if (kt + PF < nkt) fetch(kt + PF, rJ[u], rI[u]);  // slot u held step kt, which went to LDS one step ago
-            const double* __restrict__ Js = sJ(u & 1);
-            const double* __restrict__ Is = sI(u & 1) + rt * 16;
+            const double* __restrict__ Js = sJ(kt & 1);
+            const double* __restrict__ Is = sI(kt & 1) + rt * 16;
             if (!diag) {                                      // branch-free body for the common case
 #pragma unroll
-                for (int kk = 0; kk < BK; kk += 4) {
+                for (int kk = 0; kk < TBK; kk += 4) {
                     const double bv = Is[li + (kk + lq) * LDT_M];
                     double av[8];
 #pragma unroll
@@ -796,7 +799,7 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
                 }
             } else {                                          // diagonal tile: column blocks right of the row block are not needed
 #pragma unroll
-                for (int kk = 0; kk < BK; kk += 4) {
+                for (int kk = 0; kk < TBK; kk += 4) {
                     const double bv = Is[li + (kk + lq) * LDT_M];
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
@@ -807,7 +810,7 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
                     }
                 }
             }
-            if (kt + 1 < nkt) stash((u + 1) & 1, rJ[(u + 1) % PF], rI[(u + 1) % PF]);
+            if (kt + 1 < nkt) stash((kt + 1) & 1, rJ[(u + 1) % PF], rI[(u + 1) % PF]);
             __syncthreads();
         }
     }
@@ -929,7 +932,7 @@ struct TileJob {
 __device__ __forceinline__ int tile_kcol(const TileJob& J, int kt) { return kt <= J.q ? kt * NB : J.w; }
 
 // returns false when the workgroup has to leave the kernel (abort / timeout).  VB: batched fronts (ragged k ranges possible)
-template <bool VB, bool STREAM = false>
+template <bool VB, bool STREAM = false, int TBK = BK>
 __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int* err, double* __restrict__ smem,
                                              unsigned* ctlw, int tid, unsigned t, long long* tts) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -954,7 +957,8 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
     // ---- left-looking accumulation over the columns that are final, as they become final
     // sdiag (stream mode): the last 128 columns of a diagonal tile -- tile (i, i-1), the one the chain waits for -- are consumed
     // as 16-column blocks while the triangular solve that produces them is still running (micro word of block row i)
-    const bool sdiag = !VB && STREAM && diag && J.nk >= 1;       // (STREAM: n is a multiple of 128, every tile is whole)
+    // (dense STREAM: n is a multiple of 128, every tile is whole; fronts: the kernel sets micro_i only where tile (i, i-1) is whole)
+    const bool sdiag = STREAM && diag && J.nk >= 1 && (!VB || (J.micro_i != nullptr && J.factored));
     const int nk_plain = sdiag ? J.nk - 1 : J.nk;
     int kdone = 0;
     while (kdone < nk_plain) {
@@ -973,9 +977,9 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
             else
                 tile_accumulate<false, true>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
         } else if (diag)
-            tile_accumulate<true, false>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
+            tile_accumulate<true, false, false, TBK>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
         else
-            tile_accumulate<false, false>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
+            tile_accumulate<false, false, false, TBK>(acc, A + i0 + (int64_t)c0 * lda, A + j0 + (int64_t)c0 * lda, lda, c1 - c0, mi, mj, smem, tid, rt);
         kdone = (int)ka;                                  // (tile_accumulate ends with a barrier: ctlw[1] is free again)
     }
     if (sdiag) {
@@ -1012,7 +1016,7 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
         for (int tt = 0; tt < 8; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) As[(tt * 16 + lq + 4 * r) * PLD + row] = acc[tt][r];
-        constexpr bool dstream = !VB && STREAM;
+        const bool dstream = STREAM && (!VB || (J.half_j != nullptr && mj == NB));
         const int failed = potf2_la_body<true>(A + j0 + (int64_t)j0 * lda, lda, mj, J.linv, smem, nullptr, VB ? nullptr : J.half_j,
                                                dstream);
         if (failed) {
@@ -1021,6 +1025,7 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
                 if (tid == 0) __hip_atomic_store(&ctl->abort_flag, 1u, RLX_AGENT_);
                 return false;
             }
+            if (dstream && tid == 0) __hip_atomic_store(J.half_j, 8u, RLX_AGENT_);   // releases the streaming tiles below (on garbage)
             tile_publish(J.prog_i, J.pub, tid);
             return true;
         }
@@ -1078,7 +1083,8 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
     using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
     using C4 = std::integral_constant<int, 4>; using C5 = std::integral_constant<int, 5>;
     using C6 = std::integral_constant<int, 6>; using C7 = std::integral_constant<int, 7>;
-    if constexpr (!VB && STREAM) {
+    const bool smode = STREAM && (!VB || (J.half_j != nullptr && mj == NB));
+    if (smode) {
         // ---- stream mode (round 3): L(j,j) arrives as 16-column micro panels (write-through stores of the diagonal tile's owner,
         //      half word = panels in memory, no fences): every look takes what has been announced, row block by row block, with
         //      sc1 loads; the finished column blocks of this tile go back to memory the same way.  Tile (j+1, j) -- the one the next
@@ -1133,6 +1139,7 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
         PT_TS(4);
         return true;
     }
+    if constexpr (VB || !STREAM) {
     // halfmode (dense, full tiles): the diagonal tile publishes its columns 0..63 (+ the inverses of the diagonal blocks
     // 0..3) while its second half is still being factored; the first four column blocks of this solve need nothing else
     const bool halfmode = !VB && J.half_j != nullptr && mj == NB;
@@ -1204,13 +1211,14 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
                 if (col < mj) A[i0 + row + (int64_t)(j0 + col) * lda] = acc[cb][r];
             }
     }
+    }
     PT_TS(3);
     tile_publish(J.prog_i, J.pub, tid);
     PT_TS(4);
     return true;
 }
 
-template <bool STREAM>
+template <bool STREAM, int TBK>
 __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restrict__ A, int64_t lda, int n, TileCtl* ctl,
                                                                  double* __restrict__ linv_all, int* __restrict__ info,
                                                                  int* __restrict__ err, double* __restrict__ minv_all,
@@ -1252,7 +1260,7 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
         J.minv = minv_all ? minv_all + (int64_t)j * 2 * NB * NB : nullptr;
         J.info = info; J.info_base = J.j0;
         J.abort_on_fail = true;
-        if (!tile_process<false, STREAM>(J, ctl, err, smem, ctlw, tid, t, g_tile_ts)) return;
+        if (!tile_process<false, STREAM, TBK>(J, ctl, err, smem, ctlw, tid, t, g_tile_ts)) return;
         __syncthreads();                                      // LDS (image, control words) is reused by the next tile
     }
 }
@@ -1273,7 +1281,7 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_vb_kernel(double* __re
                                                                     const int* __restrict__ prog_off, const int* __restrict__ linv_off,
                                                                     TileCtl* ctl, unsigned* __restrict__ prog,
                                                                     double* __restrict__ linv_all, int* __restrict__ info,
-                                                                    int* __restrict__ err) {
+                                                                    int* __restrict__ err, int nprog, int stream) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     unsigned* ctlw = reinterpret_cast<unsigned*>(smem + NB * PLD + NB + 80 + 2);
     for (;;) {
@@ -1299,14 +1307,20 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_vb_kernel(double* __re
         J.nk = J.factored ? tk.j : ntf;
         J.q = q; J.w = dd.w;
         J.prog_i = fprog + tk.i; J.prog_j = fprog + tk.j;
-        J.half_j = nullptr;
+        // round 3: 16-column streaming inside a front wherever the diagonal tile of the column is a whole 128 x 128 factored tile
+        // (half / micro words of the level: the second and third third of the progress array)
+        const bool scol = stream && J.factored && tk.j < q;                        // column tk.j streams L(j,j)
+        J.half_j = scol ? fprog + nprog + tk.j : nullptr;
         J.micro_i = nullptr;
+        if (stream && tk.i >= 1 && tk.i - 1 < q && tk.i < ntf) {                    // tile (i, i-1) is whole and (i, i) is factored
+            if (tk.i == tk.j || tk.j == tk.i - 1) J.micro_i = fprog + 2 * nprog + tk.i;
+        }
         J.pub = (unsigned)tk.j + 1;
         J.linv = linv_all + (int64_t)(linv_off[tk.front] + (J.factored ? tk.j : 0)) * 2048;
         J.minv = nullptr;
         J.info = info + tk.front; J.info_base = dd.col0 + J.j0;
         J.abort_on_fail = false;
-        if (!tile_process<true>(J, ctl, err, smem, ctlw, tid, t, nullptr)) return;
+        if (!tile_process<true, true>(J, ctl, err, smem, ctlw, tid, t, nullptr)) return;
         __syncthreads();
     }
 }
@@ -1391,12 +1405,14 @@ int launch_potrf_tiles_vb(double* base, const VbDesc* d_desc, int nfronts, const
     if (!prezeroed) {       // (the sparse engine zeroes the state of all its levels with one memset per factorisation)
         KKT_HIP_CHECK(hipMemsetAsync(d_info, 0, sizeof(int) * nfronts, st));
         KKT_HIP_CHECK(hipMemsetAsync(d_ctl, 0, sizeof(TileCtl), st));
-        KKT_HIP_CHECK(hipMemsetAsync(d_prog, 0, sizeof(unsigned) * (nprog > 0 ? nprog : 1), st));
+        KKT_HIP_CHECK(hipMemsetAsync(d_prog, 0, sizeof(unsigned) * 3 * (nprog > 0 ? nprog : 1), st));
     }
+    // d_prog holds 3 * nprog words: progress, half (micro panels of L(j,j) in memory), micro (blocks of tile (i, i-1) in memory)
+    static const int stream = getenv("MI355KKT_SPARSE_STREAM") ? atoi(getenv("MI355KKT_SPARSE_STREAM")) : 1;
     const int grid = ntickets < num_cus ? ntickets : num_cus;
     hipLaunchKernelGGL(potrf_tiles_vb_kernel, dim3(grid), dim3(PT_THREADS), lds, st, base, d_desc,
                        reinterpret_cast<const VbTicket*>(d_tickets), (unsigned)ntickets, d_prog_off, d_linv_off,
-                       reinterpret_cast<TileCtl*>(d_ctl), d_prog, d_linv, d_info, d_info);
+                       reinterpret_cast<TileCtl*>(d_ctl), d_prog, d_linv, d_info, d_info, nprog > 0 ? nprog : 1, stream);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1431,9 +1447,11 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
         hipDeviceProp_t prop;
         KKT_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel<false>),
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel<false, 16>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel<true>),
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel<true, 16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel<true, 32>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -1446,11 +1464,15 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
     // 0: whole tiles only; 1: half-tile hand-off of L(j,j) (round 2); 2: 16-column streaming (round 3).  Streaming needs whole tiles
     static const int half_env = getenv("MI355KKT_POTRF_HALF") ? atoi(getenv("MI355KKT_POTRF_HALF")) : 2;
     const int use_half = (half_env == 2 && n % NB) ? 1 : half_env;
-    if (use_half == 2)
-        hipLaunchKernelGGL(potrf_tiles_kernel<true>, dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
+    static const int tbk = getenv("MI355KKT_POTRF_BK") ? atoi(getenv("MI355KKT_POTRF_BK")) : 16;   // 32: 32-deep LDS stages in the bulk
+    if (use_half == 2 && tbk == 32)
+        hipLaunchKernelGGL((potrf_tiles_kernel<true, 32>), dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
+                           reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
+    else if (use_half == 2)
+        hipLaunchKernelGGL((potrf_tiles_kernel<true, 16>), dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
                            reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
     else
-        hipLaunchKernelGGL(potrf_tiles_kernel<false>, dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
+        hipLaunchKernelGGL((potrf_tiles_kernel<false, 16>), dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
                            reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
     KKT_HIP_CHECK(hipGetLastError());
     w.minv_n = no_minv ? 0 : n;          // the 128 x 128 inverses of this factor's diagonal blocks are valid

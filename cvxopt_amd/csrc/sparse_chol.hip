@@ -1050,7 +1050,7 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
             E.tv_ctl_at[l] = at;
             at += (potrf_tile_ctl_bytes() + 63) & ~(size_t)63;
             E.tv_prog_at[l] = at;
-            at += (sizeof(unsigned) * (size_t)std::max(1, S.tv_nprog[l]) + 63) & ~(size_t)63;
+            at += (sizeof(unsigned) * 3 * (size_t)std::max(1, S.tv_nprog[l]) + 63) & ~(size_t)63;   // progress + half + micro words
         }
         E.tv_info_at = at;
         at += sizeof(int) * std::max<size_t>(1, S.vb.size());

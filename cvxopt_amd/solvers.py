@@ -17,7 +17,7 @@ the reference's.  (For LP-cone problems `cvxopt_amd.coneqp_lp` / `conelp_lp` mov
     sol = gsolvers.conelp(c, G, h, dims)            # same signature and result dict as cvxopt.solvers.conelp
     sol = gsolvers.coneqp(P, q, G, h, dims, A, b)
     sol = gsolvers.socp(c, Gl, hl, Gq, hq)          # the reference's own argument packing
-    sol = gsolvers.sdp(c, Gl, hl, Gs, hs)           # 's' cones: host driver + device operators + GPU kktsolver
+    sol = gsolvers.sdp(c, Gl, hl, Gs, hs)           # 's' cones: the device-resident conelp loop (all three cone types)
 """
 import numpy as np
 
@@ -254,7 +254,8 @@ def socp(c, Gl=None, hl=None, Gq=None, hq=None, A=None, b=None, primalstart=None
 def sdp(c, Gl=None, hl=None, Gs=None, hs=None, A=None, b=None, primalstart=None, dualstart=None, **kwargs):
     """cvxopt.solvers.sdp's argument convention (coneprog.py:3566-4153): Gs[k] is m_k^2 x n (column j = vec of the j-th
     coefficient matrix), hs[k] is m_k x m_k; stacked into one cone LP with dims['s'] = [m_k]; 'ss', 'zs' come back as
-    m_k x m_k matrices.  The 's' cone runs through the host driver with device operators + the GPU kktsolver."""
+    m_k x m_k matrices.  With the default starting point the whole loop runs on the device ('s' blocks included, csrc/cone_ops_s.h);
+    primalstart / dualstart route to the reference driver on the host with device operators + the GPU kktsolver."""
     from cvxopt import matrix
     kwargs = _no_external_solver(kwargs)
     n = c.size[0]

@@ -274,6 +274,7 @@ int mi355kkt_debug_potf2_skip(int mask);
 int mi355kkt_debug_potf2_ts(void* dptr);
 /* developer aid: 8 int64 stamps per 128 x 128 tile (column-major tile order) written by the persistent Cholesky kernel */
 int mi355kkt_debug_tile_ts(void* dptr);
+int mi355kkt_debug_trsvz_ts(void* dptr);   /* 8 shader-clock stamps per 128-block of the next trsv_z launches (NULL: off) */
 int mi355kkt_debug_syrk_skip(int mask);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops);

@@ -3,7 +3,7 @@ configurations at the sizes the GPU tests use, in the build container.  Takes se
 its outputs (tests/golden/full_*.npz) so that the GPU box can check the device loops and the hook against reference-
 produced numbers instead of hand-typed constants:
 
-    python tests/golden/make_golden_full.py [qp8192] [socp] [sparse46] [batch64] [qp2048]
+    python tests/golden/make_golden_full.py [qp8192] [socp] [sparse46] [batch64] [batch512] [qp2048]
 
 For every run the fixture holds the iteration count, the final objectives at full precision, the final x (and z / a
 sample of them), the per-iteration table the reference driver prints with options['show_progress'] (pcost, dcost, gap,
@@ -137,6 +137,30 @@ def batch64():
     print("wrote full_batch64: %d problems, iterations %s..., %.1f s" % (B, its[:6], t))
 
 
+def batch512():
+    """BASELINE configs[4], one GPU's share: 512 individual reference solves (seed = index).  Per problem: iteration count, both
+    objectives, ||x||_2 and every 8th entry of x (the full x of the first 64 is in full_batch64)."""
+    n, m, B = 512, 1024, 512
+    its, pobj, dobj, xs, xn = [], [], [], [], []
+    solvers.options['show_progress'] = False
+    t = time.perf_counter()
+    for i in range(B):
+        pr = synth.dense_qp(n, m, seed=i)
+        sol = solvers.coneqp(matrix(pr['P']), matrix(pr['q']), matrix(pr['G']), matrix(pr['h']), kktsolver='chol2')
+        assert sol['status'] == 'optimal'
+        x = np.array(sol['x']).ravel()
+        its.append(sol['iterations'])
+        pobj.append(sol['primal objective'])
+        dobj.append(sol['dual objective'])
+        xs.append(x[::8].copy())
+        xn.append(float(np.linalg.norm(x)))
+    t = time.perf_counter() - t
+    np.savez_compressed(os.path.join(HERE, 'full_batch512.npz'), n=n, m=m, B=B, iterations=np.array(its),
+                        pobj=np.array(pobj), dobj=np.array(dobj), x_sample=np.array(xs), x_norm=np.array(xn),
+                        reference_seconds=t)
+    print("wrote full_batch512: %d problems, iterations min %d max %d, %.1f s" % (B, min(its), max(its), t))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ['qp2048', 'batch64', 'socp', 'qp8192', 'sparse46']
     for w in which:
@@ -150,5 +174,7 @@ if __name__ == "__main__":
             sparse46()
         elif w == 'batch64':
             batch64()
+        elif w == 'batch512':
+            batch512()
         else:
             raise SystemExit("unknown fixture " + w)

@@ -2,11 +2,10 @@
 tests/golden/make_golden_full.py from the REAL reference in the build container): BASELINE configs[1..4] at the sizes the
 bench uses, device-resident loops and hook-level runs alike.  Nothing here compares HIP with HIP or with hand-typed numbers.
 
-Tolerances: same status and iteration count; objectives 1e-9 relative (1e-8 where the reference itself stops at 1e-7
-accuracy on ill-conditioned last iterations); x 1e-6 relative in the max norm; the per-iteration table the reference
-prints (pcost, dcost to 5 significant digits; gap, pres, dres to 1) to the printed precision; the Nesterov-Todd scaling of
-every factor() call of a hook-level run (||di||_2 at full precision) to 1e-9 relative over the first ten iterations, 1e-6
-afterwards."""
+Tolerances (the BOUND table below): same status and iteration count; objectives 1e-11 relative; x 1e-8 relative in the max norm
+(1e-9 / 1e-7); the per-iteration table the reference prints (pcost, dcost to 5 significant digits; gap, pres, dres
+to 1) to the printed precision; the Nesterov-Todd scaling of every factor() call of a hook-level run (||di||_2 at full
+precision) to 1e-11 relative over the first ten iterations, 2e-8 afterwards.  The errors actually achieved are recorded."""
 import contextlib
 import io
 import os
@@ -17,8 +16,21 @@ import pytest
 
 import cvxopt_amd
 from cvxopt_amd import kkt, synth
+from helpers import record
 
 pytestmark = pytest.mark.gpu
+# Bounds (relative errors against the reference fixtures).  SURVEY 8(d) states 1e-9 for the objectives and 1e-7 for x.  Every bound
+# below is AT LEAST that tight; the achieved errors of the GPU run of this file are in profiles/r03_parity_report.json (the
+# tests write them, `record`) and are quoted on the right -- the bounds leave one to two orders of magnitude for a different
+# summation order of a later kernel, not more.
+BOUND = {
+    'obj': 1e-11,                                  # objectives, configs 2 and 5: achieved 5e-15 .. 1e-14
+    'c2_x': 1e-8, 'c2_z': 2e-8, 'c2_s': 2e-8,      # config 2 (cond ~1e10 near convergence): achieved x 1.5e-10, z / s 7e-10
+    'w_early': 1e-11, 'w_late': 2e-8,              # ||di|| of every factor call: achieved <= 3.5e-13 (calls 0-9), <= 7.5e-10 after
+    'c3_obj': 1e-11, 'c3_x': 1e-10,                # config 3 (SOCP): achieved 2e-13, 5e-15
+    'c4_obj': 1e-11, 'c4_x': 1e-10, 'c4_z': 1e-10, # config 4 class (sparse): achieved 2e-16, 6e-16, 2e-15
+    'c5_x': 2e-9,                                  # config 5 (512 problems): achieved max 5e-11, median 4e-12
+}
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 LINE = re.compile(r"^\s*(\d+):\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)\s+(\S+)(?:\s+(\S+))?\s*$")
 
@@ -38,6 +50,18 @@ def table_of(text):
         if mm:
             rows.append([float(v) if v is not None else np.nan for v in mm.groups()[1:]])
     return np.array(rows)
+
+
+def objerr(sol, g):
+    return (abs(sol['primal objective'] - float(g['pobj'])) / max(1.0, abs(float(g['pobj']))),
+            abs(sol['dual objective'] - float(g['dobj'])) / max(1.0, abs(float(g['dobj']))))
+
+
+def table_err(got, ref):
+    """largest relative deviation of pcost / dcost from the reference's printed values (printed with 5 significant digits)"""
+    if got.shape[0] != ref.shape[0]:
+        return float('inf')
+    return float(np.max(np.abs(got[:, :2] - ref[:, :2]) / np.maximum(1e-300, np.abs(ref[:, :2]))))
 
 
 def check_table(got, ref):
@@ -66,10 +90,13 @@ def test_config2_device_loop_vs_reference_fixture():
                                                                   show_progress=True))
     assert sol['status'] == 'optimal' and int(g['status_optimal']) == 1
     assert sol['iterations'] == int(g['iterations'])
-    for k, key in (('primal objective', 'pobj'), ('dual objective', 'dobj')):
-        assert abs(sol[k] - float(g[key])) <= 1e-9 * max(1.0, abs(float(g[key]))), k
-    assert relerr(sol['x'], g['x']) < 1e-6
-    assert relerr(sol['z'], g['z']) < 1e-5 and relerr(sol['s'], g['s']) < 1e-5
+    ep, ed = objerr(sol, g)
+    ex, ez, es = relerr(sol['x'], g['x']), relerr(sol['z'], g['z']), relerr(sol['s'], g['s'])
+    record("config2_device_loop", iterations=sol['iterations'], pobj_relerr=ep, dobj_relerr=ed, x_relerr=ex, z_relerr=ez,
+           s_relerr=es, table_cost_relerr=table_err(tab, g['table']))
+    assert ep <= BOUND['obj'] and ed <= BOUND['obj']
+    assert ex < BOUND['c2_x']
+    assert ez < BOUND['c2_z'] and es < BOUND['c2_s']
     check_table(tab, g['table'])
 
 
@@ -79,9 +106,11 @@ def test_config2_lp_cone_fast_loop_vs_reference_fixture():
     pr = synth.dense_qp(int(g['n']), int(g['m']), seed=int(g['seed']))
     sol = cvxopt_amd.coneqp_lp(pr['P'], pr['q'], pr['G'], pr['h'])
     assert sol['status'] == 'optimal' and sol['iterations'] == int(g['iterations'])
-    assert abs(sol['primal objective'] - float(g['pobj'])) <= 1e-9 * abs(float(g['pobj']))
-    assert abs(sol['dual objective'] - float(g['dobj'])) <= 1e-9 * abs(float(g['dobj']))
-    assert relerr(sol['x'], g['x']) < 1e-6
+    ep, ed = objerr(sol, g)
+    ex = relerr(sol['x'], g['x'])
+    record("config2_lp_cone_loop", iterations=sol['iterations'], pobj_relerr=ep, dobj_relerr=ed, x_relerr=ex)
+    assert ep <= BOUND['obj'] and ed <= BOUND['obj']
+    assert ex < BOUND['c2_x']
 
 
 def test_config2_hook_level_vs_reference_fixture(ref_cvxopt):
@@ -113,16 +142,20 @@ def test_config2_hook_level_vs_reference_fixture(ref_cvxopt):
     finally:
         kkt.uninstall()
     assert sol['status'] == 'optimal' and sol['iterations'] == int(g['iterations'])
-    assert abs(sol['primal objective'] - float(g['pobj'])) <= 1e-9 * abs(float(g['pobj']))
-    assert abs(sol['dual objective'] - float(g['dobj'])) <= 1e-9 * abs(float(g['dobj']))
-    assert relerr(np.array(sol['x']).ravel(), g['x']) < 1e-6
-    check_table(tab, g['table'])
+    ep, ed = objerr(sol, g)
+    ex = relerr(np.array(sol['x']).ravel(), g['x'])
     ref_d = g['w_digest'][:, 0]
     assert len(digests) == len(ref_d)
+    derr = [abs(a - b) / b for a, b in zip(digests, ref_d)]
+    record("config2_hook_level", iterations=sol['iterations'], pobj_relerr=ep, dobj_relerr=ed, x_relerr=ex,
+           w_digest_relerr_per_factor_call=derr, table_cost_relerr=table_err(tab, g['table']))
+    assert ep <= BOUND['obj'] and ed <= BOUND['obj']
+    assert ex < BOUND['c2_x']
+    check_table(tab, g['table'])
     # (rounding-level differences of the KKT solves are amplified along the central path: ||di|| grows to 1e4 .. 1e5 and the
-    #  last iterations' systems have condition numbers around 1e10; the first ten iterations agree to 1e-9)
-    for k, (a, b) in enumerate(zip(digests, ref_d)):
-        assert abs(a - b) <= (1e-9 if k < 10 else 1e-6) * b, (k, a, b)
+    #  last iterations' systems have condition numbers around 1e10)
+    for k, e in enumerate(derr):
+        assert e <= (BOUND['w_early'] if k < 10 else BOUND['w_late']), (k, e)
 
 
 def test_config3_device_loop_vs_reference_fixture():
@@ -131,9 +164,12 @@ def test_config3_device_loop_vs_reference_fixture():
     pr = synth.socp(n=int(g['n']), ncones=int(g['N']), r=int(g['r']), seed=int(g['seed']))
     sol, tab = run_with_progress(lambda: cvxopt_amd.conelp_device(pr['c'], pr['G'], pr['h'], pr['dims'], show_progress=True))
     assert sol['status'] == 'optimal' and sol['iterations'] == int(g['iterations'])
-    assert abs(sol['primal objective'] - float(g['pobj'])) <= 1e-8 * max(1.0, abs(float(g['pobj'])))
-    assert abs(sol['dual objective'] - float(g['dobj'])) <= 1e-8 * max(1.0, abs(float(g['dobj'])))
-    assert relerr(sol['x'], g['x']) < 1e-6
+    ep, ed = objerr(sol, g)
+    ex = relerr(sol['x'], g['x'])
+    record("config3_socp_device_loop", iterations=sol['iterations'], pobj_relerr=ep, dobj_relerr=ed, x_relerr=ex,
+           table_cost_relerr=table_err(tab[:, :5], g['table'][:, :5]))
+    assert ep <= BOUND['c3_obj'] and ed <= BOUND['c3_obj']
+    assert ex < BOUND['c3_x']
     check_table(tab[:, :5], g['table'][:, :5])
 
 
@@ -159,10 +195,12 @@ def test_config4_sparse_device_loop_vs_reference_fixture():
             self.CCS = (A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64))
     sol = cvxopt_amd.coneqp_lp(Sp(sp.tril(P)), q, Sp(G), np.ones(2 * n))
     assert sol['status'] == 'optimal' and sol['iterations'] == int(g['iterations'])
-    assert abs(sol['primal objective'] - float(g['pobj'])) <= 1e-8 * max(1.0, abs(float(g['pobj'])))
-    assert abs(sol['dual objective'] - float(g['dobj'])) <= 1e-8 * max(1.0, abs(float(g['dobj'])))
-    assert relerr(sol['x'], g['x']) < 1e-6
-    assert relerr(sol['z'][::97], g['z_sample']) < 1e-5
+    ep, ed = objerr(sol, g)
+    ex, ez = relerr(sol['x'], g['x']), relerr(sol['z'][::97], g['z_sample'])
+    record("config4_sparse_device_loop", iterations=sol['iterations'], pobj_relerr=ep, dobj_relerr=ed, x_relerr=ex, z_sample_relerr=ez)
+    assert ep <= BOUND['c4_obj'] and ed <= BOUND['c4_obj']
+    assert ex < BOUND['c4_x']
+    assert ez < BOUND['c4_z']
 
 
 def test_config5_batch_sample_vs_reference_fixture():
@@ -179,7 +217,37 @@ def test_config5_batch_sample_vs_reference_fixture():
         kk.close()
     assert np.all(res['status'] == 'optimal')
     assert np.array_equal(res['iterations'], g['iterations'])
-    assert np.max(np.abs(res['primal objective'] - g['pobj']) / np.maximum(1.0, np.abs(g['pobj']))) < 1e-9
-    assert np.max(np.abs(res['dual objective'] - g['dobj']) / np.maximum(1.0, np.abs(g['dobj']))) < 1e-9
-    for b in range(B):
-        assert relerr(res['x'][b], g['x'][b]) < 1e-6, b
+    ep = float(np.max(np.abs(res['primal objective'] - g['pobj']) / np.maximum(1.0, np.abs(g['pobj']))))
+    ed = float(np.max(np.abs(res['dual objective'] - g['dobj']) / np.maximum(1.0, np.abs(g['dobj']))))
+    ex = [relerr(res['x'][b], g['x'][b]) for b in range(B)]
+    record("config5_batch64", problems=B, pobj_relerr_max=ep, dobj_relerr_max=ed, x_relerr_max=max(ex), x_relerr_median=float(np.median(ex)))
+    assert ep < BOUND['obj'] and ed < BOUND['obj']
+    assert max(ex) < BOUND['c5_x']
+
+
+def test_config5_batch512_vs_reference_fixture():
+    """BASELINE configs[4], one GPU's share of the 4096 problems: 512 problems (n=512, m=1024, seed = index) in ONE batched device
+    loop against 512 individual CPU reference solves: iteration counts, both objectives, ||x|| and every 8th entry of x"""
+    from cvxopt_amd.batch import BatchKkt, pack_problems
+    path = os.path.join(GOLD, "full_batch512.npz")
+    if not os.path.exists(path):
+        pytest.skip("full_batch512 fixture not generated")
+    g = np.load(path, allow_pickle=False)
+    B, n, m = int(g['B']), int(g['n']), int(g['m'])
+    P, q, Gt, h = pack_problems([synth.dense_qp(n, m, seed=i) for i in range(B)])
+    kk = BatchKkt(Gt, P)
+    try:
+        res = kk.coneqp(q, h)
+    finally:
+        kk.close()
+    assert np.all(res['status'] == 'optimal')
+    assert np.array_equal(res['iterations'], g['iterations'])
+    ep = float(np.max(np.abs(res['primal objective'] - g['pobj']) / np.maximum(1.0, np.abs(g['pobj']))))
+    ed = float(np.max(np.abs(res['dual objective'] - g['dobj']) / np.maximum(1.0, np.abs(g['dobj']))))
+    ex = [relerr(res['x'][b][::8], g['x_sample'][b]) for b in range(B)]
+    en = float(np.max(np.abs(np.linalg.norm(res['x'], axis=1) - g['x_norm']) / g['x_norm']))
+    record("config5_batch512", problems=B, iterations_min=int(res['iterations'].min()), iterations_max=int(res['iterations'].max()),
+           pobj_relerr_max=ep, dobj_relerr_max=ed, x_sample_relerr_max=max(ex), x_sample_relerr_median=float(np.median(ex)),
+           x_norm_relerr_max=en)
+    assert ep < BOUND['obj'] and ed < BOUND['obj']
+    assert max(ex) < BOUND['c5_x'] and en < BOUND['c5_x']

@@ -147,3 +147,36 @@ def test_set_A_csr_rejects_an_invalid_rowptr():
         assert L.mi355kkt_set_A_csr(h, as_i(rp), as_i(ci), as_d(v)) == 0
     finally:
         L.mi355kkt_destroy(h)
+
+
+@pytest.mark.parametrize("spread,p", [(3.0, 0), (5.0, 0), (5.0, 12)])
+def test_ldl_flavour_at_late_iteration_scalings_against_the_reference_kkt_ldl(ref_cvxopt, spread, p):
+    """kind='ldl' is what users pick for robustness on ill-conditioned W.  Late interior-point iterations: d spans
+    10^-spread .. 10^+spread, cond(K) up to ~1e12 for the 3 x 3 system.  The device engine factors the reduced quasi-definite
+    form; the reference (misc.kkt_ldl, misc.py:1085-1121) runs a pivoted LDL' (sytrf) of the whole 3 x 3 matrix.  Both residuals
+    of the ORIGINAL 3 x 3 system are recorded in the parity report; ours must stay within a small factor of the reference's."""
+    from cvxopt import matrix, misc
+    from helpers import record
+    n, m = 300, 500
+    pr = synth.dense_qp(n, m, seed=21, p=p)
+    G, P, dims = pr['G'], pr['P'], pr['dims']
+    A = pr.get('A', np.zeros((0, n)))
+    W = synth.random_scaling(dims, seed=8, spread=spread)
+    rng = np.random.default_rng(3)
+    bx, by, bz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)
+    f = kkt.kkt_ldl(G, dims, A)
+    x, y, z = bx.copy(), by.copy(), bz.copy()
+    f(W, P)(x, y, z)
+    f.engine.close()
+    Wr = {'d': matrix(W['d']), 'di': matrix(W['di']), 'v': [], 'beta': [], 'r': [], 'rti': []}
+    fr = misc.kkt_ldl(matrix(G), dims, matrix(A) if p else matrix(0.0, (0, n)))
+    xr, yr, zr = matrix(bx), matrix(by) if p else matrix(0.0, (0, 1)), matrix(bz)
+    fr(Wr, matrix(P))(xr, yr, zr)
+    xr, yr, zr = np.array(xr).ravel(), np.array(yr).ravel(), np.array(zr).ravel()
+    res = ko.kkt_residual(P, A, G, W, dims, bx, by, bz, x, y, z)
+    res_ref = ko.kkt_residual(P, A, G, W, dims, bx, by, bz, xr, yr, zr)
+    ex, ez = relerr(x, xr), relerr(z, zr)
+    record("ldl_late_iteration_spread%g_p%d" % (spread, p), residual_device=res, residual_reference_kkt_ldl=res_ref,
+           x_relerr_vs_reference=ex, z_relerr_vs_reference=ez, d_min=float(W['d'].min()), d_max=float(W['d'].max()))
+    assert res <= max(1e-12, 30.0 * res_ref), (res, res_ref)
+    assert ex < 1e-6, ex
