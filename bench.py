@@ -866,16 +866,30 @@ def main():
         kernel_ms = sum(syrk_ms) / max(1, len(syrk_ms))
         flops = float(m) * n * n                      # algorithmic flops of the lower-triangular SYRK
         achieved = flops / (kernel_ms * 1e-3) / 1e12
+        # HBM-side traffic of the SYRK per launch: PMC counters cannot be sampled inside this run, they come from the committed
+        # summary of separate `rocprofv3 --pmc` passes -- accepted only if it was taken on THIS version of the kernel's sources
         traffic, traffic_src = None, None
-        for name in ("r02_pmc_syrk.json", "pmc_syrk_latest.json"):
+        try:
+            import hashlib
+            hsh = hashlib.sha256()
+            for f in ("cvxopt_amd/csrc/gemm_f64.hip", "cvxopt_amd/csrc/kkt_common.h"):
+                hsh.update(open(os.path.join(ROOT, f), "rb").read())
+            src_id = hsh.hexdigest()[:16]
+        except Exception:
+            src_id = None
+        for name in ("r03_pmc_syrk.json",):
             pj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pj):
                 try:
                     d = json.load(open(pj))
                     if d.get("n") == n and d.get("m") == m:
-                        traffic = d.get("hbm_bytes_per_launch")
-                        traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction " \
-                                      "of the guide; PMC cannot be sampled inside this run)" % name
+                        if src_id is not None and d.get("kernel_source_id") == src_id:
+                            traffic = d.get("hbm_bytes_per_launch")
+                            traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction " \
+                                          "of the guide; kernel sources %s = this build)" % (name, src_id)
+                        else:
+                            traffic_src = "profiles/%s is from another version of the kernel (source id %s, this build %s): not used" \
+                                          % (name, d.get("kernel_source_id"), src_id)
                         break
                 except Exception:
                     pass

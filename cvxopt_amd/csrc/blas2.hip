@@ -725,27 +725,32 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
                                                      const double* __restrict__ zmat) {
     __shared__ __attribute__((aligned(16))) double vb[4][ZV + 2];
     __shared__ int bad;
-    // LDS-only barrier: `s_waitcnt lgkmcnt(0); s_barrier`.  __syncthreads() also waits for every outstanding GLOBAL load
-    // (vmcnt(0)): the strips of the pre-multiplied blocks are fetched while phase B runs, and with __syncthreads() each of its
-    // barriers stalled for those 64 loads per thread (measured: phase B 10 us instead of ~1.5).
+    // LDS-only barrier: `s_waitcnt lgkmcnt(0); s_barrier` (__syncthreads() also waits for every outstanding GLOBAL load)
     auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     const int tid = threadIdx.x;
     const int r = tid >> 1, half = tid & 1, ch = 64 * half;
     const int nblk = n / TB;
-    const int k = TRANS ? (nblk - 1 - (int)blockIdx.x) : (int)blockIdx.x;   // dispatch order ~ dependency order
+    // TWO workgroups per block row (2 nblk <= #CUs): role 0 accumulates the far blocks and solves the diagonal block (phases A, B)
+    // and hands c'_k on; role 1, the finisher, holds the strips of the two pre-multiplied blocks from the start of the launch
+    // and does phases C, D.  A single workgroup would have to fetch 4 x 128 KB of strips per block row on the chain (a compute
+    // unit pulls ~45 GB/s: 3 us per strip, measured), the split leaves each with two.
+    const int role = (int)blockIdx.x >= nblk ? 1 : 0;
+    const int kb = (int)blockIdx.x - role * nblk;
+    const int k = TRANS ? (nblk - 1 - kb) : kb;             // dispatch order ~ dependency order
     const int k0 = k * TB, idx = k0 + r;
     const int vpos = r + ((r >> 6) << 1);                  // my row's slot in an LDS vector
     const int vh = ch + 2 * half;                          // first slot of my half of a vector
     if (tid == 0) bad = 0;
     lds_barrier();
     int vi = 0;                                            // running stage counter: stage t uses vb[t & 3]
-    double acc = half == 0 ? x[idx] : 0.0;
     long long* tts = g_trsvz_ts;
-    TZ_TS(0);
+    u64* granx = gran;                                     // x blocks: granule block j
+    u64* granc = gran + (int64_t)(nblk + 1) * 256;         // c' blocks (role 0 -> role 1 of the same block row)
+    const int nsteps = TRANS ? (nblk - 1 - k) : k;
 
-    // receive block j of the solution into an LDS vector: thread tid polls granule tid (word `half` of row r)
-    auto recv = [&](int j, double* buf) -> bool {
-        const u64* g = gran + (int64_t)j * 256 + tid;
+    // receive a 128-vector published as 256 data-tagged granules into an LDS vector: thread tid polls granule tid
+    auto recv = [&](const u64* g0, double* buf) -> bool {
+        const u64* g = g0 + tid;
         u64 v = 0;
         bool got = false;
         for (unsigned spins = 0; spins < (1u << 22); ++spins) {
@@ -762,6 +767,11 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
         }
         return true;
     };
+    auto publish = [&](u64* g0, double v) {                // every thread one granule: its word of the row's value
+        const u64 tag = (u64)epoch << 32;
+        const u32 word = half ? (u32)__double2hiint(v) : (u32)__double2loint(v);
+        __hip_atomic_store(g0 + tid, tag | word, RLX_AGENT);
+    };
     // 64-term dot product of a register strip with my half of an LDS vector, four independent chains
     auto dot64 = [&](const double (&a)[64], const double* v) {
         const double* w = v + vh;
@@ -775,7 +785,6 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
         }
         return (d0 + d1) + (d2 + d3);
     };
-
     // Strip loads: element c of a thread's strip = column (first + c) of a column-major block, row r.  Addressed as a WAVE-UNIFORM
     // column base (scalar registers, bumped by scalar adds) + one 32-bit lane offset: no per-load address registers (with 64-bit
     // lane addresses hipcc formed the 64 addresses of a strip up front and spilled ~90 registers around every strip).
@@ -784,8 +793,47 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
     };
     const uint32_t voffM = (uint32_t)((r + ch * TB) * 8);                       // inside a 128 x 128 block with ld 128
     const uint32_t voffL = (uint32_t)(((int64_t)r + (int64_t)ch * ldl) * 8);    // inside a block of L (ld = ldl)
-    // ---- diagonal block operands (M strip, L_kk strip): loaded now, used in phase B
     double ra[64], rb[64];
+
+    if (role == 1) {
+        // ---- the finisher: x_k = c'_k - Z2_k x_{k-2} - Z1_k x_{k-1}; both strips are in registers long before they are needed
+        const double* Zk = zmat + (int64_t)k * (2 * TB * TB);
+        if (nsteps >= 1) {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) ra[c] = ldu(Zk + c * TB, voffM);
+        }
+        if (nsteps >= 2) {
+#pragma unroll
+            for (int c = 0; c < 64; ++c) rb[c] = ldu(Zk + TB * TB + c * TB, voffM);
+        }
+        if (tid == 0 && tts) tts[(int64_t)k * 8 + 0] = (long long)__builtin_readcyclecounter();
+        double t2 = 0.0;
+        double* buf;
+        if (nsteps >= 2) {                                 // phase C (needs x_{k-2} only: usually before c' arrives)
+            buf = vb[vi++ & 3];
+            if (!recv(granx + (int64_t)(TRANS ? k + 2 : k - 2) * 256, buf)) return;
+            t2 = pair_sum(dot64(rb, buf));
+        }
+        TZ_TS(3);
+        buf = vb[vi++ & 3];
+        if (!recv(granc + (int64_t)k * 256, buf)) return;   // c'_k from the other workgroup of this block row
+        TZ_TS(4);
+        double xk = buf[vpos] - t2;
+        if (nsteps >= 1) {                                 // phase D: the only stage between the arrival of x_{k-1} and my publication
+            buf = vb[vi++ & 3];
+            if (!recv(granx + (int64_t)(TRANS ? k + 1 : k - 1) * 256, buf)) return;
+            TZ_TS(5);
+            xk -= pair_sum(dot64(ra, buf));
+        }
+        TZ_TS(6);
+        publish(granx + (int64_t)k * 256, xk);
+        if (half == 0) x[idx] = xk;
+        TZ_TS(7);
+        return;
+    }
+
+    // ---- role 0: phase A (blocks three and more hops up the chain), phase B (diagonal block), hand c'_k to the finisher
+    double acc = half == 0 ? x[idx] : 0.0;
     {
         const double* Mk = minv + (int64_t)k * (2 * TB * TB) + (TRANS ? TB * TB : 0);
         const double* Lkk = L + k0 + (int64_t)k0 * ldl;
@@ -798,8 +846,6 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
             rb[j] = (TRANS ? c >= r : c <= r) ? v : 0.0;
         }
     }
-    // ---- phase A: the blocks three and more hops up the chain
-    const int nsteps = TRANS ? (nblk - 1 - k) : k;
     const int nfar = nsteps > 2 ? nsteps - 2 : 0;
     for (int s = 0; s < nfar; ++s) {
         const int j = TRANS ? (nblk - 1 - s) : s;
@@ -808,18 +854,11 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 64; ++c) l0[c] = ldu(Lkj + (int64_t)c * ldl, voffL);
         double* buf = vb[vi++ & 3];
-        if (!recv(j, buf)) return;
+        if (!recv(granx + (int64_t)j * 256, buf)) return;
         acc -= dot64(l0, buf);
     }
     TZ_TS(1);
-    // the strip of the block two hops up: fetched now (the registers of phase A's strips are free), it lands while phase B runs
-    const double* Zk = zmat + (int64_t)k * (2 * TB * TB);
-    double z2[64];
-    if (nsteps >= 2) {
-#pragma unroll
-        for (int c = 0; c < 64; ++c) z2[c] = ldu(Zk + TB * TB + c * TB, voffM);
-    }
-    // ---- phase B: c' = L_kk^-1 (b_k - sum of phase A), x0 = M b, e = b - L_kk x0, c' = x0 + M e
+    // phase B: c' = L_kk^-1 (b_k - sum of phase A): x0 = M b, e = b - L_kk x0, c' = x0 + M e
     const double b = pair_sum(acc);
     double* buf = vb[vi++ & 3];
     if (half == 0) buf[vpos] = b;
@@ -829,40 +868,12 @@ __global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ 
     if (half == 0) buf[vpos] = x0;
     lds_barrier();
     const double e = b - pair_sum(dot64(rb, buf));
-    // the strip of the block one hop up takes over the registers of the L_kk strip (dead now); it lands behind phase C
-    if (nsteps >= 1) {                                     // Z1 strip -> rb
-#pragma unroll
-        for (int c = 0; c < 64; ++c) rb[c] = ldu(Zk + c * TB, voffM);
-    }
     buf = vb[vi++ & 3];
     if (half == 0) buf[vpos] = e;
     lds_barrier();
-    double xk = x0 + pair_sum(dot64(ra, buf));
+    const double cp = x0 + pair_sum(dot64(ra, buf));
+    publish(granc + (int64_t)k * 256, cp);
     TZ_TS(2);
-    // ---- phase C: the block two hops up
-    if (nsteps >= 2) {
-        buf = vb[vi++ & 3];
-        if (!recv(TRANS ? k + 2 : k - 2, buf)) return;
-        TZ_TS(3);
-        xk -= pair_sum(dot64(z2, buf));
-    }
-    TZ_TS(4);
-    // ---- phase D: the block one hop up -- the only stage between its arrival and my publication
-    if (nsteps >= 1) {
-        buf = vb[vi++ & 3];
-        if (!recv(TRANS ? k + 1 : k - 1, buf)) return;
-        TZ_TS(5);
-        xk -= pair_sum(dot64(rb, buf));
-    }
-    TZ_TS(6);
-    // publish: every thread one granule (its word of x_r), then the plain copy for the caller
-    {
-        const u64 tag = (u64)epoch << 32;
-        const u32 word = half ? (u32)__double2hiint(xk) : (u32)__double2loint(xk);
-        __hip_atomic_store(gran + (int64_t)k * 256 + tid, tag | word, RLX_AGENT);
-        if (half == 0) x[idx] = xk;
-    }
-    TZ_TS(7);
 }
 
 // block (k, k -+ q) of the factor (forward: the lower block; backward: the mirrored upper block = L_{k+q,k}') -> Z storage
@@ -879,12 +890,125 @@ __global__ __launch_bounds__(256) void trsv_z_gather_kernel(const double* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// trsv_z_prep_kernel: Z = L_kk^-1 B (forward) / L_kk^-T B (backward) for one 128 x 128 block B on the matrix cores:
+//     Y0 = M B,   R = B - L_kk Y0,   Z = Y0 + M R          (M = inv(L_kk) from the tile Cholesky; one step of fixed-precision
+// refinement against L_kk, the scheme of the triangular solves themselves).  One 256-thread workgroup per block; the right
+// operand of each product sits in LDS ([column][k], stride 130: conflict-free fragment reads), the triangular left operand
+// is read from global memory in MFMA fragment form (16 consecutive rows per k), k-steps beyond the diagonal are skipped.
+// Output tile of wave w: rows 32 w .. 32 w + 31, all 128 columns; MFMA roles chosen so that a lane's accumulator registers are
+// consecutive ROWS of the output (lane (li, lq), register r  <->  row r0 + li, column c0 + lq + 4 r).
+// ---------------------------------------------------------------------------------------------------
+typedef double zd4 __attribute__((ext_vector_type(4)));
+constexpr int ZXS = TB + 2;      // LDS stride of one column of the right operand
+
+template <bool TRANS, bool NEG>
+__device__ __forceinline__ void zprep_mm(zd4 (&acc)[2][8], const double* __restrict__ A, int64_t lda,
+                                         const double* __restrict__ Xs, int wave, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int r0 = 32 * wave + 16 * rt;
+        // lower triangular left operand: k <= row, i.e. k-steps 0 .. (r0 + 15) / 4; upper (TRANS): k >= row, from r0 / 4 on
+        const int ks0 = TRANS ? r0 / 4 : 0, ks1 = TRANS ? TB / 4 : (r0 + 16) / 4;
+        const int row = r0 + li;
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const int kcol = 4 * ks + lk;
+            double bv = A[row + (int64_t)kcol * lda];
+            bv = (TRANS ? kcol >= row : kcol <= row) ? (NEG ? -bv : bv) : 0.0;
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                const double av = Xs[(16 * ct + li) * ZXS + kcol];
+                acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[rt][ct], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void trsv_z_prep_kernel(const double* __restrict__ L, int64_t ldl, int nblk,
+                                                          const double* __restrict__ minv, double* __restrict__ zmat) {
+    extern __shared__ __attribute__((aligned(16))) double Xs[];          // 128 columns x ZXS
+    const int k = blockIdx.x, q = 1 + (int)blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    double* Z = zmat + ((int64_t)(TRANS ? nblk : 0) + k) * (2 * TB * TB) + (int64_t)(q - 1) * TB * TB;
+    const int j = TRANS ? k + q : k - q;
+    if (j < 0 || j >= nblk) {                                             // no such block: zeros (never read by the solve)
+        for (int e = tid; e < TB * TB; e += 256) Z[e] = 0.0;
+        return;
+    }
+    // forward: the lower block (k, k - q); backward: the mirrored upper block (k, k + q) = L_{k+q,k}'
+    const double* B = L + (int64_t)k * TB + (int64_t)j * TB * ldl;
+    const double* Lkk = L + (int64_t)k * TB + (int64_t)k * TB * ldl;       // (the triangle the direction needs; the other is masked)
+    const double* M = minv + (int64_t)k * (2 * TB * TB) + (TRANS ? TB * TB : 0);
+    for (int e = tid; e < TB * TB; e += 256) Xs[(e >> 7) * ZXS + (e & (TB - 1))] = B[(e & (TB - 1)) + (int64_t)(e >> 7) * ldl];
+    __syncthreads();
+    zd4 y0[2][8], rr[2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) y0[rt][ct] = zd4{0.0, 0.0, 0.0, 0.0};
+    zprep_mm<TRANS, false>(y0, M, TB, Xs, wave, lane);                     // Y0 = M B
+    // R = B - L_kk Y0: B in accumulator layout straight from memory, Y0 through LDS
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                rr[rt][ct][r] = B[(32 * wave + 16 * rt + li) + (int64_t)(16 * ct + lq + 4 * r) * ldl];
+    __syncthreads();                                                       // every wave has read B from Xs
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[(16 * ct + lq + 4 * r) * ZXS + 32 * wave + 16 * rt + li] = y0[rt][ct][r];
+    __syncthreads();
+    zprep_mm<TRANS, true>(rr, Lkk, ldl, Xs, wave, lane);
+    __syncthreads();
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Xs[(16 * ct + lq + 4 * r) * ZXS + 32 * wave + 16 * rt + li] = rr[rt][ct][r];
+    __syncthreads();
+    zprep_mm<TRANS, false>(y0, M, TB, Xs, wave, lane);                     // Z = Y0 + M R
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Z[(32 * wave + 16 * rt + li) + (16 * ct + lq + 4 * r) * TB] = y0[rt][ct][r];
+}
+
 size_t trsv_z_doubles(int n) { return (size_t)2 * (n / TB) * 2 * TB * TB; }
 
 // Z1, Z2 of every block row for both directions; L must hold the factor AND its mirrored upper triangle (launch_mirror_lower)
-int trsv_z_prepare(const double* L, int64_t ldl, int n, double* zmat, hipStream_t st) {
+int trsv_z_prepare(const double* L, int64_t ldl, int n, double* zmat, hipStream_t st, const double* minv) {
     if (n <= 0 || n % TB) return -1;
     const int nblk = n / TB;
+    static const bool use_trsm = getenv("MI355KKT_TRSVZ_PREP") && !strcmp(getenv("MI355KKT_TRSVZ_PREP"), "trsm");
+    if (minv && !use_trsm) {
+        // matrix-core path: one workgroup per block, M = inv(L_kk) + one refinement step (trsv_z_prep_kernel)
+        constexpr size_t lds = sizeof(double) * TB * ZXS;
+        static bool attr_set = false;
+        if (!attr_set) {
+            KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_z_prep_kernel<false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_z_prep_kernel<true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((trsv_z_prep_kernel<false>), dim3(nblk, 2), dim3(256), lds, st, L, ldl, nblk, minv, zmat);
+        hipLaunchKernelGGL((trsv_z_prep_kernel<true>), dim3(nblk, 2), dim3(256), lds, st, L, ldl, nblk, minv, zmat);
+        KKT_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    // substitution path (the reference for the kernel above, $MI355KKT_TRSVZ_PREP=trsm): gather the blocks, two batched
+    // multi-right-hand-side triangular solves
     hipLaunchKernelGGL(trsv_z_gather_kernel, dim3(nblk, 2, 2), dim3(256), 0, st, L, ldl, nblk, zmat);
     KKT_HIP_CHECK(hipGetLastError());
     const int64_t sL = (int64_t)TB * (ldl + 1), sX = 2 * TB * TB;
@@ -897,11 +1021,12 @@ int launch_trsv_z(const double* L, int64_t ldl, int n, double* x, int trans, uns
                   unsigned long long* gran, const double* minv, const double* zmat) {
     if (n <= 0 || n % TB || !gran || !minv || !zmat) return -1;
     const int nblk = n / TB;
+    // two workgroups per block row (accumulate + diagonal solve | finisher); granule blocks [0, nblk) carry x, [nblk + 1, 2 nblk + 1) c'
     if (trans)
-        hipLaunchKernelGGL((trsv_z_kernel<true>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, epoch, err, gran, minv,
+        hipLaunchKernelGGL((trsv_z_kernel<true>), dim3(2 * nblk), dim3(256), 0, st, L, ldl, n, x, epoch, err, gran, minv,
                            zmat + (int64_t)nblk * 2 * TB * TB);
     else
-        hipLaunchKernelGGL((trsv_z_kernel<false>), dim3(nblk), dim3(256), 0, st, L, ldl, n, x, epoch, err, gran, minv, zmat);
+        hipLaunchKernelGGL((trsv_z_kernel<false>), dim3(2 * nblk), dim3(256), 0, st, L, ldl, n, x, epoch, err, gran, minv, zmat);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

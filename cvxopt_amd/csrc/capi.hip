@@ -1093,9 +1093,10 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
         // round 3: the two blocks next to the diagonal pre-multiplied by L_kk^-1 (blas2.hip: trsv_z_kernel) -- needs the 128 x 128
         // inverses of the tile Cholesky of THIS matrix and whole 128-blocks; experimental, $MI355KKT_TRSV=z switches it on
         static const bool use_z = getenv("MI355KKT_TRSV") && !strcmp(getenv("MI355KKT_TRSV"), "z");   // opt-in (see DESIGN: not faster yet)
-        if (use_z && h->n % 128 == 0 && h->n >= 256 && h->pw.minv_n == h->n && h->pw.minv_of == h->dS && h->dgran) {
+        if (use_z && h->n % 128 == 0 && h->n >= 256 && 2 * (h->n / 128) <= h->num_cus && h->pw.minv_n == h->n &&
+            h->pw.minv_of == h->dS && h->dgran) {
             if (!h->dZ) KKT_HIP_CHECK(hipMalloc(&h->dZ, sizeof(double) * trsv_z_doubles(h->n)));
-            if (int e = trsv_z_prepare(h->dS, h->n, h->n, h->dZ, h->st)) return e;
+            if (int e = trsv_z_prepare(h->dS, h->n, h->n, h->dZ, h->st, h->pw.d_minv)) return e;
             h->z_valid = true;
         }
     }
@@ -1185,9 +1186,10 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     // test measured a 3 x 3 residual of 3e-9 against the reference's 2e-13 with d spanning 1e-3 .. 1e3.  They therefore get one
     // step of iterative refinement against the 3 x 3 system, written in the scaled space the engine works in:
     //     [H A' Gs'; A 0 0; Gs 0 -I] [ux; uy; w] = [bx; by; zs],   Gs = W^-T G,  zs = W^-T bz,  w = W uz.
-    // ($MI355KKT_LDL_REFINE=0 switches it off; not applied with kktreg, whose regularised system is the one to be solved.)
-    static const bool ref_env = !(getenv("MI355KKT_LDL_REFINE") && atoi(getenv("MI355KKT_LDL_REFINE")) == 0);
-    const bool refine = ref_env && (h->kind == MI355KKT_LDL || h->kind == MI355KKT_LDL2) && h->kktreg == 0.0 && mk > 0 && n > 0;
+    // ($MI355KKT_LDL_REFINE=<steps>, 0 switches it off; not applied with kktreg, whose regularised system is the one to be solved.)
+    // Two steps by default: one brings d in 1e-3 .. 1e3 from 3e-9 to 2e-15 (the reference: 2e-13), d in 1e-5 .. 1e5 needs the second.
+    static const int ref_steps = getenv("MI355KKT_LDL_REFINE") ? atoi(getenv("MI355KKT_LDL_REFINE")) : 2;
+    const bool refine = ref_steps > 0 && (h->kind == MI355KKT_LDL || h->kind == MI355KKT_LDL2) && h->kktreg == 0.0 && mk > 0 && n > 0;
     double *bx0 = nullptr, *by0 = nullptr, *zs0 = nullptr, *rx = nullptr, *ry = nullptr, *rz = nullptr, *tt = nullptr;
     if (refine) {
         if (!h->dRef) KKT_HIP_CHECK(hipMalloc(&h->dRef, sizeof(double) * (2 * (size_t)n + 2 * (size_t)dmax(p, 1) + 3 * (size_t)mk)));
@@ -1231,7 +1233,7 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     // w := Gs x - zs   (/ sqrt(1+reg) when the z-block pivot is -(1+reg))       (:1563); packed space: in place for 's' cones
     double* wv = sdp ? h->dzs : dz;
     if (int e = launch_gemv_n_scaled(Gmat, ldGm, mk, n, wvec, dx, h->dzs, wv, zscale, -zscale, h->dwork, st)) return e;
-    if (refine) {
+    for (int rstep = 0; refine && rstep < ref_steps; ++rstep) {
         // residual of the 3 x 3 system in the scaled space
         //   rz = zs0 - Gs ux + w
         if (int e = launch_gemv_n_scaled(Gmat, ldGm, mk, n, wvec, dx, zs0, tt, 1.0, -1.0, h->dwork, st)) return e;     // tt = Gs ux - zs0
@@ -2241,6 +2243,15 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
 int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, const double* bv, int maxiters, double abstol,
                     double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
                     int* iters, double* stats) {
+    return mi355kkt_coneqp_init(hs, q, hv, bv, maxiters, abstol, reltol, feastol, refinement, 0, x, y, s, z, status, iters, stats);
+}
+
+/* have_init != 0: x, y, s, z hold the caller's starting point on entry (initvals of solvers.coneqp, coneprog.py:2109-2149: the
+ * caller has filled in the reference's defaults -- x = 0, y = 0, s = z = e -- for missing entries and checked s, z > 0); the
+ * factorisation / solve with W = I of the default start is skipped. */
+int mi355kkt_coneqp_init(mi355kkt_solver* hs, const double* q, const double* hv, const double* bv, int maxiters, double abstol,
+                         double reltol, double feastol, int refinement, int have_init, double* x, double* y, double* s, double* z,
+                         int* status, int* iters, double* stats) {
     if (!hs || !q || !hv || !x || !s || !z || !status || !iters || (hs->p > 0 && (!bv || !y))) {
         set_last_error("coneqp: null argument");
         return MI355KKT_EINVAL;
@@ -2305,16 +2316,27 @@ int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, cons
     if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.b, bv, sizeof(double) * np, hipMemcpyHostToDevice, st));
     KKT_HIP_CHECK(hipMemsetAsync(w.i32, 0, sizeof(int) * 8, st));
     KKT_HIP_CHECK(hipMemsetAsync(S.sc, 0, sizeof(double) * QP_NSC, st));
-    // ---- starting point with W = I (coneprog.py:2054-2106)
-    qp_launch_unit_scaling(S, st);
     int info = 0;
-    if (int e = factor(&info)) return e;
-    if (info > 0) { set_last_error("coneqp: Rank(A) < p or Rank([P; A; G]) < n"); return 1; }
-    hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S.x, S.q, -1.0, (int64_t)n);
-    if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.y, S.b, sizeof(double) * np, hipMemcpyDeviceToDevice, st));
-    KKT_HIP_CHECK(hipMemcpyAsync(S.z, S.h, sizeof(double) * m, hipMemcpyDeviceToDevice, st));
-    if (int e = solve(S.x, S.y, S.z)) return e;
-    qp_launch_start(S, st);
+    if (have_init) {
+        // ---- the caller's starting point (coneprog.py:2109-2149)
+        KKT_HIP_CHECK(hipMemcpyAsync(S.x, x, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.y, y, sizeof(double) * np, hipMemcpyHostToDevice, st));
+        KKT_HIP_CHECK(hipMemcpyAsync(S.s, s, sizeof(double) * m, hipMemcpyHostToDevice, st));
+        KKT_HIP_CHECK(hipMemcpyAsync(S.z, z, sizeof(double) * m, hipMemcpyHostToDevice, st));
+        qp_launch_symm(S, S.s, st);
+        qp_launch_symm(S, S.z, st);
+        qp_launch_start(S, st, 1);
+    } else {
+        // ---- starting point with W = I (coneprog.py:2054-2106)
+        qp_launch_unit_scaling(S, st);
+        if (int e = factor(&info)) return e;
+        if (info > 0) { set_last_error("coneqp: Rank(A) < p or Rank([P; A; G]) < n"); return 1; }
+        hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S.x, S.q, -1.0, (int64_t)n);
+        if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.y, S.b, sizeof(double) * np, hipMemcpyDeviceToDevice, st));
+        KKT_HIP_CHECK(hipMemcpyAsync(S.z, S.h, sizeof(double) * m, hipMemcpyDeviceToDevice, st));
+        if (int e = solve(S.x, S.y, S.z)) return e;
+        qp_launch_start(S, st);
+    }
     int it = 0;
     for (; it <= maxiters; ++it) {
         if (int e = products(S.x, S.y, S.z)) return e;

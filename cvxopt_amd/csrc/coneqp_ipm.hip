@@ -63,21 +63,24 @@ __global__ __launch_bounds__(1024) void qp_unit_scaling_kernel(QpState S) {
     }
 }
 
-__global__ __launch_bounds__(1024) void qp_start_kernel(QpState S) {
+// given != 0: s and z are the caller's starting point (initvals, coneprog.py:2109-2149): no s = -z, no shift into the interior
+__global__ __launch_bounds__(1024) void qp_start_kernel(QpState S, int given) {
     qp_select(S);
     __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m;
     double* sc = S.sc;
     const double q2 = lp_dot(S.q, S.q, S.n, sh), h2 = lp_dot(S.h, S.h, m, sh);
     const double b2 = S.p > 0 ? lp_dot(S.b, S.b, S.p, sh) : 0.0;
-    for (int i = tid; i < m; i += blockDim.x) S.s[i] = -S.z[i];
-    __syncthreads();
-    const double ns = sqrt(lp_dot(S.s, S.s, m, sh));
-    const double ts = cv_maxstep(S, S.s, sh);
-    if (ts >= -1e-8 * fmax(ns, 1.0)) cv_add_e(S, S.s, 1.0 + ts);
-    const double nz = sqrt(lp_dot(S.z, S.z, m, sh));
-    const double tz = cv_maxstep(S, S.z, sh);
-    if (tz >= -1e-8 * fmax(nz, 1.0)) cv_add_e(S, S.z, 1.0 + tz);
+    if (!given) {
+        for (int i = tid; i < m; i += blockDim.x) S.s[i] = -S.z[i];
+        __syncthreads();
+        const double ns = sqrt(lp_dot(S.s, S.s, m, sh));
+        const double ts = cv_maxstep(S, S.s, sh);
+        if (ts >= -1e-8 * fmax(ns, 1.0)) cv_add_e(S, S.s, 1.0 + ts);
+        const double nz = sqrt(lp_dot(S.z, S.z, m, sh));
+        const double tz = cv_maxstep(S, S.z, sh);
+        if (tz >= -1e-8 * fmax(nz, 1.0)) cv_add_e(S, S.z, 1.0 + tz);
+    }
     __syncthreads();
     const double g = lp_dot(S.s, S.z, m, sh);
     if (tid == 0) {
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(1024) void qp_symm_kernel(QpState S, double* z) { c
     } while (0)
 void qp_launch_symm(const QpState& S, double* z, hipStream_t st) { if (S.ns > 0) QP1(qp_symm_kernel, S, z); }
 void qp_launch_unit_scaling(const QpState& S, hipStream_t st) { QP1(qp_unit_scaling_kernel, S); }
-void qp_launch_start(const QpState& S, hipStream_t st) { QP1J(qp_start_kernel, S); }
+void qp_launch_start(const QpState& S, hipStream_t st, int given) { QP1J(qp_start_kernel, S, given); }
 void qp_launch_residual(const QpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st) {
     QP1J(qp_residual_kernel, S, it, maxiters, abstol, reltol, feastol);
 }

@@ -26,7 +26,8 @@ struct __attribute__((aligned(8))) d2u { double x, y; };   // 8-byte aligned pai
 
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-__device__ int g_syrk_skip = 0;   // developer ablation switch (bit0 no global fetch, bit1 no LDS stash, bit2 no barrier); 0 in production
+__device__ int g_syrk_skip = 0;   // developer ablation switch (bit0 no global fetch, bit1 no LDS stash, bit2 no barrier, bit4 no static priority,
+                                  // bit5 diagonal tiles through the general path); 0 in production
 int set_syrk_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_syrk_skip), &v, sizeof(int)) == hipSuccess ? 0 : -2; }
 
 // ---------------------------------------------------------------------------------------------------
@@ -148,6 +149,66 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
     __syncthreads();
     const int skip = g_syrk_skip & 15;
     const bool no_prio = (g_syrk_skip >> 4) & 1;
+    if (diag && (it.k1 - it.k0) >= 8192 && !((g_syrk_skip >> 5) & 1)) {
+        // ---- diagonal tiles (round 3): only the 36 16 x 16 blocks on / below the diagonal are computed, 9 per wave -- wave w owns
+        //      block rows w and 7 - w (w + 1 and 8 - w blocks) -- instead of 16 per wave with 28 of the 64 above the diagonal
+        //      (the whole wave (0, 1) among them).  At n = 8192 the diagonal tiles are 3 % of all tiles, at the batched engine's
+        //      n = 512 they are 40 %.  Plain double-buffered loop; the MFMA predicates are wave-uniform.  Measured: n = 8192,
+        //      m = 16384: 17.53 -> 17.30 ms; with short contractions (the batch: K = 1024) the plain loop costs more than the
+        //      skipped blocks save (63 -> 58 k problem-iterations/s), hence the threshold on K.
+        const int w = __builtin_amdgcn_readfirstlane(wave);     // scalar: the predicates below become s_cbranch (MFMA ignores EXEC)
+        const int li2 = lane & 15, lk2 = lane >> 4;
+        d4 acc0[8], acc1[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc0[t] = acc1[t] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) fetch(kt + 1);
+            const double* __restrict__ Xs = sJ(cur);
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 4) {
+                const double b0 = Xs[(16 * w + li2) * LDT_K + kk + lk2];
+                const double b1 = Xs[(16 * (7 - w) + li2) * LDT_K + kk + lk2];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    if (t <= 7 - w) {
+                        const double a = Xs[(16 * t + li2) * LDT_K + kk + lk2];
+                        if (t <= w) acc0[t] = MFMA_F64(a, b0, acc0[t]);
+                        acc1[t] = MFMA_F64(a, b1, acc1[t]);
+                    }
+                }
+            }
+            if (kt + 1 < nkt) stash(cur ^ 1);
+            __syncthreads();
+        }
+        // lane holds D[row = (lane >> 4) + 4 r -> column j][col = lane & 15 -> row i]
+        double* slab = it.slot >= 0 ? slabs + (int64_t)it.slot * TILE * TILE : nullptr;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int rb = half ? 7 - w : w;                 // block row
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                if (t <= rb) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int il = 16 * rb + li2, jl = 16 * t + lk2 + 4 * r;
+                        const double v0 = half ? acc1[t][r] : acc0[t][r];
+                        if (slab) {
+                            slab[il + jl * TILE] = v0;
+                        } else {
+                            const int i = i0 + il, j = j0 + jl;
+                            if (i < n && j < n && i >= j) {
+                                double v = v0;
+                                if (P) v += P[i + (int64_t)j * ldp];
+                                C[i + (int64_t)j * ldc] = v;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     if (tile_fast && ((it.k1 - it.k0) % BK) == 0 && !skip) {
         // ---- software-pipelined main loop (interior tiles): the 8 global loads of tile kt+1 are issued one
         //      after every second MFMA quad of the first half, the 8 {scale, ds_write} units that stage it into

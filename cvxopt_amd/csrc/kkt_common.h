@@ -144,7 +144,7 @@ int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int t
 // trsv_z_prepare once per factorisation (after launch_mirror_lower), zmat holds trsv_z_doubles(n) doubles; n % 128 == 0
 size_t trsv_z_doubles(int n);
 int set_trsvz_ts(long long* dptr);   // developer aid: 8 stamps per 128-block of the next trsv_z launches (nullptr: off)
-int trsv_z_prepare(const double* L, int64_t ldl, int n, double* zmat, hipStream_t st);
+int trsv_z_prepare(const double* L, int64_t ldl, int n, double* zmat, hipStream_t st, const double* minv = nullptr);
 int launch_trsv_z(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
                   unsigned long long* gran, const double* minv, const double* zmat);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
@@ -385,7 +385,7 @@ struct QpState {
     int *active = nullptr, *status = nullptr, *iters = nullptr, *nactive = nullptr;
 };
 void qp_launch_unit_scaling(const QpState& S, hipStream_t st);
-void qp_launch_start(const QpState& S, hipStream_t st);
+void qp_launch_start(const QpState& S, hipStream_t st, int given = 0);   // given: s, z hold the caller's starting point
 void qp_launch_residual(const QpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st);
 void qp_launch_singular(const QpState& S, const int* d_info, int it, hipStream_t st);
 void qp_launch_build(const QpState& S, const QpBuf& D, const QpBuf& W, int i01, int save, hipStream_t st);

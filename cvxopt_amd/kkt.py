@@ -458,7 +458,52 @@ class _Engine(object):
             ind += mk * mk
         return min(t) if t else 0.0
 
-    def coneqp_cones(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None):
+    def _interior_start(self, initvals):
+        """initvals of solvers.coneqp (coneprog.py:2109-2149) as full vectors: missing x / y are zero, missing s / z the cone's
+        identity e; a given s or z must be in the interior of the cone (ValueError otherwise, as in the reference)."""
+        n, m, p, dims = self.n, self.cdim, self.p, self.dims
+
+        def ident():
+            e = np.zeros(m)
+            e[:dims['l']] = 1.0
+            ind = dims['l']
+            for mk in dims['q']:
+                e[ind] = 1.0
+                ind += mk
+            for mk in dims['s']:
+                e[ind:ind + mk * mk:mk + 1] = 1.0
+                ind += mk * mk
+            return e
+
+        def interior(v):
+            ok = np.all(v[:dims['l']] > 0.0)
+            ind = dims['l']
+            for mk in dims['q']:
+                ok = ok and v[ind] - np.linalg.norm(v[ind + 1:ind + mk]) > 0.0
+                ind += mk
+            for mk in dims['s']:
+                X = np.tril(v[ind:ind + mk * mk].reshape(mk, mk, order='F'))
+                ok = ok and (mk == 0 or np.linalg.eigvalsh(X + X.T - np.diag(np.diag(X)))[0] > 0.0)
+                ind += mk * mk
+            return bool(ok)
+
+        def vec(key, size, default):
+            if key not in initvals:
+                return default
+            a = np.array(initvals[key], dtype=np.float64).reshape(-1, order='F').copy()
+            if a.size != size:
+                raise TypeError("initvals['%s'] has the wrong size" % key)
+            return a
+        x, y = vec('x', n, np.zeros(n)), vec('y', p, np.zeros(p))
+        s, z = vec('s', m, ident()), vec('z', m, ident())
+        if 's' in initvals and not interior(s):
+            raise ValueError("initial s is not positive")
+        if 'z' in initvals and not interior(z):
+            raise ValueError("initial z is not positive")
+        return x, y, s, z
+
+    def coneqp_cones(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None,
+                     initvals=None):
         """The reference coneqp loop (coneprog.py:2044-2547) for 'l', 'q' and 's' cones resident on the device around this
         handle (`mi355kkt_coneqp`; refinement 1 with second-order or semidefinite cones like the reference).  'q' / 's' cones
         run on the dense engine; the 's' blocks of h, s, z are in the reference's unpacked storage (s, z returned symmetric)."""
@@ -469,13 +514,16 @@ class _Engine(object):
         bv = np.ascontiguousarray(np.asarray(b if b is not None else [], dtype=np.float64).reshape(-1))
         if qv.size != n or hv.size != m or bv.size != p:
             raise TypeError("q / h / b have the wrong length")
-        x, y, s, z = np.zeros(n), np.zeros(p), np.zeros(m), np.zeros(m)
+        if initvals:
+            x, y, s, z = self._interior_start(initvals)
+        else:
+            x, y, s, z = np.zeros(n), np.zeros(p), np.zeros(m), np.zeros(m)
         status, iters = C.c_int(0), C.c_int(0)
         st = (C.c_double * 6)()
-        rc = self._loop_call(lambda: self.L.mi355kkt_coneqp(
+        rc = self._loop_call(lambda: self.L.mi355kkt_coneqp_init(
             self.h, _ptr(qv), _ptr(hv), _ptr(bv), int(maxiters), float(abstol), float(reltol), float(feastol),
-            -1 if refinement is None else int(refinement), _ptr(x), _ptr(y), _ptr(s), _ptr(z), C.byref(status),
-            C.byref(iters), st), P)
+            -1 if refinement is None else int(refinement), 1 if initvals else 0, _ptr(x), _ptr(y), _ptr(s), _ptr(z),
+            C.byref(status), C.byref(iters), st), P)
         if rc == 1:
             raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")        # coneprog.py:2065-2066
         _capi.check(rc, "mi355kkt_coneqp")
@@ -610,7 +658,7 @@ def _final_line(sol, maxiters):
 
 
 def coneqp_device(P, q, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters=100, abstol=1e-7, reltol=1e-6,
-                  feastol=1e-7, refinement=None, kktreg=None, show_progress=False):
+                  feastol=1e-7, refinement=None, kktreg=None, show_progress=False, initvals=None):
     """min 1/2 x'Px + q'x  s.t.  Gx <=_K h, Ax = b,  K = R^l_+ x second-order cones x positive semidefinite cones, with the whole
     interior-point loop on the MI355X.  Iterates match `solvers.coneqp(P, q, G, h, dims[, A, b])`."""
     kind = {'chol2': _capi.CHOL2, 'chol': _capi.CHOL, 'ldl': _capi.LDL, 'ldl2': _capi.LDL2}[kktsolver]
@@ -624,7 +672,7 @@ def coneqp_device(P, q, G, h, dims=None, A=None, b=None, kktsolver='chol', maxit
     try:
         eng.show_progress(show_progress, lp=False)
         sol = eng.coneqp_cones(q, h, P, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol,
-                               refinement=refinement)
+                               refinement=refinement, initvals=initvals)
         if show_progress:
             _final_line(sol, maxiters)
         return sol

@@ -156,9 +156,8 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
         return solvers.coneqp(P, q, G, h, dims, A=A, b=b, initvals=initvals, kktsolver=kktsolver, **kwargs)
     extra = set(kwargs) - {'options'}
     o, kktreg, debug = _options(kwargs)
-    if device_loop and initvals is None and not extra and not debug \
-            and (dims['l'] + sum(dims['q']) + sum(dims['s'])) > 0:
-        return _as_cvxopt(_kkt.coneqp_device(P, q, G, h, dims, A, b, kktsolver=ks_name, **o))
+    if device_loop and not extra and not debug and (dims['l'] + sum(dims['q']) + sum(dims['s'])) > 0:
+        return _as_cvxopt(_kkt.coneqp_device(P, q, G, h, dims, A, b, kktsolver=ks_name, initvals=initvals, **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
     ks = _kkt.kktsolver_qp(G, dims, Am, P, kind=ks_name, kktreg=kktreg)
     eng = ks.engine

@@ -194,6 +194,12 @@ int mi355kkt_conelp(mi355kkt_solver* h, const double* c, const double* hv, const
 int mi355kkt_coneqp(mi355kkt_solver* h, const double* q, const double* hv, const double* bv, int maxiters, double abstol,
                     double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
                     int* iters, double* stats);
+/* The same with a caller-supplied starting point (initvals of solvers.coneqp, coneprog.py:2109-2149): have_init != 0 -> x, y, s, z
+ * hold it on entry (the caller fills in the reference's defaults x = 0, y = 0, s = z = e for missing entries and has checked that
+ * s and z are in the interior of the cone); the W = I factorisation / solve of the default start is skipped. */
+int mi355kkt_coneqp_init(mi355kkt_solver* h, const double* q, const double* hv, const double* bv, int maxiters, double abstol,
+                         double reltol, double feastol, int refinement, int have_init, double* x, double* y, double* s, double* z,
+                         int* status, int* iters, double* stats);
 
 /* ---- batched mode: nbatch independent dense LP-cone problems of one shape (BASELINE configs[4]) ---------
  * No reference API exists for this; per problem it is exactly factor()/solve() of the

@@ -153,8 +153,9 @@ def test_set_A_csr_rejects_an_invalid_rowptr():
 def test_ldl_flavour_at_late_iteration_scalings_against_the_reference_kkt_ldl(ref_cvxopt, spread, p):
     """kind='ldl' is what users pick for robustness on ill-conditioned W.  Late interior-point iterations: d spans
     10^-spread .. 10^+spread, cond(K) up to ~1e12 for the 3 x 3 system.  The device engine factors the reduced quasi-definite
-    form; the reference (misc.kkt_ldl, misc.py:1085-1121) runs a pivoted LDL' (sytrf) of the whole 3 x 3 matrix.  Both residuals
-    of the ORIGINAL 3 x 3 system are recorded in the parity report; ours must stay within a small factor of the reference's."""
+    form and adds two steps of iterative refinement against the 3 x 3 system (without them the residual was 3e-9 at spread 3);
+    the reference (misc.kkt_ldl, misc.py:1085-1121) runs a pivoted LDL' (sytrf) of the whole 3 x 3 matrix.  Both residuals of
+    the ORIGINAL 3 x 3 system are recorded in the parity report; ours must stay within a factor of three of the reference's."""
     from cvxopt import matrix, misc
     from helpers import record
     n, m = 300, 500
@@ -178,5 +179,6 @@ def test_ldl_flavour_at_late_iteration_scalings_against_the_reference_kkt_ldl(re
     ex, ez = relerr(x, xr), relerr(z, zr)
     record("ldl_late_iteration_spread%g_p%d" % (spread, p), residual_device=res, residual_reference_kkt_ldl=res_ref,
            x_relerr_vs_reference=ex, z_relerr_vs_reference=ez, d_min=float(W['d'].min()), d_max=float(W['d'].max()))
-    assert res <= max(1e-12, 30.0 * res_ref), (res, res_ref)
-    assert ex < 1e-6, ex
+    # achieved (profiles/r03_parity_report.json): 2e-15 .. 5e-14 against the reference's 2e-13 .. 3e-13; x agrees to 3e-14 .. 1e-13
+    assert res <= max(3e-13, 3.0 * res_ref), (res, res_ref)
+    assert ex < 1e-10, ex

@@ -190,3 +190,62 @@ def test_socp_config3_full_size_timing(ref_cvxopt):
           % (t_ops, t_hook, sol['iterations']))
     _same(sol, hook)
     assert sol['status'] == 'optimal'
+
+
+@pytest.mark.parametrize("case", ["lp_cone_all", "mixed_partial", "sdp_block"])
+def test_coneqp_initvals_run_on_the_device_loop_like_the_reference(ref_cvxopt, case):
+    """initvals of solvers.coneqp (coneprog.py:2109-2149): the device-resident loop starts from the caller's point (round 3;
+    before, the host driver with device operators took over): same iteration count, objectives and iterates as the reference
+    started from the same point; a non-interior s raises the reference's ValueError."""
+    from cvxopt import matrix, solvers
+    import cvxopt_amd.solvers as gs
+    rng = np.random.default_rng(5)
+    if case == "lp_cone_all":
+        pr = synth.dense_qp(24, 60, seed=12, p=3)
+        dims = pr['dims']
+        iv = {'x': matrix(rng.standard_normal(24)), 'y': matrix(rng.standard_normal(3)),
+              's': matrix(rng.uniform(0.5, 2.0, 60)), 'z': matrix(rng.uniform(0.5, 2.0, 60))}
+        args = dict(A=matrix(pr['A']), b=matrix(pr['b']))
+        G, h = matrix(pr['G']), matrix(pr['h'])
+    elif case == "mixed_partial":
+        base = synth.socp(n=24, ncones=4, r=5, seed=2, ml=6)
+        dims = base['dims']
+        pr = {'P': synth.dense_qp(24, 8, seed=3)['P'], 'q': base['c']}
+        m = dims['l'] + sum(dims['q'])
+        s0 = np.zeros(m)
+        s0[:dims['l']] = rng.uniform(0.5, 1.5, dims['l'])
+        o = dims['l']
+        for mk in dims['q']:
+            s0[o + 1:o + mk] = rng.standard_normal(mk - 1)
+            s0[o] = np.linalg.norm(s0[o + 1:o + mk]) + 0.7
+            o += mk
+        iv = {'s': matrix(s0)}                       # only s is given: x = 0, z = e by default
+        args = {}
+        G, h = matrix(base['G']), matrix(base['h'])
+    else:
+        dims = {'l': 2, 'q': [], 's': [3]}
+        n = 4
+        Gm = rng.standard_normal((2 + 9, n))
+        for j in range(n):                           # symmetric 's' columns
+            X = Gm[2:, j].reshape(3, 3)
+            Gm[2:, j] = (X + X.T).ravel() / 2
+        x0 = rng.standard_normal(n)
+        S0 = np.eye(3) * 2.0
+        h = Gm @ x0 + np.concatenate([[1.0, 1.5], S0.ravel()])
+        B = rng.standard_normal((n, n))
+        pr = {'P': B.T @ B + 0.1 * np.eye(n), 'q': rng.standard_normal(n)}
+        Z0 = np.array([[2.0, 0.3, 0.0], [0.3, 1.5, -0.2], [0.0, -0.2, 1.0]])
+        iv = {'x': matrix(x0), 'z': matrix(np.concatenate([[0.7, 0.9], Z0.ravel(order='F')]))}
+        args = {}
+        G, h = matrix(Gm), matrix(h)
+    P, q = matrix(pr['P']), matrix(pr['q'])
+    ref = solvers.coneqp(P, q, G, h, dims, initvals=iv, **args)
+    sol = gs.coneqp(P, q, G, h, dims, initvals=iv, **args)
+    _same(sol, ref)
+    assert relerr(np.array(sol['s']).ravel(), np.array(ref['s']).ravel()) < 1e-6
+    bad = dict(iv)
+    sbad = np.array(iv['s'] if 's' in iv else matrix(1.0, (h.size[0], 1))).ravel().copy()
+    sbad[0] = -1.0
+    bad['s'] = matrix(sbad)
+    with pytest.raises(ValueError):
+        gs.coneqp(P, q, G, h, dims, initvals=bad, **args)

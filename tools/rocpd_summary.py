@@ -38,6 +38,17 @@ def pmc_per_kernel(db, counter, substr):
     return vals
 
 
+def source_id(files=("cvxopt_amd/csrc/gemm_f64.hip", "cvxopt_amd/csrc/kkt_common.h")):
+    """sha256 over the sources that define the SYRK kernel: bench.py recomputes it and refuses a PMC file of another version"""
+    import hashlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hsh = hashlib.sha256()
+    for f in files:
+        hsh.update(open(os.path.join(root, f), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def pmc(fetch_db, write_db, substr, out, n, m):
     f = pmc_per_kernel(fetch_db, "FETCH_SIZE", substr)
     w = pmc_per_kernel(write_db, "WRITE_SIZE", substr)
@@ -46,7 +57,8 @@ def pmc(fetch_db, write_db, substr, out, n, m):
     rec = {"kernel": substr, "n": int(n), "m": int(m), "launches_sampled": [len(f), len(w)],
            "FETCH_SIZE_KiB_avg": favg, "WRITE_SIZE_KiB_avg": wavg,
            "correction": "FETCH_SIZE x2 on gfx950 (guide: counts 128-B requests as 64 B); WRITE_SIZE uncalibrated, x1",
-           "hbm_bytes_per_launch": 2.0 * favg * 1024.0 + wavg * 1024.0}
+           "hbm_bytes_per_launch": 2.0 * favg * 1024.0 + wavg * 1024.0,
+           "kernel_source_id": source_id(), "kernel_source_files": ["cvxopt_amd/csrc/gemm_f64.hip", "cvxopt_amd/csrc/kkt_common.h"]}
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
 
