@@ -75,6 +75,9 @@ SIGNATURES = {
     "mi355kkt_coneqp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                   C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_int_p,
                                   c_double_p]),
+    "mi355kkt_conelp_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                       C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int_p,
+                                       c_int_p, c_double_p]),
     "mi355kkt_coneqp_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
                                        C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, c_int_p, c_int_p,
                                        c_double_p]),

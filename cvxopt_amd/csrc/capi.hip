@@ -2104,6 +2104,14 @@ static int symmetrize_G_sblocks(mi355kkt_solver* hs) {
 int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
                     double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
                     int* iters, double* stats) {
+    return mi355kkt_conelp_init(hs, c, hv, bv, maxiters, abstol, reltol, feastol, refinement, 0, 0, x, y, s, z, status, iters, stats);
+}
+
+/* have_primal: x, s hold primalstart on entry; have_dual: y, z hold dualstart (coneprog.py:696-739; the caller has checked that the
+ * given s / z are in the interior of the cone).  The part that is not given is constructed as in the default start. */
+int mi355kkt_conelp_init(mi355kkt_solver* hs, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
+                         double reltol, double feastol, int refinement, int have_primal, int have_dual, double* x, double* y,
+                         double* s, double* z, int* status, int* iters, double* stats) {
     if (!hs || !c || !hv || !x || !s || !z || !status || !iters || (hs->p > 0 && (!bv || !y))) {
         set_last_error("conelp: null argument");
         return MI355KKT_EINVAL;
@@ -2171,18 +2179,32 @@ int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, cons
     // ---- starting points with W = I (coneprog.py:664-748)
     lp_launch_unit_scaling(S, st);
     int info = 0;
-    if (int e = factor(&info)) return e;
-    if (info > 0) { set_last_error("conelp: Rank(A) < p or Rank([G; A]) < n"); return 1; }
-    KKT_HIP_CHECK(hipMemsetAsync(S.x, 0, sizeof(double) * n, st));
-    if (int e = dcopy(S.dy, S.b, np)) return e;
-    if (int e = dcopy(S.s, S.h, m)) return e;
-    if (int e = solve(S.x, S.dy, S.s)) return e;
-    lp_launch_init_primal(S, st);
-    hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S.dx, S.c, -1.0, (int64_t)n);
-    if (np > 0) KKT_HIP_CHECK(hipMemsetAsync(S.y, 0, sizeof(double) * np, st));
-    KKT_HIP_CHECK(hipMemsetAsync(S.z, 0, sizeof(double) * m, st));
-    if (int e = solve(S.dx, S.y, S.z)) return e;
-    lp_launch_init_dual(S, abstol, reltol, st);
+    if (!(have_primal && have_dual)) {                    // (the reference factors W = I only if a start has to be constructed)
+        if (int e = factor(&info)) return e;
+        if (info > 0) { set_last_error("conelp: Rank(A) < p or Rank([G; A]) < n"); return 1; }
+    }
+    if (have_primal) {                                   // coneprog.py:703-705
+        KKT_HIP_CHECK(hipMemcpyAsync(S.x, x, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        KKT_HIP_CHECK(hipMemcpyAsync(S.s, s, sizeof(double) * m, hipMemcpyHostToDevice, st));
+        lp_launch_symm(S, S.s, st);
+    } else {
+        KKT_HIP_CHECK(hipMemsetAsync(S.x, 0, sizeof(double) * n, st));
+        if (int e = dcopy(S.dy, S.b, np)) return e;
+        if (int e = dcopy(S.s, S.h, m)) return e;
+        if (int e = solve(S.x, S.dy, S.s)) return e;
+    }
+    lp_launch_init_primal(S, st, have_primal);
+    if (have_dual) {                                     // coneprog.py:735-737
+        if (np > 0) KKT_HIP_CHECK(hipMemcpyAsync(S.y, y, sizeof(double) * np, hipMemcpyHostToDevice, st));
+        KKT_HIP_CHECK(hipMemcpyAsync(S.z, z, sizeof(double) * m, hipMemcpyHostToDevice, st));
+        lp_launch_symm(S, S.z, st);
+    } else {
+        hipLaunchKernelGGL(axpby_kernel, dim3((n + 255) / 256), dim3(256), 0, st, S.dx, S.c, -1.0, (int64_t)n);
+        if (np > 0) KKT_HIP_CHECK(hipMemsetAsync(S.y, 0, sizeof(double) * np, st));
+        KKT_HIP_CHECK(hipMemsetAsync(S.z, 0, sizeof(double) * m, st));
+        if (int e = solve(S.dx, S.y, S.z)) return e;
+    }
+    lp_launch_init_dual(S, abstol, reltol, st, have_primal, have_dual);
     int it = 0;
     for (; it <= maxiters; ++it) {
         if (int e = products(S.x, S.y, S.z)) return e;

@@ -49,15 +49,19 @@ __global__ __launch_bounds__(1024) void lp_unit_scaling_kernel(LpState S) {
     }
 }
 
-__global__ __launch_bounds__(1024) void lp_init_primal_kernel(LpState S) {
+// given: s is the caller's primalstart['s'] (coneprog.py:703-705): no sign flip
+__global__ __launch_bounds__(1024) void lp_init_primal_kernel(LpState S, int given) {
     __shared__ double sh[16];
-    for (int i = threadIdx.x; i < S.m; i += blockDim.x) S.s[i] = -S.s[i];
+    if (!given)
+        for (int i = threadIdx.x; i < S.m; i += blockDim.x) S.s[i] = -S.s[i];
     __syncthreads();
     const double ts = cv_maxstep(S, S.s, sh);
     if (threadIdx.x == 0) S.sc[LP_TS] = ts;
 }
 
-__global__ __launch_bounds__(1024) void lp_init_dual_kernel(LpState S, double abstol, double reltol) {
+// have_primal / have_dual: the caller supplied primalstart / dualstart (coneprog.py:740-836): the "constructed point is optimal"
+// exit and both shifts belong to the case where neither was given; with one of them only the OTHER, constructed, vector is shifted
+__global__ __launch_bounds__(1024) void lp_init_dual_kernel(LpState S, double abstol, double reltol, int have_primal, int have_dual) {
     __shared__ double sh[16];
     const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
     double* sc = S.sc;
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(1024) void lp_init_dual_kernel(LpState S, double ab
     double relgap = 1e300;
     if (pcost < 0.0) relgap = g / -pcost;
     else if (dcost > 0.0) relgap = g / dcost;
-    const bool init_opt = (ts <= 0.0 && tz <= 0.0 && (g <= abstol || relgap <= reltol));
+    const bool init_opt = !have_primal && !have_dual && (ts <= 0.0 && tz <= 0.0 && (g <= abstol || relgap <= reltol));
     if (tid == 0) {
         sc[LP_RESX0] = fmax(1.0, sqrt(c2));
         sc[LP_RESY0] = fmax(1.0, sqrt(b2));
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(1024) void lp_init_dual_kernel(LpState S, double ab
         lp_store_result(S, 1, 0, 1.0, 1.0, 1.0, 1.0);
         return;
     }
-    if (ts >= -1e-8 * fmax(ns, 1.0)) cv_add_e(S, S.s, 1.0 + ts);
-    if (tz >= -1e-8 * fmax(nz, 1.0)) cv_add_e(S, S.z, 1.0 + tz);
+    if (!have_primal && ts >= -1e-8 * fmax(ns, 1.0)) cv_add_e(S, S.s, 1.0 + ts);
+    if (!have_dual && tz >= -1e-8 * fmax(nz, 1.0)) cv_add_e(S, S.z, 1.0 + tz);
     __syncthreads();
     const double g2 = lp_dot(S.s, S.z, m, sh);
     if (tid == 0) sc[LP_GAP] = g2;
@@ -523,8 +527,10 @@ int sdp_op_debug_launch(int op, int m, int arg, int wave_team, double* x, double
     } while (0)
 void lp_launch_symm(const LpState& S, double* z, hipStream_t st) { if (S.ns > 0) LP1(lp_symm_kernel, S, z); }
 void lp_launch_unit_scaling(const LpState& S, hipStream_t st) { LP1(lp_unit_scaling_kernel, S); }
-void lp_launch_init_primal(const LpState& S, hipStream_t st) { LP1J(lp_init_primal_kernel, S); }
-void lp_launch_init_dual(const LpState& S, double abstol, double reltol, hipStream_t st) { LP1J(lp_init_dual_kernel, S, abstol, reltol); }
+void lp_launch_init_primal(const LpState& S, hipStream_t st, int given) { LP1J(lp_init_primal_kernel, S, given); }
+void lp_launch_init_dual(const LpState& S, double abstol, double reltol, hipStream_t st, int have_primal, int have_dual) {
+    LP1J(lp_init_dual_kernel, S, abstol, reltol, have_primal, have_dual);
+}
 void lp_launch_residual(const LpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st) {
     LP1J(lp_residual_kernel, S, it, maxiters, abstol, reltol, feastol);
 }

@@ -332,8 +332,8 @@ struct LpState {
     int *active = nullptr, *status = nullptr, *iters = nullptr, *init_optimal = nullptr, *nactive = nullptr;
 };
 void lp_launch_unit_scaling(const LpState& S, hipStream_t st);
-void lp_launch_init_primal(const LpState& S, hipStream_t st);
-void lp_launch_init_dual(const LpState& S, double abstol, double reltol, hipStream_t st);
+void lp_launch_init_primal(const LpState& S, hipStream_t st, int given = 0);
+void lp_launch_init_dual(const LpState& S, double abstol, double reltol, hipStream_t st, int have_primal = 0, int have_dual = 0);
 void lp_launch_residual(const LpState& S, int it, int maxiters, double abstol, double reltol, double feastol, hipStream_t st);
 void lp_launch_singular(const LpState& S, const int* d_info, int it, hipStream_t st);
 void lp_launch_scale1(const LpState& S, hipStream_t st);

@@ -703,10 +703,12 @@ constexpr int TILE_PF = 2;
 // L2: the operands are read with sc1 loads (written a moment ago with write-through stores by another compute unit and announced
 // without fences: the streamed last 128 columns of a diagonal tile).
 // TBK: k-depth of one LDS stage (16, or 32: half the barriers per MFMA -- the dense factorisation's bulk; K a multiple of TBK)
-template <bool diag, bool TAIL, bool L2 = false, int TBK = BK>
+template <bool diag, bool TAIL, bool L2 = false, int TBKP = BK>
 __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __restrict__ Xi, const double* __restrict__ Xj,
                                                 int64_t lda, int K, int mi, int mj, double* __restrict__ smem, int tid, int rt) {
-    constexpr int PF = TBK == 32 ? 1 : TILE_PF;               // k-steps of operands in flight (global -> registers); same depth in k
+    // (four 16-deep steps in flight — 64 more registers — spill and measured slower: potrf(8192) 4.51 -> 5.19 ms)
+    constexpr int TBK = TBKP;
+    constexpr int PF = TBKP == 32 ? 1 : TILE_PF;              // k-steps of operands in flight (global -> registers); same depth in k
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int ip = (tid & 63) * 2, kq = tid >> 6;            // staging: index pair, k = kq + 8 r

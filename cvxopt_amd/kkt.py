@@ -458,47 +458,52 @@ class _Engine(object):
             ind += mk * mk
         return min(t) if t else 0.0
 
+    def _cone_identity(self):
+        dims, e = self.dims, np.zeros(self.cdim)
+        e[:dims['l']] = 1.0
+        ind = dims['l']
+        for mk in dims['q']:
+            e[ind] = 1.0
+            ind += mk
+        for mk in dims['s']:
+            e[ind:ind + mk * mk:mk + 1] = 1.0
+            ind += mk * mk
+        return e
+
+    def _in_cone_interior(self, v):
+        """misc.max_step(v, dims) < 0 (coneprog.py:708, :741, :2124): v strictly inside R^l_+ x second-order x semidefinite cones"""
+        dims = self.dims
+        ok = np.all(v[:dims['l']] > 0.0)
+        ind = dims['l']
+        for mk in dims['q']:
+            ok = ok and v[ind] - np.linalg.norm(v[ind + 1:ind + mk]) > 0.0
+            ind += mk
+        for mk in dims['s']:
+            X = np.tril(v[ind:ind + mk * mk].reshape(mk, mk, order='F'))
+            ok = ok and (mk == 0 or np.linalg.eigvalsh(X + X.T - np.diag(np.diag(X)))[0] > 0.0)
+            ind += mk * mk
+        return bool(ok)
+
+    @staticmethod
+    def _start_vec(d, key, size, default, what):
+        if key not in d:
+            return default
+        a = np.array(d[key], dtype=np.float64).reshape(-1, order='F').copy()
+        if a.size != size:
+            raise TypeError("%s['%s'] has the wrong size" % (what, key))
+        return a
+
     def _interior_start(self, initvals):
         """initvals of solvers.coneqp (coneprog.py:2109-2149) as full vectors: missing x / y are zero, missing s / z the cone's
         identity e; a given s or z must be in the interior of the cone (ValueError otherwise, as in the reference)."""
-        n, m, p, dims = self.n, self.cdim, self.p, self.dims
-
-        def ident():
-            e = np.zeros(m)
-            e[:dims['l']] = 1.0
-            ind = dims['l']
-            for mk in dims['q']:
-                e[ind] = 1.0
-                ind += mk
-            for mk in dims['s']:
-                e[ind:ind + mk * mk:mk + 1] = 1.0
-                ind += mk * mk
-            return e
-
-        def interior(v):
-            ok = np.all(v[:dims['l']] > 0.0)
-            ind = dims['l']
-            for mk in dims['q']:
-                ok = ok and v[ind] - np.linalg.norm(v[ind + 1:ind + mk]) > 0.0
-                ind += mk
-            for mk in dims['s']:
-                X = np.tril(v[ind:ind + mk * mk].reshape(mk, mk, order='F'))
-                ok = ok and (mk == 0 or np.linalg.eigvalsh(X + X.T - np.diag(np.diag(X)))[0] > 0.0)
-                ind += mk * mk
-            return bool(ok)
-
-        def vec(key, size, default):
-            if key not in initvals:
-                return default
-            a = np.array(initvals[key], dtype=np.float64).reshape(-1, order='F').copy()
-            if a.size != size:
-                raise TypeError("initvals['%s'] has the wrong size" % key)
-            return a
-        x, y = vec('x', n, np.zeros(n)), vec('y', p, np.zeros(p))
-        s, z = vec('s', m, ident()), vec('z', m, ident())
-        if 's' in initvals and not interior(s):
+        n, m, p = self.n, self.cdim, self.p
+        x = self._start_vec(initvals, 'x', n, np.zeros(n), "initvals")
+        y = self._start_vec(initvals, 'y', p, np.zeros(p), "initvals")
+        s = self._start_vec(initvals, 's', m, self._cone_identity(), "initvals")
+        z = self._start_vec(initvals, 'z', m, self._cone_identity(), "initvals")
+        if 's' in initvals and not self._in_cone_interior(s):
             raise ValueError("initial s is not positive")
-        if 'z' in initvals and not interior(z):
+        if 'z' in initvals and not self._in_cone_interior(z):
             raise ValueError("initial z is not positive")
         return x, y, s, z
 
@@ -533,10 +538,12 @@ class _Engine(object):
                 'primal infeasibility': pres, 'dual infeasibility': dres, 'primal slack': self._slack(s),
                 'dual slack': self._slack(z), 'iterations': iters.value}
 
-    def conelp(self, c, h, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None, kktreg=None):
-        """The reference conelp loop (coneprog.py:586-1436; 'l', 'q' and 's' cones, default starting point) resident on the
-        device around this handle (`mi355kkt_conelp`).  Returns a dict with the reference's keys and conventions
-        (None entries for the infeasibility-certificate cases), vectors as NumPy arrays."""
+    def conelp(self, c, h, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None, kktreg=None,
+               primalstart=None, dualstart=None):
+        """The reference conelp loop (coneprog.py:586-1436; 'l', 'q' and 's' cones) resident on the device around this handle
+        (`mi355kkt_conelp_init`); primalstart = {'x', 's'} / dualstart = {['y',] 'z'} as in the reference (coneprog.py:696-739).
+        Returns a dict with the reference's keys and conventions (None entries for the infeasibility-certificate cases), vectors
+        as NumPy arrays."""
         self._set_H(None)
         n, m, p = self.n, self.cdim, self.p
         cdim_pckd = self.dims['l'] + sum(self.dims['q']) + sum(k * (k + 1) // 2 for k in self.dims['s'])
@@ -548,12 +555,26 @@ class _Engine(object):
         if cv.size != n or hv.size != m or bv.size != p:
             raise TypeError("c / h / b have the wrong length")
         x, y, s, z = np.zeros(n), np.zeros(p), np.zeros(m), np.zeros(m)
+        if primalstart:
+            x = self._start_vec(primalstart, 'x', n, None, "primalstart")
+            s = self._start_vec(primalstart, 's', m, None, "primalstart")
+            if x is None or s is None:
+                raise KeyError("primalstart needs 'x' and 's'")
+            if not self._in_cone_interior(s):
+                raise ValueError("initial s is not positive")              # coneprog.py:708-709
+        if dualstart:
+            y = self._start_vec(dualstart, 'y', p, np.zeros(p), "dualstart")
+            z = self._start_vec(dualstart, 'z', m, None, "dualstart")
+            if z is None:
+                raise KeyError("dualstart needs 'z'")
+            if not self._in_cone_interior(z):
+                raise ValueError("initial z is not positive")              # coneprog.py:741-742
         status, iters = C.c_int(0), C.c_int(0)
         st = (C.c_double * 10)()
-        rc = self._loop_call(lambda: self.L.mi355kkt_conelp(
+        rc = self._loop_call(lambda: self.L.mi355kkt_conelp_init(
             self.h, _ptr(cv), _ptr(hv), _ptr(bv), int(maxiters), float(abstol), float(reltol), float(feastol),
-            -1 if refinement is None else int(refinement), _ptr(x), _ptr(y), _ptr(s), _ptr(z), C.byref(status),
-            C.byref(iters), st), None)
+            -1 if refinement is None else int(refinement), 1 if primalstart else 0, 1 if dualstart else 0,
+            _ptr(x), _ptr(y), _ptr(s), _ptr(z), C.byref(status), C.byref(iters), st), None)
         if rc == 1:
             raise ValueError("Rank(A) < p or Rank([G; A]) < n")           # coneprog.py:690-691
         _capi.check(rc, "mi355kkt_conelp")
@@ -622,7 +643,7 @@ def _factory(kind, G, dims, A, mnl=0, kktreg=None):
 
 
 def conelp_device(c, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters=100, abstol=1e-7, reltol=1e-6,
-                  feastol=1e-7, refinement=None, kktreg=None, show_progress=False):
+                  feastol=1e-7, refinement=None, kktreg=None, show_progress=False, primalstart=None, dualstart=None):
     """min c'x  s.t.  Gx <=_K h, Ax = b,  K = R^l_+ x second-order cones x positive semidefinite cones (`solvers.conelp` / `lp` /
     `socp` / `sdp`) with the whole self-dual interior-point loop on the MI355X.  Iterates match `solvers.conelp(c, G, h, dims[, A=A, b=b])`."""
     kind = {'chol2': _capi.CHOL2, 'chol': _capi.CHOL, 'ldl': _capi.LDL, 'ldl2': _capi.LDL2, 'qr': _capi.CHOL}[kktsolver]
@@ -636,7 +657,7 @@ def conelp_device(c, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters
     try:
         eng.show_progress(show_progress, lp=True)
         sol = eng.conelp(c, h, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol,
-                         refinement=refinement, kktreg=kktreg)
+                         refinement=refinement, kktreg=kktreg, primalstart=primalstart, dualstart=dualstart)
         if show_progress:
             _final_line(sol, maxiters)
         return sol

@@ -125,9 +125,9 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
                               **kwargs)
     extra = set(kwargs) - {'options'}
     o, kktreg, debug = _options(kwargs)
-    if device_loop and primalstart is None and dualstart is None and not extra \
-            and not debug and (dims['l'] + sum(dims['q']) + sum(dims['s'])) > 0:
-        return _as_cvxopt(_kkt.conelp_device(c, G, h, dims, A, b, kktsolver=ks_name, **o))
+    if device_loop and not extra and not debug and (dims['l'] + sum(dims['q']) + sum(dims['s'])) > 0:
+        return _as_cvxopt(_kkt.conelp_device(c, G, h, dims, A, b, kktsolver=ks_name, primalstart=primalstart,
+                                             dualstart=dualstart, **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
     ks = _kkt.kktsolver_lp(G, dims, Am, kind={'qr': 'chol'}.get(ks_name, ks_name), kktreg=kktreg)
     eng = ks.engine

@@ -184,6 +184,14 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* h, const double* q, const double* hv, co
 int mi355kkt_conelp(mi355kkt_solver* h, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
                     double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
                     int* iters, double* stats);
+/* The same with caller-supplied starting points (primalstart / dualstart of solvers.conelp, coneprog.py:696-739): have_primal -> x, s
+ * hold primalstart on entry, have_dual -> y, z hold dualstart (a missing dualstart['y'] is zero; the caller has checked that the given
+ * s / z lie in the interior of the cone: the reference's ValueError).  What is not given is constructed as in the default start;
+ * as in the reference, only a constructed vector is shifted into the interior and the "starting point is optimal" exit belongs to
+ * the fully constructed start. */
+int mi355kkt_conelp_init(mi355kkt_solver* h, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
+                         double reltol, double feastol, int refinement, int have_primal, int have_dual, double* x, double* y,
+                         double* s, double* z, int* status, int* iters, double* stats);
 
 /* The coneqp loop (coneprog.py:2044-2547) for dims = {'l': ml, 'q': [...]} around this handle (H = P optional; equality
  * constraints with the dense engine); refinement < 0: the reference's default (0 for the LP cone, 1 with second-order

@@ -249,3 +249,38 @@ def test_coneqp_initvals_run_on_the_device_loop_like_the_reference(ref_cvxopt, c
     bad['s'] = matrix(sbad)
     with pytest.raises(ValueError):
         gs.coneqp(P, q, G, h, dims, initvals=bad, **args)
+
+
+@pytest.mark.parametrize("which", ["both", "primal", "dual"])
+def test_conelp_primalstart_dualstart_run_on_the_device_loop_like_the_reference(ref_cvxopt, which):
+    """primalstart / dualstart of solvers.conelp (coneprog.py:696-739) in the device-resident loop (round 3): the given point is
+    taken as it is, only a CONSTRUCTED s or z is shifted into the interior, the 'starting point is optimal' exit belongs to the
+    fully constructed start -- same iteration count, objectives and iterates as the reference from the same starts."""
+    from cvxopt import matrix, solvers
+    import cvxopt_amd.solvers as gs
+    pr = synth.socp(n=30, ncones=5, r=6, seed=4, ml=8)
+    dims = pr['dims']
+    c, G, h = matrix(pr['c']), matrix(pr['G']), matrix(pr['h'])
+    rng = np.random.default_rng(7)
+    m = dims['l'] + sum(dims['q'])
+
+    def interior_point():
+        u = np.zeros(m)
+        u[:dims['l']] = rng.uniform(0.5, 1.5, dims['l'])
+        o = dims['l']
+        for mk in dims['q']:
+            u[o + 1:o + mk] = rng.standard_normal(mk - 1)
+            u[o] = np.linalg.norm(u[o + 1:o + mk]) + rng.uniform(0.3, 1.0)
+            o += mk
+        return u
+    ps = {'x': matrix(rng.standard_normal(30)), 's': matrix(interior_point())} if which in ("both", "primal") else None
+    ds = {'z': matrix(interior_point())} if which in ("both", "dual") else None
+    ref = solvers.conelp(c, G, h, dims, primalstart=ps, dualstart=ds)
+    sol = gs.conelp(c, G, h, dims, primalstart=ps, dualstart=ds)
+    _same(sol, ref)
+    assert relerr(np.array(sol['z']).ravel(), np.array(ref['z']).ravel()) < 1e-6
+    if ps is not None:
+        bad = np.array(ps['s']).ravel().copy()
+        bad[dims['l']] = -5.0                              # the first second-order cone leaves its interior
+        with pytest.raises(ValueError):
+            gs.conelp(c, G, h, dims, primalstart={'x': ps['x'], 's': matrix(bad)}, dualstart=ds)
