@@ -488,6 +488,18 @@ def main_sharded(args):
             "gather_ms": round(per_rank[0]["gather_exposed"], 3),
             "phases_ms_per_rank": [{k: round(v, 3) for k, v in p_.items()} for p_ in per_rank],
         }
+        # the same roofline as the one-GPU batch line (measure_batch): useful flops of the problem-iterations taken, here over the
+        # WHOLE step (scatter and gather included) against world x the FP64 matrix peak
+        flop_it = float(m) * n * n + float(n) ** 3 / 3.0 + 2.0 * (4.0 * m * n + 2.0 * n * n)
+        tf = its * flop_it / (ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "whole step of the sharded batch: scatter + lock-step interior-point iterations of every shard "
+                                     "(batched SYRK + Cholesky + solves + residual products) + gather",
+                           "bound": "mfma", "achieved": None if dry else round(tf, 2), "peak": FP64_MFMA_PEAK_TFLOPS * world,
+                           "unit": "TFLOP/s", "frac": None if dry else round(tf / (FP64_MFMA_PEAK_TFLOPS * world), 4), "traffic": None,
+                           "flops_per_problem_iteration": flop_it,
+                           "note": "useful flops only (m n^2 + n^3/3 + 2 (4 m n + 2 n^2) per problem-iteration taken) over the whole "
+                                   "job; peak = %d GPUs x %.1f" % (world, FP64_MFMA_PEAK_TFLOPS)}
+        out["cpu_baseline"] = None          # reported at N = 1 only (`python bench.py`: side_workloads.batch_configs4_one_gpu.cpu_baseline)
         if dry:
             out["dry_run"] = True
             out["note"] = "no GPU visible: gloo/NumPy plumbing check of the N-rank scatter-solve-gather path, NOT a measurement"

@@ -172,6 +172,112 @@ int launch_gemv_n_scaled(const double* G, int64_t ldg, int m, int n, const doubl
 }
 
 // ===================================================================================================
+// Residual products of the interior-point loops in ONE pass over G:  Gx = G x  and  GTz = G' z.
+// (coneprog.py:2170-2186 computes rx and rz with two sgemv calls; the batched loop paid two of its seven passes over G for them.)
+//   A workgroup owns 64 columns (16 per wave); a wave walks its columns in row blocks of 1024: the lane holds 16 rows (8 pairs,
+//   128 apart: whole 1 KB pieces of the column per load instruction), their z in registers and 16 accumulators of G x; the
+//   column's dot product with z is wave-reduced and kept in LDS.  After a row block the four waves' accumulators are summed in
+//   LDS and written as partial[chunk = blockIdx.x][row]; gemv_n_finish_kernel adds the chunks in a fixed order.
+// ===================================================================================================
+constexpr int NT_COLS = 64;     // columns per workgroup
+constexpr int NT_ROWS = 1024;   // rows per row block
+__global__ __launch_bounds__(256) void gemv_nt_fused_kernel(const double* __restrict__ G, int64_t ldg, int m, int n,
+                                                            const double* __restrict__ x, const double* __restrict__ z,
+                                                            double* __restrict__ partial, double* __restrict__ GTz, int64_t sG) {
+    __shared__ double ylds[4][NT_ROWS];
+    __shared__ double dots[NT_COLS];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    {   // batched problems along blockIdx.z
+        const int64_t bz = blockIdx.z;
+        G += bz * sG;
+        x += bz * n;
+        z += bz * m;
+        GTz += bz * n;
+        partial += bz * gridDim.x * m;
+    }
+    if (tid < NT_COLS) dots[tid] = 0.0;
+    const int c0 = blockIdx.x * NT_COLS + w * 16;
+    const int c1 = min(n, c0 + 16);
+    __syncthreads();
+    for (int rb = 0; rb < m; rb += NT_ROWS) {
+        const int i0 = rb + 2 * lane;
+        const bool whole = (rb + NT_ROWS <= m);
+        double zr[16], y[16];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = i0 + 128 * k;
+            zr[2 * k] = (i < m) ? z[i] : 0.0;
+            zr[2 * k + 1] = (i + 1 < m) ? z[i + 1] : 0.0;
+            y[2 * k] = y[2 * k + 1] = 0.0;
+        }
+#pragma unroll 2
+        for (int j = c0; j < c1; ++j) {
+            const double* __restrict__ g = G + (int64_t)j * ldg + i0;
+            const double xj = x[j];
+            double a[16];
+            if (whole) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const d2u v = *reinterpret_cast<const d2u*>(g + 128 * k);
+                    a[2 * k] = v.x;
+                    a[2 * k + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int i = i0 + 128 * k;
+                    a[2 * k] = (i < m) ? g[128 * k] : 0.0;
+                    a[2 * k + 1] = (i + 1 < m) ? g[128 * k + 1] : 0.0;
+                }
+            }
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                y[2 * k] = fma(a[2 * k], xj, y[2 * k]);
+                y[2 * k + 1] = fma(a[2 * k + 1], xj, y[2 * k + 1]);
+                d0 = fma(a[2 * k], zr[2 * k], d0);
+                d1 = fma(a[2 * k + 1], zr[2 * k + 1], d1);
+            }
+            const double d = wave_sum(d0 + d1);
+            if (lane == 0) dots[j - blockIdx.x * NT_COLS] += d;          // (row blocks in order: a fixed summation order)
+        }
+        // the four waves' G x of this row block -> one partial row per workgroup
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            ylds[w][2 * lane + 128 * k] = y[2 * k];
+            ylds[w][2 * lane + 128 * k + 1] = y[2 * k + 1];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int il = tid + 256 * r;
+            if (rb + il < m)
+                partial[(int64_t)blockIdx.x * m + rb + il] = (ylds[0][il] + ylds[1][il]) + (ylds[2][il] + ylds[3][il]);
+        }
+        __syncthreads();
+    }
+    if (tid < NT_COLS && blockIdx.x * NT_COLS + tid < n) GTz[blockIdx.x * NT_COLS + tid] = dots[tid];
+}
+
+size_t gemv_nt_work_doubles(int m, int n) {
+    const size_t nchunks = (size_t)((n + NT_COLS - 1) / NT_COLS);
+    return (nchunks ? nchunks : 1) * (size_t)(m > 0 ? m : 1);
+}
+
+// Gx := G x,  GTz := G' z  (both overwritten).  work: >= gemv_nt_work_doubles(m, n) doubles per problem.
+int launch_gemv_nt_fused(const double* G, int64_t ldg, int m, int n, const double* x, const double* z, double* Gx, double* GTz,
+                         double* work, hipStream_t st, int nbatch, int64_t sG) {
+    if (m <= 0 || n <= 0) return 0;
+    const int nchunks = (n + NT_COLS - 1) / NT_COLS;
+    hipLaunchKernelGGL(gemv_nt_fused_kernel, dim3(nchunks, 1, nbatch), dim3(256), 0, st, G, ldg, m, n, x, z, work, GTz, sG);
+    KKT_HIP_CHECK(hipGetLastError());
+    hipLaunchKernelGGL(gemv_n_finish_kernel, dim3((m + 255) / 256, 1, nbatch), dim3(256), 0, st, work, nchunks, m, nullptr, Gx, Gx,
+                       1.0, 0.0);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+// ===================================================================================================
 // Triangular solves with the Cholesky factor, blocked by 128; the 128x128 diagonal solve runs inside
 // ONE wave (lane = row, x_j broadcast with readlane, no LDS, no barriers) in two 64-row halves.
 // ===================================================================================================

@@ -1409,7 +1409,7 @@ int mi355kkt_batch_create_eq(mi355kkt_batch** out, int device, int nbatch, int n
     if ((rc = alloc(&b->dx, B * N))) return fail(rc);
     if ((rc = alloc(&b->dz, B * M))) return fail(rc);
     if ((rc = alloc(&b->dzs, B * M))) return fail(rc);
-    if ((rc = alloc(&b->dwork, B * dmax(gemv_work_doubles(ml, n), gemv_work_doubles(n, n))))) return fail(rc);
+    if ((rc = alloc(&b->dwork, B * dmax(dmax(gemv_work_doubles(ml, n), gemv_work_doubles(n, n)), gemv_nt_work_doubles(ml, n))))) return fail(rc);
     if ((rc = alloc(&b->dt1, B * dmax(N, M)))) return fail(rc);
     if ((rc = alloc(&b->dt2, B * dmax(N, M)))) return fail(rc);
     if ((rc = potrf_work_init_batched(b->pw, nbatch))) return fail(rc);
@@ -1540,6 +1540,13 @@ int mi355kkt_batch_products(mi355kkt_batch* b, const double* x, const double* z,
         if (z && M) { KKT_HIP_CHECK(hipMemcpyAsync(b->dz, z, sizeof(double) * B * M, hipMemcpyHostToDevice, b->st)); dz = b->dz; }
     }
     auto out_dev = [&](double* user, double* scratch) { return is_device ? user : scratch; };
+    // both residual products of an interior-point iteration in one pass over G (device-resident callers); $MI355KKT_BATCH_FUSED_PRODUCTS=0: two passes
+    static const bool fused_ok = !(getenv("MI355KKT_BATCH_FUSED_PRODUCTS") && atoi(getenv("MI355KKT_BATCH_FUSED_PRODUCTS")) == 0);
+    if (fused_ok && is_device && Gx && GTz && M && N && dx && dz) {
+        if (int e = launch_gemv_nt_fused(b->dG, (int64_t)M, b->ml, b->n, dx, dz, Gx, GTz, b->dwork, b->st, b->nbatch, sG)) return e;
+        Gx = nullptr;
+        GTz = nullptr;
+    }
     if (Gx && M) {
         double* o = out_dev(Gx, b->dzs);
         if (int e = launch_gemv_n_scaled(b->dG, (int64_t)M, b->ml, b->n, nullptr, dx, o, o, 1.0, 0.0, b->dwork, b->st, b->nbatch, sG)) return e;

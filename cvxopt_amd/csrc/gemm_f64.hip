@@ -12,6 +12,7 @@
 // MFMA operand roles are chosen so that the D layout (col = lane&15) runs along C's contiguous (row)
 // dimension: A-operand <- C-column block (J), B-operand <- C-row block (I).
 #include "kkt_common.h"
+#include <type_traits>
 
 #include <algorithm>
 #include <cmath>
@@ -27,7 +28,7 @@ struct __attribute__((aligned(8))) d2u { double x, y; };   // 8-byte aligned pai
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 __device__ int g_syrk_skip = 0;   // developer ablation switch (bit0 no global fetch, bit1 no LDS stash, bit2 no barrier, bit4 no static priority,
-                                  // bit5 diagonal tiles through the general path); 0 in production
+                                  // bit5 long diagonal tiles through the general path, bit6 no block masks on diagonal tiles there); 0 in production
 int set_syrk_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_syrk_skip), &v, sizeof(int)) == hipSuccess ? 0 : -2; }
 
 // ---------------------------------------------------------------------------------------------------
@@ -91,6 +92,9 @@ __device__ __forceinline__ void tn_store(double* __restrict__ Xs, int sc, int sk
     }
 }
 
+// DMASK: diagonal tiles of short contractions run the pipelined loop with block masks (see there); <false> is the kernel of the
+// long contractions (their diagonal tiles take the nine-blocks-per-wave path) with no trace of the masks in its code
+template <bool DMASK>
 __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
     const double* __restrict__ G, int64_t ldg, const double* __restrict__ di, int n, int fast_ok,
     const SyrkItem* __restrict__ items, double* __restrict__ C, int64_t ldc,
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
         if (P) P += bz * bs.d;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wj = wave >> 1, wi = wave & 1;
+    int wj = wave >> 1, wi = wave & 1;
     const int i0 = it.ti * TILE, j0 = it.tj * TILE;
     const bool diag = (it.ti == it.tj);
     const int sc = tid >> 3, sk = (tid & 7) * 2;
@@ -226,6 +230,23 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
         // half"): one s_setprio for the whole main loop, no per-phase flips.  Measured on the n = 8192, m = 16384 SYRK:
         // 17.20 -> 16.97 ms (all waves at priority 1, or alternate workgroups: no gain).  g_syrk_skip bit 4 switches it off.
         if (!no_prio && wave >= 2) __builtin_amdgcn_s_setprio(1);
+        // Diagonal tiles in THIS loop (round 3; short contractions -- the batched engine's K = 1024, where 4 of a problem's 10 tiles
+        // are diagonal -- and every diagonal tile when bit 5 of g_syrk_skip sends the long ones here too): of the four 64 x 64
+        // quadrants, (i-half 0, j-half 1) lies above the diagonal and the two diagonal ones need 10 of their 16 blocks.  The wave
+        // of the unused quadrant takes the j-blocks 2, 3 of quadrant (1, 0), its owner keeps j-blocks 0, 1 (8 blocks each); the
+        // diagonal quadrants skip the 6 blocks above the diagonal (10 blocks): 10 instead of 16 MFMAs per 4-deep k group on the
+        // critical wave.  All predicates are wave-uniform (scalar branches; MFMA ignores EXEC).  g_syrk_skip bit 6: off.
+        unsigned tmask = 0xFu;                 // the j-blocks (t) this wave computes
+        bool tri = false;                      // only blocks with i-block u >= j-block t
+        const bool dmask = DMASK && diag && it.slot < 0 && !((g_syrk_skip >> 6) & 1);
+        if (DMASK && dmask) {
+            const int w = __builtin_amdgcn_readfirstlane(wave);
+            if (w == 2) { wj = 0; wi = 1; tmask = 0xCu; }
+            else if (w == 1) tmask = 0x3u;
+            else tri = true;
+        }
+        auto main_loop = [&](auto DMc) {
+        constexpr bool DM = decltype(DMc)::value;
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             const bool has_next = kt + 1 < nkt;
@@ -251,8 +272,11 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    if (!DM || ((tmask >> t) & 1u)) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) acc[t][u] = MFMA_F64(a[pb][t], b[pb][u], acc[t][u]);
+                        for (int u = 0; u < 4; ++u)
+                            if (!DM || !tri || u >= t) acc[t][u] = MFMA_F64(a[pb][t], b[pb][u], acc[t][u]);
+                    }
                     const int q = (kk / 4) * 4 + t;          // quad index 0..15 (compile-time after unrolling)
                     if (has_next) {
                         if (q < 8) {
@@ -275,6 +299,30 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
             if (dp) dp += BK;
             __syncthreads();
         }
+        };
+        if (DMASK && dmask) {
+            main_loop(std::true_type{});
+            // epilogue of a masked diagonal tile: only the blocks this wave computed (i >= j sorts out the diagonal quadrants)
+            const int li = lane & 15, lq = lane >> 4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!((tmask >> t) & 1u)) continue;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = i0 + wi * 64 + u * 16 + li;
+                        const int j = j0 + wj * 64 + t * 16 + lq + 4 * r;
+                        if (i >= j) {                        // (tile_fast: the whole tile is inside the matrix)
+                            double v = acc[t][u][r];
+                            if (P) v += P[i + (int64_t)j * ldp];
+                            C[i + (int64_t)j * ldc] = v;
+                        }
+                    }
+            }
+            return;
+        }
+        main_loop(std::false_type{});
     } else {
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
@@ -673,7 +721,9 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
     if (plan.n == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_tn_kernel),
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_tn_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_tn_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
         attr_set = true;
     }
@@ -706,8 +756,16 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
         }
 #undef LAUNCH_DIRECT
     } else {
-        hipLaunchKernelGGL(syrk_tn_kernel, dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di, plan.n,
-                           fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs);
+        // diagonal tiles: contractions of 8192 rows and more take the nine-blocks-per-wave path inside the kernel; shorter ones (the
+        // batched engine: K = 1024, 4 of a problem's 10 tiles are diagonal) the block masks of the pipelined loop
+        if (plan.K >= 8192)
+            hipLaunchKernelGGL(syrk_tn_kernel<false>, dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di, plan.n,
+                               fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs);
+        else
+            // (work items dealt so that all tiles of a problem run on one XCD -- ids grouped by 8 problems -- were measured too:
+            //  +-1 %, the operand panels of a problem come from the Infinity Cache either way; not kept)
+            hipLaunchKernelGGL(syrk_tn_kernel<true>, dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di, plan.n,
+                               fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs);
     }
     KKT_HIP_CHECK(hipGetLastError());
     if (kernel_events) KKT_HIP_CHECK(hipEventRecord(kernel_events[1], st));

@@ -127,6 +127,10 @@ int launch_gemv_n_scaled(const double* G, int64_t ldg, int m, int n, const doubl
                          const double* x, const double* zs, double* z, double alpha, double beta,
                          double* work, hipStream_t st, int nbatch = 1, int64_t sG = 0);
 size_t gemv_work_doubles(int m, int n);
+// Gx := G x and GTz := G' z in one pass over G (blas2.hip); work: gemv_nt_work_doubles(m, n) doubles per problem
+int launch_gemv_nt_fused(const double* G, int64_t ldg, int m, int n, const double* x, const double* z, double* Gx, double* GTz,
+                         double* work, hipStream_t st, int nbatch = 1, int64_t sG = 0);
+size_t gemv_nt_work_doubles(int m, int n);
 // single right-hand side, single launch (needs ceil(n/128) co-resident workgroups: callers check against #CUs);
 // flags: ceil(n/128) words zeroed once at allocation, epoch: a fresh non-zero value per launch, err: device int
 // copies the strictly lower triangle, transposed, into the strictly upper triangle (needed by the transposed persistent solve)

@@ -22,6 +22,8 @@ def dev(capi, a):
     # plus one row, even / odd chunk counts with and without a remainder
     (5, 1, True, True), (70, 8, True, False), (130, 9, False, True), (70, 16, True, True), (70, 24, True, False),
     (260, 31, True, True), (140, 2, False, False),
+    # 33 x 33 tiles: 512 unsplit work items (diagonal tiles among them: block masks of the pipelined loop) + 49 split ones
+    (4224, 512, True, True), (4224, 256, False, False),
 ])
 def test_syrk_scaled_matches_numpy(capi, n, m, use_di, use_H):
     rng = np.random.default_rng(n * 7 + m)

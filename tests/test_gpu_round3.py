@@ -182,3 +182,33 @@ def test_ldl_flavour_at_late_iteration_scalings_against_the_reference_kkt_ldl(re
     # achieved (profiles/r03_parity_report.json): 2e-15 .. 5e-14 against the reference's 2e-13 .. 3e-13; x agrees to 3e-14 .. 1e-13
     assert res <= max(3e-13, 3.0 * res_ref), (res, res_ref)
     assert ex < 1e-10, ex
+
+
+@pytest.mark.parametrize("B,n,m", [(3, 64, 128), (2, 100, 1030), (4, 512, 1024), (2, 70, 2300), (1, 130, 61), (2, 33, 7), (1, 1, 1)])
+def test_batch_residual_products_in_one_pass_over_G(B, n, m):
+    """device-resident callers of mi355kkt_batch_products (the batched coneqp loop) get G x and G' z from ONE pass over G
+    (gemv_nt_fused_kernel): ragged row blocks (m not a multiple of 2 / 128 / 1024, several row blocks), column counts that are
+    not multiples of the 64 columns of a workgroup; against NumPy and against the two-pass host-pointer path of the same call."""
+    from cvxopt_amd.batch import BatchKkt
+    rng = np.random.default_rng(B * 1000 + n + m)
+    Gt = rng.standard_normal((B, n, m))                                 # Gt[b] = G_b' (row-major n x m == column-major m x n)
+    Bm = rng.standard_normal((B, n, n))
+    P = np.einsum('bij,bkj->bik', Bm, Bm)
+    k = BatchKkt(Gt, P)
+    x, z = rng.standard_normal((B, n)), rng.standard_normal((B, m))
+    dx, dz = _capi.DeviceBuffer.from_array(x), _capi.DeviceBuffer.from_array(z)
+    dGx, dGTz, dPx = _capi.DeviceBuffer(8 * B * m), _capi.DeviceBuffer(8 * B * n), _capi.DeviceBuffer(8 * B * n)
+    _capi.check(_capi.lib().mi355kkt_batch_products(k.h, dx.ptr, dz.ptr, dGx.ptr, dGTz.ptr, dPx.ptr, 1), "batch_products")
+    _capi.lib().mi355kkt_device_synchronize()
+    Gx = dGx.to_array((B, m), order="C")
+    GTz = dGTz.to_array((B, n), order="C")
+    Px = dPx.to_array((B, n), order="C")
+    Gx_ref = np.einsum('bnm,bn->bm', Gt, x)
+    GTz_ref = np.einsum('bnm,bm->bn', Gt, z)
+    sc_n = np.einsum('bnm,bn->bm', np.abs(Gt), np.abs(x)) + 1e-300
+    sc_t = np.einsum('bnm,bm->bn', np.abs(Gt), np.abs(z)) + 1e-300
+    assert np.max(np.abs(Gx - Gx_ref) / sc_n) < 2e-15 * max(8, n)
+    assert np.max(np.abs(GTz - GTz_ref) / sc_t) < 2e-15 * max(8, m)
+    Gx2, GTz2, Px2 = k.products(x, z)                                   # host pointers: the two-pass path
+    assert relerr(Gx, Gx2) < 1e-13 and relerr(GTz, GTz2) < 1e-13 and relerr(Px, Px2) < 1e-14
+    k.close()

@@ -8,7 +8,7 @@ import sys
 text = open(sys.argv[1]).read().split('\n')
 sub = sys.argv[2]
 start = next(i for i, l in enumerate(text) if re.match(r'^_Z\S*:', l) and sub in l)
-end = next(i for i in range(start, len(text)) if 's_endpgm' in text[i])
+end = next(i for i in range(start, len(text)) if text[i].startswith('.Lfunc_end'))   # (a kernel may hold several s_endpgm)
 lines = text[start:end + 1]
 print("kernel", lines[0][:100], "lines", len(lines))
 labels = {}
