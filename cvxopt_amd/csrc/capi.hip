@@ -1954,7 +1954,7 @@ static int sparse_products_cdim(mi355kkt_solver* hs, const double* xin, const do
 }
 // A xin -> Ax, A' yin -> ATy with the A of the handle (dense, or CSR/CSC in sparse mode)
 static int a_products(mi355kkt_solver* hs, const double* xin, const double* yin, double* Ax, double* ATy, double* gwork, hipStream_t st) {
-    const int n = hs->n, np = hs->p;
+    const int np = hs->p;
     if (np <= 0) return 0;
     if (int e = A_mul(hs, xin, Ax, gwork, st)) return e;
     return A_mulT(hs, yin, ATy, 0.0, gwork, st);

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(1024) void lp_step_kernel(LpState S, LpBuf D, int i
 
 __global__ __launch_bounds__(1024) void lp_update_kernel(LpState S, LpBuf D) {
     __shared__ double sh[16];
-    const int tid = threadIdx.x, m = S.m, n = S.n, p = S.p;
+    const int tid = threadIdx.x, n = S.n, p = S.p;
     if (!S.active[0]) return;
     double* sc = S.sc;
     const double step = sc[LP_STEP];

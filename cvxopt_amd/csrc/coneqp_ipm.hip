@@ -310,7 +310,7 @@ __global__ __launch_bounds__(1024) void qp_step_kernel(QpState S, QpBuf D, int i
 __global__ __launch_bounds__(1024) void qp_update_kernel(QpState S, QpBuf D) {
     qp_select(S, D); qp_select(S);
     __shared__ double sh[16];
-    const int tid = threadIdx.x, m = S.m;
+    const int tid = threadIdx.x;
     if (!S.active[0]) return;
     const double step = S.sc[QP_STEP];
     for (int i = tid; i < S.n; i += blockDim.x) S.x[i] += step * D.x[i];

@@ -709,7 +709,7 @@ __device__ __forceinline__ void tile_accumulate(d4 (&acc)[8], const double* __re
     // (four 16-deep steps in flight — 64 more registers — spill and measured slower: potrf(8192) 4.51 -> 5.19 ms)
     constexpr int TBK = TBKP;
     constexpr int PF = TBKP == 32 ? 1 : TILE_PF;              // k-steps of operands in flight (global -> registers); same depth in k
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
     const int li = lane & 15, lq = lane >> 4;
     const int ip = (tid & 63) * 2, kq = tid >> 6;            // staging: index pair, k = kq + 8 r
     constexpr int STG = TBK * LDT_M;                           // doubles per operand per stage

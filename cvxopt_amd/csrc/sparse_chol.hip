@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void sp_extend_add_vb_kernel(SpDev d, const Vb
     const VbDesc dd = vb[blockIdx.z];
     const int s = dd.pad;                      // supernode id
     const int h = dd.h;
-    const int c0 = blockIdx.x * EA_COLS, c1 = min(c0 + EA_COLS, h);
+    const int c0 = blockIdx.x * EA_COLS;
     const int r0 = blockIdx.y * EA_ROWS, r1 = min(r0 + EA_ROWS, h);
     if (c0 >= h || r0 >= h || r1 <= c0) return;            // outside the front / strictly above the diagonal
     double* __restrict__ F = store + dd.off;
