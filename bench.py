@@ -227,6 +227,26 @@ def cpu_batch(probs):
                       "%d interior-point iterations in %.2f s" % (len(probs), its, el)}
 
 
+_REAL_STDOUT = None
+
+
+def _quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries write to file descriptor 1 behind Python's back (RCCL prints a version
+    banner when the first communicator is created): from here on fd 1 is stderr, the result line goes to a duplicate of the
+    original stdout (`_emit`)."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    f = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    f.write(line + "\n")
+    f.flush()
+
+
 def _dist_setup(dry=False):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -346,7 +366,7 @@ def main_batch(args):
     rank, world, local_rank, torch, dist = _dist_setup()
     out = measure_batch(args, rank, world, local_rank, torch, dist, cpu=(not args.no_cpu_baseline and world == 1))
     if rank == 0:
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -528,7 +548,7 @@ def main_sharded(args):
                 out["speedup_vs_1gpu"] = round((1e3 * t1) / ms, 3)
             except Exception as e:
                 out["single_gpu_reference"] = {"error": repr(e)}
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -616,7 +636,7 @@ def main_sparse(args):
     rank, world, local_rank, torch, dist = _dist_setup()
     out = measure_sparse(args, rank, world, local_rank, torch, dist, cpu=(not args.no_cpu_baseline and world == 1))
     if rank == 0:
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -709,7 +729,7 @@ def main_socp(args):
     rank, world, local_rank, torch, dist = _dist_setup()
     out = measure_socp(args, rank, world, local_rank, torch, dist, cpu=(not args.no_cpu_baseline and world == 1))
     if rank == 0:
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -744,7 +764,7 @@ def main_sdp(args):
         its += sol['iterations']
     t = time.perf_counter() - t
     if rank == 0:
-        print(json.dumps({
+        _emit(json.dumps({
             "metric": "SDP interior-point iterations/s, device-resident conelp loop ('s' cone, order %d)" % m,
             "value": round(world * its / t, 3), "unit": "IPM iterations/s", "n_gpus": world, "steps": its, "warmup": args.warmup,
             "ms_per_step": round(1e3 * t / its, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -768,6 +788,7 @@ def main():
                                  "(reported as dry_run, value null)\n" % args.gpus)
                 sys.argv.append("--dry-run")
         sys.exit(_respawn(args))
+    _quiet_stdout()
     if args.workload == "auto":
         args.workload = "sharded" if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.dry_run) else "dense"
     if args.workload == "sharded":
@@ -979,7 +1000,7 @@ def main():
                 if isinstance(side[name], dict):
                     side[name]["wall_s"] = round(time.perf_counter() - t1, 2)
             out["side_workloads"] = side
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -14,11 +14,57 @@ def pytest_configure(config):
 
 
 def _gpu_count():
+    if os.environ.get("MI355KKT_TEST_ASSUME_GPU") == "1":      # exercises the GPU-session hooks below on a CPU host
+        return 1
     try:
         from cvxopt_amd import _capi
         return _capi.device_count()
     except Exception:
         return 0
+
+
+# ---- GPU sessions: a trace of the test that is running, and an exit that skips the runtimes' teardown -------------------
+# Round 3: one of four full `-m gpu` runs on the GPU boxes ended in a core dump of the pytest process although the same
+# tree had passed before and passed after (tools/calls/c23_last.sh).  (a) The test that is running is written to
+# gpurun_out/pytest_last_test.txt ($MI355KKT_TEST_TRACE) before it starts, so a crash names its test.  (b) After the
+# summary has been printed a session that touched the GPU leaves with os._exit: torch's HIP runtime, the HSA runtime's
+# helper threads, MKL (the in-process reference of the parity tests) and this library all unload at interpreter exit, in an
+# order nobody controls; a crash THERE would turn a green run into a failed one.
+_TRACE_PATH = os.environ.get("MI355KKT_TEST_TRACE", os.path.join(ROOT, "gpurun_out", "pytest_last_test.txt"))
+_session = {"gpu": False, "status": None, "trace_ok": None}
+
+
+def pytest_runtest_logstart(nodeid, location):
+    if _session["trace_ok"] is False or _gpu_count() <= 0:
+        return
+    _session["gpu"] = True
+    try:
+        if _session["trace_ok"] is None:
+            os.makedirs(os.path.dirname(_TRACE_PATH), exist_ok=True)
+        with open(_TRACE_PATH, "w") as f:
+            f.write(nodeid + "\n")
+        _session["trace_ok"] = True
+    except OSError:
+        _session["trace_ok"] = False
+
+
+def pytest_sessionfinish(session, exitstatus):
+    _session["status"] = int(exitstatus)
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_unconfigure(config):
+    if not _session["gpu"] or _session["status"] is None or os.environ.get("MI355KKT_TEST_NORMAL_EXIT", "0") == "1":
+        return
+    try:
+        if _session["trace_ok"]:
+            with open(_TRACE_PATH, "w") as f:
+                f.write("session finished with exit status %d\n" % _session["status"])
+    except OSError:
+        pass
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(_session["status"])
 
 
 def pytest_collection_modifyitems(config, items):
