@@ -23,15 +23,16 @@ def _gpu_count():
         return 0
 
 
-# ---- GPU sessions: a trace of the test that is running, and an exit that skips the runtimes' teardown -------------------
+# ---- GPU sessions: a trace of the test that is running, and an orderly release of device objects before interpreter exit ----
 # Round 3: one of four full `-m gpu` runs on the GPU boxes ended in a core dump of the pytest process although the same
-# tree had passed before and passed after (tools/calls/c23_last.sh).  (a) The test that is running is written to
-# gpurun_out/pytest_last_test.txt ($MI355KKT_TEST_TRACE) before it starts, so a crash names its test.  (b) After the
-# summary has been printed a session that touched the GPU leaves with os._exit: torch's HIP runtime, the HSA runtime's
-# helper threads, MKL (the in-process reference of the parity tests) and this library all unload at interpreter exit, in an
-# order nobody controls; a crash THERE would turn a green run into a failed one.
+# tree had passed before and passed after (tools/calls/c23_last.sh; the log kept only its last lines, the place is unknown).
+# (a) The test that is running is written to gpurun_out/pytest_last_test.txt ($MI355KKT_TEST_TRACE) before it starts, so a
+# crash names its test.  (b) When the session is over, every engine / device buffer still referenced by test modules is
+# collected and the device is drained while the library, torch's HIP runtime and MKL (the in-process reference of the parity
+# tests) are all still loaded -- not in whatever order interpreter finalisation picks.  The process then exits NORMALLY
+# (atexit handlers run).
 _TRACE_PATH = os.environ.get("MI355KKT_TEST_TRACE", os.path.join(ROOT, "gpurun_out", "pytest_last_test.txt"))
-_session = {"gpu": False, "status": None, "trace_ok": None}
+_session = {"gpu": False, "trace_ok": None}
 
 
 def pytest_runtest_logstart(nodeid, location):
@@ -49,22 +50,24 @@ def pytest_runtest_logstart(nodeid, location):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    _session["status"] = int(exitstatus)
-
-
-@pytest.hookimpl(trylast=True)
-def pytest_unconfigure(config):
-    if not _session["gpu"] or _session["status"] is None or os.environ.get("MI355KKT_TEST_NORMAL_EXIT", "0") == "1":
+    if not _session["gpu"]:
         return
     try:
         if _session["trace_ok"]:
             with open(_TRACE_PATH, "w") as f:
-                f.write("session finished with exit status %d\n" % _session["status"])
+                f.write("session finished with exit status %d\n" % int(exitstatus))
     except OSError:
         pass
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(_session["status"])
+    import gc
+    gc.collect()
+    try:
+        from cvxopt_amd import _capi
+        if os.environ.get("MI355KKT_TEST_ASSUME_GPU") != "1":
+            _capi.lib().mi355kkt_device_synchronize()
+        if "torch" in sys.modules and sys.modules["torch"].cuda.is_available():
+            sys.modules["torch"].cuda.synchronize()
+    except Exception:
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
