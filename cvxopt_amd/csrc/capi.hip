@@ -1020,7 +1020,10 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
         const size_t N = (size_t)h->n;
         // all or nothing: dS doubles as the "dense state exists" flag, so it is set last
         double *newS = nullptr, *newwork = nullptr;
-        const size_t work_doubles = dmax(dmax(gemv_work_doubles(h->cdim, h->n), gemv_work_doubles(h->n, h->p)), (size_t)h->cdim + 8);
+        // (p x n products with A -- the refinement of the ldl flavours computes by - A ux with this workspace -- need ceil(n / 256) * p:
+        //  more than either of the first two when p is large, the cone rows few and n > 256)
+        const size_t work_doubles = dmax(dmax(dmax(gemv_work_doubles(h->cdim, h->n), gemv_work_doubles(h->n, h->p)),
+                                              gemv_work_doubles(h->p, h->n)), (size_t)h->cdim + 8);
         if (hipMalloc(&newS, sizeof(double) * dmax(N * N, 1)) != hipSuccess ||
             hipMalloc(&newwork, sizeof(double) * work_doubles) != hipSuccess) {
             if (newS) (void)hipFree(newS);

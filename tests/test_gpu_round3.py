@@ -212,3 +212,23 @@ def test_batch_residual_products_in_one_pass_over_G(B, n, m):
     Gx2, GTz2, Px2 = k.products(x, z)                                   # host pointers: the two-pass path
     assert relerr(Gx, Gx2) < 1e-13 and relerr(GTz, GTz2) < 1e-13 and relerr(Px, Px2) < 1e-14
     k.close()
+
+
+def test_ldl_refinement_with_many_equalities_and_few_cone_rows():
+    """n > 256, p large, few inequality rows: the product by - A ux of the refinement step needs ceil(n / 256) * p doubles of GEMV
+    workspace -- more than the products with G and with L^-1 A' the buffer was sized for (found by review: 400 > 300 here)."""
+    n, m, p = 300, 10, 200
+    pr = synth.dense_qp(n, m, seed=77, p=p)
+    W = synth.random_scaling(pr['dims'], seed=9, spread=1.0)
+    rng = np.random.default_rng(4)
+    bx, by, bz = rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)
+    oracle = ko.KktChol2(pr['G'], pr['dims'], pr['A'])
+    xo, yo, zo = bx.copy(), by.copy(), bz.copy()
+    oracle.factor(W, pr['P'])(xo, yo, zo)
+    for kind in (kkt.kkt_ldl, kkt.kkt_ldl2, kkt.kkt_chol):
+        f = kkt_f = kind(pr['G'], pr['dims'], pr['A'])
+        for _ in range(2):
+            x, y, z = bx.copy(), by.copy(), bz.copy()
+            f(W, pr['P'])(x, y, z)
+            assert relerr(x, xo) < 1e-9 and relerr(y, yo) < 1e-8 and relerr(z, zo) < 1e-9
+        kkt_f.engine.close()
