@@ -117,6 +117,7 @@ SIGNATURES = {
     "mi355kkt_debug_tile_ts": (C.c_int, [C.c_void_p]),
     "mi355kkt_debug_trsvz_ts": (C.c_int, [C.c_void_p]),
     "mi355kkt_debug_syrk_skip": (C.c_int, [C.c_int]),
+    "mi355kkt_debug_throw": (C.c_int, [C.c_int]),
     "mi355kkt_op_mfma_f64_peak": (C.c_int, [C.c_int, c_float_p]),
     "mi355kkt_op_potrf": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_int_p, c_float_p]),
     "mi355kkt_op_trsm_lower": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int,

@@ -14,6 +14,8 @@
 #include <cstdarg>
 #include <cstdlib>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 
 #include "../../include/mi355kkt.h"
 #include "kkt_common.h"
@@ -31,6 +33,24 @@ void set_last_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+// No C++ exception may cross the C ABI (an uncaught std::bad_alloc from a host-side std::vector, a std::system_error ... would
+// std::terminate the caller's process -- the Python interpreter).  Every non-trivial entry point below is a function-try-block
+// that ends here: the exception becomes an error code and a message for mi355kkt_last_error().
+int kkt_catch(const char* what) noexcept {
+    try {
+        throw;
+    } catch (const std::bad_alloc&) {
+        set_last_error("%s: out of host memory", what);
+        return MI355KKT_ENOMEM;
+    } catch (const std::exception& e) {
+        set_last_error("%s: C++ exception: %s", what, e.what());
+        return MI355KKT_EHIP;
+    } catch (...) {
+        set_last_error("%s: unknown C++ exception", what);
+        return MI355KKT_EHIP;
+    }
 }
 
 // ---- tiny element-wise helpers -------------------------------------------------------------------
@@ -415,13 +435,13 @@ extern "C" {
 int mi355kkt_version(void) { return 100; }
 const char* mi355kkt_last_error(void) { return g_err; }
 
-int mi355kkt_device_count(void) {
+int mi355kkt_device_count(void) try {
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess) return 0;
     return c;
-}
+} catch (...) { return kkt_catch("mi355kkt_device_count"); }
 
-int mi355kkt_device_info(int device, char* name, int len, int* num_cus, size_t* mem_bytes) {
+int mi355kkt_device_info(int device, char* name, int len, int* num_cus, size_t* mem_bytes) try {
     hipDeviceProp_t prop;
     KKT_HIP_CHECK(hipGetDeviceProperties(&prop, device));
     if (name && len > 0) {
@@ -430,37 +450,37 @@ int mi355kkt_device_info(int device, char* name, int len, int* num_cus, size_t* 
     if (num_cus) *num_cus = prop.multiProcessorCount;
     if (mem_bytes) *mem_bytes = prop.totalGlobalMem;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_device_info"); }
 
-int mi355kkt_dev_malloc(void** ptr, size_t bytes) {
+int mi355kkt_dev_malloc(void** ptr, size_t bytes) try {
     KKT_HIP_CHECK(hipMalloc(ptr, bytes ? bytes : 8));
     return 0;
-}
-int mi355kkt_dev_free(void* ptr) {
+} catch (...) { return kkt_catch("mi355kkt_dev_malloc"); }
+int mi355kkt_dev_free(void* ptr) try {
     if (ptr) KKT_HIP_CHECK(hipFree(ptr));
     return 0;
-}
-int mi355kkt_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+} catch (...) { return kkt_catch("mi355kkt_dev_free"); }
+int mi355kkt_memcpy_h2d(void* dst, const void* src, size_t bytes) try {
     if (bytes) KKT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
-}
-int mi355kkt_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+} catch (...) { return kkt_catch("mi355kkt_memcpy_h2d"); }
+int mi355kkt_memcpy_d2h(void* dst, const void* src, size_t bytes) try {
     if (bytes) KKT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return 0;
-}
-int mi355kkt_memcpy_d2d(void* dst, const void* src, size_t bytes) {
+} catch (...) { return kkt_catch("mi355kkt_memcpy_d2h"); }
+int mi355kkt_memcpy_d2d(void* dst, const void* src, size_t bytes) try {
     if (bytes) KKT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
     return 0;
-}
-int mi355kkt_device_synchronize(void) {
+} catch (...) { return kkt_catch("mi355kkt_memcpy_d2d"); }
+int mi355kkt_device_synchronize(void) try {
     KKT_HIP_CHECK(hipDeviceSynchronize());
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_device_synchronize"); }
 
 static size_t dmax(size_t a, size_t b) { return a > b ? a : b; }
 
 int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, int ml, int nq, const int* q, int ns,
-                    const int* s) {
+                    const int* s) try {
     if (!out || n < 0 || p < 0 || ml < 0 || nq < 0 || ns < 0 || kind < 0 || kind > 3) {
         set_last_error("mi355kkt_create: invalid argument");
         return MI355KKT_EINVAL;
@@ -554,12 +574,12 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     }
     *out = h;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_create"); }
 
 static void h_unregister(mi355kkt_solver* h);
 static int ensure_hsym(mi355kkt_solver* hs);
 static int ensure_gemv_work(mi355kkt_solver* hs);
-void mi355kkt_destroy(mi355kkt_solver* h) {
+void mi355kkt_destroy(mi355kkt_solver* h) try {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->st) (void)hipStreamSynchronize(h->st);
@@ -597,7 +617,7 @@ void mi355kkt_destroy(mi355kkt_solver* h) {
         if (e) (void)hipEventDestroy(e);
     if (h->st) (void)hipStreamDestroy(h->st);
     delete h;
-}
+} catch (...) { (void)kkt_catch("mi355kkt_destroy"); }
 
 static int upload_dense(double** owned, const double* src, int64_t ld, int rows, int cols, hipStream_t st) {
     if (*owned) { (void)hipFree(*owned); *owned = nullptr; }
@@ -609,7 +629,7 @@ static int upload_dense(double** owned, const double* src, int64_t ld, int rows,
     return 0;
 }
 
-int mi355kkt_set_G_dense(mi355kkt_solver* h, const double* G, int64_t ldG) {
+int mi355kkt_set_G_dense(mi355kkt_solver* h, const double* G, int64_t ldG) try {
     if (!h || (!G && h->cdim > 0 && h->n > 0) || ldG < (h->cdim > 1 ? h->cdim : 1)) {
         set_last_error("set_G_dense: invalid argument");
         return MI355KKT_EINVAL;
@@ -619,12 +639,12 @@ int mi355kkt_set_G_dense(mi355kkt_solver* h, const double* G, int64_t ldG) {
     h->dG = h->G_owned;
     h->ldG = h->cdim > 1 ? h->cdim : 1;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_set_G_dense"); }
 
 /* Overwrites rows [row0, row0 + nrows) of the dense G held by the handle (host source, column-major, ld = ldsrc): the
  * Jacobian block Df of the nonlinear constraints that cvxprog.cp / cpl prepend to G at every iteration
  * (misc.py:1265-1266 `Gs[:mnl,:] = Df`). */
-int mi355kkt_set_G_rows(mi355kkt_solver* h, int row0, int nrows, const double* src, int64_t ldsrc) {
+int mi355kkt_set_G_rows(mi355kkt_solver* h, int row0, int nrows, const double* src, int64_t ldsrc) try {
     if (!h || nrows < 0 || row0 < 0 || row0 + nrows > h->cdim || (nrows > 0 && (!src || ldsrc < nrows))) {
         set_last_error("set_G_rows: invalid argument");
         return MI355KKT_EINVAL;
@@ -635,9 +655,9 @@ int mi355kkt_set_G_rows(mi355kkt_solver* h, int row0, int nrows, const double* s
         KKT_HIP_CHECK(hipMemcpy2D(h->G_owned + row0, sizeof(double) * h->ldG, src, sizeof(double) * ldsrc, sizeof(double) * nrows,
                                   h->n, hipMemcpyHostToDevice));
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_set_G_rows"); }
 
-int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t* rowind, const double* values) {
+int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t* rowind, const double* values) try {
     if (!h || !colptr) { set_last_error("set_G_csc: invalid argument"); return MI355KKT_EINVAL; }
     std::vector<double> dense((size_t)h->cdim * h->n, 0.0);
     for (int j = 0; j < h->n; ++j)
@@ -646,11 +666,11 @@ int mi355kkt_set_G_csc(mi355kkt_solver* h, const int64_t* colptr, const int64_t*
             dense[(size_t)j * h->cdim + rowind[k]] += values[k];
         }
     return mi355kkt_set_G_dense(h, dense.data(), h->cdim > 1 ? h->cdim : 1);
-}
+} catch (...) { return kkt_catch("mi355kkt_set_G_csc"); }
 
 /* A (p x n) in CSR: rowptr[p + 1], colind[nnz] (int64, like the CCS arrays of cvxopt), values[nnz].  The handle keeps A sparse
  * on the device (CSR + its transpose) -- reference misc.py:1483-1487 / cholmod.spsolve keep A' sparse too.  Sparse engine only. */
-int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr_in, const int64_t* colind_in, const double* values_in) {
+int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr_in, const int64_t* colind_in, const double* values_in) try {
     if (!h || (h->p > 0 && !rowptr_in)) { set_last_error("set_A_csr: null argument"); return MI355KKT_EINVAL; }
     const int p = h->p, n = h->n;
     if (p == 0) { h->A_sparse = true; return 0; }
@@ -724,14 +744,14 @@ int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr_in, const int64
     h->A_sparse = true;
     h->dA = nullptr;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_set_A_csr"); }
 
 /* set_sparse_problem whose G carries `extra_rows` more rows below the cdim cone rows: the rows of A with unit scaling, i.e.
  * S = H + G'D^2 G + A'A -- the reference's fallback for a singular S on the first factorisation (misc.py:1433-1447), which in
  * sparse mode needs a new symbolic analysis because the pattern of S grows.  The handle is in "singular" mode afterwards
  * (solve() adds A'by to bx, misc.py:1527).  extra_rows is 0 or p. */
 int mi355kkt_set_sparse_problem_aug(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
-                                    const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues, int extra_rows) {
+                                    const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues, int extra_rows) try {
     if (!h || !gcolptr) { set_last_error("set_sparse_problem: null argument"); return MI355KKT_EINVAL; }
     if (extra_rows != 0 && extra_rows != h->p) { set_last_error("set_sparse_problem_aug: extra_rows must be 0 or p"); return MI355KKT_EINVAL; }
     if (!h->q.empty() || !h->s.empty()) {
@@ -751,28 +771,28 @@ int mi355kkt_set_sparse_problem_aug(mi355kkt_solver* h, const int64_t* gcolptr, 
     h->singular = extra_rows > 0;
     h->factored = false;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_set_sparse_problem_aug"); }
 
 int mi355kkt_set_sparse_problem(mi355kkt_solver* h, const int64_t* gcolptr, const int64_t* growind, const double* gvalues,
-                                const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues) {
+                                const int64_t* hcolptr, const int64_t* hrowind, const double* hvalues) try {
     return mi355kkt_set_sparse_problem_aug(h, gcolptr, growind, gvalues, hcolptr, hrowind, hvalues, 0);
-}
-int mi355kkt_sparse_stats(const mi355kkt_solver* h, int64_t* nnzL, int* nsupernodes, int* nlevels, double* flops) {
+} catch (...) { return kkt_catch("mi355kkt_set_sparse_problem"); }
+int mi355kkt_sparse_stats(const mi355kkt_solver* h, int64_t* nnzL, int* nsupernodes, int* nlevels, double* flops) try {
     if (!h || !h->sparse) return MI355KKT_EINVAL;
     if (nnzL) *nnzL = h->sp.sym.nnzL;
     if (nsupernodes) *nsupernodes = h->sp.sym.ns;
     if (nlevels) *nlevels = h->sp.sym.nlevels;
     if (flops) *flops = h->sp.sym.flops;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_sparse_stats"); }
 
 /* which fill-reducing ordering the symbolic analysis chose: 1 nested dissection, 2 approximate minimum degree */
-int mi355kkt_sparse_ordering(const mi355kkt_solver* h) {
+int mi355kkt_sparse_ordering(const mi355kkt_solver* h) try {
     if (!h || !h->sparse) return MI355KKT_EINVAL;
     return h->sp.sym.order_method;
-}
+} catch (...) { return kkt_catch("mi355kkt_sparse_ordering"); }
 
-int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA) {
+int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA) try {
     if (!h || (!A && h->p > 0 && h->n > 0) || ldA < (h->p > 1 ? h->p : 1)) {
         set_last_error("set_A_dense: invalid argument");
         return MI355KKT_EINVAL;
@@ -782,22 +802,22 @@ int mi355kkt_set_A_dense(mi355kkt_solver* h, const double* A, int64_t ldA) {
     h->dA = h->A_owned;
     h->ldA = h->p > 1 ? h->p : 1;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_set_A_dense"); }
 
-int mi355kkt_set_G_device(mi355kkt_solver* h, const double* dG, int64_t ldG) {
+int mi355kkt_set_G_device(mi355kkt_solver* h, const double* dG, int64_t ldG) try {
     if (!h || ldG < (h->cdim > 1 ? h->cdim : 1)) { set_last_error("set_G_device: invalid argument"); return MI355KKT_EINVAL; }
     h->dG = dG;
     h->ldG = ldG;
     return 0;
-}
-int mi355kkt_set_A_device(mi355kkt_solver* h, const double* dA, int64_t ldA) {
+} catch (...) { return kkt_catch("mi355kkt_set_G_device"); }
+int mi355kkt_set_A_device(mi355kkt_solver* h, const double* dA, int64_t ldA) try {
     if (!h || ldA < (h->p > 1 ? h->p : 1)) { set_last_error("set_A_device: invalid argument"); return MI355KKT_EINVAL; }
     h->dA = dA;
     h->ldA = ldA;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_set_A_device"); }
 
-int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) {
+int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) try {
     if (!h) return MI355KKT_EINVAL;
     if (int e = bind(h)) return e;
     h->hsym_valid = false;
@@ -818,7 +838,7 @@ int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) {
     h->dH = h->H_owned;
     h->ldH = h->n > 1 ? h->n : 1;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_set_H_dense"); }
 static void h_unregister(mi355kkt_solver* h) {
     if (h->reg_ptr) {
         if (h->cst) (void)hipStreamSynchronize(h->cst);
@@ -831,7 +851,7 @@ static void h_unregister(mi355kkt_solver* h) {
  * (hipHostRegister, cached while the same buffer is passed again) and the NEXT factor() only waits for it after the
  * scaled SYRK: S = Gs'Gs runs while H crosses PCIe, then S += tril(H).  The caller keeps H alive and unmodified until
  * that factor() returns, and alive until the next set_H_* call or destroy (the Python mirror holds a reference). */
-int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH) {
+int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH) try {
     if (!h) return MI355KKT_EINVAL;
     if (!H || h->n == 0) { h_unregister(h); h->h_pending = false; return mi355kkt_set_H_dense(h, H, ldH); }
     if (int e = bind(h)) return e;
@@ -859,8 +879,8 @@ int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH)
     h->hsym_valid = false;
     h->h_pending = true;
     return 0;
-}
-int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH) {
+} catch (...) { return kkt_catch("mi355kkt_set_H_dense_async"); }
+int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH) try {
     if (!h) return MI355KKT_EINVAL;
     if (h->h_pending && h->cst) (void)hipStreamSynchronize(h->cst);
     h->h_pending = false;
@@ -869,18 +889,18 @@ int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH) {
     h->ldH = ldH;
     h->hsym_valid = false;
     return 0;
-}
-int mi355kkt_set_progress(mi355kkt_solver* h, mi355kkt_progress_fn fn, void* user) {
+} catch (...) { return kkt_catch("mi355kkt_set_H_device"); }
+int mi355kkt_set_progress(mi355kkt_solver* h, mi355kkt_progress_fn fn, void* user) try {
     if (!h) return MI355KKT_EINVAL;
     h->progress = fn;
     h->progress_user = user;
     return 0;
-}
-int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg) {
+} catch (...) { return kkt_catch("mi355kkt_set_progress"); }
+int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg) try {
     if (!h || !(reg >= 0.0)) { set_last_error("set_kktreg: reg must be >= 0"); return MI355KKT_EINVAL; }
     h->kktreg = reg;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_set_kktreg"); }
 
 // info word -> host (synchronises the stream)
 static int fetch_info(mi355kkt_solver* h, int* info) {
@@ -969,7 +989,7 @@ static int assemble_S(mi355kkt_solver* h, bool add_AtA) {
     return 0;
 }
 
-int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
+int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
     if (!h || !W) { set_last_error("factor: null argument"); return MI355KKT_EINVAL; }
     if (!h->s.empty() && !W->rti) { set_last_error("factor: W.rti missing"); return MI355KKT_EINVAL; }
     if (h->ml > 0 && !W->di) { set_last_error("factor: W.di missing"); return MI355KKT_EINVAL; }
@@ -1113,9 +1133,9 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     if (info > 0) return info;
     h->factored = true;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_factor_device"); }
 
-int mi355kkt_factor(mi355kkt_solver* h, const mi355kkt_scaling* W) {
+int mi355kkt_factor(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
     if (!h || !W) { set_last_error("factor: null argument"); return MI355KKT_EINVAL; }
     if (h->ml > 0 && !W->di) { set_last_error("factor: W.di missing"); return MI355KKT_EINVAL; }
     if (int e = bind(h)) return e;
@@ -1138,9 +1158,9 @@ int mi355kkt_factor(mi355kkt_solver* h, const mi355kkt_scaling* W) {
     }
     if (rlen) Wd.rti = h->dWst + ml + vlen + nq;
     return mi355kkt_factor_device(h, &Wd);
-}
+} catch (...) { return kkt_catch("mi355kkt_factor"); }
 
-int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz) {
+int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz) try {
     if (!h) return MI355KKT_EINVAL;
     if (!h->factored) { set_last_error("solve: no valid factorisation"); return MI355KKT_EINVAL; }
     if (int e = bind(h)) return e;
@@ -1274,7 +1294,7 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     }
     KKT_HIP_CHECK(hipEventRecord(h->ev[5], st));
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_solve_device"); }
 
 static int check_handoff(mi355kkt_solver* h) {   // stream must be idle
     if (*h->herr) {
@@ -1294,14 +1314,14 @@ static int loop_check_handoff(mi355kkt_solver* h) {
     return check_handoff(h);
 }
 
-int mi355kkt_sync(mi355kkt_solver* h) {
+int mi355kkt_sync(mi355kkt_solver* h) try {
     if (!h) return MI355KKT_EINVAL;
     KKT_HIP_CHECK(hipMemcpyAsync(h->herr, h->derr, sizeof(int), hipMemcpyDeviceToHost, h->st));
     KKT_HIP_CHECK(hipStreamSynchronize(h->st));
     return check_handoff(h);
-}
+} catch (...) { return kkt_catch("mi355kkt_sync"); }
 
-int mi355kkt_solve(mi355kkt_solver* h, double* x, double* y, double* z) {
+int mi355kkt_solve(mi355kkt_solver* h, double* x, double* y, double* z) try {
     if (!h) return MI355KKT_EINVAL;
     if (!h->factored) { set_last_error("solve: no valid factorisation"); return MI355KKT_EINVAL; }
     if (int e = bind(h)) return e;
@@ -1325,11 +1345,11 @@ int mi355kkt_solve(mi355kkt_solver* h, double* x, double* y, double* z) {
     if (p) memcpy(y, hb + n, sizeof(double) * p);
     if (m) memcpy(z, hb + n + p, sizeof(double) * m);
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_solve"); }
 
 int mi355kkt_is_singular_mode(const mi355kkt_solver* h) { return (h && h->singular) ? 1 : 0; }
 
-int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n) {
+int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n) try {
     if (!h || !out) return 0;
     (void)hipStreamSynchronize(h->st);
     if (hipEventQuery(h->ev[5]) == hipSuccess && hipEventQuery(h->ev[4]) == hipSuccess)
@@ -1338,9 +1358,9 @@ int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n) {
     int k = 0;
     for (; k < n && k < 6; ++k) out[k] = v[k];
     return k;
-}
+} catch (...) { return kkt_catch("mi355kkt_get_timings"); }
 
-int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL) {
+int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL) try {
     if (!h || !L || ldL < h->n) return MI355KKT_EINVAL;
     if (int e = bind(h)) return e;
     KKT_HIP_CHECK(hipStreamSynchronize(h->st));
@@ -1348,7 +1368,7 @@ int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL) {
         KKT_HIP_CHECK(hipMemcpy2D(L, sizeof(double) * ldL, h->dS, sizeof(double) * h->n, sizeof(double) * h->n, h->n,
                                   hipMemcpyDeviceToHost));
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_get_factor"); }
 
 // ---- batched LP-cone QP engine (BASELINE config 5: many independent small dense problems) -------------
 }  // extern "C"
@@ -1385,12 +1405,12 @@ struct mi355kkt_batch {
 
 extern "C" {
 
-int mi355kkt_batch_create(mi355kkt_batch** out, int device, int nbatch, int n, int ml) {
+int mi355kkt_batch_create(mi355kkt_batch** out, int device, int nbatch, int n, int ml) try {
     return mi355kkt_batch_create_eq(out, device, nbatch, n, ml, 0);
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_create"); }
 
 /* The same with p equality constraints per problem (A_b: p x n, set with mi355kkt_batch_set_A). */
-int mi355kkt_batch_create_eq(mi355kkt_batch** out, int device, int nbatch, int n, int ml, int p) {
+int mi355kkt_batch_create_eq(mi355kkt_batch** out, int device, int nbatch, int n, int ml, int p) try {
     if (!out || nbatch < 1 || n < 1 || ml < 0 || p < 0 || p > n) { set_last_error("batch_create: invalid argument"); return MI355KKT_EINVAL; }
     if (mi355kkt_device_count() <= device) { set_last_error("batch_create: HIP device %d not available", device); return MI355KKT_EHIP; }
     mi355kkt_batch* b = new mi355kkt_batch();
@@ -1430,10 +1450,10 @@ int mi355kkt_batch_create_eq(mi355kkt_batch** out, int device, int nbatch, int n
     }
     *out = b;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_create_eq"); }
 
 /* The same for problems with dims = {'l': nl, 'q': q[0..nq)}: G_b is cdim x n, cdim = nl + sum(q) (see include/mi355kkt.h). */
-int mi355kkt_batch_create_cones(mi355kkt_batch** out, int device, int nbatch, int n, int nl, int nq, const int* q, int p) {
+int mi355kkt_batch_create_cones(mi355kkt_batch** out, int device, int nbatch, int n, int nl, int nq, const int* q, int p) try {
     if (!out || nl < 0 || nq < 0 || (nq > 0 && !q)) { set_last_error("batch_create_cones: invalid argument"); return MI355KKT_EINVAL; }
     int64_t cdim = nl;
     for (int k = 0; k < nq; ++k) {
@@ -1463,9 +1483,9 @@ int mi355kkt_batch_create_cones(mi355kkt_batch** out, int device, int nbatch, in
     if (hipMalloc(&b->dV, sizeof(double) * B * b->sumq) != hipSuccess) return fail(MI355KKT_ENOMEM);
     if (hipMalloc(&b->dBeta, sizeof(double) * B * nq) != hipSuccess) return fail(MI355KKT_ENOMEM);
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_create_cones"); }
 
-void mi355kkt_batch_destroy(mi355kkt_batch* b) {
+void mi355kkt_batch_destroy(mi355kkt_batch* b) try {
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->st) (void)hipStreamSynchronize(b->st);
@@ -1483,11 +1503,11 @@ void mi355kkt_batch_destroy(mi355kkt_batch* b) {
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->st) (void)hipStreamDestroy(b->st);
     delete b;
-}
+} catch (...) { (void)kkt_catch("mi355kkt_batch_destroy"); }
 
 /* G: nbatch blocks of ml x n (column-major, contiguous); H: nbatch blocks of n x n (lower triangle used) or NULL.
  * is_device != 0: the pointers are device pointers (copied device-to-device). */
-int mi355kkt_batch_set_problem(mi355kkt_batch* b, const double* G, const double* H, int is_device) {
+int mi355kkt_batch_set_problem(mi355kkt_batch* b, const double* G, const double* H, int is_device) try {
     if (!b || !G) { set_last_error("batch_set_problem: null argument"); return MI355KKT_EINVAL; }
     KKT_HIP_CHECK(hipSetDevice(b->device));
     const hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -1502,10 +1522,10 @@ int mi355kkt_batch_set_problem(mi355kkt_batch* b, const double* G, const double*
         KKT_HIP_CHECK(hipStreamSynchronize(b->st));
     }
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_set_problem"); }
 
 /* A: nbatch blocks of p x n (column-major, contiguous). */
-int mi355kkt_batch_set_A(mi355kkt_batch* b, const double* A, int is_device) {
+int mi355kkt_batch_set_A(mi355kkt_batch* b, const double* A, int is_device) try {
     if (!b || (b->p > 0 && !A)) { set_last_error("batch_set_A: null argument"); return MI355KKT_EINVAL; }
     if (b->p == 0) return 0;
     KKT_HIP_CHECK(hipSetDevice(b->device));
@@ -1513,7 +1533,7 @@ int mi355kkt_batch_set_A(mi355kkt_batch* b, const double* A, int is_device) {
     b->singular = false;
     b->firstcall = true;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_set_A"); }
 
 // Ax[b] = A_b x_b, ATy[b] = A_b' y_b (device arrays; the fA of coneprog.py:2170-2186)
 static int batch_a_products(mi355kkt_batch* b, const double* dx, const double* dy, double* Ax, double* ATy) {
@@ -1532,7 +1552,7 @@ static int batch_a_products(mi355kkt_batch* b, const double* dx, const double* d
 /* The residual products of the IPM loop for every problem (reference coneprog.py:2170-2186, fP / fG):
  * Gx[b] = G_b x_b,  GTz[b] = G_b' z_b,  Hx[b] = H_b x_b.  Any output may be NULL.  Host or device arrays. */
 int mi355kkt_batch_products(mi355kkt_batch* b, const double* x, const double* z, double* Gx, double* GTz, double* Hx,
-                            int is_device) {
+                            int is_device) try {
     if (!b) return MI355KKT_EINVAL;
     KKT_HIP_CHECK(hipSetDevice(b->device));
     const size_t B = b->nbatch, N = b->n, M = b->ml;
@@ -1574,10 +1594,10 @@ int mi355kkt_batch_products(mi355kkt_batch* b, const double* x, const double* z,
     }
     if (!b->defer_sync) KKT_HIP_CHECK(hipStreamSynchronize(b->st));
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_products"); }
 
 /* di: [nbatch][ml]; info: [nbatch] (host), 0 or the failing pivot of that problem.  Returns 0 or <0. */
-int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, int* info) {
+int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, int* info) try {
     if (!b || (!di && b->ml)) { set_last_error("batch_factor: null argument"); return MI355KKT_EINVAL; }
     KKT_HIP_CHECK(hipSetDevice(b->device));
     const size_t B = b->nbatch, N = b->n, M = b->ml;
@@ -1642,11 +1662,11 @@ int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, in
     (void)hipEventElapsedTime(&b->t_factor, b->ev[0], b->ev[1]);
     if (info) memcpy(info, b->pw.h_info, sizeof(int) * B);
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_factor"); }
 
 /* Factorisation for a batch with second-order cones: di [nbatch][cdim] (the first nl entries of every slice: 1 / d of the 'l'
  * block), v [nbatch][sum(q)] (the cones' v_k back to back), beta [nbatch][nq] — the W of misc.py:307-354 per problem. */
-int mi355kkt_batch_factor_cones(mi355kkt_batch* b, const double* di, const double* v, const double* beta, int is_device, int* info) {
+int mi355kkt_batch_factor_cones(mi355kkt_batch* b, const double* di, const double* v, const double* beta, int is_device, int* info) try {
     if (!b || (!di && b->nl) || (!b->q.empty() && (!v || !beta))) { set_last_error("batch_factor_cones: null argument"); return MI355KKT_EINVAL; }
     KKT_HIP_CHECK(hipSetDevice(b->device));
     if (!b->q.empty()) {
@@ -1661,16 +1681,16 @@ int mi355kkt_batch_factor_cones(mi355kkt_batch* b, const double* di, const doubl
         }
     }
     return mi355kkt_batch_factor(b, di, is_device, info);
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_factor_cones"); }
 
 /* x: [nbatch][n], z: [nbatch][ml], in place: (bx, bz) -> (ux, W uz) per problem (p = 0). */
-int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device) {
+int mi355kkt_batch_solve(mi355kkt_batch* b, double* x, double* z, int is_device) try {
     if (b && b->p > 0) { set_last_error("batch_solve: the batch has equality constraints, use mi355kkt_batch_solve_eq"); return MI355KKT_EINVAL; }
     return mi355kkt_batch_solve_eq(b, x, nullptr, z, is_device);
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_solve"); }
 
 /* x: [nbatch][n], y: [nbatch][p], z: [nbatch][ml], in place: (bx, by, bz) -> (ux, uy, W uz) per problem (misc.py:1513-1563). */
-int mi355kkt_batch_solve_eq(mi355kkt_batch* b, double* x, double* y, double* z, int is_device) {
+int mi355kkt_batch_solve_eq(mi355kkt_batch* b, double* x, double* y, double* z, int is_device) try {
     if (!b || !x || (!z && b->ml) || (!y && b->p)) { set_last_error("batch_solve: null argument"); return MI355KKT_EINVAL; }
     KKT_HIP_CHECK(hipSetDevice(b->device));
     const size_t B = b->nbatch, N = b->n, M = b->ml, Pq = b->p;
@@ -1713,7 +1733,7 @@ int mi355kkt_batch_solve_eq(mi355kkt_batch* b, double* x, double* y, double* z, 
     }
     if (!b->defer_sync) KKT_HIP_CHECK(hipStreamSynchronize(b->st));
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_solve_eq"); }
 
 }  // extern "C"
 
@@ -1885,16 +1905,16 @@ extern "C" {
  * the host.  See include/mi355kkt.h. */
 int mi355kkt_batch_coneqp(mi355kkt_batch* b, const double* q, const double* h, int maxiters, double abstol, double reltol,
                           double feastol, double* x, double* s, double* z, int* status, int* iters, double* pcost,
-                          double* dcost, double* gap, int* iterations_run) {
+                          double* dcost, double* gap, int* iterations_run) try {
     if (b && b->p > 0) { set_last_error("batch_coneqp: the batch has equality constraints, use mi355kkt_batch_coneqp_eq"); return MI355KKT_EINVAL; }
     return mi355kkt_batch_coneqp_eq(b, q, h, nullptr, maxiters, abstol, reltol, feastol, x, nullptr, s, z, status, iters, pcost, dcost,
                                     gap, iterations_run);
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_coneqp"); }
 
 /* The same with equality constraints A_b x = bvec_b (bvec, y: [nbatch][p]). */
 int mi355kkt_batch_coneqp_eq(mi355kkt_batch* b, const double* q, const double* h, const double* bvec, int maxiters, double abstol,
                              double reltol, double feastol, double* x, double* y, double* s, double* z, int* status, int* iters,
-                             double* pcost, double* dcost, double* gap, int* iterations_run) {
+                             double* pcost, double* dcost, double* gap, int* iterations_run) try {
     if (!b || !q || (!h && b->ml) || !x || !status || !iters || (b->p > 0 && (!bvec || !y))) {
         set_last_error("batch_coneqp: null argument");
         return MI355KKT_EINVAL;
@@ -1927,7 +1947,7 @@ int mi355kkt_batch_coneqp_eq(mi355kkt_batch* b, const double* q, const double* h
     ops.solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_batch_solve_eq(b, dx, dy, dz, 1); };
     IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, iterations_run, y};
     return run_ipm(b->ipm, b->st, ops, q, h, bvec, maxiters, abstol, reltol, feastol, o);
-}
+} catch (...) { return kkt_catch("mi355kkt_batch_coneqp_eq"); }
 
 // the mirrored copy of H (only tril(H) is meaningful on input, coneprog.py:1475-1477) for plain products H x
 static int ensure_hsym(mi355kkt_solver* hs) {
@@ -1977,7 +1997,7 @@ static int ensure_gemv_work(mi355kkt_solver* hs) {
 /* out = op(M) x on the device, host vectors in and out: which = 0: G (cdim x n), 1: A (p x n), 2: H (n x n, symmetric,
  * tril(H) as set); trans != 0: op = transpose.  The operator form of the reference's fG / fA / fP closures
  * (coneprog.py:531-550, :1843-1844, :1896-1916) for callers that hand conelp / coneqp callables instead of matrices. */
-int mi355kkt_product(mi355kkt_solver* hs, int which, int trans, const double* x, double* out) {
+int mi355kkt_product(mi355kkt_solver* hs, int which, int trans, const double* x, double* out) try {
     if (!hs || !x || !out || which < 0 || which > 2) { set_last_error("product: invalid argument"); return MI355KKT_EINVAL; }
     if (int e = bind(hs)) return e;
     const int n = hs->n, m = hs->cdim, np = hs->p;
@@ -2022,13 +2042,13 @@ int mi355kkt_product(mi355kkt_solver* hs, int which, int trans, const double* x,
     KKT_HIP_CHECK(hipStreamSynchronize(st));
     memcpy(out, hs->hbuf, sizeof(double) * nout);
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_product"); }
 
 /* Single problem, LP cone, no equality constraints: the coneqp loop of coneprog.py:2044-2547 resident on the device around
  * this handle's own factor/solve (dense or sparse mode).  G (and H, if any) must have been set.  See include/mi355kkt.h. */
 int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, const double* bv, int maxiters,
                        double abstol, double reltol, double feastol, double* x, double* y, double* s, double* z, int* status,
-                       int* iters, double* pcost, double* dcost, double* gap) {
+                       int* iters, double* pcost, double* dcost, double* gap) try {
     if (!hs || !q || !hv || !x || !status || !iters || (hs->p > 0 && (!bv || !y))) {
         set_last_error("coneqp_lp: null argument");
         return MI355KKT_EINVAL;
@@ -2084,7 +2104,7 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
     ops.solve = [&](double* dx, double* dy, double* dz) { return mi355kkt_solve_device(hs, dx, dy, dz); };
     IpmHostOut o{x, s, z, status, iters, pcost, dcost, gap, nullptr, y};
     return run_ipm(hs->ipm, st, ops, q, hv, bv, maxiters, abstol, reltol, feastol, o);
-}
+} catch (...) { return kkt_catch("mi355kkt_coneqp_lp"); }
 
 // The device loops keep the 's' blocks of every cone vector as full symmetric matrices (cone_ops_s.h), so that G x is symmetric
 // and G'z is the reference's sgemv (misc.py:801-832: only the lower triangles of the 's' blocks of the columns of G count).
@@ -2113,15 +2133,15 @@ static int symmetrize_G_sblocks(mi355kkt_solver* hs) {
  * factor/solve (H must be absent).  See include/mi355kkt.h. */
 int mi355kkt_conelp(mi355kkt_solver* hs, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
                     double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
-                    int* iters, double* stats) {
+                    int* iters, double* stats) try {
     return mi355kkt_conelp_init(hs, c, hv, bv, maxiters, abstol, reltol, feastol, refinement, 0, 0, x, y, s, z, status, iters, stats);
-}
+} catch (...) { return kkt_catch("mi355kkt_conelp"); }
 
 /* have_primal: x, s hold primalstart on entry; have_dual: y, z hold dualstart (coneprog.py:696-739; the caller has checked that the
  * given s / z are in the interior of the cone).  The part that is not given is constructed as in the default start. */
 int mi355kkt_conelp_init(mi355kkt_solver* hs, const double* c, const double* hv, const double* bv, int maxiters, double abstol,
                          double reltol, double feastol, int refinement, int have_primal, int have_dual, double* x, double* y,
-                         double* s, double* z, int* status, int* iters, double* stats) {
+                         double* s, double* z, int* status, int* iters, double* stats) try {
     if (!hs || !c || !hv || !x || !s || !z || !status || !iters || (hs->p > 0 && (!bv || !y))) {
         set_last_error("conelp: null argument");
         return MI355KKT_EINVAL;
@@ -2268,22 +2288,22 @@ int mi355kkt_conelp_init(mi355kkt_solver* hs, const double* c, const double* hv,
         if (*iters == 0 && *status == 1 && hsc[LP_GAP_OUT] == 0.0) stats[0] = hsc[LP_GAP];   // optimal starting point
     }
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_conelp_init"); }
 
 /* Single problem, 'l' + 'q' cones: the coneqp loop of coneprog.py:2044-2547 (refinement 0 for the LP cone, 1 with
  * second-order cones, :1862-1865) resident on the device around this handle's factor/solve.  See include/mi355kkt.h. */
 int mi355kkt_coneqp(mi355kkt_solver* hs, const double* q, const double* hv, const double* bv, int maxiters, double abstol,
                     double reltol, double feastol, int refinement, double* x, double* y, double* s, double* z, int* status,
-                    int* iters, double* stats) {
+                    int* iters, double* stats) try {
     return mi355kkt_coneqp_init(hs, q, hv, bv, maxiters, abstol, reltol, feastol, refinement, 0, x, y, s, z, status, iters, stats);
-}
+} catch (...) { return kkt_catch("mi355kkt_coneqp"); }
 
 /* have_init != 0: x, y, s, z hold the caller's starting point on entry (initvals of solvers.coneqp, coneprog.py:2109-2149: the
  * caller has filled in the reference's defaults -- x = 0, y = 0, s = z = e -- for missing entries and checked s, z > 0); the
  * factorisation / solve with W = I of the default start is skipped. */
 int mi355kkt_coneqp_init(mi355kkt_solver* hs, const double* q, const double* hv, const double* bv, int maxiters, double abstol,
                          double reltol, double feastol, int refinement, int have_init, double* x, double* y, double* s, double* z,
-                         int* status, int* iters, double* stats) {
+                         int* status, int* iters, double* stats) try {
     if (!hs || !q || !hv || !x || !s || !z || !status || !iters || (hs->p > 0 && (!bv || !y))) {
         set_last_error("coneqp: null argument");
         return MI355KKT_EINVAL;
@@ -2419,7 +2439,7 @@ int mi355kkt_coneqp_init(mi355kkt_solver* hs, const double* q, const double* hv,
         stats[4] = hsc[QP_PRES]; stats[5] = hsc[QP_DRES];
     }
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_coneqp_init"); }
 
 float mi355kkt_batch_last_factor_ms(const mi355kkt_batch* b) { return b ? b->t_factor : 0.0f; }
 
@@ -2456,7 +2476,7 @@ static int cur_num_cus() {
 }
 
 int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
-                            int64_t ldH, double* dS, int64_t ldS, float* ms) {
+                            int64_t ldH, double* dS, int64_t ldS, float* ms) try {
     static SyrkPlan plan;   // cached for repeated calls with one shape (profiling loops)
     int kc = m;             // developer experiment: MI355KKT_SYRK_KCHUNK=<rows per launch> (must divide m)
     if (const char* e = getenv("MI355KKT_SYRK_KCHUNK")) {
@@ -2473,11 +2493,11 @@ int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const d
         if (m == 0) break;
     }
     return t.finish();
-}
+} catch (...) { return kkt_catch("mi355kkt_op_syrk_scaled"); }
 
 /* host-only: the symbolic analysis of the sparse engine (ordering + supernodes) for the pattern of H + G'G */
 int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
-                         const int64_t* hrowind, int* perm, int64_t* nnzL, int* nsupernodes, int* nlevels) {
+                         const int64_t* hrowind, int* perm, int64_t* nnzL, int* nsupernodes, int* nlevels) try {
     SparseSymbolic S;
     if (int e = symbolic_analyze(S, n, m, gcolptr, growind, hcolptr, hrowind)) return e;
     if (perm) for (int k = 0; k < n; ++k) perm[k] = S.perm[k];
@@ -2485,7 +2505,7 @@ int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* gr
     if (nsupernodes) *nsupernodes = S.ns;
     if (nlevels) *nlevels = S.nlevels;
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_op_symbolic"); }
 
 /* host-only: the whole plan of the symbolic analysis as one flat int64 array, for the CPU tests that execute the plan in
  * NumPy (tests/test_sparse_plan_cpu.py).  out = header[16] followed by the arrays in the order of the header counts:
@@ -2497,7 +2517,7 @@ int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* gr
  *   heavy_ptr[nlevels+1], heavy[nheavy]    (header[10] = nvb, header[11] = nheavy).
  * Returns the number of int64 entries of the plan (call with cap = 0 to size the buffer), or a negative error code. */
 int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
-                                     const int64_t* hrowind, int64_t* out, int64_t cap) {
+                                     const int64_t* hrowind, int64_t* out, int64_t cap) try {
     SparseSymbolic S;
     if (int e = symbolic_analyze(S, n, m, gcolptr, growind, hcolptr, hrowind)) return e;
     const int ns = S.ns;
@@ -2539,10 +2559,10 @@ int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const
     put(S.heavy_ptr, nl + 1);
     put(S.heavy, nheavy);
     return (p - out == need) ? need : (int64_t)MI355KKT_EINVAL;
-}
+} catch (...) { return (int64_t)kkt_catch("mi355kkt_debug_symbolic_plan"); }
 
 int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
-                           const double* dv, const double* dbeta, float* ms) {
+                           const double* dv, const double* dbeta, float* ms) try {
     ConeLayout cl;
     std::vector<int> qq(q, q + nq);
     if (int e = cone_layout_build(cl, ml, qq)) return e;
@@ -2553,7 +2573,7 @@ int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX
     if (!rc) rc = t.finish();
     cone_layout_free(cl);
     return rc;
-}
+} catch (...) { return kkt_catch("mi355kkt_op_cone_scale"); }
 
 }  // extern "C"
 __global__ void hwid_probe_kernel(unsigned* out) {
@@ -2565,21 +2585,21 @@ __global__ void hwid_probe_kernel(unsigned* out) {
 }
 extern "C" {
 /* developer probe: HW_ID / XCC_ID of nblocks one-wave workgroups (out: 2 * nblocks words, host) */
-int mi355kkt_debug_hwid(unsigned* out, int nblocks) {
+int mi355kkt_debug_hwid(unsigned* out, int nblocks) try {
     unsigned* d = nullptr;
     KKT_HIP_CHECK(hipMalloc(&d, sizeof(unsigned) * 2 * nblocks));
     hipLaunchKernelGGL(hwid_probe_kernel, dim3(nblocks), dim3(64), 0, nullptr, d);
     KKT_HIP_CHECK(hipMemcpy(out, d, sizeof(unsigned) * 2 * nblocks, hipMemcpyDeviceToHost));
     (void)hipFree(d);
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_debug_hwid"); }
 /* Host execution of the second-order-cone operations the device-resident loops use (the SAME source, cone_ops.h, compiled
  * for the host): for the CPU parity tests against the reference's misc / misc_solvers functions.  One cone of dimension mk.
  * op: 0 sprod (x := x o y), 1 sinv (x := y o\ x), 2 ssqr (x := y o y), 3 scale2 (x := H(y^{1/2}) x; inverse: arg),
  * 4 scale (x := W x with v = y, beta = w[0]; inverse: arg), 5 jnrm2 -> w[0], 6 compute_scaling (s = x, z = y -> v = w[0:mk],
  * lambda = w[mk:2mk], beta = w[2mk]), 7 update_scaling (s = x, z = y normalised in place; v = w[0:mk], lambda = w[mk:2mk],
  * beta = w[2mk] updated), 8 max_step term ||x1|| - x0 -> w[0]. */
-int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w) {
+int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w) try {
     if (mk < 1 || !x) return MI355KKT_EINVAL;
     switch (op) {
         case 0: mi355kkt::q_sprod(x, y, mk); break;
@@ -2594,14 +2614,14 @@ int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, d
         default: return MI355KKT_EINVAL;
     }
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_debug_cone_op_host"); }
 /* The same for the 's'-block operations (cone_ops_s.h, instantiated with a team of one thread): one block of order m, column-
  * major.  inverse = arg & 1, trans = arg & 2.
  * op: 0 scale (x := W x: r'xr | rxr' (trans) | rti x rti' (inverse) | rti'x rti (both)), 1 sprod (x := (xy + yx)/2),
  * 2 sprod diag = 'D' (x := x o diag(lam); inverse: sinv), 3 scale2 (lam, x; inverse), 4 smallest eigenvalue -> lam[0],
  * 5 eigenvalue decomposition (x := eigenvectors, lam := eigenvalues ascending), 6 compute_scaling (s = x, z = y -> r, rti, lam),
  * 7 update_scaling (Ls = x, Lz = y destroyed; r, rti, lam updated), 8 potrf (x := chol(x), strict upper zeroed). */
-int mi355kkt_debug_sdp_op_host(int op, int m, int arg, double* x, double* y, double* r, double* rti, double* lam) {
+int mi355kkt_debug_sdp_op_host(int op, int m, int arg, double* x, double* y, double* r, double* rti, double* lam) try {
     if (m < 1 || !x) return MI355KKT_EINVAL;
     const mi355kkt::ParHost par;
     const size_t mm = (size_t)m * m;
@@ -2621,10 +2641,10 @@ int mi355kkt_debug_sdp_op_host(int op, int m, int arg, double* x, double* y, dou
         default: return MI355KKT_EINVAL;
     }
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_debug_sdp_op_host"); }
 /* ... and on the DEVICE: one workgroup (team = 0: 1024 threads, the loops' configuration) or one wave (team = 1) runs the
  * operation on copies of the host arrays (any may be NULL where the operation does not use it); results come back in place. */
-int mi355kkt_debug_sdp_op_device(int op, int m, int arg, int team, double* x, double* y, double* r, double* rti, double* lam) {
+int mi355kkt_debug_sdp_op_device(int op, int m, int arg, int team, double* x, double* y, double* r, double* rti, double* lam) try {
     if (m < 1 || !x || mi355kkt_device_count() < 1) return MI355KKT_EINVAL;
     const size_t mm = (size_t)m * m, nw = 3 * mm + mi355kkt::s_jw_doubles(m, 1024) + 64;
     double* d = nullptr;
@@ -2650,7 +2670,7 @@ int mi355kkt_debug_sdp_op_device(int op, int m, int arg, int team, double* x, do
     }
     (void)hipFree(d);
     return (op == 6 || op == 8) ? (int)ret : 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_debug_sdp_op_device"); }
 
 /* The same operations run by a TEAM of nt host threads (pthread barrier as the team barrier): the SPMD form of cone_ops_s.h
  * with real concurrency between the threads of a team, as on the device (workgroup teams of 1024, wave teams of 64), for the
@@ -2686,7 +2706,7 @@ struct ParThreads {
 };
 }  // namespace
 extern "C" {
-int mi355kkt_debug_sdp_op_host_team(int op, int m, int arg, int nt, double* x, double* y, double* r, double* rti, double* lam) {
+int mi355kkt_debug_sdp_op_host_team(int op, int m, int arg, int nt, double* x, double* y, double* r, double* rti, double* lam) try {
     if (m < 1 || !x || nt < 1 || nt > 1024) return MI355KKT_EINVAL;
     const size_t mm = (size_t)m * m;
     std::vector<double> w(3 * mm + mi355kkt::s_jw_doubles(m, nt) + m), red(nt);
@@ -2718,11 +2738,11 @@ int mi355kkt_debug_sdp_op_host_team(int op, int m, int arg, int nt, double* x, d
     pthread_barrier_destroy(&bar);
     if (op == 4) lam[0] = ret[0];
     return rc[0];
-}
+} catch (...) { return kkt_catch("mi355kkt_debug_sdp_op_host_team"); }
 /* The static SYRK schedule for an n x n result contracted over K on a device with num_cus compute units, as plain integers
  * (host only): out[8 * i + 0..7] = ti, tj, k0, k1, slot, first, nparts, 0 of work item i, in launch order.  For the CPU tests
  * of the plan's invariants.  Returns the number of items (<= max_items are written). */
-int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit) {
+int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit) try {
     std::vector<mi355kkt::SyrkItem> items, split_tiles;
     int ns = 0;
     mi355kkt::make_syrk_items(n, K, num_cus, allow_split != 0, items, split_tiles, ns);
@@ -2734,13 +2754,13 @@ int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* ou
     if (nslabs) *nslabs = ns;
     if (nsplit) *nsplit = (int)split_tiles.size();
     return (int)items.size();
-}
+} catch (...) { return kkt_catch("mi355kkt_debug_syrk_plan"); }
 /* Fill-reducing ordering of a symmetric pattern (host only, for the CPU tests of csrc/ordering.cpp): colptr/rowind = CSC
  * pattern of any part of the matrix that contains each off-diagonal pair at least once; method 0 = choose, 1 = nested
  * dissection, 2 = approximate minimum degree.  perm[new] = old.  stats[0..6] = method chosen, nnz(L) and flops of the
  * dissection candidate, nnz(L) and flops of the minimum-degree candidate, supernodal tree heights of the two; stats[7] = 1
  * when the two column-count algorithms agree on the returned order (and with the tree / counts the analysis keeps). */
-int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats) {
+int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats) try {
     if (n < 0 || !colptr || !perm) return MI355KKT_EINVAL;
     mi355kkt::Graph adj(n);
     for (int j = 0; j < n; ++j)
@@ -2769,16 +2789,22 @@ int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind,
         stats[7] = (fast == slow && fast == info.colcount && par == info.parent) ? 1.0 : 0.0;
     }
     return 0;
-}
+} catch (...) { return kkt_catch("mi355kkt_debug_ordering"); }
 int mi355kkt_debug_potf2_skip(int mask) { return mi355kkt::set_potf2_skip(mask); }
 int mi355kkt_debug_tile_ts(void* dptr) { return mi355kkt::set_tile_ts((long long*)dptr); }
 int mi355kkt_debug_potf2_ts(void* dptr) { return mi355kkt::set_potf2_ts((long long*)dptr); }
 int mi355kkt_debug_trsvz_ts(void* dptr) { return mi355kkt::set_trsvz_ts((long long*)dptr); }
 int mi355kkt_debug_syrk_skip(int mask) { return mi355kkt::set_syrk_skip(mask); }
+int mi355kkt_debug_throw(int kind) try {
+    if (kind == 0) throw std::bad_alloc();
+    if (kind == 1) throw std::runtime_error("requested by the caller");
+    if (kind == 2) throw 42;
+    return 0;
+} catch (...) { return kkt_catch("mi355kkt_debug_throw"); }
 
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops) { return run_mfma_f64_peak(iters, cur_num_cus(), tflops); }
 
-int mi355kkt_op_potrf(double* dA, int64_t ldA, int n, int* info, float* ms) {
+int mi355kkt_op_potrf(double* dA, int64_t ldA, int n, int* info, float* ms) try {
     PotrfWork w;
     if (int e = potrf_work_init(w)) return e;
     if (int e = potrf_work_reserve(w, n)) { potrf_work_free(w); return e; }
@@ -2791,17 +2817,17 @@ int mi355kkt_op_potrf(double* dA, int64_t ldA, int n, int* info, float* ms) {
     }
     potrf_work_free(w);
     return rc;
-}
+} catch (...) { return kkt_catch("mi355kkt_op_potrf"); }
 
 int mi355kkt_op_trsm_lower(const double* dL, int64_t ldL, int n, double* dX, int64_t ldX, int nrhs, int trans,
-                           float* ms) {
+                           float* ms) try {
     OpTimer t(ms);
     if (int e = launch_trsm_lower(dL, ldL, n, dX, ldX, nrhs, trans, nullptr)) return e;
     return t.finish();
-}
+} catch (...) { return kkt_catch("mi355kkt_op_trsm_lower"); }
 
 int mi355kkt_op_gemv_t_scaled(const double* dG, int64_t ldG, int m, int n, const double* dw, const double* dz,
-                              double* dzs, double* dy, float* ms) {
+                              double* dzs, double* dy, float* ms) try {
     double* work = nullptr;
     KKT_HIP_CHECK(hipMalloc(&work, sizeof(double) * (size_t)(m > 0 ? m : 1)));
     OpTimer t(ms);
@@ -2809,10 +2835,10 @@ int mi355kkt_op_gemv_t_scaled(const double* dG, int64_t ldG, int m, int n, const
     if (!rc) rc = t.finish();
     (void)hipFree(work);
     return rc;
-}
+} catch (...) { return kkt_catch("mi355kkt_op_gemv_t_scaled"); }
 
 int mi355kkt_op_gemv_n_scaled(const double* dG, int64_t ldG, int m, int n, const double* dw, const double* dx,
-                              const double* dzs, double* dz, float* ms) {
+                              const double* dzs, double* dz, float* ms) try {
     double* work = nullptr;
     KKT_HIP_CHECK(hipMalloc(&work, sizeof(double) * gemv_work_doubles(m, n)));
     OpTimer t(ms);
@@ -2820,6 +2846,6 @@ int mi355kkt_op_gemv_n_scaled(const double* dG, int64_t ldG, int m, int n, const
     if (!rc) rc = t.finish();
     (void)hipFree(work);
     return rc;
-}
+} catch (...) { return kkt_catch("mi355kkt_op_gemv_n_scaled"); }
 
 }  // extern "C"

@@ -20,6 +20,8 @@
  * Return codes: 0 ok; >0 LAPACK-style "leading minor of order info is not positive definite"
  * (the Python layer raises ArithmeticError(info), reference src/C/lapack.c:32-34); <0 errors below.
  * All functions are plain C, take plain pointers and sizes, and are thread-compatible per handle.
+ * No C++ exception crosses this boundary: a failing host-side allocation (std::bad_alloc) inside the library comes back as
+ * MI355KKT_ENOMEM, any other C++ exception as MI355KKT_EHIP, with the text in mi355kkt_last_error().
  */
 #ifndef MI355KKT_H
 #define MI355KKT_H
@@ -290,6 +292,9 @@ int mi355kkt_debug_potf2_ts(void* dptr);
 int mi355kkt_debug_tile_ts(void* dptr);
 int mi355kkt_debug_trsvz_ts(void* dptr);   /* 8 shader-clock stamps per 128-block of the next trsv_z launches (NULL: off) */
 int mi355kkt_debug_syrk_skip(int mask);
+/* test aid: throws inside a guarded entry point (kind 0: std::bad_alloc, 1: std::runtime_error, 2: a non-standard exception);
+ * must RETURN MI355KKT_ENOMEM / MI355KKT_EHIP like any entry point in which host code throws */
+int mi355kkt_debug_throw(int kind);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops);
 /* in-place lower Cholesky; *info as LAPACK dpotrf */

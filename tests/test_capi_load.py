@@ -115,3 +115,18 @@ def test_product_never_imports_the_oracle():
                 # cvxopt (the reference, installed by the user) is only ever the CALLER: kkt.install() rebinds its factories,
                 # solvers.py hands its own drivers device operators; nothing else may import it
                 assert "import cvxopt\n" not in txt and "from cvxopt " not in txt or f in ("kkt.py", "solvers.py"), f
+
+
+def test_no_cpp_exception_crosses_the_c_abi():
+    """every non-trivial entry point is a function-try-block: a throwing host path returns an error code (and a message)
+    instead of std::terminate-ing the interpreter (header: 'No C++ exception crosses this boundary')"""
+    from cvxopt_amd import _capi
+    L = _capi.lib()
+    assert L.mi355kkt_debug_throw(3) == 0
+    assert L.mi355kkt_debug_throw(0) == _capi.ENOMEM
+    assert "out of host memory" in _capi.last_error()
+    assert L.mi355kkt_debug_throw(1) == _capi.EHIP
+    assert "requested by the caller" in _capi.last_error()
+    assert L.mi355kkt_debug_throw(2) == _capi.EHIP
+    with pytest.raises(MemoryError):
+        _capi.check(L.mi355kkt_debug_throw(0), "debug_throw")
