@@ -87,7 +87,7 @@ def _worker(rank, world, port, tmp, nprob, nsub):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,nprob,nsub", [(2, 5, 4), (3, 7, 4), (3, 8, 2), (2, 6, 1), (4, 5, 3), (8, 19, 2)])
+@pytest.mark.parametrize("world,nprob,nsub", [(2, 5, 4), (3, 7, 4), (3, 8, 2), (2, 6, 1), (4, 5, 3), (8, 19, 2), (4, 3, 2)])
 def test_sharded_batch_on_gloo(tmp_path, world, nprob, nsub):
     """unequal shards (5 over 2, 7 over 3), sub-batches that are empty on the short ranks, the un-pipelined path (nsub = 1),
     two solves through one persistent ShardedBatch: per-problem equality with the single-process solve"""
