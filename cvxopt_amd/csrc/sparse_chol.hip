@@ -1176,7 +1176,7 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
     const SparseSymbolic& S = E.sym;
     if (E.n == 0) { if (info) *info = 0; return 0; }
     KKT_HIP_CHECK(hipMemsetAsync(E.d_panels, 0, sizeof(double) * (S.store_doubles ? S.store_doubles : 1), st));
-    const int imax = 0x7fffffff;
+    static const int imax = 0x7fffffff;      // (static: the asynchronous copy below must not read a dead stack slot on an early error return)
     KKT_HIP_CHECK(hipMemcpyAsync(E.d_info, &imax, sizeof(int), hipMemcpyHostToDevice, st));
     const int64_t nt = (int64_t)S.asm_slot.size();
     if (nt > 0)
