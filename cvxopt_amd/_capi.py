@@ -26,7 +26,8 @@ class Scaling(C.Structure):
                 ("r", c_double_p), ("rti", c_double_p)]
 
 
-# name -> (restype, argtypes); this table is also what tests check against include/mi355kkt.h
+# name -> (restype, argtypes); this table is also what tests check against include/mi355kkt.h + include/mi355kkt_test.h
+# (mi355kkt_debug_*: only in -DMI355KKT_DEBUG builds, bound lazily by debug_signatures() for tools/dev scripts)
 SIGNATURES = {
     "mi355kkt_version": (C.c_int, []),
     "mi355kkt_last_error": (C.c_char_p, []),
@@ -56,6 +57,8 @@ SIGNATURES = {
     "mi355kkt_set_progress": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mi355kkt_set_H_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "mi355kkt_set_kktreg": (C.c_int, [C.c_void_p, C.c_double]),
+    "mi355kkt_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
+    "mi355kkt_batch_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_double]),
     "mi355kkt_factor": (C.c_int, [C.c_void_p, C.POINTER(Scaling)]),
     "mi355kkt_factor_device": (C.c_int, [C.c_void_p, C.POINTER(Scaling)]),
     "mi355kkt_solve": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -102,22 +105,17 @@ SIGNATURES = {
     "mi355kkt_op_syrk_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_int64, C.c_void_p, C.c_int64, c_float_p]),
     "mi355kkt_op_symbolic": (C.c_int, [C.c_int, C.c_int, c_i64_p, c_i64_p, c_i64_p, c_i64_p, c_int_p, c_i64_p, c_int_p, c_int_p]),
-    "mi355kkt_debug_symbolic_plan": (C.c_int64, [C.c_int, C.c_int, c_i64_p, c_i64_p, c_i64_p, c_i64_p, c_i64_p, C.c_int64]),
+    "mi355kkt_test_symbolic_plan": (C.c_int64, [C.c_int, C.c_int, c_i64_p, c_i64_p, c_i64_p, c_i64_p, c_i64_p, C.c_int64]),
     "mi355kkt_op_cone_scale": (C.c_int, [C.c_int, C.c_int, c_int_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
                                          C.c_void_p, C.c_void_p, c_float_p]),
-    "mi355kkt_debug_hwid": (C.c_int, [C.c_void_p, C.c_int]),
-    "mi355kkt_debug_cone_op_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mi355kkt_debug_sdp_op_host": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
-    "mi355kkt_debug_sdp_op_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
-    "mi355kkt_debug_sdp_op_host_team": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
-    "mi355kkt_debug_syrk_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p]),
-    "mi355kkt_debug_ordering": (C.c_int, [C.c_int, c_i64_p, c_i64_p, C.c_int, c_int_p, c_double_p]),
-    "mi355kkt_debug_potf2_skip": (C.c_int, [C.c_int]),
-    "mi355kkt_debug_potf2_ts": (C.c_int, [C.c_void_p]),
-    "mi355kkt_debug_tile_ts": (C.c_int, [C.c_void_p]),
-    "mi355kkt_debug_trsvz_ts": (C.c_int, [C.c_void_p]),
-    "mi355kkt_debug_syrk_skip": (C.c_int, [C.c_int]),
-    "mi355kkt_debug_throw": (C.c_int, [C.c_int]),
+    "mi355kkt_test_cone_op_host": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mi355kkt_test_sdp_op_host": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "mi355kkt_test_sdp_op_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "mi355kkt_test_sdp_op_host_team": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    "mi355kkt_test_syrk_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p]),
+    "mi355kkt_test_ordering": (C.c_int, [C.c_int, c_i64_p, c_i64_p, C.c_int, c_int_p, c_double_p]),
+    "mi355kkt_test_throw": (C.c_int, [C.c_int]),
+    "mi355kkt_test_set_knob": (C.c_int, [C.c_char_p, C.c_char_p]),
     "mi355kkt_op_mfma_f64_peak": (C.c_int, [C.c_int, c_float_p]),
     "mi355kkt_op_potrf": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_int_p, c_float_p]),
     "mi355kkt_op_trsm_lower": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int,
@@ -127,6 +125,21 @@ SIGNATURES = {
     "mi355kkt_op_gemv_n_scaled": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p, c_float_p]),
 }
+
+
+# include/mi355kkt_debug.h -- present only in a library built with `build.sh --debug` (load it with $CVXOPT_AMD_LIB)
+DEBUG_SIGNATURES = {
+    "mi355kkt_debug_hwid": (C.c_int, [C.c_void_p, C.c_int]),
+    "mi355kkt_debug_potf2_ts": (C.c_int, [C.c_void_p]),
+    "mi355kkt_debug_tile_ts": (C.c_int, [C.c_void_p]),
+    "mi355kkt_debug_syrk_skip": (C.c_int, [C.c_int]),
+}
+
+
+def set_knob(name, value):
+    """include/mi355kkt_test.h: developer / test knob of the library (value None unsets it; name None unsets all)"""
+    enc = lambda v: None if v is None else str(v).encode("ascii")
+    check(lib().mi355kkt_test_set_knob(enc(name), enc(value)), "mi355kkt_test_set_knob")
 
 
 def lib():
@@ -148,6 +161,11 @@ def lib():
         f = getattr(L, name)
         f.restype = res
         f.argtypes = args
+    for name, (res, args) in DEBUG_SIGNATURES.items():      # a -DMI355KKT_DEBUG build only
+        f = getattr(L, name, None)
+        if f is not None:
+            f.restype = res
+            f.argtypes = args
     _lib = L
     return L
 

@@ -159,7 +159,7 @@ class BatchKkt(object):
     def factor_ms(self):
         return float(self.L.mi355kkt_batch_last_factor_ms(self.h))
 
-    def coneqp(self, q, h, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, b=None):
+    def coneqp(self, q, h, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, b=None, use_correction=True):
         """The whole interior-point loop on the device (`mi355kkt_batch_coneqp`): same result dict as
         `coneqp_batch`; only the count of active problems crosses PCIe per iteration.  q, h may be float64 CUDA tensors
         (a sharded batch: they arrived over RCCL); the result arrays are then CUDA tensors too and nothing but the
@@ -168,6 +168,8 @@ class BatchKkt(object):
         on_device = hasattr(q, "data_ptr")
         ip = _capi.c_int_p
         nrun = C.c_int(0)
+        _capi.check(self.L.mi355kkt_batch_set_option(self.h, b"use_correction", 1.0 if use_correction else 0.0),
+                    "batch_set_option")                      # options['use_correction'] of solvers.coneqp (coneprog.py:1781)
         if on_device:
             import torch
             if not (q.is_cuda and h.is_cuda and q.dtype == torch.float64 and h.dtype == torch.float64):
@@ -242,7 +244,7 @@ def pack_problems(problems):
 # lock-step interior-point loop (host bookkeeping, device KKT)
 # ---------------------------------------------------------------------------------------------------
 def coneqp_batch(P, q, Gt, h, kkt=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, device=0,
-                 resident=False):
+                 resident=False, use_correction=True):
     """Solves the B problems in lock step.  Returns a dict of arrays: x (B,n), s, z (B,m), status (B,)
     ('optimal' | 'unknown'), iterations, primal objective, dual objective, gap.
     resident=True runs the bookkeeping on the device as well (BatchKkt.coneqp); the NumPy loop below is the
@@ -254,7 +256,8 @@ def coneqp_batch(P, q, Gt, h, kkt=None, maxiters=100, abstol=1e-7, reltol=1e-6, 
         kkt = BatchKkt(Gt, P, device=device)
     if resident:
         try:
-            return kkt.coneqp(q, h, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol)
+            return kkt.coneqp(q, h, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol,
+                              use_correction=use_correction)
         finally:
             if own:
                 kkt.close()
@@ -356,7 +359,7 @@ def coneqp_batch(P, q, Gt, h, kkt=None, maxiters=100, abstol=1e-7, reltol=1e-6, 
         ws3 = np.zeros((B, m))
         for i in (0, 1):                                               # coneprog.py:2360-2456
             ds = -lmbdasq + (sigma * mu)[:, None]
-            if i == 1:
+            if i == 1 and use_correction:                             # coneprog.py:2377-2378
                 ds = ds - ws3
             dx = -rx.copy()
             dz = -rz.copy()

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void ipm_rhs_kernel(IpmState S, int i01) {
     double* dz = S.dz + (int64_t)b * m;
     for (int i = tid; i < m; i += 256) {
         double v = -lm[i] * lm[i] + sigma * mu;
-        if (i01 == 1) v -= ws3[i];
+        if (i01 == 1 && S.correction) v -= ws3[i];      // coneprog.py:2377-2378
         v = v / lm[i];                            // sinv
         ds[i] = v;
         dz[i] = -rz[i] - d[i] * v;                // dz := -rz - W' ds

@@ -502,36 +502,16 @@ int launch_mirror_lower_jobs(const TrsvJob* d_jobs, int njobs, int nmax, hipStre
 // Persistent single-launch triangular solve (one right-hand side): workgroup k owns block row k (forward)
 // or block column k (backward) of the 128-blocked factor, streams its off-diagonal blocks while it waits
 // for the x blocks it depends on, solves its diagonal block inside the workgroup and publishes x_k.
-// Inter-workgroup hand-off follows the guide's placement-independent recipe (cdna_hip_programming.md G16):
-// producer: plain stores -> __syncthreads -> one lane: agent-scope release fence, s_waitcnt vmcnt(0), relaxed
-// agent-scope flag store; consumer: one lane polls the flag relaxed (bounded, s_sleep) -> agent-scope acquire
-// fence -> __syncthreads -> plain loads.  All nblk <= #CUs workgroups are co-resident (128 threads, no LDS
-// pressure); every spin is bounded and a timeout sets *err instead of hanging the GPU.
+// Inter-workgroup hand-off (guide G16 form R2, "the data is the flag"): the solved block travels as 256 data-tagged 8-byte
+// granules {epoch, 32-bit half of a double}, each written by ONE relaxed agent-scope (write-through) store and polled with
+// relaxed agent-scope loads by the thread that needs it -- every 8-byte granule is written and read atomically, so no release
+// fence, no acquire fence and no second trip for the payload is needed: a hop costs ~1 us instead of ~4 (flag + two fences +
+// reload; that first-round form is gone).  gran[block][256], zeroed once; epochs never repeat.  All nblk <= #CUs workgroups are
+// co-resident (256 threads, no LDS pressure); every spin is bounded and a timeout sets *err instead of hanging the GPU.
 // ===================================================================================================
 typedef unsigned int u32;
 #define RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-__device__ __forceinline__ bool wait_flag(const u32* flag, u32 epoch, int* err) {
-    // called by ONE lane; returns false on timeout
-    for (unsigned spins = 0; spins < (1u << 24); ++spins) {
-        if (__hip_atomic_load(flag, RLX_AGENT) == epoch) return true;
-        __builtin_amdgcn_s_sleep(2);
-    }
-    atomicExch(err, 1);
-    return false;
-}
-
-__device__ __forceinline__ void publish_flag(u32* flag, u32 epoch) {
-    // called by ONE lane after a __syncthreads() that follows the payload stores
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(flag, epoch, RLX_AGENT);
-}
-
-// GRAN (round 2): the solved block travels as 256 data-tagged 8-byte granules {epoch, 32-bit half of a double}, each
-// written by ONE relaxed agent-scope (write-through) store and polled with relaxed agent-scope loads by the thread that
-// needs it (guide G16 form R2: the data is the flag) -- no release fence, no acquire fence, no second trip for the payload:
-// a hop costs ~1 us instead of ~4 (flag + two fences + the x reload).  gran[block][256], zeroed once; epochs never repeat.
 typedef unsigned long long u64;
 // INV (round 2): the diagonal block is not solved by two 64-step substitution chains (2 x ~2200 clocks of readlane / FMA
 // dependencies per hop) but with M = inv(L_kk) from the factorisation (potrf_tiles_kernel) and ONE step of fixed-precision
@@ -539,10 +519,10 @@ typedef unsigned long long u64;
 //     x0 = M b,   e = b - L_kk x0,   x = x0 + M e        (backward stable like the substitution: Skeel 1980)
 // minv: per 128-block 2 x 16384 doubles, M column-major then M' column-major (the backward solve reads rows of M').
 // jobs (optional): several independent triangular systems in one launch, blockIdx.y = job (the wide supernodes of one level of
-// the sparse engine); every job has its own TRSV_JOB_STRIDE flags / granule blocks.
-template <bool TRANS, bool GRAN, bool INV>
+// the sparse engine); every job has its own TRSV_JOB_STRIDE granule blocks.
+template <bool TRANS, bool INV>
 __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __restrict__ L, int64_t ldl, int n,
-                                                              double* x, u32* flags, u32 epoch, int* err, u64* gran,
+                                                              double* x, u32 epoch, int* err, u64* gran,
                                                               const double* __restrict__ minv,
                                                               const TrsvJob* __restrict__ jobs) {
     if (jobs) {
@@ -551,7 +531,6 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
         ldl = jb.ld;
         n = jb.n;
         x = jb.x;
-        flags += (int64_t)blockIdx.y * TRSV_JOB_STRIDE;
         gran += (int64_t)blockIdx.y * TRSV_JOB_STRIDE * 256;
         if ((int)blockIdx.x * TB >= n) return;
     }
@@ -561,7 +540,6 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
     // xs / ps are double buffered: consecutive stages alternate, so no barrier is needed just to make a buffer writable again
     __shared__ double xs2[2][TB];
     __shared__ double ps2[2][TB];
-    __shared__ int ok;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = tid >> 7, r = tid & (TB - 1);
     const int nblk = (n + TB - 1) / TB;
@@ -628,7 +606,7 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
             for (int c = 0; c < 64; ++c) l0[c] = (mine && ch + c < jb) ? L[idx + (int64_t)(j0 + ch + c) * ldl] : 0.0;   // mirrored L'
 
         }
-        if (GRAN) {
+        {
             const u64* g = gran + (int64_t)j * 256 + tid;
             u64 v = 0;
             bool got = false;
@@ -642,14 +620,6 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
                 if (tid == 0) atomicExch(err, 1);
                 return;                                     // timeout: give up (err is set)
             }
-        } else {
-            if (tid == 0) ok = wait_flag(flags + j, epoch, err) ? 1 : 0;
-            __syncthreads();
-            if (!ok) return;                                // timeout: give up (err is set)
-            if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __syncthreads();
-            if (tid < TB) xs[tid] = (tid < jb) ? x[j0 + tid] : 0.0;
-            __syncthreads();
         }
         {   // four independent chains of 16 instead of one of 64 dependent FMAs (this sits on the hop's critical path)
             double a0 = acc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -662,7 +632,6 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
             }
             acc = (a0 + a1) + (a2 + a3);
         }
-        if (!GRAN) __syncthreads();                    // (flag path: xs is filled before the barrier of the next step)
     }
     // the buffer NOT read by the last step: free to write at once
     double* xs = xs2[nsteps & 1];
@@ -754,385 +723,30 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
         }
     }
     if (mine && half == 0) x[idx] = acc;
-    if (GRAN) {
-        if (half == 0) {          // rows beyond nb publish zeros (consumers mask them anyway): every granule gets its tag
-            const double v = mine ? acc : 0.0;
-            u64* g = gran + (int64_t)k * 256 + 2 * r;
-            const u64 tag = (u64)epoch << 32;
-            __hip_atomic_store(g, tag | (u32)__double2loint(v), RLX_AGENT);
-            __hip_atomic_store(g + 1, tag | (u32)__double2hiint(v), RLX_AGENT);
-        }
-        return;
+    if (half == 0) {          // rows beyond nb publish zeros (consumers mask them anyway): every granule gets its tag
+        const double v = mine ? acc : 0.0;
+        u64* g = gran + (int64_t)k * 256 + 2 * r;
+        const u64 tag = (u64)epoch << 32;
+        __hip_atomic_store(g, tag | (u32)__double2loint(v), RLX_AGENT);
+        __hip_atomic_store(g + 1, tag | (u32)__double2hiint(v), RLX_AGENT);
     }
-    __syncthreads();
-    if (tid == 0) publish_flag(flags + k, epoch);
 }
 
-int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
-                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran, const double* minv,
-                           const TrsvJob* jobs, int njobs) {
+int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err,
+                           hipStream_t st, unsigned long long* gran, const double* minv, const TrsvJob* jobs, int njobs) {
     const int nblk = (n + TB - 1) / TB;      // with jobs: n = the largest order among them
     if (nblk <= 0) return 0;
-    if (jobs && (njobs <= 0 || nblk > TRSV_JOB_STRIDE || !gran)) return -1;
-    static const bool use_flags = getenv("MI355KKT_TRSV") && !strcmp(getenv("MI355KKT_TRSV"), "flag");
-    static const bool no_inv = getenv("MI355KKT_TRSV_NOINV") != nullptr;
+    if (!gran || (jobs && (njobs <= 0 || nblk > TRSV_JOB_STRIDE))) return -1;
     const dim3 g(nblk, jobs ? njobs : 1), b(256);
-    if (gran && !use_flags && minv && !no_inv) {
+    if (minv) {
         if (trans)
-            hipLaunchKernelGGL((trsv_persistent_kernel<true, true, true>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
+            hipLaunchKernelGGL((trsv_persistent_kernel<true, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
         else
-            hipLaunchKernelGGL((trsv_persistent_kernel<false, true, true>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
-    } else if (gran && !use_flags) {
-        if (trans)
-            hipLaunchKernelGGL((trsv_persistent_kernel<true, true, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
-        else
-            hipLaunchKernelGGL((trsv_persistent_kernel<false, true, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
+            hipLaunchKernelGGL((trsv_persistent_kernel<false, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
     } else if (trans)
-        hipLaunchKernelGGL((trsv_persistent_kernel<true, false, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
+        hipLaunchKernelGGL((trsv_persistent_kernel<true, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
     else
-        hipLaunchKernelGGL((trsv_persistent_kernel<false, false, false>), g, b, 0, st, L, ldl, n, x, flags, epoch, err, gran, minv, jobs);
-    KKT_HIP_CHECK(hipGetLastError());
-    return 0;
-}
-
-// ===================================================================================================
-// Round 3: the same persistent solve with the hop's critical path cut to ONE matrix-vector stage.
-//
-//   forward:  x_k = L_kk^-1 (b_k - sum_{j<k} L_kj x_j)
-//                 = [ L_kk^-1 (b_k - sum_{j<=k-3} L_kj x_j) ]  -  Z2_k x_{k-2}  -  Z1_k x_{k-1},     Zq_k = L_kk^-1 L_{k,k-q}
-//
-//   The two blocks next to the diagonal are pre-multiplied by L_kk^-1 ONCE per factorisation (trsv_z_prepare: a backward
-//   stable multi-right-hand-side solve, 2 x 128 columns per block row and direction).  In the solve, workgroup k
-//     A  accumulates b_k - L_kj x_j for j <= k-3 as those x_j arrive (strips prefetched before each wait, as before),
-//     B  solves the diagonal block for that partial sum (M = L_kk^-1 from the tile Cholesky + one step of fixed-precision
-//        refinement against L_kk, three matrix-vector stages) -- this needs x_{k-3} only, so it runs while x_{k-2}, x_{k-1} are
-//        still being produced two and one hops up the chain,
-//     C  subtracts Z2_k x_{k-2},
-//     D  subtracts Z1_k x_{k-1} and publishes: between "x_{k-1} arrived" and "x_k published" sit one 64-term dot product per
-//        thread, one lane-pair exchange (DPP, no LDS) and the granule stores.
-//   256 threads = two ADJACENT lanes per row (columns 0..63 / 64..127 of the strip): the pair sum is a DPP move, every stage has
-//   one barrier (vector -> LDS -> all threads).  Requires n % 128 == 0 (the callers fall back to trsv_persistent_kernel).
-//   The backward solve is the mirror image on L' (read from the mirrored upper triangle), Zq_k = L_kk^-T L_{k+q,k}'.
-// ===================================================================================================
-__device__ __forceinline__ double pair_sum(double v) {           // v(lane) + v(lane ^ 1), identical bits in both lanes
-    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]
-    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
-    return v + __hiloint2double(hi, lo);
-}
-
-__device__ long long* g_trsvz_ts = nullptr;   // developer aid: 8 stamps (shader clock) per block of the last trsv_z launch when set
-int set_trsvz_ts(long long* dptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_trsvz_ts), &dptr, sizeof(dptr)) == hipSuccess ? 0 : -2; }
-#define TZ_TS(i_) do { if (tts && tid == 0) tts[(int64_t)k * 8 + (i_)] = (long long)__builtin_readcyclecounter(); } while (0)
-constexpr int ZV = TB + 2;       // LDS vector: entries 64..127 sit 2 doubles further (the two lanes of a pair read different banks)
-
-template <bool TRANS>
-__global__ __launch_bounds__(256) void trsv_z_kernel(const double* __restrict__ L, int64_t ldl, int n, double* x, u32 epoch,
-                                                     int* err, u64* gran, const double* __restrict__ minv,
-                                                     const double* __restrict__ zmat) {
-    __shared__ __attribute__((aligned(16))) double vb[4][ZV + 2];
-    __shared__ int bad;
-    // LDS-only barrier: `s_waitcnt lgkmcnt(0); s_barrier` (__syncthreads() also waits for every outstanding GLOBAL load)
-    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-    const int tid = threadIdx.x;
-    const int r = tid >> 1, half = tid & 1, ch = 64 * half;
-    const int nblk = n / TB;
-    // TWO workgroups per block row (2 nblk <= #CUs): role 0 accumulates the far blocks and solves the diagonal block (phases A, B)
-    // and hands c'_k on; role 1, the finisher, holds the strips of the two pre-multiplied blocks from the start of the launch
-    // and does phases C, D.  A single workgroup would have to fetch 4 x 128 KB of strips per block row on the chain (a compute
-    // unit pulls ~45 GB/s: 3 us per strip, measured), the split leaves each with two.
-    const int role = (int)blockIdx.x >= nblk ? 1 : 0;
-    const int kb = (int)blockIdx.x - role * nblk;
-    const int k = TRANS ? (nblk - 1 - kb) : kb;             // dispatch order ~ dependency order
-    const int k0 = k * TB, idx = k0 + r;
-    const int vpos = r + ((r >> 6) << 1);                  // my row's slot in an LDS vector
-    const int vh = ch + 2 * half;                          // first slot of my half of a vector
-    if (tid == 0) bad = 0;
-    lds_barrier();
-    int vi = 0;                                            // running stage counter: stage t uses vb[t & 3]
-    long long* tts = g_trsvz_ts;
-    u64* granx = gran;                                     // x blocks: granule block j
-    u64* granc = gran + (int64_t)(nblk + 1) * 256;         // c' blocks (role 0 -> role 1 of the same block row)
-    const int nsteps = TRANS ? (nblk - 1 - k) : k;
-
-    // receive a 128-vector published as 256 data-tagged granules into an LDS vector: thread tid polls granule tid
-    auto recv = [&](const u64* g0, double* buf) -> bool {
-        const u64* g = g0 + tid;
-        u64 v = 0;
-        bool got = false;
-        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
-            v = __hip_atomic_load(g, RLX_AGENT);
-            if ((u32)(v >> 32) == epoch) { got = true; break; }
-            __builtin_amdgcn_s_sleep(1);
-        }
-        reinterpret_cast<u32*>(buf)[2 * vpos + half] = (u32)v;
-        if (!got) bad = 1;
-        lds_barrier();
-        if (bad) {
-            if (tid == 0) atomicExch(err, 1);
-            return false;                                  // timeout: give up (err is set)
-        }
-        return true;
-    };
-    auto publish = [&](u64* g0, double v) {                // every thread one granule: its word of the row's value
-        const u64 tag = (u64)epoch << 32;
-        const u32 word = half ? (u32)__double2hiint(v) : (u32)__double2loint(v);
-        __hip_atomic_store(g0 + tid, tag | word, RLX_AGENT);
-    };
-    // 64-term dot product of a register strip with my half of an LDS vector, four independent chains
-    auto dot64 = [&](const double (&a)[64], const double* v) {
-        const double* w = v + vh;
-        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
-#pragma unroll
-        for (int c = 0; c < 64; c += 4) {
-            d0 = fma(a[c], w[c], d0);
-            d1 = fma(a[c + 1], w[c + 1], d1);
-            d2 = fma(a[c + 2], w[c + 2], d2);
-            d3 = fma(a[c + 3], w[c + 3], d3);
-        }
-        return (d0 + d1) + (d2 + d3);
-    };
-    // Strip loads: element c of a thread's strip = column (first + c) of a column-major block, row r.  Addressed as a WAVE-UNIFORM
-    // column base (scalar registers, bumped by scalar adds) + one 32-bit lane offset: no per-load address registers (with 64-bit
-    // lane addresses hipcc formed the 64 addresses of a strip up front and spilled ~90 registers around every strip).
-    auto ldu = [](const double* ubase, uint32_t voff) -> double {
-        return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(ubase) + (uint64_t)voff);
-    };
-    const uint32_t voffM = (uint32_t)((r + ch * TB) * 8);                       // inside a 128 x 128 block with ld 128
-    const uint32_t voffL = (uint32_t)(((int64_t)r + (int64_t)ch * ldl) * 8);    // inside a block of L (ld = ldl)
-    double ra[64], rb[64];
-
-    if (role == 1) {
-        // ---- the finisher: x_k = c'_k - Z2_k x_{k-2} - Z1_k x_{k-1}; both strips are in registers long before they are needed
-        const double* Zk = zmat + (int64_t)k * (2 * TB * TB);
-        if (nsteps >= 1) {
-#pragma unroll
-            for (int c = 0; c < 64; ++c) ra[c] = ldu(Zk + c * TB, voffM);
-        }
-        if (nsteps >= 2) {
-#pragma unroll
-            for (int c = 0; c < 64; ++c) rb[c] = ldu(Zk + TB * TB + c * TB, voffM);
-        }
-        if (tid == 0 && tts) tts[(int64_t)k * 8 + 0] = (long long)__builtin_readcyclecounter();
-        double t2 = 0.0;
-        double* buf;
-        if (nsteps >= 2) {                                 // phase C (needs x_{k-2} only: usually before c' arrives)
-            buf = vb[vi++ & 3];
-            if (!recv(granx + (int64_t)(TRANS ? k + 2 : k - 2) * 256, buf)) return;
-            t2 = pair_sum(dot64(rb, buf));
-        }
-        TZ_TS(3);
-        buf = vb[vi++ & 3];
-        if (!recv(granc + (int64_t)k * 256, buf)) return;   // c'_k from the other workgroup of this block row
-        TZ_TS(4);
-        double xk = buf[vpos] - t2;
-        if (nsteps >= 1) {                                 // phase D: the only stage between the arrival of x_{k-1} and my publication
-            buf = vb[vi++ & 3];
-            if (!recv(granx + (int64_t)(TRANS ? k + 1 : k - 1) * 256, buf)) return;
-            TZ_TS(5);
-            xk -= pair_sum(dot64(ra, buf));
-        }
-        TZ_TS(6);
-        publish(granx + (int64_t)k * 256, xk);
-        if (half == 0) x[idx] = xk;
-        TZ_TS(7);
-        return;
-    }
-
-    // ---- role 0: phase A (blocks three and more hops up the chain), phase B (diagonal block), hand c'_k to the finisher
-    double acc = half == 0 ? x[idx] : 0.0;
-    {
-        const double* Mk = minv + (int64_t)k * (2 * TB * TB) + (TRANS ? TB * TB : 0);
-        const double* Lkk = L + k0 + (int64_t)k0 * ldl;
-#pragma unroll
-        for (int j = 0; j < 64; ++j) ra[j] = ldu(Mk + j * TB, voffM);
-#pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            const int c = ch + j;
-            const double v = ldu(Lkk + (int64_t)j * ldl, voffL);   // unconditional (the other triangle holds the mirrored copy)
-            rb[j] = (TRANS ? c >= r : c <= r) ? v : 0.0;
-        }
-    }
-    const int nfar = nsteps > 2 ? nsteps - 2 : 0;
-    for (int s = 0; s < nfar; ++s) {
-        const int j = TRANS ? (nblk - 1 - s) : s;
-        double l0[64];
-        const double* Lkj = L + k0 + (int64_t)j * TB * ldl;          // block (k, j)  (TRANS: of the mirrored L')
-#pragma unroll
-        for (int c = 0; c < 64; ++c) l0[c] = ldu(Lkj + (int64_t)c * ldl, voffL);
-        double* buf = vb[vi++ & 3];
-        if (!recv(granx + (int64_t)j * 256, buf)) return;
-        acc -= dot64(l0, buf);
-    }
-    TZ_TS(1);
-    // phase B: c' = L_kk^-1 (b_k - sum of phase A): x0 = M b, e = b - L_kk x0, c' = x0 + M e
-    const double b = pair_sum(acc);
-    double* buf = vb[vi++ & 3];
-    if (half == 0) buf[vpos] = b;
-    lds_barrier();
-    const double x0 = pair_sum(dot64(ra, buf));
-    buf = vb[vi++ & 3];
-    if (half == 0) buf[vpos] = x0;
-    lds_barrier();
-    const double e = b - pair_sum(dot64(rb, buf));
-    buf = vb[vi++ & 3];
-    if (half == 0) buf[vpos] = e;
-    lds_barrier();
-    const double cp = x0 + pair_sum(dot64(ra, buf));
-    publish(granc + (int64_t)k * 256, cp);
-    TZ_TS(2);
-}
-
-// block (k, k -+ q) of the factor (forward: the lower block; backward: the mirrored upper block = L_{k+q,k}') -> Z storage
-__global__ __launch_bounds__(256) void trsv_z_gather_kernel(const double* __restrict__ L, int64_t ldl, int nblk,
-                                                            double* __restrict__ zmat) {
-    const int k = blockIdx.x, q = 1 + (int)blockIdx.y, dir = blockIdx.z;
-    double* Z = zmat + ((int64_t)dir * nblk + k) * (2 * TB * TB) + (int64_t)(q - 1) * TB * TB;
-    const int j = dir ? k + q : k - q;
-    const bool have = j >= 0 && j < nblk;
-    const double* B = L + (int64_t)k * TB + (int64_t)(have ? j : 0) * TB * ldl;
-    for (int e = threadIdx.x; e < TB * TB; e += 256) {
-        const int i = e & (TB - 1), c = e >> 7;
-        Z[e] = have ? B[i + (int64_t)c * ldl] : 0.0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// trsv_z_prep_kernel: Z = L_kk^-1 B (forward) / L_kk^-T B (backward) for one 128 x 128 block B on the matrix cores:
-//     Y0 = M B,   R = B - L_kk Y0,   Z = Y0 + M R          (M = inv(L_kk) from the tile Cholesky; one step of fixed-precision
-// refinement against L_kk, the scheme of the triangular solves themselves).  One 256-thread workgroup per block; the right
-// operand of each product sits in LDS ([column][k], stride 130: conflict-free fragment reads), the triangular left operand
-// is read from global memory in MFMA fragment form (16 consecutive rows per k), k-steps beyond the diagonal are skipped.
-// Output tile of wave w: rows 32 w .. 32 w + 31, all 128 columns; MFMA roles chosen so that a lane's accumulator registers are
-// consecutive ROWS of the output (lane (li, lq), register r  <->  row r0 + li, column c0 + lq + 4 r).
-// ---------------------------------------------------------------------------------------------------
-typedef double zd4 __attribute__((ext_vector_type(4)));
-constexpr int ZXS = TB + 2;      // LDS stride of one column of the right operand
-
-template <bool TRANS, bool NEG>
-__device__ __forceinline__ void zprep_mm(zd4 (&acc)[2][8], const double* __restrict__ A, int64_t lda,
-                                         const double* __restrict__ Xs, int wave, int lane) {
-    const int li = lane & 15, lk = lane >> 4;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-        const int r0 = 32 * wave + 16 * rt;
-        // lower triangular left operand: k <= row, i.e. k-steps 0 .. (r0 + 15) / 4; upper (TRANS): k >= row, from r0 / 4 on
-        const int ks0 = TRANS ? r0 / 4 : 0, ks1 = TRANS ? TB / 4 : (r0 + 16) / 4;
-        const int row = r0 + li;
-        for (int ks = ks0; ks < ks1; ++ks) {
-            const int kcol = 4 * ks + lk;
-            double bv = A[row + (int64_t)kcol * lda];
-            bv = (TRANS ? kcol >= row : kcol <= row) ? (NEG ? -bv : bv) : 0.0;
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
-                const double av = Xs[(16 * ct + li) * ZXS + kcol];
-                acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[rt][ct], 0, 0, 0);
-            }
-        }
-    }
-}
-
-template <bool TRANS>
-__global__ __launch_bounds__(256) void trsv_z_prep_kernel(const double* __restrict__ L, int64_t ldl, int nblk,
-                                                          const double* __restrict__ minv, double* __restrict__ zmat) {
-    extern __shared__ __attribute__((aligned(16))) double Xs[];          // 128 columns x ZXS
-    const int k = blockIdx.x, q = 1 + (int)blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lq = lane >> 4;
-    double* Z = zmat + ((int64_t)(TRANS ? nblk : 0) + k) * (2 * TB * TB) + (int64_t)(q - 1) * TB * TB;
-    const int j = TRANS ? k + q : k - q;
-    if (j < 0 || j >= nblk) {                                             // no such block: zeros (never read by the solve)
-        for (int e = tid; e < TB * TB; e += 256) Z[e] = 0.0;
-        return;
-    }
-    // forward: the lower block (k, k - q); backward: the mirrored upper block (k, k + q) = L_{k+q,k}'
-    const double* B = L + (int64_t)k * TB + (int64_t)j * TB * ldl;
-    const double* Lkk = L + (int64_t)k * TB + (int64_t)k * TB * ldl;       // (the triangle the direction needs; the other is masked)
-    const double* M = minv + (int64_t)k * (2 * TB * TB) + (TRANS ? TB * TB : 0);
-    for (int e = tid; e < TB * TB; e += 256) Xs[(e >> 7) * ZXS + (e & (TB - 1))] = B[(e & (TB - 1)) + (int64_t)(e >> 7) * ldl];
-    __syncthreads();
-    zd4 y0[2][8], rr[2][8];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) y0[rt][ct] = zd4{0.0, 0.0, 0.0, 0.0};
-    zprep_mm<TRANS, false>(y0, M, TB, Xs, wave, lane);                     // Y0 = M B
-    // R = B - L_kk Y0: B in accumulator layout straight from memory, Y0 through LDS
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                rr[rt][ct][r] = B[(32 * wave + 16 * rt + li) + (int64_t)(16 * ct + lq + 4 * r) * ldl];
-    __syncthreads();                                                       // every wave has read B from Xs
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Xs[(16 * ct + lq + 4 * r) * ZXS + 32 * wave + 16 * rt + li] = y0[rt][ct][r];
-    __syncthreads();
-    zprep_mm<TRANS, true>(rr, Lkk, ldl, Xs, wave, lane);
-    __syncthreads();
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Xs[(16 * ct + lq + 4 * r) * ZXS + 32 * wave + 16 * rt + li] = rr[rt][ct][r];
-    __syncthreads();
-    zprep_mm<TRANS, false>(y0, M, TB, Xs, wave, lane);                     // Z = Y0 + M R
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Z[(32 * wave + 16 * rt + li) + (16 * ct + lq + 4 * r) * TB] = y0[rt][ct][r];
-}
-
-size_t trsv_z_doubles(int n) { return (size_t)2 * (n / TB) * 2 * TB * TB; }
-
-// Z1, Z2 of every block row for both directions; L must hold the factor AND its mirrored upper triangle (launch_mirror_lower)
-int trsv_z_prepare(const double* L, int64_t ldl, int n, double* zmat, hipStream_t st, const double* minv) {
-    if (n <= 0 || n % TB) return -1;
-    const int nblk = n / TB;
-    static const bool use_trsm = getenv("MI355KKT_TRSVZ_PREP") && !strcmp(getenv("MI355KKT_TRSVZ_PREP"), "trsm");
-    if (minv && !use_trsm) {
-        // matrix-core path: one workgroup per block, M = inv(L_kk) + one refinement step (trsv_z_prep_kernel)
-        constexpr size_t lds = sizeof(double) * TB * ZXS;
-        static bool attr_set = false;
-        if (!attr_set) {
-            KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_z_prep_kernel<false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(trsv_z_prep_kernel<true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((trsv_z_prep_kernel<false>), dim3(nblk, 2), dim3(256), lds, st, L, ldl, nblk, minv, zmat);
-        hipLaunchKernelGGL((trsv_z_prep_kernel<true>), dim3(nblk, 2), dim3(256), lds, st, L, ldl, nblk, minv, zmat);
-        KKT_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
-    // substitution path (the reference for the kernel above, $MI355KKT_TRSVZ_PREP=trsm): gather the blocks, two batched
-    // multi-right-hand-side triangular solves
-    hipLaunchKernelGGL(trsv_z_gather_kernel, dim3(nblk, 2, 2), dim3(256), 0, st, L, ldl, nblk, zmat);
-    KKT_HIP_CHECK(hipGetLastError());
-    const int64_t sL = (int64_t)TB * (ldl + 1), sX = 2 * TB * TB;
-    if (int e = launch_trsm_lower(L, ldl, TB, zmat, TB, 2 * TB, 0, st, nblk, sL, sX)) return e;
-    if (int e = launch_trsm_lower(L, ldl, TB, zmat + (int64_t)nblk * sX, TB, 2 * TB, 1, st, nblk, sL, sX)) return e;
-    return 0;
-}
-
-int launch_trsv_z(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
-                  unsigned long long* gran, const double* minv, const double* zmat) {
-    if (n <= 0 || n % TB || !gran || !minv || !zmat) return -1;
-    const int nblk = n / TB;
-    // two workgroups per block row (accumulate + diagonal solve | finisher); granule blocks [0, nblk) carry x, [nblk + 1, 2 nblk + 1) c'
-    if (trans)
-        hipLaunchKernelGGL((trsv_z_kernel<true>), dim3(2 * nblk), dim3(256), 0, st, L, ldl, n, x, epoch, err, gran, minv,
-                           zmat + (int64_t)nblk * 2 * TB * TB);
-    else
-        hipLaunchKernelGGL((trsv_z_kernel<false>), dim3(2 * nblk), dim3(256), 0, st, L, ldl, n, x, epoch, err, gran, minv, zmat);
+        hipLaunchKernelGGL((trsv_persistent_kernel<false, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

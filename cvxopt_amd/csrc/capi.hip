@@ -201,7 +201,7 @@ static int sblocks_bind(ST& S, const SBlocks& sb, const std::vector<int>& s, int
     S.sigs = take(sb.sums); S.sigz = take(sb.sums); S.jw = take(sb.ns ? sb.jw_doubles() : 1);
     S.jww = S.jw + (sb.ns ? s_jw_doubles(sb.maxs, 1024) : 0);
     S.smin = sb.mins; S.smax = sb.maxs;
-    S.swmax = getenv("MI355KKT_SDP_WAVE_MAX") ? std::min(16, std::max(-16, atoi(getenv("MI355KKT_SDP_WAVE_MAX")))) : 16;
+    S.swmax = dev_knob("MI355KKT_SDP_WAVE_MAX") ? std::min(16, std::max(-16, atoi(dev_knob("MI355KKT_SDP_WAVE_MAX")))) : 16;
     S.sdim = di; S.soff = di + sb.ns; S.sloff = di + 2 * sb.ns;
     if (sb.ns) {
         std::vector<int> h(3 * (size_t)sb.ns);
@@ -210,7 +210,7 @@ static int sblocks_bind(ST& S, const SBlocks& sb, const std::vector<int>& s, int
             h[k] = s[k]; h[sb.ns + k] = off; h[2 * sb.ns + k] = loff;
             off += s[k] * s[k]; loff += s[k];
         }
-        if (hipMemcpy(di, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return MI355KKT_EHIP;
+        if (memcpy_sync(di, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return MI355KKT_EHIP;
     }
     return 0;
 }
@@ -248,7 +248,7 @@ static int lp_alloc(LpWork& w, int n, int ml, const std::vector<int>& q, const s
         std::vector<int> hq(2 * (size_t)nq);
         int off = ml;
         for (int k = 0; k < nq; ++k) { hq[k] = off; hq[nq + k] = q[k]; off += q[k]; }
-        if (hipMemcpy(qi + 8, hq.data(), sizeof(int) * 2 * nq, hipMemcpyHostToDevice) != hipSuccess) return MI355KKT_EHIP;
+        if (memcpy_sync(qi + 8, hq.data(), sizeof(int) * 2 * nq, hipMemcpyHostToDevice) != hipSuccess) return MI355KKT_EHIP;
     }
     S.qoff = qi + 8; S.qdim = qi + 8 + nq;
     return 0;
@@ -304,7 +304,7 @@ static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, const s
         std::vector<int> hq(2 * (size_t)nq);
         int off = ml;
         for (int k = 0; k < nq; ++k) { hq[k] = off; hq[nq + k] = q[k]; off += q[k]; }
-        if (hipMemcpy(qi + 8, hq.data(), sizeof(int) * 2 * nq, hipMemcpyHostToDevice) != hipSuccess) return MI355KKT_EHIP;
+        if (memcpy_sync(qi + 8, hq.data(), sizeof(int) * 2 * nq, hipMemcpyHostToDevice) != hipSuccess) return MI355KKT_EHIP;
     }
     S.qoff = qi + 8; S.qdim = qi + 8 + nq;
     return 0;
@@ -338,7 +338,6 @@ struct mi355kkt_solver {
     int krows = 0;             // rows of the scaled constraint matrix the SYRK contracts over (packed for 's' cones)
     double* dWst = nullptr;    // staging for host-side W (di | v | beta)
     // persistent triangular solves: hand-off flags (one word per 128-block), launch epoch, timeout word
-    unsigned int* dflags = nullptr;
     unsigned long long* dgran = nullptr;   // data-tagged granules of the solved blocks (256 per 128-block)
     unsigned int epoch = 0;
     int* derr = nullptr;
@@ -367,8 +366,6 @@ struct mi355kkt_solver {
     LpWork lp;                 // device-resident conelp loop (mi355kkt_conelp)
     QpWork qp;                 // device-resident coneqp loop with second-order cones (mi355kkt_coneqp)
     double* dRef = nullptr;    // iterative refinement of the ldl flavours: bx0 | by0 | zs0 | rx | ry | rz | t  (2 n + 2 p + 3 krows doubles)
-    double* dZ = nullptr;      // trsv_z: L_kk^-1 L_{k,k-1}, L_kk^-1 L_{k,k-2} (and the mirrored pair) of every 128-block row, per factor
-    bool z_valid = false;
     double* dHsym = nullptr;   // full symmetric copy of H for the residual product P x
     bool hsym_valid = false;
     double* dIpmWork = nullptr;
@@ -376,6 +373,9 @@ struct mi355kkt_solver {
     // options['show_progress'] of the reference drivers: called once per iteration of the device-resident loops
     mi355kkt_progress_fn progress = nullptr;
     void* progress_user = nullptr;
+    // mi355kkt_set_option
+    int use_correction = 1;    // options['use_correction'] of solvers.coneqp (coneprog.py:1781)
+    int ldl_refine = 2;        // refinement steps of the ldl / ldl2 flavours against the 3 x 3 system
 };
 
 // per-iteration report of a device-resident loop: the scalar block comes back with one small copy (the loop has just
@@ -384,7 +384,7 @@ static int report_progress(mi355kkt_solver* h, int it, const double* d_sc, int n
     if (!h->progress) return 0;
     double sc[64];
     if (nsc > 64) nsc = 64;
-    KKT_HIP_CHECK(hipMemcpy(sc, d_sc, sizeof(double) * nsc, hipMemcpyDeviceToHost));
+    KKT_HIP_CHECK(memcpy_sync(sc, d_sc, sizeof(double) * nsc, hipMemcpyDeviceToHost));
     double vals[8];
     for (int k = 0; k < nidx; ++k) vals[k] = sc[idx[k]];
     int nv = nidx;
@@ -461,15 +461,15 @@ int mi355kkt_dev_free(void* ptr) try {
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_dev_free"); }
 int mi355kkt_memcpy_h2d(void* dst, const void* src, size_t bytes) try {
-    if (bytes) KKT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    if (bytes) KKT_HIP_CHECK(memcpy_sync(dst, src, bytes, hipMemcpyHostToDevice));
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_memcpy_h2d"); }
 int mi355kkt_memcpy_d2h(void* dst, const void* src, size_t bytes) try {
-    if (bytes) KKT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    if (bytes) KKT_HIP_CHECK(memcpy_sync(dst, src, bytes, hipMemcpyDeviceToHost));
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_memcpy_d2h"); }
 int mi355kkt_memcpy_d2d(void* dst, const void* src, size_t bytes) try {
-    if (bytes) KKT_HIP_CHECK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToDevice));
+    if (bytes) KKT_HIP_CHECK(memcpy_sync(dst, src, bytes, hipMemcpyDeviceToDevice));
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_memcpy_d2d"); }
 int mi355kkt_device_synchronize(void) try {
@@ -544,12 +544,10 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     if ((rc = alloc(&h->dWst, 2 * C + (size_t)nq + 8))) return fail(rc);
     {
         const size_t nfl = N / 128 + 2 + 64 * TRSV_JOB_STRIDE;    // + room for 64 batched jobs of the sparse engine's wide supernodes
-        if (hipMalloc(&h->dflags, sizeof(unsigned int) * nfl) != hipSuccess) return fail(MI355KKT_ENOMEM);
-        if (hipMemset(h->dflags, 0, sizeof(unsigned int) * nfl) != hipSuccess) return fail(MI355KKT_EHIP);
         if (hipMalloc(&h->dgran, sizeof(unsigned long long) * nfl * 256) != hipSuccess) return fail(MI355KKT_ENOMEM);
-        if (hipMemset(h->dgran, 0, sizeof(unsigned long long) * nfl * 256) != hipSuccess) return fail(MI355KKT_EHIP);
+        if (memset_sync(h->dgran, 0, sizeof(unsigned long long) * nfl * 256) != hipSuccess) return fail(MI355KKT_EHIP);
         if (hipMalloc(&h->derr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
-        if (hipMemset(h->derr, 0, sizeof(int)) != hipSuccess) return fail(MI355KKT_EHIP);
+        if (memset_sync(h->derr, 0, sizeof(int)) != hipSuccess) return fail(MI355KKT_EHIP);
         if (hipHostMalloc(&h->herr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
         *h->herr = 0;
     }
@@ -600,9 +598,7 @@ void mi355kkt_destroy(mi355kkt_solver* h) try {
     }
     if (h->cst) (void)hipStreamDestroy(h->cst);
     if (h->ev_h) (void)hipEventDestroy(h->ev_h);
-    if (h->dflags) (void)hipFree(h->dflags);
     if (h->dgran) (void)hipFree(h->dgran);
-    if (h->dZ) (void)hipFree(h->dZ);
     if (h->dRef) (void)hipFree(h->dRef);
     if (h->derr) (void)hipFree(h->derr);
     if (h->herr) (void)hipHostFree(h->herr);
@@ -624,7 +620,7 @@ static int upload_dense(double** owned, const double* src, int64_t ld, int rows,
     const size_t bytes = sizeof(double) * dmax((size_t)rows * cols, 1);
     KKT_HIP_CHECK(hipMalloc(owned, bytes));
     if (rows > 0 && cols > 0)
-        KKT_HIP_CHECK(hipMemcpy2D(*owned, sizeof(double) * rows, src, sizeof(double) * ld, sizeof(double) * rows, cols,
+        KKT_HIP_CHECK(memcpy2d_sync(*owned, sizeof(double) * rows, src, sizeof(double) * ld, sizeof(double) * rows, cols,
                                   hipMemcpyHostToDevice));
     return 0;
 }
@@ -652,7 +648,7 @@ int mi355kkt_set_G_rows(mi355kkt_solver* h, int row0, int nrows, const double* s
     if (!h->G_owned || h->dG != h->G_owned) { set_last_error("set_G_rows: G must have been set with set_G_dense / set_G_csc"); return MI355KKT_EINVAL; }
     if (int e = bind(h)) return e;
     if (nrows > 0 && h->n > 0)
-        KKT_HIP_CHECK(hipMemcpy2D(h->G_owned + row0, sizeof(double) * h->ldG, src, sizeof(double) * ldsrc, sizeof(double) * nrows,
+        KKT_HIP_CHECK(memcpy2d_sync(h->G_owned + row0, sizeof(double) * h->ldG, src, sizeof(double) * ldsrc, sizeof(double) * nrows,
                                   h->n, hipMemcpyHostToDevice));
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_set_G_rows"); }
@@ -733,13 +729,13 @@ int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr_in, const int64
     KKT_HIP_CHECK(hipMalloc(&h->dAri, sizeof(int) * z));
     KKT_HIP_CHECK(hipMalloc(&h->dAv, sizeof(double) * z));
     KKT_HIP_CHECK(hipMalloc(&h->dAvc, sizeof(double) * z));
-    KKT_HIP_CHECK(hipMemcpy(h->dArp, rp.data(), sizeof(int64_t) * (p + 1), hipMemcpyHostToDevice));
-    KKT_HIP_CHECK(hipMemcpy(h->dAcp, cp.data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
+    KKT_HIP_CHECK(memcpy_sync(h->dArp, rp.data(), sizeof(int64_t) * (p + 1), hipMemcpyHostToDevice));
+    KKT_HIP_CHECK(memcpy_sync(h->dAcp, cp.data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
     if (nnz > 0) {
-        KKT_HIP_CHECK(hipMemcpy(h->dAci, ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
-        KKT_HIP_CHECK(hipMemcpy(h->dAri, ri.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
-        KKT_HIP_CHECK(hipMemcpy(h->dAv, values.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
-        KKT_HIP_CHECK(hipMemcpy(h->dAvc, vc.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(memcpy_sync(h->dAci, ci.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(memcpy_sync(h->dAri, ri.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(memcpy_sync(h->dAv, values.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(memcpy_sync(h->dAvc, vc.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
     }
     h->A_sparse = true;
     h->dA = nullptr;
@@ -764,7 +760,7 @@ int mi355kkt_set_sparse_problem_aug(mi355kkt_solver* h, const int64_t* gcolptr, 
         for (int64_t k = gcolptr[j]; k < gcolptr[j + 1]; ++k)
             if (growind[k] < 0 || growind[k] >= rows) { set_last_error("set_sparse_problem: G row index out of range"); return MI355KKT_EINVAL; }
     if (int e = sparse_engine_create(h->sp, h->n, rows, gcolptr, growind, gvalues, hcolptr, hrowind, hvalues)) return e;
-    h->sp.t_flags = h->dflags; h->sp.t_gran = h->dgran; h->sp.t_err = h->derr; h->sp.t_epoch = &h->epoch; h->sp.t_njobs_max = 64;
+    h->sp.t_gran = h->dgran; h->sp.t_err = h->derr; h->sp.t_epoch = &h->epoch; h->sp.t_njobs_max = 64;
     h->sparse = true;
     h->firstcall = true;
     h->sp_extra = extra_rows;
@@ -833,7 +829,7 @@ int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) try {
     if (ldH < (h->n > 1 ? h->n : 1)) { set_last_error("set_H_dense: ldH too small"); return MI355KKT_EINVAL; }
     if (!h->H_owned) KKT_HIP_CHECK(hipMalloc(&h->H_owned, sizeof(double) * dmax((size_t)h->n * h->n, 1)));
     if (h->n > 0)
-        KKT_HIP_CHECK(hipMemcpy2D(h->H_owned, sizeof(double) * h->n, H, sizeof(double) * ldH, sizeof(double) * h->n,
+        KKT_HIP_CHECK(memcpy2d_sync(h->H_owned, sizeof(double) * h->n, H, sizeof(double) * ldH, sizeof(double) * h->n,
                                   h->n, hipMemcpyHostToDevice));
     h->dH = h->H_owned;
     h->ldH = h->n > 1 ? h->n : 1;
@@ -901,6 +897,18 @@ int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg) try {
     h->kktreg = reg;
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_set_kktreg"); }
+
+int mi355kkt_set_option(mi355kkt_solver* h, const char* name, double value) try {
+    if (!h || !name) { set_last_error("set_option: null argument"); return MI355KKT_EINVAL; }
+    if (!strcmp(name, "use_correction")) { h->use_correction = value != 0.0 ? 1 : 0; return 0; }
+    if (!strcmp(name, "ldl_refinement")) {
+        if (!(value >= 0.0) || value > 16.0) { set_last_error("set_option: ldl_refinement must be in 0..16"); return MI355KKT_EINVAL; }
+        h->ldl_refine = (int)value;
+        return 0;
+    }
+    set_last_error("set_option: unknown option '%s'", name);
+    return MI355KKT_EINVAL;
+} catch (...) { return kkt_catch("mi355kkt_set_option"); }
 
 // info word -> host (synchronises the stream)
 static int fetch_info(mi355kkt_solver* h, int* info) {
@@ -1110,19 +1118,8 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
         if (int e = launch_potrf(h->dK, h->p, h->p, h->pw, h->st)) return e;
     }
     // L' into the (otherwise unused) upper triangle of S: the transposed persistent solve streams it coalesced
-    h->z_valid = false;
-    if ((h->n + 127) / 128 <= h->num_cus && !getenv("MI355KKT_NO_PERSISTENT_TRSV")) {
+    if ((h->n + 127) / 128 <= h->num_cus)
         if (int e = launch_mirror_lower(h->dS, h->n, h->n, h->st)) return e;
-        // round 3: the two blocks next to the diagonal pre-multiplied by L_kk^-1 (blas2.hip: trsv_z_kernel) -- needs the 128 x 128
-        // inverses of the tile Cholesky of THIS matrix and whole 128-blocks; experimental, $MI355KKT_TRSV=z switches it on
-        static const bool use_z = getenv("MI355KKT_TRSV") && !strcmp(getenv("MI355KKT_TRSV"), "z");   // opt-in (see DESIGN: not faster yet)
-        if (use_z && h->n % 128 == 0 && h->n >= 256 && 2 * (h->n / 128) <= h->num_cus && h->pw.minv_n == h->n &&
-            h->pw.minv_of == h->dS && h->dgran) {
-            if (!h->dZ) KKT_HIP_CHECK(hipMalloc(&h->dZ, sizeof(double) * trsv_z_doubles(h->n)));
-            if (int e = trsv_z_prepare(h->dS, h->n, h->n, h->dZ, h->st, h->pw.d_minv)) return e;
-            h->z_valid = true;
-        }
-    }
     KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
     if (int e = fetch_info(h, &info)) return e;
     (void)hipEventElapsedTime(&h->t_syrk, h->ev[0], h->ev[1]);
@@ -1209,9 +1206,9 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     // test measured a 3 x 3 residual of 3e-9 against the reference's 2e-13 with d spanning 1e-3 .. 1e3.  They therefore get one
     // step of iterative refinement against the 3 x 3 system, written in the scaled space the engine works in:
     //     [H A' Gs'; A 0 0; Gs 0 -I] [ux; uy; w] = [bx; by; zs],   Gs = W^-T G,  zs = W^-T bz,  w = W uz.
-    // ($MI355KKT_LDL_REFINE=<steps>, 0 switches it off; not applied with kktreg, whose regularised system is the one to be solved.)
+    // (mi355kkt_set_option(h, "ldl_refinement", steps), 0 switches it off; not applied with kktreg, whose regularised system is the one to be solved.)
     // Two steps by default: one brings d in 1e-3 .. 1e3 from 3e-9 to 2e-15 (the reference: 2e-13), d in 1e-5 .. 1e5 needs the second.
-    static const int ref_steps = getenv("MI355KKT_LDL_REFINE") ? atoi(getenv("MI355KKT_LDL_REFINE")) : 2;
+    const int ref_steps = h->ldl_refine;
     const bool refine = ref_steps > 0 && (h->kind == MI355KKT_LDL || h->kind == MI355KKT_LDL2) && h->kktreg == 0.0 && mk > 0 && n > 0;
     double *bx0 = nullptr, *by0 = nullptr, *zs0 = nullptr, *rx = nullptr, *ry = nullptr, *rz = nullptr, *tt = nullptr;
     if (refine) {
@@ -1228,11 +1225,9 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
         return e;
     if (refine) KKT_HIP_CHECK(hipMemcpyAsync(zs0, h->dzs, sizeof(double) * mk, hipMemcpyDeviceToDevice, st));
     // triangular solves with L: one persistent launch each when every 128-block can own a resident workgroup
-    const bool persistent = (n + 127) / 128 <= h->num_cus && !getenv("MI355KKT_NO_PERSISTENT_TRSV");
+    const bool persistent = (n + 127) / 128 <= h->num_cus;      // (larger orders: the multi-kernel blocked solve)
     auto tri_solve = [&](int trans, double* xv) -> int {
-        if (persistent && h->z_valid && h->pw.minv_n == n && h->pw.minv_of == h->dS)
-            return launch_trsv_z(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran, h->pw.d_minv, h->dZ);
-        if (persistent) return launch_trsv_persistent(h->dS, n, n, xv, trans, h->dflags, ++h->epoch, h->derr, st, h->dgran,
+        if (persistent) return launch_trsv_persistent(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran,
                                                       (h->pw.minv_n == n && h->pw.minv_of == h->dS) ? h->pw.d_minv : nullptr);
         return launch_trsm_lower(h->dS, n, n, xv, n, 1, trans, st);
     };
@@ -1299,7 +1294,7 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
 static int check_handoff(mi355kkt_solver* h) {   // stream must be idle
     if (*h->herr) {
         *h->herr = 0;
-        (void)hipMemset(h->derr, 0, sizeof(int));
+        (void)memset_sync(h->derr, 0, sizeof(int));
         set_last_error("persistent triangular solve: hand-off timeout (a workgroup was not co-resident?)");
         return MI355KKT_EHIP;
     }
@@ -1310,7 +1305,7 @@ static int check_handoff(mi355kkt_solver* h) {   // stream must be idle
 // back with the per-iteration word (the stream has just been synchronised) instead of iterating on garbage
 static int loop_check_handoff(mi355kkt_solver* h) {
     if (!h->derr) return 0;
-    KKT_HIP_CHECK(hipMemcpy(h->herr, h->derr, sizeof(int), hipMemcpyDeviceToHost));
+    KKT_HIP_CHECK(memcpy_sync(h->herr, h->derr, sizeof(int), hipMemcpyDeviceToHost));
     return check_handoff(h);
 }
 
@@ -1365,7 +1360,7 @@ int mi355kkt_get_factor(mi355kkt_solver* h, double* L, int64_t ldL) try {
     if (int e = bind(h)) return e;
     KKT_HIP_CHECK(hipStreamSynchronize(h->st));
     if (h->n > 0)
-        KKT_HIP_CHECK(hipMemcpy2D(L, sizeof(double) * ldL, h->dS, sizeof(double) * h->n, sizeof(double) * h->n, h->n,
+        KKT_HIP_CHECK(memcpy2d_sync(L, sizeof(double) * ldL, h->dS, sizeof(double) * h->n, sizeof(double) * h->n, h->n,
                                   hipMemcpyDeviceToHost));
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_get_factor"); }
@@ -1401,9 +1396,17 @@ struct mi355kkt_batch {
     double *dGs = nullptr, *dV = nullptr, *dBeta = nullptr;
     bool w_set = false;               // v, beta of the current factorisation are in dV, dBeta
     QpWork qp;                        // state of the device-resident loop with cones (coneqp_ipm.hip, one workgroup per problem)
+    int use_correction = 1;           // options['use_correction'] of solvers.coneqp (coneprog.py:1781), mi355kkt_batch_set_option
 };
 
 extern "C" {
+
+int mi355kkt_batch_set_option(mi355kkt_batch* b, const char* name, double value) try {
+    if (!b || !name) { set_last_error("batch_set_option: null argument"); return MI355KKT_EINVAL; }
+    if (!strcmp(name, "use_correction")) { b->use_correction = value != 0.0 ? 1 : 0; return 0; }
+    set_last_error("batch_set_option: unknown option '%s'", name);
+    return MI355KKT_EINVAL;
+} catch (...) { return kkt_catch("mi355kkt_batch_set_option"); }
 
 int mi355kkt_batch_create(mi355kkt_batch** out, int device, int nbatch, int n, int ml) try {
     return mi355kkt_batch_create_eq(out, device, nbatch, n, ml, 0);
@@ -1477,7 +1480,7 @@ int mi355kkt_batch_create_cones(mi355kkt_batch** out, int device, int nbatch, in
     if (hipMalloc(&b->d_qoff, sizeof(int) * hq.size()) != hipSuccess) return fail(MI355KKT_ENOMEM);
     b->d_qdim = b->d_qoff + nq;
     b->d_large = b->d_qoff + 2 * nq;
-    if (hipMemcpy(b->d_qoff, hq.data(), sizeof(int) * hq.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355KKT_EHIP);
+    if (memcpy_sync(b->d_qoff, hq.data(), sizeof(int) * hq.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355KKT_EHIP);
     const size_t B = nbatch;
     if (hipMalloc(&b->dGs, sizeof(double) * B * (size_t)cdim * n) != hipSuccess) return fail(MI355KKT_ENOMEM);
     if (hipMalloc(&b->dV, sizeof(double) * B * b->sumq) != hipSuccess) return fail(MI355KKT_ENOMEM);
@@ -1512,10 +1515,10 @@ int mi355kkt_batch_set_problem(mi355kkt_batch* b, const double* G, const double*
     KKT_HIP_CHECK(hipSetDevice(b->device));
     const hipMemcpyKind kind = is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const size_t B = b->nbatch, N = b->n, M = b->ml;
-    if (M) KKT_HIP_CHECK(hipMemcpy(b->dG, G, sizeof(double) * B * M * N, kind));
+    if (M) KKT_HIP_CHECK(memcpy_sync(b->dG, G, sizeof(double) * B * M * N, kind));
     b->hasH = (H != nullptr);
     if (H) {
-        KKT_HIP_CHECK(hipMemcpy(b->dH, H, sizeof(double) * B * N * N, kind));
+        KKT_HIP_CHECK(memcpy_sync(b->dH, H, sizeof(double) * B * N * N, kind));
         // only tril(H) is meaningful on input; mirror it so that H x is a plain product (SYRK reads tril only)
         hipLaunchKernelGGL(symmetrize_kernel, dim3((b->n + 15) / 16, (b->n + 15) / 16, b->nbatch), dim3(16, 16), 0, b->st,
                            b->dH, b->n, (int64_t)(N * N));
@@ -1529,7 +1532,7 @@ int mi355kkt_batch_set_A(mi355kkt_batch* b, const double* A, int is_device) try 
     if (!b || (b->p > 0 && !A)) { set_last_error("batch_set_A: null argument"); return MI355KKT_EINVAL; }
     if (b->p == 0) return 0;
     KKT_HIP_CHECK(hipSetDevice(b->device));
-    KKT_HIP_CHECK(hipMemcpy(b->dA, A, sizeof(double) * (size_t)b->nbatch * b->p * b->n, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    KKT_HIP_CHECK(memcpy_sync(b->dA, A, sizeof(double) * (size_t)b->nbatch * b->p * b->n, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     b->singular = false;
     b->firstcall = true;
     return 0;
@@ -1563,9 +1566,8 @@ int mi355kkt_batch_products(mi355kkt_batch* b, const double* x, const double* z,
         if (z && M) { KKT_HIP_CHECK(hipMemcpyAsync(b->dz, z, sizeof(double) * B * M, hipMemcpyHostToDevice, b->st)); dz = b->dz; }
     }
     auto out_dev = [&](double* user, double* scratch) { return is_device ? user : scratch; };
-    // both residual products of an interior-point iteration in one pass over G (device-resident callers); $MI355KKT_BATCH_FUSED_PRODUCTS=0: two passes
-    static const bool fused_ok = !(getenv("MI355KKT_BATCH_FUSED_PRODUCTS") && atoi(getenv("MI355KKT_BATCH_FUSED_PRODUCTS")) == 0);
-    if (fused_ok && is_device && Gx && GTz && M && N && dx && dz) {
+    // both residual products of an interior-point iteration in one pass over G (device-resident callers)
+    if (is_device && Gx && GTz && M && N && dx && dz) {
         if (int e = launch_gemv_nt_fused(b->dG, (int64_t)M, b->ml, b->n, dx, dz, Gx, GTz, b->dwork, b->st, b->nbatch, sG)) return e;
         Gx = nullptr;
         GTz = nullptr;
@@ -1813,6 +1815,7 @@ static int batch_coneqp_cones(mi355kkt_batch* b, const double* q, const double* 
     QpWork& w = b->qp;
     QpState& S0 = w.S;
     S0.nbatch = nb;                    // (a batch of one problem still runs the batched control flow below)
+    S0.correction = b->use_correction;
     const QpState& S = S0;
     hipStream_t st = b->st;
     struct Guard { mi355kkt_batch* b; ~Guard() { b->defer_sync = false; } } guard{b};
@@ -1925,6 +1928,7 @@ int mi355kkt_batch_coneqp_eq(mi355kkt_batch* b, const double* q, const double* h
         return batch_coneqp_cones(b, q, h, bvec, maxiters, abstol, reltol, feastol, x, y, s, z, status, iters, pcost, dcost, gap,
                                   iterations_run);
     if (int e = ipm_alloc(b->ipm, b->nbatch, b->n, b->ml, b->p)) return e;
+    b->ipm.S.correction = b->use_correction;
     const IpmState& S = b->ipm.S;
     struct Guard { mi355kkt_batch* b; ~Guard() { b->defer_sync = false; } } guard{b};
     b->defer_sync = true;
@@ -2062,6 +2066,7 @@ int mi355kkt_coneqp_lp(mi355kkt_solver* hs, const double* q, const double* hv, c
     const int n = hs->n, m = hs->ml;
     const int np = hs->p;
     if (int e = ipm_alloc(hs->ipm, 1, n, m, np)) return e;
+    hs->ipm.S.correction = hs->use_correction;
     const IpmState& S = hs->ipm.S;
     hipStream_t st = hs->st;
     if (int e = ensure_hsym(hs)) return e;
@@ -2314,6 +2319,7 @@ int mi355kkt_coneqp_init(mi355kkt_solver* hs, const double* q, const double* hv,
     const int n = hs->n, m = hs->cdim, np = hs->p;
     if (refinement < 0) refinement = (hs->q.empty() && hs->s.empty()) ? 0 : 1;
     if (int e = qp_alloc(hs->qp, n, hs->ml, hs->q, hs->s, np)) return e;
+    hs->qp.S.correction = hs->use_correction;
     if (int e = symmetrize_G_sblocks(hs)) return e;
     QpWork& w = hs->qp;
     const QpState& S = w.S;
@@ -2478,11 +2484,7 @@ static int cur_num_cus() {
 int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
                             int64_t ldH, double* dS, int64_t ldS, float* ms) try {
     static SyrkPlan plan;   // cached for repeated calls with one shape (profiling loops)
-    int kc = m;             // developer experiment: MI355KKT_SYRK_KCHUNK=<rows per launch> (must divide m)
-    if (const char* e = getenv("MI355KKT_SYRK_KCHUNK")) {
-        const int v = atoi(e);
-        if (v > 0 && m % v == 0) kc = v;
-    }
+    const int kc = m;
     if (plan.n != n || plan.K != kc || !plan.d_items)
         if (int e = build_syrk_plan(plan, n, kc, cur_num_cus())) return e;
     OpTimer t(ms);
@@ -2516,7 +2518,7 @@ int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* gr
  *   level_ptr[nlevels+1], level_sn[ns], level_nsmall[nlevels], vb_ptr[nlevels+1], vb[5 * nvb] (off, h, w, col0, supernode),
  *   heavy_ptr[nlevels+1], heavy[nheavy]    (header[10] = nvb, header[11] = nheavy).
  * Returns the number of int64 entries of the plan (call with cap = 0 to size the buffer), or a negative error code. */
-int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
+int64_t mi355kkt_test_symbolic_plan(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
                                      const int64_t* hrowind, int64_t* out, int64_t cap) try {
     SparseSymbolic S;
     if (int e = symbolic_analyze(S, n, m, gcolptr, growind, hcolptr, hrowind)) return e;
@@ -2559,7 +2561,7 @@ int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const
     put(S.heavy_ptr, nl + 1);
     put(S.heavy, nheavy);
     return (p - out == need) ? need : (int64_t)MI355KKT_EINVAL;
-} catch (...) { return (int64_t)kkt_catch("mi355kkt_debug_symbolic_plan"); }
+} catch (...) { return (int64_t)kkt_catch("mi355kkt_test_symbolic_plan"); }
 
 int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
                            const double* dv, const double* dbeta, float* ms) try {
@@ -2576,6 +2578,7 @@ int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX
 } catch (...) { return kkt_catch("mi355kkt_op_cone_scale"); }
 
 }  // extern "C"
+#ifdef MI355KKT_DEBUG
 __global__ void hwid_probe_kernel(unsigned* out) {
     if (threadIdx.x == 0) {
         out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_REG_HW_ID, all 32 bits
@@ -2589,17 +2592,20 @@ int mi355kkt_debug_hwid(unsigned* out, int nblocks) try {
     unsigned* d = nullptr;
     KKT_HIP_CHECK(hipMalloc(&d, sizeof(unsigned) * 2 * nblocks));
     hipLaunchKernelGGL(hwid_probe_kernel, dim3(nblocks), dim3(64), 0, nullptr, d);
-    KKT_HIP_CHECK(hipMemcpy(out, d, sizeof(unsigned) * 2 * nblocks, hipMemcpyDeviceToHost));
+    KKT_HIP_CHECK(memcpy_sync(out, d, sizeof(unsigned) * 2 * nblocks, hipMemcpyDeviceToHost));
     (void)hipFree(d);
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_debug_hwid"); }
+}  // extern "C"
+#endif  // MI355KKT_DEBUG
+extern "C" {
 /* Host execution of the second-order-cone operations the device-resident loops use (the SAME source, cone_ops.h, compiled
  * for the host): for the CPU parity tests against the reference's misc / misc_solvers functions.  One cone of dimension mk.
  * op: 0 sprod (x := x o y), 1 sinv (x := y o\ x), 2 ssqr (x := y o y), 3 scale2 (x := H(y^{1/2}) x; inverse: arg),
  * 4 scale (x := W x with v = y, beta = w[0]; inverse: arg), 5 jnrm2 -> w[0], 6 compute_scaling (s = x, z = y -> v = w[0:mk],
  * lambda = w[mk:2mk], beta = w[2mk]), 7 update_scaling (s = x, z = y normalised in place; v = w[0:mk], lambda = w[mk:2mk],
  * beta = w[2mk] updated), 8 max_step term ||x1|| - x0 -> w[0]. */
-int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w) try {
+int mi355kkt_test_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w) try {
     if (mk < 1 || !x) return MI355KKT_EINVAL;
     switch (op) {
         case 0: mi355kkt::q_sprod(x, y, mk); break;
@@ -2614,14 +2620,14 @@ int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, d
         default: return MI355KKT_EINVAL;
     }
     return 0;
-} catch (...) { return kkt_catch("mi355kkt_debug_cone_op_host"); }
+} catch (...) { return kkt_catch("mi355kkt_test_cone_op_host"); }
 /* The same for the 's'-block operations (cone_ops_s.h, instantiated with a team of one thread): one block of order m, column-
  * major.  inverse = arg & 1, trans = arg & 2.
  * op: 0 scale (x := W x: r'xr | rxr' (trans) | rti x rti' (inverse) | rti'x rti (both)), 1 sprod (x := (xy + yx)/2),
  * 2 sprod diag = 'D' (x := x o diag(lam); inverse: sinv), 3 scale2 (lam, x; inverse), 4 smallest eigenvalue -> lam[0],
  * 5 eigenvalue decomposition (x := eigenvectors, lam := eigenvalues ascending), 6 compute_scaling (s = x, z = y -> r, rti, lam),
  * 7 update_scaling (Ls = x, Lz = y destroyed; r, rti, lam updated), 8 potrf (x := chol(x), strict upper zeroed). */
-int mi355kkt_debug_sdp_op_host(int op, int m, int arg, double* x, double* y, double* r, double* rti, double* lam) try {
+int mi355kkt_test_sdp_op_host(int op, int m, int arg, double* x, double* y, double* r, double* rti, double* lam) try {
     if (m < 1 || !x) return MI355KKT_EINVAL;
     const mi355kkt::ParHost par;
     const size_t mm = (size_t)m * m;
@@ -2641,36 +2647,36 @@ int mi355kkt_debug_sdp_op_host(int op, int m, int arg, double* x, double* y, dou
         default: return MI355KKT_EINVAL;
     }
     return 0;
-} catch (...) { return kkt_catch("mi355kkt_debug_sdp_op_host"); }
+} catch (...) { return kkt_catch("mi355kkt_test_sdp_op_host"); }
 /* ... and on the DEVICE: one workgroup (team = 0: 1024 threads, the loops' configuration) or one wave (team = 1) runs the
  * operation on copies of the host arrays (any may be NULL where the operation does not use it); results come back in place. */
-int mi355kkt_debug_sdp_op_device(int op, int m, int arg, int team, double* x, double* y, double* r, double* rti, double* lam) try {
+int mi355kkt_test_sdp_op_device(int op, int m, int arg, int team, double* x, double* y, double* r, double* rti, double* lam) try {
     if (m < 1 || !x || mi355kkt_device_count() < 1) return MI355KKT_EINVAL;
     const size_t mm = (size_t)m * m, nw = 3 * mm + mi355kkt::s_jw_doubles(m, 1024) + 64;
     double* d = nullptr;
     KKT_HIP_CHECK(hipMalloc(&d, sizeof(double) * (4 * mm + (size_t)m + nw + 8)));
     double *dx = d, *dy = dx + mm, *dr = dy + mm, *drti = dr + mm, *dl = drti + mm, *dw = dl + m, *dout = dw + nw;
-    KKT_HIP_CHECK(hipMemset(d, 0, sizeof(double) * (4 * mm + (size_t)m + nw + 8)));
-    KKT_HIP_CHECK(hipMemcpy(dx, x, sizeof(double) * mm, hipMemcpyHostToDevice));
-    if (y) KKT_HIP_CHECK(hipMemcpy(dy, y, sizeof(double) * mm, hipMemcpyHostToDevice));
-    if (r) KKT_HIP_CHECK(hipMemcpy(dr, r, sizeof(double) * mm, hipMemcpyHostToDevice));
-    if (rti) KKT_HIP_CHECK(hipMemcpy(drti, rti, sizeof(double) * mm, hipMemcpyHostToDevice));
-    if (lam) KKT_HIP_CHECK(hipMemcpy(dl, lam, sizeof(double) * m, hipMemcpyHostToDevice));
+    KKT_HIP_CHECK(memset_sync(d, 0, sizeof(double) * (4 * mm + (size_t)m + nw + 8)));
+    KKT_HIP_CHECK(memcpy_sync(dx, x, sizeof(double) * mm, hipMemcpyHostToDevice));
+    if (y) KKT_HIP_CHECK(memcpy_sync(dy, y, sizeof(double) * mm, hipMemcpyHostToDevice));
+    if (r) KKT_HIP_CHECK(memcpy_sync(dr, r, sizeof(double) * mm, hipMemcpyHostToDevice));
+    if (rti) KKT_HIP_CHECK(memcpy_sync(drti, rti, sizeof(double) * mm, hipMemcpyHostToDevice));
+    if (lam) KKT_HIP_CHECK(memcpy_sync(dl, lam, sizeof(double) * m, hipMemcpyHostToDevice));
     if (int e = mi355kkt::sdp_op_debug_launch(op, m, arg, team, dx, dy, dr, drti, dl, dw, dout, nullptr)) { (void)hipFree(d); return e; }
     KKT_HIP_CHECK(hipDeviceSynchronize());
-    KKT_HIP_CHECK(hipMemcpy(x, dx, sizeof(double) * mm, hipMemcpyDeviceToHost));
-    if (y) KKT_HIP_CHECK(hipMemcpy(y, dy, sizeof(double) * mm, hipMemcpyDeviceToHost));
-    if (r) KKT_HIP_CHECK(hipMemcpy(r, dr, sizeof(double) * mm, hipMemcpyDeviceToHost));
-    if (rti) KKT_HIP_CHECK(hipMemcpy(rti, drti, sizeof(double) * mm, hipMemcpyDeviceToHost));
+    KKT_HIP_CHECK(memcpy_sync(x, dx, sizeof(double) * mm, hipMemcpyDeviceToHost));
+    if (y) KKT_HIP_CHECK(memcpy_sync(y, dy, sizeof(double) * mm, hipMemcpyDeviceToHost));
+    if (r) KKT_HIP_CHECK(memcpy_sync(r, dr, sizeof(double) * mm, hipMemcpyDeviceToHost));
+    if (rti) KKT_HIP_CHECK(memcpy_sync(rti, drti, sizeof(double) * mm, hipMemcpyDeviceToHost));
     double ret = 0.0;
-    KKT_HIP_CHECK(hipMemcpy(&ret, dout, sizeof(double), hipMemcpyDeviceToHost));
+    KKT_HIP_CHECK(memcpy_sync(&ret, dout, sizeof(double), hipMemcpyDeviceToHost));
     if (lam) {
-        KKT_HIP_CHECK(hipMemcpy(lam, dl, sizeof(double) * m, hipMemcpyDeviceToHost));
+        KKT_HIP_CHECK(memcpy_sync(lam, dl, sizeof(double) * m, hipMemcpyDeviceToHost));
         if (op == 4) lam[0] = ret;
     }
     (void)hipFree(d);
     return (op == 6 || op == 8) ? (int)ret : 0;
-} catch (...) { return kkt_catch("mi355kkt_debug_sdp_op_device"); }
+} catch (...) { return kkt_catch("mi355kkt_test_sdp_op_device"); }
 
 /* The same operations run by a TEAM of nt host threads (pthread barrier as the team barrier): the SPMD form of cone_ops_s.h
  * with real concurrency between the threads of a team, as on the device (workgroup teams of 1024, wave teams of 64), for the
@@ -2706,7 +2712,7 @@ struct ParThreads {
 };
 }  // namespace
 extern "C" {
-int mi355kkt_debug_sdp_op_host_team(int op, int m, int arg, int nt, double* x, double* y, double* r, double* rti, double* lam) try {
+int mi355kkt_test_sdp_op_host_team(int op, int m, int arg, int nt, double* x, double* y, double* r, double* rti, double* lam) try {
     if (m < 1 || !x || nt < 1 || nt > 1024) return MI355KKT_EINVAL;
     const size_t mm = (size_t)m * m;
     std::vector<double> w(3 * mm + mi355kkt::s_jw_doubles(m, nt) + m), red(nt);
@@ -2738,11 +2744,11 @@ int mi355kkt_debug_sdp_op_host_team(int op, int m, int arg, int nt, double* x, d
     pthread_barrier_destroy(&bar);
     if (op == 4) lam[0] = ret[0];
     return rc[0];
-} catch (...) { return kkt_catch("mi355kkt_debug_sdp_op_host_team"); }
+} catch (...) { return kkt_catch("mi355kkt_test_sdp_op_host_team"); }
 /* The static SYRK schedule for an n x n result contracted over K on a device with num_cus compute units, as plain integers
  * (host only): out[8 * i + 0..7] = ti, tj, k0, k1, slot, first, nparts, 0 of work item i, in launch order.  For the CPU tests
  * of the plan's invariants.  Returns the number of items (<= max_items are written). */
-int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit) try {
+int mi355kkt_test_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit) try {
     std::vector<mi355kkt::SyrkItem> items, split_tiles;
     int ns = 0;
     mi355kkt::make_syrk_items(n, K, num_cus, allow_split != 0, items, split_tiles, ns);
@@ -2754,13 +2760,13 @@ int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* ou
     if (nslabs) *nslabs = ns;
     if (nsplit) *nsplit = (int)split_tiles.size();
     return (int)items.size();
-} catch (...) { return kkt_catch("mi355kkt_debug_syrk_plan"); }
+} catch (...) { return kkt_catch("mi355kkt_test_syrk_plan"); }
 /* Fill-reducing ordering of a symmetric pattern (host only, for the CPU tests of csrc/ordering.cpp): colptr/rowind = CSC
  * pattern of any part of the matrix that contains each off-diagonal pair at least once; method 0 = choose, 1 = nested
  * dissection, 2 = approximate minimum degree.  perm[new] = old.  stats[0..6] = method chosen, nnz(L) and flops of the
  * dissection candidate, nnz(L) and flops of the minimum-degree candidate, supernodal tree heights of the two; stats[7] = 1
  * when the two column-count algorithms agree on the returned order (and with the tree / counts the analysis keeps). */
-int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats) try {
+int mi355kkt_test_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats) try {
     if (n < 0 || !colptr || !perm) return MI355KKT_EINVAL;
     mi355kkt::Graph adj(n);
     for (int j = 0; j < n; ++j)
@@ -2789,18 +2795,22 @@ int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind,
         stats[7] = (fast == slow && fast == info.colcount && par == info.parent) ? 1.0 : 0.0;
     }
     return 0;
-} catch (...) { return kkt_catch("mi355kkt_debug_ordering"); }
-int mi355kkt_debug_potf2_skip(int mask) { return mi355kkt::set_potf2_skip(mask); }
+} catch (...) { return kkt_catch("mi355kkt_test_ordering"); }
+#ifdef MI355KKT_DEBUG       // include/mi355kkt_debug.h: process-global developer switches, never in a production build
 int mi355kkt_debug_tile_ts(void* dptr) { return mi355kkt::set_tile_ts((long long*)dptr); }
 int mi355kkt_debug_potf2_ts(void* dptr) { return mi355kkt::set_potf2_ts((long long*)dptr); }
-int mi355kkt_debug_trsvz_ts(void* dptr) { return mi355kkt::set_trsvz_ts((long long*)dptr); }
 int mi355kkt_debug_syrk_skip(int mask) { return mi355kkt::set_syrk_skip(mask); }
-int mi355kkt_debug_throw(int kind) try {
+#endif
+/* test / developer knobs (csrc/knobs.h): value == NULL unsets one, name == NULL unsets all */
+int mi355kkt_test_set_knob(const char* name, const char* value) try {
+    return mi355kkt::set_dev_knob(name, value);
+} catch (...) { return kkt_catch("mi355kkt_test_set_knob"); }
+int mi355kkt_test_throw(int kind) try {
     if (kind == 0) throw std::bad_alloc();
     if (kind == 1) throw std::runtime_error("requested by the caller");
     if (kind == 2) throw 42;
     return 0;
-} catch (...) { return kkt_catch("mi355kkt_debug_throw"); }
+} catch (...) { return kkt_catch("mi355kkt_test_throw"); }
 
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops) { return run_mfma_f64_peak(iters, cur_num_cus(), tflops); }
 
@@ -2812,7 +2822,7 @@ int mi355kkt_op_potrf(double* dA, int64_t ldA, int n, int* info, float* ms) try 
     int rc = launch_potrf(dA, ldA, n, w, nullptr);
     if (!rc) rc = t.finish();
     if (!rc) {
-        if (hipMemcpy(w.h_info, w.d_info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = MI355KKT_EHIP;
+        if (memcpy_sync(w.h_info, w.d_info, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = MI355KKT_EHIP;
         if (info) *info = *w.h_info;
     }
     potrf_work_free(w);

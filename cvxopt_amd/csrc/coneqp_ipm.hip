@@ -192,7 +192,7 @@ __global__ __launch_bounds__(1024) void qp_build_kernel(QpState S, QpBuf D, QpBu
     __syncthreads();
     for (int i = tid; i < m; i += blockDim.x) {
         double v = 0.0;
-        if (i01 == 1) v -= S.ws3[i];
+        if (i01 == 1 && S.correction) v -= S.ws3[i];    // coneprog.py:2377-2378
         v -= D.s[i];
         D.s[i] = v;
         D.z[i] = -S.rz[i];

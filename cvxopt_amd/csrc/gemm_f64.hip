@@ -27,9 +27,16 @@ struct __attribute__((aligned(8))) d2u { double x, y; };   // 8-byte aligned pai
 
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
-__device__ int g_syrk_skip = 0;   // developer ablation switch (bit0 no global fetch, bit1 no LDS stash, bit2 no barrier, bit4 no static priority,
-                                  // bit5 long diagonal tiles through the general path, bit6 no block masks on diagonal tiles there); 0 in production
+// Developer ablation switch of the SYRK (bit0 no global fetch, bit1 no LDS stash, bit2 no barrier, bit4 no static priority, bit5 long
+// diagonal tiles through the general path, bit6 no block masks on diagonal tiles there): results are WRONG when it is set, so it only
+// exists in -DMI355KKT_DEBUG builds (include/mi355kkt_debug.h); production code compiles the constant 0.
+#ifdef MI355KKT_DEBUG
+__device__ int g_syrk_skip = 0;
 int set_syrk_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_syrk_skip), &v, sizeof(int)) == hipSuccess ? 0 : -2; }
+#define SYRK_SKIP g_syrk_skip
+#else
+#define SYRK_SKIP 0
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // 64x64 wave tile: acc[t][u] += Js[t-th 16 rows][k] * Is[u-th 16 rows][k] over one BK slab.
@@ -151,9 +158,9 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
         stash(0);
     }
     __syncthreads();
-    const int skip = g_syrk_skip & 15;
-    const bool no_prio = (g_syrk_skip >> 4) & 1;
-    if (diag && (it.k1 - it.k0) >= 8192 && !((g_syrk_skip >> 5) & 1)) {
+    const int skip = SYRK_SKIP & 15;
+    const bool no_prio = (SYRK_SKIP >> 4) & 1;
+    if (diag && (it.k1 - it.k0) >= 8192 && !((SYRK_SKIP >> 5) & 1)) {
         // ---- diagonal tiles (round 3): only the 36 16 x 16 blocks on / below the diagonal are computed, 9 per wave -- wave w owns
         //      block rows w and 7 - w (w + 1 and 8 - w blocks) -- instead of 16 per wave with 28 of the 64 above the diagonal
         //      (the whole wave (0, 1) among them).  At n = 8192 the diagonal tiles are 3 % of all tiles, at the batched engine's
@@ -228,17 +235,17 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
         const int li = lane & 15, lk = lane >> 4;
         // static priority for the second-dispatched half of the workgroup (guide T5 / MICROARCH "static priority for the younger
         // half"): one s_setprio for the whole main loop, no per-phase flips.  Measured on the n = 8192, m = 16384 SYRK:
-        // 17.20 -> 16.97 ms (all waves at priority 1, or alternate workgroups: no gain).  g_syrk_skip bit 4 switches it off.
+        // 17.20 -> 16.97 ms (all waves at priority 1, or alternate workgroups: no gain).  SYRK_SKIP bit 4 switches it off.
         if (!no_prio && wave >= 2) __builtin_amdgcn_s_setprio(1);
         // Diagonal tiles in THIS loop (round 3; short contractions -- the batched engine's K = 1024, where 4 of a problem's 10 tiles
-        // are diagonal -- and every diagonal tile when bit 5 of g_syrk_skip sends the long ones here too): of the four 64 x 64
+        // are diagonal -- and every diagonal tile when bit 5 of SYRK_SKIP sends the long ones here too): of the four 64 x 64
         // quadrants, (i-half 0, j-half 1) lies above the diagonal and the two diagonal ones need 10 of their 16 blocks.  The wave
         // of the unused quadrant takes the j-blocks 2, 3 of quadrant (1, 0), its owner keeps j-blocks 0, 1 (8 blocks each); the
         // diagonal quadrants skip the 6 blocks above the diagonal (10 blocks): 10 instead of 16 MFMAs per 4-deep k group on the
-        // critical wave.  All predicates are wave-uniform (scalar branches; MFMA ignores EXEC).  g_syrk_skip bit 6: off.
+        // critical wave.  All predicates are wave-uniform (scalar branches; MFMA ignores EXEC).  SYRK_SKIP bit 6: off.
         unsigned tmask = 0xFu;                 // the j-blocks (t) this wave computes
         bool tri = false;                      // only blocks with i-block u >= j-block t
-        const bool dmask = DMASK && diag && it.slot < 0 && !((g_syrk_skip >> 6) & 1);
+        const bool dmask = DMASK && diag && it.slot < 0 && !((SYRK_SKIP >> 6) & 1);
         if (DMASK && dmask) {
             const int w = __builtin_amdgcn_readfirstlane(wave);
             if (w == 2) { wj = 0; wi = 1; tmask = 0xCu; }
@@ -365,221 +372,6 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
     }
 }
 
-// ===================================================================================================
-// The same SYRK with NO LDS and NO barrier: every wave loads the MFMA operand fragments of its 64 x 64 tile
-// straight from global memory (L1 / L2) into registers, a few 8-deep chunks of k ahead of their use.
-//
-//   v_mfma_f64_16x16x4_f64 wants lane (li = lane & 15, lk = lane >> 4) to hold X[row li][k lk].  Which k the four lane
-//   groups stand for is free as long as both operands agree, so a chunk of 8 k is mapped  k = kc + 2 lk + g  (g = 0, 1: the
-//   chunk's two MFMA groups): lane (li, lk) needs 16 contiguous bytes G[kc + 2 lk .. + 1][column li] per 16-column block —
-//   ONE global_load_dwordx4 per block and chunk, and the four lk groups of a column read one contiguous 64-byte piece.
-//   Per wave and chunk: 4 + 4 operand loads (+ 1 for di) against 32 MFMAs (2048 matrix-pipe cycles); no ds_write, no
-//   ds_read, no s_barrier — the waves of a workgroup never wait for each other, so nothing but a late load can idle the
-//   matrix pipe.  The price is register space (PF + 1 chunks of fragments next to the 128 accumulator registers) and twice
-//   the L1 requests of the LDS version (each operand panel is loaded by the two waves that share it).
-//   di rides on the fragments (both operands are multiplied, like the reference's (di G)'(di G), misc.py:1418-1422).
-//   Columns beyond n are clamped to n - 1 (their results are never stored), a last partial chunk is loaded from clamped
-//   addresses with zero weights.
-// ===================================================================================================
-template <bool SCALED, int TA, int NS, int SC, int SN, int LPQ>
-__device__ __forceinline__ void direct_chunk(d4 (&acc)[TA][4], d2 (&fa)[NS][TA], d2 (&fb)[NS][4], d2 (&fw)[NS],
-                                             const char* __restrict__ pJ, const char* __restrict__ pI,
-                                             const char* __restrict__ pw, const uint32_t (&offJ)[TA],
-                                             const uint32_t (&offI)[4], uint32_t offw) {
-    if (SCALED) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) fb[SC][u] *= fw[SC];
-    }
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int t = 0; t < TA; ++t) {
-            if (SCALED && g == 0) fa[SC][t] *= fw[SC];       // J block t is first needed here (its load was issued last)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[t][u] = MFMA_F64(fa[SC][t][g], fb[SC][u][g], acc[t][u]);
-            // LPQ loads of the chunk PF ahead after every MFMA quad (front-loaded for LPQ > 1: the later a load is issued, the
-            // closer its first use), in the order of first use: the four I blocks (every quad needs them all), the weights,
-            // then the J blocks (block t is first used by quad t)
-            const int q0 = (g * TA + t) * LPQ;
-#pragma unroll
-            for (int q = q0; q < q0 + LPQ; ++q) {
-                if (q < 4) {
-                    const d2u v = *reinterpret_cast<const d2u*>(pI + offI[q]);
-                    fb[SN][q] = d2{v.x, v.y};
-                    if (q == 0 && SCALED) {
-                        const d2u w = *reinterpret_cast<const d2u*>(pw + offw);
-                        fw[SN] = d2{w.x, w.y};
-                    }
-                } else if (q - 4 < TA) {
-                    const d2u v = *reinterpret_cast<const d2u*>(pJ + offJ[q - 4]);
-                    fa[SN][q - 4] = d2{v.x, v.y};
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-}
-
-template <int TA>
-__device__ __forceinline__ void syrk_store_tile(const SyrkItem& it, const d4 (&acc)[TA][4], int n, int i0, int j0, int wi,
-                                                int wj, int lane, double* __restrict__ C, int64_t ldc,
-                                                const double* __restrict__ P, int64_t ldp, double* __restrict__ slabs) {
-    // lane holds D[row=(lane>>4)+4r -> j][col=lane&15 -> i]
-    const int li = lane & 15, lq = lane >> 4;
-    if (it.slot < 0) {
-#pragma unroll
-        for (int t = 0; t < TA; ++t)
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = i0 + wi * 64 + u * 16 + li;
-                    const int j = j0 + wj * 64 + t * 16 + lq + 4 * r;
-                    if (i < n && j < n && i >= j) {
-                        double v = acc[t][u][r];
-                        if (P) v += P[i + (int64_t)j * ldp];
-                        C[i + (int64_t)j * ldc] = v;
-                    }
-                }
-    } else {
-        double* S = slabs + (int64_t)it.slot * TILE * TILE;
-#pragma unroll
-        for (int t = 0; t < TA; ++t)
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int il = wi * 64 + u * 16 + li;
-                    const int jl = wj * 64 + t * 16 + lq + 4 * r;
-                    S[il + jl * TILE] = acc[t][u][r];
-                }
-    }
-}
-
-// TA = 4: 256 threads, four waves of 64 x 64 (two waves per SIMD).  (TA = 8 — 128 threads, two waves of 64 rows x 128 columns, ONE
-// wave per SIMD with the whole 512-entry register file — compiles, but hipcc's register allocator answers the 256 accumulator
-// registers with ~800 accvgpr moves and 86 scratch accesses per 192 MFMAs in the loop: not instantiated.)
-template <bool SCALED, int TA, int PF, int LPQ>
-__global__ __launch_bounds__(TA == 4 ? 256 : 128, TA == 4 ? 2 : 1) void syrk_tn_direct_kernel(
-    const double* __restrict__ G, int64_t ldg, const double* __restrict__ di, int n,
-    const SyrkItem* __restrict__ items, double* __restrict__ C, int64_t ldc, const double* __restrict__ P, int64_t ldp,
-    double* __restrict__ slabs, BatchStrides bs) {
-    constexpr int NS = PF + 1;
-    const SyrkItem it = items[blockIdx.x];
-    {
-        const int64_t bz = blockIdx.z;
-        G += bz * bs.a;
-        if (SCALED) di += bz * bs.b;
-        C += bz * bs.c;
-        if (P) P += bz * bs.d;
-    }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wj = TA == 4 ? (wave >> 1) : 0, wi = wave & 1;
-    const int li = lane & 15, lk = lane >> 4;
-    const int i0 = it.ti * TILE, j0 = it.tj * TILE;
-
-    d4 acc[TA][4];
-#pragma unroll
-    for (int t = 0; t < TA; ++t)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[t][u] = d4{0.0, 0.0, 0.0, 0.0};
-
-    const int klen = it.k1 - it.k0;
-    const int nfull = klen >> 3, ktail = klen & 7;
-    const char* baseJ = reinterpret_cast<const char*>(G + (int64_t)j0 * ldg + it.k0);
-    const char* baseI = reinterpret_cast<const char*>(G + (int64_t)i0 * ldg + it.k0);
-    const char* basew = SCALED ? reinterpret_cast<const char*>(di + it.k0) : nullptr;
-    uint32_t offJ[TA], offI[4];
-#pragma unroll
-    for (int t = 0; t < TA; ++t) {
-        const int cj = min(j0 + wj * 64 + t * 16 + li, n - 1) - j0;
-        offJ[t] = (uint32_t)(((int64_t)cj * ldg + 2 * lk) * 8);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const int ci = min(i0 + wi * 64 + u * 16 + li, n - 1) - i0;
-        offI[u] = (uint32_t)(((int64_t)ci * ldg + 2 * lk) * 8);
-    }
-    const uint32_t offw = (uint32_t)(2 * lk * 8);
-
-    d2 fa[NS][TA], fb[NS][4], fw[NS];
-    if (nfull > 0) {
-        // prologue: chunks 0 .. PF-1 (indices clamped: a short tile reloads its last chunk, harmless)
-#pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            const int64_t cb = (int64_t)min(s, nfull - 1) * 64;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const d2u b = *reinterpret_cast<const d2u*>(baseI + cb + offI[u]);
-                fb[s][u] = d2{b.x, b.y};
-            }
-#pragma unroll
-            for (int t = 0; t < TA; ++t) {
-                const d2u a = *reinterpret_cast<const d2u*>(baseJ + cb + offJ[t]);
-                fa[s][t] = d2{a.x, a.y};
-            }
-            if (SCALED) {
-                const d2u w = *reinterpret_cast<const d2u*>(basew + cb + offw);
-                fw[s] = d2{w.x, w.y};
-            }
-        }
-        const int last = nfull - 1;
-        int c = 0;
-#define DIRECT_STEP(SC)                                                                                           \
-        {                                                                                                         \
-            const int64_t cb = (int64_t)min(c + (SC) + PF, last) * 64;                                            \
-            direct_chunk<SCALED, TA, NS, (SC), ((SC) + PF) % NS, LPQ>(acc, fa, fb, fw, baseJ + cb, baseI + cb,         \
-                                                                 SCALED ? basew + cb : nullptr, offJ, offI, offw); \
-        }
-        for (; c + NS <= nfull; c += NS) {
-            DIRECT_STEP(0)
-            DIRECT_STEP(1)
-            if (NS > 2) DIRECT_STEP(2 % NS)
-            if (NS > 3) DIRECT_STEP(3 % NS)
-        }
-        if (c < nfull) DIRECT_STEP(0)
-        if (c + 1 < nfull) DIRECT_STEP(1)
-        if (NS > 3 && c + 2 < nfull) DIRECT_STEP(2 % NS)
-#undef DIRECT_STEP
-    }
-    if (ktail) {
-        // last partial chunk: addresses clamped into the range, rows >= k1 get weight zero
-        const int kc = nfull * 8 + 2 * lk;                    // this lane's first k inside [0, klen)
-        const bool v0 = kc < klen, v1 = kc + 1 < klen;
-        const int64_t kb = (int64_t)max(0, min(kc, klen - 2)) * 8 - (int64_t)(2 * lk) * 8;   // the offsets already carry 2 lk
-        const bool shifted = v0 && !v1;                      // the pair was moved down by one row: its .y is row kc
-        d2 w = {0.0, 0.0};
-        if (SCALED) {
-            if (v0) w.x = di[it.k0 + kc];
-            if (v1) w.y = di[it.k0 + kc + 1];
-        } else {
-            w.x = v0 ? 1.0 : 0.0;
-            w.y = v1 ? 1.0 : 0.0;
-        }
-        auto fetch = [&](const char* base, uint32_t off) -> d2 {
-            d2u a;
-            if (klen >= 2) {
-                a = *reinterpret_cast<const d2u*>(base + kb + off);
-                if (shifted) a.x = a.y;
-            } else {                                          // a single row in the range
-                a.x = a.y = *reinterpret_cast<const double*>(base + off - (int64_t)(2 * lk) * 8);
-            }
-            return d2{a.x * w.x, a.y * w.y};
-        };
-        d2 ta[TA], tb[4];
-#pragma unroll
-        for (int t = 0; t < TA; ++t) ta[t] = fetch(baseJ, offJ[t]);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) tb[u] = fetch(baseI, offI[u]);
-#pragma unroll
-        for (int g = 0; g < 2; ++g)
-#pragma unroll
-            for (int t = 0; t < TA; ++t)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[t][u] = MFMA_F64(ta[t][g], tb[u][g], acc[t][u]);
-    }
-    syrk_store_tile<TA>(it, acc, n, i0, j0, wi, wj, lane, C, ldc, P, ldp, slabs);
-}
-
 // Deterministic fix-up for split tiles: C = P + slab[first] + slab[first+1] + ...  (fixed order)
 __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkItem* __restrict__ tiles, int n,
                                                           const double* __restrict__ slabs,
@@ -682,10 +474,10 @@ int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split)
     plan.nslabs = nslabs;
     plan.nsplit_tiles = (int)split_tiles.size();
     KKT_HIP_CHECK(hipMalloc(&plan.d_items, sizeof(SyrkItem) * std::max<size_t>(1, items.size())));
-    KKT_HIP_CHECK(hipMemcpy(plan.d_items, items.data(), sizeof(SyrkItem) * items.size(), hipMemcpyHostToDevice));
+    KKT_HIP_CHECK(memcpy_sync(plan.d_items, items.data(), sizeof(SyrkItem) * items.size(), hipMemcpyHostToDevice));
     if (!split_tiles.empty()) {
         KKT_HIP_CHECK(hipMalloc(&plan.d_split_tiles, sizeof(SyrkItem) * split_tiles.size()));
-        KKT_HIP_CHECK(hipMemcpy(plan.d_split_tiles, split_tiles.data(), sizeof(SyrkItem) * split_tiles.size(),
+        KKT_HIP_CHECK(memcpy_sync(plan.d_split_tiles, split_tiles.data(), sizeof(SyrkItem) * split_tiles.size(),
                                 hipMemcpyHostToDevice));
         KKT_HIP_CHECK(hipMalloc(&plan.d_slabs, sizeof(double) * (size_t)nslabs * TILE * TILE));
     }
@@ -701,18 +493,6 @@ void free_syrk_plan(SyrkPlan& plan) {
 
 static constexpr size_t kGemmLds = sizeof(double) * 4 * STAGE_DOUBLES;   // 73,728 B
 
-// 0: LDS-staged syrk_tn_kernel, otherwise a syrk_tn_direct_kernel variant (waves' tile shape, chunks of look-ahead)
-static int syrk_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MI355KKT_SYRK");
-        v = 0;
-        if (e && !strcmp(e, "direct411")) v = 411;   // one chunk ahead, one load after every MFMA quad
-        if (e && !strcmp(e, "direct412")) v = 412;   // one chunk ahead, the loads front-loaded two per quad
-        if (e && !strcmp(e, "direct414")) v = 414;   // one chunk ahead, four loads per quad (all nine within the first three quads)
-    }
-    return v;
-}
 static constexpr size_t kGemmLdsWide = 84 * 1024;                        // > 80 KiB: one workgroup per CU
 
 int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const double* di, double* C,
@@ -733,29 +513,7 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
         set_last_error("launch_syrk_scaled: batched launch needs an unsplit plan");
         return -1;
     }
-    // $MI355KKT_SYRK: "lds" = the LDS-staged kernel, "direct411" / "direct412" / "direct414" = the barrier-free register kernels
-    const int variant = syrk_variant();
-    const bool off_ok = (int64_t)(TILE - 1) * ldg * 8 + 64 < (int64_t)UINT32_MAX;   // 32-bit lane offsets inside a tile
-    if (variant != 0 && off_ok) {
-        const dim3 grid(plan.nitems, 1, nbatch);
-#define LAUNCH_DIRECT(SC_, PF_, LPQ_)                                                                                     \
-        hipLaunchKernelGGL((syrk_tn_direct_kernel<SC_, 4, PF_, LPQ_>), grid, dim3(256), 0, st, G, ldg, di, plan.n, plan.d_items, C, \
-                           ldc, P, ldp, plan.d_slabs, bs)
-        if (di) {
-            switch (variant) {
-                case 411: LAUNCH_DIRECT(true, 1, 1); break;
-                case 414: LAUNCH_DIRECT(true, 1, 4); break;
-                default: LAUNCH_DIRECT(true, 1, 2); break;
-            }
-        } else {
-            switch (variant) {
-                case 411: LAUNCH_DIRECT(false, 1, 1); break;
-                case 414: LAUNCH_DIRECT(false, 1, 4); break;
-                default: LAUNCH_DIRECT(false, 1, 2); break;
-            }
-        }
-#undef LAUNCH_DIRECT
-    } else {
+    {
         // diagonal tiles: contractions of 8192 rows and more take the nine-blocks-per-wave path inside the kernel; shorter ones (the
         // batched engine: K = 1024, 4 of a problem's 10 tiles are diagonal) the block masks of the pipelined loop
         if (plan.K >= 8192)
@@ -1083,7 +841,7 @@ int launch_syrk_nt_update_vb(double* base, const VbDesc* d_desc, int nfronts, in
     const int nt = (maxh - k0 - 1 + TILE - 1) / TILE;
     if (nt <= 0) return 0;
     // few tiles in the whole level (the top of the supernodal tree): 32-row tiles, four times the workgroups
-    static const int vb_short_max = getenv("MI355KKT_VB_SHORT_TILES") ? atoi(getenv("MI355KKT_VB_SHORT_TILES")) : 1024;
+    constexpr int vb_short_max = 1024;
     if ((int64_t)nfronts * (nt * (nt + 1) / 2) <= vb_short_max) {
         hipLaunchKernelGGL((nt_update_short_kernel<32, true>), dim3((maxh - k0 - 1 + 31) / 32, nt, nfronts), dim3(256), kGemmLds, st, base,
                            (int64_t)0, base, (int64_t)0, base, (int64_t)0, 0, 0, k0, 1, d_desc);
@@ -1102,9 +860,9 @@ int launch_gemm_nt_update(double* C, int64_t ldc, const double* A, int64_t lda, 
     if (int e = nt_attr()) return e;
     const int fast_ok = (((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 7) == 0) ? 1 : 0;
     // skinny updates of the Cholesky chain (few tiles): half-height tiles, twice the workgroups, half the latency
-    static const bool half_ok = getenv("MI355KKT_NO_HALF_TILES") == nullptr;
+    constexpr bool half_ok = true;
     const int full_tiles = ((M + TILE - 1) / TILE) * ((N + TILE - 1) / TILE);
-    static const int quarter_max = getenv("MI355KKT_QUARTER_TILES") ? atoi(getenv("MI355KKT_QUARTER_TILES")) : 128;
+    constexpr int quarter_max = 128;
     if (half_ok && nbatch == 1 && full_tiles <= 192) {
         if (full_tiles <= quarter_max)
             hipLaunchKernelGGL((nt_update_short_kernel<32, false>), dim3((M + 31) / 32, (N + TILE - 1) / TILE), dim3(256), kGemmLds, st, C, ldc,

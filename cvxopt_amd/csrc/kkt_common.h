@@ -1,6 +1,8 @@
 // Shared declarations for the MI355X (gfx950) KKT backend.  Internal header (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "knobs.h"
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -21,6 +23,26 @@ void set_last_error(const char* fmt, ...);
             return -2; /* MI355KKT_EHIP */                                               \
         }                                                                                \
     } while (0)
+
+// ---- host-synchronous copies / fills ---------------------------------------------------------------
+// hipMemcpy(device-to-device) and hipMemset on device memory return BEFORE the work is done: they are only ordered on the legacy
+// stream, and every handle computes on its own hipStreamNonBlocking stream, which the legacy stream does not order.  (Found by
+// tests/test_gpu_stress.py in round 4: a d2d copy of a right-hand side raced with the solve launched right after it once the
+// legacy stream was busy.)  Everything in this library that means "copy / fill now, then launch on another stream" goes through
+// these: the plain call followed by a wait on the legacy stream.  Setup-time cost only (never inside factor / solve).
+inline hipError_t memcpy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpy(dst, src, bytes, kind);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+inline hipError_t memcpy2d_sync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+                                hipMemcpyKind kind) {
+    hipError_t e = hipMemcpy2D(dst, dpitch, src, spitch, width, height, kind);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+inline hipError_t memset_sync(void* p, int value, size_t bytes) {
+    hipError_t e = hipMemset(p, value, bytes);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
 
 // ---- tile geometry of the FP64 MFMA kernels -----------------------------------------------------
 constexpr int TILE = 128;      // C tile (both dims) owned by one 256-thread workgroup
@@ -89,13 +111,14 @@ struct PotrfWork {
     int minv_n = 0;
     const double* minv_of = nullptr;
     // look-ahead: the bulk of each trailing update runs on `side` while the next panel is factored on the main stream
-    hipStream_t side = nullptr, aux = nullptr;
-    std::vector<hipEvent_t> ev_panel, ev_bulk, ev_t1, ev_usr, ev_ir;
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_panel, ev_bulk;
 };
-int set_potf2_skip(int v);   // developer ablation switch
-int set_tile_ts(long long* dptr);    // developer aid: 8 int64 stamps per tile written by potrf_tiles_kernel (nullptr: off)
-int set_potf2_ts(long long* dptr);   // developer aid: device buffer of 48 timestamps written by potf2_la_kernel (nullptr: off)
-int set_syrk_skip(int v);    // developer ablation switch
+#ifdef MI355KKT_DEBUG          // developer aids, include/mi355kkt_debug.h
+int set_tile_ts(long long* dptr);    // 8 int64 stamps per tile written by potrf_tiles_kernel (nullptr: off)
+int set_potf2_ts(long long* dptr);   // device buffer of 48 timestamps written by potf2_la_kernel (nullptr: off)
+int set_syrk_skip(int v);            // ablation switch of the SYRK (results are wrong when != 0)
+#endif
 int potrf_work_init(PotrfWork& w);
 int potrf_work_reserve(PotrfWork& w, int n);   // state of the persistent tile kernel (allocated lazily otherwise)
 void potrf_work_free(PotrfWork& w);
@@ -132,25 +155,17 @@ int launch_gemv_nt_fused(const double* G, int64_t ldg, int m, int n, const doubl
                          double* work, hipStream_t st, int nbatch = 1, int64_t sG = 0);
 size_t gemv_nt_work_doubles(int m, int n);
 // single right-hand side, single launch (needs ceil(n/128) co-resident workgroups: callers check against #CUs);
-// flags: ceil(n/128) words zeroed once at allocation, epoch: a fresh non-zero value per launch, err: device int
+// gran: 256 u64 per 128-block, zeroed once at allocation; epoch: a fresh non-zero value per launch; err: device int
 // copies the strictly lower triangle, transposed, into the strictly upper triangle (needed by the transposed persistent solve)
 int launch_mirror_lower(double* A, int64_t lda, int n, hipStream_t st);
 // trans != 0 solves L' x = b and REQUIRES the mirrored upper triangle (launch_mirror_lower after the factorisation)
-// gran != nullptr: data-tagged granule hand-off (256 u64 per 128-block, zeroed once) instead of flag + fences
 // minv != nullptr: inverses of the 128 x 128 diagonal blocks (per block M then M', 2 x 16384 doubles) from the tile Cholesky
 struct TrsvJob { const double* L; int64_t ld; int n; int pad; double* x; };   // one system of a batched launch
 int launch_mirror_lower_jobs(const TrsvJob* d_jobs, int njobs, int nmax, hipStream_t st);   // the same for a list of matrices
-constexpr int TRSV_JOB_STRIDE = 64;    // flags / granule blocks reserved per job (orders up to 8192)
-int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int* flags,
-                           unsigned int epoch, int* err, hipStream_t st, unsigned long long* gran = nullptr,
-                           const double* minv = nullptr, const TrsvJob* jobs = nullptr, int njobs = 0);
-// round 3: the persistent solve with the two blocks next to the diagonal pre-multiplied by L_kk^-1 (blas2.hip, trsv_z_kernel):
-// trsv_z_prepare once per factorisation (after launch_mirror_lower), zmat holds trsv_z_doubles(n) doubles; n % 128 == 0
-size_t trsv_z_doubles(int n);
-int set_trsvz_ts(long long* dptr);   // developer aid: 8 stamps per 128-block of the next trsv_z launches (nullptr: off)
-int trsv_z_prepare(const double* L, int64_t ldl, int n, double* zmat, hipStream_t st, const double* minv = nullptr);
-int launch_trsv_z(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
-                  unsigned long long* gran, const double* minv, const double* zmat);
+constexpr int TRSV_JOB_STRIDE = 64;    // granule blocks reserved per job (orders up to 8192)
+int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err,
+                           hipStream_t st, unsigned long long* gran, const double* minv = nullptr,
+                           const TrsvJob* jobs = nullptr, int njobs = 0);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);
@@ -210,7 +225,6 @@ struct SparseEngine {
            *d_rem_multi = nullptr;
     int rem_multi_cols = 0;
     // hand-off state of the persistent dense triangular solve (blas2.hip) used for the wide supernodes: borrowed from the handle
-    unsigned int* t_flags = nullptr;
     unsigned long long* t_gran = nullptr;
     int* t_err = nullptr;
     unsigned int* t_epoch = nullptr;
@@ -281,6 +295,7 @@ int launch_batch_cone_scale(const double* in, int64_t ldi, int64_t sIn, double* 
 // ---- device-resident LP-cone coneqp loop for a batch (batch_ipm.hip) --------------------------------
 struct IpmState {
     int n = 0, m = 0, p = 0;
+    int correction = 1;        // options['use_correction'] (coneprog.py:1781): 0 drops the Mehrotra term ds o dz of the second solve
     // equality constraints A x = b (single-problem entry point only; p = 0 in the batched mode), [B][p]
     double *b = nullptr, *y = nullptr, *ry = nullptr, *dy = nullptr, *Ax = nullptr, *y_out = nullptr, *resy0 = nullptr;
     double* ATy = nullptr;     // [B][n]
@@ -367,6 +382,7 @@ struct QpState {
     // max(p, 1), [m] with m, v with max(sum(q), 1), beta with max(nq, 1), sc with QP_NSC, active / status / iters with 1 — and
     // the kernels shift their copy of the state to their problem first (qp_select, coneqp_ipm.hip).  'l' + 'q' cones only.
     int nbatch = 1;
+    int correction = 1;                               // options['use_correction'] (coneprog.py:1781, :2377, :2426)
     const int *qoff = nullptr, *qdim = nullptr;
     // 's' blocks (cone_ops_s.h): block k is sdim[k] x sdim[k], full symmetric storage, at soff[k] of the cone vectors, at
     // sloff[k] of lmbda (compact layout: sdim[k] entries), at soff[k] - lq of r / rti / sw1..3, at sloff[k] - lq of sigs / sigz

@@ -1,0 +1,14 @@
+// Developer / test knobs of the library (kernel-selection thresholds, ordering choices of the sparse analysis, ...).
+//
+// A production library must not change its numerics or its kernel selection because of a stray environment variable, so the
+// knobs are NOT read from the environment: dev_knob(name) returns the value set through mi355kkt_test_set_knob()
+// (include/mi355kkt_test.h: an explicit call by a test or a developer script) or nullptr.  Only -DMI355KKT_DEBUG builds fall back
+// to getenv(name).  The one environment variable every build honours is MI355KKT_ROCTX (profiler ranges; no effect on results).
+#pragma once
+
+namespace mi355kkt {
+
+const char* dev_knob(const char* name);                    // nullptr: not set
+int set_dev_knob(const char* name, const char* value);     // value == nullptr: unset; name == nullptr: unset all
+
+}  // namespace mi355kkt

@@ -8,6 +8,7 @@
 //     level is thinned to a minimal vertex separator; parts below a size limit are ordered by the minimum-degree
 //     routine with the already-placed separators as a halo (constrained minimum degree).
 #include "ordering.h"
+#include "knobs.h"
 
 #include <algorithm>
 #include <atomic>
@@ -187,7 +188,7 @@ void relaxed_supernodes(const std::vector<int>& parent, const std::vector<int64_
     const int n = (int)parent.size();
     // widest supernode: wider ones (the top separators of a nested dissection) are factored and solved by the multi-workgroup
     // dense kernels as ONE front instead of a chain of 256-column pieces, one level each ($MI355KKT_SN_MAXW: experiments)
-    const int MAXW = getenv("MI355KKT_SN_MAXW") ? std::max(1, atoi(getenv("MI355KKT_SN_MAXW"))) : 8192;   // (read per analysis)
+    const int MAXW = dev_knob("MI355KKT_SN_MAXW") ? std::max(1, atoi(dev_knob("MI355KKT_SN_MAXW"))) : 8192;   // (read per analysis)
     sn_first.clear();
     sn_of.assign(n, 0);
     int64_t true_nnz = 0;        // nonzeros of L in the columns of the current supernode
@@ -929,7 +930,7 @@ struct Dissector {
         }
         for (int v : sep) part[v].store(-1, std::memory_order_relaxed);
         if (depth == 0 && on_top) on_top(sep.size(), nodes.size());
-        if (depth < 3 && getenv("MI355KKT_ND_DEBUG"))
+        if (depth < 3 && dev_knob("MI355KKT_ND_DEBUG"))
             fprintf(stderr, "[nd] depth %d: %zu nodes -> left %zu right %zu separator %zu (level %zu of %zu, raw %zu, thinned %zu)\n", depth, nodes.size(),
                     left.size(), right.size(), sep.size(), best_l, levels.size(), levels[best_l].size(), sep0);
         const size_t off_r = off + left.size(), off_s = off_r + right.size();
@@ -959,16 +960,16 @@ void fill_reducing_ordering(const Graph& adj, std::vector<int>& order, int metho
     OrderingInfo I;
     order.assign(n, -1);
     if (n == 0) { if (info) *info = I; return; }
-    if (const char* e = getenv("MI355KKT_ORDERING")) {
+    if (const char* e = dev_knob("MI355KKT_ORDERING")) {
         if (!strcmp(e, "nd")) method = 1;
         else if (!strcmp(e, "amd")) method = 2;
         else if (!strcmp(e, "auto")) method = 0;
     }
     // leaves of the dissection: breadth-first order (chains that amalgamate into few, wide supernodes: what the small-front
     // kernels like) or, with MI355KKT_ND_LEAF_AMD, constrained minimum degree (about 6 % less fill, 3x more supernodes)
-    const bool amd_leaves = getenv("MI355KKT_ND_LEAF_AMD") != nullptr;
-    const int leaf = getenv("MI355KKT_ND_LEAF") ? atoi(getenv("MI355KKT_ND_LEAF")) : (amd_leaves ? 120 : 48);
-    const bool dbg = getenv("MI355KKT_SPARSE_DEBUG") != nullptr;
+    const bool amd_leaves = dev_knob("MI355KKT_ND_LEAF_AMD") != nullptr;
+    const int leaf = dev_knob("MI355KKT_ND_LEAF") ? atoi(dev_knob("MI355KKT_ND_LEAF")) : (amd_leaves ? 120 : 48);
+    const bool dbg = dev_knob("MI355KKT_SPARSE_DEBUG") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!dbg) return;
@@ -1009,7 +1010,7 @@ void fill_reducing_ordering(const Graph& adj, std::vector<int>& order, int metho
             run_amd();
         }
     };
-    static const bool amd_always = getenv("MI355KKT_ORDERING_BOTH") != nullptr;
+    static const bool amd_always = dev_knob("MI355KKT_ORDERING_BOTH") != nullptr;
     if (method == 0 && (n < 2000 || amd_always)) start_amd();
     else if (method == 2) run_amd();
     if (method != 2) {
@@ -1017,8 +1018,8 @@ void fill_reducing_ordering(const Graph& adj, std::vector<int>& order, int metho
         std::vector<int> nodes(n);
         std::iota(nodes.begin(), nodes.end(), 0);
         Dissector nd(adj, ond, leaf, amd_leaves);
-        if (const char* e = getenv("MI355KKT_ND_MODE")) nd.nd_mode = atoi(e);
-        nd.norefine = getenv("MI355KKT_ND_NOREFINE") != nullptr;
+        if (const char* e = dev_knob("MI355KKT_ND_MODE")) nd.nd_mode = atoi(e);
+        nd.norefine = dev_knob("MI355KKT_ND_NOREFINE") != nullptr;
         if (method == 0)
             nd.on_top = [&](size_t sep, size_t part) {
                 top_seen = true;

@@ -1,9 +1,10 @@
 // Dense FP64 Cholesky (lower, in place) for gfx950: the device replacement of lapack.potrf
 // (reference src/C/lapack.c:1471-1523 -> dpotrf_, called from misc.py:1282, :1429, :1460, :1472).
 //
-// Blocked right-looking factorisation with NB = 128 column panels:
-//   potf2_kernel      one workgroup, LDS-resident 128x128 diagonal block: 16-column micro panels
-//                     (rank-1 updates inside the micro panel) + FP64-MFMA rank-16 updates of the rest
+// n >= 1024: ONE persistent left-looking tile kernel (potrf_tiles_kernel, below).  Smaller matrices, batches and the sparse
+// engine's small fronts: blocked right-looking factorisation with NB = 128 column panels:
+//   potf2_la_kernel   one workgroup, LDS-resident 128x128 diagonal block: 16-column micro panels held by a panel wave,
+//                     FP64-MFMA rank-16 updates of the rest one step behind (look-ahead)
 //   trsm_panel_kernel X L_kk' = B for the rows below the diagonal block (one row per lane)
 //   nt_update_kernel  trailing update A22 -= L21 L21' on the matrix cores (gemm_f64.hip)
 // A non-positive pivot sets *info = (1-based column) exactly like LAPACK's info > 0; every later
@@ -13,15 +14,19 @@
 #include "kkt_common.h"
 #include <type_traits>
 
+// The fence-free hand-offs of the tile kernel (st_wt / ld_l2 + s_waitcnt, DESIGN 4a') rest on gfx942 / gfx950 behaviour: agent-scope
+// relaxed stores are write-through past the XCD's L2 (sc1), agent-scope relaxed loads bypass it, and a wave's stores are
+// acknowledged in issue order (vmcnt).  Other targets must not compile this file silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "potrf.hip: the streaming hand-off protocol is written for gfx942 / gfx950 only"
+#endif
+
 namespace mi355kkt {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2_ __attribute__((ext_vector_type(2)));
 struct __attribute__((aligned(8))) d2u_ { double x, y; };   // 8-byte aligned pair (one dwordx4 load)
 #define MFMA_F64(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
-
-__device__ int g_potf2_skip = 0;   // developer ablation switch (bit0 a, bit1 b, bit2 c, bit3 inverses); 0 in production
-int set_potf2_skip(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_potf2_skip), &v, sizeof(int)) == hipSuccess ? 0 : -2; }
 
 constexpr int NB = 128;
 constexpr int PLD = 144;   // LDS leading dimension of the diagonal block (== 16 mod 32: conflict-free frags)
@@ -32,214 +37,8 @@ __device__ __forceinline__ double readlane_d(double v, int srclane) {   // srcla
     return __hiloint2double(hi, lo);
 }
 
-// d = sqrt(p), inv = 1/sqrt(p) to ~1 ulp from one v_rsq_f64 + two coupled Newton steps (p > 0, normal)
-__device__ __forceinline__ void sqrt_rsqrt(double p, double& d, double& inv) {
-    const double y0 = __builtin_amdgcn_rsq(p);
-    double g = p * y0, h = 0.5 * y0;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    r = fma(-g, g, p);          // final correction of sqrt
-    g = fma(r, h, g);
-    d = g;
-    inv = 2.0 * h;
-}
-
-// Diagonal block factorisation, one workgroup, block resident in LDS.  Per 16-column micro panel:
-//   (a) wave 0 factors the 16x16 diagonal block in registers (lane = row, pivots/multipliers broadcast
-//       with v_readlane: no LDS round trip, no barrier on the 16-step dependency chain)
-//   (b) one thread per row below solves x L_d' = r (L_d read as LDS broadcasts)
-//   (c) all four waves apply the rank-16 update to the remaining columns with v_mfma_f64_16x16x4_f64
-// linv_out[blk][k][g] = inv(L_d)[g][k] (16x16 diagonal blocks, zero upper) is exported for trsm_panel_kernel.
-__global__ __launch_bounds__(256) void potf2_kernel(double* __restrict__ A, int64_t lda, int nb, int col0,
-                                                    int* __restrict__ info, double* __restrict__ linv_out,
-                                                    int64_t bstride, const VbDesc* __restrict__ vb) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    if (vb) {                                    // variable batched fronts: col0 carries the panel offset k0
-        const VbDesc dd = vb[blockIdx.z];
-        const int k0 = col0;
-        if (k0 >= dd.w) return;
-        nb = min(NB, dd.w - k0);
-        lda = dd.h;
-        A += dd.off + k0 + (int64_t)k0 * lda;
-        col0 = dd.col0 + k0;
-    } else {
-        A += (int64_t)blockIdx.z * bstride;      // batched problems along blockIdx.z
-    }
-    info += blockIdx.z;
-    if (linv_out) linv_out += (int64_t)blockIdx.z * 2048;
-    double* As = smem;                       // NB x PLD, column-major, lower triangle valid
-    double* Ld = smem + NB * PLD;            // 16 x 16 current diagonal block, Ld[c * 16 + k] = L[c][k]
-    double* dinv = Ld + 256;                 // 16 reciprocal pivots of the current micro panel
-    int* flag = reinterpret_cast<int*>(dinv + 16);
-    if (*info != 0) return;
-    const int skip = g_potf2_skip;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) *flag = 0;
-    {   // block -> LDS, 16 independent loads in flight per thread (the whole nb x nb square; only tril is used)
-        const int r = tid & (NB - 1), c0 = tid >> 7;
-        const int rr = min(r, nb - 1);
-        for (int cc = 0; cc < nb; cc += 32) {
-            double v[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) v[i] = A[rr + (int64_t)min(cc + c0 + 2 * i, nb - 1) * lda];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) As[(cc + c0 + 2 * i) * PLD + r] = v[i];
-        }
-    }
-    __syncthreads();
-    for (int jb = 0; jb < nb; jb += 16) {
-        const int pw = min(16, nb - jb);
-        // ---- (a) 16x16 diagonal block in wave 0, lane i <-> row jb + (i & 15)  (lanes >= 16 mirror lanes 0..15).
-        //      Written without per-element predicates: the strict upper triangle of the block carries garbage that
-        //      never reaches the lower triangle (each update only mixes entries of one row).
-        if (wave == 0 && !(skip & 1)) {
-            const int l15 = lane & 15;
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) a[c] = As[(jb + c) * PLD + jb + l15];
-            if (pw < 16) {                       // ragged last block: rows >= pw act as identity rows
-#pragma unroll
-                for (int c = 0; c < 16; ++c) a[c] = (l15 < pw) ? ((c < pw) ? a[c] : 0.0) : ((c == l15) ? 1.0 : 0.0);
-            }
-            int bad = 0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                __builtin_amdgcn_sched_barrier(0);
-                const double p = readlane_d(a[j], j);
-                if (!(p > 0.0) && bad == 0) bad = j + 1;             // uniform (p is wave-uniform)
-                double d, inv;
-                sqrt_rsqrt(bad ? 1.0 : p, d, inv);
-                const double l = a[j] * inv;                         // lane j: p / sqrt(p) = L[j][j]
-                a[j] = l;
-                if (lane == 0) dinv[j] = inv;
-#pragma unroll
-                for (int c = j + 1; c < 16; ++c) {
-                    a[c] = fma(-l, readlane_d(l, c), a[c]);
-                    if (((c - j) & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // <= 4 broadcast values live in SGPRs
-                }
-            }
-            if (bad) {
-                if (lane == 0) *flag = jb + bad;
-            } else if (lane < pw) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c < pw) As[(jb + c) * PLD + jb + lane] = a[c];
-            }
-        }
-        __syncthreads();
-        if (*flag) break;
-        // ---- (b) rows below the diagonal block: x L_d' = r, one row per thread.  Column k+1 of L_d is
-        //      prefetched from LDS (wave-wide broadcast reads) into a second register set while column k is
-        //      applied, so the FMAs never wait on an LDS round trip.
-        if (jb + 16 < nb && wave * 64 < nb - jb - 16 && !(skip & 2)) {
-            const int row = jb + 16 + tid;
-            const int rr = min(row, NB - 1);
-            double x[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) x[c] = As[(jb + c) * PLD + rr];
-            double colA[16], colB[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) colA[c] = As[jb * PLD + jb + c];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                double(&cur)[16] = (k & 1) ? colB : colA;
-                double(&nxt)[16] = (k & 1) ? colA : colB;
-                if (k < 15) {
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) nxt[c] = As[(jb + k + 1) * PLD + jb + c];
-                }
-                x[k] *= dinv[k];
-#pragma unroll
-                for (int c = k + 1; c < 16; ++c) x[c] = fma(-x[k], cur[c], x[c]);
-            }
-            if (row < nb) {
-#pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    if (c < pw) As[(jb + c) * PLD + row] = x[c];
-            }
-        }
-        __syncthreads();
-        // ---- (c) rank-16 update of columns >= jb+16 on the matrix cores (16x16 tiles, rt >= ct)
-        const int t0 = jb / 16 + 1, nt = (nb + 15) / 16;
-        const int ntr = nt - t0;
-        const int ntiles = ntr * (ntr + 1) / 2;
-        const int li = lane & 15, lq = lane >> 4;
-        for (int t = wave; t < ((skip & 4) ? 0 : ntiles); t += 4) {
-            int a = 0, rem = t;                  // t -> (ct = t0 + a, rt = ct + rem), column-major triangle
-            while (rem >= ntr - a) {
-                rem -= ntr - a;
-                ++a;
-            }
-            const int ct = t0 + a, rt = ct + rem;
-            d4 acc;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = As[(ct * 16 + lq + 4 * r) * PLD + rt * 16 + li];
-#pragma unroll
-            for (int kk = 0; kk < 16; kk += 4) {
-                const double av = -As[(jb + kk + lq) * PLD + ct * 16 + li];
-                const double bv = As[(jb + kk + lq) * PLD + rt * 16 + li];
-                acc = MFMA_F64(av, bv, acc);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) As[(ct * 16 + lq + 4 * r) * PLD + rt * 16 + li] = acc[r];
-        }
-        __syncthreads();
-    }
-    if (*flag) {
-        if (tid == 0) *info = col0 + *flag;
-        return;
-    }
-    // inverses of the 16x16 diagonal blocks for the MFMA triangular solves (trsm_panel_kernel): row-oriented
-    // forward recurrence, rows of M broadcast with v_readlane; blocks are independent -> two per wave.
-    if (linv_out && !(skip & 8)) {
-        for (int jb = wave * 16; jb < nb; jb += 64) {
-            const int pw = min(16, nb - jb);
-            const int l15 = lane & 15;
-            double a[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const double v = As[(jb + c) * PLD + jb + l15];
-                a[c] = (c < l15 && l15 < pw) ? v : 0.0;                  // strictly lower part of row l15
-            }
-            const double myinv = (l15 < pw) ? 1.0 / As[(jb + l15) * PLD + jb + l15] : 1.0;
-            double mrow[16];                                             // unscaled row: e_i - sum_k L[i][k] M[k][:]
-#pragma unroll
-            for (int j = 0; j < 16; ++j) mrow[j] = (j == l15) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < 15; ++k) {
-                __builtin_amdgcn_sched_barrier(0);
-                const double dk = readlane_d(myinv, k);
-#pragma unroll
-                for (int j = 0; j <= k; ++j) {
-                    mrow[j] = fma(-a[k], readlane_d(mrow[j], k) * dk, mrow[j]);
-                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    linv_out[(jb / 16) * 256 + j * 16 + lane] = (lane < pw) ? mrow[j] * myinv : 0.0;
-            }
-        }
-    }
-    {
-        const int r = tid & (NB - 1), c0 = tid >> 7;
-        for (int cc = 0; cc < nb; cc += 32) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = cc + c0 + 2 * i;
-                if (r < nb && c < nb && r >= c) A[r + (int64_t)c * lda] = As[c * PLD + r];
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// potf2_la_kernel: the same diagonal-block factorisation restructured around its dependency chain (round 2).
+// potf2_la_kernel: the diagonal-block factorisation, structured around its dependency chain (round 2).
 // 512 threads.  Wave 0 is the *panel wave*: it holds the current 16-column micro panel of ALL remaining rows in
 // registers (lane l <-> rows jb + l and jb + 64 + l), so the factorisation of the 16x16 diagonal block and the
 // triangular solve of every row below it are ONE instruction stream - the multipliers of column j are broadcast
@@ -258,7 +57,13 @@ constexpr int P2T = 512;
 // dirty line of the XCD's L2 (~2-6 us with a freshly written tile), an acquire fence costs ~1.7 us: too much for 16-column steps.
 __device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ld_l2(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ long long* g_potf2_ts = nullptr;   // developer aid: when set, wave 0 / lane 0 logs s_memtime at phase boundaries
+// developer aid (-DMI355KKT_DEBUG builds only, include/mi355kkt_debug.h): when set, wave 0 / lane 0 logs s_memtime at phase boundaries
+#ifdef MI355KKT_DEBUG
+__device__ long long* g_potf2_ts = nullptr;
+#define POTF2_TS_PTR g_potf2_ts
+#else
+#define POTF2_TS_PTR ((long long*)nullptr)
+#endif
 #define P2_TS(i_) do { if (ts && tid == 0) ts[(i_)] = (long long)__builtin_readcyclecounter(); } while (0)
 
 // rank-16 update of one 16x16 tile (ct, rt >= ct) of the LDS-resident block with micro panel jb
@@ -571,11 +376,13 @@ __global__ __launch_bounds__(P2T) void potf2_la_kernel(double* __restrict__ A, i
     info += blockIdx.z;
     if (linv_out) linv_out += (int64_t)blockIdx.z * 2048;
     if (*info != 0) return;
-    long long* ts = (blockIdx.z == 0) ? g_potf2_ts : nullptr;
+    long long* ts = (blockIdx.z == 0) ? POTF2_TS_PTR : nullptr;
     const int failed = potf2_la_body<false>(A, lda, nb, linv_out, smem, ts);
     if (failed && threadIdx.x == 0) *info = col0 + failed;
 }
+#ifdef MI355KKT_DEBUG
 int set_potf2_ts(long long* dptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_potf2_ts), &dptr, sizeof(dptr)) == hipSuccess ? 0 : -2; }
+#endif
 
 // X L' = B for the rows below a full 128x128 diagonal block, entirely on the matrix cores.
 // One wave owns a strip of 16 rows; tiles are kept transposed (MFMA row index = column of X, MFMA
@@ -679,7 +486,13 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(const double* __restric
 //     (guide G16; one acquire covers every k that has become available since the last look).
 // ===================================================================================================
 constexpr int PT_THREADS = 512;
-__device__ long long* g_tile_ts = nullptr;    // developer aid: 8 stamps per tile (s_memtime) when set
+// developer aid (-DMI355KKT_DEBUG builds only): 8 stamps per tile (s_memtime) when set
+#ifdef MI355KKT_DEBUG
+__device__ long long* g_tile_ts = nullptr;
+#define TILE_TS_PTR g_tile_ts
+#else
+#define TILE_TS_PTR ((long long*)nullptr)
+#endif
 #define PT_TS(k_) do { if (tts && tid == 0) tts[(int64_t)t * 8 + (k_)] = (long long)__builtin_readcyclecounter(); } while (0)
 struct TileCtl {
     unsigned ticket, abort_flag, pad0, pad1;
@@ -1262,7 +1075,7 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_kernel(double* __restr
         J.minv = minv_all ? minv_all + (int64_t)j * 2 * NB * NB : nullptr;
         J.info = info; J.info_base = J.j0;
         J.abort_on_fail = true;
-        if (!tile_process<false, STREAM, TBK>(J, ctl, err, smem, ctlw, tid, t, g_tile_ts)) return;
+        if (!tile_process<false, STREAM, TBK>(J, ctl, err, smem, ctlw, tid, t, TILE_TS_PTR)) return;
         __syncthreads();                                      // LDS (image, control words) is reused by the next tile
     }
 }
@@ -1327,26 +1140,21 @@ __global__ __launch_bounds__(PT_THREADS) void potrf_tiles_vb_kernel(double* __re
     }
 }
 
+#ifdef MI355KKT_DEBUG
 int set_tile_ts(long long* dptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_tile_ts), &dptr, sizeof(dptr)) == hipSuccess ? 0 : -2; }
+#endif
 
-// One diagonal-block factorisation launch (nz blocks along blockIdx.z).  MI355KKT_POTF2=old selects the round-1 kernel.
+// One diagonal-block factorisation launch (nz blocks along blockIdx.z).
 static int launch_potf2(double* A, int64_t lda, int nb, int col0, int* info, double* linv, int64_t bstride,
                         const VbDesc* vb, int nz, hipStream_t st) {
-    static const bool use_old = getenv("MI355KKT_POTF2") && !strcmp(getenv("MI355KKT_POTF2"), "old");
     static bool attr_set = false;
-    constexpr size_t lds_old = sizeof(double) * (NB * PLD + 256 + 16) + 16;
     constexpr size_t lds_la = sizeof(double) * (NB * PLD + NB + 80) + 16;
     if (!attr_set) {
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_old));
         KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potf2_la_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_la));
         attr_set = true;
     }
-    if (use_old)
-        hipLaunchKernelGGL(potf2_kernel, dim3(1, 1, nz), dim3(256), lds_old, st, A, lda, nb, col0, info, linv, bstride, vb);
-    else
-        hipLaunchKernelGGL(potf2_la_kernel, dim3(1, 1, nz), dim3(P2T), lds_la, st, A, lda, nb, col0, info, linv, bstride, vb);
+    hipLaunchKernelGGL(potf2_la_kernel, dim3(1, 1, nz), dim3(P2T), lds_la, st, A, lda, nb, col0, info, linv, bstride, vb);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -1361,8 +1169,6 @@ int potrf_work_init_batched(PotrfWork& w, int nbatch) {
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         if (hipStreamCreateWithPriority(&w.side, hipStreamNonBlocking, least) != hipSuccess)
             KKT_HIP_CHECK(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
-        if (hipStreamCreateWithPriority(&w.aux, hipStreamNonBlocking, greatest) != hipSuccess)
-            KKT_HIP_CHECK(hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking));
     }
     return 0;
 }
@@ -1378,11 +1184,7 @@ void potrf_work_free(PotrfWork& w) {
     if (w.d_minv) (void)hipFree(w.d_minv);
     for (auto e : w.ev_panel) (void)hipEventDestroy(e);
     for (auto e : w.ev_bulk) (void)hipEventDestroy(e);
-    for (auto e : w.ev_t1) (void)hipEventDestroy(e);
-    for (auto e : w.ev_usr) (void)hipEventDestroy(e);
-    for (auto e : w.ev_ir) (void)hipEventDestroy(e);
     if (w.side) (void)hipStreamDestroy(w.side);
-    if (w.aux) (void)hipStreamDestroy(w.aux);
     w = PotrfWork();
 }
 
@@ -1410,7 +1212,7 @@ int launch_potrf_tiles_vb(double* base, const VbDesc* d_desc, int nfronts, const
         KKT_HIP_CHECK(hipMemsetAsync(d_prog, 0, sizeof(unsigned) * 3 * (nprog > 0 ? nprog : 1), st));
     }
     // d_prog holds 3 * nprog words: progress, half (micro panels of L(j,j) in memory), micro (blocks of tile (i, i-1) in memory)
-    static const int stream = getenv("MI355KKT_SPARSE_STREAM") ? atoi(getenv("MI355KKT_SPARSE_STREAM")) : 1;
+    constexpr int stream = 1;        // 16-column streaming inside whole tiles of the fronts (DESIGN 4a')
     const int grid = ntickets < num_cus ? ntickets : num_cus;
     hipLaunchKernelGGL(potrf_tiles_vb_kernel, dim3(grid), dim3(PT_THREADS), lds, st, base, d_desc,
                        reinterpret_cast<const VbTicket*>(d_tickets), (unsigned)ntickets, d_prog_off, d_linv_off,
@@ -1453,8 +1255,6 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel<true, 16>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(potrf_tiles_kernel<true, 32>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     const int NT = (n + NB - 1) / NB;
@@ -1462,33 +1262,25 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
     KKT_HIP_CHECK(hipMemsetAsync(w.d_ctl, 0, sizeof(TileCtl), st));
     const int ntiles = NT * (NT + 1) / 2;
     const int grid = ntiles < num_cus ? ntiles : num_cus;
-    static const bool no_minv = getenv("MI355KKT_NO_MINV") != nullptr;
-    // 0: whole tiles only; 1: half-tile hand-off of L(j,j) (round 2); 2: 16-column streaming (round 3).  Streaming needs whole tiles
-    static const int half_env = getenv("MI355KKT_POTRF_HALF") ? atoi(getenv("MI355KKT_POTRF_HALF")) : 2;
-    const int use_half = (half_env == 2 && n % NB) ? 1 : half_env;
-    static const int tbk = getenv("MI355KKT_POTRF_BK") ? atoi(getenv("MI355KKT_POTRF_BK")) : 16;   // 32: 32-deep LDS stages in the bulk
-    if (use_half == 2 && tbk == 32)
-        hipLaunchKernelGGL((potrf_tiles_kernel<true, 32>), dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
-                           reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
-    else if (use_half == 2)
+    // whole tiles only: 16-column streaming along the chain (round 3); ragged last tiles: the half-tile hand-off of L(j,j) (round 2)
+    const int use_half = (n % NB) ? 1 : 2;
+    if (use_half == 2)
         hipLaunchKernelGGL((potrf_tiles_kernel<true, 16>), dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
-                           reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
+                           reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, w.d_minv, use_half);
     else
         hipLaunchKernelGGL((potrf_tiles_kernel<false, 16>), dim3(grid), dim3(PT_THREADS), lds, st, A, lda, n,
-                           reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, no_minv ? nullptr : w.d_minv, use_half);
+                           reinterpret_cast<TileCtl*>(w.d_ctl), w.d_linv_all, w.d_info, w.d_info, w.d_minv, use_half);
     KKT_HIP_CHECK(hipGetLastError());
-    w.minv_n = no_minv ? 0 : n;          // the 128 x 128 inverses of this factor's diagonal blocks are valid
+    w.minv_n = n;                        // the 128 x 128 inverses of this factor's diagonal blocks are valid
     w.minv_of = A;
     return 0;
 }
 
 int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st) {
     KKT_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int) * nbatch, st));
-    {   // single large matrix: the persistent left-looking tile kernel (MI355KKT_POTRF=streams keeps the launch chain below)
-        static const bool use_streams = getenv("MI355KKT_POTRF") && !strcmp(getenv("MI355KKT_POTRF"), "streams");
-        static const int tiles_min_n = getenv("MI355KKT_TILES_MIN_N") ? atoi(getenv("MI355KKT_TILES_MIN_N")) : 1024;
-        if (nbatch == 1 && !use_streams && n >= tiles_min_n && (n + NB - 1) / NB <= 252) return launch_potrf_tiles(A, lda, n, w, st);
-    }
+    // single large matrix: the persistent left-looking tile kernel (up to 252 block columns: TileCtl)
+    constexpr int tiles_min_n = 1024;
+    if (nbatch == 1 && n >= tiles_min_n && (n + NB - 1) / NB <= 252) return launch_potrf_tiles(A, lda, n, w, st);
     w.minv_n = 0;                         // the launch chain below does not produce the 128 x 128 diagonal-block inverses
     // Outer panels of 256 columns = two 128-column sub-panels; the trailing matrix is touched once per
     // outer panel with a rank-256 update (halves the C read-modify-write traffic of a rank-128 scheme).
@@ -1510,107 +1302,8 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
     // ---- look-ahead variant (single large matrix): the update of the NEXT outer panel's columns stays on
     //      `st`; the rest of the trailing update runs on w.side, concurrently with the next panel's
     //      potf2 / trsm (which occupy only a few compute units).
-    const char* mode_env = getenv("MI355KKT_POTRF_STREAMS");
-    const int lookahead_streams = mode_env ? atoi(mode_env) : 2;
-    if (nbatch == 1 && n >= 8 * NB && w.side && w.aux && lookahead_streams == 3) {
-        // Three streams.  st (critical path): potf2 -> trsm -> diagonal-block-only updates -> next potf2 ...
-        // w.aux: the rest of the skinny updates (rows below the next diagonal block) - overlaps with the next potf2.
-        // w.side (low priority, one workgroup per CU): the bulk rank-256 update of everything further right.
-        const int nsteps = (n + 2 * NB - 1) / (2 * NB);
-        auto grow = [&](std::vector<hipEvent_t>& v) -> int {
-            while ((int)v.size() < nsteps + 1) {
-                hipEvent_t e1;
-                KKT_HIP_CHECK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-                v.push_back(e1);
-            }
-            return 0;
-        };
-        if (int e = grow(w.ev_panel)) return e;
-        if (int e = grow(w.ev_bulk)) return e;
-        if (int e = grow(w.ev_t1)) return e;
-        if (int e = grow(w.ev_usr)) return e;
-        if (int e = grow(w.ev_ir)) return e;
-        auto potf2 = [&](int k0, int nb) {
-            (void)launch_potf2(A + k0 + (int64_t)k0 * lda, lda, nb, k0, w.d_info, w.d_dinv, (int64_t)0, nullptr, 1, st);
-        };
-        auto trsm = [&](int k0, int nb) {
-            const int m = n - k0 - nb;
-            if (m <= 0) return;
-            double* Akk = A + k0 + (int64_t)k0 * lda;
-            if (nb == NB)
-                hipLaunchKernelGGL(trsm_panel_kernel<true>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Akk, w.d_dinv,
-                                   Akk + nb, lda, m, w.d_info, (int64_t)0, nb, nullptr);
-            else
-                hipLaunchKernelGGL(trsm_panel_kernel<false>, dim3((m + TRSM_ROWS - 1) / TRSM_ROWS), dim3(256), 0, st, Akk, w.d_dinv,
-                                   Akk + nb, lda, m, w.d_info, (int64_t)0, nb, nullptr);
-        };
-        // C[r0:r0+M, c0:c0+N] -= L[r0:.., kp:kp+K] L[c0:.., kp:kp+K]'
-        auto upd = [&](int r0, int M, int c0, int N, int kp, int K, hipStream_t s_) -> int {
-            if (M <= 0 || N <= 0) return 0;
-            return launch_gemm_nt_update(A + r0 + (int64_t)c0 * lda, lda, A + r0 + (int64_t)kp * lda, lda,
-                                         A + c0 + (int64_t)kp * lda, lda, M, N, K, s_);
-        };
-        int step = 0;
-        bool bulk_pending = false, ir_pending = false;
-        for (int k0 = 0; k0 < n; k0 += 2 * NB, ++step) {
-            const int nb1 = (n - k0 < NB) ? (n - k0) : NB;
-            potf2(k0, nb1);
-            if (ir_pending) KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_ir[step - 1], 0));   // rows below were updated on aux
-            trsm(k0, nb1);
-            const int k1 = k0 + nb1;
-            if (k1 >= n) break;
-            const int nb2 = (n - k1 < NB) ? (n - k1) : NB;
-            KKT_HIP_CHECK(hipEventRecord(w.ev_t1[step], st));
-            // sub-panel 2: its diagonal block on the critical path, the rows below it on aux
-            if (int e = upd(k1, nb2, k1, nb2, k0, nb1, st)) return e;
-            KKT_HIP_CHECK(hipStreamWaitEvent(w.aux, w.ev_t1[step], 0));
-            if (int e = upd(k1 + nb2, n - k1 - nb2, k1, nb2, k0, nb1, w.aux)) return e;
-            KKT_HIP_CHECK(hipEventRecord(w.ev_usr[step], w.aux));
-            potf2(k1, nb2);
-            KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_usr[step], 0));
-            trsm(k1, nb2);
-            const int k2 = k1 + nb2;
-            if (k2 >= n) { ir_pending = false; break; }
-            KKT_HIP_CHECK(hipEventRecord(w.ev_panel[step], st));          // outer panel `step` complete
-            const int K = nb1 + nb2;
-            const int wnext = (n - k2 < 2 * NB) ? (n - k2) : 2 * NB;      // width of the next outer panel
-            const int d1 = (wnext < NB) ? wnext : NB;                     // its first diagonal block
-            if (bulk_pending) {
-                KKT_HIP_CHECK(hipStreamWaitEvent(st, w.ev_bulk[step - 1], 0));
-                KKT_HIP_CHECK(hipStreamWaitEvent(w.aux, w.ev_bulk[step - 1], 0));
-            }
-            // next panel: first diagonal block on the critical path, all rows below it (both sub-panels' columns) on aux
-            if (int e = upd(k2, d1, k2, d1, k0, K, st)) return e;
-            KKT_HIP_CHECK(hipStreamWaitEvent(w.aux, w.ev_panel[step], 0));
-            if (int e = upd(k2 + d1, n - k2 - d1, k2, wnext, k0, K, w.aux)) return e;
-            KKT_HIP_CHECK(hipEventRecord(w.ev_ir[step], w.aux));
-            ir_pending = true;
-            // everything to the right of the next panel: bulk, low priority, one workgroup per CU
-            const int k3 = k2 + wnext;
-            if (k3 < n) {
-                // released after the skinny next-panel update on aux (which then shares the machine only with potf2)
-                KKT_HIP_CHECK(hipStreamWaitEvent(w.side, getenv("MI355KKT_BULK_EARLY") ? w.ev_panel[step] : w.ev_ir[step], 0));
-                if (int e = launch_syrk_nt_update(A + k3 + (int64_t)k3 * lda, lda, A + k3 + (int64_t)k0 * lda, lda, n - k3, K,
-                                                  w.side, 1, 0, getenv("MI355KKT_BULK_1WG") != nullptr))
-                    return e;
-                KKT_HIP_CHECK(hipEventRecord(w.ev_bulk[step], w.side));
-                bulk_pending = true;
-            } else {
-                bulk_pending = false;
-            }
-        }
-        // join: nothing may be in flight on aux / side when the caller's stream continues
-        hipEvent_t ej = w.ev_t1[nsteps];
-        KKT_HIP_CHECK(hipEventRecord(ej, w.aux));
-        KKT_HIP_CHECK(hipStreamWaitEvent(st, ej, 0));
-        hipEvent_t eb = w.ev_usr[nsteps];
-        KKT_HIP_CHECK(hipEventRecord(eb, w.side));
-        KKT_HIP_CHECK(hipStreamWaitEvent(st, eb, 0));
-        KKT_HIP_CHECK(hipGetLastError());
-        return 0;
-    }
-    static const int outer1_max_n = getenv("MI355KKT_POTRF_OUTER1") ? atoi(getenv("MI355KKT_POTRF_OUTER1")) : 2048;
-    if (nbatch == 1 && n >= 8 * NB && w.side && lookahead_streams == 2) {
+    constexpr int outer1_max_n = 2048;
+    if (nbatch == 1 && n >= 8 * NB && w.side) {     // (only orders beyond the tile kernel's 252 block columns get here)
         // Outer panels of two 128-column sub-panels while the trailing matrix is large (rank-256 bulk updates touch it half
         // as often), of ONE sub-panel once at most outer1_max_n columns remain: there the chain of panel kernels dominates
         // and potf2 + trsm + one K=128 skinny update per 128 columns is the shorter chain.

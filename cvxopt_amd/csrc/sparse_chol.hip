@@ -73,7 +73,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     S.n = n;
     S.m = m;
     if (n == 0) return 0;
-    const bool dbg = getenv("MI355KKT_SPARSE_DEBUG") != nullptr;
+    const bool dbg = dev_knob("MI355KKT_SPARSE_DEBUG") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!dbg) return;
@@ -204,8 +204,8 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     S.upd_ld.assign(ns, 0);
     S.big.assign(ns, 0);
     int64_t off = 0;
-    const double big_flops = getenv("MI355KKT_SPARSE_BIG_FLOPS") ? atof(getenv("MI355KKT_SPARSE_BIG_FLOPS")) : 5.0e4;
-    const int64_t big_h = getenv("MI355KKT_SPARSE_BIG_H") ? atoi(getenv("MI355KKT_SPARSE_BIG_H")) : 48;
+    const double big_flops = dev_knob("MI355KKT_SPARSE_BIG_FLOPS") ? atof(dev_knob("MI355KKT_SPARSE_BIG_FLOPS")) : 5.0e4;
+    const int64_t big_h = dev_knob("MI355KKT_SPARSE_BIG_H") ? atoi(dev_knob("MI355KKT_SPARSE_BIG_H")) : 48;
     for (int s = 0; s < ns; ++s) {
         const int64_t h = S.sn_rowptr[s + 1] - S.sn_rowptr[s], w = S.sn_first[s + 1] - S.sn_first[s];
         const double fl = (double)w * h * h;
@@ -313,7 +313,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
             if (S.sn_first[S.level_sn[k] + 1] - S.sn_first[S.level_sn[k]] > sp_wide_threshold()) S.wide.push_back(S.level_sn[k]);
         S.wide_ptr[l + 1] = (int)S.wide.size();
     }
-    if (getenv("MI355KKT_SPARSE_DEBUG")) {
+    if (dev_knob("MI355KKT_SPARSE_DEBUG")) {
         fprintf(stderr, "[sparse] n=%d supernodes=%d levels=%d store=%.1f MB\n", n, ns, S.nlevels, off * 8.0 / 1e6);
         for (int l = 0; l < S.nlevels; ++l) {
             int nb = 0, nsm = 0, maxh_s = 0, maxh_b = 0, maxw_b = 0;
@@ -688,7 +688,7 @@ constexpr int64_t SP_HEAVY = 32768;     // supernodes with more off-diagonal pan
 // (128; at most 256, the capacity of the kernels' LDS vector; $MI355KKT_SP_WIDE: experiments.  46^3: solve 1.98 ms at 256,
 // 1.76 ms at 128, 1.74 ms at 64)
 int sp_wide_threshold() {
-    static const int v = getenv("MI355KKT_SP_WIDE") ? std::min(256, std::max(32, atoi(getenv("MI355KKT_SP_WIDE")))) : 128;
+    static const int v = dev_knob("MI355KKT_SP_WIDE") ? std::min(256, std::max(32, atoi(dev_knob("MI355KKT_SP_WIDE")))) : 128;
     return v;
 }
 
@@ -1007,7 +1007,7 @@ __global__ void sp_scale2_kernel(const double* __restrict__ w, const double* __r
 template <class T>
 static int up(T** d, const std::vector<T>& h) {
     KKT_HIP_CHECK(hipMalloc(d, sizeof(T) * (h.size() ? h.size() : 1)));
-    if (!h.empty()) KKT_HIP_CHECK(hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+    if (!h.empty()) KKT_HIP_CHECK(memcpy_sync(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1129,7 +1129,7 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
             for (int k = S.wide_ptr[l]; k < S.wide_ptr[l + 1]; ++k)
                 E.wide_maxw[l] = std::max(E.wide_maxw[l], S.sn_first[S.wide[k] + 1] - S.sn_first[S.wide[k]]);
         KKT_HIP_CHECK(hipMalloc(&E.d_wide_jobs, sizeof(TrsvJob) * std::max<size_t>(1, jobs.size())));
-        if (!jobs.empty()) KKT_HIP_CHECK(hipMemcpy(E.d_wide_jobs, jobs.data(), sizeof(TrsvJob) * jobs.size(), hipMemcpyHostToDevice));
+        if (!jobs.empty()) KKT_HIP_CHECK(memcpy_sync(E.d_wide_jobs, jobs.data(), sizeof(TrsvJob) * jobs.size(), hipMemcpyHostToDevice));
         if (int e = up(&E.d_wide, S.wide)) return e;
         if (int e = up(&E.d_ea_off, S.ea_off)) return e;
         if (int e = up(&E.d_ea_lb, S.ea_lb)) return e;
@@ -1183,7 +1183,7 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
         hipLaunchKernelGGL(sp_assemble_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, nt, E.d_asm_slot,
                            E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r, E.d_gv, E.d_hv, d_di, E.d_panels);
     const SpDev d = devview(E);
-    static const bool old_chain = getenv("MI355KKT_SPARSE_TILES") && !strcmp(getenv("MI355KKT_SPARSE_TILES"), "0");
+    static const bool old_chain = dev_knob("MI355KKT_SPARSE_TILES") && !strcmp(dev_knob("MI355KKT_SPARSE_TILES"), "0");
     if (!old_chain) KKT_HIP_CHECK(hipMemsetAsync(E.d_tv_state, 0, E.tv_state_bytes, st));
     for (int l = 0; l < S.nlevels; ++l) {
         const int nsmall = S.level_nsmall[l];
@@ -1233,9 +1233,9 @@ static int sp_wide_forward(SparseEngine& E, const SpDev& d, int l, double* x, do
     if (nw == 0) return 0;
     hipLaunchKernelGGL(sp_fwd_wide_gather_kernel, dim3(nw, nrhs), dim3(256), 0, st, d, E.d_wide + k0, x, rem, E.d_rem_off, xstride,
                        remstride);
-    if (nrhs == 1 && x == E.d_xp && E.t_flags && E.t_njobs_max > 0) {      // the level's systems, up to t_njobs_max per launch
+    if (nrhs == 1 && x == E.d_xp && E.t_gran && E.t_njobs_max > 0) {      // the level's systems, up to t_njobs_max per launch
         for (int c0 = 0; c0 < nw; c0 += E.t_njobs_max)
-            if (int e = launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 0, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran,
+            if (int e = launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 0, ++*E.t_epoch, E.t_err, st, E.t_gran,
                                                nullptr, E.d_wide_jobs + k0 + c0, std::min(E.t_njobs_max, nw - c0)))
                 return e;
         return 0;
@@ -1244,8 +1244,8 @@ static int sp_wide_forward(SparseEngine& E, const SpDev& d, int l, double* x, do
         const int s = S.wide[k], f = S.sn_first[s], w = S.sn_first[s + 1] - f;
         const int h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
         const double* P = E.d_panels + S.panel_off[s];
-        if (nrhs == 1 && E.t_flags) {
-            if (int e = launch_trsv_persistent(P, h, w, x + f, 0, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran)) return e;
+        if (nrhs == 1 && E.t_gran) {
+            if (int e = launch_trsv_persistent(P, h, w, x + f, 0, ++*E.t_epoch, E.t_err, st, E.t_gran)) return e;
         } else if (int e = launch_trsm_lower(P, h, w, x + f, xstride, nrhs, 0, st))
             return e;
     }
@@ -1255,9 +1255,9 @@ static int sp_wide_backward(SparseEngine& E, int l, double* x, hipStream_t st) {
     const SparseSymbolic& S = E.sym;
     const int k0 = S.wide_ptr[l], nw = S.wide_ptr[l + 1] - k0;
     if (nw == 0) return 0;
-    if (x == E.d_xp && E.t_flags && E.t_njobs_max > 0) {
+    if (x == E.d_xp && E.t_gran && E.t_njobs_max > 0) {
         for (int c0 = 0; c0 < nw; c0 += E.t_njobs_max)
-            if (int e = launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 1, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran,
+            if (int e = launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 1, ++*E.t_epoch, E.t_err, st, E.t_gran,
                                                nullptr, E.d_wide_jobs + k0 + c0, std::min(E.t_njobs_max, nw - c0)))
                 return e;
         return 0;
@@ -1266,8 +1266,8 @@ static int sp_wide_backward(SparseEngine& E, int l, double* x, hipStream_t st) {
         const int s = S.wide[k], f = S.sn_first[s], w = S.sn_first[s + 1] - f;
         const int h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
         const double* P = E.d_panels + S.panel_off[s];
-        if (E.t_flags) {      // (L' streamed from the mirrored upper triangle, see sparse_engine_factor)
-            if (int e = launch_trsv_persistent(P, h, w, x + f, 1, E.t_flags, ++*E.t_epoch, E.t_err, st, E.t_gran)) return e;
+        if (E.t_gran) {      // (L' streamed from the mirrored upper triangle, see sparse_engine_factor)
+            if (int e = launch_trsv_persistent(P, h, w, x + f, 1, ++*E.t_epoch, E.t_err, st, E.t_gran)) return e;
         } else if (int e = launch_trsm_lower(P, h, w, x + f, w, 1, 1, st))
             return e;
     }

@@ -164,6 +164,10 @@ class _Engine(object):
             return out
         return _dense_view(M, what)
 
+    def set_option(self, name, value):
+        """per-handle options of the C ABI (include/mi355kkt.h: "use_correction", "ldl_refinement")"""
+        _capi.check(self.L.mi355kkt_set_option(self.h, name.encode("ascii"), float(value)), "mi355kkt_set_option")
+
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
             self.L.mi355kkt_destroy(self.h)       # also unpins the caller's H buffer
@@ -414,11 +418,13 @@ class _Engine(object):
         _capi.check(self.L.mi355kkt_product(self.h, int(which), 1 if trans else 0, _ptr(xv), _ptr(out)), "mi355kkt_product")
         return out
 
-    def coneqp(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, keep_H=False):
+    def coneqp(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, keep_H=False,
+               use_correction=True):
         """The reference coneqp loop (coneprog.py:2044-2547; LP cone, no equalities) resident on the device around
         this handle (`mi355kkt_coneqp_lp`).  Returns a dict with the reference's keys, vectors as NumPy arrays."""
         if self.dims['q'] or self.dims['s']:
             raise NotImplementedError("device-resident coneqp: LP cone only")
+        self.set_option("use_correction", 1.0 if use_correction else 0.0)
         if not keep_H:                    # keep_H: H was placed with set_H_device / a previous call
             self._set_H(P)
         if self._mode == "undecided":
@@ -508,18 +514,19 @@ class _Engine(object):
         return x, y, s, z
 
     def coneqp_cones(self, q, h, P=None, b=None, maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7, refinement=None,
-                     initvals=None):
+                     initvals=None, use_correction=True):
         """The reference coneqp loop (coneprog.py:2044-2547) for 'l', 'q' and 's' cones resident on the device around this
         handle (`mi355kkt_coneqp`; refinement 1 with second-order or semidefinite cones like the reference).  'q' / 's' cones
         run on the dense engine; the 's' blocks of h, s, z are in the reference's unpacked storage (s, z returned symmetric)."""
         self._set_H(P)
+        self.set_option("use_correction", 1.0 if use_correction else 0.0)      # options['use_correction'], coneprog.py:1781
         n, m, p = self.n, self.cdim, self.p
         qv = np.ascontiguousarray(np.asarray(q, dtype=np.float64).reshape(-1))
         hv = np.ascontiguousarray(np.asarray(h, dtype=np.float64).reshape(-1))
         bv = np.ascontiguousarray(np.asarray(b if b is not None else [], dtype=np.float64).reshape(-1))
         if qv.size != n or hv.size != m or bv.size != p:
             raise TypeError("q / h / b have the wrong length")
-        if initvals:
+        if initvals is not None:           # {} is a starting point too: x = 0, y = 0, s = z = e (coneprog.py:2107-2149)
             x, y, s, z = self._interior_start(initvals)
         else:
             x, y, s, z = np.zeros(n), np.zeros(p), np.zeros(m), np.zeros(m)
@@ -527,7 +534,7 @@ class _Engine(object):
         st = (C.c_double * 6)()
         rc = self._loop_call(lambda: self.L.mi355kkt_coneqp_init(
             self.h, _ptr(qv), _ptr(hv), _ptr(bv), int(maxiters), float(abstol), float(reltol), float(feastol),
-            -1 if refinement is None else int(refinement), 1 if initvals else 0, _ptr(x), _ptr(y), _ptr(s), _ptr(z),
+            -1 if refinement is None else int(refinement), 1 if initvals is not None else 0, _ptr(x), _ptr(y), _ptr(s), _ptr(z),
             C.byref(status), C.byref(iters), st), P)
         if rc == 1:
             raise ValueError("Rank(A) < p or Rank([P; A; G]) < n")        # coneprog.py:2065-2066
@@ -555,25 +562,25 @@ class _Engine(object):
         if cv.size != n or hv.size != m or bv.size != p:
             raise TypeError("c / h / b have the wrong length")
         x, y, s, z = np.zeros(n), np.zeros(p), np.zeros(m), np.zeros(m)
-        if primalstart:
+        if primalstart is not None:        # (coneprog.py:684, :703-705: a dict without 'x' / 's' is a KeyError there too)
             x = self._start_vec(primalstart, 'x', n, None, "primalstart")
             s = self._start_vec(primalstart, 's', m, None, "primalstart")
             if x is None or s is None:
-                raise KeyError("primalstart needs 'x' and 's'")
+                raise KeyError('x' if x is None else 's')
             if not self._in_cone_interior(s):
                 raise ValueError("initial s is not positive")              # coneprog.py:708-709
-        if dualstart:
+        if dualstart is not None:          # (coneprog.py:713, :733-735)
             y = self._start_vec(dualstart, 'y', p, np.zeros(p), "dualstart")
             z = self._start_vec(dualstart, 'z', m, None, "dualstart")
             if z is None:
-                raise KeyError("dualstart needs 'z'")
+                raise KeyError('z')
             if not self._in_cone_interior(z):
                 raise ValueError("initial z is not positive")              # coneprog.py:741-742
         status, iters = C.c_int(0), C.c_int(0)
         st = (C.c_double * 10)()
         rc = self._loop_call(lambda: self.L.mi355kkt_conelp_init(
             self.h, _ptr(cv), _ptr(hv), _ptr(bv), int(maxiters), float(abstol), float(reltol), float(feastol),
-            -1 if refinement is None else int(refinement), 1 if primalstart else 0, 1 if dualstart else 0,
+            -1 if refinement is None else int(refinement), 1 if primalstart is not None else 0, 1 if dualstart is not None else 0,
             _ptr(x), _ptr(y), _ptr(s), _ptr(z), C.byref(status), C.byref(iters), st), None)
         if rc == 1:
             raise ValueError("Rank(A) < p or Rank([G; A]) < n")           # coneprog.py:690-691
@@ -679,7 +686,7 @@ def _final_line(sol, maxiters):
 
 
 def coneqp_device(P, q, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters=100, abstol=1e-7, reltol=1e-6,
-                  feastol=1e-7, refinement=None, kktreg=None, show_progress=False, initvals=None):
+                  feastol=1e-7, refinement=None, kktreg=None, show_progress=False, initvals=None, use_correction=True):
     """min 1/2 x'Px + q'x  s.t.  Gx <=_K h, Ax = b,  K = R^l_+ x second-order cones x positive semidefinite cones, with the whole
     interior-point loop on the MI355X.  Iterates match `solvers.coneqp(P, q, G, h, dims[, A, b])`."""
     kind = {'chol2': _capi.CHOL2, 'chol': _capi.CHOL, 'ldl': _capi.LDL, 'ldl2': _capi.LDL2}[kktsolver]
@@ -693,7 +700,7 @@ def coneqp_device(P, q, G, h, dims=None, A=None, b=None, kktsolver='chol', maxit
     try:
         eng.show_progress(show_progress, lp=False)
         sol = eng.coneqp_cones(q, h, P, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol,
-                               refinement=refinement, initvals=initvals)
+                               refinement=refinement, initvals=initvals, use_correction=use_correction)
         if show_progress:
             _final_line(sol, maxiters)
         return sol
@@ -706,7 +713,8 @@ def conelp_lp(c, G, h, A=None, b=None, **kw):
     return conelp_device(c, G, h, None, A, b, **kw)
 
 
-def coneqp_lp(P, q, G, h, A=None, b=None, kktsolver='chol2', maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7):
+def coneqp_lp(P, q, G, h, A=None, b=None, kktsolver='chol2', maxiters=100, abstol=1e-7, reltol=1e-6, feastol=1e-7,
+              use_correction=True):
     """min 1/2 x'Px + q'x  s.t.  Gx <= h, Ax = b  with the whole interior-point loop on the MI355X (no host round trips
     for the residual products or the cone-vector bookkeeping).  P, G: cvxopt 'd' matrices or NumPy arrays
     (only tril(P) is read, like the reference).  Iterates match `solvers.coneqp(P, q, G, h)`."""
@@ -714,7 +722,8 @@ def coneqp_lp(P, q, G, h, A=None, b=None, kktsolver='chol2', maxiters=100, absto
     m, n = _size(G)
     eng = _Engine(kind, G, {'l': m, 'q': [], 's': []}, A if A is not None else _EmptyA(n))
     try:
-        return eng.coneqp(q, h, P, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol)
+        return eng.coneqp(q, h, P, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol,
+                          use_correction=use_correction)
     finally:
         eng.close()
 

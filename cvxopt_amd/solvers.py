@@ -4,8 +4,8 @@ operator + kktsolver plug-in API.
 The reference drivers accept G, A (and P) as Python callables instead of matrices (`conelp`: coneprog.py:521-550,
 `coneqp`: :1838-1917) as long as `kktsolver` is a callable too.  Here both are device backed:
 
-    * when the cones are 'l' / 'q' only and the default starting point is used, the whole loop runs on the device
-      (`cvxopt_amd.conelp_device` / `coneqp_device`; `device_loop=False` forces the host-driver path below),
+    * by default the whole loop runs on the device, all three cone types, starting points and the reference's options
+      included (`cvxopt_amd.conelp_device` / `coneqp_device`; `device_loop=False` forces the host-driver path below),
     * `kktsolver`     = the GPU KKT engine of `cvxopt_amd.kkt` (factor + solves in HBM),
     * `G`, `A`, `P`   = closures around `mi355kkt_product`: y := alpha op(M) x + beta y with M resident in HBM
                         (for 's' cones with the trisc/triusc convention of misc.sgemv, misc.py:801-832),
@@ -80,16 +80,42 @@ def _as_cvxopt(sol):
     return out
 
 
-def _options(kwargs):
-    """solver options as the reference reads them (kwargs['options'] over solvers.options; coneprog.py:428-500, :1772-1803)"""
+def _options(kwargs, dims, lp, kktsolver):
+    """solver options read and VALIDATED as the reference does (kwargs['options'] over solvers.options; conelp:
+    coneprog.py:425-455 + :502-509, coneqp: :1770-1801 + :1862-1869): same defaults, same ValueErrors, in the same order --
+    the kktsolver name is checked between the tolerances and `refinement`, as there (:458-466 / :1805-1813).
+    Returns (options for the device loop, kktreg, debug, resolved kktsolver name or None for a user callable)."""
     from cvxopt import solvers
     o = kwargs.get('options', solvers.options)
+    num = (float, int)
     kktreg = o.get('kktreg', None)
-    if kktreg is not None and (not isinstance(kktreg, (float, int)) or kktreg < 0.0):
-        raise ValueError("options['kktreg'] must be a nonnegative scalar")                 # coneprog.py:430-434
-    return dict(maxiters=o.get('maxiters', 100), abstol=o.get('abstol', 1e-7), reltol=o.get('reltol', 1e-6),
-                feastol=o.get('feastol', 1e-7), refinement=o.get('refinement', None), kktreg=kktreg,
-                show_progress=bool(o.get('show_progress', True))), kktreg, bool(o.get('debug', False))
+    if kktreg is not None and (not isinstance(kktreg, num) or kktreg < 0.0):
+        raise ValueError("options['kktreg'] must be a nonnegative scalar")                 # :429-433 / :1774-1778
+    maxiters = o.get('maxiters', 100)
+    if not isinstance(maxiters, int) or maxiters < 1:
+        raise ValueError("options['maxiters'] must be a positive integer")                 # :435-437 / :1783-1785
+    abstol = o.get('abstol', 1e-7)
+    if not isinstance(abstol, num):
+        raise ValueError("options['abstol'] must be a scalar")
+    reltol = o.get('reltol', 1e-6)
+    if not isinstance(reltol, num):
+        raise ValueError("options['reltol'] must be a scalar")
+    if reltol <= 0.0 and abstol <= 0.0:
+        raise ValueError("at least one of options['reltol'] and options['abstol'] must be positive")   # :447-449 / :1795-1797
+    feastol = o.get('feastol', 1e-7)
+    if not isinstance(feastol, num) or feastol <= 0.0:
+        raise ValueError("options['feastol'] must be a positive scalar")                   # :451-453 / :1799-1801
+    ks_name = _resolve_kktsolver(kktsolver, dims, lp)
+    refinement = o.get('refinement', None)
+    if refinement is None:
+        refinement = 1 if (dims['q'] or dims['s']) else 0                                  # :503-507 / :1862-1865
+    elif not isinstance(refinement, int) or refinement < 0:
+        raise ValueError("options['refinement'] must be a nonnegative integer")            # :508-509 / :1867-1869
+    out = dict(maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol, refinement=refinement, kktreg=kktreg,
+               show_progress=bool(o.get('show_progress', True)))
+    if not lp:
+        out['use_correction'] = bool(o.get('use_correction', True))                        # :1781 (coneqp only)
+    return out, kktreg, bool(o.get('debug', False)), ks_name
 
 
 def _resolve_kktsolver(kktsolver, dims, lp):
@@ -113,18 +139,19 @@ def _resolve_kktsolver(kktsolver, dims, lp):
 
 def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None, kktsolver=None, device_loop='auto',
            **kwargs):
-    """cvxopt.solvers.conelp on the MI355X, same signature and result dict.  With the default starting point the whole
-    loop runs on the device (`mi355kkt_conelp`, all three cone types); otherwise the reference driver runs on the
-    host with G, A as device operators and the GPU kktsolver ('chol' | 'chol2' | 'ldl' | 'ldl2')."""
+    """cvxopt.solvers.conelp on the MI355X, same signature and result dict.  The whole loop runs on the device
+    (`mi355kkt_conelp_init`, all three cone types, primalstart / dualstart included, coneprog.py:696-739).  The reference driver
+    runs on the host with G, A as device operators and the GPU kktsolver ('chol' | 'chol2' | 'ldl' | 'ldl2') only for
+    `device_loop=False`, options['debug'], extra keyword arguments (xnewcopy ...) or a problem without cone rows."""
     from cvxopt import solvers, spmatrix
     dims = _dims_of(h, dims)
     n = c.size[0]
-    ks_name = _resolve_kktsolver(kktsolver, dims, lp=True)
-    if ks_name is None:                        # a user kktsolver(W): the reference driver and the user's code, nothing of ours
+    if kktsolver is not None and not isinstance(kktsolver, str):
+        # a user kktsolver(W): the reference driver and the user's code, nothing of ours
         return solvers.conelp(c, G, h, dims, A=A, b=b, primalstart=primalstart, dualstart=dualstart, kktsolver=kktsolver,
                               **kwargs)
     extra = set(kwargs) - {'options'}
-    o, kktreg, debug = _options(kwargs)
+    o, kktreg, debug, ks_name = _options(kwargs, dims, True, kktsolver)
     if device_loop and not extra and not debug and (dims['l'] + sum(dims['q']) + sum(dims['s'])) > 0:
         return _as_cvxopt(_kkt.conelp_device(c, G, h, dims, A, b, kktsolver=ks_name, primalstart=primalstart,
                                              dualstart=dualstart, **o))
@@ -144,18 +171,20 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
 
 def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktsolver=None, device_loop='auto',
            **kwargs):
-    """cvxopt.solvers.coneqp on the MI355X, same signature and result dict.  Without initvals the whole loop runs on the
-    device (`mi355kkt_coneqp`, all three cone types); otherwise the reference driver runs with P, G, A as device operators."""
+    """cvxopt.solvers.coneqp on the MI355X, same signature and result dict.  The whole loop runs on the device
+    (`mi355kkt_coneqp_init`, all three cone types, initvals and options['use_correction'] included, coneprog.py:2109-2149, :1781);
+    the reference driver runs on the host with P, G, A as device operators only for `device_loop=False`, options['debug'], extra
+    keyword arguments or a problem without cone rows."""
     from cvxopt import solvers, spmatrix, matrix
     n = q.size[0]
     if G is None:
         G, h = spmatrix([], [], [], (0, n)), matrix(0.0, (0, 1))
     dims = _dims_of(h, dims)
-    ks_name = _resolve_kktsolver(kktsolver, dims, lp=False)
-    if ks_name is None:                        # a user kktsolver(W): the reference driver and the user's code, nothing of ours
+    if kktsolver is not None and not isinstance(kktsolver, str):
+        # a user kktsolver(W): the reference driver and the user's code, nothing of ours
         return solvers.coneqp(P, q, G, h, dims, A=A, b=b, initvals=initvals, kktsolver=kktsolver, **kwargs)
     extra = set(kwargs) - {'options'}
-    o, kktreg, debug = _options(kwargs)
+    o, kktreg, debug, ks_name = _options(kwargs, dims, False, kktsolver)
     if device_loop and not extra and not debug and (dims['l'] + sum(dims['q']) + sum(dims['s'])) > 0:
         return _as_cvxopt(_kkt.coneqp_device(P, q, G, h, dims, A, b, kktsolver=ks_name, initvals=initvals, **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
@@ -253,8 +282,8 @@ def socp(c, Gl=None, hl=None, Gq=None, hq=None, A=None, b=None, primalstart=None
 def sdp(c, Gl=None, hl=None, Gs=None, hs=None, A=None, b=None, primalstart=None, dualstart=None, **kwargs):
     """cvxopt.solvers.sdp's argument convention (coneprog.py:3566-4153): Gs[k] is m_k^2 x n (column j = vec of the j-th
     coefficient matrix), hs[k] is m_k x m_k; stacked into one cone LP with dims['s'] = [m_k]; 'ss', 'zs' come back as
-    m_k x m_k matrices.  With the default starting point the whole loop runs on the device ('s' blocks included, csrc/cone_ops_s.h);
-    primalstart / dualstart route to the reference driver on the host with device operators + the GPU kktsolver."""
+    m_k x m_k matrices.  The whole loop runs on the device ('s' blocks included, csrc/cone_ops_s.h), primalstart / dualstart
+    included (stacked here and handed to `mi355kkt_conelp_init`)."""
     from cvxopt import matrix
     kwargs = _no_external_solver(kwargs)
     n = c.size[0]

@@ -127,6 +127,13 @@ int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH)
 /* diagonal regularisation of kkt_ldl (reference misc.py:1095-1098): K[x,x] += reg, K[y,y] -= reg,
  * K[z,z] = -1 - reg.  0 disables it. */
 int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg);
+/* Per-handle options (no process-wide switches):
+ *   "use_correction"  1 (default) / 0: options['use_correction'] of solvers.coneqp (coneprog.py:1781; 0 drops the Mehrotra
+ *                     term ds o dz from the second right-hand side, :2377, :2426) for mi355kkt_coneqp* on this handle;
+ *   "ldl_refinement"  steps of iterative refinement against the 3 x 3 system in solve() of the MI355KKT_LDL / _LDL2 flavours
+ *                     (default 2, 0 = the plain reduced solve; not applied with kktreg).
+ * Unknown names: MI355KKT_EINVAL. */
+int mi355kkt_set_option(mi355kkt_solver* h, const char* name, double value);
 /* options['show_progress'] of the reference drivers (coneprog.py:2161-2208, :984-990) for the device-resident loops
  * mi355kkt_conelp / mi355kkt_coneqp: fn is called once per iteration, right after the stopping test, with
  * values = pcost, dcost, gap, pres, dres [, kappa/tau for conelp]; NULL switches it off (the default). */
@@ -217,6 +224,8 @@ int mi355kkt_coneqp_init(mi355kkt_solver* h, const double* q, const double* hv, 
  * (one blockIdx.z slice per problem).  Arrays are packed problem after problem, column-major inside. */
 typedef struct mi355kkt_batch mi355kkt_batch;
 int mi355kkt_batch_create(mi355kkt_batch** out, int device, int nbatch, int n, int ml);
+/* "use_correction" as mi355kkt_set_option, for mi355kkt_batch_coneqp* on this batch */
+int mi355kkt_batch_set_option(mi355kkt_batch* b, const char* name, double value);
 void mi355kkt_batch_destroy(mi355kkt_batch* b);
 int mi355kkt_batch_set_problem(mi355kkt_batch* b, const double* G, const double* H, int is_device);
 int mi355kkt_batch_factor(mi355kkt_batch* b, const double* di, int is_device, int* info);
@@ -257,44 +266,18 @@ int mi355kkt_batch_create_cones(mi355kkt_batch** out, int device, int nbatch, in
 int mi355kkt_batch_factor_cones(mi355kkt_batch* b, const double* di, const double* v, const double* beta, int is_device, int* info);
 
 /* ---- stand-alone device operators (each is one stage of factor()/solve(); used by the per-kernel
- * parity tests and by the profiler).  All pointers are DEVICE pointers; calls are synchronous. ---- */
+ * parity tests and by the profiler).  All pointers are DEVICE pointers; calls are synchronous.
+ * (Test hooks -- stateless host executions of device-side code, plans, orderings -- are declared in mi355kkt_test.h;
+ * developer switches that can change results exist only in -DMI355KKT_DEBUG builds: mi355kkt_debug.h.) ---- */
 /* S(lower) = H(lower) + G' diag(di)^2 G ;  di or H may be NULL */
 int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
                             int64_t ldH, double* dS, int64_t ldS, float* ms);
 /* host-only: symbolic analysis of the sparse engine (nested-dissection ordering perm[new] = old, supernodal nnz(L)) */
 int mi355kkt_op_symbolic(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
                          const int64_t* hrowind, int* perm, int64_t* nnzL, int* nsupernodes, int* nlevels);
-/* host-only: the complete symbolic plan (supernodes, row lists, storage offsets, extend-add maps, assembly lists) as one flat
- * int64 array -- layout in csrc/capi.hip; returns its length (cap = 0 sizes it) or a negative error code */
-int64_t mi355kkt_debug_symbolic_plan(int n, int m, const int64_t* gcolptr, const int64_t* growind, const int64_t* hcolptr,
-                                     const int64_t* hrowind, int64_t* out, int64_t cap);
 /* X(:, 0:ncols) := W^-T X on the 'l' and 'q' rows, in place (misc_solvers.scale, trans='T', inverse='I') */
 int mi355kkt_op_cone_scale(int ml, int nq, const int* q, double* dX, int64_t ldX, int ncols, const double* ddi,
                            const double* dv, const double* dbeta, float* ms);
-/* developer ablation switch for potf2_kernel phases (timing experiments only; results are wrong when != 0) */
-int mi355kkt_debug_hwid(unsigned* out, int nblocks);
-/* the second-order-cone operations of the device-resident loops (csrc/cone_ops.h) executed on the HOST, one cone: for the CPU
- * parity tests against misc.sprod / sinv / ssqr / scale2 / scale / jnrm2 / compute_scaling / update_scaling / max_step */
-int mi355kkt_debug_cone_op_host(int op, int mk, int arg, double* x, double* y, double* w);
-int mi355kkt_debug_sdp_op_host(int op, int m, int arg, double* x, double* y, double* r, double* rti, double* lam);
-int mi355kkt_debug_sdp_op_device(int op, int m, int arg, int team, double* x, double* y, double* r, double* rti, double* lam);
-int mi355kkt_debug_sdp_op_host_team(int op, int m, int arg, int nt, double* x, double* y, double* r, double* rti, double* lam);
-/* the static work list of the scaled SYRK (host only): 8 ints per item = ti, tj, k0, k1, slot, first, nparts, 0; returns #items */
-int mi355kkt_debug_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit);
-/* fill-reducing ordering of a symmetric CSC pattern (host only; csrc/ordering.cpp -- the step cholmod.symbolic performs through
- * cholmod_analyze_p, reference src/C/cholmod.c:309): method 0 choose / 1 nested dissection / 2 approximate minimum degree;
- * perm[new] = old; stats[8] = chosen method, nnz and flops of both candidates, supernodal tree heights, count cross-check */
-int mi355kkt_debug_ordering(int n, const int64_t* colptr, const int64_t* rowind, int method, int* perm, double* stats);
-int mi355kkt_debug_potf2_skip(int mask);
-/* developer aid: device buffer of 48 int64 shader-clock stamps written by the diagonal-block kernel at its phase boundaries (NULL: off) */
-int mi355kkt_debug_potf2_ts(void* dptr);
-/* developer aid: 8 int64 stamps per 128 x 128 tile (column-major tile order) written by the persistent Cholesky kernel */
-int mi355kkt_debug_tile_ts(void* dptr);
-int mi355kkt_debug_trsvz_ts(void* dptr);   /* 8 shader-clock stamps per 128-block of the next trsv_z launches (NULL: off) */
-int mi355kkt_debug_syrk_skip(int mask);
-/* test aid: throws inside a guarded entry point (kind 0: std::bad_alloc, 1: std::runtime_error, 2: a non-standard exception);
- * must RETURN MI355KKT_ENOMEM / MI355KKT_EHIP like any entry point in which host code throws */
-int mi355kkt_debug_throw(int kind);
 /* issue-bound v_mfma_f64_16x16x4_f64 microbenchmark (measured FP64 matrix peak of this device) */
 int mi355kkt_op_mfma_f64_peak(int iters, float* tflops);
 /* in-place lower Cholesky; *info as LAPACK dpotrf */

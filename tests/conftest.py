@@ -101,3 +101,24 @@ def capi():
 
 def to_matrix(cvx, a):
     return cvx.matrix(np.asfortranarray(np.atleast_2d(a.T).T if a.ndim == 1 else a))
+
+
+class _Knobs(object):
+    """developer / test knobs of the library (include/mi355kkt_test.h: mi355kkt_test_set_knob) with monkeypatch's setenv / delenv
+    surface -- the library does not read them from the environment (csrc/knobs.h)"""
+
+    def setenv(self, name, value):
+        from cvxopt_amd import _capi
+        _capi.set_knob(name, value)
+
+    def delenv(self, name, raising=False):
+        from cvxopt_amd import _capi
+        _capi.set_knob(name, None)
+
+
+@pytest.fixture
+def knobs():
+    k = _Knobs()
+    yield k
+    from cvxopt_amd import _capi
+    _capi.set_knob(None, None)

@@ -1,5 +1,6 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol declared in
-include/mi355kkt.h, the ctypes table covers exactly that set, and the host mirror fails loudly without a GPU."""
+include/mi355kkt.h (the boundary) and include/mi355kkt_test.h (the test hooks), the ctypes table covers exactly that set, the
+production library holds NO mi355kkt_debug_* switch, and the host mirror fails loudly without a GPU."""
 import ctypes
 import os
 import re
@@ -10,10 +11,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, "include", "mi355kkt.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(mi355kkt_[a-zA-Z0-9_]+)\s*\(", src)))
+def header_symbols(names=("mi355kkt.h", "mi355kkt_test.h")):
+    out = set()
+    for name in names:
+        src = open(os.path.join(ROOT, "include", name)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        out |= set(re.findall(r"\b(mi355kkt_[a-zA-Z0-9_]+)\s*\(", src))
+    return sorted(out)
 
 
 def test_header_declares_the_expected_surface():
@@ -35,6 +39,57 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_table_matches_header():
     from cvxopt_amd import _capi
     assert sorted(_capi.SIGNATURES.keys()) == header_symbols()
+
+
+def test_boundary_header_is_free_of_test_and_debug_entry_points():
+    """nothing in the production header (or binary) can change results behind the caller's back"""
+    from cvxopt_amd import _capi
+    boundary = header_symbols(("mi355kkt.h",))
+    assert not [s for s in boundary if "_debug_" in s or "_test_" in s]
+    assert all(s.startswith("mi355kkt_test_") for s in header_symbols(("mi355kkt_test.h",)))
+    if os.path.basename(_capi.LIB_PATH) == "libmi355kkt.so":           # (a --debug build is loaded only through $CVXOPT_AMD_LIB)
+        L = _capi.lib()
+        for s in header_symbols(("mi355kkt_debug.h",)):
+            assert s.startswith("mi355kkt_debug_") and not hasattr(L, s), "%s is exported by the production library" % s
+
+
+def test_the_library_does_not_read_knobs_from_the_environment(monkeypatch):
+    """kernel selection / ordering knobs are set through mi355kkt_test_set_knob only (csrc/knobs.h)"""
+    import subprocess
+    import sys
+    so = os.path.join(ROOT, "cvxopt_amd", "libmi355kkt.so")
+    strings = subprocess.run(["strings", "-a", so], capture_output=True, text=True).stdout if os.path.exists(so) else ""
+    if strings:
+        assert "MI355KKT_ROCTX" in strings                  # the one tracing switch
+        src = "".join(open(os.path.join(ROOT, "cvxopt_amd", "csrc", f)).read()
+                      for f in os.listdir(os.path.join(ROOT, "cvxopt_amd", "csrc")) if f.endswith((".hip", ".cpp", ".h")))
+        calls = re.findall(r"(?<![_a-zA-Z])getenv\(\s*\"?([A-Za-z0-9_]*)", src)
+        assert sorted(set(calls)) == ["MI355KKT_ROCTX", "name"], calls      # knobs.cpp: getenv(name) under MI355KKT_DEBUG only
+    # functional: an ordering knob in the environment changes nothing, the same knob through the API does
+    from scipy.sparse import diags
+    from cvxopt_amd import _capi
+    n = 400
+    A = (diags([1.0, 1.0], [1, 20], shape=(n, n)) + diags([1.0, 1.0], [1, 20], shape=(n, n)).T).tocsc()
+    A.sort_indices()
+
+    def method():
+        perm = np.zeros(n, dtype=np.int32)
+        stats = np.zeros(8)
+        rc = _capi.lib().mi355kkt_test_ordering(n, A.indptr.astype(np.int64).ctypes.data_as(_capi.c_i64_p),
+                                                A.indices.astype(np.int64).ctypes.data_as(_capi.c_i64_p), 0,
+                                                perm.ctypes.data_as(_capi.c_int_p), stats.ctypes.data_as(_capi.c_double_p))
+        assert rc == 0
+        return int(stats[0])
+    base = method()
+    other = "amd" if base == 1 else "nd"
+    monkeypatch.setenv("MI355KKT_ORDERING", other)
+    assert method() == base
+    try:
+        _capi.set_knob("MI355KKT_ORDERING", other)
+        assert method() == (2 if other == "amd" else 1)
+    finally:
+        _capi.set_knob(None, None)
+    assert method() == base
 
 
 def test_no_torch_types_in_the_abi():
@@ -122,11 +177,11 @@ def test_no_cpp_exception_crosses_the_c_abi():
     instead of std::terminate-ing the interpreter (header: 'No C++ exception crosses this boundary')"""
     from cvxopt_amd import _capi
     L = _capi.lib()
-    assert L.mi355kkt_debug_throw(3) == 0
-    assert L.mi355kkt_debug_throw(0) == _capi.ENOMEM
+    assert L.mi355kkt_test_throw(3) == 0
+    assert L.mi355kkt_test_throw(0) == _capi.ENOMEM
     assert "out of host memory" in _capi.last_error()
-    assert L.mi355kkt_debug_throw(1) == _capi.EHIP
+    assert L.mi355kkt_test_throw(1) == _capi.EHIP
     assert "requested by the caller" in _capi.last_error()
-    assert L.mi355kkt_debug_throw(2) == _capi.EHIP
+    assert L.mi355kkt_test_throw(2) == _capi.EHIP
     with pytest.raises(MemoryError):
-        _capi.check(L.mi355kkt_debug_throw(0), "debug_throw")
+        _capi.check(L.mi355kkt_test_throw(0), "test_throw")

@@ -1,5 +1,5 @@
 """CPU parity of the second-order-cone operations the device-resident loops use.  cone_ops.h is compiled for the host as well
-(`mi355kkt_debug_cone_op_host` runs the very same functions the kernels call); here they are compared with the reference's
+(`mi355kkt_test_cone_op_host` runs the very same functions the kernels call); here they are compared with the reference's
 misc / misc_solvers on random cones -- sprod, sinv, ssqr, scale2 (both ways), scale (W and W^-1), jnrm2, max_step,
 compute_scaling and a chain of update_scaling steps."""
 import ctypes as C
@@ -13,7 +13,7 @@ from cvxopt_amd import _capi
 def _op(op, mk, x, y=None, w=None, arg=0):
     L = _capi.lib()
     p = lambda a: a.ctypes.data if a is not None else None
-    rc = L.mi355kkt_debug_cone_op_host(op, mk, arg, p(x), p(y), p(w))
+    rc = L.mi355kkt_test_cone_op_host(op, mk, arg, p(x), p(y), p(w))
     assert rc == 0
 
 

@@ -409,20 +409,25 @@ def test_persistent_triangular_solves_stress(n, m):
     f.engine.close()
 
 
-def test_multi_kernel_trsv_path_still_matches(monkeypatch):
-    monkeypatch.setenv("MI355KKT_NO_PERSISTENT_TRSV", "1")
-    n, m = 700, 900
-    pr = synth.dense_qp(n, m, seed=4)
-    W = synth.random_scaling(pr['dims'], seed=2)
-    f = kkt.kkt_chol2(pr['G'], pr['dims'], np.zeros((0, n)))
+def test_multi_kernel_trsm_path_still_matches():
+    """the blocked multi-kernel triangular solve (orders beyond the persistent kernel's co-residency limit, multiple right-hand
+    sides: Asct = L^-1 A') against NumPy, through the stand-alone operator"""
+    import ctypes as C
+    from cvxopt_amd import _capi
     rng = np.random.default_rng(0)
-    bx, bz = rng.standard_normal(n), rng.standard_normal(m)
-    x, y, z = bx.copy(), np.zeros(0), bz.copy()
-    f(W, pr['P'])(x, y, z)
-    xo, yo, zo = bx.copy(), np.zeros(0), bz.copy()
-    ko.KktChol2(pr['G'], pr['dims'], np.zeros((0, n))).factor(W, pr['P'])(xo, yo, zo)
-    assert relerr(x, xo) < 1e-9 and relerr(z, zo) < 1e-9
-    f.engine.close()
+    n, nrhs = 700, 3
+    Lm = np.tril(rng.standard_normal((n, n))) / np.sqrt(n) + 2.0 * np.eye(n)
+    X = rng.standard_normal((n, nrhs))
+    dL, ms = _capi.DeviceBuffer.from_array(np.asfortranarray(Lm)), C.c_float(0)
+    for trans in (0, 1):
+        dX = _capi.DeviceBuffer.from_array(np.asfortranarray(X))
+        _capi.check(_capi.lib().mi355kkt_op_trsm_lower(C.c_void_p(dL.ptr), n, n, C.c_void_p(dX.ptr), n, nrhs, trans, C.byref(ms)),
+                    "op_trsm_lower")
+        got = dX.to_array((n, nrhs))
+        want = np.linalg.solve(Lm.T if trans else Lm, X)
+        assert relerr(got, want) < 1e-11
+        dX.free()
+    dL.free()
 
 
 def test_full_size_config2_coneqp_matches_reference_probe(ref_cvxopt):

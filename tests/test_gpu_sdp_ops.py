@@ -25,9 +25,9 @@ def run(op, m, arg, x, y=None, r=None, rti=None, lam=None, team=None):
     L = _capi.lib()
     a = [None if v is None else v.copy(order='F') for v in (x, y, r, rti, lam)]
     if team is None:
-        rc = L.mi355kkt_debug_sdp_op_host(op, m, arg, *[p(v) for v in a])
+        rc = L.mi355kkt_test_sdp_op_host(op, m, arg, *[p(v) for v in a])
     else:
-        rc = L.mi355kkt_debug_sdp_op_device(op, m, arg, team, *[p(v) for v in a])
+        rc = L.mi355kkt_test_sdp_op_device(op, m, arg, team, *[p(v) for v in a])
     return rc, a
 
 

@@ -269,14 +269,14 @@ def _hub_laplacian(n, seed=0):
 
 @pytest.mark.parametrize("pattern", ["mesh", "hubs"])
 @pytest.mark.parametrize("ordering", ["auto", "amd", "nd", "nd+amd-leaves", "nd-multilevel"])
-def test_sparse_unstructured_patterns_with_every_ordering(pattern, ordering, monkeypatch):
+def test_sparse_unstructured_patterns_with_every_ordering(pattern, ordering, knobs):
     """the orderings of csrc/ordering.cpp (approximate minimum degree, nested dissection with level-set / multilevel
     separators, minimum-degree leaves) only change the elimination order: same solution as the dense oracle"""
     env = {"auto": {}, "amd": {"MI355KKT_ORDERING": "amd"}, "nd": {"MI355KKT_ORDERING": "nd"},
            "nd+amd-leaves": {"MI355KKT_ORDERING": "nd", "MI355KKT_ND_LEAF_AMD": "1"},
            "nd-multilevel": {"MI355KKT_ORDERING": "nd", "MI355KKT_ND_MODE": "2"}}[ordering]
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        knobs.setenv(k, v)
     P = _mesh_laplacian(1800, seed=2) if pattern == "mesh" else _hub_laplacian(1500, seed=2)
     n = P.shape[0]
     G = box(n)

@@ -21,7 +21,7 @@ def ordering(S, method=0):
     ri = np.ascontiguousarray(S.indices, dtype=np.int64)
     perm = np.full(n, -1, dtype=np.int32)
     stats = np.zeros(8)
-    rc = L.mi355kkt_debug_ordering(n, cp.ctypes.data_as(_capi.c_i64_p), ri.ctypes.data_as(_capi.c_i64_p), method,
+    rc = L.mi355kkt_test_ordering(n, cp.ctypes.data_as(_capi.c_i64_p), ri.ctypes.data_as(_capi.c_i64_p), method,
                                    perm.ctypes.data_as(_capi.c_int_p), stats.ctypes.data_as(_capi.c_double_p))
     assert rc == 0
     assert sorted(perm.tolist()) == list(range(n))
@@ -118,7 +118,7 @@ def test_choice_follows_the_cost_model():
     assert amd['levels_amd'] > 500 and st['levels_nd'] < 40 and st['method'] == 1
 
 
-def test_dissection_beats_natural_and_bfs_orderings_on_an_unstructured_mesh(monkeypatch):
+def test_dissection_beats_natural_and_bfs_orderings_on_an_unstructured_mesh(knobs):
     S = delaunay(6000, seed=3)
     n = S.shape[0]
     perm, st = ordering(S, 1)
@@ -127,12 +127,12 @@ def test_dissection_beats_natural_and_bfs_orderings_on_an_unstructured_mesh(monk
     ref = mmd_fill(S)
     assert st['nnz_nd'] < 0.35 * min(natural, rcm)
     assert st['nnz_nd'] <= 1.6 * ref             # breadth-first leaves (wide supernodes for the device kernels), multilevel on parts >= 600
-    monkeypatch.setenv('MI355KKT_ND_LEAF_AMD', '1')
-    monkeypatch.setenv('MI355KKT_ND_MODE', '7')  # multilevel separators for every part
+    knobs.setenv('MI355KKT_ND_LEAF_AMD', '1')
+    knobs.setenv('MI355KKT_ND_MODE', '7')  # multilevel separators for every part
     perm, st2 = ordering(S, 1)
     assert st2['nnz_nd'] <= 1.1 * ref            # + constrained-minimum-degree leaves: the fill of a minimum-degree ordering
     assert st2['nnz_nd'] == exact_fill(S, perm)
-    monkeypatch.setenv('MI355KKT_ND_MODE', '1')  # level-set separators only: visibly worse on a mesh
+    knobs.setenv('MI355KKT_ND_MODE', '1')  # level-set separators only: visibly worse on a mesh
     _, st3 = ordering(S, 1)
     assert st3['nnz_nd'] > st2['nnz_nd']
 
@@ -161,7 +161,7 @@ def delaunay3d(n, seed=0):
     return laplacian_of(sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)))
 
 
-def test_multilevel_dissection_on_a_tetrahedral_mesh(monkeypatch):
+def test_multilevel_dissection_on_a_tetrahedral_mesh(knobs):
     """the class config 4 stands for (finite-element stiffness patterns): the refined multilevel separators cut the
     factorisation work well below both minimum degree and the plain level-set dissection"""
     S = delaunay3d(8000, seed=1)
@@ -169,12 +169,12 @@ def test_multilevel_dissection_on_a_tetrahedral_mesh(monkeypatch):
     _, amd = ordering(S, 2)
     assert st['method'] == 1
     assert st['flops_nd'] < 0.6 * amd['flops_amd'] and st['nnz_nd'] < 0.85 * amd['nnz_amd']
-    monkeypatch.setenv('MI355KKT_ND_MODE', '1')
+    knobs.setenv('MI355KKT_ND_MODE', '1')
     _, levelset = ordering(S, 1)
     assert st['flops_nd'] < 0.5 * levelset['flops_nd']
 
 
-def test_minimum_degree_candidate_runs_only_without_small_separators(monkeypatch):
+def test_minimum_degree_candidate_runs_only_without_small_separators(knobs):
     """structural, deterministic rule of fill_reducing_ordering: mesh-like graphs (top separator <= 1.5 |part|^(2/3)) skip the
     minimum-degree candidate -- 4/5 of the ordering time at 46^3 -- and keep the choice they had with both candidates;
     graphs without small separators still get both; $MI355KKT_ORDERING_BOTH restores the two-candidate run"""

@@ -1,5 +1,5 @@
 """CPU parity of the 's'-block operations of the device-resident loops.  cone_ops_s.h is written once over a "team" of
-threads; `mi355kkt_debug_sdp_op_host` runs the very same functions with a team of one.  They are compared here with the
+threads; `mi355kkt_test_sdp_op_host` runs the very same functions with a team of one.  They are compared here with the
 reference's misc / misc_solvers (compute_scaling, update_scaling, scale, scale2, sprod, sinv, max_step with and without
 sigma) on random blocks.  LAPACK's eigen / singular vectors are unique up to signs (and order inside clusters), so scaling
 matrices are compared through the quantities that do not depend on that choice: r r', rti rti', the sorted lmbda, and the
@@ -13,7 +13,7 @@ from cvxopt_amd import _capi
 def _op(op, m, x, y=None, r=None, rti=None, lam=None, arg=0):
     L = _capi.lib()
     p = lambda a: a.ctypes.data if a is not None else None
-    return L.mi355kkt_debug_sdp_op_host(op, m, arg, p(x), p(y), p(r), p(rti), p(lam))
+    return L.mi355kkt_test_sdp_op_host(op, m, arg, p(x), p(y), p(r), p(rti), p(lam))
 
 
 def _F(a):
@@ -205,7 +205,7 @@ def test_potrf_block_reports_the_failing_pivot():
 @pytest.mark.parametrize("nt", [4, 64])
 @pytest.mark.parametrize("m", [2, 5, 16, 33])
 def test_operations_with_a_team_of_host_threads(m, nt):
-    """the same SPMD source run by nt host threads with a pthread barrier as the team barrier (`mi355kkt_debug_sdp_op_host_team`):
+    """the same SPMD source run by nt host threads with a pthread barrier as the team barrier (`mi355kkt_test_sdp_op_host_team`):
     real concurrency inside a team, as on the device; results must be those of the team of one"""
     L = _capi.lib()
     p = lambda a: a.ctypes.data if a is not None else None
@@ -216,7 +216,7 @@ def test_operations_with_a_team_of_host_threads(m, nt):
     sc, zc = s.copy(order='F'), z.copy(order='F')
     assert _op(6, m, sc, zc, r, rti, lam) == 0
     sc, zc = s.copy(order='F'), z.copy(order='F')
-    assert L.mi355kkt_debug_sdp_op_host_team(6, m, 0, nt, p(sc), p(zc), p(r1), p(rti1), p(lam1)) == 0
+    assert L.mi355kkt_test_sdp_op_host_team(6, m, 0, nt, p(sc), p(zc), p(r1), p(rti1), p(lam1)) == 0
     assert np.allclose(lam, lam1, rtol=1e-12, atol=0)
     assert np.allclose(r @ r.T, r1 @ r1.T, rtol=0, atol=1e-11 * np.linalg.norm(r) ** 2)
     for op, arg, second in ((0, 0, None), (0, 3, None), (1, 0, y), (3, 1, None), (2, 0, None)):
@@ -225,9 +225,9 @@ def test_operations_with_a_team_of_host_threads(m, nt):
         lam0 = rng.random(m) + 0.2
         assert _op(op, m, a, yc, r, rti, lam0, arg=arg) == 0
         yc = None if second is None else second.copy(order='F')
-        assert L.mi355kkt_debug_sdp_op_host_team(op, m, arg, nt, p(b), p(yc), p(r), p(rti), p(lam0)) == 0
+        assert L.mi355kkt_test_sdp_op_host_team(op, m, arg, nt, p(b), p(yc), p(r), p(rti), p(lam0)) == 0
         assert np.allclose(a, b, rtol=1e-13, atol=1e-13 * np.abs(a).max()), (op, arg)
     a, sig = x.copy(order='F'), np.zeros(m)
-    assert L.mi355kkt_debug_sdp_op_host_team(5, m, 0, nt, p(a), None, None, None, p(sig)) == 0
+    assert L.mi355kkt_test_sdp_op_host_team(5, m, 0, nt, p(a), None, None, None, p(sig)) == 0
     assert np.allclose(sig, np.linalg.eigvalsh(x), atol=1e-12 * np.linalg.norm(x))
     assert np.allclose(a @ np.diag(sig) @ a.T, x, atol=1e-12 * np.linalg.norm(x))

@@ -25,10 +25,10 @@ class Plan(object):
         m, n = G.shape
         a = [np.ascontiguousarray(v, dtype=np.int64) for v in (G.indptr, G.indices, H.indptr, H.indices)]
         ptr = [v.ctypes.data_as(_capi.c_i64_p) for v in a]
-        need = L.mi355kkt_debug_symbolic_plan(n, m, ptr[0], ptr[1], ptr[2], ptr[3], None, 0)
+        need = L.mi355kkt_test_symbolic_plan(n, m, ptr[0], ptr[1], ptr[2], ptr[3], None, 0)
         assert need > 0, need
         out = np.zeros(need, dtype=np.int64)
-        got = L.mi355kkt_debug_symbolic_plan(n, m, ptr[0], ptr[1], ptr[2], ptr[3], out.ctypes.data_as(_capi.c_i64_p), need)
+        got = L.mi355kkt_test_symbolic_plan(n, m, ptr[0], ptr[1], ptr[2], ptr[3], out.ctypes.data_as(_capi.c_i64_p), need)
         assert got == need
         (self.n, self.ns, self.nlevels, self.store, nt, nc, self.method, nrows, nch, nrel, nvb, nheavy) = [int(v) for v in out[:12]]
         pos = [16]
@@ -177,9 +177,9 @@ ORDERINGS = {
 
 @pytest.mark.parametrize("ordering", list(ORDERINGS))
 @pytest.mark.parametrize("problem", list(PROBLEMS))
-def test_plan_executes_to_the_cholesky_factor(problem, ordering, monkeypatch):
+def test_plan_executes_to_the_cholesky_factor(problem, ordering, knobs):
     for k, v in ORDERINGS[ordering].items():
-        monkeypatch.setenv(k, v)
+        knobs.setenv(k, v)
     G, H = PROBLEMS[problem]()
     plan = Plan(G, H)
     plan.check_structure()
@@ -194,14 +194,14 @@ def test_plan_executes_to_the_cholesky_factor(problem, ordering, monkeypatch):
     assert np.linalg.norm(S @ x - b) <= 1e-10 * np.linalg.norm(b)
 
 
-def test_big_front_threshold_switches_the_storage_layout(monkeypatch):
+def test_big_front_threshold_switches_the_storage_layout(knobs):
     """every front as a full frontal matrix / every front as panel + update matrix: same factor"""
     G, H = PROBLEMS['laplace 11^3, box (big fronts)']()
     di = np.ones(G.shape[0])
     out = []
     for flops, hmin in ((0, 1), (1e30, 1 << 30)):
-        monkeypatch.setenv('MI355KKT_SPARSE_BIG_FLOPS', repr(flops))
-        monkeypatch.setenv('MI355KKT_SPARSE_BIG_H', str(hmin))
+        knobs.setenv('MI355KKT_SPARSE_BIG_FLOPS', repr(flops))
+        knobs.setenv('MI355KKT_SPARSE_BIG_H', str(hmin))
         plan = Plan(G, H)
         plan.check_structure()
         assert bool(plan.big.all()) == (flops == 0) and bool(plan.big.any()) == (flops == 0)
@@ -210,7 +210,7 @@ def test_big_front_threshold_switches_the_storage_layout(monkeypatch):
 
 
 @pytest.mark.parametrize("seed", range(4))
-def test_random_patterns_orderings_and_thresholds(seed, monkeypatch):
+def test_random_patterns_orderings_and_thresholds(seed, knobs):
     """seeded fuzz: random H / G patterns (empty rows, dense-ish rows, disconnected parts), a random ordering variant and
     random big-front thresholds per case"""
     rng = np.random.default_rng(100 + seed)
@@ -228,12 +228,12 @@ def test_random_patterns_orderings_and_thresholds(seed, monkeypatch):
         name = list(ORDERINGS)[int(rng.integers(len(ORDERINGS)))]
         for k in ('MI355KKT_ORDERING', 'MI355KKT_ND_LEAF_AMD', 'MI355KKT_ND_MODE', 'MI355KKT_ND_NOREFINE',
                   'MI355KKT_SPARSE_BIG_FLOPS', 'MI355KKT_SPARSE_BIG_H'):
-            monkeypatch.delenv(k, raising=False)
+            knobs.delenv(k, raising=False)
         for k, v in ORDERINGS[name].items():
-            monkeypatch.setenv(k, v)
+            knobs.setenv(k, v)
         if rng.random() < 0.4:
-            monkeypatch.setenv('MI355KKT_SPARSE_BIG_FLOPS', repr(float(rng.choice([0, 1e3, 1e30]))))
-            monkeypatch.setenv('MI355KKT_SPARSE_BIG_H', str(int(rng.choice([1, 8, 48]))))
+            knobs.setenv('MI355KKT_SPARSE_BIG_FLOPS', repr(float(rng.choice([0, 1e3, 1e30]))))
+            knobs.setenv('MI355KKT_SPARSE_BIG_H', str(int(rng.choice([1, 8, 48]))))
         di = 10.0 ** rng.uniform(-1, 1, G.shape[0])
         plan = Plan(G, H)
         plan.check_structure()
@@ -255,13 +255,13 @@ def test_structure_of_a_larger_plan_with_heavy_supernodes():
 
 
 @pytest.mark.parametrize("maxw", ["8", "256", None])
-def test_supernode_width_cap_changes_the_partition_not_the_factor(maxw, monkeypatch):
+def test_supernode_width_cap_changes_the_partition_not_the_factor(maxw, knobs):
     """$MI355KKT_SN_MAXW: chains of narrow pieces (8), the round-1 cap (256), the default (8192: the 16^3 grid's root separator
     of 256 columns and its children become single wide supernodes, more than the 128 columns of sp_wide_threshold()): the
     executed plan is the same Cholesky factor, with fewer levels the wider the supernodes may be"""
-    monkeypatch.setenv('MI355KKT_ORDERING', 'nd')
+    knobs.setenv('MI355KKT_ORDERING', 'nd')
     if maxw is not None:
-        monkeypatch.setenv('MI355KKT_SN_MAXW', maxw)
+        knobs.setenv('MI355KKT_SN_MAXW', maxw)
     G, H = box(4096), lap3(16)
     plan = Plan(G, H)
     plan.check_structure()

@@ -16,7 +16,7 @@ def plan(n, K, cus=256, split=True):
     cap = 1 << 16
     out = np.zeros(8 * cap, dtype=np.int32)
     ns, nsp = C.c_int(), C.c_int()
-    cnt = L.mi355kkt_debug_syrk_plan(n, K, cus, 1 if split else 0, out.ctypes.data_as(_capi.c_int_p), cap, C.byref(ns), C.byref(nsp))
+    cnt = L.mi355kkt_test_syrk_plan(n, K, cus, 1 if split else 0, out.ctypes.data_as(_capi.c_int_p), cap, C.byref(ns), C.byref(nsp))
     assert 0 <= cnt <= cap
     return out[:8 * cnt].reshape(cnt, 8), ns.value, nsp.value
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # Host-side ThreadSanitizer build of libmi355kkt: the SPMD 's'-block operations of csrc/cone_ops_s.h run by teams of host
-# threads (mi355kkt_debug_sdp_op_host_team, a pthread barrier as the team barrier) under TSan -- a missing barrier or a data
+# threads (mi355kkt_test_sdp_op_host_team, a pthread barrier as the team barrier) under TSan -- a missing barrier or a data
 # race between the threads of a team shows up here without a GPU.  Second part: the threaded host analysis of the sparse engine.
 #     bash tools/tsan_host.sh
 set -euo pipefail
