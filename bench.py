@@ -477,7 +477,7 @@ def main_sharded(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # per-phase wall time of the step on every rank (mean over the timed steps), gathered as plain objects outside the timing
-    keys = ("scatter_exposed", "scatter_all", "upload", "solve", "gather_exposed", "total")
+    keys = ("scatter_exposed", "scatter_all", "upload", "solve", "pack", "gather_exposed", "total")
     mine = {k: (sum(p_[k] for p_ in phase) / max(1, len(phase))) for k in keys}
     per_rank = [mine]
     if dist is not None:
@@ -546,6 +546,11 @@ def main_sharded(args):
                                                "note": "the same %d problems solved by the root GPU alone: persistent engine, upload "
                                                        "of the resident problem data into it + solve per step (no collectives)" % B}
                 out["speedup_vs_1gpu"] = round((1e3 * t1) / ms, 3)
+                # what the sharding plumbing costs beyond the solves (767 vs 719 ms at world size 1): per rank
+                # total - solve = scatter wait + upload + packing + gather wait + the sub-batch loop's own host time
+                out["plumbing_ms_per_rank"] = [round(p_["total"] - p_["solve"], 3) for p_ in per_rank]
+                out["single_gpu_reference"]["sub_batches"] = "1 engine over all %d problems (the sharded step runs %d sub-batch " \
+                    "engines per rank: %d lock-step loops with their own per-iteration host synchronisation)" % (B, sb.nsub, sb.nsub)
             except Exception as e:
                 out["single_gpu_reference"] = {"error": repr(e)}
         _emit(json.dumps(out))
@@ -919,7 +924,7 @@ def main():
             src_id = hsh.hexdigest()[:16]
         except Exception:
             src_id = None
-        for name in ("r03_pmc_syrk.json",):
+        for name in ("r04_pmc_syrk.json", "r03_pmc_syrk.json"):
             pj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pj):
                 try:
@@ -962,6 +967,13 @@ def main():
                                    % (0 if (n, m) == (256, 512) else 1, n, m),
                        "replicas": world, "formulation": "reduced S = P + G'D^2G, Cholesky (kkt_chol2/ldl engine)"},
             "phases_ms": {k: round(v, 3) for k, v in tm.items()},
+            # the same step at the HOOK boundary (SURVEY 8(d) / BASELINE.md 3: host W, P, x, y, z cross PCIe inside the timing) as
+            # headline fields next to value / ms_per_step; `value` itself stays the resident-input rate (bench contract: a
+            # PCIe-inclusive rate is never `value`), the CPU reference is timed at the hook, so speedup_vs_cpu_at_hook is the
+            # like-for-like ratio
+            "value_boundary": "inputs resident in HBM (factor_device + 2 solve_device); hook_value / hook_ms_per_step = the same "
+                              "step through kkt_chol2(G, dims, A)(W, P)(x, y, z) with host buffers",
+            "hook_value": None if (hook is None or not hook.get("ms_per_step")) else round(1e3 / hook["ms_per_step"], 4),
             "hook_ms_per_step": None if hook is None else hook.get("ms_per_step"),
             "hook": hook,
             "ipm_end_to_end": ipm,

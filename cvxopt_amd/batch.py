@@ -429,7 +429,10 @@ class ShardedBatch(object):
     `dist.gather`.  No collective inside the interior-point loop.
     """
 
-    def __init__(self, B, n, m, hasP, group=None, root=0, nsub=4, local_solver=None, device_of_rank=None):
+    def __init__(self, B, n, m, hasP, group=None, root=0, nsub=4, local_solver=None, device_of_rank=None, engine_factory=None):
+        """engine_factory(shape=(cnt, n, m), device=index) -> an object with BatchKkt's set_problem / coneqp / close: the
+        device-resident branch then runs with it whatever the backend (tests walk the RCCL branch's exact ordering -- scatter
+        lists, async work handles, wait order, packed gather -- over gloo with host tensors this way); None: `BatchKkt` on RCCL."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -457,7 +460,8 @@ class ShardedBatch(object):
         if self.rank == root:
             self.gathered = [[torch.empty((self.sb[k + 1] - self.sb[k], self.width), **f64) for _ in range(self.world)]
                              for k in range(self.nsub)]
-        self.on_device = (self.backend == "nccl" and local_solver is None)
+        self.engine_factory = engine_factory
+        self.on_device = engine_factory is not None or (self.backend == "nccl" and local_solver is None)
         self.engines = [None] * self.nsub          # BatchKkt per sub-batch, created at the first solve and kept
         self.last_timings = {}
 
@@ -503,14 +507,14 @@ class ShardedBatch(object):
     def _wait(self, works):
         for w in works:
             w.wait()
-        if self.backend == "nccl":               # host waits for THESE collectives only (later ones keep flying)
+        if self.dev.type == "cuda":              # host waits for THESE collectives only (later ones keep flying)
             self.torch.cuda.current_stream(self.dev).synchronize()
 
     def solve(self, P, q, Gt, h, return_device=False, **opts):
         """P, q, Gt, h are only read on the root (other ranks may pass None).  The root returns the FULL gathered result dict,
         the other ranks their local shard's.  `self.last_timings` (ms, this rank): scatter_exposed (until the first sub-batch
-        was complete here), scatter_all (until the last one was), upload, solve (sum over sub-batches), gather_exposed (after the
-        last solve), total."""
+        was complete here), scatter_all (until the last one was), upload, solve (sum over sub-batches), pack (results into the packed
+        gather rows), gather_exposed (after the last solve), total."""
         import time
         torch, dist = self.torch, self.dist
         n, m, root = self.n, self.m, self.root
@@ -526,7 +530,7 @@ class ShardedBatch(object):
             if self.hasP:
                 wk.append(self._scatter_sub(k, fulls[3] if fulls else None, self.P_l))
             works.append(wk)
-        tm = {"scatter_exposed": 0.0, "scatter_all": 0.0, "upload": 0.0, "solve": 0.0, "gather_exposed": 0.0}
+        tm = {"scatter_exposed": 0.0, "scatter_all": 0.0, "upload": 0.0, "solve": 0.0, "pack": 0.0, "gather_exposed": 0.0}
         gworks, lockstep = [], 0
         sopts = {k_: v for k_, v in opts.items() if k_ != "resident"}
         for k in range(self.nsub):
@@ -542,14 +546,16 @@ class ShardedBatch(object):
                 q_k, h_k = self.q_l[a:b], self.h_l[a:b]
                 if self.on_device and opts.get("resident", True):
                     if self.engines[k] is None:
-                        self.engines[k] = BatchKkt(shape=(cnt, n, m), device=self.dev.index)
+                        make = self.engine_factory or BatchKkt
+                        self.engines[k] = make(shape=(cnt, n, m), device=self.dev.index)
                     eng = self.engines[k]
                     t2 = time.perf_counter()
                     eng.set_problem(G_k, P_k)
                     t3 = time.perf_counter()
                     res = eng.coneqp(q_k, h_k, **sopts)
+                    t3b = time.perf_counter()
                     tm["upload"] += 1e3 * (t3 - t2)
-                    tm["solve"] += 1e3 * (time.perf_counter() - t3)
+                    tm["solve"] += 1e3 * (t3b - t3)
                     pk = self.pack[a:b]
                     pk[:, :n] = res['x']
                     pk[:, n:n + m] = res['s']
@@ -560,6 +566,7 @@ class ShardedBatch(object):
                     pk[:, n + 2 * m + 3] = res['status_code'].to(torch.float64)
                     pk[:, n + 2 * m + 4] = res['iterations'].to(torch.float64)
                     lockstep = max(lockstep, int(res['lockstep iterations']))
+                    tm["pack"] += 1e3 * (time.perf_counter() - t3b)       # (enqueue time of the packing copies on a GPU)
                 else:
                     t3 = time.perf_counter()
                     Pn = P_k.cpu().numpy() if P_k is not None else None
@@ -603,7 +610,9 @@ class ShardedBatch(object):
                         'lockstep iterations': ls})
             return vec
         if self.rank != root:
-            return unpack(self.pack[:self.nloc], lockstep)
+            # (a copy: self.pack is persistent and the next solve() overwrites it -- a caller holding return_device views of
+            #  the previous result must not see them change)
+            return unpack(self.pack[:self.nloc].clone() if return_device else self.pack[:self.nloc], lockstep)
         # rank r's shard = its rows of every sub-batch, in order
         pieces = []
         for r, (lo, hi) in enumerate(self.bounds):
@@ -637,8 +646,12 @@ def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, dev
         meta = [(int(q.shape[0]), int(q.shape[1]), int(h.shape[1]), P is not None)]
     dist.broadcast_object_list(meta, src=root, group=group)
     B, n, m, hasP = meta[0]
-    key = (id(group), root, B, n, m, hasP, int(nsub), id(local_solver), dist.get_backend(group), dist.get_world_size(group))
+    # keyed on the group OBJECT (kept alive by the cache entry, so its id cannot be recycled under us) and this rank in it;
+    # local_solver is not part of the key (it is re-assigned below: a fresh lambda per call must not rebuild the engines)
+    key = (group, rank, root, B, n, m, hasP, int(nsub), dist.get_backend(group), dist.get_world_size(group))
     sb = _SHARDED_CACHE.get(key)
+    if sb is not None and sb.on_device != (sb.engine_factory is not None or (sb.backend == "nccl" and local_solver is None)):
+        sb = None                                     # device-resident <-> host-solver switch: rebuild
     if sb is None:
         for old in list(_SHARDED_CACHE.values()):    # one shape at a time: the engines hold GBs
             old.close()
@@ -647,3 +660,11 @@ def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, dev
                                                 device_of_rank=device_of_rank)
     sb.local_solver = local_solver
     return sb.solve(P, q, Gt, h, return_device=return_device, **opts)
+
+
+def clear_sharded_cache():
+    """closes the cached ShardedBatch (engines, buffers): call before torch.distributed.destroy_process_group() -- the cache
+    entry holds the group it was built for"""
+    for old in list(_SHARDED_CACHE.values()):
+        old.close()
+    _SHARDED_CACHE.clear()

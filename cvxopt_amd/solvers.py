@@ -143,12 +143,14 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
     (`mi355kkt_conelp_init`, all three cone types, primalstart / dualstart included, coneprog.py:696-739).  The reference driver
     runs on the host with G, A as device operators and the GPU kktsolver ('chol' | 'chol2' | 'ldl' | 'ldl2') only for
     `device_loop=False`, options['debug'], extra keyword arguments (xnewcopy ...) or a problem without cone rows."""
-    from cvxopt import solvers, spmatrix
+    # (the reference drivers are taken from their defining module: `cvxopt.solvers.conelp = cvxopt_amd.solvers.conelp` is a
+    #  legitimate way to drop this backend in, and must not make the host-driver path call itself)
+    from cvxopt import coneprog, spmatrix
     dims = _dims_of(h, dims)
     n = c.size[0]
     if kktsolver is not None and not isinstance(kktsolver, str):
         # a user kktsolver(W): the reference driver and the user's code, nothing of ours
-        return solvers.conelp(c, G, h, dims, A=A, b=b, primalstart=primalstart, dualstart=dualstart, kktsolver=kktsolver,
+        return coneprog.conelp(c, G, h, dims, A=A, b=b, primalstart=primalstart, dualstart=dualstart, kktsolver=kktsolver,
                               **kwargs)
     extra = set(kwargs) - {'options'}
     o, kktreg, debug, ks_name = _options(kwargs, dims, True, kktsolver)
@@ -164,7 +166,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
         kw = {}
         if A is not None:
             kw = {'A': Aop, 'b': b}
-        return solvers.conelp(c, Gop, h, dims, primalstart=primalstart, dualstart=dualstart, kktsolver=ks, **kw, **kwargs)
+        return coneprog.conelp(c, Gop, h, dims, primalstart=primalstart, dualstart=dualstart, kktsolver=ks, **kw, **kwargs)
     finally:
         eng.close()
 
@@ -175,14 +177,14 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
     (`mi355kkt_coneqp_init`, all three cone types, initvals and options['use_correction'] included, coneprog.py:2109-2149, :1781);
     the reference driver runs on the host with P, G, A as device operators only for `device_loop=False`, options['debug'], extra
     keyword arguments or a problem without cone rows."""
-    from cvxopt import solvers, spmatrix, matrix
+    from cvxopt import coneprog, spmatrix, matrix
     n = q.size[0]
     if G is None:
         G, h = spmatrix([], [], [], (0, n)), matrix(0.0, (0, 1))
     dims = _dims_of(h, dims)
     if kktsolver is not None and not isinstance(kktsolver, str):
         # a user kktsolver(W): the reference driver and the user's code, nothing of ours
-        return solvers.coneqp(P, q, G, h, dims, A=A, b=b, initvals=initvals, kktsolver=kktsolver, **kwargs)
+        return coneprog.coneqp(P, q, G, h, dims, A=A, b=b, initvals=initvals, kktsolver=kktsolver, **kwargs)
     extra = set(kwargs) - {'options'}
     o, kktreg, debug, ks_name = _options(kwargs, dims, False, kktsolver)
     if device_loop and not extra and not debug and (dims['l'] + sum(dims['q']) + sum(dims['s'])) > 0:
@@ -199,7 +201,7 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
         kw = {}
         if A is not None:
             kw = {'A': Aop, 'b': b}
-        return solvers.coneqp(Pop, q, Gop, h, dims, initvals=initvals, kktsolver=ks, **kw, **kwargs)
+        return coneprog.coneqp(Pop, q, Gop, h, dims, initvals=initvals, kktsolver=ks, **kw, **kwargs)
     finally:
         _kkt.options['assume_constant_H'] = const_H
         eng.close()
@@ -341,20 +343,20 @@ def cpl(c, F, G=None, h=None, dims=None, A=None, b=None, kktsolver=None, **kwarg
     `factor(W, H, Df)` / solve on the device through the kktsolver names ('ldl', 'ldl2', 'chol', 'chol2'; default as the
     reference: 'chol' with q / s cones, 'chol2' otherwise).  The nonlinear-constraint rows (mnl, Df) are refreshed on the
     device at every call (`mi355kkt_set_G_rows`)."""
-    from cvxopt import solvers
+    from cvxopt import cvxprog
     with _gpu_factories():
-        return solvers.cpl(c, F, G, h, dims, A, b, kktsolver=kktsolver, **kwargs)
+        return cvxprog.cpl(c, F, G, h, dims, A, b, kktsolver=kktsolver, **kwargs)
 
 
 def cp(F, G=None, h=None, dims=None, A=None, b=None, kktsolver=None, **kwargs):
     """cvxopt.solvers.cp (cvxprog.py:1359) with the GPU factories behind the kktsolver names."""
-    from cvxopt import solvers
+    from cvxopt import cvxprog
     with _gpu_factories():
-        return solvers.cp(F, G, h, dims, A, b, kktsolver=kktsolver, **kwargs)
+        return cvxprog.cp(F, G, h, dims, A, b, kktsolver=kktsolver, **kwargs)
 
 
 def gp(K, F, g, G=None, h=None, A=None, b=None, kktsolver=None, **kwargs):
     """cvxopt.solvers.gp (cvxprog.py:1967: geometric program, calls cp) with the GPU factories."""
-    from cvxopt import solvers
+    from cvxopt import cvxprog
     with _gpu_factories():
-        return solvers.gp(K, F, g, G, h, A, b, kktsolver=kktsolver, **kwargs)
+        return cvxprog.gp(K, F, g, G, h, A, b, kktsolver=kktsolver, **kwargs)

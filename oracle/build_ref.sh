@@ -45,4 +45,24 @@ for f in sorted(os.listdir(src)):
                            dfile='cvxopt/' + f, doraise=True, optimize=0)
 PY
 cp "$HERE/cholmod_shim.py" "$OUT/cholmod.py"
-echo "build_ref: done -> $OUT"
+# The reference's OWN test-suite and documentation examples for this path (tests/test_custom_kkt.py, test_examples.py,
+# test_modeling.py; examples/doc/chap8-10), staged sourceless like the drivers: byte-compiled .pyc files + the one data file
+# test_modeling reads.  tests/test_gpu_reference_suite.py runs them through the GPU backend on the box.
+python3 - "$REF" "$HERE/_ref/reftests" <<'PY'
+import sys, os, py_compile, shutil
+ref, out = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.join(out, "tests"), exist_ok=True)
+for f in ("test_custom_kkt.py", "test_examples.py", "test_modeling.py"):
+    py_compile.compile(os.path.join(ref, "tests", f), cfile=os.path.join(out, "tests", f + "c"), dfile="reftests/tests/" + f,
+                       doraise=True, optimize=0)
+shutil.copyfile(os.path.join(ref, "tests", "boeing2.mps"), os.path.join(out, "tests", "boeing2.mps"))
+for chap in ("chap8", "chap9", "chap10"):
+    src = os.path.join(ref, "examples", "doc", chap)
+    dst = os.path.join(out, "examples", "doc", chap)
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(os.listdir(src)):
+        if f.endswith(".py"):
+            py_compile.compile(os.path.join(src, f), cfile=os.path.join(dst, f + "c"), dfile="reftests/examples/doc/%s/%s" % (chap, f),
+                               doraise=True, optimize=0)
+PY
+echo "build_ref: done -> $OUT (+ $HERE/_ref/reftests)"

@@ -104,3 +104,85 @@ def test_sharded_batch_on_gloo(tmp_path, world, nprob, nsub):
         assert np.allclose(got['x%d' % rep], ref['x'], rtol=0, atol=1e-12)
         assert np.allclose(got['z%d' % rep], ref['z'], rtol=0, atol=1e-12)
         assert np.allclose(got['pobj%d' % rep], ref['primal objective'], rtol=1e-13)
+
+
+def _worker_device_branch(rank, world, port, tmp, nprob, nsub):
+    """the DEVICE-RESIDENT branch of ShardedBatch (what runs over RCCL with BatchKkt engines) over gloo with host tensors:
+    tensor inputs on the root, persistent engines per sub-batch, tensors back (return_device=True), two solves"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    import torch.distributed as dist
+    from cvxopt_amd import batch
+    from batch_helpers import TensorEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sb = batch.ShardedBatch(nprob, 16, 40, True, nsub=nsub, engine_factory=TensorEngine)
+    assert sb.on_device
+    out, held = {}, None
+    for rep in range(2):
+        if rank == 0:
+            P, q, Gt, h = pack_problems(make_batch(nprob, 16, 40, seed0=3 + 100 * rep))
+            args = [torch.from_numpy(a) for a in (P, q, Gt, h)]          # "already resident": tensors, as on the RCCL path
+        else:
+            args = [None] * 4
+        res = sb.solve(*args, return_device=True, use_correction=(rep == 0))
+        assert hasattr(res['x'], "numpy")                                  # tensors come back
+        if rep == 0:
+            held = (res['x'], res['x'].clone())
+        if rank == 0:
+            out.update({"x%d" % rep: res['x'].numpy(), "it%d" % rep: res['iterations'], "z%d" % rep: res['z'].numpy()})
+        else:
+            lo, hi = batch.shard_bounds(nprob, world)[rank]
+            assert tuple(res['x'].shape) == (hi - lo, 16)
+    # the first result must not have been overwritten by the second solve (non-root ranks used to hand out views of sb.pack)
+    assert torch.equal(held[0], held[1])
+    # engines: one per non-empty sub-batch of this rank, created once and reused by the second solve
+    creates = [e for e in TensorEngine.log if e[0] == "create"]
+    solves = [e for e in TensorEngine.log if e[0] == "coneqp"]
+    nonempty = sum(1 for k in range(sb.nsub) if sb._rows(k)[1] > sb._rows(k)[0])
+    assert len(creates) == nonempty and len(solves) == 2 * nonempty
+    assert [e[0] for e in TensorEngine.log[:3]] == ["create", "set_problem", "coneqp"][:len(TensorEngine.log)]
+    sb.close()
+    if rank == 0:
+        np.savez(tmp, **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nprob,nsub", [(2, 5, 4), (3, 7, 2), (4, 3, 2)])
+def test_sharded_batch_device_resident_branch_on_gloo(tmp_path, world, nprob, nsub):
+    """the first multi-GPU run must not be the first execution of the RCCL branch's control flow"""
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path / "out.npz")
+    port = 31500 + (os.getpid() % 2000) + 7 * world + nprob
+    mp.spawn(_worker_device_branch, args=(world, port, tmp, nprob, nsub), nprocs=world, join=True)
+    got = np.load(tmp)
+    for rep in range(2):
+        P, q, Gt, h = pack_problems(make_batch(nprob, 16, 40, seed0=3 + 100 * rep))
+        ref = coneqp_batch(P, q, Gt, h, kkt=NumpyBatchKkt(Gt, P), use_correction=(rep == 0))
+        assert np.array_equal(got['it%d' % rep], ref['iterations'])
+        assert np.allclose(got['x%d' % rep], ref['x'], rtol=0, atol=1e-12)
+        assert np.allclose(got['z%d' % rep], ref['z'], rtol=0, atol=1e-12)
+
+
+def test_sharded_cache_key_survives_fresh_lambdas_and_is_cleared(tmp_path):
+    """a new lambda per call must not rebuild the ShardedBatch; clear_sharded_cache() closes it"""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_cache, args=(29400 + os.getpid() % 2000,), nprocs=1, join=True)
+
+
+def _worker_cache(rank, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from cvxopt_amd import batch
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    P, q, Gt, h = pack_problems(make_batch(3, 8, 20, seed0=1))
+    seen = []
+    for _ in range(3):
+        batch.coneqp_batch_sharded(P, q, Gt, h, local_solver=lambda *a, **k: numpy_local_solver(*a, **k), nsub=2)
+        seen.append(id(next(iter(batch._SHARDED_CACHE.values()))))
+    assert len(set(seen)) == 1 and len(batch._SHARDED_CACHE) == 1
+    batch.clear_sharded_cache()
+    assert not batch._SHARDED_CACHE
+    dist.destroy_process_group()

@@ -156,8 +156,8 @@ def test_external_solver_bridges_are_refused(ref_cvxopt, monkeypatch):
 def test_cvxprog_wrappers_bind_the_gpu_factories_for_the_call_only(ref_cvxopt, monkeypatch):
     """cp / cpl / gp run the reference drivers with cvxopt.misc.kkt_* pointing at the GPU factories during the call."""
     import cvxopt.misc as misc
-    from cvxopt import solvers
-    from cvxopt_amd import kkt
+    from cvxopt import cvxprog as solvers      # the wrappers take the drivers from their defining module (a patched cvxopt.solvers
+    from cvxopt_amd import kkt                 # attribute -- e.g. cvxopt.solvers.cp = cvxopt_amd.solvers.cp -- must not recurse)
     before = {n: getattr(misc, n) for n in ('kkt_chol', 'kkt_chol2', 'kkt_ldl', 'kkt_ldl2', 'kkt_qr')}
     seen = {}
 
