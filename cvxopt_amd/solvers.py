@@ -207,11 +207,15 @@ def coneqp(P, q, G=None, h=None, dims=None, A=None, b=None, initvals=None, kktso
         eng.close()
 
 
-def _no_external_solver(kwargs):
-    """`solver=` of solvers.lp / qp / socp / sdp selects GLPK / MOSEK / DSDP in the reference (coneprog.py:2550, :3013,
-    :3566, :4156): bridges to other codes, outside this backend.  None (the default) is accepted and dropped."""
+_EXTERNAL = {'lp': ('glpk', 'mosek'), 'socp': ('mosek',), 'sdp': ('dsdp',), 'qp': ('mosek',)}
+
+
+def _no_external_solver(kwargs, which):
+    """`solver=` of solvers.lp / qp / socp / sdp selects GLPK / MOSEK / DSDP in the reference (coneprog.py:2807, :2877, :3332,
+    :3893, :4343): bridges to other codes, outside this backend.  Every OTHER value -- None, 'default' (what modeling.op.solve
+    passes, modeling.py:2627), any unknown string -- means conelp / coneqp there, and so it does here."""
     solver = kwargs.pop('solver', None)
-    if solver is not None:
+    if solver in _EXTERNAL[which]:
         raise ValueError("cvxopt_amd.solvers: solver=%r selects an external solver of the reference; only the default "
                          "(conelp / coneqp) runs on the device" % (solver,))
     return kwargs
@@ -261,7 +265,7 @@ def _split_cone_vectors(sol, ml, sizes, suffix, shape):
 def socp(c, Gl=None, hl=None, Gq=None, hq=None, A=None, b=None, primalstart=None, dualstart=None, **kwargs):
     """cvxopt.solvers.socp's argument convention (coneprog.py:3013-3378: stacks Gl, Gq[k] and calls conelp)."""
     from cvxopt import matrix
-    kwargs = _no_external_solver(kwargs)
+    kwargs = _no_external_solver(kwargs, 'socp')
     n = c.size[0]
     Gq, hq = list(Gq or []), list(hq or [])
     if len(Gq) != len(hq):
@@ -287,7 +291,7 @@ def sdp(c, Gl=None, hl=None, Gs=None, hs=None, A=None, b=None, primalstart=None,
     m_k x m_k matrices.  The whole loop runs on the device ('s' blocks included, csrc/cone_ops_s.h), primalstart / dualstart
     included (stacked here and handed to `mi355kkt_conelp_init`)."""
     from cvxopt import matrix
-    kwargs = _no_external_solver(kwargs)
+    kwargs = _no_external_solver(kwargs, 'sdp')
     n = c.size[0]
     Gs, hs = list(Gs or []), list(hs or [])
     ms = [int(round(Gk.size[0] ** 0.5)) for Gk in Gs]
@@ -316,12 +320,12 @@ def sdp(c, Gl=None, hl=None, Gs=None, hs=None, A=None, b=None, primalstart=None,
 
 def lp(c, G, h, A=None, b=None, **kwargs):
     """cvxopt.solvers.lp (coneprog.py:2562: conelp with dims = {'l': m})."""
-    return conelp(c, G, h, {'l': h.size[0], 'q': [], 's': []}, A, b, **_no_external_solver(kwargs))
+    return conelp(c, G, h, {'l': h.size[0], 'q': [], 's': []}, A, b, **_no_external_solver(kwargs, 'lp'))
 
 
 def qp(P, q, G=None, h=None, A=None, b=None, **kwargs):
     """cvxopt.solvers.qp (coneprog.py:4258: coneqp with dims = {'l': m})."""
-    return coneqp(P, q, G, h, None, A, b, **_no_external_solver(kwargs))
+    return coneqp(P, q, G, h, None, A, b, **_no_external_solver(kwargs, 'qp'))
 
 
 class _gpu_factories(object):

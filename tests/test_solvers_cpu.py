@@ -151,6 +151,14 @@ def test_external_solver_bridges_are_refused(ref_cvxopt, monkeypatch):
                  lambda: gs.socp(c, G, h, solver='mosek'), lambda: gs.sdp(c, G, h, solver='dsdp')):
         with pytest.raises(ValueError):
             call()
+    # anything else -- 'default' is what cvxopt.modeling.op.solve passes (modeling.py:2627; found by running the reference's own
+    # test_modeling / chap10 examples through cvxopt_amd.solvers in round 4) -- means conelp / coneqp in the reference
+    # (coneprog.py:2807, :2877: only the names of the bridges are compared)
+    seen.clear()
+    gs.lp(c, G, h, solver='default')
+    gs.lp(c, G, h, solver='dsdp')                    # not a bridge of lp: falls through to conelp there too
+    gs.qp(matrix([[1.0, 0.0], [0.0, 1.0]]), c, G, h, solver='default')
+    assert seen['conelp'] == {} and seen['coneqp'] == {}
 
 
 def test_cvxprog_wrappers_bind_the_gpu_factories_for_the_call_only(ref_cvxopt, monkeypatch):
