@@ -524,7 +524,7 @@ template <bool TRANS, bool INV>
 __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __restrict__ L, int64_t ldl, int n,
                                                               double* x, u32 epoch, int* err, u64* gran,
                                                               const double* __restrict__ minv,
-                                                              const TrsvJob* __restrict__ jobs) {
+                                                              const TrsvJob* __restrict__ jobs, int xmap) {
     if (jobs) {
         const TrsvJob jb = jobs[blockIdx.y];
         L = jb.L;
@@ -543,7 +543,12 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = tid >> 7, r = tid & (TB - 1);
     const int nblk = (n + TB - 1) / TB;
-    const int k = TRANS ? (nblk - 1 - (int)blockIdx.x) : (int)blockIdx.x;   // dispatch order ~ dependency order
+    // position of this workgroup along the chain.  xmap (experiment, round 4): workgroup ids are dealt round-robin over the 8 XCDs
+    // (observed dispatch, not a contract -- only speed depends on it): with pos = (id % 8) * (nblk / 8) + id / 8 eight consecutive
+    // block rows sit on one XCD, so seven of eight hand-offs stay inside that XCD's L2
+    int pos = (int)blockIdx.x;
+    if (xmap && (nblk & 7) == 0) pos = (pos & 7) * (nblk >> 3) + (pos >> 3);
+    const int k = TRANS ? (nblk - 1 - pos) : pos;
     const int k0 = k * TB;
     const int nb = min(TB, n - k0);
     const int idx = k0 + r;                           // my row (forward) / my column (backward)
@@ -732,21 +737,216 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
     }
 }
 
+// ===================================================================================================
+// Round 4: the same solve as TWO pipelined sweeps, two workgroups per block row.
+//
+// trsv_persistent_kernel<.., INV> solves every diagonal block with M = inv(L_kk) plus one step of fixed-precision refinement:
+// three dependent matrix-vector stages per hop (x0 = M b, e = b - L_kk x0, x = x0 + M e), 4.2 us per 128 rows of which the
+// hand-off is ~1 us.  Here the refinement leaves the hop: the correction is applied GLOBALLY, as a second sweep that follows the
+// first one block behind.
+//     sweep 1 (workgroup A_k):  b1_k = rhs_k - sum_{j<k} L_kj x0_j,   x0_k = M_k b1_k,   e_k = b1_k - L_kk x0_k
+//     sweep 2 (workgroup B_k):  b2_k = e_k  - sum_{j<k} L_kj d_j,     d_k  = M_k b2_k,   x_k = x0_k + d_k
+// e is exactly the residual rhs - L x0 (row block k: rhs_k - sum_{j<=k} L_kj x0_j), d the block solve of L d = e with the same
+// inverses: x = x0 + d is ONE step of fixed-precision iterative refinement of the whole triangular solve -- backward stable under
+// the same condition as the per-block refinement it replaces (Skeel 1980; Higham, Accuracy and Stability, Thm 12.3: the solver
+// need only be "not too unstable", here eps cond(L_kk) << 1).  Each chain's hop is hand-off + 64 FMAs + ONE matrix-vector stage;
+// B_k needs e_k from A_k (one more hand-off, off the chains' critical paths) and streams the strips of its block row a second
+// time (they are in the Infinity Cache / L2: A_k read them a moment ago).  2 nblk co-resident workgroups: orders up to 128 x #CUs / 2.
+// Hand-offs are the data-tagged granules of the kernel above: blocks [0, nblk) carry x0, [nblk, 2 nblk) d, [2 nblk, 3 nblk) e.
+// Deterministic (fixed summation order); every spin is bounded and a timeout sets *err.
+// ===================================================================================================
+constexpr int TRSV_PAIR_XCD_DEFAULT = 0;
+
+template <bool TRANS>
+__global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict__ L, int64_t ldl, int n, double* x, u32 epoch,
+                                                        int* err, u64* gran, const double* __restrict__ minv, int xcd) {
+    __shared__ double xs2[2][TB];
+    __shared__ double ps2[2][TB];
+    __shared__ double es[TB];
+    const int tid = threadIdx.x;
+    const int half = tid >> 7, r = tid & (TB - 1);
+    const int nblk = n / TB;                                // whole 128-blocks only (checked by the launcher)
+    // Workgroup ids are dealt round-robin over the 8 XCDs (observed dispatch order -- not a contract: only SPEED depends on it).
+    // With nblk a multiple of 8, XCD x = id % 8 gets the chain positions x nblk/8 .. (x + 1) nblk/8 - 1 of BOTH sweeps (its slots
+    // alternate between the roles), so seven of eight hand-offs of either chain stay inside one XCD and can be polled in its L2.
+    int role, pos;
+    const int per = nblk >> 3;                              // chain positions per XCD (0: no grouping)
+    if (xcd && per > 0 && (nblk & 7) == 0) {
+        const int xc = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        role = slot & 1;
+        pos = xc * per + (slot >> 1);
+    } else {
+        role = (int)blockIdx.x & 1;                         // 0: sweep 1 (A_k), 1: sweep 2 (B_k)
+        pos = (int)blockIdx.x >> 1;
+    }
+    const bool grouped = xcd && per > 0 && (nblk & 7) == 0;
+    const int k = TRANS ? (nblk - 1 - pos) : pos;
+    const int k0 = k * TB;
+    const int idx = k0 + r;                                 // my row (forward) / my column (backward)
+    u64* gX = gran;
+    u64* gD = gran + (int64_t)nblk * 256;
+    u64* gE = gran + (int64_t)2 * nblk * 256;
+    const u64* gin = role == 0 ? gX : gD;                   // the solved blocks my far-field products consume
+    double acc = (role == 0 && half == 0) ? x[idx] : 0.0;
+    // ---- diagonal block operands: issue their loads now (independent of everything), use them at the end
+    const double* Lkk = L + k0 + (int64_t)k0 * ldl;
+    const double* Mk = minv + (int64_t)k * (2 * TB * TB) + (TRANS ? TB * TB : 0);
+    const int c0 = 64 * half;
+    double ra[64], rb[64];
+#pragma unroll
+    for (int j = 0; j < 64; ++j) ra[j] = Mk[r + (int64_t)(c0 + j) * TB];
+    if (role == 0) {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            const int c = c0 + j;
+            const bool in = TRANS ? c >= r : c <= r;          // (the other triangle holds the mirrored copy)
+            rb[j] = in ? Lkk[r + (int64_t)c * ldl] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 64; ++j) rb[j] = 0.0;
+    }
+    // all 256 threads: the 256 granules of block j of a granule set -> 128 doubles at dst; false on a timeout (err is set)
+    // `local`: the producer of block j sits on MY XCD (by the id -> XCD assumption above): poll with workgroup-scope loads first --
+    // they bypass the L1 but are served by the XCD's L2, where the producer's write-through store lands on its way to memory --
+    // and fall back to agent-scope loads (past the L2) after a bounded number of tries: if the assumption is wrong the local
+    // polls only ever see a stale tag, never a wrong value (tag and payload share one 8-byte word).
+    auto wait_block = [&](const u64* gbase, int j, double* dst, bool local) -> bool {
+        const u64* g = gbase + (int64_t)j * 256 + tid;
+        u64 v = 0;
+        bool got = false;
+        if (local) {
+            for (unsigned spins = 0; spins < 4096u; ++spins) {
+                v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((u32)(v >> 32) == epoch) { got = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        for (unsigned spins = 0; !got && spins < (1u << 22); ++spins) {
+            v = __hip_atomic_load(g, RLX_AGENT);
+            if ((u32)(v >> 32) == epoch) { got = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        reinterpret_cast<u32*>(dst)[tid] = (u32)v;            // little endian: granule 2i / 2i+1 = low / high word of entry i
+        if (__syncthreads_or(got ? 0 : 1)) {
+            if (tid == 0) atomicExch(err, 1);
+            return false;
+        }
+        return true;
+    };
+    auto publish = [&](u64* gbase, double v) {                // threads of half 0: entry r of block k
+        u64* g = gbase + (int64_t)k * 256 + 2 * r;
+        const u64 tag = (u64)epoch << 32;
+        __hip_atomic_store(g, tag | (u32)__double2loint(v), RLX_AGENT);
+        __hip_atomic_store(g + 1, tag | (u32)__double2hiint(v), RLX_AGENT);
+    };
+    // ---- off-diagonal blocks, in dependency order
+    const int nsteps = TRANS ? (nblk - 1 - k) : k;
+    for (int s = 0; s < nsteps; ++s) {
+        const int j = TRANS ? (nblk - 1 - s) : s;
+        const int j0 = j * TB;
+        double* xs = xs2[s & 1];
+        double l0[64];
+#pragma unroll
+        for (int c = 0; c < 64; ++c) l0[c] = L[idx + (int64_t)(j0 + c0 + c) * ldl];     // (backward: the mirrored L')
+        // (same XCD as the producer: same chain-position group of `per` blocks; the far field was written long ago: either way)
+        const int pj = TRANS ? (nblk - 1 - j) : j;
+        if (!wait_block(gin, j, xs, grouped && xcd > 1 && pj / per == pos / per)) return;
+        double a0 = acc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+            a0 = fma(-l0[c], xs[c0 + c], a0);
+            a1 = fma(-l0[c + 1], xs[c0 + c + 1], a1);
+            a2 = fma(-l0[c + 2], xs[c0 + c + 2], a2);
+            a3 = fma(-l0[c + 3], xs[c0 + c + 3], a3);
+        }
+        acc = (a0 + a1) + (a2 + a3);
+    }
+    double* xs = xs2[nsteps & 1];                            // the buffer NOT read by the last step
+    double* xo = xs2[(nsteps & 1) ^ 1];
+    double* ps = ps2[0];
+    double* po = ps2[1];
+    // 64-term dot product of my register strip with one half of an LDS vector, as four independent chains
+    auto dot64 = [&](const double (&a)[64], const double* v) {
+        double d0 = 0.0, d1 = 0.0, d2 = 0.0, d3 = 0.0;
+#pragma unroll
+        for (int c = 0; c < 64; c += 4) {
+            d0 = fma(a[c], v[c0 + c], d0);
+            d1 = fma(a[c + 1], v[c0 + c + 1], d1);
+            d2 = fma(a[c + 2], v[c0 + c + 2], d2);
+            d3 = fma(a[c + 3], v[c0 + c + 3], d3);
+        }
+        return (d0 + d1) + (d2 + d3);
+    };
+    // ---- combine the two partial sums of every row / column
+    if (half == 1) ps[r] = acc;
+    __syncthreads();
+    if (half == 0) acc += ps[r];
+    if (role == 0) {
+        // x0 = M b1
+        if (half == 0) xs[r] = acc;
+        __syncthreads();
+        const double p0 = dot64(ra, xs);
+        if (half == 1) po[r] = p0;
+        __syncthreads();
+        const double x0 = p0 + po[r];                        // (meaningful in half 0)
+        if (half == 0) {
+            publish(gX, x0);                                 // -> A_i, i beyond k, and B_k
+            xo[r] = x0;
+        }
+        __syncthreads();
+        // e = b1 - L_kk x0
+        const double q0 = dot64(rb, xo);
+        if (half == 1) ps[r] = q0;
+        __syncthreads();
+        if (half == 0) publish(gE, acc - (q0 + ps[r]));       // -> B_k
+        return;
+    }
+    // ---- sweep 2: b2 = e_k - sum L_kj d_j,  d_k = M b2,  x_k = x0_k + d_k
+    if (!wait_block(gE, k, es, grouped && xcd > 1)) return;          // (A_k sits on my XCD)
+    if (half == 0) xs[r] = acc + es[r];
+    __syncthreads();
+    const double p0 = dot64(ra, xs);
+    if (half == 1) po[r] = p0;
+    __syncthreads();
+    const double dk = p0 + po[r];
+    if (half == 0) publish(gD, dk);                          // -> B_i, i beyond k
+    if (!wait_block(gX, k, es, false)) return;               // (published by A_k before e_k: there since long)
+    if (half == 0) x[idx] = es[r] + dk;
+}
+
+int launch_trsv_pair(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
+                     unsigned long long* gran, const double* minv) {
+    if (n <= 0 || n % TB || !gran || !minv) return -1;
+    const dim3 g(2 * (n / TB)), b(256);
+    // xcd: 0 plain ids, 1 chain positions grouped per XCD, 2 grouped + hand-offs inside an XCD polled in its L2 (experiment knob)
+    const char* xk = dev_knob("MI355KKT_TRSV_XCD");
+    const int xcd = xk ? atoi(xk) : TRSV_PAIR_XCD_DEFAULT;
+    if (trans)
+        hipLaunchKernelGGL((trsv_pair_kernel<true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, xcd);
+    else
+        hipLaunchKernelGGL((trsv_pair_kernel<false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, xcd);
+    KKT_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err,
                            hipStream_t st, unsigned long long* gran, const double* minv, const TrsvJob* jobs, int njobs) {
     const int nblk = (n + TB - 1) / TB;      // with jobs: n = the largest order among them
     if (nblk <= 0) return 0;
     if (!gran || (jobs && (njobs <= 0 || nblk > TRSV_JOB_STRIDE))) return -1;
     const dim3 g(nblk, jobs ? njobs : 1), b(256);
+    const char* xm = dev_knob("MI355KKT_TRSV_XMAP");
+    const int xmap = (xm && !jobs) ? atoi(xm) : 0;
     if (minv) {
         if (trans)
-            hipLaunchKernelGGL((trsv_persistent_kernel<true, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
+            hipLaunchKernelGGL((trsv_persistent_kernel<true, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs, xmap);
         else
-            hipLaunchKernelGGL((trsv_persistent_kernel<false, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
+            hipLaunchKernelGGL((trsv_persistent_kernel<false, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs, xmap);
     } else if (trans)
-        hipLaunchKernelGGL((trsv_persistent_kernel<true, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
+        hipLaunchKernelGGL((trsv_persistent_kernel<true, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs, xmap);
     else
-        hipLaunchKernelGGL((trsv_persistent_kernel<false, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
+        hipLaunchKernelGGL((trsv_persistent_kernel<false, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs, xmap);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -310,6 +310,8 @@ static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, const s
     return 0;
 }
 
+constexpr bool TRSV_PAIR_DEFAULT = true;      // knob MI355KKT_TRSV_PAIR=0 selects the one-sweep kernel (A/B measurements, tests)
+
 struct mi355kkt_solver {
     int device = 0, kind = 0;
     int n = 0, p = 0, ml = 0, cdim = 0;
@@ -1226,7 +1228,13 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     if (refine) KKT_HIP_CHECK(hipMemcpyAsync(zs0, h->dzs, sizeof(double) * mk, hipMemcpyDeviceToDevice, st));
     // triangular solves with L: one persistent launch each when every 128-block can own a resident workgroup
     const bool persistent = (n + 127) / 128 <= h->num_cus;      // (larger orders: the multi-kernel blocked solve)
+    // round 4: two pipelined sweeps (trsv_pair_kernel) when the tile Cholesky left the 128 x 128 inverses of THIS factor, the order
+    // is a multiple of 128 and both chains fit the device
+    const bool have_minv = h->pw.minv_n == n && h->pw.minv_of == h->dS;
+    const char* pk = dev_knob("MI355KKT_TRSV_PAIR");
+    const bool pair = persistent && have_minv && n % 128 == 0 && n >= 256 && 2 * (n / 128) <= h->num_cus && (pk ? atoi(pk) != 0 : TRSV_PAIR_DEFAULT);
     auto tri_solve = [&](int trans, double* xv) -> int {
+        if (pair) return launch_trsv_pair(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran, h->pw.d_minv);
         if (persistent) return launch_trsv_persistent(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran,
                                                       (h->pw.minv_n == n && h->pw.minv_of == h->dS) ? h->pw.d_minv : nullptr);
         return launch_trsm_lower(h->dS, n, n, xv, n, 1, trans, st);

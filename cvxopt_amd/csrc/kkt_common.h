@@ -166,6 +166,10 @@ constexpr int TRSV_JOB_STRIDE = 64;    // granule blocks reserved per job (order
 int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err,
                            hipStream_t st, unsigned long long* gran, const double* minv = nullptr,
                            const TrsvJob* jobs = nullptr, int njobs = 0);
+// round 4: the same solve as two pipelined sweeps with two workgroups per block row (blas2.hip, trsv_pair_kernel): needs the
+// 128 x 128 inverses (minv), n % 128 == 0, 2 n / 128 co-resident workgroups and 3 n / 128 granule blocks
+int launch_trsv_pair(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
+                     unsigned long long* gran, const double* minv);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);
