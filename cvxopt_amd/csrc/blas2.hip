@@ -524,7 +524,7 @@ template <bool TRANS, bool INV>
 __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __restrict__ L, int64_t ldl, int n,
                                                               double* x, u32 epoch, int* err, u64* gran,
                                                               const double* __restrict__ minv,
-                                                              const TrsvJob* __restrict__ jobs, int xmap) {
+                                                              const TrsvJob* __restrict__ jobs) {
     if (jobs) {
         const TrsvJob jb = jobs[blockIdx.y];
         L = jb.L;
@@ -543,12 +543,7 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = tid >> 7, r = tid & (TB - 1);
     const int nblk = (n + TB - 1) / TB;
-    // position of this workgroup along the chain.  xmap (experiment, round 4): workgroup ids are dealt round-robin over the 8 XCDs
-    // (observed dispatch, not a contract -- only speed depends on it): with pos = (id % 8) * (nblk / 8) + id / 8 eight consecutive
-    // block rows sit on one XCD, so seven of eight hand-offs stay inside that XCD's L2
-    int pos = (int)blockIdx.x;
-    if (xmap && (nblk & 7) == 0) pos = (pos & 7) * (nblk >> 3) + (pos >> 3);
-    const int k = TRANS ? (nblk - 1 - pos) : pos;
+    const int k = TRANS ? (nblk - 1 - (int)blockIdx.x) : (int)blockIdx.x;   // dispatch order ~ dependency order
     const int k0 = k * TB;
     const int nb = min(TB, n - k0);
     const int idx = k0 + r;                           // my row (forward) / my column (backward)
@@ -755,31 +750,17 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
 // Hand-offs are the data-tagged granules of the kernel above: blocks [0, nblk) carry x0, [nblk, 2 nblk) d, [2 nblk, 3 nblk) e.
 // Deterministic (fixed summation order); every spin is bounded and a timeout sets *err.
 // ===================================================================================================
-constexpr int TRSV_PAIR_XCD_DEFAULT = 0;
-
 template <bool TRANS>
 __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict__ L, int64_t ldl, int n, double* x, u32 epoch,
-                                                        int* err, u64* gran, const double* __restrict__ minv, int xcd) {
+                                                        int* err, u64* gran, const double* __restrict__ minv) {
     __shared__ double xs2[2][TB];
     __shared__ double ps2[2][TB];
     __shared__ double es[TB];
     const int tid = threadIdx.x;
     const int half = tid >> 7, r = tid & (TB - 1);
     const int nblk = n / TB;                                // whole 128-blocks only (checked by the launcher)
-    // Workgroup ids are dealt round-robin over the 8 XCDs (observed dispatch order -- not a contract: only SPEED depends on it).
-    // With nblk a multiple of 8, XCD x = id % 8 gets the chain positions x nblk/8 .. (x + 1) nblk/8 - 1 of BOTH sweeps (its slots
-    // alternate between the roles), so seven of eight hand-offs of either chain stay inside one XCD and can be polled in its L2.
-    int role, pos;
-    const int per = nblk >> 3;                              // chain positions per XCD (0: no grouping)
-    if (xcd && per > 0 && (nblk & 7) == 0) {
-        const int xc = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-        role = slot & 1;
-        pos = xc * per + (slot >> 1);
-    } else {
-        role = (int)blockIdx.x & 1;                         // 0: sweep 1 (A_k), 1: sweep 2 (B_k)
-        pos = (int)blockIdx.x >> 1;
-    }
-    const bool grouped = xcd && per > 0 && (nblk & 7) == 0;
+    const int role = (int)blockIdx.x & 1;                   // 0: sweep 1 (A_k), 1: sweep 2 (B_k)
+    const int pos = (int)blockIdx.x >> 1;
     const int k = TRANS ? (nblk - 1 - pos) : pos;
     const int k0 = k * TB;
     const int idx = k0 + r;                                 // my row (forward) / my column (backward)
@@ -807,22 +788,11 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
         for (int j = 0; j < 64; ++j) rb[j] = 0.0;
     }
     // all 256 threads: the 256 granules of block j of a granule set -> 128 doubles at dst; false on a timeout (err is set)
-    // `local`: the producer of block j sits on MY XCD (by the id -> XCD assumption above): poll with workgroup-scope loads first --
-    // they bypass the L1 but are served by the XCD's L2, where the producer's write-through store lands on its way to memory --
-    // and fall back to agent-scope loads (past the L2) after a bounded number of tries: if the assumption is wrong the local
-    // polls only ever see a stale tag, never a wrong value (tag and payload share one 8-byte word).
-    auto wait_block = [&](const u64* gbase, int j, double* dst, bool local) -> bool {
+    auto wait_block = [&](const u64* gbase, int j, double* dst) -> bool {
         const u64* g = gbase + (int64_t)j * 256 + tid;
         u64 v = 0;
         bool got = false;
-        if (local) {
-            for (unsigned spins = 0; spins < 4096u; ++spins) {
-                v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if ((u32)(v >> 32) == epoch) { got = true; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        for (unsigned spins = 0; !got && spins < (1u << 22); ++spins) {
+        for (unsigned spins = 0; spins < (1u << 22); ++spins) {
             v = __hip_atomic_load(g, RLX_AGENT);
             if ((u32)(v >> 32) == epoch) { got = true; break; }
             __builtin_amdgcn_s_sleep(1);
@@ -849,9 +819,7 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
         double l0[64];
 #pragma unroll
         for (int c = 0; c < 64; ++c) l0[c] = L[idx + (int64_t)(j0 + c0 + c) * ldl];     // (backward: the mirrored L')
-        // (same XCD as the producer: same chain-position group of `per` blocks; the far field was written long ago: either way)
-        const int pj = TRANS ? (nblk - 1 - j) : j;
-        if (!wait_block(gin, j, xs, grouped && xcd > 1 && pj / per == pos / per)) return;
+        if (!wait_block(gin, j, xs)) return;
         double a0 = acc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
         for (int c = 0; c < 64; c += 4) {
@@ -903,7 +871,7 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
         return;
     }
     // ---- sweep 2: b2 = e_k - sum L_kj d_j,  d_k = M b2,  x_k = x0_k + d_k
-    if (!wait_block(gE, k, es, grouped && xcd > 1)) return;          // (A_k sits on my XCD)
+    if (!wait_block(gE, k, es)) return;
     if (half == 0) xs[r] = acc + es[r];
     __syncthreads();
     const double p0 = dot64(ra, xs);
@@ -911,7 +879,7 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
     __syncthreads();
     const double dk = p0 + po[r];
     if (half == 0) publish(gD, dk);                          // -> B_i, i beyond k
-    if (!wait_block(gX, k, es, false)) return;               // (published by A_k before e_k: there since long)
+    if (!wait_block(gX, k, es)) return;                      // (published by A_k before e_k: there since long)
     if (half == 0) x[idx] = es[r] + dk;
 }
 
@@ -919,13 +887,10 @@ int launch_trsv_pair(const double* L, int64_t ldl, int n, double* x, int trans, 
                      unsigned long long* gran, const double* minv) {
     if (n <= 0 || n % TB || !gran || !minv) return -1;
     const dim3 g(2 * (n / TB)), b(256);
-    // xcd: 0 plain ids, 1 chain positions grouped per XCD, 2 grouped + hand-offs inside an XCD polled in its L2 (experiment knob)
-    const char* xk = dev_knob("MI355KKT_TRSV_XCD");
-    const int xcd = xk ? atoi(xk) : TRSV_PAIR_XCD_DEFAULT;
     if (trans)
-        hipLaunchKernelGGL((trsv_pair_kernel<true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, xcd);
+        hipLaunchKernelGGL((trsv_pair_kernel<true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
     else
-        hipLaunchKernelGGL((trsv_pair_kernel<false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, xcd);
+        hipLaunchKernelGGL((trsv_pair_kernel<false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }
@@ -936,17 +901,15 @@ int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int t
     if (nblk <= 0) return 0;
     if (!gran || (jobs && (njobs <= 0 || nblk > TRSV_JOB_STRIDE))) return -1;
     const dim3 g(nblk, jobs ? njobs : 1), b(256);
-    const char* xm = dev_knob("MI355KKT_TRSV_XMAP");
-    const int xmap = (xm && !jobs) ? atoi(xm) : 0;
     if (minv) {
         if (trans)
-            hipLaunchKernelGGL((trsv_persistent_kernel<true, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs, xmap);
+            hipLaunchKernelGGL((trsv_persistent_kernel<true, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
         else
-            hipLaunchKernelGGL((trsv_persistent_kernel<false, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs, xmap);
+            hipLaunchKernelGGL((trsv_persistent_kernel<false, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
     } else if (trans)
-        hipLaunchKernelGGL((trsv_persistent_kernel<true, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs, xmap);
+        hipLaunchKernelGGL((trsv_persistent_kernel<true, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
     else
-        hipLaunchKernelGGL((trsv_persistent_kernel<false, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs, xmap);
+        hipLaunchKernelGGL((trsv_persistent_kernel<false, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, jobs);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

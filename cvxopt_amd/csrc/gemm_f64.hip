@@ -430,8 +430,6 @@ void make_syrk_items(int n, int K, int num_cus, bool allow_split, std::vector<Sy
     const int max_split = std::max(1, K / (8 * BK));   // at least 8 k-steps per piece
     int split = 1;
     if (R > 0 && allow_split) split = std::max(1, std::min(slots / R, max_split));
-    if (R > 0 && allow_split)
-        if (const char* e = dev_knob("MI355KKT_SYRK_SPLIT")) split = std::max(1, std::min(atoi(e), max_split));   // (experiments)
 
     std::vector<SyrkItem> ordered_full;
     for (int t = 0; t < nfull; ++t) ordered_full.push_back({seq[t].first, seq[t].second, 0, K, -1, 0, 0, 0});
