@@ -64,5 +64,18 @@ for chap in ("chap8", "chap9", "chap10"):
         if f.endswith(".py"):
             py_compile.compile(os.path.join(src, f), cfile=os.path.join(dst, f + "c"), dfile="reftests/examples/doc/%s/%s" % (chap, f),
                                doraise=True, optimize=0)
+# examples/book (Boyd & Vandenberghe figures: lp / qp / socp / sdp / cp / gp on real data): byte-compiled scripts + their pickled
+# data files (*.bin: cvxopt matrices, data not source); tests/test_gpu_reference_examples.py runs each on the host reference and
+# through cvxopt_amd.solvers and compares every matrix the script leaves behind
+for chap in ("chap4", "chap6", "chap7", "chap8"):
+    src = os.path.join(ref, "examples", "book", chap)
+    dst = os.path.join(out, "examples", "book", chap)
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(os.listdir(src)):
+        if f.endswith(".py"):
+            py_compile.compile(os.path.join(src, f), cfile=os.path.join(dst, f + "c"), dfile="reftests/examples/book/%s/%s" % (chap, f),
+                               doraise=True, optimize=0)
+        elif f.endswith(".bin"):
+            shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
 PY
 echo "build_ref: done -> $OUT (+ $HERE/_ref/reftests)"
