@@ -762,7 +762,7 @@ int mi355kkt_set_sparse_problem_aug(mi355kkt_solver* h, const int64_t* gcolptr, 
         for (int64_t k = gcolptr[j]; k < gcolptr[j + 1]; ++k)
             if (growind[k] < 0 || growind[k] >= rows) { set_last_error("set_sparse_problem: G row index out of range"); return MI355KKT_EINVAL; }
     if (int e = sparse_engine_create(h->sp, h->n, rows, gcolptr, growind, gvalues, hcolptr, hrowind, hvalues)) return e;
-    h->sp.t_gran = h->dgran; h->sp.t_err = h->derr; h->sp.t_epoch = &h->epoch; h->sp.t_njobs_max = 64;
+    h->sp.t_gran = h->dgran; h->sp.t_err = h->derr; h->sp.t_epoch = &h->epoch; h->sp.t_njobs_max = 64; h->sp.t_num_cus = h->num_cus;
     h->sparse = true;
     h->firstcall = true;
     h->sp_extra = extra_rows;
@@ -1021,6 +1021,7 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
         // singular S: the caller (the Python mirror, on the first factorisation with p > 0) re-creates the sparse problem with
         // the rows of A appended -- mi355kkt_set_sparse_problem_aug, a new symbolic analysis since the pattern of S grows --
         // and factors again: the S + A'A fallback of misc.py:1433-1447
+        if (sinfo < 0) { set_last_error("sparse factor: tile hand-off timeout in the root front (info = %d)", sinfo); return MI355KKT_EHIP; }
         if (sinfo > 0) return sinfo;
         if (h->p > 0) {
             // equality constraints (misc.py:1464-1487, sparse branch): Asct = L^-1 P A' with all p right-hand sides in

@@ -233,6 +233,8 @@ struct SparseEngine {
     int* t_err = nullptr;
     unsigned int* t_epoch = nullptr;
     int t_njobs_max = 0;                       // jobs the borrowed flags / granules have room for
+    int t_num_cus = 0;                         // compute units of the device (co-residency limit of the two-sweep solves)
+    int dense_root_level = -1;                 // level whose single big front is factored by the dense tile kernel (-1: none)
     int64_t* d_ea_off = nullptr;
     int* d_ea_lb = nullptr;
     TrsvJob* d_wide_jobs = nullptr;            // one per wide supernode, in the order of sym.wide (x = d_xp + first column)

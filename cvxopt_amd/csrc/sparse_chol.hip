@@ -674,8 +674,10 @@ __global__ void sp_merge_info_vb_kernel(const int* __restrict__ local, int n, in
     if (z < n && local[z] > 0) atomicMin(global, local[z]);
 }
 
+// (a negative local word is a hand-off timeout of the dense tile kernel: it wins over every pivot index and reaches the caller)
 __global__ void sp_merge_info_kernel(const int* __restrict__ local, int offset, int* __restrict__ global) {
     if (*local > 0) atomicMin(global, offset + *local);
+    else if (*local < 0) atomicMin(global, *local);
 }
 
 // ---- triangular solves with one supernode's w x w diagonal block (w <= 256), right-hand side in LDS ----------------
@@ -1175,6 +1177,7 @@ static SpDev devview(const SparseEngine& E) {
 int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, int* info) {
     const SparseSymbolic& S = E.sym;
     if (E.n == 0) { if (info) *info = 0; return 0; }
+    E.dense_root_level = -1;
     KKT_HIP_CHECK(hipMemsetAsync(E.d_panels, 0, sizeof(double) * (S.store_doubles ? S.store_doubles : 1), st));
     static const int imax = 0x7fffffff;      // (static: the asynchronous copy below must not read a dead stack slot on an early error return)
     KKT_HIP_CHECK(hipMemcpyAsync(E.d_info, &imax, sizeof(int), hipMemcpyHostToDevice, st));
@@ -1196,7 +1199,18 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
             const VbDesc* dv = E.d_vb + S.vb_ptr[l];
             hipLaunchKernelGGL(sp_extend_add_vb_kernel, dim3((S.vb_maxh[l] + EA_COLS - 1) / EA_COLS, (S.vb_maxh[l] + EA_ROWS - 1) / EA_ROWS, nbig),
                                dim3(256), 0, st, d, dv, E.d_panels);
-            if (old_chain) {
+            // Round 4: a level whose only front is ONE big supernode without rows below it -- the root separator -- is a plain dense
+            // Cholesky: the dense engine's persistent tile kernel runs it (no ragged-extent / ticket-table bookkeeping: 0 spilled
+            // registers against the fronts' kernel's 61; 1.44 instead of 2.2 ms at 4096 columns) and leaves the 128 x 128 inverses
+            // of its diagonal blocks for the solves (sp_wide_forward / _backward).
+            const VbDesc& only = S.vb[S.vb_ptr[l]];
+            const bool dense_root = !old_chain && nbig == 1 && nsmall == 0 && only.h == only.w && only.w >= 1024 &&
+                                    (only.w + 127) / 128 <= 252 && !dev_knob("MI355KKT_SPARSE_NO_DENSE_ROOT");
+            if (dense_root) {
+                if (int e = launch_potrf(E.d_panels + only.off, only.h, only.w, E.pw_vb, st)) return e;
+                hipLaunchKernelGGL(sp_merge_info_kernel, dim3(1), dim3(1), 0, st, E.pw_vb.d_info, only.col0, E.d_info);
+                E.dense_root_level = l;
+            } else if (old_chain) {
                 if (int e = launch_potrf_partial_vb(E.d_panels, dv, nbig, S.vb_maxh[l], S.vb_maxw[l], E.pw_vb, st)) return e;
                 hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3((nbig + 255) / 256), dim3(256), 0, st, E.pw_vb.d_info, nbig, E.d_info);
             } else if (int e = launch_potrf_tiles_vb(E.d_panels, dv, nbig, E.d_tv_tickets + 4 * (size_t)S.tv_ptr[l],
@@ -1223,6 +1237,20 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
     return 0;
 }
 
+// The root supernode after a dense-root factorisation (sparse_engine_factor): its diagonal block was factored by the dense tile
+// kernel, which left the 128 x 128 inverses in E.pw_vb -- the two-sweep solve of the dense engine when the order allows it,
+// the one-sweep kernel with the inverses otherwise.
+static int sp_root_solve(SparseEngine& E, int s, double* x, int trans, hipStream_t st) {
+    const SparseSymbolic& S = E.sym;
+    const int f = S.sn_first[s], w = S.sn_first[s + 1] - f;
+    const int h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
+    const double* P = E.d_panels + S.panel_off[s];
+    const double* minv = (E.pw_vb.minv_n == w && E.pw_vb.minv_of == P) ? E.pw_vb.d_minv : nullptr;
+    if (minv && w % 128 == 0 && 2 * (w / 128) <= E.t_num_cus)
+        return launch_trsv_pair(P, h, w, x + f, trans, ++*E.t_epoch, E.t_err, st, E.t_gran, minv);
+    return launch_trsv_persistent(P, h, w, x + f, trans, ++*E.t_epoch, E.t_err, st, E.t_gran, minv);
+}
+
 // Wide supernodes of level l (w > SP_WIDE; the top separators): children contributions gathered in global memory, the dense
 // diagonal block through the persistent multi-workgroup triangular solve of the dense engine (one right-hand side) or the
 // blocked trsm (several).  Runs after the level's sp_fwd_kernel and before its sp_fwd_rem_kernel.
@@ -1233,6 +1261,8 @@ static int sp_wide_forward(SparseEngine& E, const SpDev& d, int l, double* x, do
     if (nw == 0) return 0;
     hipLaunchKernelGGL(sp_fwd_wide_gather_kernel, dim3(nw, nrhs), dim3(256), 0, st, d, E.d_wide + k0, x, rem, E.d_rem_off, xstride,
                        remstride);
+    if (nrhs == 1 && E.t_gran && nw == 1 && l == E.dense_root_level)       // the dense root: inverses from the tile Cholesky
+        return sp_root_solve(E, S.wide[k0], x, 0, st);
     if (nrhs == 1 && x == E.d_xp && E.t_gran && E.t_njobs_max > 0) {      // the level's systems, up to t_njobs_max per launch
         for (int c0 = 0; c0 < nw; c0 += E.t_njobs_max)
             if (int e = launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 0, ++*E.t_epoch, E.t_err, st, E.t_gran,
@@ -1255,6 +1285,7 @@ static int sp_wide_backward(SparseEngine& E, int l, double* x, hipStream_t st) {
     const SparseSymbolic& S = E.sym;
     const int k0 = S.wide_ptr[l], nw = S.wide_ptr[l + 1] - k0;
     if (nw == 0) return 0;
+    if (E.t_gran && nw == 1 && l == E.dense_root_level) return sp_root_solve(E, S.wide[k0], x, 1, st);
     if (x == E.d_xp && E.t_gran && E.t_njobs_max > 0) {
         for (int c0 = 0; c0 < nw; c0 += E.t_njobs_max)
             if (int e = launch_trsv_persistent(nullptr, 0, E.wide_maxw[l], nullptr, 1, ++*E.t_epoch, E.t_err, st, E.t_gran,
