@@ -1358,6 +1358,9 @@ int mi355kkt_get_timings(mi355kkt_solver* h, float* out, int n) try {
     (void)hipStreamSynchronize(h->st);
     if (hipEventQuery(h->ev[5]) == hipSuccess && hipEventQuery(h->ev[4]) == hipSuccess)
         (void)hipEventElapsedTime(&h->t_solve, h->ev[4], h->ev[5]);
+    // (events that were never recorded -- timings() before the first solve -- make hipEventElapsedTime fail with "invalid resource
+    //  handle"; that must not stay behind as the runtime's sticky last error: the next launch check would report it.  Found in round 4.)
+    (void)hipGetLastError();
     const float v[6] = {h->t_syrk, h->t_potrf, h->t_schur, h->t_factor, h->t_solve, h->t_syrk_kernel};
     int k = 0;
     for (; k < n && k < 6; ++k) out[k] = v[k];
