@@ -1,4 +1,7 @@
-"""Developer probe: batched config-5 timing on one GPU (B problems of n=512, m=1024)."""
+"""Developer probe: batched config-5 timing on one GPU (B problems of n=512, m=1024).
+
+    python tools/dev/bench_batch_dev.py B [KNOB=VALUE ...]      (test knobs of include/mi355kkt_test.h, e.g. MI355KKT_BATCH_TILES=0)
+"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -6,6 +9,10 @@ from cvxopt_amd import synth
 from cvxopt_amd.batch import BatchKkt, coneqp_batch, pack_problems
 
 B, n, m = int(sys.argv[1]), 512, 1024
+for kv in sys.argv[2:]:
+    from cvxopt_amd import _capi
+    _capi.set_knob(*kv.split("=", 1))
+    print("knob", kv)
 t = time.time()
 rng = np.random.default_rng(0)
 base = synth.dense_qp(n, m, seed=0)
