@@ -112,8 +112,7 @@ SIGNATURES = {
     "mi355kkt_test_sdp_op_host": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "mi355kkt_test_sdp_op_device": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     "mi355kkt_test_sdp_op_host_team": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
-    "mi355kkt_test_syrk_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p, c_int_p, c_int_p]),
-    "mi355kkt_test_syrk_sync_state": (C.c_int, [c_int_p]),
+    "mi355kkt_test_syrk_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p, c_int_p]),
     "mi355kkt_test_ordering": (C.c_int, [C.c_int, c_i64_p, c_i64_p, C.c_int, c_int_p, c_double_p]),
     "mi355kkt_test_throw": (C.c_int, [C.c_int]),
     "mi355kkt_test_set_knob": (C.c_int, [C.c_char_p, C.c_char_p]),

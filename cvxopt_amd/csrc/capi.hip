@@ -16,7 +16,6 @@
 #include <mutex>
 #include <new>
 #include <stdexcept>
-#include <string>
 
 #include "../../include/mi355kkt.h"
 #include "kkt_common.h"
@@ -2494,19 +2493,12 @@ static int cur_num_cus() {
     return prop.multiProcessorCount;
 }
 
-static const SyrkPlan* g_op_syrk_plan = nullptr;   // the plan of the last mi355kkt_op_syrk_scaled (for the test hook below)
 int mi355kkt_op_syrk_scaled(const double* dG, int64_t ldG, int m, int n, const double* ddi, const double* dH,
                             int64_t ldH, double* dS, int64_t ldS, float* ms) try {
     static SyrkPlan plan;   // cached for repeated calls with one shape (profiling loops)
-    static std::string plan_knob;
     const int kc = m;
-    const char* kv = dev_knob("MI355KKT_SYRK_SYNC");
-    const std::string knob = kv ? kv : "";
-    if (plan.n != n || plan.K != kc || !plan.d_items || knob != plan_knob) {
+    if (plan.n != n || plan.K != kc || !plan.d_items)
         if (int e = build_syrk_plan(plan, n, kc, cur_num_cus())) return e;
-        plan_knob = knob;
-    }
-    g_op_syrk_plan = &plan;
     OpTimer t(ms);
     for (int k0 = 0; k0 < m || k0 == 0; k0 += (kc > 0 ? kc : 1)) {
         if (int e = launch_syrk_scaled(plan, dG + k0, ldG, ddi ? ddi + k0 : nullptr, dS, ldS, k0 == 0 ? dH : dS,
@@ -2766,37 +2758,24 @@ int mi355kkt_test_sdp_op_host_team(int op, int m, int arg, int nt, double* x, do
     return rc[0];
 } catch (...) { return kkt_catch("mi355kkt_test_sdp_op_host_team"); }
 /* The static SYRK schedule for an n x n result contracted over K on a device with num_cus compute units, as plain integers
- * (host only): out[12 * i + 0..11] = ti, tj, k0, k1, slot, first, nparts, next, grp, gm, 0, 0 of segment i; the first
- * `*nlaunch` segments are the launch's workgroups in launch order, the others continuation segments reached through `next`
- * (1 + index).  allow_split bit 0: split the remainder round (stream-K); bit 1: XCD-local synchronisation groups.  For the CPU
- * tests of the plan's invariants.  Returns the number of segments (<= max_items are written). */
+ * (host only): out[8 * i + 0..7] = ti, tj, k0, k1, slot, first, nparts, next of segment i; the first `*nlaunch` segments are the
+ * launch's workgroups in launch order, the others continuation segments reached through `next` (1 + index).  For the CPU tests
+ * of the plan's invariants.  Returns the number of segments (<= max_items are written). */
 int mi355kkt_test_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit,
-                            int* nlaunch, int* ngroups) try {
+                            int* nlaunch) try {
     std::vector<mi355kkt::SyrkItem> items, split_tiles;
-    int ns = 0, nl = 0, ng = 0;
-    mi355kkt::make_syrk_items(n, K, num_cus, (allow_split & 1) != 0, (allow_split & 2) != 0, items, nl, split_tiles, ns, ng);
+    int ns = 0, nl = 0;
+    mi355kkt::make_syrk_items(n, K, num_cus, allow_split != 0, items, nl, split_tiles, ns);
     for (size_t i = 0; i < items.size() && (int)i < max_items; ++i) {
         const mi355kkt::SyrkItem& it = items[i];
-        int* o = out + 12 * i;
+        int* o = out + 8 * i;
         o[0] = it.ti; o[1] = it.tj; o[2] = it.k0; o[3] = it.k1; o[4] = it.slot; o[5] = it.first; o[6] = it.nparts; o[7] = it.next;
-        o[8] = it.grp; o[9] = it.gm; o[10] = 0; o[11] = 0;
     }
     if (nslabs) *nslabs = ns;
     if (nsplit) *nsplit = (int)split_tiles.size();
     if (nlaunch) *nlaunch = nl;
-    if (ngroups) *ngroups = ng;
     return (int)items.size();
 } catch (...) { return kkt_catch("mi355kkt_test_syrk_plan"); }
-/* XCD-local synchronisation of the SYRK (csrc/kkt_common.h, SyrkSync): number of synchronisation groups of the plan the last
- * mi355kkt_op_syrk_scaled call used (0: it ran free) and, in *timeouts, how many of its waits ran into their bound so far */
-int mi355kkt_test_syrk_sync_state(int* timeouts) try {
-    if (timeouts) *timeouts = 0;
-    if (!g_op_syrk_plan) return 0;
-    const int t = mi355kkt::syrk_sync_timeouts(*g_op_syrk_plan, nullptr);
-    if (t < 0) return MI355KKT_EHIP;
-    if (timeouts) *timeouts = t;
-    return g_op_syrk_plan->ngroups;
-} catch (...) { return kkt_catch("mi355kkt_test_syrk_sync_state"); }
 /* Fill-reducing ordering of a symmetric pattern (host only, for the CPU tests of csrc/ordering.cpp): colptr/rowind = CSC
  * pattern of any part of the matrix that contains each off-diagonal pair at least once; method 0 = choose, 1 = nested
  * dissection, 2 = approximate minimum degree.  perm[new] = old.  stats[0..6] = method chosen, nnz(L) and flops of the

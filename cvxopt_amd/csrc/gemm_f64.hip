@@ -12,15 +12,12 @@
 // MFMA operand roles are chosen so that the D layout (col = lane&15) runs along C's contiguous (row)
 // dimension: A-operand <- C-column block (J), B-operand <- C-row block (I).
 #include "kkt_common.h"
-#include "knobs.h"
 #include <type_traits>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdlib>
-#include <cstring>
-#include <cstdio>
 
 namespace mi355kkt {
 
@@ -104,58 +101,25 @@ __device__ __forceinline__ void tn_store(double* __restrict__ Xs, int sc, int sk
 
 // DMASK: diagonal tiles of short contractions run the pipelined loop with block masks (see there); <false> is the kernel of the
 // long contractions (their diagonal tiles take the nine-blocks-per-wave path) with no trace of the masks in its code.
-// SYNC: the XCD-local k synchronisation (SyrkSync, kkt_common.h) is compiled in; a tile follows it when its item names a group.
 // One call = one contraction segment of one tile; the kernel below calls it once per segment of its workgroup.
-#define SYRK_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-constexpr int SYRK_SYNC_SPINS = 160;    // bound of one wait: ~0.1 ms of polling, then the tile free-runs
-
-template <bool DMASK, bool SYNC>
+template <bool DMASK>
 __device__ __forceinline__ void syrk_tile(
-    const SyrkItem& it, const double* __restrict__ G, int64_t ldg, const double* __restrict__ di, int n, int fast_ok,
-    double* __restrict__ C, int64_t ldc, const double* __restrict__ P, int64_t ldp, double* __restrict__ slabs,
-    double* __restrict__ smem, const SyrkSync& sy) {
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));           // opaque per segment: nothing derived from it is hoisted out of the kernel's segment loop
+    const SyrkItem& it, const double* __restrict__ G, int ldg32, const double* __restrict__ di, int n, int fast_ok,
+    double* __restrict__ C, int ldc32, const double* __restrict__ P, int ldp32, double* __restrict__ slabs,
+    double* __restrict__ smem, int wave_s) {
+    // (leading dimensions travel as 32-bit scalars across the kernel's segment loop: three scalar registers less to keep live)
+    const int64_t ldg = ldg32, ldc = ldc32, ldp = ldp32;
+    // the thread index is rebuilt per segment from the wave's index (a scalar) and the lane id, and made opaque: nothing derived
+    // from it is hoisted out of the kernel's segment loop and no vector register stays live across segments (the kernel sits at
+    // 256 registers)
+    int tid = wave_s * 64 + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
     int wj = wave >> 1, wi = wave & 1;
     const int i0 = it.ti * TILE, j0 = it.tj * TILE;
     const bool diag = (it.ti == it.tj);
     const int sc = tid >> 3, sk = (tid & 7) * 2;
     const bool tile_fast = fast_ok && (i0 + TILE <= n) && (j0 + TILE <= n);
-
-    // ---- XCD-local k synchronisation (wave 0 only; every predicate below is wave-uniform)
-    const bool sync_on = SYNC && sy.cnt != nullptr && it.grp > 0;
-    const int wvu = __builtin_amdgcn_readfirstlane(wave);
-    unsigned* const scnt = sync_on ? sy.cnt + 2 + (int64_t)(it.grp - 1) * sy.npts : nullptr;
-    const unsigned sneed = (unsigned)it.gm * sy.epoch;
-    const int semask = (1 << sy.eshift) - 1;
-    bool free_run = false;
-    unsigned pollv = 0;
-    auto sync_arrive = [&](int kt) {      // top of k-step kt: announce the point, start the poll of the point `lag` behind
-        if (SYNC && sync_on && wvu == 0 && (kt & semask) == 0) {
-            const int p = kt >> sy.eshift;
-            if (lane == 0) __hip_atomic_fetch_add(scnt + p, 1u, SYRK_RLX_AGENT);
-            if (!free_run && p >= sy.lag) pollv = __hip_atomic_load(scnt + p - sy.lag, SYRK_RLX_AGENT);
-        }
-    };
-    auto sync_check = [&](int kt) {       // in front of the barrier that ends k-step kt: the poll has long returned
-        if (SYNC && sync_on && wvu == 0 && !free_run && (kt & semask) == 0 && (kt >> sy.eshift) >= sy.lag) {
-            unsigned v = (unsigned)__builtin_amdgcn_readfirstlane((int)pollv);
-            if ((int)(v - sneed) < 0) {
-                const unsigned* q = scnt + (kt >> sy.eshift) - sy.lag;
-                bool ok = false;
-                for (int spin = 0; spin < SYRK_SYNC_SPINS; ++spin) {
-                    __builtin_amdgcn_s_sleep(4);
-                    v = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(q, SYRK_RLX_AGENT));
-                    if ((int)(v - sneed) >= 0) { ok = true; break; }
-                }
-                if (!ok) {                // the group is not where the plan expected it: stop following it, count the event
-                    free_run = true;
-                    if (lane == 0) __hip_atomic_fetch_add(sy.cnt, 1u, SYRK_RLX_AGENT);
-                }
-            }
-        }
-    };
 
     // stage s: J operand at smem + s*2*STAGE, I operand right after (aliased for diagonal tiles)
     const int ioff = diag ? 0 : STAGE_DOUBLES;
@@ -209,7 +173,6 @@ __device__ __forceinline__ void syrk_tile(
         for (int t = 0; t < 8; ++t) acc0[t] = acc1[t] = d4{0.0, 0.0, 0.0, 0.0};
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
-            sync_arrive(kt);
             if (kt + 1 < nkt) fetch(kt + 1);
             const double* __restrict__ Xs = sJ(cur);
 #pragma unroll
@@ -226,7 +189,6 @@ __device__ __forceinline__ void syrk_tile(
                 }
             }
             if (kt + 1 < nkt) stash(cur ^ 1);
-            sync_check(kt);
             __syncthreads();
         }
         // lane holds D[row = (lane >> 4) + 4 r -> column j][col = lane & 15 -> row i]
@@ -294,7 +256,6 @@ __device__ __forceinline__ void syrk_tile(
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             const bool has_next = kt + 1 < nkt;
-            sync_arrive(kt);
             const double* __restrict__ Js = sJ(cur) + wj * 64 * LDT_K;
             const double* __restrict__ Is = sI(cur) + wi * 64 * LDT_K;
             double* nJ = sJ(cur ^ 1);
@@ -342,7 +303,6 @@ __device__ __forceinline__ void syrk_tile(
 #pragma unroll
             for (int r = 0; r < 8; ++r) gp[r] += BK;
             if (dp) dp += BK;
-            sync_check(kt);
             __syncthreads();
         }
         };
@@ -372,11 +332,9 @@ __device__ __forceinline__ void syrk_tile(
     } else {
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
-            sync_arrive(kt);
             if (kt + 1 < nkt && !(skip & 1)) fetch(kt + 1);
             wave_mma<LDT_K, 1>(sJ(cur) + wj * 64 * LDT_K, sI(cur) + wi * 64 * LDT_K, acc, lane);
             if (kt + 1 < nkt && !(skip & 2)) stash(cur ^ 1);
-            sync_check(kt);
             if (!(skip & 4)) __syncthreads();
         }
     }
@@ -413,11 +371,11 @@ __device__ __forceinline__ void syrk_tile(
     }
 }
 
-template <bool DMASK, bool SYNC>
+template <bool DMASK>
 __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
     const double* __restrict__ G, int64_t ldg, const double* __restrict__ di, int n, int fast_ok,
     const SyrkItem* __restrict__ items, double* __restrict__ C, int64_t ldc,
-    const double* __restrict__ P, int64_t ldp, double* __restrict__ slabs, BatchStrides bs, SyrkSync sy) {
+    const double* __restrict__ P, int64_t ldp, double* __restrict__ slabs, BatchStrides bs) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     {   // batched problems along blockIdx.z (all strides 0 for a single problem)
         const int64_t bz = blockIdx.z;
@@ -429,9 +387,10 @@ __global__ __launch_bounds__(256, 2) void syrk_tn_kernel(
     // stream-K: a workgroup of the remainder round owns an equal share of that round's k-steps, i.e. the end of one tile's
     // contraction and the beginning of the next one's -- a chain of segments, each with its own partial slab
     int idx = blockIdx.x;
+    const int wave_s = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     for (;;) {
         const SyrkItem it = items[idx];
-        syrk_tile<DMASK, SYNC>(it, G, ldg, di, n, fast_ok, C, ldc, P, ldp, slabs, smem, sy);
+        syrk_tile<DMASK>(it, G, (int)ldg, di, n, fast_ok, C, (int)ldc, P, (int)ldp, slabs, smem, wave_s);
         if (it.next == 0) break;
         idx = it.next - 1;
         __syncthreads();                   // the segment's last reads of the stage buffers are done before the next one fills them
@@ -472,63 +431,43 @@ __global__ __launch_bounds__(256) void syrk_reduce_kernel(const SyrkItem* __rest
 // that XCD's private L2; whole rounds run unsplit tiles; the remainder round is stream-K: its k-steps
 // are dealt out evenly over all workgroup slots (a workgroup finishes one tile's contraction and begins
 // the next one's), with slabs summed in a fixed order by syrk_reduce_kernel.
-// sync_groups (round 4): the full super-tiles come first in the order and every run of (slots / 8)
-// consecutive tiles of an XCD's chunk -- the workgroups it runs side by side -- is a synchronisation group.
+// (Round 4 also built an XCD-local synchronisation of the k progress of the 64 workgroups an XCD runs side by side, so
+//  that shared panels are fetched once per XCD: HBM traffic 35.3 -> 10.6 GB per launch, L2 hit rate 50 -> 84 %, kernel
+//  7.5-24 % slower, clock unchanged -- removed; DESIGN 4b', profiles/r04_syrk_xcd_sync_experiment.txt, commit 4e2b5cc.)
 // ---------------------------------------------------------------------------------------------------
-// the static schedule itself (host only, no device memory): work items in launch order, the split tiles, the slab count
-void make_syrk_items(int n, int K, int num_cus, bool allow_split, bool sync_groups, std::vector<SyrkItem>& items, int& nlaunch,
-                     std::vector<SyrkItem>& split_tiles, int& nslabs, int& ngroups) {
+// the static schedule itself (host only, no device memory): segments in launch order, the split tiles, the slab count
+void make_syrk_items(int n, int K, int num_cus, bool allow_split, std::vector<SyrkItem>& items, int& nlaunch,
+                     std::vector<SyrkItem>& split_tiles, int& nslabs) {
     items.clear();
     split_tiles.clear();
     nslabs = 0;
     nlaunch = 0;
-    ngroups = 0;
     if (n <= 0) return;
     const int nt = (n + TILE - 1) / TILE;
     std::vector<std::pair<int, int>> seq;
     const int ns = (nt + 7) / 8;
-    auto super_tile = [&](int SI, int SJ) {
-        for (int a = 0; a < 8; ++a)
-            for (int b = 0; b < 8; ++b) {
-                const int ti = SI * 8 + a, tj = SJ * 8 + b;
-                if (ti < nt && tj <= ti) seq.emplace_back(ti, tj);
-            }
-    };
-    auto whole = [&](int SI, int SJ) { return SJ < SI && SI * 8 + 8 <= nt; };   // all 64 tiles inside the lower triangle
-    if (sync_groups) {          // whole super-tiles first: a group of 64 consecutive tiles then reads 16 operand panels
-        for (int SI = 0; SI < ns; ++SI)
-            for (int SJ = 0; SJ <= SI; ++SJ)
-                if (whole(SI, SJ)) super_tile(SI, SJ);
-        for (int SI = 0; SI < ns; ++SI)
-            for (int SJ = 0; SJ <= SI; ++SJ)
-                if (!whole(SI, SJ)) super_tile(SI, SJ);
-    } else {
-        for (int SI = 0; SI < ns; ++SI)
-            for (int SJ = 0; SJ <= SI; ++SJ) super_tile(SI, SJ);
-    }
+    for (int SI = 0; SI < ns; ++SI)
+        for (int SJ = 0; SJ <= SI; ++SJ)
+            for (int a = 0; a < 8; ++a)
+                for (int b = 0; b < 8; ++b) {
+                    const int ti = SI * 8 + a, tj = SJ * 8 + b;
+                    if (ti < nt && tj <= ti) seq.emplace_back(ti, tj);
+                }
     const int T = (int)seq.size();
     const int slots = std::max(8, 2 * num_cus);
     const int nfull = (T / slots) * slots;
     const int R = T - nfull;
-    auto full_item = [&](int t) { return SyrkItem{seq[t].first, seq[t].second, 0, K, -1, 0, 0, 0, 0, 0, 0, 0}; };
+    auto full_item = [&](int t) { return SyrkItem{seq[t].first, seq[t].second, 0, K, -1, 0, 0, 0}; };
 
     // XCD-contiguous permutation of the full tiles: id -> xcd = id % 8 gets a contiguous chunk
     {
         const int N = nfull, q = N / 8, r = N % 8;
         items.resize(N);
-        const int per = slots / 8;                      // workgroups an XCD runs side by side
-        const bool groups = sync_groups && N > 0 && r == 0 && slots % 8 == 0 && q % per == 0;
-        const int rounds = groups ? q / per : 0;
         for (int id = 0; id < N; ++id) {
             const int x = id % 8, l = id / 8;
             const int pos = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + l;
             items[id] = full_item(pos);
-            if (groups) {
-                items[id].grp = 1 + x * rounds + l / per;
-                items[id].gm = per;
-            }
         }
-        ngroups = groups ? 8 * rounds : 0;
     }
     nlaunch = nfull;
     if (R == 0) return;
@@ -563,16 +502,14 @@ void make_syrk_items(int n, int K, int num_cus, bool allow_split, bool sync_grou
             seg_items[a] = full_item(t);
         } else {
             for (size_t c = a; c < b; ++c)
-                seg_items[c] = SyrkItem{seq[t].first, seq[t].second, segs[c].ka, segs[c].kb, nslabs + (int)(c - a), nslabs, parts,
-                                        0, 0, 0, 0, 0};
-            split_tiles.push_back(SyrkItem{seq[t].first, seq[t].second, 0, K, -1, nslabs, parts, 0, 0, 0, 0, 0});
+                seg_items[c] = SyrkItem{seq[t].first, seq[t].second, segs[c].ka, segs[c].kb, nslabs + (int)(c - a), nslabs, parts, 0};
+            split_tiles.push_back(SyrkItem{seq[t].first, seq[t].second, 0, K, -1, nslabs, parts, 0});
             nslabs += parts;
         }
         a = b;
     }
     // launch order: the first segment of every workgroup, then the continuation segments (chained through `next`)
     std::vector<int> where(segs.size(), -1);
-    items.resize(nfull + W);
     int extra = nfull + W;
     for (size_t a = 0; a < segs.size();) {
         size_t b = a;
@@ -589,38 +526,18 @@ void make_syrk_items(int n, int K, int num_cus, bool allow_split, bool sync_grou
     nlaunch = nfull + W;
 }
 
-// XCD-local k synchronisation: announce every 2^eshift k-steps, run at most `lag` points ahead of the slowest member.
-// Test / developer knob MI355KKT_SYRK_SYNC = "off" | "<eshift>,<lag>" (read when a plan is built; include/mi355kkt_test.h).
-static void syrk_sync_config(bool& on, int& eshift, int& lag) {
-    // measured (profiles/r04_syrk_xcd_sync_experiment.txt): HBM traffic 35.3 -> 10.6 GB per launch, L2 hit rate 50 -> 84 %, but the
-    // kernel is 7.5 % (announce every 8 k-steps, lag 1) to 24 % (every 2, lag 2) SLOWER and the clock does not move (2.35 GHz
-    // either way): off unless the knob asks for it
-    on = false;
-    eshift = 3;
-    lag = 1;
-    if (const char* v = dev_knob("MI355KKT_SYRK_SYNC")) {
-        int a = 0, b = 0;
-        if (sscanf(v, "%d,%d", &a, &b) == 2 && a >= 0 && a <= 6 && b >= 1 && b <= 64) { on = true; eshift = a; lag = b; }
-    }
-}
-
 int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split) {
     free_syrk_plan(plan);
     plan.n = n;
     plan.K = K;
     if (n <= 0) return 0;
     std::vector<SyrkItem> items, split_tiles;
-    int nslabs = 0, nlaunch = 0, ngroups = 0, eshift = 0, lag = 0;
-    bool sync_on = false;
-    syrk_sync_config(sync_on, eshift, lag);
-    // groups only where the panels are worth sharing: a single problem (allow_split) with a long contraction
-    const bool want_groups = sync_on && allow_split && K >= 2048 && n % TILE == 0 && K % BK == 0;
-    make_syrk_items(n, K, num_cus, allow_split, want_groups, items, nlaunch, split_tiles, nslabs, ngroups);
+    int nslabs = 0, nlaunch = 0;
+    make_syrk_items(n, K, num_cus, allow_split, items, nlaunch, split_tiles, nslabs);
     plan.nitems = nlaunch;
     plan.nitems_total = (int)items.size();
     plan.nslabs = nslabs;
     plan.nsplit_tiles = (int)split_tiles.size();
-    plan.ngroups = ngroups;
     KKT_HIP_CHECK(hipMalloc(&plan.d_items, sizeof(SyrkItem) * std::max<size_t>(1, items.size())));
     KKT_HIP_CHECK(memcpy_sync(plan.d_items, items.data(), sizeof(SyrkItem) * items.size(), hipMemcpyHostToDevice));
     if (!split_tiles.empty()) {
@@ -629,16 +546,6 @@ int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split)
                                 hipMemcpyHostToDevice));
         KKT_HIP_CHECK(hipMalloc(&plan.d_slabs, sizeof(double) * (size_t)nslabs * TILE * TILE));
     }
-    if (ngroups > 0) {
-        const int nkt = (K + BK - 1) / BK;
-        plan.sync.eshift = eshift;
-        plan.sync.lag = lag;
-        plan.sync.npts = (nkt >> eshift) + 1;
-        plan.sync.epoch = 0;
-        const size_t bytes = sizeof(unsigned) * (2 + (size_t)ngroups * plan.sync.npts);
-        KKT_HIP_CHECK(hipMalloc(&plan.sync.cnt, bytes));
-        KKT_HIP_CHECK(memset_sync(plan.sync.cnt, 0, bytes));
-    }
     return 0;
 }
 
@@ -646,17 +553,7 @@ void free_syrk_plan(SyrkPlan& plan) {
     if (plan.d_items) (void)hipFree(plan.d_items);
     if (plan.d_split_tiles) (void)hipFree(plan.d_split_tiles);
     if (plan.d_slabs) (void)hipFree(plan.d_slabs);
-    if (plan.sync.cnt) (void)hipFree(plan.sync.cnt);
     plan = SyrkPlan();
-}
-
-// waits of the plan's launches that ran into their bound so far (0 on an undisturbed device); < 0: error
-int syrk_sync_timeouts(const SyrkPlan& plan, hipStream_t st) {
-    if (!plan.sync.cnt) return 0;
-    unsigned v = 0;
-    if (hipStreamSynchronize(st) != hipSuccess) return -1;
-    if (memcpy_sync(&v, plan.sync.cnt, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return (int)v;
 }
 
 static constexpr size_t kGemmLds = sizeof(double) * 4 * STAGE_DOUBLES;   // 73,728 B
@@ -669,11 +566,9 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
     if (plan.n == 0) return 0;
     static bool attr_set = false;
     if (!attr_set) {
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_tn_kernel<false, false>),
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_tn_kernel<false>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_tn_kernel<false, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
-        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_tn_kernel<true, false>),
+        KKT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(syrk_tn_kernel<true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmLds));
         attr_set = true;
     }
@@ -686,19 +581,14 @@ int launch_syrk_scaled(const SyrkPlan& plan, const double* G, int64_t ldg, const
     {
         // diagonal tiles: contractions of 8192 rows and more take the nine-blocks-per-wave path inside the kernel; shorter ones (the
         // batched engine: K = 1024, 4 of a problem's 10 tiles are diagonal) the block masks of the pipelined loop
-        if (plan.K >= 8192 && plan.ngroups > 0 && nbatch == 1 && fast_ok) {
-            SyrkSync sy = plan.sync;
-            sy.epoch = ++plan.sync.epoch;
-            hipLaunchKernelGGL((syrk_tn_kernel<false, true>), dim3(plan.nitems, 1, 1), dim3(256), kGemmLds, st, G, ldg, di, plan.n,
-                               fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs, sy);
-        } else if (plan.K >= 8192)
-            hipLaunchKernelGGL((syrk_tn_kernel<false, false>), dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di,
-                               plan.n, fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs, SyrkSync());
+        if (plan.K >= 8192)
+            hipLaunchKernelGGL(syrk_tn_kernel<false>, dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di, plan.n,
+                               fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs);
         else
             // (work items dealt so that all tiles of a problem run on one XCD -- ids grouped by 8 problems -- were measured too:
             //  +-1 %, the operand panels of a problem come from the Infinity Cache either way; not kept)
-            hipLaunchKernelGGL((syrk_tn_kernel<true, false>), dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di,
-                               plan.n, fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs, SyrkSync());
+            hipLaunchKernelGGL(syrk_tn_kernel<true>, dim3(plan.nitems, 1, nbatch), dim3(256), kGemmLds, st, G, ldg, di, plan.n,
+                               fast_ok, plan.d_items, C, ldc, P, ldp, plan.d_slabs, bs);
     }
     KKT_HIP_CHECK(hipGetLastError());
     if (kernel_events) KKT_HIP_CHECK(hipEventRecord(kernel_events[1], st));

@@ -61,22 +61,6 @@ struct SyrkItem {  // one contraction segment of one tile in the scaled SYRK
     int first;     // for partial items: index of first slab of this tile; count in `nparts`
     int nparts;
     int next;      // 0: the workgroup is done after this segment; else 1 + index of the segment it continues with (stream-K)
-    int grp;       // 0: free-running; else 1 + index of the XCD-local group whose k progress this tile follows (see SyrkSync)
-    int gm;        // members of that group
-    int pad0, pad1;
-};
-
-// XCD-local k synchronisation of the scaled SYRK (round 4): the workgroups one XCD runs side by side (one "round" of its
-// chunk of the work list = one 8 x 8 super-tile of C) announce their k progress every 2^eshift k-steps in a counter per
-// (group, point) and do not run more than `lag` points ahead of the slowest member, so that the operand panels they share
-// are fetched into that XCD's L2 once instead of once per workgroup.  Counters only ever grow (one launch adds `gm` to each):
-// nothing is reset between launches.  cnt[0] counts the waits that ran into their bound (the workgroup then free-runs
-// to the end of its tile: a wrong placement guess costs time, never a hang).
-struct SyrkSync {
-    unsigned* cnt = nullptr;   // [2 + ngroups * npts]
-    unsigned epoch = 0;        // launches so far, this one included
-    int npts = 0;              // points per group
-    int eshift = 0, lag = 0;
 };
 
 struct SyrkPlan {
@@ -86,17 +70,13 @@ struct SyrkPlan {
     SyrkItem* d_items = nullptr;       // device copy, XCD-friendly order
     SyrkItem* d_split_tiles = nullptr; // one entry per split tile (first/nparts used by the reducer)
     double* d_slabs = nullptr;         // nslabs * TILE*TILE doubles
-    int ngroups = 0;                   // XCD-local synchronisation groups (0: none)
-    mutable SyrkSync sync;             // (epoch advances with every launch)
 };
 
 int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split = true);
-// items: the launch's workgroups first (nlaunch of them), continuation segments after; sync_groups: lay the full tiles out in
-// XCD-local groups (grp / gm set) -- returns their number in ngroups
-void make_syrk_items(int n, int K, int num_cus, bool allow_split, bool sync_groups, std::vector<SyrkItem>& items, int& nlaunch,
-                     std::vector<SyrkItem>& split_tiles, int& nslabs, int& ngroups);
+// items: the launch's workgroups first (nlaunch of them), continuation segments after
+void make_syrk_items(int n, int K, int num_cus, bool allow_split, std::vector<SyrkItem>& items, int& nlaunch,
+                     std::vector<SyrkItem>& split_tiles, int& nslabs);
 void free_syrk_plan(SyrkPlan& plan);
-int syrk_sync_timeouts(const SyrkPlan& plan, hipStream_t st);   // waits that ran into their bound so far; < 0: error
 
 // C(lower) = P(lower) + Gs' Gs with Gs = diag(di) G   (di == nullptr: no scaling; P == nullptr: 0)
 // kernel_events (optional): two events recorded immediately around the syrk_tn_kernel launch.

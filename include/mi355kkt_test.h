@@ -27,13 +27,11 @@ int mi355kkt_test_cone_op_host(int op, int mk, int arg, double* x, double* y, do
 int mi355kkt_test_sdp_op_host(int op, int m, int arg, double* x, double* y, double* r, double* rti, double* lam);
 int mi355kkt_test_sdp_op_host_team(int op, int m, int arg, int nt, double* x, double* y, double* r, double* rti, double* lam);
 int mi355kkt_test_sdp_op_device(int op, int m, int arg, int team, double* x, double* y, double* r, double* rti, double* lam);
-/* the static work list of the scaled SYRK (host only): 12 ints per segment = ti, tj, k0, k1, slot, first, nparts, next, grp, gm,
- * 0, 0; the first *nlaunch segments are the launch's workgroups, the rest continuation segments (next = 1 + index);
- * allow_split bit 0: stream-K remainder round, bit 1: XCD-local synchronisation groups; returns #segments */
+/* the static work list of the scaled SYRK (host only): 8 ints per segment = ti, tj, k0, k1, slot, first, nparts, next; the first
+ * *nlaunch segments are the launch's workgroups, the rest continuation segments of the stream-K remainder round (next = 1 + index);
+ * returns #segments */
 int mi355kkt_test_syrk_plan(int n, int K, int num_cus, int allow_split, int* out, int max_items, int* nslabs, int* nsplit,
-                            int* nlaunch, int* ngroups);
-/* groups of the plan behind the last mi355kkt_op_syrk_scaled call (0: free-running); *timeouts = waits that hit their bound */
-int mi355kkt_test_syrk_sync_state(int* timeouts);
+                            int* nlaunch);
 /* fill-reducing ordering of a symmetric CSC pattern (host only; csrc/ordering.cpp -- the step cholmod.symbolic performs through
  * cholmod_analyze_p, reference src/C/cholmod.c:309): method 0 choose / 1 nested dissection / 2 approximate minimum degree;
  * perm[new] = old; stats[8] = chosen method, nnz and flops of both candidates, supernodal tree heights, count cross-check */
@@ -44,7 +42,7 @@ int mi355kkt_test_throw(int kind);
 /* Knobs of the sparse symbolic analysis and a few kernel-selection thresholds (csrc/knobs.h): "MI355KKT_ORDERING" = nd | amd,
  * "MI355KKT_ND_MODE", "MI355KKT_ND_LEAF", "MI355KKT_ND_LEAF_AMD", "MI355KKT_ND_NOREFINE", "MI355KKT_ORDERING_BOTH",
  * "MI355KKT_SN_MAXW", "MI355KKT_SPARSE_BIG_FLOPS", "MI355KKT_SPARSE_BIG_H", "MI355KKT_SP_WIDE", "MI355KKT_SPARSE_TILES",
- * "MI355KKT_SYRK_SYNC" = off | "<eshift>,<lag>",
+ * "MI355KKT_BATCH_TILES" = 0 (launch chain),
  * "MI355KKT_SDP_WAVE_MAX", "MI355KKT_SDP_NO_MFMA", "MI355KKT_SPARSE_DEBUG", "MI355KKT_ND_DEBUG".  They are set ONLY by this
  * call -- the library never reads them from the environment -- so that tests can drive every ordering / plan shape through the
  * same code.  value == NULL unsets one knob, name == NULL all of them.  Process-wide; returns 0. */

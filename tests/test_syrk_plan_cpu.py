@@ -1,8 +1,7 @@
 """CPU test of the static SYRK schedule (host logic of csrc/gemm_f64.hip, `make_syrk_items`): every lower-triangular tile
 is produced exactly once -- either by one full-K segment or by split pieces whose k-ranges partition [0, K) on BK
 boundaries and whose slab slots are consecutive -- for the shapes the engine builds plans for; the remainder round is
-stream-K (every workgroup of it owns the same number of k-steps, +-1, as a chain of segments); with synchronisation groups the
-workgroups an XCD runs side by side form groups of 2 * CUs / 8 tiles that read few distinct operand panels."""
+stream-K (every workgroup of it owns the same number of k-steps, +-1, as a chain of segments)."""
 import ctypes as C
 
 import numpy as np
@@ -13,15 +12,15 @@ from cvxopt_amd import _capi
 TILE, BK = 128, 16
 
 
-def plan(n, K, cus=256, split=True, groups=False):
+def plan(n, K, cus=256, split=True):
     L = _capi.lib()
     cap = 1 << 16
-    out = np.zeros(12 * cap, dtype=np.int32)
-    ns, nsp, nl, ng = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-    cnt = L.mi355kkt_test_syrk_plan(n, K, cus, (1 if split else 0) | (2 if groups else 0), out.ctypes.data_as(_capi.c_int_p), cap,
-                                    C.byref(ns), C.byref(nsp), C.byref(nl), C.byref(ng))
+    out = np.zeros(8 * cap, dtype=np.int32)
+    ns, nsp, nl = C.c_int(), C.c_int(), C.c_int()
+    cnt = L.mi355kkt_test_syrk_plan(n, K, cus, 1 if split else 0, out.ctypes.data_as(_capi.c_int_p), cap, C.byref(ns), C.byref(nsp),
+                                    C.byref(nl))
     assert 0 <= cnt <= cap
-    return out[:12 * cnt].reshape(cnt, 12), ns.value, nsp.value, nl.value, ng.value
+    return out[:8 * cnt].reshape(cnt, 8), ns.value, nsp.value, nl.value
 
 
 SHAPES = [(8192, 16384, 256, True), (2048, 8192, 256, True), (512, 1024, 256, False), (300, 77, 256, True), (1, 5, 256, True),
@@ -29,13 +28,12 @@ SHAPES = [(8192, 16384, 256, True), (2048, 8192, 256, True), (512, 1024, 256, Fa
           (8192, 4096, 256, True), (2176, 8192, 256, True)]
 
 
-@pytest.mark.parametrize("groups", [False, True])
 @pytest.mark.parametrize("n,K,cus,split", SHAPES)
-def test_every_lower_tile_is_covered_exactly_once(n, K, cus, split, groups):
-    items, nslabs, nsplit, nlaunch, ngroups = plan(n, K, cus, split, groups)
+def test_every_lower_tile_is_covered_exactly_once(n, K, cus, split):
+    items, nslabs, nsplit, nlaunch = plan(n, K, cus, split)
     nt = (n + TILE - 1) // TILE
     full, pieces = {}, {}
-    for ti, tj, k0, k1, slot, first, nparts, nxt, grp, gm, _, _ in items:
+    for ti, tj, k0, k1, slot, first, nparts, nxt in items:
         assert 0 <= tj <= ti < nt
         assert 0 <= k0 < k1 <= K
         if slot < 0:
@@ -43,7 +41,6 @@ def test_every_lower_tile_is_covered_exactly_once(n, K, cus, split, groups):
             full[(ti, tj)] = full.get((ti, tj), 0) + 1
         else:
             assert split
-            assert grp == 0
             pieces.setdefault((ti, tj), []).append((k0, k1, slot, first, nparts))
     assert not (set(full) & set(pieces))
     assert all(v == 1 for v in full.values())
@@ -65,7 +62,7 @@ def test_every_lower_tile_is_covered_exactly_once(n, K, cus, split, groups):
 
 @pytest.mark.parametrize("n,K,cus,split", SHAPES)
 def test_chains_reach_every_segment_once_and_balance_the_remainder_round(n, K, cus, split):
-    items, nslabs, nsplit, nlaunch, ngroups = plan(n, K, cus, split)
+    items, nslabs, nsplit, nlaunch = plan(n, K, cus, split)
     assert 0 < nlaunch <= len(items)
     seen = np.zeros(len(items), dtype=int)
     loads = []
@@ -92,43 +89,14 @@ def test_chains_reach_every_segment_once_and_balance_the_remainder_round(n, K, c
 
 def test_headline_shape_fills_the_last_round():
     """config 2: 2080 tiles on 512 slots -> 4 full rounds + 32 tiles split 16 ways = one more full round of 512 pieces."""
-    for groups in (False, True):
-        items, nslabs, nsplit, nlaunch, ngroups = plan(8192, 16384, groups=groups)
-        assert nsplit == 32 and nslabs == 512 and len(items) == 2048 + 512 == nlaunch
-        assert np.all(items[:2048, 4] < 0) and np.all(items[2048:, 4] >= 0)
-        assert set((items[2048:, 3] - items[2048:, 2]).tolist()) == {1024}
-        assert ngroups == (32 if groups else 0)
+    items, nslabs, nsplit, nlaunch = plan(8192, 16384)
+    assert nsplit == 32 and nslabs == 512 and len(items) == 2048 + 512 == nlaunch
+    assert np.all(items[:2048, 4] < 0) and np.all(items[2048:, 4] >= 0)
+    assert set((items[2048:, 3] - items[2048:, 2]).tolist()) == {1024}
 
 
 def test_socp_shape_is_balanced_over_all_slots():
     """config 3 (n = 2048, K = 8192): 136 tiles of 512 k-steps on 512 slots -> 136 k-steps per workgroup, two segments at most."""
-    items, nslabs, nsplit, nlaunch, ngroups = plan(2048, 8192)
-    assert nlaunch == 512 and nsplit == 136 and ngroups == 0
+    items, nslabs, nsplit, nlaunch = plan(2048, 8192)
+    assert nlaunch == 512 and nsplit == 136
     assert 512 < len(items) <= 512 + 136
-
-
-@pytest.mark.parametrize("n,K,cus", [(8192, 16384, 256), (4096, 8192, 256), (8192, 8192, 256), (16384, 16384, 256), (4096, 8192, 64)])
-def test_groups_are_the_workgroups_one_xcd_runs_side_by_side(n, K, cus):
-    items, nslabs, nsplit, nlaunch, ngroups = plan(n, K, cus, True, True)
-    per = 2 * cus // 8
-    nfull = int(np.sum(items[:nlaunch, 4] < 0))
-    assert nfull % (2 * cus) == 0 and ngroups == nfull // per
-    members = {}
-    for wid in range(nfull):
-        ti, tj, k0, k1, slot, first, nparts, nxt, grp, gm = items[wid][:10]
-        assert slot < 0 and grp >= 1 and gm == per
-        members.setdefault(grp, []).append(wid)
-    assert sorted(members) == list(range(1, ngroups + 1))
-    shared = []
-    for grp, ws in members.items():
-        assert len(ws) == per
-        assert len(set(w % 8 for w in ws)) == 1                          # one XCD (workgroup ids are dealt round-robin)
-        ls = sorted(w // 8 for w in ws)
-        assert ls == list(range(ls[0], ls[0] + per)) and ls[0] % per == 0   # consecutive in that XCD's dispatch order: one round
-        panels = set()
-        for w in ws:
-            panels.update((int(items[w][0]), int(items[w][1])))
-        shared.append(len(panels))
-    if cus == 256:
-        assert max(shared) <= 24 and np.mean(shared) <= 18                # 64 tiles read 16 panels where the super-tile is whole
-    assert np.all(items[nfull:, 8] == 0)

@@ -1,7 +1,4 @@
-"""Developer probe: a handful of launches of the headline SYRK (n = 8192, m = 16384) and nothing else, for rocprofv3 --pmc passes.
-
-    python tools/dev/syrk_prof_dev.py [reps] [MI355KKT_SYRK_SYNC knob: off | <eshift>,<lag>]
-"""
+"""Developer probe: a handful of launches of the headline SYRK (n = 8192, m = 16384) and nothing else, for rocprofv3 --pmc passes."""
 import ctypes as C, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -9,8 +6,6 @@ from cvxopt_amd import _capi
 L = _capi.lib()
 n, m = 8192, 16384
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-if len(sys.argv) > 2:
-    _capi.set_knob("MI355KKT_SYRK_SYNC", sys.argv[2])
 rng = np.random.default_rng(0)
 G = np.asfortranarray(rng.standard_normal((m, n)))
 di = rng.uniform(0.5, 2, m)
