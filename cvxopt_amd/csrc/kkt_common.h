@@ -112,15 +112,6 @@ struct PotrfWork {
     double* d_minv = nullptr;
     int minv_n = 0;
     const double* minv_of = nullptr;
-    // batched factorisation through the variable-batched tile kernel (one persistent launch for all problems of a batch):
-    // descriptors / tickets / per-problem progress words and 16 x 16 inverses for (vb_n, vb_nbatch, vb_stride)
-    VbDesc* d_vb_desc = nullptr;
-    void* d_vb_tickets = nullptr;
-    int* d_vb_prog_off = nullptr;          // [nbatch] progress-word offsets, then [nbatch] inverse-block offsets
-    unsigned* d_vb_prog = nullptr;
-    double* d_vb_linv = nullptr;
-    int vb_n = 0, vb_nbatch = 0, vb_ntickets = 0, vb_nprog = 0;
-    int64_t vb_stride = 0;
     // look-ahead: the bulk of each trailing update runs on `side` while the next panel is factored on the main stream
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_bulk;

@@ -12,9 +12,6 @@
 #include <cstdlib>
 
 #include "kkt_common.h"
-#include "knobs.h"
-#include <cstring>
-#include <vector>
 #include <type_traits>
 
 // The fence-free hand-offs of the tile kernel (st_wt / ld_l2 + s_waitcnt, DESIGN 4a') rest on gfx942 / gfx950 behaviour: agent-scope
@@ -1185,11 +1182,6 @@ void potrf_work_free(PotrfWork& w) {
     if (w.d_ctl) (void)hipFree(w.d_ctl);
     if (w.d_linv_all) (void)hipFree(w.d_linv_all);
     if (w.d_minv) (void)hipFree(w.d_minv);
-    if (w.d_vb_desc) (void)hipFree(w.d_vb_desc);
-    if (w.d_vb_tickets) (void)hipFree(w.d_vb_tickets);
-    if (w.d_vb_prog_off) (void)hipFree(w.d_vb_prog_off);
-    if (w.d_vb_prog) (void)hipFree(w.d_vb_prog);
-    if (w.d_vb_linv) (void)hipFree(w.d_vb_linv);
     for (auto e : w.ev_panel) (void)hipEventDestroy(e);
     for (auto e : w.ev_bulk) (void)hipEventDestroy(e);
     if (w.side) (void)hipStreamDestroy(w.side);
@@ -1284,54 +1276,9 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
     return 0;
 }
 
-// Batched factorisation as ONE persistent launch (round 4): the nbatch matrices are nbatch "fronts" of the variable-batched tile
-// kernel, every column of each to be eliminated; tickets in the order (tile column, problem, tile row), so all problems' chains
-// run side by side and a problem's four-hop chain (n = 512) hides behind the other problems' tiles.  Replaces the
-// potf2 / trsm / update launch chain (13 launches for n = 512, each waiting for the slowest problem of its predecessor).
-static int potrf_work_reserve_vb(PotrfWork& w, int n, int nbatch, int64_t bstride) {
-    if (w.d_vb_desc && w.vb_n == n && w.vb_nbatch == nbatch && w.vb_stride == bstride) return 0;
-    for (void* p : {(void*)w.d_vb_desc, w.d_vb_tickets, (void*)w.d_vb_prog_off, (void*)w.d_vb_prog, (void*)w.d_vb_linv})
-        if (p) (void)hipFree(p);
-    w.d_vb_desc = nullptr; w.d_vb_tickets = nullptr; w.d_vb_prog_off = nullptr; w.d_vb_prog = nullptr; w.d_vb_linv = nullptr;
-    w.vb_n = 0;
-    const int NT = (n + NB - 1) / NB;
-    std::vector<VbDesc> desc(nbatch);
-    std::vector<int> offs(2 * (size_t)nbatch);
-    for (int f = 0; f < nbatch; ++f) {
-        desc[f] = VbDesc{(int64_t)f * bstride, n, n, 0, 0};
-        offs[f] = f * NT;
-        offs[nbatch + f] = f * NT;
-    }
-    std::vector<VbTicket> tk;
-    tk.reserve((size_t)nbatch * NT * (NT + 1) / 2);
-    for (int j = 0; j < NT; ++j)
-        for (int f = 0; f < nbatch; ++f)
-            for (int i = j; i < NT; ++i) tk.push_back(VbTicket{f, i, j, 0});
-    const int nprog = nbatch * NT;
-    if (!w.d_ctl) KKT_HIP_CHECK(hipMalloc(&w.d_ctl, sizeof(TileCtl)));
-    KKT_HIP_CHECK(hipMalloc(&w.d_vb_desc, sizeof(VbDesc) * desc.size()));
-    KKT_HIP_CHECK(hipMalloc(&w.d_vb_tickets, sizeof(VbTicket) * tk.size()));
-    KKT_HIP_CHECK(hipMalloc(&w.d_vb_prog_off, sizeof(int) * offs.size()));
-    KKT_HIP_CHECK(hipMalloc(&w.d_vb_prog, sizeof(unsigned) * 3 * (size_t)nprog));
-    KKT_HIP_CHECK(hipMalloc(&w.d_vb_linv, sizeof(double) * 2048 * (size_t)nprog));
-    KKT_HIP_CHECK(memcpy_sync(w.d_vb_desc, desc.data(), sizeof(VbDesc) * desc.size(), hipMemcpyHostToDevice));
-    KKT_HIP_CHECK(memcpy_sync(w.d_vb_tickets, tk.data(), sizeof(VbTicket) * tk.size(), hipMemcpyHostToDevice));
-    KKT_HIP_CHECK(memcpy_sync(w.d_vb_prog_off, offs.data(), sizeof(int) * offs.size(), hipMemcpyHostToDevice));
-    w.vb_n = n; w.vb_nbatch = nbatch; w.vb_stride = bstride;
-    w.vb_ntickets = (int)tk.size(); w.vb_nprog = nprog;
-    return 0;
-}
-
 int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st) {
-    // a batch of matrices of two and more tile columns stored with lda == n: all of them in one persistent launch
-    // (test / developer knob MI355KKT_BATCH_TILES=0: the launch chain below)
-    if (nbatch > 1 && n > NB && lda == n && (n + NB - 1) / NB <= 252 &&
-        !(dev_knob("MI355KKT_BATCH_TILES") && !strcmp(dev_knob("MI355KKT_BATCH_TILES"), "0"))) {
-        if (int e = potrf_work_reserve_vb(w, n, nbatch, bstride)) return e;
-        w.minv_n = 0;
-        return launch_potrf_tiles_vb(A, w.d_vb_desc, nbatch, w.d_vb_tickets, w.vb_ntickets, w.d_vb_prog_off,
-                                     w.d_vb_prog_off + nbatch, w.d_ctl, w.d_vb_prog, w.vb_nprog, w.d_vb_linv, w.d_info, st);
-    }
+    // (round 4 measured the batch as nbatch "fronts" of the variable-batched tile kernel, one launch instead of this chain: 512
+    //  problems of n = 512: factor 4.35 -> 4.8 ms, SLOWER -- profiles/r04_batch_tiles_ab.txt; not kept)
     KKT_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int) * nbatch, st));
     // single large matrix: the persistent left-looking tile kernel (up to 252 block columns: TileCtl)
     constexpr int tiles_min_n = 1024;

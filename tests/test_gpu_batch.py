@@ -66,35 +66,6 @@ def test_batched_factor_reports_per_problem_failures_several_panels():
     g.close()
 
 
-@pytest.mark.parametrize("B,n,m", [(9, 512, 1024), (4, 300, 450)])
-def test_batched_tile_kernel_and_launch_chain_agree(B, n, m, knobs):
-    """the batch's Cholesky as one persistent launch of the variable-batched tile kernel (default, round 4) against the
-    potf2 / trsm / update launch chain it replaces (knob MI355KKT_BATCH_TILES=0): same solutions, same failure report"""
-    probs = [synth.dense_qp(n, m, seed=300 + i) for i in range(B)]
-    P, q, Gt, h = pack_problems(probs)
-    P[1] = 0.0
-    Gt[1, :, m // 3:] = 0.0                   # problem 1: S has rank m / 3 < n
-    rng = np.random.default_rng(n)
-    di = 10.0 ** rng.uniform(-1.0, 1.0, (B, m))
-    x, z = rng.standard_normal((B, n)), rng.standard_normal((B, m))
-    out = {}
-    for mode in ("tiles", "chain"):
-        if mode == "chain":
-            knobs.setenv("MI355KKT_BATCH_TILES", "0")
-        g = BatchKkt(Gt, P)
-        info = g.factor(di)
-        xs, zs = x.copy(), z.copy()
-        g.solve(xs, zs)
-        out[mode] = (info.copy(), xs, zs)
-        g.close()
-    (it, xt, zt), (ic, xc, zc) = out["tiles"], out["chain"]
-    ok = [b for b in range(B) if b != 1]
-    assert np.all(it[ok] == 0) and np.all(ic[ok] == 0)
-    assert it[1] > 0 and ic[1] > 0 and abs(int(it[1]) - int(ic[1])) <= 2
-    for b in ok:
-        assert relerr(xt[b], xc[b]) < 1e-9 and relerr(zt[b], zc[b]) < 1e-9, b
-
-
 def test_coneqp_batch_gpu_matches_golden_reference_run():
     g = load_golden("coneqp_qp256")
     pr = synth.dense_qp(int(g['n']), int(g['m']), seed=int(g['seed']))
