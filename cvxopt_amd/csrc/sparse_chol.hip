@@ -694,21 +694,33 @@ int sp_wide_threshold() {
     return v;
 }
 
+__device__ __forceinline__ double sp_bcast(double v, int srclane) {   // srclane wave-uniform: two v_readlane, no LDS round trip
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ void sp_trsv_fwd_lds(const double* __restrict__ P, int h, int w, double* xs) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int jb = 0; jb < w; jb += SPB) {
         const int nbk = min(SPB, w - jb);
         if (wave == 0) {
+            // round 4: the chain is multiply + broadcast + FMA per column (the reciprocal of the lane's pivot is formed once, off the
+            // chain; a division per step was 12-15 dependent instructions) and ends at the block's width (a one-column supernode
+            // used to walk all 32 steps)
             double Lr[SPB];
             const int r = min(lane, nbk - 1);
 #pragma unroll
-            for (int k = 0; k < SPB; ++k) Lr[k] = (k < nbk) ? P[(jb + r) + (int64_t)(jb + k) * h] : 1.0;
+            for (int k = 0; k < SPB; ++k) Lr[k] = (k < nbk) ? P[(jb + r) + (int64_t)(jb + k) * h] : 0.0;
+            const double dinv = 1.0 / P[(jb + r) + (int64_t)(jb + r) * h];
             double xi = (lane < nbk) ? xs[jb + lane] : 0.0;
 #pragma unroll
             for (int k = 0; k < SPB; ++k) {
-                if (lane == k) xi = xi / Lr[k];
-                const double v = __shfl(xi, k, 64);
-                if (lane > k && lane < nbk) xi -= Lr[k] * v;
+                if (k < nbk) {                                   // wave-uniform
+                    const double v = sp_bcast(xi * dinv, k);      // x_k (lane k's value is final here)
+                    if (lane == k) xi = v;
+                    if (lane > k) xi = fma(-Lr[k], v, xi);
+                }
             }
             if (lane < nbk) xs[jb + lane] = xi;
         }
@@ -740,14 +752,15 @@ __device__ __forceinline__ void sp_trsv_bwd_lds(const double* __restrict__ P, in
             double Lc[SPB];      // Lc[k] = L[jb + k][jb + lane]  (column `lane` of the block)
             const int c = min(lane, nbk - 1);
 #pragma unroll
-            for (int k = 0; k < SPB; ++k) Lc[k] = (k < nbk) ? P[(jb + k) + (int64_t)(jb + c) * h] : 1.0;
+            for (int k = 0; k < SPB; ++k) Lc[k] = (k < nbk) ? P[(jb + k) + (int64_t)(jb + c) * h] : 0.0;
+            const double dinv = 1.0 / P[(jb + c) + (int64_t)(jb + c) * h];
             double xi = (lane < nbk) ? xs[jb + lane] : 0.0;
 #pragma unroll
             for (int k = SPB - 1; k >= 0; --k) {
-                if (k < nbk) {
-                    if (lane == k) xi = xi / Lc[k];
-                    const double v = __shfl(xi, k, 64);
-                    if (lane < k) xi -= Lc[k] * v;
+                if (k < nbk) {                                   // wave-uniform
+                    const double v = sp_bcast(xi * dinv, k);
+                    if (lane == k) xi = v;
+                    if (lane < k) xi = fma(-Lc[k], v, xi);
                 }
             }
             if (lane < nbk) xs[jb + lane] = xi;
