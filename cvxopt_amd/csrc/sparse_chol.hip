@@ -729,11 +729,18 @@ __device__ __forceinline__ void sp_trsv_fwd_lds(const double* __restrict__ P, in
             const double* __restrict__ Pi = P + i + (int64_t)jb * h;
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
             int k = 0;
-            for (; k + 4 <= nbk; k += 4) {           // four loads in flight per thread
-                a0 += Pi[(int64_t)k * h] * xs[jb + k];
-                a1 += Pi[(int64_t)(k + 1) * h] * xs[jb + k + 1];
-                a2 += Pi[(int64_t)(k + 2) * h] * xs[jb + k + 2];
-                a3 += Pi[(int64_t)(k + 3) * h] * xs[jb + k + 3];
+            for (; k + 8 <= nbk; k += 8) {           // eight loads in flight per thread (the loop is latency-bound: round 4;
+                double v[8];                         //  all 32 of a block at once cost registers, i.e. leaf-level occupancy)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = Pi[(int64_t)(k + q) * h];
+                a0 += v[0] * xs[jb + k];
+                a1 += v[1] * xs[jb + k + 1];
+                a2 += v[2] * xs[jb + k + 2];
+                a3 += v[3] * xs[jb + k + 3];
+                a0 += v[4] * xs[jb + k + 4];
+                a1 += v[5] * xs[jb + k + 5];
+                a2 += v[6] * xs[jb + k + 6];
+                a3 += v[7] * xs[jb + k + 7];
             }
             for (; k < nbk; ++k) a0 += Pi[(int64_t)k * h] * xs[jb + k];
             xs[i] -= (a0 + a1) + (a2 + a3);
@@ -821,7 +828,20 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
         const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
         const double* __restrict__ Rc = rem + rem_off[c];
         const int* __restrict__ rm = d.relmap + d.relmap_off[c];
-        for (int i = tid; i < hc; i += 256) {
+        int i = tid;
+        for (; i + 768 < hc; i += 1024) {                 // four independent (map, value) pairs in flight per thread
+            int pq[4];
+            double vq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pq[q] = rm[i + 256 * q]; vq[q] = Rc[i + 256 * q]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int p = pq[q];
+                if (p < w) xs[p] += vq[q];
+                else R[p - w] += vq[q];
+            }
+        }
+        for (; i < hc; i += 256) {
             const int p = rm[i];
             if (p < w) xs[p] += Rc[i];
             else R[p - w] += Rc[i];
@@ -835,11 +855,18 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
         const double* __restrict__ Pi = P + w + i;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         int j = 0;
-        for (; j + 4 <= w; j += 4) {
-            a0 += Pi[(int64_t)j * h] * xs[j];
-            a1 += Pi[(int64_t)(j + 1) * h] * xs[j + 1];
-            a2 += Pi[(int64_t)(j + 2) * h] * xs[j + 2];
-            a3 += Pi[(int64_t)(j + 3) * h] * xs[j + 3];
+        for (; j + 8 <= w; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = Pi[(int64_t)(j + q) * h];
+            a0 += v[0] * xs[j];
+            a1 += v[1] * xs[j + 1];
+            a2 += v[2] * xs[j + 2];
+            a3 += v[3] * xs[j + 3];
+            a0 += v[4] * xs[j + 4];
+            a1 += v[5] * xs[j + 5];
+            a2 += v[6] * xs[j + 6];
+            a3 += v[7] * xs[j + 7];
         }
         for (; j < w; ++j) a0 += Pi[(int64_t)j * h] * xs[j];
         R[i] -= (a0 + a1) + (a2 + a3);
@@ -874,9 +901,15 @@ __global__ __launch_bounds__(256) void sp_fwd_rem_kernel(SpDev d, const int* __r
         __syncthreads();
         const double* __restrict__ Pc = P + (int64_t)c0 * h;
         int j = wave;
-        for (; j + 4 < wc; j += 8) {                    // two loads in flight per thread
-            a0 += Pc[(int64_t)j * h] * xs[j];
-            a1 += Pc[(int64_t)(j + 4) * h] * xs[j + 4];
+        for (; j + 28 < wc; j += 32) {                  // eight loads in flight per thread (two were: the kernel is latency-bound)
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = Pc[(int64_t)(j + 4 * q) * h];
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                a0 += v[q] * xs[j + 4 * q];
+                a1 += v[q + 1] * xs[j + 4 * q + 4];
+            }
         }
         for (; j < wc; j += 4) a0 += Pc[(int64_t)j * h] * xs[j];
     }
@@ -885,33 +918,46 @@ __global__ __launch_bounds__(256) void sp_fwd_rem_kernel(SpDev d, const int* __r
     if (wave == 0 && i < hu) rem[rem_off[s] + i] -= (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-// children contributions of a wide supernode (w > SP_WIDE), straight in global memory: x_s += updates into its columns,
-// R_s = updates below them; one workgroup per right-hand side, children one after the other (deterministic, no atomics)
-__global__ __launch_bounds__(256) void sp_fwd_wide_gather_kernel(SpDev d, const int* __restrict__ wide, double* __restrict__ x,
-                                                                 double* __restrict__ rem, const int64_t* __restrict__ rem_off,
-                                                                 int64_t xstride, int64_t remstride) {
-    x += (int64_t)blockIdx.y * xstride;
-    rem += (int64_t)blockIdx.y * remstride;
-    const int s = wide[blockIdx.x];                     // the wide supernodes of a level, one workgroup each
-    const int tid = threadIdx.x;
+// children contributions of a wide supernode (w > SP_WIDE): x_s += updates into its columns, R_s = updates below them.
+// Round 4: grid (64-position blocks of the front, wide supernodes of the level, right-hand sides), one wave per block.  The
+// share of a child that lands in a block is a contiguous range of its rows (the extend-add boundary tables of the big fronts:
+// every wide supernode is one); the wave spreads it over the block's 64 positions through LDS and every lane keeps the sum of
+// ITS position in a register, children one after the other -- deterministic, no atomics, one global write per position.
+// (One workgroup per supernode walking whole children was 15-50 us per level: two dependent loads per entry, 256 threads.)
+__global__ __launch_bounds__(64) void sp_fwd_wide_gather_kernel(SpDev d, const int* __restrict__ wide, double* __restrict__ x,
+                                                                double* __restrict__ rem, const int64_t* __restrict__ rem_off,
+                                                                int64_t xstride, int64_t remstride) {
+    __shared__ double val[64];
+    x += (int64_t)blockIdx.z * xstride;
+    rem += (int64_t)blockIdx.z * remstride;
+    const int s = wide[blockIdx.y];
+    const int lane = threadIdx.x;
     const int f = d.sn_first[s];
     const int w = d.sn_first[s + 1] - f;
-    const int hu = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]) - w;
-    double* __restrict__ R = rem + rem_off[s];
-    for (int i = tid; i < hu; i += 256) R[i] = 0.0;
-    __syncthreads();
+    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
+    const int p0 = blockIdx.x * 64;
+    if (p0 >= h) return;
+    const int p = p0 + lane;
+    const int nbt = (h + 63) / 64;
+    double acc = 0.0;
     for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
         const int c = d.child_list[ci];
         const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
+        if (hc <= 0) continue;
+        const int* __restrict__ lb = d.ea_lb + d.ea_off[c];
+        const int ia = lb[blockIdx.x], ib = lb[min((int)blockIdx.x + 1, nbt)];
+        if (ib <= ia) continue;                              // (wave-uniform)
         const double* __restrict__ Rc = rem + rem_off[c];
         const int* __restrict__ rm = d.relmap + d.relmap_off[c];
-        for (int i = tid; i < hc; i += 256) {
-            const int p = rm[i];
-            if (p < w) x[f + p] += Rc[i];
-            else R[p - w] += Rc[i];
-        }
+        val[lane] = 0.0;
+        __syncthreads();
+        if (ia + lane < ib) val[rm[ia + lane] - p0] = Rc[ia + lane];    // at most 64 rows land in 64 positions
+        __syncthreads();
+        acc += val[lane];
         __syncthreads();
     }
+    if (p < w) x[f + p] += acc;
+    else if (p < h) rem[rem_off[s] + p - w] = acc;
 }
 
 // y_j -= sum_{i >= w} L[i][j] x[rows[i]] for `ncol` columns starting at j0: one wave per column, lanes along the
@@ -919,34 +965,100 @@ __global__ __launch_bounds__(256) void sp_fwd_wide_gather_kernel(SpDev d, const 
 __device__ __forceinline__ void sp_bwd_cols(const double* __restrict__ P, const int* __restrict__ rows, int h, int w,
                                             const double* __restrict__ x, int j0, int j1, double* out, int out_off) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = j0 + wave; j < j1; j += 4) {
+    // round 4: a wave takes FOUR consecutive columns at a time -- x[rows[i]] is gathered once for the four (the gather is the long
+    // dependent load), eight column loads are in flight per lane -- instead of one column with four chunks of it
+    for (int j = j0 + 4 * wave; j < j1; j += 16) {
+        const int nc = min(4, j1 - j);
         const double* __restrict__ col = P + (int64_t)j * h;
-        double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0}, bcc[4] = {0.0, 0.0, 0.0, 0.0};
         int i = w + lane;
-        for (; i + 192 < h; i += 256) {
-            acc += col[i] * x[rows[i]];
-            acc1 += col[i + 64] * x[rows[i + 64]];
-            acc2 += col[i + 128] * x[rows[i + 128]];
-            acc3 += col[i + 192] * x[rows[i + 192]];
-        }
-        for (; i < h; i += 64) acc += col[i] * x[rows[i]];
-        acc = (acc + acc1) + (acc2 + acc3);
+        if (nc == 4) {
+            for (; i + 64 < h; i += 128) {
+                const double xa = x[rows[i]], xb = x[rows[i + 64]];
+                double va[4], vb[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (lane == 0) out[j - out_off] -= acc;
+                for (int c = 0; c < 4; ++c) { va[c] = col[i + (int64_t)c * h]; vb[c] = col[i + 64 + (int64_t)c * h]; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { acc[c] += va[c] * xa; bcc[c] += vb[c] * xb; }
+            }
+            for (; i < h; i += 64) {
+                const double xa = x[rows[i]];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += col[i + (int64_t)c * h] * xa;
+            }
+        } else {
+            for (; i < h; i += 64) {
+                const double xa = x[rows[i]];
+                for (int c = 0; c < nc; ++c) acc[c] += col[i + (int64_t)c * h] * xa;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += bcc[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+        }
+        if (lane == 0)
+            for (int c = 0; c < nc; ++c) out[j + c - out_off] -= acc[c];
     }
 }
 
-// heavy supernodes of a level, before sp_bwd_kernel: grid (groups of 16 columns, heavy supernodes)
+// heavy supernodes of a level, before sp_bwd_kernel: y_j -= sum_{i >= w} L[i][j] x[rows[i]].  Grid (groups of FOUR columns, heavy
+// supernodes); the four waves of a workgroup split the rows (64-row chunks, wave = chunk mod 4; two chunks in flight per wave,
+// x[rows[i]] gathered once for the four columns) and their partial sums are added in wave order: deterministic.  (Round 4: 16
+// columns per workgroup with one wave per 4 columns walking ALL rows left the device at ~1.4 waves per SIMD, latency-bound.)
 __global__ __launch_bounds__(256) void sp_bwd_gemv_kernel(SpDev d, const int* __restrict__ heavy,
                                                           const double* __restrict__ panels, double* __restrict__ x) {
+    __shared__ double red[4][4];
     const int s = heavy[blockIdx.y];
     const int f = d.sn_first[s];
     const int w = d.sn_first[s + 1] - f;
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
-    const int j0 = blockIdx.x * 16;
+    const int j0 = blockIdx.x * 4;
     if (j0 >= w) return;
-    sp_bwd_cols(panels + d.panel_off[s], d.sn_rows + d.sn_rowptr[s], h, w, x, j0, min(j0 + 16, w), x + f, 0);
+    const int nc = min(4, w - j0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* __restrict__ col = panels + d.panel_off[s] + (int64_t)j0 * h;
+    const int* __restrict__ rows = d.sn_rows + d.sn_rowptr[s];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0}, bcc[4] = {0.0, 0.0, 0.0, 0.0};
+    int i = w + 64 * wave + lane;
+    if (nc == 4) {
+        for (; i + 256 < h; i += 512) {
+            const double xa = x[rows[i]], xb = x[rows[i + 256]];
+            double va[4], vb[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { va[c] = col[i + (int64_t)c * h]; vb[c] = col[i + 256 + (int64_t)c * h]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { acc[c] += va[c] * xa; bcc[c] += vb[c] * xb; }
+        }
+        for (; i < h; i += 256) {
+            const double xa = x[rows[i]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] += col[i + (int64_t)c * h] * xa;
+        }
+    } else {
+        for (; i < h; i += 256) {
+            const double xa = x[rows[i]];
+            for (int c = 0; c < nc; ++c) acc[c] += col[i + (int64_t)c * h] * xa;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] += bcc[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += __shfl_xor(acc[c], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) red[wave][c] = acc[c];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nc) {
+        const int c = threadIdx.x;
+        x[f + j0 + c] -= (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
 }
 
 // backward substitution (root level first):  x_s = L11^-T (y_s - L21' x[rows below])
@@ -1272,8 +1384,10 @@ static int sp_wide_forward(SparseEngine& E, const SpDev& d, int l, double* x, do
     const SparseSymbolic& S = E.sym;
     const int k0 = S.wide_ptr[l], nw = S.wide_ptr[l + 1] - k0;
     if (nw == 0) return 0;
-    hipLaunchKernelGGL(sp_fwd_wide_gather_kernel, dim3(nw, nrhs), dim3(256), 0, st, d, E.d_wide + k0, x, rem, E.d_rem_off, xstride,
-                       remstride);
+    int maxh = 0;
+    for (int k = k0; k < k0 + nw; ++k) maxh = std::max(maxh, (int)(S.sn_rowptr[S.wide[k] + 1] - S.sn_rowptr[S.wide[k]]));
+    hipLaunchKernelGGL(sp_fwd_wide_gather_kernel, dim3((maxh + 63) / 64, nw, nrhs), dim3(64), 0, st, d, E.d_wide + k0, x, rem,
+                       E.d_rem_off, xstride, remstride);
     if (nrhs == 1 && E.t_gran && nw == 1 && l == E.dense_root_level)       // the dense root: inverses from the tile Cholesky
         return sp_root_solve(E, S.wide[k0], x, 0, st);
     if (nrhs == 1 && x == E.d_xp && E.t_gran && E.t_njobs_max > 0) {      // the level's systems, up to t_njobs_max per launch
@@ -1436,7 +1550,7 @@ int sparse_engine_backward(SparseEngine& E, double* d_out, hipStream_t st) {
         const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
         const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
         if (nh > 0)
-            hipLaunchKernelGGL(sp_bwd_gemv_kernel, dim3((S.heavy_maxw[l] + 15) / 16, nh), dim3(256), 0, st, d,
+            hipLaunchKernelGGL(sp_bwd_gemv_kernel, dim3((S.heavy_maxw[l] + 3) / 4, nh), dim3(256), 0, st, d,
                                E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp);
         if (cnt > 0) hipLaunchKernelGGL(sp_bwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp);
         if (int e = sp_wide_backward(E, l, E.d_xp, st)) return e;
