@@ -239,6 +239,9 @@ struct SparseEngine {
     int dense_root_level = -1;                 // level whose single big front is factored by the dense tile kernel (-1: none)
     int64_t* d_ea_off = nullptr;
     int* d_ea_lb = nullptr;
+    int64_t* d_zero_off = nullptr;             // the panels as chunks (sp_zero_chunks_kernel clears them before every factorisation)
+    int* d_zero_len = nullptr;
+    int n_zero_chunks = 0;
     TrsvJob* d_wide_jobs = nullptr;            // one per wide supernode, in the order of sym.wide (x = d_xp + first column)
     int* d_wide = nullptr;                     // sym.wide on the device
     std::vector<int> wide_maxw;                // per level

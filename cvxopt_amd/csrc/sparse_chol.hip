@@ -536,6 +536,17 @@ struct SpDev {   // device copies of the symbolic structure (plain pointers for 
     int wide;                  // sp_wide_threshold()
 };
 
+// clears the panels (the h x w columns to be factored) of all supernodes: chunk c = `len[c]` doubles at store + off[c] (at most
+// SP_ZERO_CHUNK each; the list is built once, sparse_engine_create).  The update matrices need no clearing pass: the small fronts
+// clear their own (sp_front_kernel), the big fronts' are cleared tile by tile inside sp_extend_add_vb_kernel.
+constexpr int SP_ZERO_CHUNK = 32768;
+__global__ __launch_bounds__(256) void sp_zero_chunks_kernel(const int64_t* __restrict__ off, const int* __restrict__ len,
+                                                             double* __restrict__ store) {
+    double* __restrict__ p = store + off[blockIdx.x];
+    const int n = len[blockIdx.x];
+    for (int i = threadIdx.x; i < n; i += 256) p[i] = 0.0;
+}
+
 // One workgroup = one frontal matrix.  F = [ L-panel (h x w) | U (h-w x h-w) ]: the panel already holds the
 // entries of S; U starts as the extend-add of the children's update matrices.
 __global__ __launch_bounds__(256) void sp_front_kernel(SpDev d, int level_begin, double* panels, double* upd,
@@ -628,6 +639,16 @@ __global__ __launch_bounds__(256) void sp_extend_add_vb_kernel(SpDev d, const Vb
     if (c0 >= h || r0 >= h || r1 <= c0) return;            // outside the front / strictly above the diagonal
     double* __restrict__ F = store + dd.off;
     const int nbt = (h + 63) / 64;             // last entry of a child's boundary table (= its number of update rows)
+    {   // round 4: the front's Schur part (rows and columns beyond its w panel columns) starts from zero HERE, tile by tile, right
+        // before the children are added (the lines stay in the L2) -- sparse_engine_factor clears only the panels (sp_zero_chunks_kernel)
+        // instead of the whole store, whose big fronts are h x h squares with an unused upper triangle: 3.9 GB at 64^3
+        const int wp = dd.w;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int i = r0 + lane;
+        if (i < r1 && i >= wp)
+            for (int j = max(c0, wp) + wave; j < min(c0 + EA_COLS, h); j += 4) F[i + (int64_t)j * h] = 0.0;
+        __syncthreads();
+    }
     for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
         const int c = d.child_list[ci];
         const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
@@ -1242,6 +1263,22 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     if (int e = up(&E.d_rem_off, rem_off)) return e;
     KKT_HIP_CHECK(hipMalloc(&E.d_rem, sizeof(double) * (rem_off[S.ns] ? rem_off[S.ns] : 1)));
     KKT_HIP_CHECK(hipMalloc(&E.d_panels, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
+    {   // the panels as chunks of at most SP_ZERO_CHUNK doubles (sp_zero_chunks_kernel); the first factorisation's store is cleared
+        // as a whole once (nothing but the panels and the lower triangles of the update matrices is ever read, but let it be defined)
+        KKT_HIP_CHECK(memset_sync(E.d_panels, 0, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
+        std::vector<int64_t> zoff;
+        std::vector<int> zlen;
+        for (int sn = 0; sn < S.ns; ++sn) {
+            const int64_t hh = S.sn_rowptr[sn + 1] - S.sn_rowptr[sn], ww = S.sn_first[sn + 1] - S.sn_first[sn];
+            for (int64_t a = 0; a < hh * ww; a += SP_ZERO_CHUNK) {
+                zoff.push_back(S.panel_off[sn] + a);
+                zlen.push_back((int)std::min<int64_t>(SP_ZERO_CHUNK, hh * ww - a));
+            }
+        }
+        E.n_zero_chunks = (int)zoff.size();
+        if (int e = up(&E.d_zero_off, zoff)) return e;
+        if (int e = up(&E.d_zero_len, zlen)) return e;
+    }
     E.d_upd = nullptr;          // update matrices live in the same buffer (offsets are absolute)
     KKT_HIP_CHECK(hipMalloc(&E.d_xp, sizeof(double) * (n ? n : 1)));
     {   // the wide supernodes as jobs of the batched persistent triangular solve (single right-hand side: x = d_xp)
@@ -1271,7 +1308,7 @@ void sparse_engine_free(SparseEngine& E) {
                     E.d_relmap_off, E.d_relmap, E.d_level_sn, E.d_upd_ld, E.d_asm_slot, E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r,
                     E.d_perm, E.d_gv, E.d_hv, E.d_gcp, E.d_gri, E.d_grp, E.d_gci, E.d_gnzmap, E.d_rem_off, E.d_rem,
                     E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap, E.d_rem_multi, E.d_iperm,
-                    E.d_tv_tickets, E.d_tv_prog_off, E.d_tv_linv_off, E.d_tv_state, E.d_tv_linv, E.d_wide_jobs, E.d_wide, E.d_ea_off, E.d_ea_lb};
+                    E.d_tv_tickets, E.d_tv_prog_off, E.d_tv_linv_off, E.d_tv_state, E.d_tv_linv, E.d_wide_jobs, E.d_wide, E.d_ea_off, E.d_ea_lb, E.d_zero_off, E.d_zero_len};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
@@ -1303,7 +1340,10 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
     const SparseSymbolic& S = E.sym;
     if (E.n == 0) { if (info) *info = 0; return 0; }
     E.dense_root_level = -1;
-    KKT_HIP_CHECK(hipMemsetAsync(E.d_panels, 0, sizeof(double) * (S.store_doubles ? S.store_doubles : 1), st));
+    if (dev_knob("MI355KKT_SPARSE_POISON"))      // test knob: every byte of the store that is not cleared on purpose reads as NaN
+        KKT_HIP_CHECK(hipMemsetAsync(E.d_panels, 0xff, sizeof(double) * (S.store_doubles ? S.store_doubles : 1), st));
+    if (E.n_zero_chunks > 0)
+        hipLaunchKernelGGL(sp_zero_chunks_kernel, dim3(E.n_zero_chunks), dim3(256), 0, st, E.d_zero_off, E.d_zero_len, E.d_panels);
     static const int imax = 0x7fffffff;      // (static: the asynchronous copy below must not read a dead stack slot on an early error return)
     KKT_HIP_CHECK(hipMemcpyAsync(E.d_info, &imax, sizeof(int), hipMemcpyHostToDevice, st));
     const int64_t nt = (int64_t)S.asm_slot.size();
@@ -1350,10 +1390,12 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
         hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3(((unsigned)S.vb.size() + 255) / 256), dim3(256), 0, st,
                            reinterpret_cast<const int*>(E.d_tv_state + E.tv_info_at), (int)S.vb.size(), E.d_info);
     // the transposed persistent solve of the wide supernodes streams L11' from the (unused) upper triangle of the front
-    if (!S.wide.empty()) {
-        int wmax = 0;
-        for (int w : E.wide_maxw) wmax = std::max(wmax, w);
-        if (int e = launch_mirror_lower_jobs(E.d_wide_jobs, (int)S.wide.size(), wmax, st)) return e;
+    // (one launch per level, its grid sized for THAT level's widest supernode: one launch for all of them sized for the root was
+    //  4.1 M workgroups at 64^3, nearly all of them empty -- 0.4 ms of dispatch per factorisation)
+    for (int l = 0; l < S.nlevels; ++l) {
+        const int k0 = S.wide_ptr[l], nw = S.wide_ptr[l + 1] - k0;
+        if (nw > 0)
+            if (int e = launch_mirror_lower_jobs(E.d_wide_jobs + k0, nw, E.wide_maxw[l], st)) return e;
     }
     KKT_HIP_CHECK(hipGetLastError());
     KKT_HIP_CHECK(hipMemcpyAsync(E.h_info, E.d_info, sizeof(int), hipMemcpyDeviceToHost, st));

@@ -75,6 +75,40 @@ def test_sparse_factor_solve_matches_dense_oracle(maker, arg):
     f.engine.close()
 
 
+@pytest.mark.parametrize("maker,arg", [(laplace3d, (20,)), (laplace2d, (150, 120))])
+def test_sparse_factor_reads_nothing_it_has_not_written(maker, arg, knobs):
+    """round 4: a factorisation clears the supernodes' panels and, tile by tile, the update matrices of the big fronts -- not the
+    whole store.  With the store poisoned (every byte 0xff = NaN, test knob MI355KKT_SPARSE_POISON) before each factorisation the
+    solutions must be bit for bit those of the unpoisoned run: nothing outside the cleared regions is ever read."""
+    P = maker(*arg)
+    n = P.shape[0]
+    G = box(n)
+    dims = {'l': 2 * n, 'q': [], 's': []}
+    A = np.zeros((0, n))
+    rng = np.random.default_rng(n)
+    bx, bz = rng.standard_normal(n), rng.standard_normal(2 * n)
+    out = []
+    for poison in (False, True, True):
+        if poison:
+            knobs.setenv("MI355KKT_SPARSE_POISON", "1")
+        f = kkt.kkt_chol2(FakeSp(G), dims, A)
+        sols = []
+        for it in range(2):                       # the second factorisation runs over the first one's left-overs
+            W = synth.random_scaling(dims, seed=it, spread=1.5)
+            x, y, z = bx.copy(), np.zeros(0), bz.copy()
+            f(W, FakeSp(sp.tril(P)))(x, y, z)
+            assert np.all(np.isfinite(x)) and np.all(np.isfinite(z))
+            sols.append((x, z))
+        S = (P + G.T @ sp.diags(W['di'] ** 2) @ G).tocsc()
+        rhs = bx + G.T @ (W['di'] ** 2 * bz)
+        assert np.linalg.norm(S @ sols[-1][0] - rhs) / np.linalg.norm(rhs) < 1e-11
+        out.append(sols)
+        f.engine.close()
+    for a, b in ((out[0], out[1]), (out[1], out[2])):
+        for (xa, za), (xb, zb) in zip(a, b):
+            assert np.array_equal(xa, xb) and np.array_equal(za, zb)
+
+
 def test_sparse_general_G_pattern_and_dense_engine_agree():
     """G with off-diagonal couplings (S gets fill from G'D^2G) -- sparse engine vs the dense device engine."""
     rng = np.random.default_rng(3)
