@@ -239,6 +239,7 @@ struct SparseEngine {
     int dense_root_level = -1;                 // level whose single big front is factored by the dense tile kernel (-1: none)
     int64_t* d_ea_off = nullptr;
     int* d_ea_lb = nullptr;
+    std::vector<int> lvl_small;                // per level: supernodes that take the one-wave kernels (sp_fwd_small_kernel)
     int64_t* d_zero_off = nullptr;             // the panels as chunks (sp_zero_chunks_kernel clears them before every factorisation)
     int* d_zero_len = nullptr;
     int n_zero_chunks = 0;

@@ -822,6 +822,165 @@ __device__ __forceinline__ void sp_trsv_bwd_lds(const double* __restrict__ P, in
     }
 }
 
+// ---- small supernodes (round 4): ONE WAVE per supernode, four per workgroup, no workgroup barrier ---------------------------------
+// At 64^3 the lowest four levels hold 33 000 of the 37 000 supernodes, none wider than 22 columns or taller than 144 rows (level 0:
+// 20 893 supernodes of 1.7 columns on average): a 256-thread workgroup with two barriers per 32 columns for each of them is
+// latency and occupancy, not work (level 0: 82 us forward, 104 us backward).  Supernodes with w <= SP_SMALL_W columns and
+// hu <= SP_SMALL_HU rows below the diagonal block take these kernels -- vector and remainder in the wave's slice of LDS, cross-lane
+// traffic through LDS / readlane, children one after the other (deterministic) -- the others sp_fwd_kernel / sp_bwd_kernel, which
+// skip what is small.
+constexpr int SP_SMALL_W = 32, SP_SMALL_HU = 192;
+__device__ __forceinline__ bool sp_is_small(int w, int hu) { return w <= SP_SMALL_W && hu <= SP_SMALL_HU; }
+
+// one wave: the whole forward step of the small supernode s (f, w, h, hu: its first column, width, height, rows below);
+// `xs`: SP_SMALL_W + SP_SMALL_HU doubles of LDS owned by this wave
+__device__ __forceinline__ void sp_fwd_small_body(const SpDev& d, int s, int f, int w, int h, int hu, int lane,
+                                                  const double* __restrict__ panels, double* __restrict__ x,
+                                                  double* __restrict__ rem, const int64_t* __restrict__ rem_off, double* xs) {
+    double* R = xs + SP_SMALL_W;
+    const double* __restrict__ P = panels + d.panel_off[s];
+    // operands of the diagonal block first (independent of the children): lane = row r of L11
+    const int r = min(lane, w - 1);
+    double Lr[SP_SMALL_W];
+#pragma unroll
+    for (int c = 0; c < SP_SMALL_W; ++c) Lr[c] = (c < w) ? P[r + (int64_t)c * h] : 0.0;
+    const double dinv = 1.0 / P[r + (int64_t)r * h];
+    if (lane < w) xs[lane] = x[f + lane];
+    for (int i = lane; i < hu; i += 64) R[i] = 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int ci = d.child_ptr[s]; ci < d.child_ptr[s + 1]; ++ci) {
+        const int c = d.child_list[ci];
+        const int hc = (int)(d.sn_rowptr[c + 1] - d.sn_rowptr[c]) - (d.sn_first[c + 1] - d.sn_first[c]);
+        const double* __restrict__ Rc = rem + rem_off[c];
+        const int* __restrict__ rm = d.relmap + d.relmap_off[c];
+        for (int i = lane; i < hc; i += 64) {            // a child's rows land on distinct positions: plain read-modify-writes
+            const int p = rm[i];
+            double* dst = (p < w) ? xs + p : R + (p - w);
+            *dst += Rc[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    double xi = (lane < w) ? xs[lane] : 0.0;
+#pragma unroll
+    for (int c = 0; c < SP_SMALL_W; ++c) {
+        if (c < w) {                                     // wave-uniform
+            const double v = sp_bcast(xi * dinv, c);
+            if (lane == c) xi = v;
+            if (lane > c) xi = fma(-Lr[c], v, xi);
+        }
+    }
+    if (lane < w) {
+        xs[lane] = xi;
+        x[f + lane] = xi;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double* __restrict__ Rg = rem + rem_off[s];
+    for (int i = lane; i < hu; i += 64) {
+        const double* __restrict__ Pi = P + w + i;
+        double a0 = 0.0, a1 = 0.0;
+        int j = 0;
+        for (; j + 8 <= w; j += 8) {                     // eight loads in flight
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = Pi[(int64_t)(j + q) * h];
+#pragma unroll
+            for (int q = 0; q < 8; q += 2) {
+                a0 += v[q] * xs[j + q];
+                a1 += v[q + 1] * xs[j + q + 1];
+            }
+        }
+        for (; j + 2 <= w; j += 2) {
+            a0 += Pi[(int64_t)j * h] * xs[j];
+            a1 += Pi[(int64_t)(j + 1) * h] * xs[j + 1];
+        }
+        if (j < w) a0 += Pi[(int64_t)j * h] * xs[j];
+        Rg[i] = R[i] - (a0 + a1);
+    }
+}
+
+__global__ __launch_bounds__(256) void sp_fwd_small_kernel(SpDev d, int level_begin, int count, const double* __restrict__ panels,
+                                                           double* __restrict__ x, double* __restrict__ rem,
+                                                           const int64_t* __restrict__ rem_off, int64_t xstride, int64_t remstride) {
+    __shared__ double lds[4][SP_SMALL_W + SP_SMALL_HU];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= count) return;
+    x += (int64_t)blockIdx.y * xstride;
+    rem += (int64_t)blockIdx.y * remstride;
+    const int s = d.level_sn[level_begin + k];
+    const int f = d.sn_first[s];
+    const int w = d.sn_first[s + 1] - f;
+    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
+    sp_fwd_small_body(d, s, f, w, h, h - w, lane, panels, x, rem, rem_off, lds[wave]);
+}
+
+__device__ __forceinline__ void sp_bwd_small_body(const SpDev& d, int s, int f, int w, int h, int hu, int lane,
+                                                  const double* __restrict__ panels, double* __restrict__ x) {
+    const double* __restrict__ P = panels + d.panel_off[s];
+    const int* __restrict__ rows = d.sn_rows + d.sn_rowptr[s] + w;
+    // lane = column c of L11 for the transposed solve: Lc[k] = L[k][c]
+    const int c = min(lane, w - 1);
+    double Lc[SP_SMALL_W];
+#pragma unroll
+    for (int q = 0; q < SP_SMALL_W; ++q) Lc[q] = (q < w) ? P[q + (int64_t)c * h] : 0.0;
+    const double dinv = 1.0 / P[c + (int64_t)c * h];
+    double xi = (lane < w) ? x[f + lane] : 0.0;
+    // y_j -= sum_i L21[i][j] x[rows[i]]: lanes along the (at most three chunks of) rows, one wave reduction per column
+    const double xr0 = (lane < hu) ? x[rows[lane]] : 0.0;
+    const double xr1 = (lane + 64 < hu) ? x[rows[lane + 64]] : 0.0;
+    const double xr2 = (lane + 128 < hu) ? x[rows[lane + 128]] : 0.0;
+    const double* __restrict__ P21 = P + w;
+    const bool in0 = lane < hu, in1 = lane + 64 < hu, in2 = lane + 128 < hu;
+    int j = 0;
+    for (; j + 4 <= w; j += 4) {                         // four columns at a time: twelve loads, four reductions in flight
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double* __restrict__ col = P21 + (int64_t)(j + q) * h;
+            const double c0 = in0 ? col[lane] : 0.0, c1 = in1 ? col[lane + 64] : 0.0, c2 = in2 ? col[lane + 128] : 0.0;
+            v[q] = fma(c2, xr2, fma(c1, xr1, c0 * xr0));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] += __shfl_xor(v[q], o, 64);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (lane == j + q) xi -= v[q];
+    }
+    for (; j < w; ++j) {
+        const double* __restrict__ col = P21 + (int64_t)j * h;
+        double v = in0 ? col[lane] * xr0 : 0.0;
+        if (in1) v = fma(col[lane + 64], xr1, v);
+        if (in2) v = fma(col[lane + 128], xr2, v);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == j) xi -= v;
+    }
+#pragma unroll
+    for (int q = SP_SMALL_W - 1; q >= 0; --q) {
+        if (q < w) {                                     // wave-uniform
+            const double v = sp_bcast(xi * dinv, q);
+            if (lane == q) xi = v;
+            if (lane < q) xi = fma(-Lc[q], v, xi);
+        }
+    }
+    if (lane < w) x[f + lane] = xi;
+}
+
+__global__ __launch_bounds__(256) void sp_bwd_small_kernel(SpDev d, int level_begin, int count, const double* __restrict__ panels,
+                                                           double* __restrict__ x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= count) return;
+    const int s = d.level_sn[level_begin + k];
+    const int f = d.sn_first[s];
+    const int w = d.sn_first[s + 1] - f;
+    const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
+    sp_bwd_small_body(d, s, f, w, h, h - w, lane, panels, x);
+}
+
 // forward substitution, one workgroup per supernode of a level:  y_s = L11^-1 (b_s + children updates),
 // then the front's right-hand-side remainder r_s = (children updates below) - L21 y_s is left for the parent
 // (by sp_fwd_rem_kernel, many workgroups, when the panel is large).
@@ -839,6 +998,10 @@ __global__ __launch_bounds__(256) void sp_fwd_kernel(SpDev d, int level_begin, c
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
     const int hu = h - w;
     if (w > d.wide) return;                             // sp_fwd_wide_gather_kernel + launch_trsv_persistent + sp_fwd_rem_kernel
+    if (sp_is_small(w, hu)) {                           // (a mixed level: the one-wave path on wave 0, the other waves leave)
+        if (tid < 64) sp_fwd_small_body(d, s, f, w, h, hu, tid, panels, x, rem, rem_off, xs);
+        return;
+    }
     const double* __restrict__ P = panels + d.panel_off[s];
     double* __restrict__ R = rem + rem_off[s];          // hu entries
     for (int i = tid; i < hu; i += 256) R[i] = 0.0;
@@ -1093,6 +1256,10 @@ __global__ __launch_bounds__(256) void sp_bwd_kernel(SpDev d, int level_begin, c
     const int h = (int)(d.sn_rowptr[s + 1] - d.sn_rowptr[s]);
     const double* __restrict__ P = panels + d.panel_off[s];
     if (w > d.wide) return;                             // sp_bwd_gemv_kernel + launch_trsv_persistent (transposed)
+    if (sp_is_small(w, h - w)) {                        // (a mixed level: the one-wave path on wave 0)
+        if (tid < 64) sp_bwd_small_body(d, s, f, w, h, h - w, tid, panels, x);
+        return;
+    }
     if (tid < w) xs[tid] = x[f + tid];
     __syncthreads();
     if ((int64_t)(h - w) * w <= SP_HEAVY && h > w) {
@@ -1288,6 +1455,14 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
             jobs[k] = TrsvJob{E.d_panels + S.panel_off[s], S.sn_rowptr[s + 1] - S.sn_rowptr[s], S.sn_first[s + 1] - S.sn_first[s], 0,
                               E.d_xp + S.sn_first[s]};
         }
+        E.lvl_small.assign(S.nlevels, 0);
+        for (int l = 0; l < S.nlevels; ++l)
+            for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
+                const int sn = S.level_sn[k];
+                const int ww = S.sn_first[sn + 1] - S.sn_first[sn];
+                const int hu = (int)(S.sn_rowptr[sn + 1] - S.sn_rowptr[sn]) - ww;
+                if (ww <= SP_SMALL_W && hu <= SP_SMALL_HU) E.lvl_small[l]++;
+            }
         E.wide_maxw.assign(S.nlevels, 0);
         for (int l = 0; l < S.nlevels; ++l)
             for (int k = S.wide_ptr[l]; k < S.wide_ptr[l + 1]; ++k)
@@ -1474,6 +1649,29 @@ static int sp_wide_backward(SparseEngine& E, int l, double* x, hipStream_t st) {
     return 0;
 }
 
+// the level kernels of the supernodes that are not wide (E.lvl_small[l] = number of small supernodes of level l)
+static void sp_launch_fwd_level(SparseEngine& E, const SpDev& d, int l, double* x, double* rem, int64_t xstride, int64_t remstride,
+                                int nj, hipStream_t st) {
+    const SparseSymbolic& S = E.sym;
+    const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
+    if (cnt <= 0) return;
+    if (E.lvl_small[l] == cnt)                   // small supernodes only: four per workgroup
+        hipLaunchKernelGGL(sp_fwd_small_kernel, dim3((cnt + 3) / 4, nj), dim3(256), 0, st, d, S.level_ptr[l], cnt, E.d_panels, x, rem,
+                           E.d_rem_off, xstride, remstride);
+    else                                         // (its small supernodes run the same one-wave body on one wave of their workgroup)
+        hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt, nj), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, x, rem, E.d_rem_off, xstride,
+                           remstride);
+}
+static void sp_launch_bwd_level(SparseEngine& E, const SpDev& d, int l, double* x, hipStream_t st) {
+    const SparseSymbolic& S = E.sym;
+    const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
+    if (cnt <= 0) return;
+    if (E.lvl_small[l] == cnt)
+        hipLaunchKernelGGL(sp_bwd_small_kernel, dim3((cnt + 3) / 4), dim3(256), 0, st, d, S.level_ptr[l], cnt, E.d_panels, x);
+    else
+        hipLaunchKernelGGL(sp_bwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, x);
+}
+
 // forward half: E.d_xp := L^-1 P b (b = d_in, original ordering); optionally copied to d_out_perm (permuted ordering)
 int sparse_engine_forward(SparseEngine& E, const double* d_in, double* d_out_perm, hipStream_t st) {
     const SparseSymbolic& S = E.sym;
@@ -1482,10 +1680,7 @@ int sparse_engine_forward(SparseEngine& E, const double* d_in, double* d_out_per
     const dim3 g((E.n + 255) / 256);
     hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, d_in, E.d_xp, E.d_perm, E.n, 1);
     for (int l = 0; l < S.nlevels; ++l) {
-        const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
-        if (cnt > 0)
-            hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp, E.d_rem,
-                               E.d_rem_off, (int64_t)0, (int64_t)0);
+        sp_launch_fwd_level(E, d, l, E.d_xp, E.d_rem, 0, 0, 1, st);
         if (int e = sp_wide_forward(E, d, l, E.d_xp, E.d_rem, 0, 0, 1, st)) return e;
         const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
         if (nh > 0)
@@ -1519,10 +1714,7 @@ int sparse_engine_forward_rows(SparseEngine& E, const double* d_A, int64_t lda, 
         double* out = d_out + (size_t)j0 * E.n;
         hipLaunchKernelGGL(sp_gather_rows_kernel, dim3((E.n + 255) / 256, nj), dim3(256), 0, st, d_A + j0, lda, E.d_perm, E.n, out);
         for (int l = 0; l < S.nlevels; ++l) {
-            const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
-            if (cnt > 0)
-                hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt, nj), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, out, E.d_rem_multi,
-                                   E.d_rem_off, (int64_t)E.n, remtot);
+            sp_launch_fwd_level(E, d, l, out, E.d_rem_multi, (int64_t)E.n, remtot, nj, st);
             if (int e = sp_wide_forward(E, d, l, out, E.d_rem_multi, (int64_t)E.n, remtot, nj, st)) return e;
             const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
             if (nh > 0)
@@ -1568,10 +1760,7 @@ int sparse_engine_forward_rows_csr(SparseEngine& E, const int64_t* d_rp, const i
         double* out = d_out + (size_t)j0 * E.n;
         hipLaunchKernelGGL(sp_scatter_rows_csr_kernel, dim3(nj), dim3(256), 0, st, d_rp, d_ci, d_v, j0, E.d_iperm, E.n, out);
         for (int l = 0; l < S.nlevels; ++l) {
-            const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
-            if (cnt > 0)
-                hipLaunchKernelGGL(sp_fwd_kernel, dim3(cnt, nj), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, out, E.d_rem_multi,
-                                   E.d_rem_off, (int64_t)E.n, remtot);
+            sp_launch_fwd_level(E, d, l, out, E.d_rem_multi, (int64_t)E.n, remtot, nj, st);
             if (int e = sp_wide_forward(E, d, l, out, E.d_rem_multi, (int64_t)E.n, remtot, nj, st)) return e;
             const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
             if (nh > 0)
@@ -1589,12 +1778,11 @@ int sparse_engine_backward(SparseEngine& E, double* d_out, hipStream_t st) {
     const SpDev d = devview(E);
     const dim3 g((E.n + 255) / 256);
     for (int l = S.nlevels - 1; l >= 0; --l) {
-        const int cnt = S.level_ptr[l + 1] - S.level_ptr[l];
         const int nh = S.heavy_ptr[l + 1] - S.heavy_ptr[l];
         if (nh > 0)
             hipLaunchKernelGGL(sp_bwd_gemv_kernel, dim3((S.heavy_maxw[l] + 3) / 4, nh), dim3(256), 0, st, d,
                                E.d_heavy + S.heavy_ptr[l], E.d_panels, E.d_xp);
-        if (cnt > 0) hipLaunchKernelGGL(sp_bwd_kernel, dim3(cnt), dim3(256), 0, st, d, S.level_ptr[l], E.d_panels, E.d_xp);
+        sp_launch_bwd_level(E, d, l, E.d_xp, st);
         if (int e = sp_wide_backward(E, l, E.d_xp, st)) return e;
     }
     hipLaunchKernelGGL(sp_permute_kernel, g, dim3(256), 0, st, E.d_xp, d_out, E.d_perm, E.n, 0);
