@@ -942,9 +942,10 @@ def main():
         traffic, traffic_src = None, None
         try:
             import hashlib
-            hsh = hashlib.sha256()
-            for f in ("cvxopt_amd/csrc/gemm_f64.hip", "cvxopt_amd/csrc/kkt_common.h"):
-                hsh.update(open(os.path.join(ROOT, f), "rb").read())
+            hsh = hashlib.sha256()                     # (the same definition as tools/rocpd_summary.py: source_id)
+            hsh.update(open(os.path.join(ROOT, "cvxopt_amd/csrc/gemm_f64.hip"), "rb").read())
+            txt = open(os.path.join(ROOT, "cvxopt_amd/csrc/kkt_common.h")).read()
+            hsh.update(txt[txt.index("// ---- tile geometry of the FP64 MFMA kernels"):txt.index("// ---- dense Cholesky")].encode())
             src_id = hsh.hexdigest()[:16]
         except Exception:
             src_id = None

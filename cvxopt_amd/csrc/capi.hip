@@ -855,6 +855,10 @@ int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH)
     if (int e = bind(h)) return e;
     if (ldH < (h->n > 1 ? h->n : 1)) { set_last_error("set_H_dense_async: ldH too small"); return MI355KKT_EINVAL; }
     const size_t bytes = sizeof(double) * ((size_t)ldH * (h->n - 1) + h->n);
+    // A small H is uploaded synchronously: pinning it in place would lock whole pages of the caller's heap (a 10 x 10 matrix
+    // shares its page with unrelated allocations, the caller's and the runtime's) for an overlap that only matters when the copy
+    // takes as long as a kernel -- the headline's H is 512 MB.
+    if (bytes < ((size_t)4 << 20)) return mi355kkt_set_H_dense(h, H, ldH);      // (waits for a pending upload, unpins)
     if (h->reg_ptr != (const void*)H || h->reg_bytes != bytes) {
         h_unregister(h);
         if (hipHostRegister(const_cast<double*>(H), bytes, hipHostRegisterDefault) != hipSuccess) {

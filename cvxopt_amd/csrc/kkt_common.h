@@ -44,6 +44,21 @@ inline hipError_t memset_sync(void* p, int value, size_t bytes) {
     return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
 }
 
+// ---- device allocations start from zero --------------------------------------------------------------
+// Every hipMalloc of this library goes through malloc_zeroed (the macro below): allocate, clear, wait.  A fresh process gets
+// zero pages from the driver anyway; a long-lived one gets whatever an earlier handle left in the recycled block -- the state
+// of a handle must not depend on which of the two it is.  (Round 4: the whole GPU test-suite in ONE process -- ~2000 handles
+// created and destroyed before it -- aborted in / hung near the 's'-cone book examples that pass in a process of their own,
+// DESIGN 12.)  Setup-time cost only: nothing on the factor / solve path allocates.
+inline hipError_t malloc_zeroed(void** p, size_t bytes) {
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return e;
+    return bytes ? memset_sync(*p, 0, bytes) : hipSuccess;
+}
+template <class T>
+inline hipError_t malloc_zeroed(T** p, size_t bytes) { return malloc_zeroed(reinterpret_cast<void**>(p), bytes); }
+#define hipMalloc(ptr_, bytes_) ::mi355kkt::malloc_zeroed((ptr_), (bytes_))
+
 // ---- tile geometry of the FP64 MFMA kernels -----------------------------------------------------
 constexpr int TILE = 128;      // C tile (both dims) owned by one 256-thread workgroup
 constexpr int BK = 16;         // k-depth staged per LDS buffer

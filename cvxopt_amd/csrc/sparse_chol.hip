@@ -212,7 +212,8 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         S.flops += fl;   // rough
         S.nnzL += h * w;
         S.panel_off[s] = off;
-        if (fl >= big_flops && h >= big_h) {
+        // (a wide supernode is always a big front: its solves use the extend-add boundary tables that only big fronts' children carry)
+        if ((fl >= big_flops && h >= big_h) || w > sp_wide_threshold()) {
             S.big[s] = 1;
             S.upd_off[s] = off + w + w * h;
             S.upd_ld[s] = (int)h;

@@ -54,8 +54,9 @@ def test_sparse_H_then_no_H_then_the_same_sparse_H_on_a_dense_G_factory():
 
 def test_pinned_host_H_is_released_by_the_next_set_H():
     """async dense H (pinned in place) -> H = None -> a NEW buffer of the same size: the old registration must be gone
-    (header: 'alive until the next set_H_*'), the new contents must arrive."""
-    n, m = 256, 300
+    (header: 'alive until the next set_H_*'), the new contents must arrive.  (n = 768: an H below 4 MB is uploaded synchronously
+    and never pinned.)"""
+    n, m = 768, 800
     pr = synth.dense_qp(n, m, seed=4)
     W = synth.random_scaling(pr['dims'], seed=5, spread=1.0)
     rng = np.random.default_rng(2)

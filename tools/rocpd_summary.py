@@ -38,14 +38,17 @@ def pmc_per_kernel(db, counter, substr):
     return vals
 
 
-def source_id(files=("cvxopt_amd/csrc/gemm_f64.hip", "cvxopt_amd/csrc/kkt_common.h")):
-    """sha256 over the sources that define the SYRK kernel: bench.py recomputes it and refuses a PMC file of another version"""
+def source_id():
+    """sha256 over the sources that define the SYRK kernel -- csrc/gemm_f64.hip and the tile-geometry / SYRK block of
+    csrc/kkt_common.h (from "// ---- tile geometry" to "// ---- dense Cholesky"; the rest of that header belongs to other
+    engines) -- bench.py recomputes it and refuses a PMC file of another version"""
     import hashlib
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hsh = hashlib.sha256()
-    for f in files:
-        hsh.update(open(os.path.join(root, f), "rb").read())
+    hsh.update(open(os.path.join(root, "cvxopt_amd/csrc/gemm_f64.hip"), "rb").read())
+    txt = open(os.path.join(root, "cvxopt_amd/csrc/kkt_common.h")).read()
+    hsh.update(txt[txt.index("// ---- tile geometry of the FP64 MFMA kernels"):txt.index("// ---- dense Cholesky")].encode())
     return hsh.hexdigest()[:16]
 
 
@@ -58,7 +61,8 @@ def pmc(fetch_db, write_db, substr, out, n, m):
            "FETCH_SIZE_KiB_avg": favg, "WRITE_SIZE_KiB_avg": wavg,
            "correction": "FETCH_SIZE x2 on gfx950 (guide: counts 128-B requests as 64 B); WRITE_SIZE uncalibrated, x1",
            "hbm_bytes_per_launch": 2.0 * favg * 1024.0 + wavg * 1024.0,
-           "kernel_source_id": source_id(), "kernel_source_files": ["cvxopt_amd/csrc/gemm_f64.hip", "cvxopt_amd/csrc/kkt_common.h"]}
+           "kernel_source_id": source_id(),
+           "kernel_source_files": ["cvxopt_amd/csrc/gemm_f64.hip", "cvxopt_amd/csrc/kkt_common.h (tile geometry / SYRK block)"]}
     json.dump(rec, open(out, "w"), indent=1)
     print(json.dumps(rec))
 
