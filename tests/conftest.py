@@ -74,6 +74,12 @@ def pytest_collection_modifyitems(config, items):
     # GPU tests must FAIL (not skip) on a GPU box whose library is missing; on CPU-only hosts they are
     # deselected by `-m "not gpu"`.  If someone runs them anyway without a GPU, skip with a clear reason.
     if _gpu_count() > 0:
+        # a GPU test that stops making progress must end as a FAILURE with the stacks of all threads (pytest-timeout's report),
+        # not as a session that never returns (round 4, call r4c17); 20 minutes is ten times the slowest test of the suite
+        if config.pluginmanager.hasplugin("timeout"):
+            for it in items:
+                if "gpu" in it.keywords and it.get_closest_marker("timeout") is None:
+                    it.add_marker(pytest.mark.timeout(1200, method="thread"))   # (signals do not interrupt a wait inside the HIP runtime)
         return
     skip = pytest.mark.skip(reason="no HIP device visible")
     for it in items:
