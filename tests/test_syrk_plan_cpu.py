@@ -100,3 +100,56 @@ def test_socp_shape_is_balanced_over_all_slots():
     items, nslabs, nsplit, nlaunch = plan(2048, 8192)
     assert nlaunch == 512 and nsplit == 136
     assert 512 < len(items) <= 512 + 136
+
+
+@pytest.mark.parametrize("n,K,cus", [(300, 77, 256), (640, 2048, 8), (1000, 3000, 4), (129, 16, 8), (513, 1111, 16), (2048, 512, 256)])
+def test_numpy_execution_of_the_plan_gives_the_scaled_syrk(n, K, cus):
+    """the plan executed the way the kernel executes it -- every launched workgroup walks its chain of segments, a segment adds its
+    k range of its tile to C (final items) or writes a slab, the reducer sums a split tile's slabs in slot order -- is
+    S = P + G' diag(di)^2 G on the lower triangle"""
+    rng = np.random.default_rng(n + K)
+    G = rng.standard_normal((K, n))
+    di = rng.uniform(0.5, 2.0, K)
+    P = rng.standard_normal((n, n))
+    P = P + P.T
+    items, nslabs, nsplit, nlaunch = plan(n, K, cus)
+    Gs = G * di[:, None]
+    C = np.full((n, n), np.nan)
+    slabs = {}
+    written = set()
+    for w in range(nlaunch):
+        i = w
+        while True:
+            ti, tj, k0, k1, slot, first, nparts, nxt = (int(v) for v in items[i])
+            I = slice(ti * TILE, min(n, (ti + 1) * TILE))
+            J = slice(tj * TILE, min(n, (tj + 1) * TILE))
+            part = Gs[k0:k1, I].T @ Gs[k0:k1, J]
+            if slot < 0:
+                assert (ti, tj) not in written
+                written.add((ti, tj))
+                C[I, J] = P[I, J] + part
+            else:
+                assert slot not in slabs
+                slabs[slot] = (ti, tj, first, nparts, part)
+            if nxt == 0:
+                break
+            i = nxt - 1
+    assert sorted(slabs) == list(range(nslabs))
+    for slot, (ti, tj, first, nparts, part) in sorted(slabs.items()):
+        if slot != first:
+            continue
+        I = slice(ti * TILE, min(n, (ti + 1) * TILE))
+        J = slice(tj * TILE, min(n, (tj + 1) * TILE))
+        acc = P[I, J].copy()
+        for s_ in range(first, first + nparts):                       # fixed order, as syrk_reduce_kernel
+            assert slabs[s_][:2] == (ti, tj)
+            acc = acc + slabs[s_][4]
+        assert (ti, tj) not in written
+        written.add((ti, tj))
+        C[I, J] = acc
+    ref = P + Gs.T @ Gs
+    low = np.tril_indices(n)
+    nt = (n + TILE - 1) // TILE
+    assert len(written) == nt * (nt + 1) // 2
+    assert np.all(np.isfinite(C[low]))
+    assert np.max(np.abs(C[low] - ref[low])) <= 1e-11 * np.max(np.abs(ref))
