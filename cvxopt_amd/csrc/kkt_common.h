@@ -53,7 +53,9 @@ inline hipError_t memset_sync(void* p, int value, size_t bytes) {
 inline hipError_t malloc_zeroed(void** p, size_t bytes) {
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return e;
-    return bytes ? memset_sync(*p, 0, bytes) : hipSuccess;
+    // test knob MI355KKT_ALLOC_POISON (include/mi355kkt_test.h): every byte 0xff instead -- a NaN in every double, -1 in every
+    // int: a kernel that reads what nobody wrote shows up as a wrong result instead of depending on the block's history
+    return bytes ? memset_sync(*p, dev_knob("MI355KKT_ALLOC_POISON") ? 0xff : 0, bytes) : hipSuccess;
 }
 template <class T>
 inline hipError_t malloc_zeroed(T** p, size_t bytes) { return malloc_zeroed(reinterpret_cast<void**>(p), bytes); }

@@ -122,9 +122,25 @@ class _Knobs(object):
         _capi.set_knob(name, None)
 
 
+def _session_knobs():
+    """MI355KKT_TEST_ALLOC_POISON=1 in the environment of a GPU test run: every device allocation of the library starts as 0xff
+    bytes (test knob MI355KKT_ALLOC_POISON, csrc/kkt_common.h: malloc_zeroed) -- a hunt for reads of memory nobody wrote"""
+    if os.environ.get("MI355KKT_TEST_ALLOC_POISON") == "1":
+        from cvxopt_amd import _capi
+        _capi.set_knob("MI355KKT_ALLOC_POISON", "1")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _apply_session_knobs():
+    if os.environ.get("MI355KKT_TEST_ALLOC_POISON") == "1" and _gpu_count() > 0:
+        _session_knobs()
+    yield
+
+
 @pytest.fixture
 def knobs():
     k = _Knobs()
     yield k
     from cvxopt_amd import _capi
     _capi.set_knob(None, None)
+    _session_knobs()
