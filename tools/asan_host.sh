@@ -16,8 +16,10 @@ for f in gemm_f64 potrf blas2 cone_scale sparse_chol batch_ipm conelp_ipm coneqp
   ( "$HIPCC" --offload-arch=gfx950 -std=c++17 -fPIC $SAN -I"$ROOT/include" -c "$SRC/$f.hip" -o "$OUT/$f.o" ) &
   pids+=($!)
 done
-( "$HIPCC" -std=c++17 -fPIC $SAN -c "$SRC/ordering.cpp" -o "$OUT/ordering.o" ) &
-pids+=($!)
+for f in ordering knobs; do
+  ( "$HIPCC" -std=c++17 -fPIC $SAN -c "$SRC/$f.cpp" -o "$OUT/$f.o" ) &
+  pids+=($!)
+done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC $SAN -o "$OUT/libmi355kkt.so" "$OUT"/*.o
 RT="$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)"
