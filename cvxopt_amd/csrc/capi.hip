@@ -130,8 +130,8 @@ struct IpmWork {
     int B = 0;
 };
 static void ipm_free(IpmWork& w) {
-    if (w.f64) (void)hipFree(w.f64);
-    if (w.i32) (void)hipFree(w.i32);
+    if (w.f64) (void)dev_free(w.f64);
+    if (w.i32) (void)dev_free(w.i32);
     if (w.pinned) (void)hipHostFree(w.pinned);
     w = IpmWork();
 }
@@ -140,8 +140,8 @@ static int ipm_alloc(IpmWork& w, int nbatch, int n, int m, int np = 0) {
     const size_t B = nbatch, N = n, M = m ? m : 1, Pq = np;
     const size_t nd = B * (8 * N + 13 * M + 6 * Pq + 9);
     // all or nothing: a partially allocated state must not look complete to the next call
-    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) { ipm_free(w); return MI355KKT_ENOMEM; }
-    if (hipMalloc(&w.i32, sizeof(int) * (5 * B + 1)) != hipSuccess) { ipm_free(w); return MI355KKT_ENOMEM; }
+    if (DEV_ALLOC(&w.f64, sizeof(double) * nd) != hipSuccess) { ipm_free(w); return MI355KKT_ENOMEM; }
+    if (DEV_ALLOC(&w.i32, sizeof(int) * (5 * B + 1)) != hipSuccess) { ipm_free(w); return MI355KKT_ENOMEM; }
     if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) { ipm_free(w); return MI355KKT_ENOMEM; }
     w.B = nbatch;
     IpmState& S = w.S;
@@ -173,8 +173,8 @@ struct LpWork {
     int* pinned = nullptr;
 };
 static void lp_free(LpWork& w) {
-    if (w.f64) (void)hipFree(w.f64);
-    if (w.i32) (void)hipFree(w.i32);
+    if (w.f64) (void)dev_free(w.f64);
+    if (w.i32) (void)dev_free(w.i32);
     if (w.pinned) (void)hipHostFree(w.pinned);
     w = LpWork();
 }
@@ -224,8 +224,8 @@ static int lp_alloc(LpWork& w, int n, int ml, const std::vector<int>& q, const s
     const size_t N = n ? n : 1, M = m ? m : 1, Pq = np ? np : 1;
     const size_t nd = 10 * N + 9 * Pq + 23 * M + (size_t)sumq + nq + LP_NSC + 8 + sb.doubles();
     // all or nothing: a partially allocated state must not look complete to the next call
-    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
-    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq + 3 * (size_t)sb.ns)) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
+    if (DEV_ALLOC(&w.f64, sizeof(double) * nd) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
+    if (DEV_ALLOC(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq + 3 * (size_t)sb.ns)) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
     if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) { lp_free(w); return MI355KKT_ENOMEM; }
     LpState& S = w.S;
     S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq;
@@ -261,8 +261,8 @@ struct QpWork {
     int* pinned = nullptr;
 };
 static void qp_free(QpWork& w) {
-    if (w.f64) (void)hipFree(w.f64);
-    if (w.i32) (void)hipFree(w.i32);
+    if (w.f64) (void)dev_free(w.f64);
+    if (w.i32) (void)dev_free(w.i32);
     if (w.pinned) (void)hipHostFree(w.pinned);
     w = QpWork();
 }
@@ -277,8 +277,8 @@ static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, const s
     if (B > 1 && sb.ns > 0) return MI355KKT_ENOTIMPL;
     const size_t nd = B * (10 * N + 8 * Pq + 21 * M + (size_t)(sumq ? sumq : 1) + (nq ? nq : 1) + QP_NSC) + 8 + sb.doubles();
     // all or nothing: a partially allocated state must not look complete to the next call
-    if (hipMalloc(&w.f64, sizeof(double) * nd) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
-    if (hipMalloc(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq + 3 * (size_t)sb.ns + 4 * B)) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
+    if (DEV_ALLOC(&w.f64, sizeof(double) * nd) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
+    if (DEV_ALLOC(&w.i32, sizeof(int) * (8 + 2 * (size_t)nq + 3 * (size_t)sb.ns + 4 * B)) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
     if (hipHostMalloc(&w.pinned, sizeof(int) * 4) != hipSuccess) { qp_free(w); return MI355KKT_ENOMEM; }
     QpState& S = w.S;
     S.n = n; S.m = m; S.p = np; S.ml = ml; S.nq = nq; S.nbatch = (int)B;
@@ -455,11 +455,11 @@ int mi355kkt_device_info(int device, char* name, int len, int* num_cus, size_t* 
 } catch (...) { return kkt_catch("mi355kkt_device_info"); }
 
 int mi355kkt_dev_malloc(void** ptr, size_t bytes) try {
-    KKT_HIP_CHECK(hipMalloc(ptr, bytes ? bytes : 8));
+    KKT_HIP_CHECK(DEV_ALLOC(ptr, bytes ? bytes : 8));
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_dev_malloc"); }
 int mi355kkt_dev_free(void* ptr) try {
-    if (ptr) KKT_HIP_CHECK(hipFree(ptr));
+    if (ptr) KKT_HIP_CHECK(dev_free(ptr));
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_dev_free"); }
 int mi355kkt_memcpy_h2d(void* dst, const void* src, size_t bytes) try {
@@ -526,7 +526,7 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     for (auto& e : h->ev)
         if (hipEventCreate(&e) != hipSuccess) return fail(MI355KKT_EHIP);
     auto alloc = [&](double** ptr, size_t doubles) -> int {
-        if (hipMalloc(ptr, sizeof(double) * dmax(doubles, 1)) != hipSuccess) {
+        if (DEV_ALLOC(ptr, sizeof(double) * dmax(doubles, 1)) != hipSuccess) {
             set_last_error("hipMalloc of %zu doubles failed", doubles);
             return MI355KKT_ENOMEM;
         }
@@ -546,9 +546,9 @@ int mi355kkt_create(mi355kkt_solver** out, int device, int kind, int n, int p, i
     if ((rc = alloc(&h->dWst, 2 * C + (size_t)nq + 8))) return fail(rc);
     {
         const size_t nfl = N / 128 + 2 + 64 * TRSV_JOB_STRIDE;    // + room for 64 batched jobs of the sparse engine's wide supernodes
-        if (hipMalloc(&h->dgran, sizeof(unsigned long long) * nfl * 256) != hipSuccess) return fail(MI355KKT_ENOMEM);
+        if (DEV_ALLOC(&h->dgran, sizeof(unsigned long long) * nfl * 256) != hipSuccess) return fail(MI355KKT_ENOMEM);
         if (memset_sync(h->dgran, 0, sizeof(unsigned long long) * nfl * 256) != hipSuccess) return fail(MI355KKT_EHIP);
-        if (hipMalloc(&h->derr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
+        if (DEV_ALLOC(&h->derr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
         if (memset_sync(h->derr, 0, sizeof(int)) != hipSuccess) return fail(MI355KKT_EHIP);
         if (hipHostMalloc(&h->herr, sizeof(int)) != hipSuccess) return fail(MI355KKT_ENOMEM);
         *h->herr = 0;
@@ -590,22 +590,22 @@ void mi355kkt_destroy(mi355kkt_solver* h) try {
     ipm_free(h->ipm);
     lp_free(h->lp);
     qp_free(h->qp);
-    if (h->dHsym) (void)hipFree(h->dHsym);
-    if (h->dIpmWork) (void)hipFree(h->dIpmWork);
-    if (h->dSpWork) (void)hipFree(h->dSpWork);
+    if (h->dHsym) (void)dev_free(h->dHsym);
+    if (h->dIpmWork) (void)dev_free(h->dIpmWork);
+    if (h->dSpWork) (void)dev_free(h->dSpWork);
     h_unregister(h);
     {
         void* ap[] = {h->dArp, h->dAcp, h->dAci, h->dAri, h->dAv, h->dAvc};
-        for (void* q : ap) if (q) (void)hipFree(q);
+        for (void* q : ap) if (q) (void)dev_free(q);
     }
     if (h->cst) (void)hipStreamDestroy(h->cst);
     if (h->ev_h) (void)hipEventDestroy(h->ev_h);
-    if (h->dgran) (void)hipFree(h->dgran);
-    if (h->dRef) (void)hipFree(h->dRef);
-    if (h->derr) (void)hipFree(h->derr);
+    if (h->dgran) (void)dev_free(h->dgran);
+    if (h->dRef) (void)dev_free(h->dRef);
+    if (h->derr) (void)dev_free(h->derr);
     if (h->herr) (void)hipHostFree(h->herr);
     for (double* b : bufs)
-        if (b) (void)hipFree(b);
+        if (b) (void)dev_free(b);
     if (h->hbuf) (void)hipHostFree(h->hbuf);
     potrf_work_free(h->pw);
     free_syrk_plan(h->planS);
@@ -618,9 +618,9 @@ void mi355kkt_destroy(mi355kkt_solver* h) try {
 } catch (...) { (void)kkt_catch("mi355kkt_destroy"); }
 
 static int upload_dense(double** owned, const double* src, int64_t ld, int rows, int cols, hipStream_t st) {
-    if (*owned) { (void)hipFree(*owned); *owned = nullptr; }
+    if (*owned) { (void)dev_free(*owned); *owned = nullptr; }
     const size_t bytes = sizeof(double) * dmax((size_t)rows * cols, 1);
-    KKT_HIP_CHECK(hipMalloc(owned, bytes));
+    KKT_HIP_CHECK(DEV_ALLOC(owned, bytes));
     if (rows > 0 && cols > 0)
         KKT_HIP_CHECK(memcpy2d_sync(*owned, sizeof(double) * rows, src, sizeof(double) * ld, sizeof(double) * rows, cols,
                                   hipMemcpyHostToDevice));
@@ -722,15 +722,15 @@ int mi355kkt_set_A_csr(mi355kkt_solver* h, const int64_t* rowptr_in, const int64
             }
     }
     void* old[] = {h->dArp, h->dAcp, h->dAci, h->dAri, h->dAv, h->dAvc};
-    for (void* q : old) if (q) (void)hipFree(q);
+    for (void* q : old) if (q) (void)dev_free(q);
     h->dArp = h->dAcp = nullptr; h->dAci = h->dAri = nullptr; h->dAv = h->dAvc = nullptr;
     const size_t z = (size_t)(nnz > 0 ? nnz : 1);
-    KKT_HIP_CHECK(hipMalloc(&h->dArp, sizeof(int64_t) * (p + 1)));
-    KKT_HIP_CHECK(hipMalloc(&h->dAcp, sizeof(int64_t) * ((size_t)n + 1)));
-    KKT_HIP_CHECK(hipMalloc(&h->dAci, sizeof(int) * z));
-    KKT_HIP_CHECK(hipMalloc(&h->dAri, sizeof(int) * z));
-    KKT_HIP_CHECK(hipMalloc(&h->dAv, sizeof(double) * z));
-    KKT_HIP_CHECK(hipMalloc(&h->dAvc, sizeof(double) * z));
+    KKT_HIP_CHECK(DEV_ALLOC(&h->dArp, sizeof(int64_t) * (p + 1)));
+    KKT_HIP_CHECK(DEV_ALLOC(&h->dAcp, sizeof(int64_t) * ((size_t)n + 1)));
+    KKT_HIP_CHECK(DEV_ALLOC(&h->dAci, sizeof(int) * z));
+    KKT_HIP_CHECK(DEV_ALLOC(&h->dAri, sizeof(int) * z));
+    KKT_HIP_CHECK(DEV_ALLOC(&h->dAv, sizeof(double) * z));
+    KKT_HIP_CHECK(DEV_ALLOC(&h->dAvc, sizeof(double) * z));
     KKT_HIP_CHECK(memcpy_sync(h->dArp, rp.data(), sizeof(int64_t) * (p + 1), hipMemcpyHostToDevice));
     KKT_HIP_CHECK(memcpy_sync(h->dAcp, cp.data(), sizeof(int64_t) * ((size_t)n + 1), hipMemcpyHostToDevice));
     if (nnz > 0) {
@@ -829,7 +829,7 @@ int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) try {
         return 0;
     }
     if (ldH < (h->n > 1 ? h->n : 1)) { set_last_error("set_H_dense: ldH too small"); return MI355KKT_EINVAL; }
-    if (!h->H_owned) KKT_HIP_CHECK(hipMalloc(&h->H_owned, sizeof(double) * dmax((size_t)h->n * h->n, 1)));
+    if (!h->H_owned) KKT_HIP_CHECK(DEV_ALLOC(&h->H_owned, sizeof(double) * dmax((size_t)h->n * h->n, 1)));
     if (h->n > 0)
         KKT_HIP_CHECK(memcpy2d_sync(h->H_owned, sizeof(double) * h->n, H, sizeof(double) * ldH, sizeof(double) * h->n,
                                   h->n, hipMemcpyHostToDevice));
@@ -871,7 +871,7 @@ int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH)
     }
     if (!h->cst) KKT_HIP_CHECK(hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking));
     if (!h->ev_h) KKT_HIP_CHECK(hipEventCreateWithFlags(&h->ev_h, hipEventDisableTiming));
-    if (!h->H_owned) KKT_HIP_CHECK(hipMalloc(&h->H_owned, sizeof(double) * dmax((size_t)h->n * h->n, 1)));
+    if (!h->H_owned) KKT_HIP_CHECK(DEV_ALLOC(&h->H_owned, sizeof(double) * dmax((size_t)h->n * h->n, 1)));
     KKT_HIP_CHECK(hipStreamSynchronize(h->st));            // nothing on the compute stream may still read the old H
     KKT_HIP_CHECK(hipMemcpy2DAsync(h->H_owned, sizeof(double) * h->n, H, sizeof(double) * ldH, sizeof(double) * h->n, h->n,
                                    hipMemcpyHostToDevice, h->cst));
@@ -1031,7 +1031,7 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
             // equality constraints (misc.py:1464-1487, sparse branch): Asct = L^-1 P A' with all p right-hand sides in
             // one pass of the supernodal forward solve (kept in the permuted ordering), K = Asct' Asct, dense Cholesky of K
             if (!h->dA && !h->A_sparse) { set_last_error("factor: A not set"); return MI355KKT_EINVAL; }
-            if (!h->dSpWork) KKT_HIP_CHECK(hipMalloc(&h->dSpWork, sizeof(double) * gemv_work_doubles(h->n, h->p)));
+            if (!h->dSpWork) KKT_HIP_CHECK(DEV_ALLOC(&h->dSpWork, sizeof(double) * gemv_work_doubles(h->n, h->p)));
             if (h->A_sparse) {
                 if (int e = sparse_engine_forward_rows_csr(h->sp, h->dArp, h->dAci, h->dAv, h->p, h->dAsct, h->st)) return e;
             } else if (int e = sparse_engine_forward_rows(h->sp, h->dA, h->ldA, h->p, h->dAsct, h->st)) return e;
@@ -1059,18 +1059,18 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
         //  more than either of the first two when p is large, the cone rows few and n > 256)
         const size_t work_doubles = dmax(dmax(dmax(gemv_work_doubles(h->cdim, h->n), gemv_work_doubles(h->n, h->p)),
                                               gemv_work_doubles(h->p, h->n)), (size_t)h->cdim + 8);
-        if (hipMalloc(&newS, sizeof(double) * dmax(N * N, 1)) != hipSuccess ||
-            hipMalloc(&newwork, sizeof(double) * work_doubles) != hipSuccess) {
-            if (newS) (void)hipFree(newS);
+        if (DEV_ALLOC(&newS, sizeof(double) * dmax(N * N, 1)) != hipSuccess ||
+            DEV_ALLOC(&newwork, sizeof(double) * work_doubles) != hipSuccess) {
+            if (newS) (void)dev_free(newS);
             set_last_error("factor: out of device memory for the %zu x %zu reduced KKT matrix", N, N);
             return MI355KKT_ENOMEM;
         }
         if (int e = build_syrk_plan(h->planS, h->n, h->krows, h->num_cus)) {
-            (void)hipFree(newS);
-            (void)hipFree(newwork);
+            (void)dev_free(newS);
+            (void)dev_free(newwork);
             return e;
         }
-        (void)hipFree(h->dwork);
+        (void)dev_free(h->dwork);
         h->dwork = newwork;
         h->dS = newS;
     }
@@ -1219,7 +1219,7 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     const bool refine = ref_steps > 0 && (h->kind == MI355KKT_LDL || h->kind == MI355KKT_LDL2) && h->kktreg == 0.0 && mk > 0 && n > 0;
     double *bx0 = nullptr, *by0 = nullptr, *zs0 = nullptr, *rx = nullptr, *ry = nullptr, *rz = nullptr, *tt = nullptr;
     if (refine) {
-        if (!h->dRef) KKT_HIP_CHECK(hipMalloc(&h->dRef, sizeof(double) * (2 * (size_t)n + 2 * (size_t)dmax(p, 1) + 3 * (size_t)mk)));
+        if (!h->dRef) KKT_HIP_CHECK(DEV_ALLOC(&h->dRef, sizeof(double) * (2 * (size_t)n + 2 * (size_t)dmax(p, 1) + 3 * (size_t)mk)));
         bx0 = h->dRef; by0 = bx0 + n; zs0 = by0 + dmax(p, 1); rx = zs0 + mk; ry = rx + n; rz = ry + dmax(p, 1); tt = rz + mk;
         KKT_HIP_CHECK(hipMemcpyAsync(bx0, dx, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
         if (p > 0) KKT_HIP_CHECK(hipMemcpyAsync(by0, dy, sizeof(double) * p, hipMemcpyDeviceToDevice, st));
@@ -1442,7 +1442,7 @@ int mi355kkt_batch_create_eq(mi355kkt_batch** out, int device, int nbatch, int n
     if (hipStreamCreateWithFlags(&b->st, hipStreamNonBlocking) != hipSuccess) return fail(MI355KKT_EHIP);
     for (auto& e : b->ev) if (hipEventCreate(&e) != hipSuccess) return fail(MI355KKT_EHIP);
     const size_t B = nbatch, N = n, M = ml;
-    auto alloc = [&](double** p, size_t d) { return hipMalloc(p, sizeof(double) * (d ? d : 1)) == hipSuccess ? 0 : MI355KKT_ENOMEM; };
+    auto alloc = [&](double** p, size_t d) { return DEV_ALLOC(p, sizeof(double) * (d ? d : 1)) == hipSuccess ? 0 : MI355KKT_ENOMEM; };
     int rc;
     if ((rc = alloc(&b->dG, B * M * N))) return fail(rc);
     if ((rc = alloc(&b->dH, B * N * N))) return fail(rc);
@@ -1493,14 +1493,14 @@ int mi355kkt_batch_create_cones(mi355kkt_batch** out, int device, int nbatch, in
     for (int k = 0; k < nq; ++k)
         if (q[k] > 32) hq.push_back(k);
     b->nlarge = (int)hq.size() - 2 * nq;
-    if (hipMalloc(&b->d_qoff, sizeof(int) * hq.size()) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    if (DEV_ALLOC(&b->d_qoff, sizeof(int) * hq.size()) != hipSuccess) return fail(MI355KKT_ENOMEM);
     b->d_qdim = b->d_qoff + nq;
     b->d_large = b->d_qoff + 2 * nq;
     if (memcpy_sync(b->d_qoff, hq.data(), sizeof(int) * hq.size(), hipMemcpyHostToDevice) != hipSuccess) return fail(MI355KKT_EHIP);
     const size_t B = nbatch;
-    if (hipMalloc(&b->dGs, sizeof(double) * B * (size_t)cdim * n) != hipSuccess) return fail(MI355KKT_ENOMEM);
-    if (hipMalloc(&b->dV, sizeof(double) * B * b->sumq) != hipSuccess) return fail(MI355KKT_ENOMEM);
-    if (hipMalloc(&b->dBeta, sizeof(double) * B * nq) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    if (DEV_ALLOC(&b->dGs, sizeof(double) * B * (size_t)cdim * n) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    if (DEV_ALLOC(&b->dV, sizeof(double) * B * b->sumq) != hipSuccess) return fail(MI355KKT_ENOMEM);
+    if (DEV_ALLOC(&b->dBeta, sizeof(double) * B * nq) != hipSuccess) return fail(MI355KKT_ENOMEM);
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_batch_create_cones"); }
 
@@ -1508,11 +1508,11 @@ void mi355kkt_batch_destroy(mi355kkt_batch* b) try {
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->st) (void)hipStreamSynchronize(b->st);
-    if (b->d_qoff) (void)hipFree(b->d_qoff);
-    { double* cb[] = {b->dGs, b->dV, b->dBeta}; for (double* p : cb) if (p) (void)hipFree(p); }
+    if (b->d_qoff) (void)dev_free(b->d_qoff);
+    { double* cb[] = {b->dGs, b->dV, b->dBeta}; for (double* p : cb) if (p) (void)dev_free(p); }
     qp_free(b->qp);
     double* bufs[] = {b->dG, b->dH, b->dS, b->dW, b->dx, b->dz, b->dzs, b->dwork, b->dt1, b->dt2, b->dA, b->dAsct, b->dK, b->dy, b->dtp};
-    for (double* p : bufs) if (p) (void)hipFree(p);
+    for (double* p : bufs) if (p) (void)dev_free(p);
     ipm_free(b->ipm);
     potrf_work_free(b->pw);
     potrf_work_free(b->pwK);
@@ -1974,7 +1974,7 @@ static int ensure_hsym(mi355kkt_solver* hs) {
     if (!hs->dH || hs->sparse || hs->hsym_valid) return 0;
     const int n = hs->n;
     if (hs->h_pending) KKT_HIP_CHECK(hipStreamWaitEvent(hs->st, hs->ev_h, 0));   // asynchronous upload of H in flight
-    if (!hs->dHsym) KKT_HIP_CHECK(hipMalloc(&hs->dHsym, sizeof(double) * dmax((size_t)n * n, 1)));
+    if (!hs->dHsym) KKT_HIP_CHECK(DEV_ALLOC(&hs->dHsym, sizeof(double) * dmax((size_t)n * n, 1)));
     if (n > 0) {
         KKT_HIP_CHECK(hipMemcpy2DAsync(hs->dHsym, sizeof(double) * n, hs->dH, sizeof(double) * hs->ldH, sizeof(double) * n, n,
                                        hipMemcpyDeviceToDevice, hs->st));
@@ -2006,10 +2006,10 @@ static int ensure_gemv_work(mi355kkt_solver* hs) {
     if (hs->dIpmWork) return 0;
     const int n = hs->n, m = hs->cdim, np = hs->p;
     if (hs->sparse) {          // only the (dense) A products need it
-        if (np > 0) KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * gemv_work_doubles(np, n)));
+        if (np > 0) KKT_HIP_CHECK(DEV_ALLOC(&hs->dIpmWork, sizeof(double) * gemv_work_doubles(np, n)));
         return 0;
     }
-    KKT_HIP_CHECK(hipMalloc(&hs->dIpmWork, sizeof(double) * dmax(dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n)),
+    KKT_HIP_CHECK(DEV_ALLOC(&hs->dIpmWork, sizeof(double) * dmax(dmax(gemv_work_doubles(m, n), gemv_work_doubles(n, n)),
                                                                 gemv_work_doubles(np, n))));
     return 0;
 }
@@ -2606,10 +2606,10 @@ extern "C" {
 /* developer probe: HW_ID / XCC_ID of nblocks one-wave workgroups (out: 2 * nblocks words, host) */
 int mi355kkt_debug_hwid(unsigned* out, int nblocks) try {
     unsigned* d = nullptr;
-    KKT_HIP_CHECK(hipMalloc(&d, sizeof(unsigned) * 2 * nblocks));
+    KKT_HIP_CHECK(DEV_ALLOC(&d, sizeof(unsigned) * 2 * nblocks));
     hipLaunchKernelGGL(hwid_probe_kernel, dim3(nblocks), dim3(64), 0, nullptr, d);
     KKT_HIP_CHECK(memcpy_sync(out, d, sizeof(unsigned) * 2 * nblocks, hipMemcpyDeviceToHost));
-    (void)hipFree(d);
+    (void)dev_free(d);
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_debug_hwid"); }
 }  // extern "C"
@@ -2670,7 +2670,7 @@ int mi355kkt_test_sdp_op_device(int op, int m, int arg, int team, double* x, dou
     if (m < 1 || !x || mi355kkt_device_count() < 1) return MI355KKT_EINVAL;
     const size_t mm = (size_t)m * m, nw = 3 * mm + mi355kkt::s_jw_doubles(m, 1024) + 64;
     double* d = nullptr;
-    KKT_HIP_CHECK(hipMalloc(&d, sizeof(double) * (4 * mm + (size_t)m + nw + 8)));
+    KKT_HIP_CHECK(DEV_ALLOC(&d, sizeof(double) * (4 * mm + (size_t)m + nw + 8)));
     double *dx = d, *dy = dx + mm, *dr = dy + mm, *drti = dr + mm, *dl = drti + mm, *dw = dl + m, *dout = dw + nw;
     KKT_HIP_CHECK(memset_sync(d, 0, sizeof(double) * (4 * mm + (size_t)m + nw + 8)));
     KKT_HIP_CHECK(memcpy_sync(dx, x, sizeof(double) * mm, hipMemcpyHostToDevice));
@@ -2678,7 +2678,7 @@ int mi355kkt_test_sdp_op_device(int op, int m, int arg, int team, double* x, dou
     if (r) KKT_HIP_CHECK(memcpy_sync(dr, r, sizeof(double) * mm, hipMemcpyHostToDevice));
     if (rti) KKT_HIP_CHECK(memcpy_sync(drti, rti, sizeof(double) * mm, hipMemcpyHostToDevice));
     if (lam) KKT_HIP_CHECK(memcpy_sync(dl, lam, sizeof(double) * m, hipMemcpyHostToDevice));
-    if (int e = mi355kkt::sdp_op_debug_launch(op, m, arg, team, dx, dy, dr, drti, dl, dw, dout, nullptr)) { (void)hipFree(d); return e; }
+    if (int e = mi355kkt::sdp_op_debug_launch(op, m, arg, team, dx, dy, dr, drti, dl, dw, dout, nullptr)) { (void)dev_free(d); return e; }
     KKT_HIP_CHECK(hipDeviceSynchronize());
     KKT_HIP_CHECK(memcpy_sync(x, dx, sizeof(double) * mm, hipMemcpyDeviceToHost));
     if (y) KKT_HIP_CHECK(memcpy_sync(y, dy, sizeof(double) * mm, hipMemcpyDeviceToHost));
@@ -2690,7 +2690,7 @@ int mi355kkt_test_sdp_op_device(int op, int m, int arg, int team, double* x, dou
         KKT_HIP_CHECK(memcpy_sync(lam, dl, sizeof(double) * m, hipMemcpyDeviceToHost));
         if (op == 4) lam[0] = ret;
     }
-    (void)hipFree(d);
+    (void)dev_free(d);
     return (op == 6 || op == 8) ? (int)ret : 0;
 } catch (...) { return kkt_catch("mi355kkt_test_sdp_op_device"); }
 
@@ -2824,6 +2824,27 @@ int mi355kkt_debug_syrk_skip(int mask) { return mi355kkt::set_syrk_skip(mask); }
 int mi355kkt_test_set_knob(const char* name, const char* value) try {
     return mi355kkt::set_dev_knob(name, value);
 } catch (...) { return kkt_catch("mi355kkt_test_set_knob"); }
+/* writes the ring of the library's last 65536 device allocations / releases to `path` when the process receives SIGABRT (the
+ * HIP runtime abort()s on one of its own threads after reporting a GPU memory fault), then lets the previous handler run */
+int mi355kkt_test_install_abort_dump(const char* path) try {
+    return mi355kkt::install_abort_dump(path) == 0 ? 0 : MI355KKT_EINVAL;
+} catch (...) { return kkt_catch("mi355kkt_test_install_abort_dump"); }
+/* allocates ndoubles doubles through the library's allocator and reads the element at index `at` from a kernel (at >= ndoubles:
+ * out of bounds on purpose -- under the knob MI355KKT_ALLOC_GUARD that must be a GPU memory fault, which ends the process);
+ * *out = the value read */
+int mi355kkt_test_guard_probe(int ndoubles, int at, double* out) try {
+    if (ndoubles < 1 || at < 0 || !out) return MI355KKT_EINVAL;
+    double *blk = nullptr, *res = nullptr;
+    KKT_HIP_CHECK(DEV_ALLOC(&blk, sizeof(double) * (size_t)ndoubles));
+    if (DEV_ALLOC(&res, sizeof(double)) != hipSuccess) { (void)dev_free(blk); return MI355KKT_ENOMEM; }
+    hipLaunchKernelGGL(row_gather_kernel, dim3(1), dim3(64), 0, nullptr, blk + at, (int64_t)0, 1, res);
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, res, sizeof(double), hipMemcpyDeviceToHost);
+    (void)dev_free(blk);
+    (void)dev_free(res);
+    KKT_HIP_CHECK(e);
+    return 0;
+} catch (...) { return kkt_catch("mi355kkt_test_guard_probe"); }
 int mi355kkt_test_throw(int kind) try {
     if (kind == 0) throw std::bad_alloc();
     if (kind == 1) throw std::runtime_error("requested by the caller");
@@ -2858,22 +2879,22 @@ int mi355kkt_op_trsm_lower(const double* dL, int64_t ldL, int n, double* dX, int
 int mi355kkt_op_gemv_t_scaled(const double* dG, int64_t ldG, int m, int n, const double* dw, const double* dz,
                               double* dzs, double* dy, float* ms) try {
     double* work = nullptr;
-    KKT_HIP_CHECK(hipMalloc(&work, sizeof(double) * (size_t)(m > 0 ? m : 1)));
+    KKT_HIP_CHECK(DEV_ALLOC(&work, sizeof(double) * (size_t)(m > 0 ? m : 1)));
     OpTimer t(ms);
     int rc = launch_gemv_t_scaled(dG, ldG, m, n, dw, dz, dzs, dy, work, nullptr);
     if (!rc) rc = t.finish();
-    (void)hipFree(work);
+    (void)dev_free(work);
     return rc;
 } catch (...) { return kkt_catch("mi355kkt_op_gemv_t_scaled"); }
 
 int mi355kkt_op_gemv_n_scaled(const double* dG, int64_t ldG, int m, int n, const double* dw, const double* dx,
                               const double* dzs, double* dz, float* ms) try {
     double* work = nullptr;
-    KKT_HIP_CHECK(hipMalloc(&work, sizeof(double) * gemv_work_doubles(m, n)));
+    KKT_HIP_CHECK(DEV_ALLOC(&work, sizeof(double) * gemv_work_doubles(m, n)));
     OpTimer t(ms);
     int rc = launch_gemv_n_scaled(dG, ldG, m, n, dw, dx, dzs, dz, 1.0, -1.0, work, nullptr);
     if (!rc) rc = t.finish();
-    (void)hipFree(work);
+    (void)dev_free(work);
     return rc;
 } catch (...) { return kkt_catch("mi355kkt_op_gemv_n_scaled"); }
 

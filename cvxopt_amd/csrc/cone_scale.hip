@@ -263,7 +263,7 @@ int cone_layout_build_s(ConeLayout& cl, int lq_rows, const std::vector<int>& s) 
     cl.cdim_packed = po;
     cl.rlen = ro;
     auto up = [&](int** d, const std::vector<int>& h) -> int {
-        KKT_HIP_CHECK(hipMalloc(d, sizeof(int) * (h.size() ? h.size() : 1)));
+        KKT_HIP_CHECK(DEV_ALLOC(d, sizeof(int) * (h.size() ? h.size() : 1)));
         if (!h.empty()) KKT_HIP_CHECK(memcpy_sync(*d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
         return 0;
     };
@@ -290,10 +290,10 @@ int launch_sdp_scale_pack(const ConeLayout& cl, const double* in, int64_t ldi, d
             else need = std::max(need, (size_t)nk * nk * (1 + (size_t)std::min(ncols, std::max(1, (int)((size_t)(32 << 20) / ((size_t)nk * nk))))));
         }
         if (need > cl.cong_doubles) {
-            if (cl.d_cong) (void)hipFree(cl.d_cong);
+            if (cl.d_cong) (void)dev_free(cl.d_cong);
             cl.d_cong = nullptr;
             cl.cong_doubles = 0;
-            KKT_HIP_CHECK(hipMalloc(&cl.d_cong, sizeof(double) * need));
+            KKT_HIP_CHECK(DEV_ALLOC(&cl.d_cong, sizeof(double) * need));
             cl.cong_doubles = need;
         }
         if (small_max > 0) {
@@ -380,7 +380,7 @@ int cone_layout_build(ConeLayout& cl, int ml, const std::vector<int>& q) {
     cl.n_small = (int)small_ids.size();
     cl.n_large = (int)large_ids.size();
     auto up = [&](int** d, const std::vector<int>& h) -> int {
-        KKT_HIP_CHECK(hipMalloc(d, sizeof(int) * (h.size() ? h.size() : 1)));
+        KKT_HIP_CHECK(DEV_ALLOC(d, sizeof(int) * (h.size() ? h.size() : 1)));
         if (!h.empty()) KKT_HIP_CHECK(memcpy_sync(*d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
         return 0;
     };
@@ -393,19 +393,19 @@ int cone_layout_build(ConeLayout& cl, int ml, const std::vector<int>& q) {
     if (int e = up(&cl.d_s_dim, s_dim)) return e;
     if (int e = up(&cl.d_s_voff, s_voff)) return e;
     // beta for the compacted small set is gathered on the device at factor time (beta changes per factor)
-    KKT_HIP_CHECK(hipMalloc(&cl.d_s_beta, sizeof(double) * (cl.n_small ? cl.n_small : 1)));
+    KKT_HIP_CHECK(DEV_ALLOC(&cl.d_s_beta, sizeof(double) * (cl.n_small ? cl.n_small : 1)));
     return 0;
 }
 
 void cone_layout_free(ConeLayout& cl) {
     int* ip[] = {cl.d_off, cl.d_dim, cl.d_voff, cl.d_small_ids, cl.d_large_ids, cl.d_s_off, cl.d_s_dim, cl.d_s_voff};
     for (int* p : ip)
-        if (p) (void)hipFree(p);
-    if (cl.d_s_beta) (void)hipFree(cl.d_s_beta);
+        if (p) (void)dev_free(p);
+    if (cl.d_s_beta) (void)dev_free(cl.d_s_beta);
     int* sp[] = {cl.d_sdim, cl.d_soff, cl.d_spoff, cl.d_sroff};
     for (int* p : sp)
-        if (p) (void)hipFree(p);
-    if (cl.d_cong) (void)hipFree(cl.d_cong);
+        if (p) (void)dev_free(p);
+    if (cl.d_cong) (void)dev_free(cl.d_cong);
     cl = ConeLayout();
 }
 

@@ -538,21 +538,21 @@ int build_syrk_plan(SyrkPlan& plan, int n, int K, int num_cus, bool allow_split)
     plan.nitems_total = (int)items.size();
     plan.nslabs = nslabs;
     plan.nsplit_tiles = (int)split_tiles.size();
-    KKT_HIP_CHECK(hipMalloc(&plan.d_items, sizeof(SyrkItem) * std::max<size_t>(1, items.size())));
+    KKT_HIP_CHECK(DEV_ALLOC(&plan.d_items, sizeof(SyrkItem) * std::max<size_t>(1, items.size())));
     KKT_HIP_CHECK(memcpy_sync(plan.d_items, items.data(), sizeof(SyrkItem) * items.size(), hipMemcpyHostToDevice));
     if (!split_tiles.empty()) {
-        KKT_HIP_CHECK(hipMalloc(&plan.d_split_tiles, sizeof(SyrkItem) * split_tiles.size()));
+        KKT_HIP_CHECK(DEV_ALLOC(&plan.d_split_tiles, sizeof(SyrkItem) * split_tiles.size()));
         KKT_HIP_CHECK(memcpy_sync(plan.d_split_tiles, split_tiles.data(), sizeof(SyrkItem) * split_tiles.size(),
                                 hipMemcpyHostToDevice));
-        KKT_HIP_CHECK(hipMalloc(&plan.d_slabs, sizeof(double) * (size_t)nslabs * TILE * TILE));
+        KKT_HIP_CHECK(DEV_ALLOC(&plan.d_slabs, sizeof(double) * (size_t)nslabs * TILE * TILE));
     }
     return 0;
 }
 
 void free_syrk_plan(SyrkPlan& plan) {
-    if (plan.d_items) (void)hipFree(plan.d_items);
-    if (plan.d_split_tiles) (void)hipFree(plan.d_split_tiles);
-    if (plan.d_slabs) (void)hipFree(plan.d_slabs);
+    if (plan.d_items) (void)dev_free(plan.d_items);
+    if (plan.d_split_tiles) (void)dev_free(plan.d_split_tiles);
+    if (plan.d_slabs) (void)dev_free(plan.d_slabs);
     plan = SyrkPlan();
 }
 
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(256, 2) void mfma_f64_peak_kernel(double* out, int 
 
 int run_mfma_f64_peak(int iters, int num_cus, float* tflops) {
     double* d = nullptr;
-    KKT_HIP_CHECK(hipMalloc(&d, 8));
+    KKT_HIP_CHECK(DEV_ALLOC(&d, 8));
     hipEvent_t a, b;
     KKT_HIP_CHECK(hipEventCreate(&a));
     KKT_HIP_CHECK(hipEventCreate(&b));
@@ -1101,7 +1101,7 @@ int run_mfma_f64_peak(int iters, int num_cus, float* tflops) {
     if (tflops) *tflops = (float)(flops / (ms * 1e-3) / 1e12);
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
-    (void)hipFree(d);
+    (void)dev_free(d);
     return 0;
 }
 

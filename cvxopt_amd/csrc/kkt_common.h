@@ -44,22 +44,20 @@ inline hipError_t memset_sync(void* p, int value, size_t bytes) {
     return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
 }
 
-// ---- device allocations start from zero --------------------------------------------------------------
-// Every hipMalloc of this library goes through malloc_zeroed (the macro below): allocate, clear, wait.  A fresh process gets
-// zero pages from the driver anyway; a long-lived one gets whatever an earlier handle left in the recycled block -- the state
-// of a handle must not depend on which of the two it is.  (Round 4: the whole GPU test-suite in ONE process -- ~2000 handles
-// created and destroyed before it -- aborted in / hung near the 's'-cone book examples that pass in a process of their own,
-// DESIGN 12.)  Setup-time cost only: nothing on the factor / solve path allocates.
-inline hipError_t malloc_zeroed(void** p, size_t bytes) {
-    hipError_t e = hipMalloc(p, bytes);
-    if (e != hipSuccess) return e;
-    // test knob MI355KKT_ALLOC_POISON (include/mi355kkt_test.h): every byte 0xff instead -- a NaN in every double, -1 in every
-    // int: a kernel that reads what nobody wrote shows up as a wrong result instead of depending on the block's history
-    return bytes ? memset_sync(*p, dev_knob("MI355KKT_ALLOC_POISON") ? 0xff : 0, bytes) : hipSuccess;
-}
+// ---- device allocations (devmem.cpp) ---------------------------------------------------------------
+// Every device allocation of this library goes through DEV_ALLOC / dev_free: allocate, clear to zero on a private stream, wait.
+// A fresh process gets zero pages from the driver anyway; a long-lived one gets whatever an earlier handle left in the recycled
+// block -- the state of a handle must not depend on which of the two it is.  Test knobs (mi355kkt_test.h) turn the
+// clear into 0xff poison (MI355KKT_ALLOC_POISON), drop it (MI355KKT_ALLOC_RAW) or put every block at the end of its own mapping
+// so that an out-of-bounds access faults at once (MI355KKT_ALLOC_GUARD).  The call site is recorded for the abort dump.
+hipError_t dev_alloc(void** p, size_t bytes, const char* file, int line);
+hipError_t dev_free(void* p);
+int install_abort_dump(const char* path);
 template <class T>
-inline hipError_t malloc_zeroed(T** p, size_t bytes) { return malloc_zeroed(reinterpret_cast<void**>(p), bytes); }
-#define hipMalloc(ptr_, bytes_) ::mi355kkt::malloc_zeroed((ptr_), (bytes_))
+inline hipError_t dev_alloc_typed(T** p, size_t bytes, const char* file, int line) {
+    return dev_alloc(reinterpret_cast<void**>(p), bytes, file, line);
+}
+#define DEV_ALLOC(ptr_, bytes_) ::mi355kkt::dev_alloc_typed((ptr_), (bytes_), __FILE__, __LINE__)
 
 // ---- tile geometry of the FP64 MFMA kernels -----------------------------------------------------
 constexpr int TILE = 128;      // C tile (both dims) owned by one 256-thread workgroup

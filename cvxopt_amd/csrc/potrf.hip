@@ -1160,8 +1160,8 @@ static int launch_potf2(double* A, int64_t lda, int nb, int col0, int* info, dou
 }
 
 int potrf_work_init_batched(PotrfWork& w, int nbatch) {
-    KKT_HIP_CHECK(hipMalloc(&w.d_info, sizeof(int) * nbatch));
-    KKT_HIP_CHECK(hipMalloc(&w.d_dinv, sizeof(double) * 8 * 256 * nbatch));   // inverses of the 16x16 diagonal blocks
+    KKT_HIP_CHECK(DEV_ALLOC(&w.d_info, sizeof(int) * nbatch));
+    KKT_HIP_CHECK(DEV_ALLOC(&w.d_dinv, sizeof(double) * 8 * 256 * nbatch));   // inverses of the 16x16 diagonal blocks
     KKT_HIP_CHECK(hipHostMalloc(&w.h_info, sizeof(int) * nbatch));
     memset(w.h_info, 0, sizeof(int) * nbatch);
     {   // the bulk updates yield to the critical-path kernels of the main stream at workgroup granularity
@@ -1176,12 +1176,12 @@ int potrf_work_init_batched(PotrfWork& w, int nbatch) {
 int potrf_work_init(PotrfWork& w) { return potrf_work_init_batched(w, 1); }
 
 void potrf_work_free(PotrfWork& w) {
-    if (w.d_info) (void)hipFree(w.d_info);
-    if (w.d_dinv) (void)hipFree(w.d_dinv);
+    if (w.d_info) (void)dev_free(w.d_info);
+    if (w.d_dinv) (void)dev_free(w.d_dinv);
     if (w.h_info) (void)hipHostFree(w.h_info);
-    if (w.d_ctl) (void)hipFree(w.d_ctl);
-    if (w.d_linv_all) (void)hipFree(w.d_linv_all);
-    if (w.d_minv) (void)hipFree(w.d_minv);
+    if (w.d_ctl) (void)dev_free(w.d_ctl);
+    if (w.d_linv_all) (void)dev_free(w.d_linv_all);
+    if (w.d_minv) (void)dev_free(w.d_minv);
     for (auto e : w.ev_panel) (void)hipEventDestroy(e);
     for (auto e : w.ev_bulk) (void)hipEventDestroy(e);
     if (w.side) (void)hipStreamDestroy(w.side);
@@ -1225,16 +1225,16 @@ size_t potrf_tile_ctl_bytes() { return sizeof(TileCtl); }
 // device state of the persistent tile kernel for matrices up to n x n (idempotent; launch_potrf calls it lazily)
 int potrf_work_reserve(PotrfWork& w, int n) {
     const int NT = (n + NB - 1) / NB;
-    if (!w.d_ctl) KKT_HIP_CHECK(hipMalloc(&w.d_ctl, sizeof(TileCtl)));
+    if (!w.d_ctl) KKT_HIP_CHECK(DEV_ALLOC(&w.d_ctl, sizeof(TileCtl)));
     if (w.linv_tiles < NT) {
-        if (w.d_linv_all) (void)hipFree(w.d_linv_all);
+        if (w.d_linv_all) (void)dev_free(w.d_linv_all);
         w.d_linv_all = nullptr;
         w.linv_tiles = 0;
         w.minv_n = 0;
-        KKT_HIP_CHECK(hipMalloc(&w.d_linv_all, sizeof(double) * 2048 * (size_t)NT));
-        if (w.d_minv) (void)hipFree(w.d_minv);
+        KKT_HIP_CHECK(DEV_ALLOC(&w.d_linv_all, sizeof(double) * 2048 * (size_t)NT));
+        if (w.d_minv) (void)dev_free(w.d_minv);
         w.d_minv = nullptr;
-        KKT_HIP_CHECK(hipMalloc(&w.d_minv, sizeof(double) * 2 * NB * NB * (size_t)NT));
+        KKT_HIP_CHECK(DEV_ALLOC(&w.d_minv, sizeof(double) * 2 * NB * NB * (size_t)NT));
         w.linv_tiles = NT;
     }
     return 0;

@@ -1322,7 +1322,7 @@ __global__ void sp_scale2_kernel(const double* __restrict__ w, const double* __r
 // ---- host-side driver object -----------------------------------------------------------------------------
 template <class T>
 static int up(T** d, const std::vector<T>& h) {
-    KKT_HIP_CHECK(hipMalloc(d, sizeof(T) * (h.size() ? h.size() : 1)));
+    KKT_HIP_CHECK(DEV_ALLOC(d, sizeof(T) * (h.size() ? h.size() : 1)));
     if (!h.empty()) KKT_HIP_CHECK(memcpy_sync(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
     return 0;
 }
@@ -1371,9 +1371,9 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
         E.tv_info_at = at;
         at += sizeof(int) * std::max<size_t>(1, S.vb.size());
         E.tv_state_bytes = at;
-        KKT_HIP_CHECK(hipMalloc(&E.d_tv_state, at));
+        KKT_HIP_CHECK(DEV_ALLOC(&E.d_tv_state, at));
     }
-    KKT_HIP_CHECK(hipMalloc(&E.d_tv_linv, sizeof(double) * 2048 * (size_t)std::max(1, S.tv_linv_max)));
+    KKT_HIP_CHECK(DEV_ALLOC(&E.d_tv_linv, sizeof(double) * 2048 * (size_t)std::max(1, S.tv_linv_max)));
     if (int e = potrf_work_init_batched(E.pw_vb, std::max(1, S.vb_maxcount))) return e;
     {   // G in CSC (values + int rows) and CSR (for G x)
         std::vector<double> gvals(gv, gv + gnnz), hvals;
@@ -1429,8 +1429,8 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     for (int s = 0; s < S.ns; ++s)
         rem_off[s + 1] = rem_off[s] + (S.sn_rowptr[s + 1] - S.sn_rowptr[s]) - (S.sn_first[s + 1] - S.sn_first[s]);
     if (int e = up(&E.d_rem_off, rem_off)) return e;
-    KKT_HIP_CHECK(hipMalloc(&E.d_rem, sizeof(double) * (rem_off[S.ns] ? rem_off[S.ns] : 1)));
-    KKT_HIP_CHECK(hipMalloc(&E.d_panels, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
+    KKT_HIP_CHECK(DEV_ALLOC(&E.d_rem, sizeof(double) * (rem_off[S.ns] ? rem_off[S.ns] : 1)));
+    KKT_HIP_CHECK(DEV_ALLOC(&E.d_panels, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
     {   // the panels as chunks of at most SP_ZERO_CHUNK doubles (sp_zero_chunks_kernel); the first factorisation's store is cleared
         // as a whole once (nothing but the panels and the lower triangles of the update matrices is ever read, but let it be defined)
         KKT_HIP_CHECK(memset_sync(E.d_panels, 0, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
@@ -1448,7 +1448,7 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
         if (int e = up(&E.d_zero_len, zlen)) return e;
     }
     E.d_upd = nullptr;          // update matrices live in the same buffer (offsets are absolute)
-    KKT_HIP_CHECK(hipMalloc(&E.d_xp, sizeof(double) * (n ? n : 1)));
+    KKT_HIP_CHECK(DEV_ALLOC(&E.d_xp, sizeof(double) * (n ? n : 1)));
     {   // the wide supernodes as jobs of the batched persistent triangular solve (single right-hand side: x = d_xp)
         std::vector<TrsvJob> jobs(S.wide.size());
         for (size_t k = 0; k < S.wide.size(); ++k) {
@@ -1468,13 +1468,13 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
         for (int l = 0; l < S.nlevels; ++l)
             for (int k = S.wide_ptr[l]; k < S.wide_ptr[l + 1]; ++k)
                 E.wide_maxw[l] = std::max(E.wide_maxw[l], S.sn_first[S.wide[k] + 1] - S.sn_first[S.wide[k]]);
-        KKT_HIP_CHECK(hipMalloc(&E.d_wide_jobs, sizeof(TrsvJob) * std::max<size_t>(1, jobs.size())));
+        KKT_HIP_CHECK(DEV_ALLOC(&E.d_wide_jobs, sizeof(TrsvJob) * std::max<size_t>(1, jobs.size())));
         if (!jobs.empty()) KKT_HIP_CHECK(memcpy_sync(E.d_wide_jobs, jobs.data(), sizeof(TrsvJob) * jobs.size(), hipMemcpyHostToDevice));
         if (int e = up(&E.d_wide, S.wide)) return e;
         if (int e = up(&E.d_ea_off, S.ea_off)) return e;
         if (int e = up(&E.d_ea_lb, S.ea_lb)) return e;
     }
-    KKT_HIP_CHECK(hipMalloc(&E.d_info, sizeof(int)));
+    KKT_HIP_CHECK(DEV_ALLOC(&E.d_info, sizeof(int)));
     KKT_HIP_CHECK(hipHostMalloc(&E.h_info, sizeof(int)));
     return 0;
 }
@@ -1486,7 +1486,7 @@ void sparse_engine_free(SparseEngine& E) {
                     E.d_panels, E.d_upd, E.d_xp, E.d_info, E.d_heavy, E.d_vb, E.d_hrp, E.d_hci, E.d_hmap, E.d_rem_multi, E.d_iperm,
                     E.d_tv_tickets, E.d_tv_prog_off, E.d_tv_linv_off, E.d_tv_state, E.d_tv_linv, E.d_wide_jobs, E.d_wide, E.d_ea_off, E.d_ea_lb, E.d_zero_off, E.d_zero_len};
     for (void* p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)dev_free(p);
     if (E.h_info) (void)hipHostFree(E.h_info);
     potrf_work_free(E.pw_vb);
     E = SparseEngine();
@@ -1705,9 +1705,9 @@ int sparse_engine_forward_rows(SparseEngine& E, const double* d_A, int64_t lda, 
     const SpDev d = devview(E);
     const int64_t remtot = S.sn_rowptr[S.ns] - (int64_t)E.n;        // sum over supernodes of (h - w)
     if (E.rem_multi_cols < nrhs) {
-        if (E.d_rem_multi) (void)hipFree(E.d_rem_multi);
+        if (E.d_rem_multi) (void)dev_free(E.d_rem_multi);
         E.d_rem_multi = nullptr;
-        KKT_HIP_CHECK(hipMalloc(&E.d_rem_multi, sizeof(double) * (size_t)(remtot > 0 ? remtot : 1) * nrhs));
+        KKT_HIP_CHECK(DEV_ALLOC(&E.d_rem_multi, sizeof(double) * (size_t)(remtot > 0 ? remtot : 1) * nrhs));
         E.rem_multi_cols = nrhs;
     }
     for (int j0 = 0; j0 < nrhs; j0 += 65535) {                      // grid.y / grid.z limit
@@ -1750,10 +1750,10 @@ int sparse_engine_forward_rows_csr(SparseEngine& E, const int64_t* d_rp, const i
     const int64_t remtot = S.sn_rowptr[S.ns] - (int64_t)E.n;
     const int need = std::min(chunk, nrhs);
     if (E.rem_multi_cols < need) {
-        if (E.d_rem_multi) (void)hipFree(E.d_rem_multi);
+        if (E.d_rem_multi) (void)dev_free(E.d_rem_multi);
         E.d_rem_multi = nullptr;
         E.rem_multi_cols = 0;
-        KKT_HIP_CHECK(hipMalloc(&E.d_rem_multi, sizeof(double) * (size_t)(remtot > 0 ? remtot : 1) * need));
+        KKT_HIP_CHECK(DEV_ALLOC(&E.d_rem_multi, sizeof(double) * (size_t)(remtot > 0 ? remtot : 1) * need));
         E.rem_multi_cols = need;
     }
     for (int j0 = 0; j0 < nrhs; j0 += chunk) {

@@ -42,11 +42,20 @@ int mi355kkt_test_throw(int kind);
 /* Knobs of the sparse symbolic analysis and a few kernel-selection thresholds (csrc/knobs.h): "MI355KKT_ORDERING" = nd | amd,
  * "MI355KKT_ND_MODE", "MI355KKT_ND_LEAF", "MI355KKT_ND_LEAF_AMD", "MI355KKT_ND_NOREFINE", "MI355KKT_ORDERING_BOTH",
  * "MI355KKT_SN_MAXW", "MI355KKT_SPARSE_BIG_FLOPS", "MI355KKT_SPARSE_BIG_H", "MI355KKT_SP_WIDE", "MI355KKT_SPARSE_TILES",
- * "MI355KKT_SDP_WAVE_MAX", "MI355KKT_SDP_NO_MFMA", "MI355KKT_SPARSE_DEBUG", "MI355KKT_ND_DEBUG", "MI355KKT_SPARSE_POISON", "MI355KKT_ALLOC_POISON"
- * (every device allocation starts as 0xff bytes instead of zeros).  They are set ONLY by this
+ * "MI355KKT_SDP_WAVE_MAX", "MI355KKT_SDP_NO_MFMA", "MI355KKT_SPARSE_DEBUG", "MI355KKT_ND_DEBUG", "MI355KKT_SPARSE_POISON",
+ * "MI355KKT_TRSV_PAIR" (0: the one-sweep triangular solve), "MI355KKT_SPARSE_NO_DENSE_ROOT", and the allocator modes below.  They are set ONLY by this
  * call -- the library never reads them from the environment -- so that tests can drive every ordering / plan shape through the
  * same code.  value == NULL unsets one knob, name == NULL all of them.  Process-wide; returns 0. */
 int mi355kkt_test_set_knob(const char* name, const char* value);
+
+/* Device-allocator test modes (csrc/devmem.cpp), knobs of mi355kkt_test_set_knob: "MI355KKT_ALLOC_POISON" (blocks start as 0xff
+ * bytes), "MI355KKT_ALLOC_RAW" (blocks are not cleared), "MI355KKT_ALLOC_GUARD" (every block ends where its own mapping ends: an
+ * out-of-bounds access of a kernel is a GPU memory fault at once).
+ * mi355kkt_test_install_abort_dump: on SIGABRT the ring of the last 65536 allocations / releases (pointer, bytes, call site) is
+ * written to `path` before the previous handler runs -- maps the address of a reported GPU memory fault to its owner
+ * (tools/alloc_owner.py).  mi355kkt_test_guard_probe: reads element `at` of a fresh block of ndoubles doubles from a kernel. */
+int mi355kkt_test_install_abort_dump(const char* path);
+int mi355kkt_test_guard_probe(int ndoubles, int at, double* out);
 
 #ifdef __cplusplus
 }

@@ -122,18 +122,29 @@ class _Knobs(object):
         _capi.set_knob(name, None)
 
 
+_SESSION_KNOBS = (("MI355KKT_TEST_ALLOC_POISON", "MI355KKT_ALLOC_POISON"), ("MI355KKT_TEST_ALLOC_GUARD", "MI355KKT_ALLOC_GUARD"),
+                  ("MI355KKT_TEST_ALLOC_RAW", "MI355KKT_ALLOC_RAW"))
+
+
 def _session_knobs():
-    """MI355KKT_TEST_ALLOC_POISON=1 in the environment of a GPU test run: every device allocation of the library starts as 0xff
-    bytes (test knob MI355KKT_ALLOC_POISON, csrc/kkt_common.h: malloc_zeroed) -- a hunt for reads of memory nobody wrote"""
-    if os.environ.get("MI355KKT_TEST_ALLOC_POISON") == "1":
-        from cvxopt_amd import _capi
-        _capi.set_knob("MI355KKT_ALLOC_POISON", "1")
+    """Allocator test modes for a whole GPU test run, from the ENVIRONMENT OF THE TEST SESSION (the library itself never reads it;
+    csrc/devmem.cpp): MI355KKT_TEST_ALLOC_POISON=1 -- every device allocation starts as 0xff bytes (a hunt for reads of memory
+    nobody wrote); MI355KKT_TEST_ALLOC_GUARD=1 -- every block ends where its own mapping ends (an out-of-bounds access of a kernel
+    is a GPU memory fault in the test that performs it); MI355KKT_TEST_ALLOC_RAW=1 -- blocks are not cleared at all."""
+    from cvxopt_amd import _capi
+    for env, knob in _SESSION_KNOBS:
+        if os.environ.get(env) == "1":
+            _capi.set_knob(knob, "1")
 
 
 @pytest.fixture(scope="session", autouse=True)
 def _apply_session_knobs():
-    if os.environ.get("MI355KKT_TEST_ALLOC_POISON") == "1" and _gpu_count() > 0:
+    if _gpu_count() > 0 and os.environ.get("MI355KKT_TEST_ASSUME_GPU") != "1":
         _session_knobs()
+        dump = os.environ.get("MI355KKT_TEST_ABORT_DUMP")       # path: allocation ring written there on SIGABRT
+        if dump:
+            from cvxopt_amd import _capi
+            _capi.lib().mi355kkt_test_install_abort_dump(dump.encode())
     yield
 
 

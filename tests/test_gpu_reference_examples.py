@@ -102,6 +102,9 @@ def _as_array(v, depth=0):
 # chap6/basispursuit is left out: it hands conelp its own kktsolver (nothing of this backend runs) and spends 75 s in Python
 SKIP = {"chap6/basispursuit"}
 FIXTURE = os.path.join(ROOT, "tests", "golden", "book_examples.npz")
+# MI355KKT_BOOK_INPROCESS=1: the scripts run inside the pytest process (one long-lived process with the whole suite's history in
+# front of chap7/probbounds' 451 solver handles: the conditions of the round-4 abort); otherwise one interpreter per script
+INPROCESS = os.environ.get("MI355KKT_BOOK_INPROCESS", "0") == "1"
 
 
 def reference_results():
@@ -154,18 +157,21 @@ def test_book_example_same_results_through_the_backend(ref_cvxopt, example, tmp_
     import subprocess
     fx = np.load(FIXTURE, allow_pickle=False)
     ref = {k.split("::", 1)[1]: fx[k] for k in fx.files if k.startswith(example + "::")}
-    out = str(tmp_path / "got.npz")
-    env = dict(os.environ, PYTHONFAULTHANDLER="1")
-    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
-    child = subprocess.run([sys.executable, os.path.abspath(__file__), example, out], env=env, cwd=ROOT, capture_output=True,
-                           text=True, timeout=900)
-    if child.returncode != 0 or not os.path.exists(out):
-        pytest.fail("the interpreter running %s ended with code %s\n--- stdout (tail)\n%s\n--- stderr (tail)\n%s"
-                    % (example, child.returncode, child.stdout[-2000:], child.stderr[-6000:]))
-    z = np.load(out, allow_pickle=False)
-    meta = json.loads(str(z["__meta__"]))
-    got = {k: z[k] for k in z.files if k != "__meta__"}
-    calls, seconds = meta["calls"], meta["seconds"]
+    if INPROCESS:
+        got, calls, seconds = _run_through_backend(example)
+    else:
+        out = str(tmp_path / "got.npz")
+        env = dict(os.environ, PYTHONFAULTHANDLER="1")
+        env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), example, out], env=env, cwd=ROOT, capture_output=True,
+                               text=True, timeout=900)
+        if child.returncode != 0 or not os.path.exists(out):
+            pytest.fail("the interpreter running %s ended with code %s\n--- stdout (tail)\n%s\n--- stderr (tail)\n%s"
+                        % (example, child.returncode, child.stdout[-2000:], child.stderr[-6000:]))
+        z = np.load(out, allow_pickle=False)
+        meta = json.loads(str(z["__meta__"]))
+        got = {k: z[k] for k in z.files if k != "__meta__"}
+        calls, seconds = meta["calls"], meta["seconds"]
     assert set(got) == set(ref), sorted(set(got) ^ set(ref))
     worst, which = 0.0, None
     for k in ref:

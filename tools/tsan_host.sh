@@ -15,7 +15,7 @@ for f in gemm_f64 potrf blas2 cone_scale sparse_chol batch_ipm conelp_ipm coneqp
   ( "$HIPCC" --offload-arch=gfx950 -std=c++17 -fPIC $SAN -I"$ROOT/include" -c "$SRC/$f.hip" -o "$OUT/$f.o" ) &
   pids+=($!)
 done
-for f in ordering knobs; do
+for f in ordering knobs devmem; do
   ( "$HIPCC" -std=c++17 -fPIC $SAN -c "$SRC/$f.cpp" -o "$OUT/$f.o" ) &
   pids+=($!)
 done
