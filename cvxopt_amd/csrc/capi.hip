@@ -830,6 +830,9 @@ int mi355kkt_set_H_dense(mi355kkt_solver* h, const double* H, int64_t ldH) try {
     }
     if (ldH < (h->n > 1 ? h->n : 1)) { set_last_error("set_H_dense: ldH too small"); return MI355KKT_EINVAL; }
     if (!h->H_owned) KKT_HIP_CHECK(DEV_ALLOC(&h->H_owned, sizeof(double) * dmax((size_t)h->n * h->n, 1)));
+    // nothing on the compute stream may still read the old H (a queued solve_device of the ldl flavours reads it for its residual,
+    // a device loop for P x): the copy below is only ordered on the legacy stream
+    if (h->st) KKT_HIP_CHECK(hipStreamSynchronize(h->st));
     if (h->n > 0)
         KKT_HIP_CHECK(memcpy2d_sync(h->H_owned, sizeof(double) * h->n, H, sizeof(double) * ldH, sizeof(double) * h->n,
                                   h->n, hipMemcpyHostToDevice));

@@ -278,7 +278,7 @@ int cone_layout_build_s(ConeLayout& cl, int lq_rows, const std::vector<int>& s) 
 int launch_sdp_scale_pack(const ConeLayout& cl, const double* in, int64_t ldi, double* out, int64_t ldo, int ncols,
                           const double* d_rti, double extra, hipStream_t st) {
     if (cl.ns == 0 || ncols <= 0) return 0;
-    static const bool no_mfma = dev_knob("MI355KKT_SDP_NO_MFMA") != nullptr;
+    const bool no_mfma = dev_knob("MI355KKT_SDP_NO_MFMA") != nullptr;
     if (cl.s_maxn > SDP_MAXN && ncols >= 16 && !no_mfma) {
         // a whole matrix of columns (Gs = W^-T G): blocks > 80 as two batched FP64-MFMA products each (gemm_f64.hip),
         // the smaller ones through the LDS-resident kernel

@@ -8,7 +8,10 @@
 
 namespace mi355kkt {
 
-const char* dev_knob(const char* name);                    // nullptr: not set
+// nullptr: not set.  The returned string is a copy owned by the calling thread, valid until that thread's next dev_knob() call.
+// Knobs are read where a plan / an engine is CREATED (or once per call): nothing is latched in function-local statics, so a
+// later mi355kkt_test_set_knob() -- or the reset between two tests -- always takes effect.
+const char* dev_knob(const char* name);
 int set_dev_knob(const char* name, const char* value);     // value == nullptr: unset; name == nullptr: unset all
 
 }  // namespace mi355kkt

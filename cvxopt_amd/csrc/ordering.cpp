@@ -1010,7 +1010,7 @@ void fill_reducing_ordering(const Graph& adj, std::vector<int>& order, int metho
             run_amd();
         }
     };
-    static const bool amd_always = dev_knob("MI355KKT_ORDERING_BOTH") != nullptr;
+    const bool amd_always = dev_knob("MI355KKT_ORDERING_BOTH") != nullptr;
     if (method == 0 && (n < 2000 || amd_always)) start_amd();
     else if (method == 2) run_amd();
     if (method != 2) {

@@ -929,14 +929,26 @@ __device__ __forceinline__ bool tile_process(const TileJob& J, TileCtl* ctl, int
             }
             solve_block(cbc);
             // column block cb of the tile is final: to memory (write-through)
-            if (row < mi) {
+            if (announce && mi == NB) {
+                // a whole tile on the chain: every lane stores, NO branch between this block's four stores and the wait -- they sit
+                // in one basic block, which is what tools/check_stream_isa.py verifies on the compiled code
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st_wt(A + i0 + row + (int64_t)(j0 + 16 * cb + lq + 4 * r) * lda, acc[cb][r]);
-            }
-            if (announce && cb > 0) {                     // blocks 0 .. cb-1 were stored a block ago: drained by now
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (all but this block's four stores)
-                __syncthreads();
-                if (tid == 0) __hip_atomic_store(J.micro_i, (unsigned)cb, RLX_AGENT_);
+                if (cb > 0) {                             // blocks 0 .. cb-1 were stored a block ago: drained by now
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (all but this block's four stores)
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(J.micro_i, (unsigned)cb, RLX_AGENT_);
+                }
+            } else {
+                if (row < mi) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st_wt(A + i0 + row + (int64_t)(j0 + 16 * cb + lq + 4 * r) * lda, acc[cb][r]);
+                }
+                if (announce && cb > 0) {                 // ragged last factored tile of a front: lanes past its rows store nothing,
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // so the count of outstanding stores is not known: drain all
+                    __syncthreads();
+                    if (tid == 0) __hip_atomic_store(J.micro_i, (unsigned)cb, RLX_AGENT_);
+                }
             }
             return true;
         };

@@ -712,7 +712,7 @@ constexpr int64_t SP_HEAVY = 32768;     // supernodes with more off-diagonal pan
 // (128; at most 256, the capacity of the kernels' LDS vector; $MI355KKT_SP_WIDE: experiments.  46^3: solve 1.98 ms at 256,
 // 1.76 ms at 128, 1.74 ms at 64)
 int sp_wide_threshold() {
-    static const int v = dev_knob("MI355KKT_SP_WIDE") ? std::min(256, std::max(32, atoi(dev_knob("MI355KKT_SP_WIDE")))) : 128;
+    const int v = dev_knob("MI355KKT_SP_WIDE") ? std::min(256, std::max(32, atoi(dev_knob("MI355KKT_SP_WIDE")))) : 128;
     return v;
 }
 
@@ -1431,9 +1431,8 @@ int sparse_engine_create(SparseEngine& E, int n, int m, const int64_t* gcp, cons
     if (int e = up(&E.d_rem_off, rem_off)) return e;
     KKT_HIP_CHECK(DEV_ALLOC(&E.d_rem, sizeof(double) * (rem_off[S.ns] ? rem_off[S.ns] : 1)));
     KKT_HIP_CHECK(DEV_ALLOC(&E.d_panels, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
-    {   // the panels as chunks of at most SP_ZERO_CHUNK doubles (sp_zero_chunks_kernel); the first factorisation's store is cleared
-        // as a whole once (nothing but the panels and the lower triangles of the update matrices is ever read, but let it be defined)
-        KKT_HIP_CHECK(memset_sync(E.d_panels, 0, sizeof(double) * (S.store_doubles ? S.store_doubles : 1)));
+    {   // the panels as chunks of at most SP_ZERO_CHUNK doubles (sp_zero_chunks_kernel); the store as a whole starts defined: the
+        // allocator cleared it (devmem.cpp) -- nothing but the panels and the lower triangles of the update matrices is ever read
         std::vector<int64_t> zoff;
         std::vector<int> zlen;
         for (int sn = 0; sn < S.ns; ++sn) {
@@ -1527,7 +1526,7 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
         hipLaunchKernelGGL(sp_assemble_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, nt, E.d_asm_slot,
                            E.d_asm_ptr, E.d_asm_a, E.d_asm_b, E.d_asm_r, E.d_gv, E.d_hv, d_di, E.d_panels);
     const SpDev d = devview(E);
-    static const bool old_chain = dev_knob("MI355KKT_SPARSE_TILES") && !strcmp(dev_knob("MI355KKT_SPARSE_TILES"), "0");
+    const bool old_chain = dev_knob("MI355KKT_SPARSE_TILES") && !strcmp(dev_knob("MI355KKT_SPARSE_TILES"), "0");
     if (!old_chain) KKT_HIP_CHECK(hipMemsetAsync(E.d_tv_state, 0, E.tv_state_bytes, st));
     for (int l = 0; l < S.nlevels; ++l) {
         const int nsmall = S.level_nsmall[l];

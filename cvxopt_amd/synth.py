@@ -90,3 +90,54 @@ def tet_mesh_laplacian(n, seed=0, shift=1e-2):
     A = sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(n, n)).tocsc()
     A.data[:] = 1.0                      # duplicates were summed: back to a 0/1 adjacency matrix
     return (sp.diags(np.asarray(A.sum(1)).ravel() + shift) - A).tocsc()
+
+
+def tet_mesh_elasticity(nnodes, seed=0, shift=1e-2):
+    """3 degrees of freedom per node on the Delaunay tetrahedralisation of `nnodes` random points in the unit cube: the stiffness
+    matrix of the pin-jointed network of its edges (every edge a spring of unit stiffness along its direction d plus a weak
+    isotropic part: block (d d' + 0.1 I) on the two diagonal positions, its negative off the diagonal) + shift I.  Symmetric
+    positive definite, order 3 nnodes, irregular 3 x 3 block pattern with ~47 entries per row -- the structure (vector unknowns on an
+    unstructured 3-D mesh) of the structural-mechanics matrices of the SuiteSparse collection the sparse config names, which no
+    Laplacian has (scipy.sparse CSC)."""
+    import scipy.sparse as sp
+    from scipy.spatial import Delaunay
+    pts = np.random.default_rng(seed).random((nnodes, 3))
+    t = Delaunay(pts).simplices
+    e = np.concatenate([t[:, [a, b]] for a in range(4) for b in range(a + 1, 4)])
+    e = np.unique(np.sort(e, axis=1), axis=0)                # every edge once, (i < j)
+    d = pts[e[:, 1]] - pts[e[:, 0]]
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    B = d[:, :, None] * d[:, None, :] + 0.1 * np.eye(3)[None, :, :]        # one 3 x 3 block per edge
+    i3, j3 = 3 * e[:, 0], 3 * e[:, 1]
+    a, b = np.meshgrid(np.arange(3), np.arange(3), indexing='ij')
+    rows, cols, vals = [], [], []
+    for (r0, c0, sgn) in ((i3, i3, 1.0), (j3, j3, 1.0), (i3, j3, -1.0), (j3, i3, -1.0)):
+        rows.append((r0[:, None, None] + a[None]).ravel())
+        cols.append((c0[:, None, None] + b[None]).ravel())
+        vals.append((sgn * (B if sgn > 0 or r0 is i3 else np.transpose(B, (0, 2, 1)))).ravel())
+    n = 3 * nnodes
+    K = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsc()
+    K = ((K + K.T) * 0.5 + shift * sp.eye(n)).tocsc()
+    K.sort_indices()
+    return K
+
+
+def read_matrix_market(path, shift=0.0):
+    """A symmetric positive definite matrix from a Matrix-Market file (coordinate real general / symmetric; a pattern file gets the
+    graph Laplacian of its pattern) as scipy.sparse CSC, for `bench.py --workload sparse --mtx FILE` -- the door for the
+    SuiteSparse matrix BASELINE configs[3] names on the day its file is reachable (there is no network in the build).  The
+    matrix is symmetrised ((A + A')/2); `shift` adds shift * max|diag| * I for files that are only semidefinite."""
+    import scipy.io
+    import scipy.sparse as sp
+    A = scipy.io.mmread(path)
+    A = sp.csc_matrix(A)
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("%s: %d x %d is not square" % (path, A.shape[0], A.shape[1]))
+    if A.dtype.kind not in "fiu":                         # (pattern files come back as ones)
+        raise ValueError("%s: real matrices only" % path)
+    A = A.astype(np.float64)
+    A = ((A + A.T) * 0.5).tocsc()
+    if shift:
+        A = (A + shift * float(np.max(np.abs(A.diagonal()))) * sp.eye(A.shape[0])).tocsc()
+    A.sort_indices()
+    return A
