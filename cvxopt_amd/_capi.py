@@ -118,6 +118,7 @@ SIGNATURES = {
     "mi355kkt_test_set_knob": (C.c_int, [C.c_char_p, C.c_char_p]),
     "mi355kkt_test_install_abort_dump": (C.c_int, [C.c_char_p]),
     "mi355kkt_test_guard_probe": (C.c_int, [C.c_int, C.c_int, c_double_p]),
+    "mi355kkt_test_guard_violations": (C.c_int, []),
     "mi355kkt_op_mfma_f64_peak": (C.c_int, [C.c_int, c_float_p]),
     "mi355kkt_op_potrf": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, c_int_p, c_float_p]),
     "mi355kkt_op_trsm_lower": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int,

@@ -8,13 +8,14 @@
 //   MI355KKT_ALLOC_POISON   every byte starts as 0xff (NaN in every double, -1 in every int): a read of memory nobody wrote
 //                           changes a result instead of being hidden by the zeros
 //   MI355KKT_ALLOC_RAW      no clear at all (the block's history shows through: the conditions of the round-4 abort)
-//   MI355KKT_ALLOC_GUARD    "electric fence" for the GPU: every allocation is its own >= 2 MB mapping (which bypasses the
-//                           runtime's sub-allocator for small blocks) and the caller's block is placed at the END of it, so that
-//                           the first byte past the block is the first byte of an unmapped page: an out-of-bounds access by a
-//                           kernel -- also the "harmless" over-read of a vector load whose tail is masked -- becomes a memory
-//                           access fault at once, in the test that performs it, instead of once in 2000 handles when a block
-//                           happens to end where a mapping ends.  (8-byte granularity: blocks whose size is not a multiple of 8
-//                           keep up to 7 bytes of slack.)
+//   MI355KKT_ALLOC_GUARD    "electric fence" for the GPU: every allocation is its own mapping of a whole number of 2 MB (which
+//                           bypasses the runtime's sub-allocator for small blocks), filled with 0xff, and the caller's block is
+//                           placed at the END of it: the first byte past the block is either unmapped or the poisoned front of the
+//                           next guarded mapping.  An out-of-bounds access by a kernel -- also the "harmless" over-read of a
+//                           vector load whose tail is masked -- becomes a memory fault (reported by the runtime as an error of
+//                           the next synchronisation) or a NaN at once, in the test that performs it, instead of once in 2000
+//                           handles when a block happens to end where a mapping ends.  (8-byte granularity: blocks whose size
+//                           is not a multiple of 8 keep up to 7 bytes of slack.)
 // Every allocation and release is also written to a ring of the last 65536 events; mi355kkt_test_install_abort_dump(path)
 // installs a SIGABRT handler that writes the ring to `path` before the previous handler runs: the HIP runtime reports a GPU
 // memory fault with the faulting address and abort()s on one of its own threads, and the ring maps that address to its owner
@@ -122,10 +123,13 @@ hipError_t dev_alloc(void** p, size_t bytes, const char* file, int line) {
     const int fill = dev_knob("MI355KKT_ALLOC_POISON") ? 0xff : 0;
     const bool raw = dev_knob("MI355KKT_ALLOC_RAW") != nullptr;
     if (guard) {
+        // (measured, call r5c01: the runtime rounds a >= 2 MB allocation up to a multiple of 2 MB and maps all of it -- a block placed
+        //  at the end of a request that is NOT such a multiple is followed by up to 2 MB of readable padding.  So the request is a
+        //  multiple of 2 MB with at least 4 KB of poison in front of the block: what follows the block is either unmapped or the
+        //  0xff-poisoned front of the neighbouring guarded mapping -- a fault or a NaN, never a plausible number.)
         constexpr size_t PAGE = 4096, HUGE = (size_t)2 << 20;
         const size_t user = (bytes + 7) & ~(size_t)7;
-        size_t total = HUGE + ((user + PAGE - 1) & ~(PAGE - 1));
-        if (total % HUGE == 0) total += PAGE;              // the mapping must not end on a 2 MB boundary a neighbour may start at
+        const size_t total = (user + PAGE + HUGE - 1) / HUGE * HUGE;
         void* base = nullptr;
         hipError_t e = hipMalloc(&base, total);
         if (e != hipSuccess) return e;
@@ -153,16 +157,37 @@ hipError_t dev_alloc(void** p, size_t bytes, const char* file, int line) {
     return e;
 }
 
+std::atomic<int> g_violations{0};
+int guard_violations() { return g_violations.load(); }
+
 hipError_t dev_free(void* p) {
     if (!p) return hipSuccess;
     record(p, 0, nullptr, 0, 2);
     void* base = p;
+    bool guarded = false;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = guard_bases().find(p);
         if (it != guard_bases().end()) {
             base = it->second;
             guard_bases().erase(it);
+            guarded = true;
+        }
+    }
+    if (guarded) {
+        // an out-of-bounds WRITE behind the block that precedes this mapping lands in the first bytes of its poisoned front
+        // (at least 4 KB of 0xff): look at them before the mapping goes
+        unsigned char front[4096];
+        if (hipMemcpy(front, base, sizeof(front), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (size_t i = 0; i < sizeof(front); ++i)
+                if (front[i] != 0xff) {
+                    g_violations.fetch_add(1);
+                    fprintf(stderr, "mi355kkt guard: byte %zu in front of block %p is 0x%02x, not poison: something wrote past the end of "
+                                    "the block mapped before it\n", i, p, front[i]);
+                    break;
+                }
+        } else {
+            (void)hipGetLastError();
         }
     }
     return hipFree(base);

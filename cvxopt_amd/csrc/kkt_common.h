@@ -53,6 +53,7 @@ inline hipError_t memset_sync(void* p, int value, size_t bytes) {
 hipError_t dev_alloc(void** p, size_t bytes, const char* file, int line);
 hipError_t dev_free(void* p);
 int install_abort_dump(const char* path);
+int guard_violations();          // MI355KKT_ALLOC_GUARD: overwritten poison found so far (an out-of-bounds write)
 template <class T>
 inline hipError_t dev_alloc_typed(T** p, size_t bytes, const char* file, int line) {
     return dev_alloc(reinterpret_cast<void**>(p), bytes, file, line);

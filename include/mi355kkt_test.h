@@ -50,12 +50,15 @@ int mi355kkt_test_set_knob(const char* name, const char* value);
 
 /* Device-allocator test modes (csrc/devmem.cpp), knobs of mi355kkt_test_set_knob: "MI355KKT_ALLOC_POISON" (blocks start as 0xff
  * bytes), "MI355KKT_ALLOC_RAW" (blocks are not cleared), "MI355KKT_ALLOC_GUARD" (every block ends where its own mapping ends: an
- * out-of-bounds access of a kernel is a GPU memory fault at once).
+ * out-of-bounds access of a kernel is a GPU memory fault or reads 0xff poison at once), "MI355KKT_PIN_SMALL_H" (set_H_dense_async pins
+ * a host H of any size in place, as the round-4 build did).
  * mi355kkt_test_install_abort_dump: on SIGABRT the ring of the last 65536 allocations / releases (pointer, bytes, call site) is
  * written to `path` before the previous handler runs -- maps the address of a reported GPU memory fault to its owner
  * (tools/alloc_owner.py).  mi355kkt_test_guard_probe: reads element `at` of a fresh block of ndoubles doubles from a kernel. */
 int mi355kkt_test_install_abort_dump(const char* path);
 int mi355kkt_test_guard_probe(int ndoubles, int at, double* out);
+/* MI355KKT_ALLOC_GUARD: number of released blocks whose poisoned front had been overwritten (an out-of-bounds write) */
+int mi355kkt_test_guard_violations(void);
 
 #ifdef __cplusplus
 }

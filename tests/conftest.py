@@ -62,6 +62,11 @@ def pytest_sessionfinish(session, exitstatus):
     gc.collect()
     try:
         from cvxopt_amd import _capi
+        if os.environ.get("MI355KKT_TEST_ALLOC_GUARD") == "1":
+            nv = _capi.lib().mi355kkt_test_guard_violations()
+            print("\nmi355kkt guard: %d overwritten fronts (out-of-bounds writes) in this session" % nv)
+            if nv and session.exitstatus == 0:
+                session.exitstatus = 1
         if os.environ.get("MI355KKT_TEST_ASSUME_GPU") != "1":
             _capi.lib().mi355kkt_device_synchronize()
         if "torch" in sys.modules and sys.modules["torch"].cuda.is_available():
@@ -123,14 +128,15 @@ class _Knobs(object):
 
 
 _SESSION_KNOBS = (("MI355KKT_TEST_ALLOC_POISON", "MI355KKT_ALLOC_POISON"), ("MI355KKT_TEST_ALLOC_GUARD", "MI355KKT_ALLOC_GUARD"),
-                  ("MI355KKT_TEST_ALLOC_RAW", "MI355KKT_ALLOC_RAW"))
+                  ("MI355KKT_TEST_ALLOC_RAW", "MI355KKT_ALLOC_RAW"), ("MI355KKT_TEST_PIN_SMALL_H", "MI355KKT_PIN_SMALL_H"))
 
 
 def _session_knobs():
     """Allocator test modes for a whole GPU test run, from the ENVIRONMENT OF THE TEST SESSION (the library itself never reads it;
     csrc/devmem.cpp): MI355KKT_TEST_ALLOC_POISON=1 -- every device allocation starts as 0xff bytes (a hunt for reads of memory
     nobody wrote); MI355KKT_TEST_ALLOC_GUARD=1 -- every block ends where its own mapping ends (an out-of-bounds access of a kernel
-    is a GPU memory fault in the test that performs it); MI355KKT_TEST_ALLOC_RAW=1 -- blocks are not cleared at all."""
+    is a GPU memory fault or a NaN in the test that performs it); MI355KKT_TEST_ALLOC_RAW=1 -- blocks are not cleared at all;
+    MI355KKT_TEST_PIN_SMALL_H=1 -- a host H of any size is pinned in place (RAW + PIN_SMALL_H = the build that aborted in round 4)."""
     from cvxopt_amd import _capi
     for env, knob in _SESSION_KNOBS:
         if os.environ.get(env) == "1":
