@@ -133,13 +133,18 @@ _SESSION_KNOBS = (("MI355KKT_TEST_ALLOC_POISON", "MI355KKT_ALLOC_POISON"), ("MI3
 
 def _session_knobs():
     """Allocator test modes for a whole GPU test run, from the ENVIRONMENT OF THE TEST SESSION (the library itself never reads it;
-    csrc/devmem.cpp): MI355KKT_TEST_ALLOC_POISON=1 -- every device allocation starts as 0xff bytes (a hunt for reads of memory
-    nobody wrote); MI355KKT_TEST_ALLOC_GUARD=1 -- every block ends where its own mapping ends (an out-of-bounds access of a kernel
+    csrc/devmem.cpp): MI355KKT_TEST_ALLOC_POISON (default ON for GPU sessions, =0 to switch off) -- every device allocation starts as
+    0xff bytes: a read of memory nobody wrote changes a result; MI355KKT_TEST_ALLOC_GUARD=1 -- every block ends where its own mapping ends (an out-of-bounds access of a kernel
     is a GPU memory fault or a NaN in the test that performs it); MI355KKT_TEST_ALLOC_RAW=1 -- blocks are not cleared at all;
     MI355KKT_TEST_PIN_SMALL_H=1 -- a host H of any size is pinned in place (RAW + PIN_SMALL_H = the build that aborted in round 4)."""
+    if _gpu_count() <= 0 or os.environ.get("MI355KKT_TEST_ASSUME_GPU") == "1":
+        return
     from cvxopt_amd import _capi
     for env, knob in _SESSION_KNOBS:
-        if os.environ.get(env) == "1":
+        # poison is the DEFAULT of a GPU test session (MI355KKT_TEST_ALLOC_POISON=0 switches it off): the product clears its
+        # device blocks to zero, and no test may pass only because of that
+        on = os.environ.get(env, "1" if env == "MI355KKT_TEST_ALLOC_POISON" else "0") == "1"
+        if on and not (env == "MI355KKT_TEST_ALLOC_POISON" and os.environ.get("MI355KKT_TEST_ALLOC_RAW") == "1"):
             _capi.set_knob(knob, "1")
 
 

@@ -102,9 +102,10 @@ def _as_array(v, depth=0):
 # chap6/basispursuit is left out: it hands conelp its own kktsolver (nothing of this backend runs) and spends 75 s in Python
 SKIP = {"chap6/basispursuit"}
 FIXTURE = os.path.join(ROOT, "tests", "golden", "book_examples.npz")
-# MI355KKT_BOOK_INPROCESS=1: the scripts run inside the pytest process (one long-lived process with the whole suite's history in
-# front of chap7/probbounds' 451 solver handles: the conditions of the round-4 abort); otherwise one interpreter per script
-INPROCESS = os.environ.get("MI355KKT_BOOK_INPROCESS", "0") == "1"
+# The scripts run INSIDE the pytest process: one long-lived process with the whole suite's history in front of chap7/probbounds' 451
+# solver handles -- the conditions of the round-4 abort, whose cause (small host buffers pinned in place) is gone.
+# MI355KKT_BOOK_INPROCESS=0: one interpreter per script (the round-4 containment, kept as an option).
+INPROCESS = os.environ.get("MI355KKT_BOOK_INPROCESS", "1") == "1"
 
 
 def reference_results():
@@ -147,10 +148,10 @@ def _run_through_backend(example):
 
 @pytest.mark.parametrize("example", [e for e in _examples() if e not in SKIP])
 def test_book_example_same_results_through_the_backend(ref_cvxopt, example, tmp_path):
-    """Every script runs in an interpreter of its own, like a user's run of it (`python <this file> <example> <out.npz>`, the
-    `__main__` block below): the scripts rebind module globals of cvxopt and create up to 451 solver handles each, and a script
-    that brings its interpreter down (round 4, call r4c16: the whole GPU suite in one process aborted inside chap7/probbounds) fails
-    ITS test with the child's stderr in the report instead of taking the session with it."""
+    """Every script runs through the backend in this process by default (round 5); with MI355KKT_BOOK_INPROCESS=0 in an interpreter of
+    its own (`python <this file> <example> <out.npz>`, the `__main__` block below), where a script that brings its interpreter
+    down fails ITS test with the child's stderr in the report (round 4, call r4c16: the whole GPU suite in one process aborted
+    inside chap7/probbounds; cause and fix: DESIGN 12)."""
     if example == "missing":
         pytest.fail("oracle/_ref/reftests/examples/book missing: run `bash oracle/build_ref.sh` where /root/reference exists")
     import json
