@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
 // ===================================================================================================
 template <bool TRANS>
 __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict__ L, int64_t ldl, int n, double* x, u32 epoch,
-                                                        int* err, u64* gran, const double* __restrict__ minv) {
+                                                        int* err, u64* gran, const double* __restrict__ minv, int backoff) {
     __shared__ double xs2[2][TB];
     __shared__ double ps2[2][TB];
     __shared__ double es[TB];
@@ -788,14 +788,20 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
         for (int j = 0; j < 64; ++j) rb[j] = 0.0;
     }
     // all 256 threads: the 256 granules of block j of a granule set -> 128 doubles at dst; false on a timeout (err is set)
-    auto wait_block = [&](const u64* gbase, int j, double* dst) -> bool {
+    // dist: hops between the producer and the front of my own work.  Far behind the front the poll backs off (round 5): every
+    // workgroup of the launch waits for the SAME block -- the front's -- and 128 of them polling it at full rate load the few
+    // memory channels its granules live in; only the next block's owners need the data at once
+    auto wait_block = [&](const u64* gbase, int j, double* dst, int dist = 0) -> bool {
         const u64* g = gbase + (int64_t)j * 256 + tid;
         u64 v = 0;
         bool got = false;
         for (unsigned spins = 0; spins < (1u << 22); ++spins) {
             v = __hip_atomic_load(g, RLX_AGENT);
             if ((u32)(v >> 32) == epoch) { got = true; break; }
-            __builtin_amdgcn_s_sleep(1);
+            if (backoff && dist > 8) __builtin_amdgcn_s_sleep(127);
+            else if (backoff && dist > 4) __builtin_amdgcn_s_sleep(64);
+            else if (backoff && dist > 2) __builtin_amdgcn_s_sleep(16);
+            else __builtin_amdgcn_s_sleep(1);
         }
         reinterpret_cast<u32*>(dst)[tid] = (u32)v;            // little endian: granule 2i / 2i+1 = low / high word of entry i
         if (__syncthreads_or(got ? 0 : 1)) {
@@ -819,7 +825,7 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
         double l0[64];
 #pragma unroll
         for (int c = 0; c < 64; ++c) l0[c] = L[idx + (int64_t)(j0 + c0 + c) * ldl];     // (backward: the mirrored L')
-        if (!wait_block(gin, j, xs)) return;
+        if (!wait_block(gin, j, xs, nsteps - s)) return;
         double a0 = acc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
         for (int c = 0; c < 64; c += 4) {
@@ -887,10 +893,12 @@ int launch_trsv_pair(const double* L, int64_t ldl, int n, double* x, int trans, 
                      unsigned long long* gran, const double* minv) {
     if (n <= 0 || n % TB || !gran || !minv) return -1;
     const dim3 g(2 * (n / TB)), b(256);
+    const char* bk = dev_knob("MI355KKT_TRSV_BACKOFF");      // (A/B: 0 = every workgroup polls at full rate, as in round 4)
+    const int backoff = (bk && atoi(bk) == 0) ? 0 : 1;
     if (trans)
-        hipLaunchKernelGGL((trsv_pair_kernel<true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
+        hipLaunchKernelGGL((trsv_pair_kernel<true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, backoff);
     else
-        hipLaunchKernelGGL((trsv_pair_kernel<false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
+        hipLaunchKernelGGL((trsv_pair_kernel<false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv, backoff);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -170,42 +170,6 @@ __device__ __forceinline__ int potf2_panel16(double (&a)[16], double (&b)[16], d
     return __builtin_amdgcn_readfirstlane(badv);
 }
 
-// Round 5: the 16 x 16 diagonal block of a micro panel in the matrix cores' OWN register layout -- lane (li, lq) holds the elements
-// (row li, column lq + 4 r), r = 0..3 -- together with a 16 x 16 identity that receives the same column operations: when the sixteen
-// columns are done, D holds L_d and I holds I L_d^-T = inv(L_d)', the operand every other row block of the panel needs for its
-// triangular solve on the matrix cores (potf2_la_body, phase TU).  The rank-1 update of column j is ONE masked MFMA per tile
-// (A = -L[c][j] on the lanes of column j's group with c > j, B = L[rho][j] on the same lanes, zeros elsewhere: the three other
-// k slices contribute 0 x 0): no v_readlane broadcast of the fifteen multipliers, no LDS round trip, nothing per row below the
-// block.  What is left per column for the one wave that owns the chain: two multiplications, five selects, two MFMAs and the
-// scalar pivot recurrence of potf2_panel16 (two readlanes, one FMA, v_rsq + the third-order step, one column ahead of the
-// updates) -- ~22 instructions instead of 37 (rows 0..63 in registers) or 47 (all 128): measured stamps in DESIGN 4a''.
-// The strict upper triangle of D must be zero on entry (it then stays finite: the symmetric counterparts of the updates); a
-// non-positive pivot leaves NaNs in D from its column on (the caller looks at the diagonal afterwards).
-__device__ __forceinline__ void potf2_panel16_mfma(d4& D, d4& I, int lane) {
-    const int li = lane & 15, lq = lane >> 4;
-    double inv = rsqrt_halley(readlane_d(D[0], 0));
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int g = j & 3, k = j >> 2;
-        double x = 0.0, y = 1.0;
-        if (j < 15) {                                          // (j + 1, j) and (j + 1, j + 1): final after the update with column j - 1
-            x = readlane_d(D[k], (j + 1) + 16 * g);
-            y = readlane_d(D[(j + 1) >> 2], (j + 1) + 16 * ((j + 1) & 3));
-        }
-        const bool mg = lq == g;
-        const double la = D[k] * inv, lb = I[k] * inv;
-        D[k] = mg ? la : D[k];
-        I[k] = mg ? lb : I[k];
-        const double opA = (mg && li > j) ? -la : 0.0;
-        const double opBd = mg ? la : 0.0, opBi = mg ? lb : 0.0;
-        const double t = x * inv;
-        const double pn = fma(-t, t, y);
-        D = MFMA_F64(opA, opBd, D);
-        I = MFMA_F64(opA, opBi, I);
-        inv = rsqrt_halley(pn);
-    }
-}
-
 // The diagonal-block factorisation proper.  FROM_LDS: the block (lower triangle, column-major, leading dimension PLD)
 // already sits at the start of `smem` (the persistent tile kernel dumps its accumulators there); otherwise it is read
 // from A.  L goes to A (lower triangle only), the inverses of the 16x16 diagonal blocks to linv_out (may be null).
@@ -230,11 +194,8 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
     int lane = tid & 63;
     const int nt = (nb + 15) >> 4;
     const bool halfp = half_word != nullptr && nb == NB && linv_out != nullptr;
-    // round 5: whole tiles that are already in LDS (the tile kernels) take the matrix-core panel (potf2_panel16_mfma) and solve the
-    // rows below each diagonal block on the matrix cores (phase TU); ragged tiles and the stand-alone kernel keep the round-2 panel
-    const bool v2 = FROM_LDS && nb == NB;
     P2_TS(0);
-    if (tid == 0) { flag[0] = 0; flag[1] = 0x7fffffff; }
+    if (tid == 0) *flag = 0;
     double a[16], b[16];
     if (!FROM_LDS) {
         if (wave == 0) {                         // micro panel 0 straight from global memory into the panel wave
@@ -266,28 +227,7 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
         const int pw = min(16, nb - jb);
         asm volatile("" : "+v"(lane));           // opaque per iteration: the per-lane predicates below stay out of (spilled) SGPRs
         P2_TS(1 + (jb >> 4) * 5);
-        if (wave == 0 && v2) {
-            const int li = lane & 15, lq = lane >> 4;
-            d4 D, I;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = As[(jb + lq + 4 * r) * PLD + jb + li];
-                D[r] = (li >= lq + 4 * r) ? v : 0.0;
-                I[r] = (li == lq + 4 * r) ? 1.0 : 0.0;
-            }
-            P2_TS(2 + (jb >> 4) * 5);
-            potf2_panel16_mfma(D, I, lane);
-            P2_TS(3 + (jb >> 4) * 5);
-            int bad = 0x7fffffff;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // L_d in place (lower triangle), inv(L_d)' into the padding rows: element (block, k, g) at As[(16 block + k) PLD + 128 + g]
-                if (li >= lq + 4 * r) As[(jb + lq + 4 * r) * PLD + jb + li] = D[r];
-                As[(jb + li) * PLD + NB + lq + 4 * r] = I[r];
-                if (li == lq + 4 * r && !(D[r] > 0.0 && D[r] < 1.0e300)) bad = min(bad, jb + li + 1);   // (NaN from the first bad pivot on)
-            }
-            if (bad != 0x7fffffff) atomicMin(&flag[1], bad);
-        } else if (wave == 0) {
+        if (wave == 0) {
             if (FROM_LDS || jb > 0) {
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
@@ -322,16 +262,7 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
                     }
                 }
             }
-            if (halfp && wave == 7 && (stream || pjb < 64) && v2) {
-                // the inverse of the diagonal block of micro panel pjb sits in the padding rows (panel wave, one step ago)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int e = lane + 64 * q, j = e >> 4, i = e & 15;          // inv(L_d)[i][j] = As[(pjb + j) PLD + 128 + i]
-                    const double v = As[(pjb + j) * PLD + NB + i];
-                    if (stream) st_wt(linv_out + (pjb >> 4) * 256 + e, v);
-                    else linv_out[(pjb >> 4) * 256 + e] = v;
-                }
-            } else if (halfp && wave == 7 && (stream || pjb < 64)) {
+            if (halfp && wave == 7 && (stream || pjb < 64)) {
                 // inverse of the 16 x 16 diagonal block of micro panel pjb (final since the last barrier), column-oriented
                 // substitution as at the end of this function; the look-ahead waves have slack behind the panel wave
                 const int j = lane & 15;
@@ -369,10 +300,6 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // half: columns 0..63 + inverses 0..3; stream: micro panel jb - 16
         __syncthreads();                         // micro panel jb is in LDS; update jb-16 is complete
         P2_TS(5 + (jb >> 4) * 5);
-        if (v2 && flag[1] != 0x7fffffff) {                     // (uniform: read after the barrier)
-            if (tid == 0) flag[0] = flag[1];
-            __syncthreads();
-        }
         if (*flag) break;
         if (halfp && stream) {
             if (jb >= 16 && tid == P2T - 64)     // micro panels 0 .. jb/16 - 1 and their inverses are in memory (sc1 stores, drained)
@@ -383,54 +310,7 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
             __hip_atomic_store(half_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (jb + 16 >= nb) break;
-        if (v2) {
-            // ---- phase TU (round 5): the rows below the diagonal block, X L_d' = R on the matrix cores (inverse + one refinement
-            //      step, as trsm_panel_kernel / tile_process), one 16-row tile per wave, and -- without a barrier in between --
-            //      the update of that wave's tile of the NEXT column block, whose two operands are the solved tile of block row
-            //      t0 (every wave solves it for itself: 12 MFMAs) and its own: both still in registers.
-            const int li = lane & 15, lq = lane >> 4;
-            const int t0 = jb / 16 + 1, rt = t0 + wave;
-            const bool on = rt < 8;
-            double mi4[4], ld4[4];
-            d4 r0 = d4{0.0, 0.0, 0.0, 0.0}, r1 = r0, acc = r0;
-            if (on) {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    mi4[s4] = As[(jb + 4 * s4 + lq) * PLD + NB + li];                    // inv(L_d)[li][4 s + lq]
-                    const double lv = As[(jb + 4 * s4 + lq) * PLD + jb + li];
-                    ld4[s4] = (4 * s4 + lq <= li) ? -lv : 0.0;                          // -L_d[li][4 s + lq], lower triangle
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    r0[r] = As[(jb + lq + 4 * r) * PLD + t0 * 16 + li];
-                    r1[r] = As[(jb + lq + 4 * r) * PLD + rt * 16 + li];
-                    acc[r] = As[(t0 * 16 + lq + 4 * r) * PLD + rt * 16 + li];
-                }
-            }
-            __syncthreads();                      // every wave has read block row t0 before its owner overwrites it
-            if (on) {
-                auto solve = [&](const d4& a4) {
-                    d4 x0 = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) x0 = MFMA_F64(mi4[s4], a4[s4], x0);
-                    d4 e4 = a4;
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) e4 = MFMA_F64(ld4[s4], x0[s4], e4);
-                    d4 xx = x0;
-#pragma unroll
-                    for (int s4 = 0; s4 < 4; ++s4) xx = MFMA_F64(mi4[s4], e4[s4], xx);
-                    return xx;
-                };
-                const d4 x0t = solve(r0);
-                const d4 x1t = wave ? solve(r1) : x0t;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) As[(jb + lq + 4 * r) * PLD + rt * 16 + li] = x1t[r];
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) acc = MFMA_F64(-x0t[s4], x1t[s4], acc);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) As[(t0 * 16 + lq + 4 * r) * PLD + rt * 16 + li] = acc[r];
-            }
-        } else {   // column block jb/16 + 1 (the next micro panel): one tile per wave
+        {   // column block jb/16 + 1 (the next micro panel): one tile per wave
             const int t0 = jb / 16 + 1;
             if (t0 + wave < nt) potf2_tile_update(As, jb, t0, t0 + wave, lane);
         }
@@ -453,15 +333,7 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
     }
     // inverses of the 16x16 diagonal blocks (trsm_panel_kernel): wave w <-> block w, lane j <-> column j of inv(L_d)
     // (blocks 0..3 were done on the way when half_word is set; all but the last one in stream mode)
-    if (v2 && linv_out && wave < nt && !(halfp && (stream ? wave < nt - 1 : wave < 4))) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {             // block `wave` from the padding rows (panel wave)
-            const int e = lane + 64 * q, j = e >> 4, i = e & 15;
-            const double v = As[(wave * 16 + j) * PLD + NB + i];
-            if (stream) st_wt(linv_out + wave * 256 + e, v);
-            else linv_out[wave * 256 + e] = v;
-        }
-    } else if (linv_out && wave < nt && !(halfp && (stream ? wave < nt - 1 : wave < 4))) {
+    if (linv_out && wave < nt && !(halfp && (stream ? wave < nt - 1 : wave < 4))) {
         const int jb = wave * 16, pw = min(16, nb - jb);
         const int j = lane & 15;
         double x[16];
@@ -1424,7 +1296,9 @@ int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstr
     // single large matrix: the persistent left-looking tile kernel (up to 252 block columns: TileCtl)
     constexpr int tiles_min_n = 1024;
     if (nbatch == 1 && n >= tiles_min_n && (n + NB - 1) / NB <= 252) return launch_potrf_tiles(A, lda, n, w, st);
-    w.minv_n = 0;                         // the launch chain below does not produce the 128 x 128 diagonal-block inverses
+    // the launch chain below does not produce the 128 x 128 diagonal-block inverses: those of an earlier tile factorisation of THIS
+    // matrix are stale now; those of another matrix (S, while the small Schur complement K goes through here) stay valid
+    if (w.minv_of == A) w.minv_n = 0;
     // Outer panels of 256 columns = two 128-column sub-panels; the trailing matrix is touched once per
     // outer panel with a rank-256 update (halves the C read-modify-write traffic of a rank-128 scheme).
     auto panel = [&](int k0, int nb) -> int {   // factor diagonal block at k0 and solve the rows below it

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256, 2) void trsv_wide_kernel(const double* __restr
                 got1 = (u32)(v1 >> 32) == epoch;
             }
             if (got0 && got1) break;
-            if (dist > 1) __builtin_amdgcn_s_sleep(32);
+            if (dist > 8) __builtin_amdgcn_s_sleep(127);         // (~4 us: far behind the front)
+            else if (dist > 4) __builtin_amdgcn_s_sleep(64);
+            else if (dist > 1) __builtin_amdgcn_s_sleep(16);
             else __builtin_amdgcn_s_sleep(1);
         }
         reinterpret_cast<u32*>(dst)[tid] = (u32)v0;          // little endian: granule 2 i / 2 i + 1 = low / high word of entry i

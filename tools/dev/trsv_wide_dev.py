@@ -24,8 +24,9 @@ for n, m, spread in ((8192, 1024, 1.0), (2048, 1024, 1.0), (4096, 1024, 3.0), (1
     S = pr['P'] + (pr['G'] * (di * di)[:, None]).T @ pr['G']
     rhs = bx + pr['G'].T @ (di * di * bz)
     res = {}
-    for wide in (0, 1, 0, 1):
+    for wide, backoff in ((0, 0), (0, 1), (1, 1), (0, 0), (0, 1), (1, 1)):
         _capi.set_knob("MI355KKT_TRSV_WIDE", wide)
+        _capi.set_knob("MI355KKT_TRSV_BACKOFF", backoff)
         fbest = 1e9
         for rep in range(3):
             eng.factor_device(di_ptr=did.ptr)
@@ -41,7 +42,7 @@ for n, m, spread in ((8192, 1024, 1.0), (2048, 1024, 1.0), (4096, 1024, 3.0), (1
         x = xd.to_array((n,))
         r = float(np.linalg.norm(S @ x - rhs) / np.linalg.norm(rhs))
         res[wide] = x
-        print("n=%d spread=%g wide=%d: factor %.4f ms, solve %.4f ms, relative residual of S x = rhs %.2e" % (n, spread, wide, fbest, best, r))
+        print("n=%d spread=%g wide=%d backoff=%d: factor %.4f ms, solve %.4f ms, relative residual of S x = rhs %.2e" % (n, spread, wide, backoff, fbest, best, r))
     print("    max relative difference wide vs two-sweep: %.2e" % (np.max(np.abs(res[1] - res[0])) / np.max(np.abs(res[0]))))
     _capi.set_knob(None, None)
     eng.close()
