@@ -1132,24 +1132,6 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
     // L' into the (otherwise unused) upper triangle of S: the transposed persistent solve streams it coalesced
     if ((h->n + 127) / 128 <= h->num_cus)
         if (int e = launch_mirror_lower(h->dS, h->n, h->n, h->st)) return e;
-    // round 5: the 256 x 256 diagonal-block inverses of the wide triangular solves (trsv_wide.hip), from the 128 x 128 ones the tile
-    // Cholesky of S has just left (not when the Cholesky of K has replaced them: p >= 1024)
-    h->pw.minv2_n = 0;
-    if (h->n >= 512 && h->n % 256 == 0 && h->pw.minv_n == h->n && h->pw.minv_of == h->dS && (h->n + 127) / 128 <= h->num_cus) {
-        const char* wk = dev_knob("MI355KKT_TRSV_WIDE");
-        if (!wk || atoi(wk) != 0) {
-            if (h->pw.minv2_cap < h->n) {
-                if (h->pw.d_minv2) (void)dev_free(h->pw.d_minv2);
-                h->pw.d_minv2 = nullptr;
-                h->pw.minv2_cap = 0;
-                KKT_HIP_CHECK(DEV_ALLOC(&h->pw.d_minv2, sizeof(double) * 2 * 256 * 256 * (size_t)(h->n / 256)));
-                h->pw.minv2_cap = h->n;
-            }
-            if (int e = launch_pair_inverse(h->dS, h->n, h->n, h->pw.d_minv, h->pw.d_minv2, h->st)) return e;
-            h->pw.minv2_n = h->n;
-            h->pw.minv2_of = h->dS;
-        }
-    }
     KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
     if (int e = fetch_info(h, &info)) return e;
     (void)hipEventElapsedTime(&h->t_syrk, h->ev[0], h->ev[1]);
@@ -1261,10 +1243,7 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     const bool have_minv = h->pw.minv_n == n && h->pw.minv_of == h->dS;
     const char* pk = dev_knob("MI355KKT_TRSV_PAIR");
     const bool pair = persistent && have_minv && n % 128 == 0 && n >= 256 && 2 * (n / 128) <= h->num_cus && (pk ? atoi(pk) != 0 : TRSV_PAIR_DEFAULT);
-    // round 5: 256-row hops over eight workgroups each (trsv_wide.hip) when the factorisation left the 256 x 256 inverses
-    const bool wide = persistent && h->pw.minv2_n == n && h->pw.minv2_of == h->dS && n % 256 == 0;
     auto tri_solve = [&](int trans, double* xv) -> int {
-        if (wide) return launch_trsv_wide(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran, h->pw.d_minv2);
         if (pair) return launch_trsv_pair(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran, h->pw.d_minv);
         if (persistent) return launch_trsv_persistent(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran,
                                                       (h->pw.minv_n == n && h->pw.minv_of == h->dS) ? h->pw.d_minv : nullptr);

@@ -128,11 +128,6 @@ struct PotrfWork {
     double* d_minv = nullptr;
     int minv_n = 0;
     const double* minv_of = nullptr;
-    // round 5: inverses of the 256 x 256 diagonal blocks (M2 then M2', 2 x 65536 doubles per block) formed from d_minv by
-    // launch_pair_inverse for the wide triangular solves (trsv_wide.hip); valid for the factor `minv2_of` of order `minv2_n`
-    double* d_minv2 = nullptr;
-    int minv2_n = 0, minv2_cap = 0;
-    const double* minv2_of = nullptr;
     // look-ahead: the bulk of each trailing update runs on `side` while the next panel is factored on the main stream
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_bulk;
@@ -193,11 +188,6 @@ int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int t
 // 128 x 128 inverses (minv), n % 128 == 0, 2 n / 128 co-resident workgroups and 3 n / 128 granule blocks
 int launch_trsv_pair(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
                      unsigned long long* gran, const double* minv);
-// round 5 (trsv_wide.hip): 256-row hops, eight workgroups per block row, two sweeps; n % 256 == 0, 10 n granules, minv2 from
-// launch_pair_inverse (out: n / 256 blocks of 2 x 256 x 256 doubles; minv: the 128 x 128 inverses of the tile Cholesky)
-int launch_pair_inverse(const double* L, int64_t ldl, int n, const double* minv, double* out, hipStream_t st);
-int launch_trsv_wide(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
-                     unsigned long long* gran, const double* minv2);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);

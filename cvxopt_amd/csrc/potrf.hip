@@ -353,6 +353,13 @@ __device__ __forceinline__ int potf2_la_body(double* __restrict__ A, int64_t lda
                 else linv_out[wave * 256 + j * 16 + i] = v;
             }
         }
+    } else if (linv_out && wave >= nt && wave < 8) {
+        // a ragged block (nb < 128): the inverse blocks beyond its last 16 x 16 block are ZERO, written here -- the consumers stage
+        // all eight blocks of a tile (tile_invert_diag, the persistent solves' M) and multiply what lies beyond nb by zeros; 0 x
+        // whatever the allocation held is only 0 if that was finite.  (Round 5, found by the 0xff-poisoned test allocator:
+        // tests/test_gpu_stress.py n = 1500 returned NaNs; with the product's zero-filled blocks it had been right by accident.)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) linv_out[wave * 256 + lane + 64 * q] = 0.0;
     }
     P2_TS(42);
     return 0;
@@ -1194,7 +1201,6 @@ void potrf_work_free(PotrfWork& w) {
     if (w.d_ctl) (void)dev_free(w.d_ctl);
     if (w.d_linv_all) (void)dev_free(w.d_linv_all);
     if (w.d_minv) (void)dev_free(w.d_minv);
-    if (w.d_minv2) (void)dev_free(w.d_minv2);
     for (auto e : w.ev_panel) (void)hipEventDestroy(e);
     for (auto e : w.ev_bulk) (void)hipEventDestroy(e);
     if (w.side) (void)hipStreamDestroy(w.side);

@@ -1550,21 +1550,6 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
                 if (int e = launch_potrf(E.d_panels + only.off, only.h, only.w, E.pw_vb, st)) return e;
                 hipLaunchKernelGGL(sp_merge_info_kernel, dim3(1), dim3(1), 0, st, E.pw_vb.d_info, only.col0, E.d_info);
                 E.dense_root_level = l;
-                // round 5: the root's 256 x 256 inverses for the wide triangular solves (trsv_wide.hip), as in the dense engine
-                E.pw_vb.minv2_n = 0;
-                const char* wk = dev_knob("MI355KKT_TRSV_WIDE");
-                if (only.w % 256 == 0 && E.pw_vb.minv_n == only.w && (!wk || atoi(wk) != 0)) {
-                    if (E.pw_vb.minv2_cap < only.w) {
-                        if (E.pw_vb.d_minv2) (void)dev_free(E.pw_vb.d_minv2);
-                        E.pw_vb.d_minv2 = nullptr;
-                        E.pw_vb.minv2_cap = 0;
-                        KKT_HIP_CHECK(DEV_ALLOC(&E.pw_vb.d_minv2, sizeof(double) * 2 * 256 * 256 * (size_t)(only.w / 256)));
-                        E.pw_vb.minv2_cap = only.w;
-                    }
-                    if (int e = launch_pair_inverse(E.d_panels + only.off, only.h, only.w, E.pw_vb.d_minv, E.pw_vb.d_minv2, st)) return e;
-                    E.pw_vb.minv2_n = only.w;
-                    E.pw_vb.minv2_of = E.d_panels + only.off;
-                }
             } else if (old_chain) {
                 if (int e = launch_potrf_partial_vb(E.d_panels, dv, nbig, S.vb_maxh[l], S.vb_maxw[l], E.pw_vb, st)) return e;
                 hipLaunchKernelGGL(sp_merge_info_vb_kernel, dim3((nbig + 255) / 256), dim3(256), 0, st, E.pw_vb.d_info, nbig, E.d_info);
@@ -1603,8 +1588,6 @@ static int sp_root_solve(SparseEngine& E, int s, double* x, int trans, hipStream
     const int h = (int)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]);
     const double* P = E.d_panels + S.panel_off[s];
     const double* minv = (E.pw_vb.minv_n == w && E.pw_vb.minv_of == P) ? E.pw_vb.d_minv : nullptr;
-    if (minv && E.pw_vb.minv2_n == w && E.pw_vb.minv2_of == P && w % 256 == 0)
-        return launch_trsv_wide(P, h, w, x + f, trans, ++*E.t_epoch, E.t_err, st, E.t_gran, E.pw_vb.d_minv2);
     if (minv && w % 128 == 0 && 2 * (w / 128) <= E.t_num_cus)
         return launch_trsv_pair(P, h, w, x + f, trans, ++*E.t_epoch, E.t_err, st, E.t_gran, minv);
     return launch_trsv_persistent(P, h, w, x + f, trans, ++*E.t_epoch, E.t_err, st, E.t_gran, minv);

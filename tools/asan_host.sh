@@ -12,7 +12,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 mkdir -p "$OUT"
 SAN="-fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -g -O1"
 pids=()
-for f in gemm_f64 potrf blas2 trsv_wide cone_scale sparse_chol batch_ipm conelp_ipm coneqp_ipm capi; do
+for f in gemm_f64 potrf blas2 cone_scale sparse_chol batch_ipm conelp_ipm coneqp_ipm capi; do
   ( "$HIPCC" --offload-arch=gfx950 -std=c++17 -fPIC $SAN -I"$ROOT/include" -c "$SRC/$f.hip" -o "$OUT/$f.o" ) &
   pids+=($!)
 done

@@ -1,7 +1,6 @@
-"""Developer probe (round 5): wide triangular solves (trsv_wide_kernel: 256-row hops over eight workgroups each) against the round-4
-two-sweep kernel, same process, same matrices: factor() and solve() time (solve = gemv + 2 trsv + gemv), agreement of the two
-results, residual of the reduced system.  (The knob is read when the factorisation forms -- or does not form -- the 256 x 256
-inverses, so every switch is followed by a factor_device.)"""
+"""Developer probe (round 5): the two-sweep triangular solves with and without the dedicated poller wave (test knob
+MI355KKT_TRSV_AHEAD=0: every thread polls its own granule behind its strip loads, the round-4 kernel), same process, same factor:
+solve() time (gemv + 2 trsv + gemv), bitwise agreement of the two results, residual of the reduced system."""
 import os
 import sys
 
@@ -23,15 +22,11 @@ for n, m, spread in ((8192, 1024, 1.0), (2048, 1024, 1.0), (4096, 1024, 3.0), (1
     xd, zd, yd = _capi.DeviceBuffer(8 * n), _capi.DeviceBuffer(8 * m), _capi.DeviceBuffer(8)
     S = pr['P'] + (pr['G'] * (di * di)[:, None]).T @ pr['G']
     rhs = bx + pr['G'].T @ (di * di * bz)
+    eng.factor_device(di_ptr=did.ptr)
+    eng.sync()
     res = {}
-    for wide, backoff in ((0, 0), (0, 1), (1, 1), (0, 0), (0, 1), (1, 1)):
-        _capi.set_knob("MI355KKT_TRSV_WIDE", wide)
-        _capi.set_knob("MI355KKT_TRSV_BACKOFF", backoff)
-        fbest = 1e9
-        for rep in range(3):
-            eng.factor_device(di_ptr=did.ptr)
-            eng.sync()
-            fbest = min(fbest, eng.timings()["factor_ms"])
+    for poller in (0, 1, 0, 1):
+        _capi.set_knob("MI355KKT_TRSV_AHEAD", poller)
         best = 1e9
         for rep in range(8):
             _capi.check(_capi.lib().mi355kkt_memcpy_h2d(xd.ptr, bx.ctypes.data, 8 * n), "h2d")
@@ -41,8 +36,8 @@ for n, m, spread in ((8192, 1024, 1.0), (2048, 1024, 1.0), (4096, 1024, 3.0), (1
             best = min(best, eng.timings()["solve_ms"])
         x = xd.to_array((n,))
         r = float(np.linalg.norm(S @ x - rhs) / np.linalg.norm(rhs))
-        res[wide] = x
-        print("n=%d spread=%g wide=%d backoff=%d: factor %.4f ms, solve %.4f ms, relative residual of S x = rhs %.2e" % (n, spread, wide, backoff, fbest, best, r))
-    print("    max relative difference wide vs two-sweep: %.2e" % (np.max(np.abs(res[1] - res[0])) / np.max(np.abs(res[0]))))
+        res[poller] = x
+        print("n=%d spread=%g poller=%d: solve %.4f ms, relative residual of S x = rhs %.2e" % (n, spread, poller, best, r))
+    print("    bitwise equal: %s" % np.array_equal(res[0], res[1]))
     _capi.set_knob(None, None)
     eng.close()
