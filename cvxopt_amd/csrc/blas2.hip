@@ -750,14 +750,7 @@ __global__ __launch_bounds__(256) void trsv_persistent_kernel(const double* __re
 // Hand-offs are the data-tagged granules of the kernel above: blocks [0, nblk) carry x0, [nblk, 2 nblk) d, [2 nblk, 3 nblk) e.
 // Deterministic (fixed summation order); every spin is bounded and a timeout sets *err.
 // ===================================================================================================
-// Round 5 (AHEAD): the strip of the NEXT step is requested only after the current step's block has been seen.  A wave's
-// vector-memory loads return in issue order; round 4 issued the 64 loads of a step's strip right before waiting for the block
-// they multiply, so the poll sat BEHIND 128 KB of strip traffic and could not see a granule before the strip had arrived (~3 us at
-// the ~45 GB/s one compute unit pulls; the bare hand-off is ~0.6 us, profiles/r04_handoff_pingpong.txt).  Now a strip is in
-// flight for one whole hop before it is used and the poll has nothing in front of it.  Registers: the two strips replace the
-// diagonal block's row of L (sweep 1 loads it after x0 is published: it only feeds e_k, which sweep 2 needs a hop later).
-// Same arithmetic in the same order: results are bit-identical to the round-4 kernel (tests/test_gpu_round5.py).
-template <bool TRANS, bool AHEAD>
+template <bool TRANS>
 __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict__ L, int64_t ldl, int n, double* x, u32 epoch,
                                                         int* err, u64* gran, const double* __restrict__ minv) {
     __shared__ double xs2[2][TB];
@@ -780,24 +773,19 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
     const double* Lkk = L + k0 + (int64_t)k0 * ldl;
     const double* Mk = minv + (int64_t)k * (2 * TB * TB) + (TRANS ? TB * TB : 0);
     const int c0 = 64 * half;
-    double ra[64];
+    double ra[64], rb[64];
 #pragma unroll
     for (int j = 0; j < 64; ++j) ra[j] = Mk[r + (int64_t)(c0 + j) * TB];
-    auto load_rb = [&](double (&rb)[64]) {                    // my half of my row of L_kk (sweep 1: e = b1 - L_kk x0)
+    if (role == 0) {
 #pragma unroll
         for (int j = 0; j < 64; ++j) {
             const int c = c0 + j;
             const bool in = TRANS ? c >= r : c <= r;          // (the other triangle holds the mirrored copy)
             rb[j] = in ? Lkk[r + (int64_t)c * ldl] : 0.0;
         }
-    };
-    double rb0[64];
-    if (!AHEAD) {
-        if (role == 0) load_rb(rb0);
-        else {
+    } else {
 #pragma unroll
-            for (int j = 0; j < 64; ++j) rb0[j] = 0.0;
-        }
+        for (int j = 0; j < 64; ++j) rb[j] = 0.0;
     }
     // all 256 threads: the 256 granules of block j of a granule set -> 128 doubles at dst; false on a timeout (err is set)
     auto wait_block = [&](const u64* gbase, int j, double* dst) -> bool {
@@ -824,12 +812,14 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
     };
     // ---- off-diagonal blocks, in dependency order
     const int nsteps = TRANS ? (nblk - 1 - k) : k;
-    auto load_strip = [&](int s, double (&l0)[64]) {
-        const int j0 = (TRANS ? (nblk - 1 - s) : s) * TB;
+    for (int s = 0; s < nsteps; ++s) {
+        const int j = TRANS ? (nblk - 1 - s) : s;
+        const int j0 = j * TB;
+        double* xs = xs2[s & 1];
+        double l0[64];
 #pragma unroll
         for (int c = 0; c < 64; ++c) l0[c] = L[idx + (int64_t)(j0 + c0 + c) * ldl];     // (backward: the mirrored L')
-    };
-    auto consume = [&](const double (&l0)[64], const double* xs) {
+        if (!wait_block(gin, j, xs)) return;
         double a0 = acc, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
         for (int c = 0; c < 64; c += 4) {
@@ -839,28 +829,6 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
             a3 = fma(-l0[c + 3], xs[c0 + c + 3], a3);
         }
         acc = (a0 + a1) + (a2 + a3);
-    };
-    if (AHEAD) {
-        // two strips alternate: the one of step s + 1 is requested once the block of step s has been seen
-        double la[64], lb[64];
-        if (nsteps > 0) load_strip(0, la);
-        for (int s = 0; s < nsteps; s += 2) {
-            if (!wait_block(gin, TRANS ? (nblk - 1 - s) : s, xs2[0])) return;
-            if (s + 1 < nsteps) load_strip(s + 1, lb);
-            consume(la, xs2[0]);
-            if (s + 1 < nsteps) {
-                if (!wait_block(gin, TRANS ? (nblk - 2 - s) : s + 1, xs2[1])) return;
-                if (s + 2 < nsteps) load_strip(s + 2, la);
-                consume(lb, xs2[1]);
-            }
-        }
-    } else {
-        for (int s = 0; s < nsteps; ++s) {
-            double l0[64];
-            load_strip(s, l0);
-            if (!wait_block(gin, TRANS ? (nblk - 1 - s) : s, xs2[s & 1])) return;
-            consume(l0, xs2[s & 1]);
-        }
     }
     double* xs = xs2[nsteps & 1];                            // the buffer NOT read by the last step
     double* xo = xs2[(nsteps & 1) ^ 1];
@@ -894,10 +862,9 @@ __global__ __launch_bounds__(256) void trsv_pair_kernel(const double* __restrict
             publish(gX, x0);                                 // -> A_i, i beyond k, and B_k
             xo[r] = x0;
         }
-        if (AHEAD) load_rb(rb0);                             // (off the chain: e_k is what sweep 2 needs one hop from now)
         __syncthreads();
         // e = b1 - L_kk x0
-        const double q0 = dot64(rb0, xo);
+        const double q0 = dot64(rb, xo);
         if (half == 1) ps[r] = q0;
         __syncthreads();
         if (half == 0) publish(gE, acc - (q0 + ps[r]));       // -> B_k
@@ -920,16 +887,10 @@ int launch_trsv_pair(const double* L, int64_t ldl, int n, double* x, int trans, 
                      unsigned long long* gran, const double* minv) {
     if (n <= 0 || n % TB || !gran || !minv) return -1;
     const dim3 g(2 * (n / TB)), b(256);
-    const char* pk = dev_knob("MI355KKT_TRSV_AHEAD");        // (A/B: 0 = the round-4 order: strip loads in front of the poll)
-    if (pk && atoi(pk) == 0) {
-        if (trans)
-            hipLaunchKernelGGL((trsv_pair_kernel<true, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
-        else
-            hipLaunchKernelGGL((trsv_pair_kernel<false, false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
-    } else if (trans)
-        hipLaunchKernelGGL((trsv_pair_kernel<true, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
+    if (trans)
+        hipLaunchKernelGGL((trsv_pair_kernel<true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
     else
-        hipLaunchKernelGGL((trsv_pair_kernel<false, true>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
+        hipLaunchKernelGGL((trsv_pair_kernel<false>), g, b, 0, st, L, ldl, n, x, epoch, err, gran, minv);
     KKT_HIP_CHECK(hipGetLastError());
     return 0;
 }

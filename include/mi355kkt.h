@@ -123,7 +123,9 @@ int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH);
  * (S = Gs'Gs, then S += tril(H)).  This is what makes "re-upload H at every factor(W, H)" -- the only safe reading of the
  * hook when the caller may have changed H in place (cvxprog.py:526-537) -- cost next to nothing at n = 8192.
  * The caller keeps H alive and unmodified until that factor() returns and alive until the next set_H_* / destroy.
- * An H of less than 4 MB is copied synchronously (set_H_dense): nothing of the caller's heap is pinned for it. */
+ * An H of less than 4 MB is copied synchronously (set_H_dense): nothing of the caller's heap is pinned for it -- pinning small
+ * matrices where they lie (pages shared with the rest of the caller's heap) ended in GPU memory faults in long-lived processes
+ * (the round-4 abort, reproduced and isolated in round 5). */
 int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH);
 /* diagonal regularisation of kkt_ldl (reference misc.py:1095-1098): K[x,x] += reg, K[y,y] -= reg,
  * K[z,z] = -1 - reg.  0 disables it. */
