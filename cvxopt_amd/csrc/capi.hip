@@ -862,24 +862,43 @@ int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH)
     // shares its page with unrelated allocations, the caller's and the runtime's) for an overlap that only matters when the copy
     // takes as long as a kernel -- the headline's H is 512 MB.
     // (test knob MI355KKT_PIN_SMALL_H: pin whatever the size -- the behaviour of the build that aborted in round 4)
-    if (bytes < ((size_t)4 << 20) && !dev_knob("MI355KKT_PIN_SMALL_H"))
+    const bool pin_any = dev_knob("MI355KKT_PIN_SMALL_H") != nullptr;
+    if (bytes < ((size_t)4 << 20) && !pin_any)
         return mi355kkt_set_H_dense(h, H, ldH);                                  // (waits for a pending upload, unpins)
-    if (h->reg_ptr != (const void*)H || h->reg_bytes != bytes) {
+    // Round 5: only WHOLE PAGES THAT BELONG TO H ALONE are ever pinned.  A large array may still be a heap chunk (glibc raises its
+    // mmap threshold up to 32 MB as a process ages), and then its first and last page are shared with its neighbours -- the
+    // class of input that ended in GPU memory faults for small matrices.  The page-aligned interior is registered
+    // and copied asynchronously; the up to two partial pages at the ends (< 8 KB) are copied synchronously from pageable memory.
+    // Needs a contiguous H (ldH == n; anything else takes the synchronous path).
+    const bool contiguous = ldH == (h->n > 1 ? h->n : 1);
+    const uintptr_t b0 = reinterpret_cast<uintptr_t>(H), b1 = b0 + bytes;
+    uintptr_t p0 = pin_any ? b0 : ((b0 + 4095) & ~(uintptr_t)4095), p1 = pin_any ? b1 : (b1 & ~(uintptr_t)4095);
+    if (!pin_any && (!contiguous || p1 <= p0 || p1 - p0 < ((size_t)2 << 20))) return mi355kkt_set_H_dense(h, H, ldH);
+    const void* rptr = reinterpret_cast<const void*>(p0);
+    const size_t rbytes = (size_t)(p1 - p0);
+    if (h->reg_ptr != rptr || h->reg_bytes != rbytes) {
         h_unregister(h);
-        if (hipHostRegister(const_cast<double*>(H), bytes, hipHostRegisterDefault) != hipSuccess) {
+        if (hipHostRegister(const_cast<void*>(rptr), rbytes, hipHostRegisterDefault) != hipSuccess) {
             (void)hipGetLastError();                       // not pinnable: plain synchronous upload
             h->h_pending = false;
             return mi355kkt_set_H_dense(h, H, ldH);
         }
-        h->reg_ptr = H;
-        h->reg_bytes = bytes;
+        h->reg_ptr = rptr;
+        h->reg_bytes = rbytes;
     }
     if (!h->cst) KKT_HIP_CHECK(hipStreamCreateWithFlags(&h->cst, hipStreamNonBlocking));
     if (!h->ev_h) KKT_HIP_CHECK(hipEventCreateWithFlags(&h->ev_h, hipEventDisableTiming));
     if (!h->H_owned) KKT_HIP_CHECK(DEV_ALLOC(&h->H_owned, sizeof(double) * dmax((size_t)h->n * h->n, 1)));
     KKT_HIP_CHECK(hipStreamSynchronize(h->st));            // nothing on the compute stream may still read the old H
-    KKT_HIP_CHECK(hipMemcpy2DAsync(h->H_owned, sizeof(double) * h->n, H, sizeof(double) * ldH, sizeof(double) * h->n, h->n,
-                                   hipMemcpyHostToDevice, h->cst));
+    if (pin_any && !contiguous) {
+        KKT_HIP_CHECK(hipMemcpy2DAsync(h->H_owned, sizeof(double) * h->n, H, sizeof(double) * ldH, sizeof(double) * h->n, h->n,
+                                       hipMemcpyHostToDevice, h->cst));
+    } else {
+        char* dst = reinterpret_cast<char*>(h->H_owned);
+        if (p0 > b0) KKT_HIP_CHECK(memcpy_sync(dst, H, (size_t)(p0 - b0), hipMemcpyHostToDevice));
+        if (b1 > p1) KKT_HIP_CHECK(memcpy_sync(dst + (p1 - b0), reinterpret_cast<const void*>(p1), (size_t)(b1 - p1), hipMemcpyHostToDevice));
+        KKT_HIP_CHECK(hipMemcpyAsync(dst + (p0 - b0), rptr, rbytes, hipMemcpyHostToDevice, h->cst));
+    }
     KKT_HIP_CHECK(hipEventRecord(h->ev_h, h->cst));
     h->dH = h->H_owned;
     h->ldH = h->n > 1 ? h->n : 1;
