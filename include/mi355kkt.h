@@ -123,7 +123,8 @@ int mi355kkt_set_H_device(mi355kkt_solver* h, const double* dH, int64_t ldH);
  * (S = Gs'Gs, then S += tril(H)).  This is what makes "re-upload H at every factor(W, H)" -- the only safe reading of the
  * hook when the caller may have changed H in place (cvxprog.py:526-537) -- cost next to nothing at n = 8192.
  * The caller keeps H alive and unmodified until that factor() returns and alive until the next set_H_* / destroy.
- * An H of less than 4 MB is copied synchronously (set_H_dense): nothing of the caller's heap is pinned for it -- pinning small
+ * Only the page-aligned interior of a contiguous H (ldH == n) is pinned and copied asynchronously; the partial pages at its ends
+ * are copied synchronously.  An H of less than 4 MB is copied synchronously (set_H_dense): nothing of the caller's heap is pinned for it -- pinning small
  * matrices where they lie (pages shared with the rest of the caller's heap) ended in GPU memory faults in long-lived processes
  * (the round-4 abort, reproduced and isolated in round 5). */
 int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH);
