@@ -3,7 +3,7 @@ configurations at the sizes the GPU tests use, in the build container.  Takes se
 its outputs (tests/golden/full_*.npz) so that the GPU box can check the device loops and the hook against reference-
 produced numbers instead of hand-typed constants:
 
-    python tests/golden/make_golden_full.py [qp8192] [socp] [sparse46] [batch64] [batch512] [qp2048]
+    python tests/golden/make_golden_full.py [qp8192] [socp] [sparse46] [elasticity] [batch64] [batch512] [qp2048]
 
 For every run the fixture holds the iteration count, the final objectives at full precision, the final x (and z / a
 sample of them), the per-iteration table the reference driver prints with options['show_progress'] (pcost, dcost, gap,
@@ -96,6 +96,29 @@ def socp_full():
     print("wrote full_socp2048: %d iterations, pobj %.12e, %.1f s" % (sol['iterations'], sol['primal objective'], t))
 
 
+def elasticity():
+    """the irregular stand-in of config 4 (round 5): box QP on the 3-dof stiffness matrix of a 3000-node tetrahedral mesh (n = 9000)
+    through the reference's sparse kkt_chol2 branch (CHOLMOD replaced by the SuperLU shim: solutions are ordering independent)"""
+    import scipy.sparse as sp
+    nodes = 3000
+    P = synth.tet_mesh_elasticity(nodes, seed=7)
+    n = P.shape[0]
+    rng = np.random.default_rng(7)
+    q = rng.standard_normal(n)
+    G = sp.vstack([sp.eye(n), -sp.eye(n)]).tocsc()
+    h = np.ones(2 * n)
+    sol, table, dig, t = run_logged(lambda: solvers.coneqp(spm(sp.tril(P)), matrix(q), spm(G), matrix(h), kktsolver='chol2'),
+                                    'kkt_chol2')
+    x = np.array(sol['x']).ravel()
+    z = np.array(sol['z']).ravel()
+    rec = {'nodes': nodes, 'n': n, 'seed': 7, 'iterations': sol['iterations'], 'pobj': sol['primal objective'],
+           'dobj': sol['dual objective'], 'gap': sol['gap'], 'status_optimal': int(sol['status'] == 'optimal'),
+           'x': x, 'z': z, 'table': table, 'w_digest': dig, 'reference_seconds': t,
+           'note': "reference sparse branch of kkt_chol2 with oracle/cholmod_shim.py (SuperLU) in place of CHOLMOD"}
+    np.savez_compressed(os.path.join(HERE, 'full_elasticity9000.npz'), **rec)
+    print("wrote full_elasticity9000: %d iterations, pobj %.12e, %.1f s" % (sol['iterations'], sol['primal objective'], t))
+
+
 def sparse46():
     import scipy.sparse as sp
     k = 46
@@ -172,6 +195,8 @@ if __name__ == "__main__":
             socp_full()
         elif w == 'sparse46':
             sparse46()
+        elif w == 'elasticity':
+            elasticity()
         elif w == 'batch64':
             batch64()
         elif w == 'batch512':
