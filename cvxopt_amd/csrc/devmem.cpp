@@ -74,6 +74,7 @@ hipError_t clear(void* p, int value, size_t bytes) {
     return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
 
+// (a crash handler: snprintf is not on the async-signal-safe list, but the process is about to die and the ring is all it reads)
 void abort_dump(int sig) {
     if (g_dump_path[0]) {
         const int fd = open(g_dump_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);

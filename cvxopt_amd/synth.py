@@ -111,10 +111,10 @@ def tet_mesh_elasticity(nnodes, seed=0, shift=1e-2):
     i3, j3 = 3 * e[:, 0], 3 * e[:, 1]
     a, b = np.meshgrid(np.arange(3), np.arange(3), indexing='ij')
     rows, cols, vals = [], [], []
-    for (r0, c0, sgn) in ((i3, i3, 1.0), (j3, j3, 1.0), (i3, j3, -1.0), (j3, i3, -1.0)):
+    for (r0, c0, sgn) in ((i3, i3, 1.0), (j3, j3, 1.0), (i3, j3, -1.0), (j3, i3, -1.0)):    # (B is symmetric: no transposes needed)
         rows.append((r0[:, None, None] + a[None]).ravel())
         cols.append((c0[:, None, None] + b[None]).ravel())
-        vals.append((sgn * (B if sgn > 0 or r0 is i3 else np.transpose(B, (0, 2, 1)))).ravel())
+        vals.append((sgn * B).ravel())
     n = 3 * nnodes
     K = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n)).tocsc()
     K = ((K + K.T) * 0.5 + shift * sp.eye(n)).tocsc()
