@@ -185,3 +185,19 @@ def test_no_cpp_exception_crosses_the_c_abi():
     assert L.mi355kkt_test_throw(2) == _capi.EHIP
     with pytest.raises(MemoryError):
         _capi.check(L.mi355kkt_test_throw(0), "test_throw")
+
+
+def test_every_knob_the_sources_read_is_documented_in_the_test_header():
+    """knobs were used in the sources that include/mi355kkt_test.h did not name.  Every dev_knob("...") literal of csrc/
+    must appear in the header's list."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "mi355kkt_test.h")).read()
+    used = set()
+    for path in glob.glob(os.path.join(root, "cvxopt_amd", "csrc", "*")):
+        if path.endswith((".hip", ".cpp", ".h")):
+            used |= set(re.findall(r'dev_knob\("(MI355KKT_[A-Z0-9_]+)"\)', open(path).read()))
+    assert used, "no knob found: the pattern of this test is stale"
+    missing = sorted(k for k in used if '"%s"' % k not in header)
+    assert not missing, missing
