@@ -9,6 +9,7 @@
 //           x = L^-T (x - Asct y);  z = Gs x - zs
 // G and A stay resident in HBM; per factor() only W (O(cdim) doubles) crosses PCIe, per solve() only
 // x, y, z.
+#include <unistd.h>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
@@ -872,7 +873,9 @@ int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH)
     // Needs a contiguous H (ldH == n; anything else takes the synchronous path).
     const bool contiguous = ldH == (h->n > 1 ? h->n : 1);
     const uintptr_t b0 = reinterpret_cast<uintptr_t>(H), b1 = b0 + bytes;
-    uintptr_t p0 = pin_any ? b0 : ((b0 + 4095) & ~(uintptr_t)4095), p1 = pin_any ? b1 : (b1 & ~(uintptr_t)4095);
+    // (the host's page size, not a hard-coded 4096: with 64 KB pages a 4 KB-aligned interior would still share OS pages: ADVICE r5)
+    static const uintptr_t pgmask = []() { const long v = sysconf(_SC_PAGESIZE); return (uintptr_t)(v > 0 ? v : 4096) - 1; }();
+    uintptr_t p0 = pin_any ? b0 : ((b0 + pgmask) & ~pgmask), p1 = pin_any ? b1 : (b1 & ~pgmask);
     if (!pin_any && (!contiguous || p1 <= p0 || p1 - p0 < ((size_t)2 << 20))) return mi355kkt_set_H_dense(h, H, ldH);
     const void* rptr = reinterpret_cast<const void*>(p0);
     const size_t rbytes = (size_t)(p1 - p0);

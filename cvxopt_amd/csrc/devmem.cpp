@@ -68,10 +68,26 @@ hipStream_t clear_stream() {
     return g_clear[dev];
 }
 
+void drop_clear_stream(hipStream_t st) {          // the cached handle went stale (hipDeviceReset by the host application)
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (hipStream_t& s : g_clear)
+        if (s == st) s = nullptr;                 // (not destroyed: the handle belongs to a context that no longer exists)
+}
+
 hipError_t clear(void* p, int value, size_t bytes) {
     hipStream_t st = clear_stream();           // (nullptr: the legacy stream, as a last resort)
     hipError_t e = hipMemsetAsync(p, value, bytes, st);
-    return e != hipSuccess ? e : hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess && st) {
+        // a cached private stream does not survive a device reset.  Forget it, clear the error and retry ONCE on a
+        // fresh stream (or on the legacy stream if none can be made); a second failure is the caller's error
+        (void)hipGetLastError();
+        drop_clear_stream(st);
+        st = clear_stream();
+        e = hipMemsetAsync(p, value, bytes, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    return e;
 }
 
 // (a crash handler: snprintf is not on the async-signal-safe list, but the process is about to die and the ring is all it reads)
@@ -152,6 +168,7 @@ hipError_t dev_alloc(void** p, size_t bytes, const char* file, int line) {
     if (e != hipSuccess) return e;
     record(*p, bytes, file, line, 1);
     if (bytes && !raw && (e = clear(*p, fill, bytes)) != hipSuccess) {
+        record(*p, 0, nullptr, 0, 2);          // the ring pairs every alloc with a free
         (void)hipFree(*p);
         *p = nullptr;
     }

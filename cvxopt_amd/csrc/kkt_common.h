@@ -216,6 +216,7 @@ struct SparseSymbolic {
     std::vector<int64_t> ea_off;                                  // extend-add tile-boundary tables of the children of big fronts
     std::vector<int> ea_lb;
     std::vector<int> wide, wide_ptr;                              // per level: supernodes wider than 256 columns (dense multi-workgroup solves)
+    int wide_threshold = 128;   // sp_wide_threshold() as read ONCE by the symbolic analysis: the plan and the kernels' views must agree
     int64_t store_doubles = 0;
     std::vector<int> child_ptr, child_list, relmap;
     std::vector<int64_t> asm_slot, asm_ptr;       // numeric assembly: one entry per structural nonzero of S

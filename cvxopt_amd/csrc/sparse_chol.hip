@@ -199,6 +199,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     // storage: one buffer.  Small front: panel (h x w, ld h) followed by its update matrix (hu x hu, ld hu).
     // Big front (handled by the dense MFMA kernels): the whole h x h frontal matrix, panel = its first w columns,
     // update matrix = its trailing block (ld h).
+    S.wide_threshold = sp_wide_threshold();     // latched here for the life of this analysis
     S.panel_off.assign(ns + 1, 0);
     S.upd_off.assign(ns, 0);
     S.upd_ld.assign(ns, 0);
@@ -213,7 +214,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         S.nnzL += h * w;
         S.panel_off[s] = off;
         // (a wide supernode is always a big front: its solves use the extend-add boundary tables that only big fronts' children carry)
-        if ((fl >= big_flops && h >= big_h) || w > sp_wide_threshold()) {
+        if ((fl >= big_flops && h >= big_h) || w > S.wide_threshold) {
             S.big[s] = 1;
             S.upd_off[s] = off + w + w * h;
             S.upd_ld[s] = (int)h;
@@ -297,7 +298,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
         for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k) {
             const int sn = S.level_sn[k];
             const int64_t h = S.sn_rowptr[sn + 1] - S.sn_rowptr[sn], w = S.sn_first[sn + 1] - S.sn_first[sn];
-            if ((h - w) * w > 32768 || (w > sp_wide_threshold() && h > w)) {      // == SP_HEAVY / SP_WIDE in the kernels
+            if ((h - w) * w > 32768 || (w > S.wide_threshold && h > w)) {      // == SP_HEAVY / SP_WIDE in the kernels
                 S.heavy.push_back(sn);
                 S.heavy_maxhu[l] = std::max<int>(S.heavy_maxhu[l], (int)(h - w));
                 S.heavy_maxw[l] = std::max<int>(S.heavy_maxw[l], (int)w);
@@ -311,7 +312,7 @@ int symbolic_analyze(SparseSymbolic& S, int n, int m, const int64_t* gcp, const 
     S.wide_ptr.assign(S.nlevels + 1, 0);
     for (int l = 0; l < S.nlevels; ++l) {
         for (int k = S.level_ptr[l]; k < S.level_ptr[l + 1]; ++k)
-            if (S.sn_first[S.level_sn[k] + 1] - S.sn_first[S.level_sn[k]] > sp_wide_threshold()) S.wide.push_back(S.level_sn[k]);
+            if (S.sn_first[S.level_sn[k] + 1] - S.sn_first[S.level_sn[k]] > S.wide_threshold) S.wide.push_back(S.level_sn[k]);
         S.wide_ptr[l + 1] = (int)S.wide.size();
     }
     if (dev_knob("MI355KKT_SPARSE_DEBUG")) {
@@ -1506,7 +1507,7 @@ static SpDev devview(const SparseEngine& E) {
     d.level_sn = E.d_level_sn;
     d.ea_off = E.d_ea_off;
     d.ea_lb = E.d_ea_lb;
-    d.wide = sp_wide_threshold();
+    d.wide = E.sym.wide_threshold;
     return d;
 }
 

@@ -123,21 +123,38 @@ def tet_mesh_elasticity(nnodes, seed=0, shift=1e-2):
 
 
 def read_matrix_market(path, shift=0.0):
-    """A symmetric positive definite matrix from a Matrix-Market file (coordinate real general / symmetric; a pattern file gets the
-    graph Laplacian of its pattern) as scipy.sparse CSC, for `bench.py --workload sparse --mtx FILE` -- the door for the
-    SuiteSparse matrix BASELINE configs[3] names on the day its file is reachable (there is no network in the build).  The
-    matrix is symmetrised ((A + A')/2); `shift` adds shift * max|diag| * I for files that are only semidefinite."""
+    """A symmetric positive definite matrix from a Matrix-Market file (coordinate real / integer, general / symmetric) as
+    scipy.sparse CSC, for `bench.py --workload sparse --mtx FILE` -- the door for the SuiteSparse matrix BASELINE configs[3] names
+    on the day its file is reachable (there is no network in the build).  A `pattern` file carries no values: it gets the graph
+    Laplacian of its (symmetrised) pattern, L = D - A off the diagonal, plus the identity (positive definite).  Anything else is
+    symmetrised ((A + A')/2); `shift` adds shift * max|diag| * I for files that are only semidefinite.  A result whose diagonal
+    is not strictly positive cannot be positive definite and is refused here, with the remedy, instead of deep in the
+    factorisation."""
     import scipy.io
     import scipy.sparse as sp
-    A = scipy.io.mmread(path)
-    A = sp.csc_matrix(A)
+    info = scipy.io.mminfo(path)                          # (rows, cols, entries, format, field, symmetry)
+    field = str(info[4]).lower()
+    A = sp.csc_matrix(scipy.io.mmread(path))
     if A.shape[0] != A.shape[1]:
         raise ValueError("%s: %d x %d is not square" % (path, A.shape[0], A.shape[1]))
-    if A.dtype.kind not in "fiu":                         # (pattern files come back as ones)
-        raise ValueError("%s: real matrices only" % path)
-    A = A.astype(np.float64)
-    A = ((A + A.T) * 0.5).tocsc()
+    if field == "pattern":
+        n = A.shape[0]
+        B = ((abs(A) + abs(A).T) > 0).astype(np.float64).tolil()
+        B.setdiag(0.0)
+        B = B.tocsc()
+        B.eliminate_zeros()
+        deg = np.asarray(B.sum(axis=1)).ravel()
+        A = (sp.diags(deg + 1.0) - B).tocsc()
+    else:
+        if A.dtype.kind not in "fiu":
+            raise ValueError("%s: real matrices only (field %r)" % (path, field))
+        A = A.astype(np.float64)
+        A = ((A + A.T) * 0.5).tocsc()
     if shift:
         A = (A + shift * float(np.max(np.abs(A.diagonal()))) * sp.eye(A.shape[0])).tocsc()
+    dmin = float(A.diagonal().min()) if A.shape[0] else 1.0
+    if not dmin > 0.0:
+        raise ValueError("%s: smallest diagonal entry %.3g is not positive, the matrix cannot be positive definite; for a "
+                         "semidefinite / indefinite file pass --mtx-shift S (adds S * max|diag| * I)" % (path, dmin))
     A.sort_indices()
     return A

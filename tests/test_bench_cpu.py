@@ -64,3 +64,27 @@ def test_matrix_market_door_and_the_elasticity_stand_in(tmp_path):
                                           perm.ctypes.data_as(_capi.c_int_p), C.byref(nnzL), C.byref(ns), C.byref(nl))
     assert rc == 0 and sorted(perm.tolist()) == list(range(n))
     assert nnzL.value >= Kt.nnz and 1 <= ns.value <= n
+
+
+def test_matrix_market_pattern_file_and_non_positive_diagonal(tmp_path):
+    """a `pattern` file gets the graph Laplacian of its pattern (+ I: positive definite), and a file whose diagonal is
+    not positive is refused with the remedy instead of failing deep in the factorisation."""
+    import numpy as np
+    import pytest
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sla
+    from cvxopt_amd import synth
+    p = tmp_path / "ring.mtx"            # a 6-cycle, lower triangle only, no values
+    edges = [(2, 1), (3, 2), (4, 3), (5, 4), (6, 5), (6, 1)]
+    p.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n6 6 %d\n" % len(edges)
+                 + "".join("%d %d\n" % e for e in edges))
+    A = synth.read_matrix_market(str(p))
+    assert abs(A - A.T).max() == 0.0 and np.all(A.diagonal() == 3.0)          # degree 2 + 1
+    assert abs(A).sum() == 6 * 3.0 + 12 * 1.0 and (A - sp.diags(A.diagonal())).max() == 0.0     # off-diagonal entries are -1
+    assert sla.eigsh(A, k=1, which='SA', return_eigenvectors=False)[0] > 0.99
+    q = tmp_path / "indef.mtx"
+    q.write_text("%%MatrixMarket matrix coordinate real symmetric\n3 3 4\n1 1 2.0\n2 2 -1.0\n3 3 1.0\n3 1 0.5\n")
+    with pytest.raises(ValueError, match="--mtx-shift"):
+        synth.read_matrix_market(str(q))
+    B = synth.read_matrix_market(str(q), shift=1.0)
+    assert B.diagonal().min() == 1.0

@@ -82,8 +82,34 @@ def pmc_any(db, substr):
     print(json.dumps({"kernel": substr, "db": db, "avg_per_dispatch": out}))
 
 
+def pmc_table(fetch_db, write_db, out):
+    """bytes moved past the L2 per kernel NAME over a whole run: FETCH_SIZE (x2, KiB) and WRITE_SIZE (KiB) passes side by side"""
+    def per_name(db, counter):
+        cur = sqlite3.connect(db).cursor()
+        cols = [c[1] for c in cur.execute("pragma table_info('counters_collection')")]
+        namecol = "kernel_name" if "kernel_name" in cols else "name"
+        tot, disp = {}, {}
+        for kname, cname, val, did in cur.execute("select %s, counter_name, value, dispatch_id from counters_collection" % namecol):
+            if cname == counter:
+                tot[kname] = tot.get(kname, 0.0) + float(val)
+                disp.setdefault(kname, set()).add(did)
+        return tot, {k: len(v) for k, v in disp.items()}
+    f, fd = per_name(fetch_db, "FETCH_SIZE")
+    w, wd = per_name(write_db, "WRITE_SIZE")
+    names = sorted(set(f) | set(w), key=lambda k: -(2.0 * f.get(k, 0.0) + w.get(k, 0.0)))
+    lines = ["| kernel | launches | fetch GB (FETCH_SIZE x2) | write GB | GB per launch |", "|---|---|---|---|---|"]
+    for k in names:
+        n = max(fd.get(k, 0), wd.get(k, 0), 1)
+        fb, wb = 2.0 * f.get(k, 0.0) * 1024.0 / 1e9, w.get(k, 0.0) * 1024.0 / 1e9
+        lines.append("| `%s` | %d | %.3f | %.3f | %.4f |" % (k[:90], n, fb, wb, (fb + wb) / n))
+    open(out, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines[:16]))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "pmctable":
+        pmc_table(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "pmcany":
         pmc_any(sys.argv[2], sys.argv[3])
