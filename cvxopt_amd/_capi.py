@@ -135,6 +135,7 @@ DEBUG_SIGNATURES = {
     "mi355kkt_debug_hwid": (C.c_int, [C.c_void_p, C.c_int]),
     "mi355kkt_debug_potf2_ts": (C.c_int, [C.c_void_p]),
     "mi355kkt_debug_tile_ts": (C.c_int, [C.c_void_p]),
+    "mi355kkt_debug_wide_ts": (C.c_int, [C.c_void_p]),
     "mi355kkt_debug_syrk_skip": (C.c_int, [C.c_int]),
 }
 

@@ -25,7 +25,7 @@ fi
 if [ "$CLEAN" = 1 ]; then rm -rf "$OBJ" "$OUT"; fi
 mkdir -p "$OBJ"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $DEFS"
-HIP_SRCS="gemm_f64 potrf blas2 cone_scale sparse_chol batch_ipm conelp_ipm coneqp_ipm capi"
+HIP_SRCS="gemm_f64 potrf blas2 trsv512 cone_scale sparse_chol batch_ipm conelp_ipm coneqp_ipm capi"
 HOST_SRCS="ordering knobs devmem"
 # every header an object may depend on (coarse on purpose: a header edit rebuilds everything that could include it)
 DEPS=("$HERE"/*.h "$HERE/../../include"/*.h "$HERE/build.sh")

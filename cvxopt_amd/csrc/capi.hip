@@ -311,6 +311,7 @@ static int qp_alloc(QpWork& w, int n, int ml, const std::vector<int>& q, const s
     return 0;
 }
 
+constexpr bool TRSV_WIDE_DEFAULT = true;      // knob MI355KKT_TRSV_WIDE=0: the round-4 pair kernel instead of the 512-row hops (A/B, tests)
 constexpr bool TRSV_PAIR_DEFAULT = true;      // knob MI355KKT_TRSV_PAIR=0 selects the one-sweep kernel (A/B measurements, tests)
 
 struct mi355kkt_solver {
@@ -944,6 +945,14 @@ int mi355kkt_set_option(mi355kkt_solver* h, const char* name, double value) try 
 } catch (...) { return kkt_catch("mi355kkt_set_option"); }
 
 // info word -> host (synchronises the stream)
+// the all-CU triangular solves (trsv512.hip) serve this handle's S: dense engine, order a multiple of 128 from 1024 up to
+// 32 rows x #CUs, and not switched off by the test knob
+static bool trsv_wide_wanted(const mi355kkt_solver* h) {
+    const char* k = dev_knob("MI355KKT_TRSV_WIDE");
+    if (!(k ? atoi(k) != 0 : TRSV_WIDE_DEFAULT)) return false;
+    return trsv_wide_rows(h->n, h->num_cus) != 0;
+}
+
 static int fetch_info(mi355kkt_solver* h, int* info) {
     KKT_HIP_CHECK(hipMemcpyAsync(h->pw.h_info, h->pw.d_info, sizeof(int), hipMemcpyDeviceToHost, h->st));
     KKT_HIP_CHECK(hipStreamSynchronize(h->st));
@@ -1154,6 +1163,10 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
     // L' into the (otherwise unused) upper triangle of S: the transposed persistent solve streams it coalesced
     if ((h->n + 127) / 128 <= h->num_cus)
         if (int e = launch_mirror_lower(h->dS, h->n, h->n, h->st)) return e;
+    // round 6: 512 x 512 inverses of the diagonal blocks for the all-CU triangular solves (trsv512.hip), from the 128 x 128 ones the
+    // tile Cholesky of S left (not when K went through the tile kernel after it: they are K's then)
+    if (trsv_wide_wanted(h) && h->pw.minv_n == h->n && h->pw.minv_of == h->dS)
+        if (int e = launch_block_inverse512(h->dS, h->n, h->n, h->pw, h->st)) return e;
     KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
     if (int e = fetch_info(h, &info)) return e;
     (void)hipEventElapsedTime(&h->t_syrk, h->ev[0], h->ev[1]);
@@ -1265,7 +1278,9 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     const bool have_minv = h->pw.minv_n == n && h->pw.minv_of == h->dS;
     const char* pk = dev_knob("MI355KKT_TRSV_PAIR");
     const bool pair = persistent && have_minv && n % 128 == 0 && n >= 256 && 2 * (n / 128) <= h->num_cus && (pk ? atoi(pk) != 0 : TRSV_PAIR_DEFAULT);
+    const int wide_rows = (trsv_wide_wanted(h) && h->pw.m512_n == n && h->pw.m512_of == h->dS) ? trsv_wide_rows(n, h->num_cus) : 0;
     auto tri_solve = [&](int trans, double* xv) -> int {
+        if (wide_rows) return launch_trsv_wide(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->pw, wide_rows, h->num_cus);
         if (pair) return launch_trsv_pair(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran, h->pw.d_minv);
         if (persistent) return launch_trsv_persistent(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran,
                                                       (h->pw.minv_n == n && h->pw.minv_of == h->dS) ? h->pw.d_minv : nullptr);
@@ -2844,6 +2859,7 @@ int mi355kkt_test_ordering(int n, const int64_t* colptr, const int64_t* rowind, 
 } catch (...) { return kkt_catch("mi355kkt_test_ordering"); }
 #ifdef MI355KKT_DEBUG       // include/mi355kkt_debug.h: process-global developer switches, never in a production build
 int mi355kkt_debug_tile_ts(void* dptr) { return mi355kkt::set_tile_ts((long long*)dptr); }
+int mi355kkt_debug_wide_ts(void* dptr) { return mi355kkt::set_wide_ts((long long*)dptr); }
 int mi355kkt_debug_potf2_ts(void* dptr) { return mi355kkt::set_potf2_ts((long long*)dptr); }
 int mi355kkt_debug_syrk_skip(int mask) { return mi355kkt::set_syrk_skip(mask); }
 #endif

@@ -128,11 +128,21 @@ struct PotrfWork {
     double* d_minv = nullptr;
     int minv_n = 0;
     const double* minv_of = nullptr;
+    // round 6 (trsv512.hip): 512 x 512 inverses of the diagonal blocks (per 512-block M then M'), formed from d_minv after the
+    // factorisation (launch_block_inverse512); valid for matrix `m512_of` of order `m512_n`.  d_gran512: the wide solves' granules
+    double* d_m512 = nullptr;
+    double* d_m512_scratch = nullptr;
+    unsigned long long* d_gran512 = nullptr;
+    int m512_blocks = 0;
+    unsigned m512_launches = 0;       // formation launches so far (their stage counters only ever grow)
+    int m512_n = 0;
+    const double* m512_of = nullptr;
     // look-ahead: the bulk of each trailing update runs on `side` while the next panel is factored on the main stream
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev_panel, ev_bulk;
 };
 #ifdef MI355KKT_DEBUG          // developer aids, include/mi355kkt_debug.h
+int set_wide_ts(long long* dptr);    // 16 int64 stamps (100 MHz) per workgroup written by trsv_wide_kernel (nullptr: off)
 int set_tile_ts(long long* dptr);    // 8 int64 stamps per tile written by potrf_tiles_kernel (nullptr: off)
 int set_potf2_ts(long long* dptr);   // device buffer of 48 timestamps written by potf2_la_kernel (nullptr: off)
 int set_syrk_skip(int v);            // ablation switch of the SYRK (results are wrong when != 0)
@@ -188,6 +198,13 @@ int launch_trsv_persistent(const double* L, int64_t ldl, int n, double* x, int t
 // 128 x 128 inverses (minv), n % 128 == 0, 2 n / 128 co-resident workgroups and 3 n / 128 granule blocks
 int launch_trsv_pair(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
                      unsigned long long* gran, const double* minv);
+// round 6: 512-row hops over all compute units (trsv512.hip).  trsv_wide_rows: rows per workgroup for this order, 0 = not served
+// (n >= 1024, a multiple of 128); launch_block_inverse512 after the tile Cholesky of L (needs its 128 x 128
+// inverses); launch_trsv_wide: same contract as launch_trsv_pair
+int trsv_wide_rows(int n, int num_cus);
+int launch_block_inverse512(const double* L, int64_t ldl, int n, PotrfWork& w, hipStream_t st);
+int launch_trsv_wide(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
+                     PotrfWork& w, int rows, int num_cus);
 // x := L^-1 x (trans=0) or L^-T x (trans=1), L lower n x n, nrhs right-hand sides (ldx)
 int launch_trsm_lower(const double* L, int64_t ldl, int n, double* X, int64_t ldx, int nrhs,
                       int trans, hipStream_t st, int nbatch = 1, int64_t sL = 0, int64_t sX = 0);

@@ -1201,6 +1201,12 @@ void potrf_work_free(PotrfWork& w) {
     if (w.d_ctl) (void)dev_free(w.d_ctl);
     if (w.d_linv_all) (void)dev_free(w.d_linv_all);
     if (w.d_minv) (void)dev_free(w.d_minv);
+    if (w.d_m512) (void)dev_free(w.d_m512);
+    if (w.d_m512_scratch) (void)dev_free(w.d_m512_scratch);
+    if (w.d_gran512) (void)dev_free(w.d_gran512);
+    w.d_m512 = w.d_m512_scratch = nullptr;
+    w.d_gran512 = nullptr;
+    w.m512_blocks = w.m512_n = 0;
     for (auto e : w.ev_panel) (void)hipEventDestroy(e);
     for (auto e : w.ev_bulk) (void)hipEventDestroy(e);
     if (w.side) (void)hipStreamDestroy(w.side);
@@ -1298,6 +1304,7 @@ static int launch_potrf_tiles(double* A, int64_t lda, int n, PotrfWork& w, hipSt
 int launch_potrf_batched(double* A, int64_t lda, int n, int nbatch, int64_t bstride, PotrfWork& w, hipStream_t st) {
     // (round 4 measured the batch as nbatch "fronts" of the variable-batched tile kernel, one launch instead of this chain: 512
     //  problems of n = 512: factor 4.35 -> 4.8 ms, SLOWER -- profiles/r04_batch_tiles_ab.txt; not kept)
+    if (w.m512_of == A) w.m512_n = 0;        // the 512 x 512 inverses of an earlier factor of this matrix are stale
     KKT_HIP_CHECK(hipMemsetAsync(w.d_info, 0, sizeof(int) * nbatch, st));
     // single large matrix: the persistent left-looking tile kernel (up to 252 block columns: TileCtl)
     constexpr int tiles_min_n = 1024;

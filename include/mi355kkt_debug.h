@@ -18,6 +18,8 @@ int mi355kkt_debug_hwid(unsigned* out, int nblocks);
 int mi355kkt_debug_potf2_ts(void* dptr);
 /* 8 int64 stamps per 128 x 128 tile (column-major tile order) written by the persistent Cholesky kernel (NULL: off) */
 int mi355kkt_debug_tile_ts(void* dptr);
+/* 16 int64 stamps (s_memrealtime: 100 MHz, common to all compute units) per workgroup of the 512-row triangular solve (NULL: off) */
+int mi355kkt_debug_wide_ts(void* dptr);
 /* ablation of the SYRK's phases (bit0 no global fetch, bit1 no LDS stash, bit2 no barrier, bit4 no static priority, bit5 long
  * diagonal tiles through the general path, bit6 no block masks): RESULTS ARE WRONG when != 0 */
 int mi355kkt_debug_syrk_skip(int mask);
