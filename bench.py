@@ -51,6 +51,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=512, help="problems per GPU for --workload batch")
     ap.add_argument("--total-batch", type=int, default=4096, help="problems in the whole job for --workload sharded")
     ap.add_argument("--dry-run", action="store_true", help="--gpus N plumbing check on CPU (gloo, NumPy, tiny batch)")
+    ap.add_argument("--transport", default="auto", choices=["auto", "ipc", "rccl"],
+                    help="--workload sharded: how the shards travel.  ipc: every rank pulls its shard from the root's exported buffers "
+                         "with device-to-device copies and pushes its results back (no data-path collective); rccl: dist.scatter / "
+                         "dist.gather; auto (default): ipc if a 4 KB probe works on every rank, else rccl (DESIGN 7)")
     ap.add_argument("--nsub", type=int, default=4, help="--workload sharded: sub-batches per rank the scatter / solve / gather is "
                                                         "pipelined over (1 = scatter everything, then solve, then gather)")
     ap.add_argument("--grid", type=int, default=64, help="k for the k^3 Laplacian of --workload sparse (64: n = 262 144, inside "
@@ -455,8 +459,18 @@ def main_sharded(args):
     if dry:
         HostKkt = _host_kkt_for_dry_run()
         local = lambda P_, q_, G_, h_, **kw: coneqp_batch(P_, q_, G_, h_, kkt=HostKkt(G_, P_))
+    # transport of the shards: no data-path collective when every rank can map the root's buffers
+    transport, transport_note = "rccl", "dry run: gloo collectives"
+    if not dry:
+        transport, transport_note = args.transport, "requested"
+        if args.transport == "auto":
+            from cvxopt_amd.batch import ipc_transport_works
+            ok, whys = ipc_transport_works()
+            transport = "ipc" if ok else "rccl"
+            transport_note = "auto: 4 KB IPC probe succeeded on every rank" if ok else "auto: IPC probe failed (%s)" % (
+                "; ".join("rank %d: %s" % (r_, w_) for r_, w_ in enumerate(whys) if w_))
     # persistent per-rank state (receive buffers, one engine per sub-batch): created once, OUTSIDE the timed steps
-    sb = ShardedBatch(B, n, m, True, root=0, nsub=args.nsub, local_solver=local)
+    sb = ShardedBatch(B, n, m, True, root=0, nsub=args.nsub, local_solver=local, transport=transport)
     phase = []
 
     def step():
@@ -501,7 +515,9 @@ def main_sharded(args):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[4]: %d independent dense QPs n=%d, m=%d resident on the root GPU; step = "
                                    "scatter (%s) -> device-resident coneqp per shard -> gather (%s), all timed"
-                                   % (B, n, m, "gloo" if dry else "RCCL", "gloo" if dry else "RCCL"),
+                                   % (B, n, m, "gloo" if dry else ("RCCL" if transport == "rccl" else "IPC pull, no collective"),
+                                      "gloo" if dry else ("RCCL" if transport == "rccl" else "IPC push")),
+                       "transport": transport, "transport_note": transport_note,
                        "problems": B, "problems_per_rank": [b - a for a, b in __import__("cvxopt_amd.batch", fromlist=["x"]).shard_bounds(B, world)],
                        "problem_iterations": its, "all_optimal": all_opt,
                        "lockstep_iterations_root": int(r.get('lockstep iterations', 0)), "sub_batches": sb.nsub},

@@ -38,6 +38,9 @@ SIGNATURES = {
     "mi355kkt_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355kkt_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mi355kkt_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mi355kkt_ipc_export": (C.c_int, [C.c_void_p, C.c_void_p, c_i64_p, c_i64_p]),
+    "mi355kkt_ipc_open": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mi355kkt_ipc_close": (C.c_int, [C.c_void_p]),
     "mi355kkt_device_synchronize": (C.c_int, []),
     "mi355kkt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   c_int_p, C.c_int, c_int_p]),

@@ -411,6 +411,20 @@ def shard_bounds(B, world):
     return [(starts[r], starts[r + 1]) for r in range(world)]
 
 
+class _ForeignMemory(object):
+    """CUDA array interface over device memory this process did not allocate (an IPC mapping)"""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f8", "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+
+
+def _foreign_tensor(torch, ptr, shape, dev):
+    if int(np.prod(shape)) == 0:
+        return torch.empty(shape, dtype=torch.float64, device=dev)
+    return torch.as_tensor(_ForeignMemory(ptr, shape), device=dev)
+
+
 _STATUS_NAMES = np.array(['unknown', 'optimal', 'unknown', 'unknown'], dtype=object)
 
 
@@ -429,17 +443,30 @@ class ShardedBatch(object):
     `dist.gather`.  No collective inside the interior-point loop.
     """
 
-    def __init__(self, B, n, m, hasP, group=None, root=0, nsub=4, local_solver=None, device_of_rank=None, engine_factory=None):
+    def __init__(self, B, n, m, hasP, group=None, root=0, nsub=4, local_solver=None, device_of_rank=None, engine_factory=None,
+                 transport="rccl"):
         """engine_factory(shape=(cnt, n, m), device=index) -> an object with BatchKkt's set_problem / coneqp / close: the
         device-resident branch then runs with it whatever the backend (tests walk the RCCL branch's exact ordering -- scatter
-        lists, async work handles, wait order, packed gather -- over gloo with host tensors this way); None: `BatchKkt` on RCCL."""
+        lists, async work handles, wait order, packed gather -- over gloo with host tensors this way); None: `BatchKkt` on RCCL.
+
+        transport = "rccl": `dist.scatter` / `dist.gather` of the group's backend (RCCL: grouped send / recv).
+        transport = "ipc": NO data-path collective.  The root exports the allocations that hold q, h, Gt, P and its result buffer
+        (mi355kkt_ipc_export: hipIpcGetMemHandle); every rank maps them once (mi355kkt_ipc_open) and PULLS the rows of its shard
+        with device-to-device copies on a stream of its own, sub-batch by sub-batch, and PUSHES its packed result rows straight
+        into the root's result buffer -- seven independent point-to-point streams over seven xGMI links, nothing for a collective
+        library to schedule or serialise.  The group only carries the handles (an object broadcast) and the closing barrier, so it
+        may be gloo: the ranks then only need a visible GPU each -- or all the SAME one (how the path is tested on a one-GPU box)."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.group, self.root = group, root
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.backend = dist.get_backend(group)
-        self.dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+        if transport not in ("rccl", "ipc"):
+            raise ValueError("ShardedBatch: transport must be 'rccl' or 'ipc'")
+        self.transport = transport
+        on_gpu = self.backend == "nccl" or transport == "ipc"
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
         self.B, self.n, self.m, self.hasP = int(B), int(n), int(m), bool(hasP)
         self.local_solver, self.device_of_rank = local_solver, device_of_rank
         self.bounds = shard_bounds(self.B, self.world)
@@ -457,25 +484,160 @@ class ShardedBatch(object):
         self.P_l = torch.empty((self.mx, self.n, self.n), **f64) if self.hasP else None
         self.pack = torch.zeros((self.mx, self.width), **f64)
         self.gathered = None
-        if self.rank == root:
+        if self.rank == root and transport != "ipc":
             self.gathered = [[torch.empty((self.sb[k + 1] - self.sb[k], self.width), **f64) for _ in range(self.world)]
                              for k in range(self.nsub)]
         self.engine_factory = engine_factory
-        self.on_device = engine_factory is not None or (self.backend == "nccl" and local_solver is None)
+        self.on_device = engine_factory is not None or (on_gpu and local_solver is None)
         self.engines = [None] * self.nsub          # BatchKkt per sub-batch, created at the first solve and kept
         self.last_timings = {}
+        if transport == "ipc":
+            self._ipc_init()
 
     def close(self):
         for e in self.engines:
             if e is not None:
                 e.close()
         self.engines = [None] * self.nsub
+        if getattr(self, "_ipc_open", None):
+            if self.dev.type == "cuda":
+                self.torch.cuda.synchronize(self.dev)
+            for base in self._ipc_open.values():
+                _capi.lib().mi355kkt_ipc_close(C.c_void_p(base))
+            self._ipc_open = {}
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+    # ---- transport = "ipc" -------------------------------------------------------------------------------------------------
+    def _ipc_init(self):
+        torch = self.torch
+        self._ipc_open = {}                       # handle bytes -> base address of the mapping in this process
+        self.pull_stream = torch.cuda.Stream(self.dev)
+        self.push_stream = torch.cuda.Stream(self.dev)
+        self.result = None                        # root: (B, width), problem order; exported once
+        self._result_ref = None                   # others: the root's result buffer, mapped
+        if self.rank == self.root:
+            self.result = torch.zeros((self.B, self.width), dtype=torch.float64, device=self.dev)
+
+    def _ipc_export(self, t):
+        """(handle bytes, byte offset, shape) of a contiguous float64 CUDA tensor of this process"""
+        hd = (C.c_ubyte * 64)()
+        off, size = C.c_int64(), C.c_int64()
+        _capi.check(_capi.lib().mi355kkt_ipc_export(C.c_void_p(t.data_ptr()), hd, C.byref(off), C.byref(size)), "ipc_export")
+        return bytes(hd), int(off.value), tuple(int(v) for v in t.shape)
+
+    def _ipc_view(self, desc):
+        """a tensor of this process over memory another process exported (mapped on first sight of its allocation)"""
+        hd, off, shape = desc
+        base = self._ipc_open.get(hd)
+        if base is None:
+            out = C.c_void_p()
+            buf = (C.c_ubyte * 64).from_buffer_copy(hd)
+            _capi.check(_capi.lib().mi355kkt_ipc_open(buf, C.byref(out)), "ipc_open")
+            base = self._ipc_open[hd] = int(out.value)
+        return _foreign_tensor(self.torch, base + off, shape, self.dev)
+
+    def _solve_ipc(self, P, q, Gt, h, return_device, opts):
+        import time
+        torch, dist = self.torch, self.dist
+        n, m, root = self.n, self.m, self.root
+        t0 = time.perf_counter()
+        descs = [None]
+        if self.rank == root:
+            fulls = [self._as_tensor(q), self._as_tensor(h), self._as_tensor(Gt), self._as_tensor(P) if self.hasP else None]
+            fulls = [None if t is None else t.contiguous() for t in fulls]
+            torch.cuda.current_stream(self.dev).synchronize()       # the data is in HBM before anybody is told where it is
+            descs = [[None if t is None else self._ipc_export(t) for t in fulls] + [self._ipc_export(self.result)]]
+        dist.broadcast_object_list(descs, src=root, group=self.group)
+        if self.rank == root:
+            srcs, result = fulls, self.result
+        else:
+            d = descs[0]
+            srcs = [None if e is None else self._ipc_view(e) for e in d[:4]]
+            result = self._ipc_view(d[4])
+        # every pull is enqueued now, in the order it will be consumed; an event per sub-batch
+        dsts = [self.q_l, self.h_l, self.G_l, self.P_l]
+        pulled = []
+        with torch.cuda.stream(self.pull_stream):
+            for k in range(self.nsub):
+                a, b = self._rows(k)
+                if b > a:
+                    for src, dst in zip(srcs, dsts):
+                        if src is not None:
+                            dst[a:b].copy_(src[self.lo + a:self.lo + b], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.pull_stream)
+                pulled.append(ev)
+        tm = {"scatter_exposed": 0.0, "scatter_all": 0.0, "upload": 0.0, "solve": 0.0, "pack": 0.0, "gather_exposed": 0.0}
+        lockstep = 0
+        cur = torch.cuda.current_stream(self.dev)
+        for k in range(self.nsub):
+            pulled[k].synchronize()
+            t1 = time.perf_counter()
+            if k == 0:
+                tm["scatter_exposed"] = 1e3 * (t1 - t0)
+            tm["scatter_all"] = 1e3 * (t1 - t0)
+            a, b = self._rows(k)
+            cnt = b - a
+            if cnt <= 0:
+                continue
+            if self.engines[k] is None:
+                make = self.engine_factory or BatchKkt
+                self.engines[k] = make(shape=(cnt, n, m), device=self.dev.index)
+            eng = self.engines[k]
+            t2 = time.perf_counter()
+            eng.set_problem(self.G_l[a:b], self.P_l[a:b] if self.hasP else None)
+            t3 = time.perf_counter()
+            res = eng.coneqp(self.q_l[a:b], self.h_l[a:b], **opts)
+            t3b = time.perf_counter()
+            tm["upload"] += 1e3 * (t3 - t2)
+            tm["solve"] += 1e3 * (t3b - t3)
+            pk = self.pack[a:b]
+            pk[:, :n] = res['x']
+            pk[:, n:n + m] = res['s']
+            pk[:, n + m:n + 2 * m] = res['z']
+            pk[:, n + 2 * m] = res['primal objective']
+            pk[:, n + 2 * m + 1] = res['dual objective']
+            pk[:, n + 2 * m + 2] = res['gap']
+            pk[:, n + 2 * m + 3] = res['status_code'].to(torch.float64)
+            pk[:, n + 2 * m + 4] = res['iterations'].to(torch.float64)
+            lockstep = max(lockstep, int(res['lockstep iterations']))
+            # this sub-batch's rows go into the root's result buffer (problem order) while the next one is solved
+            done = torch.cuda.Event()
+            done.record(cur)
+            self.push_stream.wait_event(done)
+            with torch.cuda.stream(self.push_stream):
+                result[self.lo + a:self.lo + b].copy_(pk, non_blocking=True)
+            tm["pack"] += 1e3 * (time.perf_counter() - t3b)
+        t4 = time.perf_counter()
+        self.push_stream.synchronize()
+        self.pull_stream.synchronize()
+        dist.barrier(group=self.group)            # control plane only: every shard is in the root's buffer, nobody reads the inputs any more
+        t5 = time.perf_counter()
+        tm["gather_exposed"] = 1e3 * (t5 - t4)
+        tm["total"] = 1e3 * (t5 - t0)
+        self.last_timings = tm
+        t = self.result if self.rank == root else self.pack[:self.nloc]
+        if return_device:
+            t = t.clone()                          # (persistent buffers: the next solve() overwrites them)
+        return self._unpack(t, lockstep, return_device)
+
+    def _unpack(self, t, ls, return_device):
+        n, m = self.n, self.m
+        sc = t[:, n + 2 * m:].cpu().numpy()                        # pcost dcost gap status iters: O(B) doubles
+        if return_device:
+            vec = {'x': t[:, :n], 's': t[:, n:n + m], 'z': t[:, n + m:n + 2 * m]}
+        else:
+            a_ = t[:, :n + 2 * m].cpu().numpy()
+            vec = {'x': a_[:, :n].copy(), 's': a_[:, n:n + m].copy(), 'z': a_[:, n + m:n + 2 * m].copy()}
+        vec.update({'primal objective': sc[:, 0].copy(), 'dual objective': sc[:, 1].copy(), 'gap': sc[:, 2].copy(),
+                    'status': _STATUS_NAMES[sc[:, 3].astype(int)], 'iterations': sc[:, 4].astype(int),
+                    'lockstep iterations': ls})
+        return vec
 
     def _rows(self, k):
         """rows of MY shard in sub-batch k"""
@@ -516,6 +678,10 @@ class ShardedBatch(object):
         was complete here), scatter_all (until the last one was), upload, solve (sum over sub-batches), pack (results into the packed
         gather rows), gather_exposed (after the last solve), total."""
         import time
+        if self.transport == "ipc":
+            if not (self.on_device and opts.get("resident", True)):
+                raise NotImplementedError("ShardedBatch(transport='ipc') serves the device-resident solve only")
+            return self._solve_ipc(P, q, Gt, h, return_device, {k_: v for k_, v in opts.items() if k_ != "resident"})
         torch, dist = self.torch, self.dist
         n, m, root = self.n, self.m, self.root
         t0 = time.perf_counter()
@@ -625,11 +791,56 @@ class ShardedBatch(object):
         return full
 
 
+def ipc_transport_works(group=None, root=0):
+    """Collective (every rank of `group` calls it): can every rank map an allocation of the root's GPU and read it?  A 4 KB
+    probe through exactly the calls ShardedBatch(transport="ipc") makes -- mi355kkt_ipc_export on the root, mi355kkt_ipc_open +
+    a device-to-device copy everywhere else.  Returns (ok, reasons): ok only if EVERY rank succeeded, so that all ranks choose
+    the same transport (`bench.py --gpus N --transport auto`)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    L = _capi.lib()
+    desc, src, why, base = [None], None, "", None
+    try:
+        if rank == root:
+            src = torch.arange(512, dtype=torch.float64, device=dev)
+            torch.cuda.current_stream(dev).synchronize()
+            hd = (C.c_ubyte * 64)()
+            off, size = C.c_int64(), C.c_int64()
+            _capi.check(L.mi355kkt_ipc_export(C.c_void_p(src.data_ptr()), hd, C.byref(off), C.byref(size)), "ipc_export")
+            desc = [(bytes(hd), int(off.value))]
+    except Exception as e:                     # the broadcast below must still happen on every rank
+        why = "export: %r" % (e,)
+    dist.broadcast_object_list(desc, src=root, group=group)
+    if rank != root:
+        try:
+            if desc[0] is None:
+                raise RuntimeError("the root could not export")
+            out = C.c_void_p()
+            _capi.check(L.mi355kkt_ipc_open((C.c_ubyte * 64).from_buffer_copy(desc[0][0]), C.byref(out)), "ipc_open")
+            base = int(out.value)
+            got = torch.empty(512, dtype=torch.float64, device=dev)
+            got.copy_(_foreign_tensor(torch, base + desc[0][1], (512,), dev))
+            torch.cuda.current_stream(dev).synchronize()
+            if not torch.equal(got.cpu(), torch.arange(512, dtype=torch.float64)):
+                raise RuntimeError("the mapped allocation does not hold the root's data")
+        except Exception as e:
+            why = "open / copy: %r" % (e,)
+        finally:
+            if base is not None:
+                L.mi355kkt_ipc_close(C.c_void_p(base))
+    whys = [None] * world
+    dist.all_gather_object(whys, why, group=group)
+    del src
+    return all(not w for w in whys), whys
+
+
 _SHARDED_CACHE = {}
 
 
 def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, device_of_rank=None, return_device=False, nsub=4,
-                         **opts):
+                         transport="rccl", **opts):
     """P, q, Gt, h are only read on `root` (other ranks may pass None): NumPy arrays, or -- with RCCL -- float64 CUDA
     tensors already resident in the root's HBM (then the scatter sends views of them, nothing is staged or copied).
     Root returns the FULL gathered result dict (NumPy), the other ranks their local shard's.
@@ -648,16 +859,17 @@ def coneqp_batch_sharded(P, q, Gt, h, group=None, root=0, local_solver=None, dev
     B, n, m, hasP = meta[0]
     # keyed on the group OBJECT (kept alive by the cache entry, so its id cannot be recycled under us) and this rank in it;
     # local_solver is not part of the key (it is re-assigned below: a fresh lambda per call must not rebuild the engines)
-    key = (group, rank, root, B, n, m, hasP, int(nsub), dist.get_backend(group), dist.get_world_size(group))
+    key = (group, rank, root, B, n, m, hasP, int(nsub), dist.get_backend(group), dist.get_world_size(group), transport)
     sb = _SHARDED_CACHE.get(key)
-    if sb is not None and sb.on_device != (sb.engine_factory is not None or (sb.backend == "nccl" and local_solver is None)):
+    if sb is not None and sb.on_device != (sb.engine_factory is not None or
+                                           ((sb.backend == "nccl" or transport == "ipc") and local_solver is None)):
         sb = None                                     # device-resident <-> host-solver switch: rebuild
     if sb is None:
         for old in list(_SHARDED_CACHE.values()):    # one shape at a time: the engines hold GBs
             old.close()
         _SHARDED_CACHE.clear()
         sb = _SHARDED_CACHE[key] = ShardedBatch(B, n, m, hasP, group=group, root=root, nsub=nsub, local_solver=local_solver,
-                                                device_of_rank=device_of_rank)
+                                                device_of_rank=device_of_rank, transport=transport)
     sb.local_solver = local_solver
     return sb.solve(P, q, Gt, h, return_device=return_device, **opts)
 

@@ -480,6 +480,33 @@ int mi355kkt_device_synchronize(void) try {
     KKT_HIP_CHECK(hipDeviceSynchronize());
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_device_synchronize"); }
+// device memory shared between the processes of one node (batch scatter / gather without a collective)
+int mi355kkt_ipc_export(const void* dptr, void* handle64, int64_t* offset, int64_t* alloc_bytes) try {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI promises a 64-byte handle");
+    if (!dptr || !handle64 || !offset) { set_last_error("mi355kkt_ipc_export: null argument"); return MI355KKT_EINVAL; }
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    KKT_HIP_CHECK(hipMemGetAddressRange(&base, &size, const_cast<void*>(dptr)));
+    hipIpcMemHandle_t hd;
+    KKT_HIP_CHECK(hipIpcGetMemHandle(&hd, base));
+    memcpy(handle64, &hd, sizeof(hd));
+    *offset = (int64_t)((const char*)dptr - (const char*)base);
+    if (alloc_bytes) *alloc_bytes = (int64_t)size;
+    return 0;
+} catch (...) { return kkt_catch("mi355kkt_ipc_export"); }
+int mi355kkt_ipc_open(const void* handle64, void** base) try {
+    if (!handle64 || !base) { set_last_error("mi355kkt_ipc_open: null argument"); return MI355KKT_EINVAL; }
+    hipIpcMemHandle_t hd;
+    memcpy(&hd, handle64, sizeof(hd));
+    void* p = nullptr;
+    KKT_HIP_CHECK(hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess));
+    *base = p;
+    return 0;
+} catch (...) { return kkt_catch("mi355kkt_ipc_open"); }
+int mi355kkt_ipc_close(void* base) try {
+    if (base) KKT_HIP_CHECK(hipIpcCloseMemHandle(base));
+    return 0;
+} catch (...) { return kkt_catch("mi355kkt_ipc_close"); }
 
 static size_t dmax(size_t a, size_t b) { return a > b ? a : b; }
 

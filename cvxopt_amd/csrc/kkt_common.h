@@ -136,6 +136,7 @@ struct PotrfWork {
     int m512_blocks = 0;
     unsigned m512_launches = 0;       // formation launches so far (their stage counters only ever grow)
     int m512_n = 0;
+    int m512_shape_n = 0;             // the order whose zero pattern d_m512 currently has
     const double* m512_of = nullptr;
     // look-ahead: the bulk of each trailing update runs on `side` while the next panel is factored on the main stream
     hipStream_t side = nullptr;

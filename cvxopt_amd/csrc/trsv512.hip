@@ -360,10 +360,12 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
 // ===================================================================================================
 // C(64 x 64) = alpha A(64 x k0..k1) B(k0..k1 x 64), column-major; Ct (optional): the transposed tile, element (j, i) at
 // Ct[j + i ldct].  Four waves, one 32 x 32 quarter each, v_mfma_f64_16x16x4 straight from global memory (the operands are a few
-// hundred KB that the factorisation has just left in the caches): lane (li, lk) feeds A[i0 + li][k + lk] and B[k + lk][j0 + li],
+// hundred KB that the factorisation has just left in the caches): lane (li, lk) feeds A[i0 + li][k + lk] and B[k + lk][j0 + li] (see Bt below),
 // register r of the result is C[i0 + li][j0 + (lane >> 4) + 4 r].
 typedef double d4w __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void mfma_tile64(const double* __restrict__ A, int64_t lda, const double* __restrict__ B, int64_t ldb,
+// B arrives TRANSPOSED (Bt[j + k ldbt] = B[k][j]): both operands are then read with 16 consecutive lanes on 128 consecutive bytes
+// (every B of the four stages has a transposed twin anyway: M', and the T products are stored both ways)
+__device__ __forceinline__ void mfma_tile64(const double* __restrict__ A, int64_t lda, const double* __restrict__ Bt, int64_t ldbt,
                                             int k0, int k1, double alpha, double* C, int64_t ldc, double* Ct, int64_t ldct, int tid) {
     const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int i0 = 32 * (wv & 1), j0 = 32 * (wv >> 1);
@@ -373,15 +375,15 @@ __device__ __forceinline__ void mfma_tile64(const double* __restrict__ A, int64_
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc[u][t] = d4w{0.0, 0.0, 0.0, 0.0};
     const double* Ap = A + (i0 + li) + (int64_t)lk * lda;
-    const double* Bp = B + lk + (int64_t)(j0 + li) * ldb;
+    const double* Bp = Bt + (j0 + li) + (int64_t)lk * ldbt;
     for (int k = k0; k < k1; k += 64) {                        // (k0, k1: multiples of 64) sixteen MFMA steps' operands at a time:
         double a0[16], a1[16], b0[16], b1[16];                 // a product is a chain of (k1 - k0) / 64 memory latencies
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
             a0[s4] = Ap[(int64_t)(k + 4 * s4) * lda];
             a1[s4] = Ap[16 + (int64_t)(k + 4 * s4) * lda];
-            b0[s4] = Bp[k + 4 * s4];
-            b1[s4] = Bp[k + 4 * s4 + 16 * ldb];
+            b0[s4] = Bp[(int64_t)(k + 4 * s4) * ldbt];
+            b1[s4] = Bp[16 + (int64_t)(k + 4 * s4) * ldbt];
         }
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
@@ -419,38 +421,54 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
     const int qn = min(WB, n - o) / 128;                       // 128-blocks in this 512-block (1..4)
     double* M = m512 + (int64_t)b * 2 * WB * WB;
     double* Mt = M + (int64_t)WB * WB;
-    double* T = scratch + (int64_t)b * 256 * 256;
+    double* T = scratch + (int64_t)b * 2 * 256 * 256;         // the transposed products (read again) ...
+    double* T2 = T + 256 * 256;                               // ... and their plain copies (never read: mfma_tile64 writes both)
     constexpr int NB2 = 128 * 128;
+    // (one cache operation per workgroup and direction: a release / acquire fence in every wave -- measured -- is what the kernel
+    //  then consists of: 114 us at 64 workgroups, 280 us at 256)
     auto block_sync = [&](u32 target) {
-        __threadfence();                                       // my stores are out (and written back) before anybody is told
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every wave drains its own stores
         __syncthreads();
         if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // ... and they are written back before anybody is told
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(cnt + b, 1u, RLX_AGENT);
             for (unsigned spins = 0; spins < (1u << 24); ++spins) {
                 if ((int)(__hip_atomic_load(cnt + b, RLX_AGENT) - target) >= 0) break;
                 __builtin_amdgcn_s_sleep(2);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // what the others wrote is read from memory, not from a stale line
         }
         __syncthreads();
-        __threadfence();                                       // what the others wrote is read from memory, not from a stale line
     };
     {   // stage 1
         if (t >= 12) {
             const int d = t - 12;                               // copy diagonal block d
             if (d < qn) {
                 const double* src = minv + (int64_t)(4 * b + d) * 2 * NB2;
-                for (int e = tid; e < NB2; e += 256) {
-                    const int i = e & 127, jc = e >> 7;
-                    M[(128 * d + i) + (int64_t)(128 * d + jc) * WB] = src[e];
-                    Mt[(128 * d + i) + (int64_t)(128 * d + jc) * WB] = src[NB2 + e];
+                // (sixteen elements of each in flight per thread: one at a time, the copy is a chain of 64 memory latencies -- measured,
+                //  ~100 us, the whole formation)
+                for (int e0 = tid; e0 < NB2; e0 += 16 * 256) {
+                    double va[16], vb[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) { va[u] = src[e0 + 256 * u]; vb[u] = src[NB2 + e0 + 256 * u]; }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int e = e0 + 256 * u, i = e & 127, jc = e >> 7;
+                        M[(128 * d + i) + (int64_t)(128 * d + jc) * WB] = va[u];
+                        Mt[(128 * d + i) + (int64_t)(128 * d + jc) * WB] = vb[u];
+                    }
                 }
             }
         } else if (t < 8) {
             const int p = t >> 2, ti = (t >> 1) & 1, tj = t & 1;
             if (2 * p + 1 < qn) {
                 const double* A = L + (o + 128 * (2 * p + 1) + 64 * ti) + (int64_t)(o + 128 * 2 * p) * ldl;
-                const double* B = minv + (int64_t)(4 * b + 2 * p) * 2 * NB2 + (int64_t)(64 * tj) * 128;
-                mfma_tile64(A, ldl, B, 128, 64 * tj, 128, 1.0, T + (int64_t)p * NB2 + 64 * ti + (int64_t)(64 * tj) * 128, 128, nullptr, 0, tid);
+                const double* Bt = minv + (int64_t)(4 * b + 2 * p) * 2 * NB2 + NB2 + 64 * tj;       // M_2p' (rows 64 tj..)
+                // only T' is needed (the B operand of stage 2); it lives in the first half of the block's scratch
+                double* Tt = T + (int64_t)p * NB2;
+                mfma_tile64(A, ldl, Bt, 128, 64 * tj, 128, 1.0, T + 2 * NB2 + (int64_t)p * NB2 + 64 * ti + (int64_t)(64 * tj) * 128, 128,
+                            Tt + 64 * tj + (int64_t)(64 * ti) * 128, 128, tid);
             }
         }
     }
@@ -459,9 +477,9 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
         const int p = t >> 2, ti = (t >> 1) & 1, tj = t & 1;
         if (2 * p + 1 < qn) {
             const double* A = minv + (int64_t)(4 * b + 2 * p + 1) * 2 * NB2 + 64 * ti;
-            const double* B = T + (int64_t)p * NB2 + (int64_t)(64 * tj) * 128;
+            const double* Bt = T + (int64_t)p * NB2 + 64 * tj;                                      // T_p' (rows 64 tj..)
             const int ri = 128 * (2 * p + 1) + 64 * ti, cj = 128 * 2 * p + 64 * tj;
-            mfma_tile64(A, 128, B, 128, 0, 64 * ti + 64, -1.0, M + ri + (int64_t)cj * WB, WB, Mt + cj + (int64_t)ri * WB, WB, tid);
+            mfma_tile64(A, 128, Bt, 128, 0, 64 * ti + 64, -1.0, M + ri + (int64_t)cj * WB, WB, Mt + cj + (int64_t)ri * WB, WB, tid);
         }
     }
     block_sync(base + 32);
@@ -470,15 +488,17 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
     const bool work = rows2 > 0 && 64 * ti < rows2;
     if (work) {   // stage 3
         const double* A = L + (o + 256 + 64 * ti) + (int64_t)o * ldl;
-        const double* B = M + (int64_t)(64 * tj) * WB;
-        mfma_tile64(A, ldl, B, WB, 64 * tj, 256, 1.0, T + 64 * ti + (int64_t)(64 * tj) * 256, 256, nullptr, 0, tid);
+        const double* Bt = Mt + 64 * tj;                                                             // M(0..255, 0..255)' (rows 64 tj..)
+        // T2 is 256 x 256 at most and only its transpose is read again: T2'[j + i 256]; the plain copy goes to the second scratch
+        mfma_tile64(A, ldl, Bt, WB, 64 * tj, 256, 1.0, T2 + 64 * ti + (int64_t)(64 * tj) * 256, 256,
+                    T + 64 * tj + (int64_t)(64 * ti) * 256, 256, tid);
     }
     block_sync(base + 48);
     if (work) {   // stage 4
         const double* A = M + (256 + 64 * ti) + (int64_t)256 * WB;
-        const double* B = T + (int64_t)(64 * tj) * 256;
+        const double* Bt = T + 64 * tj;                                                              // T2' (rows 64 tj..)
         const int ri = 256 + 64 * ti, cj = 64 * tj;
-        mfma_tile64(A, WB, B, 256, 0, 64 * ti + 64, -1.0, M + ri + (int64_t)cj * WB, WB, Mt + cj + (int64_t)ri * WB, WB, tid);
+        mfma_tile64(A, WB, Bt, 256, 0, 64 * ti + 64, -1.0, M + ri + (int64_t)cj * WB, WB, Mt + cj + (int64_t)ri * WB, WB, tid);
     }
 }
 
@@ -505,19 +525,22 @@ int launch_block_inverse512(const double* L, int64_t ldl, int n, PotrfWork& w, h
         w.m512_n = 0;
         const size_t mb = sizeof(double) * 2 * WB * WB * (size_t)NBk, gb = sizeof(u64) * 4 * 2 * WB * (size_t)NBk;
         KKT_HIP_CHECK(DEV_ALLOC(&w.d_m512, mb));
-        KKT_HIP_CHECK(DEV_ALLOC(&w.d_m512_scratch, sizeof(double) * (256 * 256 * (size_t)NBk + NBk)));       // + the stage counters
-        KKT_HIP_CHECK(hipMemsetAsync(w.d_m512_scratch + 256 * 256 * (size_t)NBk, 0, sizeof(double) * NBk, st));
+        KKT_HIP_CHECK(DEV_ALLOC(&w.d_m512_scratch, sizeof(double) * (2 * 256 * 256 * (size_t)NBk + NBk)));       // + the stage counters
+        KKT_HIP_CHECK(hipMemsetAsync(w.d_m512_scratch + 2 * 256 * 256 * (size_t)NBk, 0, sizeof(double) * NBk, st));
         w.m512_launches = 0;
         KKT_HIP_CHECK(DEV_ALLOC(&w.d_gran512, gb));
         // the blocks above the diagonal of M (below it in M') are never written: zeros for good; granule tags start at epoch 0
         KKT_HIP_CHECK(hipMemsetAsync(w.d_m512, 0, mb, st));
         KKT_HIP_CHECK(hipMemsetAsync(w.d_gran512, 0, gb, st));
         w.m512_blocks = NBk;
-    } else if (w.m512_n != n) {
+        w.m512_shape_n = n;
+    } else if (w.m512_shape_n != n) {
         // another order in the same storage: what an earlier, larger or differently ragged factor left must not survive
+        // (m512_n = 0 only says "stale": a refactorisation of the same order rewrites exactly what it wrote before)
         KKT_HIP_CHECK(hipMemsetAsync(w.d_m512, 0, sizeof(double) * 2 * WB * WB * (size_t)NBk, st));
+        w.m512_shape_n = n;
     }
-    u32* cnt = reinterpret_cast<u32*>(w.d_m512_scratch + 256 * 256 * (size_t)w.m512_blocks);
+    u32* cnt = reinterpret_cast<u32*>(w.d_m512_scratch + 2 * 256 * 256 * (size_t)w.m512_blocks);
     hipLaunchKernelGGL(block_inverse512_kernel, dim3(16, NBk), dim3(256), 0, st, L, ldl, n, w.d_minv, w.d_m512, w.d_m512_scratch, cnt,
                        48u * w.m512_launches++);
     KKT_HIP_CHECK(hipGetLastError());

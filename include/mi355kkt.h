@@ -73,6 +73,13 @@ int mi355kkt_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int mi355kkt_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int mi355kkt_memcpy_d2d(void* dst, const void* src, size_t bytes);
 int mi355kkt_device_synchronize(void);
+/* Cross-process sharing of device memory on one node (the batch scatter / gather without a collective: SURVEY 8(e) "alternative
+ * without xGMI collectives"; cvxopt_amd.batch.ShardedBatch(transport="ipc")).  export: a 64-byte handle of the ALLOCATION that
+ * contains dptr, and dptr's byte offset in it (dptr may point into a pooled allocation).  open, in ANOTHER process: maps that
+ * allocation (peer access over xGMI when it lives on another device) and returns its base address there; close unmaps it. */
+int mi355kkt_ipc_export(const void* dptr, void* handle64, int64_t* offset, int64_t* alloc_bytes);
+int mi355kkt_ipc_open(const void* handle64, void** base);
+int mi355kkt_ipc_close(void* base);
 
 /* ---- solver handle: mirrors `factor = misc.kkt_<name>(G, dims, A[, mnl][, kktreg])` ------------- */
 /* dims = {'l': ml, 'q': q[0..nq), 's': s[0..ns)};  n variables, p equalities.  G is cdim x n with

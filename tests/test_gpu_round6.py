@@ -133,3 +133,90 @@ def test_sparse_info_is_the_first_bad_column_of_the_engines_own_order():
     S = (P + G.T @ G).toarray()[np.ix_(perm, perm)]
     _, info = sla.lapack.dpotrf(np.asfortranarray(S), lower=1)
     assert info > 0 and int(ei.value.args[0]) == info
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_batch_over_ipc_without_a_collective(world):
+    """ShardedBatch(transport="ipc"): `world` processes -- sharing this box's GPU(s) -- pull their shards from
+    the root's exported buffers and push their results into its result buffer; per-problem equality with the single-GPU solve,
+    uneven and empty shards, nsub = 1, 2, 4 (tests/run_batch_sharded_ipc.py)."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(29540 + world),
+                          os.path.join(here, "run_batch_sharded_ipc.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "SHARDED_IPC_OK world=%d" % world in out.stdout
+
+
+# ---- (b) the 512-row all-CU triangular solves -----------------------------------------------------------------------------------
+def _engine_solves(n, m, p, wide, rhs, spread=1.5):
+    """solve() of one dense engine through the hook with the wide solves on / off (test knob MI355KKT_TRSV_WIDE)"""
+    pr = synth.dense_qp(n, m, seed=n + 3, p=p)
+    G, P, dims = pr['G'], pr['P'], pr['dims']
+    A = pr.get('A', np.zeros((0, n)))
+    W = synth.random_scaling(dims, seed=5, spread=spread)
+    _capi.set_knob("MI355KKT_TRSV_WIDE", wide)
+    f = kkt.kkt_chol2(G, dims, A)
+    try:
+        s = f(W, P)
+        out = []
+        for bx, by, bz in rhs:
+            x, y, z = bx.copy(), by.copy(), bz.copy()
+            s(x, y, z)
+            out.append((x, y, z))
+    finally:
+        f.engine.close()
+        _capi.set_knob("MI355KKT_TRSV_WIDE", None)
+    return pr, W, out
+
+
+@pytest.mark.parametrize("n,p", [(1024, 0), (1152, 0), (1920, 4), (2048, 0), (2176, 0), (3072, 9), (4096, 0), (4224, 0)])
+def test_wide_triangular_solves_match_the_pair_kernel_and_the_oracle(n, p):
+    """orders that are multiples of 128 from 1024 up: whole 512-blocks (1024, 2048, 3072, 4096), ragged last block of 128 / 256 / 384
+    rows (1152, 2176 / 1920 / 4224), 8 rows per workgroup (n <= 2048) and 16; with and without the Schur complement of equality
+    constraints behind the solves.  Same answer as the round-4 two-sweep kernel to 1e-9, KKT residual no worse than 3 x the oracle's
+    (LAPACK on the CPU), bit for bit the same under repetition."""
+    m = n + 64
+    rng = np.random.default_rng(n)
+    rhs = [(rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)) for _ in range(2)]
+    pr, W, wide = _engine_solves(n, m, p, 1, rhs)
+    _, _, again = _engine_solves(n, m, p, 1, rhs)
+    _, _, pair = _engine_solves(n, m, p, 0, rhs)
+    G, P, dims = pr['G'], pr['P'], pr['dims']
+    A = pr.get('A', np.zeros((0, n)))
+    oracle = ko.KktChol2(G, dims, A).factor(W, P)
+    worst_pair, res_w, res_p, res_o = 0.0, 0.0, 0.0, 0.0
+    for (bx, by, bz), w3, a3, p3 in zip(rhs, wide, again, pair):
+        for u, v in zip(w3, a3):
+            assert np.array_equal(u, v)                         # deterministic
+        worst_pair = max(worst_pair, relerr(w3[0], p3[0]), relerr(w3[2], p3[2]))
+        xo, yo, zo = bx.copy(), by.copy(), bz.copy()
+        oracle(xo, yo, zo)
+        res_w = max(res_w, ko.kkt_residual(P, A, G, W, dims, bx, by, bz, *w3))
+        res_p = max(res_p, ko.kkt_residual(P, A, G, W, dims, bx, by, bz, *p3))
+        res_o = max(res_o, ko.kkt_residual(P, A, G, W, dims, bx, by, bz, xo, yo, zo))
+    record("round6_wide_%d_%d" % (n, p), wide_vs_pair=worst_pair, kkt_residual_wide=res_w, kkt_residual_pair=res_p,
+           kkt_residual_oracle=res_o)
+    assert worst_pair < 1e-9, worst_pair
+    assert res_w <= max(1e-12, 3.0 * res_o), (res_w, res_o)
+
+
+def test_wide_solves_two_slices_per_workgroup_at_8192():
+    """n = 8192: 512 slices of 16 rows on 256 compute units -- every workgroup takes a second slice when its first is done"""
+    n, m = 8192, 1024
+    rng = np.random.default_rng(1)
+    rhs = [(rng.standard_normal(n), np.zeros(0), rng.standard_normal(m))]
+    pr, W, wide = _engine_solves(n, m, 0, 1, rhs, spread=1.0)
+    _, _, pair = _engine_solves(n, m, 0, 0, rhs, spread=1.0)
+    G, P, dims = pr['G'], pr['P'], pr['dims']
+    (bx, by, bz), w3, p3 = rhs[0], wide[0], pair[0]
+    assert relerr(w3[0], p3[0]) < 1e-9 and relerr(w3[2], p3[2]) < 1e-9
+    A = np.zeros((0, n))
+    res_w = ko.kkt_residual(P, A, G, W, dims, bx, by, bz, *w3)
+    res_p = ko.kkt_residual(P, A, G, W, dims, bx, by, bz, *p3)
+    record("round6_wide_8192", kkt_residual_wide=res_w, kkt_residual_pair=res_p)
+    assert res_w <= max(1e-12, 2.0 * res_p), (res_w, res_p)
