@@ -380,6 +380,12 @@ struct mi355kkt_solver {
     // mi355kkt_set_option
     int use_correction = 1;    // options['use_correction'] of solvers.coneqp (coneprog.py:1781)
     int ldl_refine = 2;        // refinement steps of the ldl / ldl2 flavours against the 3 x 3 system
+    // round 6, the 'qr' mapping (misc.kkt_qr -> this engine): the same refinement, but only for factorisations whose reduced matrix
+    // is ill conditioned -- (max L_ii / min L_ii)^2, a lower bound of cond(S), read back with the info word, above QR_REFINE_COND
+    int qr_refine = 0;         // steps (0: off; mi355kkt_set_option "qr_refinement")
+    bool qr_active = false;    // this factorisation's solves are refined
+    double* d_cond = nullptr;  // {min, max} of diag(L), device / pinned host
+    double* h_cond = nullptr;
 };
 
 // per-iteration report of a device-resident loop: the scalar block comes back with one small copy (the loop has just
@@ -631,6 +637,8 @@ void mi355kkt_destroy(mi355kkt_solver* h) try {
     if (h->ev_h) (void)hipEventDestroy(h->ev_h);
     if (h->dgran) (void)dev_free(h->dgran);
     if (h->dRef) (void)dev_free(h->dRef);
+    if (h->d_cond) (void)dev_free(h->d_cond);
+    if (h->h_cond) (void)hipHostFree(h->h_cond);
     if (h->derr) (void)dev_free(h->derr);
     if (h->herr) (void)hipHostFree(h->herr);
     for (double* b : bufs)
@@ -967,9 +975,38 @@ int mi355kkt_set_option(mi355kkt_solver* h, const char* name, double value) try 
         h->ldl_refine = (int)value;
         return 0;
     }
+    if (!strcmp(name, "qr_refinement")) {
+        if (!(value >= 0.0) || value > 16.0) { set_last_error("set_option: qr_refinement must be in 0..16"); return MI355KKT_EINVAL; }
+        h->qr_refine = (int)value;
+        h->qr_active = false;
+        return 0;
+    }
     set_last_error("set_option: unknown option '%s'", name);
     return MI355KKT_EINVAL;
 } catch (...) { return kkt_catch("mi355kkt_set_option"); }
+
+// {min, max} of |diag(L)|: one workgroup, fixed order
+constexpr double QR_REFINE_COND = 1e8;       // (max L_ii / min L_ii)^2 from which the 'qr' mapping refines its solves
+__global__ __launch_bounds__(256) void diag_minmax_kernel(const double* __restrict__ S, int64_t ld, int n, double* __restrict__ out) {
+    __shared__ double lo[256], hi[256];
+    double a = 1e300, b = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double v = fabs(S[i + (int64_t)i * ld]);
+        a = v < a ? v : a;                                     // (a NaN pivot never gets here: info > 0 is returned first)
+        b = v > b ? v : b;
+    }
+    lo[threadIdx.x] = a;
+    hi[threadIdx.x] = b;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if ((int)threadIdx.x < s2) {
+            lo[threadIdx.x] = fmin(lo[threadIdx.x], lo[threadIdx.x + s2]);
+            hi[threadIdx.x] = fmax(hi[threadIdx.x], hi[threadIdx.x + s2]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = lo[0]; out[1] = hi[0]; }
+}
 
 // info word -> host (synchronises the stream)
 // the all-CU triangular solves (trsv512.hip) serve this handle's S: dense engine, order a multiple of 128 from 1024 up to
@@ -1194,8 +1231,20 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
     // tile Cholesky of S left (not when K went through the tile kernel after it: they are K's then)
     if (trsv_wide_wanted(h) && h->pw.minv_n == h->n && h->pw.minv_of == h->dS)
         if (int e = launch_block_inverse512(h->dS, h->n, h->n, h->pw, h->st)) return e;
+    if (h->qr_refine > 0) {
+        if (!h->d_cond) {
+            KKT_HIP_CHECK(DEV_ALLOC(&h->d_cond, 2 * sizeof(double)));
+            KKT_HIP_CHECK(hipHostMalloc(&h->h_cond, 2 * sizeof(double)));
+        }
+        hipLaunchKernelGGL(diag_minmax_kernel, dim3(1), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->n, h->d_cond);
+        KKT_HIP_CHECK(hipMemcpyAsync(h->h_cond, h->d_cond, 2 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+    }
     KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
     if (int e = fetch_info(h, &info)) return e;
+    if (h->qr_refine > 0) {
+        const double r = h->h_cond[1] / h->h_cond[0];
+        h->qr_active = !(r * r < QR_REFINE_COND);              // (also for inf / nan)
+    }
     (void)hipEventElapsedTime(&h->t_syrk, h->ev[0], h->ev[1]);
     (void)hipEventElapsedTime(&h->t_potrf, h->ev[1], h->ev[2]);
     (void)hipEventElapsedTime(&h->t_schur, h->ev[2], h->ev[3]);
@@ -1282,8 +1331,9 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     //     [H A' Gs'; A 0 0; Gs 0 -I] [ux; uy; w] = [bx; by; zs],   Gs = W^-T G,  zs = W^-T bz,  w = W uz.
     // (mi355kkt_set_option(h, "ldl_refinement", steps), 0 switches it off; not applied with kktreg, whose regularised system is the one to be solved.)
     // Two steps by default: one brings d in 1e-3 .. 1e3 from 3e-9 to 2e-15 (the reference: 2e-13), d in 1e-5 .. 1e5 needs the second.
-    const int ref_steps = h->ldl_refine;
-    const bool refine = ref_steps > 0 && (h->kind == MI355KKT_LDL || h->kind == MI355KKT_LDL2) && h->kktreg == 0.0 && mk > 0 && n > 0;
+    const bool ldl_kind = h->kind == MI355KKT_LDL || h->kind == MI355KKT_LDL2;
+    const int ref_steps = ldl_kind ? h->ldl_refine : (h->qr_active ? h->qr_refine : 0);
+    const bool refine = ref_steps > 0 && h->kktreg == 0.0 && mk > 0 && n > 0;
     double *bx0 = nullptr, *by0 = nullptr, *zs0 = nullptr, *rx = nullptr, *ry = nullptr, *rz = nullptr, *tt = nullptr;
     if (refine) {
         if (!h->dRef) KKT_HIP_CHECK(DEV_ALLOC(&h->dRef, sizeof(double) * (2 * (size_t)n + 2 * (size_t)dmax(p, 1) + 3 * (size_t)mk)));

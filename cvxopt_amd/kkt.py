@@ -662,6 +662,8 @@ def conelp_device(c, G, h, dims=None, A=None, b=None, kktsolver='chol', maxiters
         kind = _capi.CHOL
     eng = _Engine(kind, G, dims, A if A is not None else _EmptyA(n), kktreg=kktreg if kind == _capi.LDL else None)
     try:
+        if kktsolver == 'qr':
+            eng.set_option("qr_refinement", QR_REFINEMENT)      # (defined below, next to kkt_qr)
         eng.show_progress(show_progress, lp=True)
         sol = eng.conelp(c, h, b=b, maxiters=maxiters, abstol=abstol, reltol=reltol, feastol=feastol,
                          refinement=refinement, kktreg=kktreg, primalstart=primalstart, dualstart=dualstart)
@@ -757,10 +759,19 @@ def kkt_ldl2(G, dims, A, mnl=0):
     return _factory(_capi.LDL2, G, dims, A, mnl)
 
 
+QR_REFINEMENT = 4     # refinement steps of the 'qr' mapping (only for factorisations with an ill-conditioned reduced matrix)
+
+
 def kkt_qr(G, dims, A):
-    """Mirror of misc.kkt_qr (misc.py:1570; conelp only, H = 0).  Same KKT system, solved by the device
-    engine's reduced Cholesky form instead of two QR factorisations."""
+    """Mirror of misc.kkt_qr (misc.py:1570; conelp only, H = 0).  Same KKT system; the reference factors W^-T G Q2 by QR (error
+    proportional to cond(W^-T G)), this engine factors the reduced matrix Gs'Gs by Cholesky (cond squared).  Round 6: solves of a
+    factorisation whose Cholesky factor shows (max L_ii / min L_ii)^2 >= 1e8 get four steps of iterative refinement against the
+    unreduced 3 x 3 system (option "qr_refinement", include/mi355kkt.h) -- free while the problem is well conditioned; with it the
+    mapping follows the reference's 'qr' (same status, iteration count, objective) up to cond(W^-T G) ~ 3e6, where the plain
+    Cholesky mapping of rounds 1-5 lost it at ~1e5 (as the reference's own 'chol' does); beyond ~1e7 the reduced matrix is
+    numerically singular and only a QR-accurate factor would help (measured: profiles/r06_kkt_qr_conditioning.txt)."""
     fac = _factory(_capi.CHOL, G, dims, A, 0)
+    fac.engine.set_option("qr_refinement", QR_REFINEMENT)
 
     def factor(W):
         return fac(W, None)
@@ -782,7 +793,7 @@ def kktsolver_qp(G, dims, A, P, kind="chol2", kktreg=None):
 
 def kktsolver_lp(G, dims, A, kind="chol", kktreg=None):
     """`kktsolver` callable for solvers.conelp (coneprog.py:571-585 does `factor(W)`)."""
-    fac = {"chol2": kkt_chol2, "chol": kkt_chol, "ldl2": kkt_ldl2}.get(kind)
+    fac = {"chol2": kkt_chol2, "chol": kkt_chol, "ldl2": kkt_ldl2, "qr": kkt_qr}.get(kind)
     factor = kkt_ldl(G, dims, A, kktreg=kktreg) if kind == "ldl" else fac(G, dims, A)
 
     def kktsolver(W):

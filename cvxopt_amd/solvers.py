@@ -158,7 +158,7 @@ def conelp(c, G, h, dims=None, A=None, b=None, primalstart=None, dualstart=None,
         return _as_cvxopt(_kkt.conelp_device(c, G, h, dims, A, b, kktsolver=ks_name, primalstart=primalstart,
                                              dualstart=dualstart, **o))
     Am = A if A is not None else spmatrix([], [], [], (0, n))
-    ks = _kkt.kktsolver_lp(G, dims, Am, kind={'qr': 'chol'}.get(ks_name, ks_name), kktreg=kktreg)
+    ks = _kkt.kktsolver_lp(G, dims, Am, kind=ks_name, kktreg=kktreg)
     eng = ks.engine
     try:
         eng._set_H(None)                       # decides dense / sparse mode and places G in HBM

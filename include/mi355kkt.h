@@ -142,7 +142,11 @@ int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg);
  *   "use_correction"  1 (default) / 0: options['use_correction'] of solvers.coneqp (coneprog.py:1781; 0 drops the Mehrotra
  *                     term ds o dz from the second right-hand side, :2377, :2426) for mi355kkt_coneqp* on this handle;
  *   "ldl_refinement"  steps of iterative refinement against the 3 x 3 system in solve() of the MI355KKT_LDL / _LDL2 flavours
- *                     (default 2, 0 = the plain reduced solve; not applied with kktreg).
+ *                     (default 2, 0 = the plain reduced solve; not applied with kktreg);
+ *   "qr_refinement"   steps of the same refinement for the flavours WITHOUT it (MI355KKT_CHOL / _CHOL2), applied only to the solves
+ *                     of a factorisation whose reduced matrix is ill conditioned: (max L_ii / min L_ii)^2 >= 1e8, read back with
+ *                     the info word.  This is how misc.kkt_qr (reference misc.py:1570-1699: two QR factorisations, error
+ *                     proportional to cond(W^-T G)) is mapped onto the Cholesky engine (cond squared); 0 (default): off.
  * Unknown names: MI355KKT_EINVAL. */
 int mi355kkt_set_option(mi355kkt_solver* h, const char* name, double value);
 /* options['show_progress'] of the reference drivers (coneprog.py:2161-2208, :984-990) for the device-resident loops

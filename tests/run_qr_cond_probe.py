@@ -1,6 +1,6 @@
 """Probe script (test infrastructure: it imports the reference through oracle/refloader) (round 6): a conelp family whose W^-T G is ill conditioned from the first iteration (two
 nearly dependent columns of G: cond(G) = 1 / eps), solved by the reference with kktsolver = 'qr' and 'chol' and by this backend with
-'qr' (-> reduced Cholesky engine), 'ldl' (reduced form + refinement against the 3 x 3 system), host-driver and device loop."""
+'qr' (-> reduced Cholesky engine + conditional refinement, round 6), 'ldl' (reduced form + refinement against the 3 x 3 system), host-driver and device loop."""
 import os
 import sys
 

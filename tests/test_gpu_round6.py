@@ -220,3 +220,38 @@ def test_wide_solves_two_slices_per_workgroup_at_8192():
     res_p = ko.kkt_residual(P, A, G, W, dims, bx, by, bz, *p3)
     record("round6_wide_8192", kkt_residual_wide=res_w, kkt_residual_pair=res_p)
     assert res_w <= max(1e-12, 2.0 * res_p), (res_w, res_p)
+
+
+# ---- (c) kkt_qr where QR and normal equations differ ---------------------------------------------------------------------------
+def _illcond_lp(n, m, eps, seed):
+    """an LP whose G has two nearly dependent columns: sigma_min(G) ~ eps, so cond(W^-T G) >= ~1 / eps from the first iteration"""
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((m, n))
+    G[:, n - 1] = G[:, 0] + eps * rng.standard_normal(m)
+    x0 = rng.standard_normal(n)
+    h = G @ x0 + rng.uniform(0.5, 2.0, m)
+    c = -G.T @ rng.uniform(0.5, 2.0, m)
+    return c, G, h
+
+
+@pytest.mark.parametrize("eps", [1e-3, 1e-5, 1e-6])
+@pytest.mark.parametrize("device_loop", [True, False])
+def test_kkt_qr_mapping_follows_the_references_qr_where_cholesky_alone_does_not(ref_cvxopt, eps, device_loop):
+    """VERDICT r5 item 5(b).  The reference's kkt_qr (misc.py:1570-1699) factors W^-T G by QR; the backend maps 'qr' onto its reduced
+    Cholesky engine.  With cond(G) = 3e5 / 3e6 the reference's own 'chol' loses digits or stalls and so did the plain mapping of
+    rounds 1-5 (tests/run_qr_cond_probe.py, profiles/r06_kkt_qr_conditioning.txt); with the conditional refinement against the
+    3 x 3 system ("qr_refinement") the backend's 'qr' gives the reference's status, iteration count and objectives here, through
+    the device loop and through the reference's host driver.  (cond(G) >= 3e7: only the reference's QR survives -- documented
+    limit)"""
+    import cvxopt_amd.solvers as gs
+    cvx = ref_cvxopt
+    c, G, h = _illcond_lp(40, 120, eps, 1)
+    M = lambda a: cvx.matrix(np.asfortranarray(np.atleast_2d(a.T).T if a.ndim == 1 else a))
+    ref = cvx.solvers.conelp(M(c), M(G), M(h), kktsolver='qr')
+    got = gs.conelp(M(c), M(G), M(h), kktsolver='qr', device_loop=device_loop)
+    assert ref['status'] == 'optimal'
+    assert got['status'] == ref['status'] and got['iterations'] == ref['iterations']
+    for k in ('primal objective', 'dual objective'):
+        assert abs(got[k] - ref[k]) <= 1e-8 * abs(ref[k]), (k, got[k], ref[k])
+    record("round6_kkt_qr_eps%g_%s" % (eps, "dev" if device_loop else "host"), pobj=got['primal objective'],
+           pobj_ref=ref['primal objective'], gap=got['gap'], gap_ref=ref['gap'])
