@@ -53,3 +53,50 @@ def test_no_hbm_leak_over_many_handles():
         cycle()
     after = _free_bytes()
     assert before - after < 64 * 1024 * 1024, (before, after)
+
+
+def test_smoke_subset_with_the_products_own_zero_filled_blocks(knobs):
+    """GPU test sessions poison every device block (0xff) by default, so the allocator path the PRODUCT runs -- blocks cleared
+    to zero on the allocator's private stream (csrc/devmem.cpp), the sparse engine's panel store relying on it -- would never be
+    executed by the suite.  Here the poison is switched off for one test: sparse engine create + two factorisations + solves, a dense
+    engine with equality constraints, a few handle-churn cycles; results against the dense oracle."""
+    import scipy.sparse as sp
+    from cvxopt_amd import _capi, kkt, synth
+    from oracle import kkt_oracle as ko
+    from test_gpu_sparse import FakeSp
+    knobs.delenv("MI355KKT_ALLOC_POISON")
+    knobs.delenv("MI355KKT_ALLOC_RAW")
+    rng = np.random.default_rng(5)
+    # sparse: 12^3 Laplacian box QP
+    P = synth.grid_laplacian(12)
+    n = P.shape[0]
+    G = sp.vstack([sp.eye(n), -sp.eye(n)]).tocsc()
+    dims = {'l': 2 * n, 'q': [], 's': []}
+    for cycle in range(3):
+        f = kkt.kkt_chol2(FakeSp(G), dims, np.zeros((0, n)))
+        try:
+            for seed in (1, 2):
+                W = synth.random_scaling(dims, seed=seed, spread=1.0)
+                bx, bz = rng.standard_normal(n), rng.standard_normal(2 * n)
+                x, y, z = bx.copy(), np.zeros(0), bz.copy()
+                f(W, FakeSp(sp.tril(P)))(x, y, z)
+                assert f.engine._mode == "sparse"
+                xo, yo, zo = bx.copy(), np.zeros(0), bz.copy()
+                ko.KktChol2(np.asfortranarray(G.toarray()), dims, np.zeros((0, n))).factor(W, np.asfortranarray(P.toarray()))(xo, yo, zo)
+                assert np.max(np.abs(x - xo)) <= 1e-9 * np.max(np.abs(xo)) and np.max(np.abs(z - zo)) <= 1e-9 * np.max(np.abs(zo))
+        finally:
+            f.engine.close()
+    # dense with equality constraints, ragged order (launch chain + persistent solves)
+    pr = synth.dense_qp(300, 500, seed=3, p=7)
+    for cycle in range(3):
+        f = kkt.kkt_chol2(pr['G'], pr['dims'], pr['A'])
+        try:
+            W = synth.random_scaling(pr['dims'], seed=cycle, spread=1.0)
+            bx, by, bz = rng.standard_normal(300), rng.standard_normal(7), rng.standard_normal(500)
+            x, y, z = bx.copy(), by.copy(), bz.copy()
+            f(W, pr['P'])(x, y, z)
+            xo, yo, zo = bx.copy(), by.copy(), bz.copy()
+            ko.KktChol2(pr['G'], pr['dims'], pr['A']).factor(W, pr['P'])(xo, yo, zo)
+            assert np.max(np.abs(x - xo)) <= 1e-9 * np.max(np.abs(xo)) and np.max(np.abs(y - yo)) <= 1e-8 * np.max(np.abs(yo))
+        finally:
+            f.engine.close()

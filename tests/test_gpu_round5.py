@@ -53,7 +53,7 @@ def test_solves_match_the_oracle_with_and_without_equalities(n, p):
         worst_ref = max(worst_ref, ko.kkt_residual(P, A, G, W, dims, bx, by, bz, xo, yo, zo))
     record("round5_solves_%d_%d" % (n, p), x_vs_oracle=worst, kkt_residual=worst_res, kkt_residual_oracle=worst_ref)
     assert worst < 1e-9, worst
-    assert worst_res <= max(1e-12, 10.0 * worst_ref), (worst_res, worst_ref)   # as accurate as LAPACK on the CPU
+    assert worst_res <= max(1e-12, 3.0 * worst_ref), (worst_res, worst_ref)    # as accurate as LAPACK on the CPU (round 6: 3 x, was 10 x)
 
 
 def test_solves_with_second_order_cones_and_equalities():
