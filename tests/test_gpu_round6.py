@@ -256,3 +256,39 @@ def test_kkt_qr_mapping_follows_the_references_qr_where_cholesky_alone_does_not(
         assert abs(got[k] - ref[k]) <= 1e-8 * abs(ref[k]), (k, got[k], ref[k])
     record("round6_kkt_qr_eps%g_%s" % (eps, "dev" if device_loop else "host"), pobj=got['primal objective'],
            pobj_ref=ref['primal objective'], gap=got['gap'], gap_ref=ref['gap'])
+
+
+def test_sparse_dense_root_through_the_wide_solves():
+    """The sparse engine's dense root (one big supernode without rows below it, factored by the dense tile kernel) takes the 512-row
+    solves when its width is a multiple of 128 from 1024 up: a 32 x 32 x 65 grid, whose nested-dissection root is the 32 x 32 middle
+    plane (1024 columns).  Same solution with the wide solves on and off, and against a sparse LU of the same matrix."""
+    import scipy.sparse.linalg as spla
+    from test_gpu_sparse import FakeSp
+    nx, ny, nz = 32, 32, 65
+    ex = lambda k: sp.diags([-np.ones(k - 1), 2 * np.ones(k), -np.ones(k - 1)], [-1, 0, 1])
+    P = (sp.kron(sp.kron(sp.eye(nz), sp.eye(ny)), ex(nx)) + sp.kron(sp.kron(sp.eye(nz), ex(ny)), sp.eye(nx)) +
+         sp.kron(sp.kron(ex(nz), sp.eye(ny)), sp.eye(nx)) + 1e-2 * sp.eye(nx * ny * nz)).tocsc()
+    n = P.shape[0]
+    G = sp.vstack([sp.eye(n), -sp.eye(n)]).tocsc()
+    dims = {'l': 2 * n, 'q': [], 's': []}
+    W = synth.random_scaling(dims, seed=2, spread=1.0)
+    rng = np.random.default_rng(0)
+    bx, bz = rng.standard_normal(n), rng.standard_normal(2 * n)
+    sols = {}
+    for wide in (1, 0):
+        _capi.set_knob("MI355KKT_TRSV_WIDE", wide)
+        f = kkt.kkt_chol2(FakeSp(G), dims, np.zeros((0, n)))
+        try:
+            x, y, z = bx.copy(), np.zeros(0), bz.copy()
+            f(W, FakeSp(sp.tril(P)))(x, y, z)
+            assert f.engine._mode == "sparse"
+            sols[wide] = (x, z)
+        finally:
+            f.engine.close()
+            _capi.set_knob("MI355KKT_TRSV_WIDE", None)
+    di = W['di']
+    S = (P + G.T @ sp.diags(di * di) @ G).tocsc()
+    xs = spla.splu(S).solve(bx + G.T @ (di * di * bz))
+    for wide in (1, 0):
+        assert relerr(sols[wide][0], xs) < 1e-10
+    assert relerr(sols[1][0], sols[0][0]) < 1e-11 and relerr(sols[1][1], sols[0][1]) < 1e-11
