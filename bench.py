@@ -975,7 +975,7 @@ def main():
             src_id = hsh.hexdigest()[:16]
         except Exception:
             src_id = None
-        for name in ("r05_pmc_syrk.json", "r04_pmc_syrk.json", "r03_pmc_syrk.json"):
+        for name in ("r06_pmc_syrk.json", "r05_pmc_syrk.json", "r04_pmc_syrk.json", "r03_pmc_syrk.json"):
             pj = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pj):
                 try:
