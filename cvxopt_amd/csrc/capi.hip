@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(256) void diag_minmax_kernel(const double* __restri
 static bool trsv_wide_wanted(const mi355kkt_solver* h) {
     const char* k = dev_knob("MI355KKT_TRSV_WIDE");
     if (!(k ? atoi(k) != 0 : TRSV_WIDE_DEFAULT)) return false;
-    return trsv_wide_rows(h->n, h->num_cus) != 0;
-}
+    return trsv_wide_rows(h->n, h->num_cus, k && atoi(k) == 2) != 0;      // (knob value 2: orders that are not multiples of 128 too --
+}                                                                          //  the shape the sparse engine's root takes; tests)
 
 static int fetch_info(mi355kkt_solver* h, int* info) {
     KKT_HIP_CHECK(hipMemcpyAsync(h->pw.h_info, h->pw.d_info, sizeof(int), hipMemcpyDeviceToHost, h->st));
@@ -1355,7 +1355,7 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     const bool have_minv = h->pw.minv_n == n && h->pw.minv_of == h->dS;
     const char* pk = dev_knob("MI355KKT_TRSV_PAIR");
     const bool pair = persistent && have_minv && n % 128 == 0 && n >= 256 && 2 * (n / 128) <= h->num_cus && (pk ? atoi(pk) != 0 : TRSV_PAIR_DEFAULT);
-    const int wide_rows = (trsv_wide_wanted(h) && h->pw.m512_n == n && h->pw.m512_of == h->dS) ? trsv_wide_rows(n, h->num_cus) : 0;
+    const int wide_rows = (trsv_wide_wanted(h) && h->pw.m512_n == n && h->pw.m512_of == h->dS) ? trsv_wide_rows(n, h->num_cus, true) : 0;
     auto tri_solve = [&](int trans, double* xv) -> int {
         if (wide_rows) return launch_trsv_wide(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->pw, wide_rows, h->num_cus);
         if (pair) return launch_trsv_pair(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran, h->pw.d_minv);

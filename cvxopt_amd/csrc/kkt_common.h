@@ -202,7 +202,7 @@ int launch_trsv_pair(const double* L, int64_t ldl, int n, double* x, int trans, 
 // round 6: 512-row hops over all compute units (trsv512.hip).  trsv_wide_rows: rows per workgroup for this order, 0 = not served
 // (n >= 1024, a multiple of 128); launch_block_inverse512 after the tile Cholesky of L (needs its 128 x 128
 // inverses); launch_trsv_wide: same contract as launch_trsv_pair
-int trsv_wide_rows(int n, int num_cus);
+int trsv_wide_rows(int n, int num_cus, bool any_order = false);   // any_order: n need not be a multiple of 128 (the sparse root)
 int launch_block_inverse512(const double* L, int64_t ldl, int n, PotrfWork& w, hipStream_t st);
 int launch_trsv_wide(const double* L, int64_t ldl, int n, double* x, int trans, unsigned int epoch, int* err, hipStream_t st,
                      PotrfWork& w, int rows, int num_cus);

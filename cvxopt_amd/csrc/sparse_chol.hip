@@ -1554,7 +1554,7 @@ int sparse_engine_factor(SparseEngine& E, const double* d_di, hipStream_t st, in
                 // round 6: the root's solves in 512-row hops over all compute units (trsv512.hip) -- the 512 x 512 inverses of its
                 // diagonal blocks from the 128 x 128 ones the tile kernel has just left
                 const char* kw = dev_knob("MI355KKT_TRSV_WIDE");
-                if (!(kw && atoi(kw) == 0) && E.t_num_cus > 0 && trsv_wide_rows(only.w, E.t_num_cus) != 0 &&
+                if (!(kw && atoi(kw) == 0) && E.t_num_cus > 0 && trsv_wide_rows(only.w, E.t_num_cus, true) != 0 &&
                     E.pw_vb.minv_n == only.w && E.pw_vb.minv_of == E.d_panels + only.off)
                     if (int e = launch_block_inverse512(E.d_panels + only.off, only.h, only.w, E.pw_vb, st)) return e;
             } else if (old_chain) {
@@ -1596,7 +1596,7 @@ static int sp_root_solve(SparseEngine& E, int s, double* x, int trans, hipStream
     const double* P = E.d_panels + S.panel_off[s];
     const double* minv = (E.pw_vb.minv_n == w && E.pw_vb.minv_of == P) ? E.pw_vb.d_minv : nullptr;
     if (E.pw_vb.m512_n == w && E.pw_vb.m512_of == P && h == w)             // (formed by sparse_engine_factor when the order allows it)
-        if (const int rows = trsv_wide_rows(w, E.t_num_cus))
+        if (const int rows = trsv_wide_rows(w, E.t_num_cus, true))
             return launch_trsv_wide(P, h, w, x + f, trans, ++*E.t_epoch, E.t_err, st, E.pw_vb, rows, E.t_num_cus);
     if (minv && w % 128 == 0 && 2 * (w / 128) <= E.t_num_cus)
         return launch_trsv_pair(P, h, w, x + f, trans, ++*E.t_epoch, E.t_err, st, E.t_gran, minv);

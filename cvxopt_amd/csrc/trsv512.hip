@@ -68,11 +68,12 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
     const int tid = threadIdx.x, r = tid % R, g = tid / R;
     const int NBk = (n + WB - 1) / WB;
     bool timeout = false;
-    for (int w = blockIdx.x; w < n / R; w += gridDim.x) {
+    const int nsl = (n + R - 1) / R;                       // slices of R rows; the last one may be partial (any order n is served)
+    for (int w = blockIdx.x; w < nsl; w += gridDim.x) {
     const int w_ts = w;
     (void)w_ts;
     WIDE_TS(0);
-    const int row0 = TRANS ? n - (w + 1) * R : w * R;     // slice order = dependency order
+    const int row0 = (TRANS ? nsl - 1 - w : w) * R;        // slice order = dependency order
     const int j = row0 / WB, j0 = j * WB;
     const int idx = row0 + r;                              // my row of L (forward) / of L' (backward)
     const int rb = row0 - j0;
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
         for (int c = 0; c < CPT; ++c) Ms[(int64_t)(cp + c) * R + r] = sb[c];
     }
     if (nsteps > 1) load_off(sb, 1);
-    double accA = g == 0 ? x[idx] : 0.0, accB = 0.0;
+    // (rows beyond n in a partial slice: their strips hold whatever lies behind the column in memory -- finite, never stored, never
+    //  polled by anybody: the granules of a ragged block end at n; their rows of the block inverse are zero)
+    double accA = (g == 0 && idx < n) ? x[idx] : 0.0, accB = 0.0;
     __syncthreads();                                           // Ms complete
     WIDE_TS(1);
 
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
         const double dj = reduce(dot_m(bv), 1);
         if (g == 0 && !timeout) {
             publish(gD, dj);
-            x[idx] = x0 + dj;
+            if (idx < n) x[idx] = x0 + dj;
         }
         WIDE_TS(11);
     };
@@ -365,8 +368,10 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
 typedef double d4w __attribute__((ext_vector_type(4)));
 // B arrives TRANSPOSED (Bt[j + k ldbt] = B[k][j]): both operands are then read with 16 consecutive lanes on 128 consecutive bytes
 // (every B of the four stages has a transposed twin anyway: M', and the T products are stored both ways)
+// arows: rows of the A tile that exist (an operand taken from L below a ragged last block: the rest reads as zero)
 __device__ __forceinline__ void mfma_tile64(const double* __restrict__ A, int64_t lda, const double* __restrict__ Bt, int64_t ldbt,
-                                            int k0, int k1, double alpha, double* C, int64_t ldc, double* Ct, int64_t ldct, int tid) {
+                                            int k0, int k1, double alpha, double* C, int64_t ldc, double* Ct, int64_t ldct, int tid,
+                                            int arows = 64) {
     const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int i0 = 32 * (wv & 1), j0 = 32 * (wv >> 1);
     d4w acc[2][2];
@@ -376,12 +381,13 @@ __device__ __forceinline__ void mfma_tile64(const double* __restrict__ A, int64_
         for (int t = 0; t < 2; ++t) acc[u][t] = d4w{0.0, 0.0, 0.0, 0.0};
     const double* Ap = A + (i0 + li) + (int64_t)lk * lda;
     const double* Bp = Bt + (j0 + li) + (int64_t)lk * ldbt;
+    const bool ra0 = i0 + li < arows, ra1 = i0 + 16 + li < arows;
     for (int k = k0; k < k1; k += 64) {                        // (k0, k1: multiples of 64) sixteen MFMA steps' operands at a time:
         double a0[16], a1[16], b0[16], b1[16];                 // a product is a chain of (k1 - k0) / 64 memory latencies
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
-            a0[s4] = Ap[(int64_t)(k + 4 * s4) * lda];
-            a1[s4] = Ap[16 + (int64_t)(k + 4 * s4) * lda];
+            a0[s4] = ra0 ? Ap[(int64_t)(k + 4 * s4) * lda] : 0.0;
+            a1[s4] = ra1 ? Ap[16 + (int64_t)(k + 4 * s4) * lda] : 0.0;
             b0[s4] = Bp[(int64_t)(k + 4 * s4) * ldbt];
             b1[s4] = Bp[16 + (int64_t)(k + 4 * s4) * ldbt];
         }
@@ -418,7 +424,8 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
                                                                double* __restrict__ scratch, u32* cnt, u32 base) {
     const int tid = threadIdx.x, t = blockIdx.x, b = blockIdx.y;
     const int o = b * WB;
-    const int qn = min(WB, n - o) / 128;                       // 128-blocks in this 512-block (1..4)
+    const int nbk = min(WB, n - o);                            // rows of this 512-block
+    const int qn = (nbk + 127) / 128;                          // its 128-blocks (1..4), the last one possibly ragged
     double* M = m512 + (int64_t)b * 2 * WB * WB;
     double* Mt = M + (int64_t)WB * WB;
     double* T = scratch + (int64_t)b * 2 * 256 * 256;         // the transposed products (read again) ...
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
                 // only T' is needed (the B operand of stage 2); it lives in the first half of the block's scratch
                 double* Tt = T + (int64_t)p * NB2;
                 mfma_tile64(A, ldl, Bt, 128, 64 * tj, 128, 1.0, T + 2 * NB2 + (int64_t)p * NB2 + 64 * ti + (int64_t)(64 * tj) * 128, 128,
-                            Tt + 64 * tj + (int64_t)(64 * ti) * 128, 128, tid);
+                            Tt + 64 * tj + (int64_t)(64 * ti) * 128, 128, tid, nbk - 128 * (2 * p + 1) - 64 * ti);
             }
         }
     }
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
         }
     }
     block_sync(base + 32);
-    const int rows2 = 128 * (qn - 2);
+    const int rows2 = 128 * (qn - 2);                          // (whole 128-blocks of storage; rows beyond nbk are zero)
     const int ti = t >> 2, tj = t & 3;
     const bool work = rows2 > 0 && 64 * ti < rows2;
     if (work) {   // stage 3
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
         const double* Bt = Mt + 64 * tj;                                                             // M(0..255, 0..255)' (rows 64 tj..)
         // T2 is 256 x 256 at most and only its transpose is read again: T2'[j + i 256]; the plain copy goes to the second scratch
         mfma_tile64(A, ldl, Bt, WB, 64 * tj, 256, 1.0, T2 + 64 * ti + (int64_t)(64 * tj) * 256, 256,
-                    T + 64 * tj + (int64_t)(64 * ti) * 256, 256, tid);
+                    T + 64 * tj + (int64_t)(64 * ti) * 256, 256, tid, nbk - 256 - 64 * ti);
     }
     block_sync(base + 48);
     if (work) {   // stage 4
@@ -506,14 +513,14 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
 int set_wide_ts(long long* dptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wide_ts), &dptr, sizeof(dptr)) == hipSuccess ? 0 : -2; }
 #endif
 
-int trsv_wide_rows(int n, int num_cus) {              // rows per workgroup, 0: this order is not served
-    if (n < 1024 || n % 128 || (int64_t)n * n * 8 >= ((int64_t)1 << 31)) return 0;
-    return n / 8 <= num_cus ? 8 : 16;
+int trsv_wide_rows(int n, int num_cus, bool any_order) {   // rows per workgroup, 0: this order is not served
+    if (n < 1024 || (!any_order && n % 128) || (int64_t)n * n * 8 >= ((int64_t)1 << 31)) return 0;
+    return (n + 7) / 8 <= num_cus ? 8 : 16;
 }
 
 // state: w.d_m512 (2 x 512 x 512 doubles per 512-block), w.d_m512_scratch, w.d_gran512 (4 sets x 1024 granules per block)
 int launch_block_inverse512(const double* L, int64_t ldl, int n, PotrfWork& w, hipStream_t st) {
-    if (n <= 0 || n % 128 || w.minv_n != n || w.minv_of != L || !w.d_minv) return -1;
+    if (n <= 0 || w.minv_n != n || w.minv_of != L || !w.d_minv) return -1;
     const int NBk = (n + WB - 1) / WB;
     if (w.m512_blocks < NBk) {
         if (w.d_m512) (void)dev_free(w.d_m512);
@@ -561,7 +568,7 @@ static int launch_wide_r(const double* L, int64_t ldl, int n, double* x, int tra
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const dim3 g(std::min(n / R, num_cus)), b(WideGeom<R>::T);
+    const dim3 g(std::min((n + R - 1) / R, num_cus)), b(WideGeom<R>::T);
     const unsigned lbytes = (unsigned)(((int64_t)ldl * (n - 1) + n) * 8);      // (< 2 GB: checked by launch_trsv_wide)
     if (trans)
         hipLaunchKernelGGL((trsv_wide_kernel<R, true>), g, b, lds, st, L, ldl, n, x, epoch, err, gran, m512, lbytes);

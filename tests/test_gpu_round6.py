@@ -206,6 +206,30 @@ def test_wide_triangular_solves_match_the_pair_kernel_and_the_oracle(n, p):
     assert res_w <= max(1e-12, 3.0 * res_o), (res_w, res_o)
 
 
+@pytest.mark.parametrize("n,p", [(1100, 0), (1500, 7), (2100, 0), (4200, 3)])
+def test_wide_solves_for_orders_that_are_not_multiples_of_128(n, p):
+    """the shape the sparse engine's dense root takes (any width >= 1024): partial last slice of rows, ragged last 128-block in the
+    formation of the 512 x 512 inverses -- on the dense engine through test knob value 2, against the round-4 kernels and the oracle"""
+    m = n + 64
+    rng = np.random.default_rng(n)
+    rhs = [(rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)) for _ in range(2)]
+    pr, W, wide = _engine_solves(n, m, p, 2, rhs)
+    _, _, again = _engine_solves(n, m, p, 2, rhs)
+    _, _, base = _engine_solves(n, m, p, 0, rhs)
+    G, P, dims = pr['G'], pr['P'], pr['dims']
+    A = pr.get('A', np.zeros((0, n)))
+    oracle = ko.KktChol2(G, dims, A).factor(W, P)
+    for (bx, by, bz), w3, a3, b3 in zip(rhs, wide, again, base):
+        for u, v in zip(w3, a3):
+            assert np.array_equal(u, v)
+        assert relerr(w3[0], b3[0]) < 1e-9 and relerr(w3[2], b3[2]) < 1e-9
+        xo, yo, zo = bx.copy(), by.copy(), bz.copy()
+        oracle(xo, yo, zo)
+        res_w = ko.kkt_residual(P, A, G, W, dims, bx, by, bz, *w3)
+        res_o = ko.kkt_residual(P, A, G, W, dims, bx, by, bz, xo, yo, zo)
+        assert res_w <= max(1e-12, 3.0 * res_o), (res_w, res_o)
+
+
 def test_wide_solves_two_slices_per_workgroup_at_8192():
     """n = 8192: 512 slices of 16 rows on 256 compute units -- every workgroup takes a second slice when its first is done"""
     n, m = 8192, 1024
