@@ -1009,13 +1009,12 @@ __global__ __launch_bounds__(256) void diag_minmax_kernel(const double* __restri
 }
 
 // info word -> host (synchronises the stream)
-// the all-CU triangular solves (trsv512.hip) serve this handle's S: dense engine, order a multiple of 128 from 1024 up to
-// 32 rows x #CUs, and not switched off by the test knob
+// the all-CU triangular solves (trsv512.hip) serve this handle's S: dense engine, order 1024 and up, not switched off by the test knob
 static bool trsv_wide_wanted(const mi355kkt_solver* h) {
     const char* k = dev_knob("MI355KKT_TRSV_WIDE");
     if (!(k ? atoi(k) != 0 : TRSV_WIDE_DEFAULT)) return false;
-    return trsv_wide_rows(h->n, h->num_cus, k && atoi(k) == 2) != 0;      // (knob value 2: orders that are not multiples of 128 too --
-}                                                                          //  the shape the sparse engine's root takes; tests)
+    return trsv_wide_rows(h->n, h->num_cus, !(k && atoi(k) == 128)) != 0; // (any order >= 1024; knob value 128: multiples of 128 only --
+}                                                                          //  ragged orders then take the round-4 one-sweep kernel: A/B)
 
 static int fetch_info(mi355kkt_solver* h, int* info) {
     KKT_HIP_CHECK(hipMemcpyAsync(h->pw.h_info, h->pw.d_info, sizeof(int), hipMemcpyDeviceToHost, h->st));

@@ -43,7 +43,7 @@ int mi355kkt_test_throw(int kind);
  * "MI355KKT_ND_MODE", "MI355KKT_ND_LEAF", "MI355KKT_ND_LEAF_AMD", "MI355KKT_ND_NOREFINE", "MI355KKT_ORDERING_BOTH",
  * "MI355KKT_SN_MAXW", "MI355KKT_SPARSE_BIG_FLOPS", "MI355KKT_SPARSE_BIG_H", "MI355KKT_SP_WIDE", "MI355KKT_SPARSE_TILES",
  * "MI355KKT_SDP_WAVE_MAX", "MI355KKT_SDP_NO_MFMA", "MI355KKT_SPARSE_DEBUG", "MI355KKT_ND_DEBUG", "MI355KKT_SPARSE_POISON",
- * "MI355KKT_TRSV_PAIR" (0: the one-sweep triangular solve), "MI355KKT_TRSV_WIDE" (0: no 512-row all-CU solves; 2: also for dense orders that are not multiples of 128),
+ * "MI355KKT_TRSV_PAIR" (0: the one-sweep triangular solve), "MI355KKT_TRSV_WIDE" (0: no 512-row all-CU solves; 128: only for orders that are multiples of 128),
  * "MI355KKT_SPARSE_NO_DENSE_ROOT", and the allocator modes below.  They are set ONLY by this
  * call -- the library never reads them from the environment -- so that tests can drive every ordering / plan shape through the
  * same code.  value == NULL unsets one knob, name == NULL all of them.  Process-wide; returns 0. */

@@ -208,13 +208,13 @@ def test_wide_triangular_solves_match_the_pair_kernel_and_the_oracle(n, p):
 
 @pytest.mark.parametrize("n,p", [(1100, 0), (1500, 7), (2100, 0), (4200, 3)])
 def test_wide_solves_for_orders_that_are_not_multiples_of_128(n, p):
-    """the shape the sparse engine's dense root takes (any width >= 1024): partial last slice of rows, ragged last 128-block in the
-    formation of the 512 x 512 inverses -- on the dense engine through test knob value 2, against the round-4 kernels and the oracle"""
+    """any order >= 1024 (the dense engine's default, and the shape the sparse engine's dense root takes): partial last slice of rows,
+    ragged last 128-block in the formation of the 512 x 512 inverses -- against the round-4 kernels and the oracle"""
     m = n + 64
     rng = np.random.default_rng(n)
     rhs = [(rng.standard_normal(n), rng.standard_normal(p), rng.standard_normal(m)) for _ in range(2)]
-    pr, W, wide = _engine_solves(n, m, p, 2, rhs)
-    _, _, again = _engine_solves(n, m, p, 2, rhs)
+    pr, W, wide = _engine_solves(n, m, p, 1, rhs)
+    _, _, again = _engine_solves(n, m, p, 1, rhs)
     _, _, base = _engine_solves(n, m, p, 0, rhs)
     G, P, dims = pr['G'], pr['P'], pr['dims']
     A = pr.get('A', np.zeros((0, n)))
