@@ -420,9 +420,13 @@ class _ForeignMemory(object):
 
 
 def _foreign_tensor(torch, ptr, shape, dev):
+    """A zero-copy view of an IPC mapping.  NO `device=` for torch.as_tensor: the tensor must stay on the device that OWNS the memory
+    (the root's GPU, as torch learns from the pointer's attributes) -- asking for this rank's device would make torch copy the
+    whole exported allocation across xGMI at every solve; the row ranges a rank needs are moved by the cross-device `copy_` of
+    `_solve_ipc` (a peer copy of exactly those rows)."""
     if int(np.prod(shape)) == 0:
         return torch.empty(shape, dtype=torch.float64, device=dev)
-    return torch.as_tensor(_ForeignMemory(ptr, shape), device=dev)
+    return torch.as_tensor(_ForeignMemory(ptr, shape))
 
 
 _STATUS_NAMES = np.array(['unknown', 'optimal', 'unknown', 'unknown'], dtype=object)
