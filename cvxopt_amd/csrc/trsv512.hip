@@ -253,6 +253,13 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
 
     // ---- start: strip 0 is requested first, then my rows of the block inverse travel through the second buffer into LDS, then
     // strip 1
+    // (rows beyond n in a partial slice: their strips hold whatever lies behind the column in memory -- finite, never stored, never
+    //  polled by anybody: the granules of a ragged block end at n; their rows of the block inverse are zero)
+    double accA = (g == 0 && idx < n) ? x[idx] : 0.0, accB = 0.0;
+    // the first block row's t_0 is its right-hand side: it goes out before anything else is requested, so that the exchange runs
+    // while the rows of the block inverse are still on their way (3 us at the head of every solve's critical path)
+    const bool first = nsteps == 0;
+    if (first && g == 0) publish(gT, accA);
     double sa[CPT], sb[CPT];
     if (nsteps > 0) load_first(sa);
     {
@@ -266,9 +273,6 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
         for (int c = 0; c < CPT; ++c) Ms[(int64_t)(cp + c) * R + r] = sb[c];
     }
     if (nsteps > 1) load_off(sb, 1);
-    // (rows beyond n in a partial slice: their strips hold whatever lies behind the column in memory -- finite, never stored, never
-    //  polled by anybody: the granules of a ragged block end at n; their rows of the block inverse are zero)
-    double accA = (g == 0 && idx < n) ? x[idx] : 0.0, accB = 0.0;
     __syncthreads();                                           // Ms complete
     WIDE_TS(1);
 
@@ -300,8 +304,8 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
         }
         WIDE_TS(3);
         // t_j complete: exchange it inside the block row, apply M_j, publish x0_j            (critical path of sweep 1)
-        const double tsum = reduce(accA, 0);
-        if (g == 0) publish(gT, tsum);
+        const double tsum = first ? accA : reduce(accA, 0);     // (first block row: published at the start; accA is the entry itself)
+        if (!first && g == 0) publish(gT, tsum);
         WIDE_TS(4);
         const double* ts = wait_block(gT, j);
         WIDE_TS(5);
