@@ -375,7 +375,7 @@ typedef double d4w __attribute__((ext_vector_type(4)));
 // arows: rows of the A tile that exist (an operand taken from L below a ragged last block: the rest reads as zero)
 __device__ __forceinline__ void mfma_tile64(const double* __restrict__ A, int64_t lda, const double* __restrict__ Bt, int64_t ldbt,
                                             int k0, int k1, double alpha, double* C, int64_t ldc, double* Ct, int64_t ldct, int tid,
-                                            int arows = 64) {
+                                            int arows = 64, const double* zero = nullptr) {
     const int wv = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
     const int i0 = 32 * (wv & 1), j0 = 32 * (wv >> 1);
     d4w acc[2][2];
@@ -383,25 +383,47 @@ __device__ __forceinline__ void mfma_tile64(const double* __restrict__ A, int64_
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int t = 0; t < 2; ++t) acc[u][t] = d4w{0.0, 0.0, 0.0, 0.0};
-    const double* Ap = A + (i0 + li) + (int64_t)lk * lda;
-    const double* Bp = Bt + (j0 + li) + (int64_t)lk * ldbt;
+    // rows of A that do not exist read a location that holds zero (`zero`), through the ADDRESS: a select on the loaded value would
+    // make every request wait for its data
     const bool ra0 = i0 + li < arows, ra1 = i0 + 16 + li < arows;
-    for (int k = k0; k < k1; k += 64) {                        // (k0, k1: multiples of 64) sixteen MFMA steps' operands at a time:
-        double a0[16], a1[16], b0[16], b1[16];                 // a product is a chain of (k1 - k0) / 64 memory latencies
+    const double* Ap0 = ra0 ? A + (i0 + li) + (int64_t)lk * lda : zero;
+    const double* Ap1 = ra1 ? A + (i0 + 16 + li) + (int64_t)lk * lda : zero;
+    const int64_t lda0 = ra0 ? lda : 0, lda1 = ra1 ? lda : 0;
+    const double* Bp = Bt + (j0 + li) + (int64_t)lk * ldbt;
+    // (k0, k1: multiples of 64) sixteen MFMA steps' operands at a time, the NEXT sixteen requested before the matrix cores start on
+    // the current ones: a product is one memory latency + its matrix-core time, not (k1 - k0) / 64 latencies.  The request past the
+    // end re-reads the last chunk (unconditional loads: no select on a loop-carried register array)
+    struct Ops { double a0[16], a1[16], b0[16], b1[16]; };
+    auto load = [&](Ops& o, int k) {
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
-            a0[s4] = ra0 ? Ap[(int64_t)(k + 4 * s4) * lda] : 0.0;
-            a1[s4] = ra1 ? Ap[16 + (int64_t)(k + 4 * s4) * lda] : 0.0;
-            b0[s4] = Bp[(int64_t)(k + 4 * s4) * ldbt];
-            b1[s4] = Bp[16 + (int64_t)(k + 4 * s4) * ldbt];
+            o.a0[s4] = Ap0[(int64_t)(k + 4 * s4) * lda0];
+            o.a1[s4] = Ap1[(int64_t)(k + 4 * s4) * lda1];
+            o.b0[s4] = Bp[(int64_t)(k + 4 * s4) * ldbt];
+            o.b1[s4] = Bp[16 + (int64_t)(k + 4 * s4) * ldbt];
         }
+    };
+    auto mma = [&](const Ops& o) {
 #pragma unroll
         for (int s4 = 0; s4 < 16; ++s4) {
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[s4], a0[s4], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[s4], a0[s4], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[s4], a1[s4], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[s4], a1[s4], acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.b0[s4], o.a0[s4], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.b1[s4], o.a0[s4], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.b0[s4], o.a1[s4], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.b1[s4], o.a1[s4], acc[1][1], 0, 0, 0);
         }
+    };
+    Ops oa, ob;
+    const int klast = k1 - 64;
+    int k = k0;
+    if (k < k1) load(oa, k);
+    while (k < k1) {
+        load(ob, min(k + 64, klast));
+        mma(oa);
+        k += 64;
+        if (k >= k1) break;
+        load(oa, min(k + 64, klast));
+        mma(ob);
+        k += 64;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -479,7 +501,7 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
                 // only T' is needed (the B operand of stage 2); it lives in the first half of the block's scratch
                 double* Tt = T + (int64_t)p * NB2;
                 mfma_tile64(A, ldl, Bt, 128, 64 * tj, 128, 1.0, T + 2 * NB2 + (int64_t)p * NB2 + 64 * ti + (int64_t)(64 * tj) * 128, 128,
-                            Tt + 64 * tj + (int64_t)(64 * ti) * 128, 128, tid, nbk - 128 * (2 * p + 1) - 64 * ti);
+                            Tt + 64 * tj + (int64_t)(64 * ti) * 128, 128, tid, nbk - 128 * (2 * p + 1) - 64 * ti, M + WB);
             }
         }
     }
@@ -502,7 +524,7 @@ __global__ __launch_bounds__(256) void block_inverse512_kernel(const double* __r
         const double* Bt = Mt + 64 * tj;                                                             // M(0..255, 0..255)' (rows 64 tj..)
         // T2 is 256 x 256 at most and only its transpose is read again: T2'[j + i 256]; the plain copy goes to the second scratch
         mfma_tile64(A, ldl, Bt, WB, 64 * tj, 256, 1.0, T2 + 64 * ti + (int64_t)(64 * tj) * 256, 256,
-                    T + 64 * tj + (int64_t)(64 * ti) * 256, 256, tid, nbk - 256 - 64 * ti);
+                    T + 64 * tj + (int64_t)(64 * ti) * 256, 256, tid, nbk - 256 - 64 * ti, M + WB);
     }
     block_sync(base + 48);
     if (work) {   // stage 4
