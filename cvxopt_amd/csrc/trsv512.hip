@@ -46,7 +46,7 @@ __device__ long long* g_wide_ts = nullptr;
 // four 512-entry blocks of right-hand-side data (padded likewise), the reduction buffers
 template <int R>
 struct WideGeom {
-    static constexpr int T = 256;
+    static constexpr int T = 512;          // (256 threads -- measured -- pull the strips half as fast: 190 against 123 us at n = 8192)
     static constexpr int CG = T / R;        // column groups (threads per row)
     static constexpr int CPT = WB / CG;     // columns per thread and strip
     static constexpr int WG4 = 2 * WB / T;  // granules each thread polls per block
@@ -594,6 +594,9 @@ static int launch_wide_r(const double* L, int64_t ldl, int n, double* x, int tra
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    // (never more workgroups than compute units: a workgroup that has gone on to its second slice waits for slices of workgroups that
+    //  must be running already -- 8 rows at n = 4096 / 8192 with two workgroups per compute unit were measured: 58 us against 49 at
+    //  4096, and a hand-off timeout at 8192, where the second 256 were not co-resident)
     const dim3 g(std::min((n + R - 1) / R, num_cus)), b(WideGeom<R>::T);
     const unsigned lbytes = (unsigned)(((int64_t)ldl * (n - 1) + n) * 8);      // (< 2 GB: checked by launch_trsv_wide)
     if (trans)

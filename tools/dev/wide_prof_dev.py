@@ -30,4 +30,5 @@ for rep in range(6):
         eng.solve_device(xd.ptr, yd.ptr, zd.ptr)
     eng.sync()
 print("n=%d wide=%d" % (n, wide), eng.timings())
+_capi.set_knob(None, None)
 eng.close()
