@@ -520,6 +520,8 @@ class ShardedBatch(object):
     def _ipc_init(self):
         torch = self.torch
         self._ipc_open = {}                       # handle bytes -> base address of the mapping in this process
+        self._ipc_seen = set()                    # handles the current solve has used (mappings of allocations the root no longer
+                                                  # exports are closed at the end of a solve once more than a handful have piled up)
         self.pull_stream = torch.cuda.Stream(self.dev)
         self.push_stream = torch.cuda.Stream(self.dev)
         self.result = None                        # root: (B, width), problem order; exported once
@@ -538,6 +540,7 @@ class ShardedBatch(object):
         """a tensor of this process over memory another process exported (mapped on first sight of its allocation)"""
         hd, off, shape = desc
         base = self._ipc_open.get(hd)
+        self._ipc_seen.add(hd)
         if base is None:
             out = C.c_void_p()
             buf = (C.c_ubyte * 64).from_buffer_copy(hd)
@@ -621,6 +624,10 @@ class ShardedBatch(object):
         self.push_stream.synchronize()
         self.pull_stream.synchronize()
         dist.barrier(group=self.group)            # control plane only: every shard is in the root's buffer, nobody reads the inputs any more
+        if len(self._ipc_open) > 8:               # a root that exports fresh allocations at every solve: drop the mappings of the old ones
+            for hd in [h_ for h_ in self._ipc_open if h_ not in self._ipc_seen]:
+                _capi.lib().mi355kkt_ipc_close(C.c_void_p(self._ipc_open.pop(hd)))
+        self._ipc_seen = set()
         t5 = time.perf_counter()
         tm["gather_exposed"] = 1e3 * (t5 - t4)
         tm["total"] = 1e3 * (t5 - t0)
