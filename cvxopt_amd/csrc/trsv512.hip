@@ -541,6 +541,9 @@ int set_wide_ts(long long* dptr) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wide_ts
 
 int trsv_wide_rows(int n, int num_cus, bool any_order) {   // rows per workgroup, 0: this order is not served
     if (n < 1024 || (!any_order && n % 128) || (int64_t)n * n * 8 >= ((int64_t)1 << 31)) return 0;
+    // the 32 (16 rows) or 64 (8 rows) workgroups of a block row exchange with each other: they must be DIFFERENT workgroups of the
+    // launch, all co-resident -- a device (or partition) with fewer compute units than that keeps the round-4 kernels
+    if (num_cus < 64) return 0;
     return (n + 7) / 8 <= num_cus ? 8 : 16;
 }
 
