@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
     // the first block row's t_0 is its right-hand side: it goes out before anything else is requested, so that the exchange runs
     // while the rows of the block inverse are still on their way (3 us at the head of every solve's critical path)
     const bool first = nsteps == 0;
-    if (first && g == 0) publish(gT, accA);
+    if (R < 16 && first && g == 0) publish(gT, accA);
     double sa[CPT], sb[CPT];
     if (nsteps > 0) load_first(sa);
     {
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(WideGeom<R>::T) void trsv_wide_kernel(const double*
         }
         WIDE_TS(3);
         // t_j complete: exchange it inside the block row, apply M_j, publish x0_j            (critical path of sweep 1)
-        const double tsum = first ? accA : reduce(accA, 0);     // (first block row: published at the start; accA is the entry itself)
-        if (!first && g == 0) publish(gT, tsum);
+        const double tsum = (R < 16 && first) ? accA : reduce(accA, 0);   // (first block row, 8 rows: published at the start)
+        if (!(R < 16 && first) && g == 0) publish(gT, tsum);
         WIDE_TS(4);
         const double* ts = wait_block(gT, j);
         WIDE_TS(5);
