@@ -469,6 +469,9 @@ class ShardedBatch(object):
         if transport not in ("rccl", "ipc"):
             raise ValueError("ShardedBatch: transport must be 'rccl' or 'ipc'")
         self.transport = transport
+        if transport == "ipc" and not torch.cuda.is_available():
+            raise RuntimeError("ShardedBatch(transport='ipc') moves device memory between the ranks' GPUs: no HIP device is visible "
+                               "(there is no CPU fallback; transport='rccl' over a gloo group is the host-side dry run)")
         on_gpu = self.backend == "nccl" or transport == "ipc"
         self.dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
         self.B, self.n, self.m, self.hasP = int(B), int(n), int(m), bool(hasP)

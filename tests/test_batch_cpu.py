@@ -186,3 +186,27 @@ def _worker_cache(rank, port):
     batch.clear_sharded_cache()
     assert not batch._SHARDED_CACHE
     dist.destroy_process_group()
+
+
+def test_ipc_transport_needs_a_gpu_and_says_so(tmp_path):
+    """round 6: ShardedBatch(transport="ipc") without a visible HIP device fails loudly (no CPU fallback); an unknown transport is a
+    ValueError"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the ipc transport is exercised by tests/test_gpu_round6.py")
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_ipc_refused, args=(31400 + os.getpid() % 2000,), nprocs=1, join=True)
+
+
+def _worker_ipc_refused(rank, port):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch.distributed as dist
+    from cvxopt_amd import batch
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        with pytest.raises(RuntimeError, match="no HIP device is visible"):
+            batch.ShardedBatch(4, 8, 20, True, transport="ipc")
+        with pytest.raises(ValueError):
+            batch.ShardedBatch(4, 8, 20, True, transport="carrier pigeon")
+    finally:
+        dist.destroy_process_group()
