@@ -386,6 +386,16 @@ struct mi355kkt_solver {
     bool qr_active = false;    // this factorisation's solves are refined
     double* d_cond = nullptr;  // {min, max} of diag(L), device / pinned host
     double* h_cond = nullptr;
+    // ... and beyond QR2_COND the factor itself is repaired (CholeskyQR2, Yamamoto et al. 2015): with L1 = chol(Gs'Gs) -- inaccurate
+    // there, but it exists -- Q1 = Gs L1^-T is nearly orthonormal, L2 = chol(Q1'Q1) is accurate, and S = L1 (L2 L2') L1' holds to
+    // working precision column by column: the accuracy of a QR factor of Gs (what misc.kkt_qr computes) from three products the
+    // engine already has (transpose, triangular solve with many right-hand sides, SYRK, Cholesky).  conelp without H only.
+    bool qr2_active = false;   // this factorisation carries the second factor
+    bool pw2_ready = false;
+    double* dQt = nullptr;     // n x rows: Gs', then Q1' = L1^-1 Gs'
+    double* dQ = nullptr;      // rows x n: (LP cone: Gs first,) then Q1
+    double* dS2 = nullptr;     // n x n: Q1'Q1, then L2
+    PotrfWork pw2;
 };
 
 // per-iteration report of a device-resident loop: the scalar block comes back with one small copy (the loop has just
@@ -639,6 +649,10 @@ void mi355kkt_destroy(mi355kkt_solver* h) try {
     if (h->dRef) (void)dev_free(h->dRef);
     if (h->d_cond) (void)dev_free(h->d_cond);
     if (h->h_cond) (void)hipHostFree(h->h_cond);
+    if (h->dQt) (void)dev_free(h->dQt);
+    if (h->dQ) (void)dev_free(h->dQ);
+    if (h->dS2) (void)dev_free(h->dS2);
+    if (h->pw2_ready) potrf_work_free(h->pw2);
     if (h->derr) (void)dev_free(h->derr);
     if (h->herr) (void)hipHostFree(h->herr);
     for (double* b : bufs)
@@ -987,6 +1001,13 @@ int mi355kkt_set_option(mi355kkt_solver* h, const char* name, double value) try 
 
 // {min, max} of |diag(L)|: one workgroup, fixed order
 constexpr double QR_REFINE_COND = 1e8;       // (max L_ii / min L_ii)^2 from which the 'qr' mapping refines its solves
+constexpr double QR2_COND = 1e10;            // ... and from which it repairs the factor by CholeskyQR2
+// out(rows x n) = diag(d) G  (the LP cone's Gs = W^-T G, which the SYRK never materialises)
+__global__ void qr_scale_rows_kernel(const double* __restrict__ G, int64_t ldg, const double* __restrict__ d, int rows, int n,
+                                     double* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i < rows && j < n) out[i + (int64_t)j * rows] = d[i] * G[i + (int64_t)j * ldg];
+}
 __global__ __launch_bounds__(256) void diag_minmax_kernel(const double* __restrict__ S, int64_t ld, int n, double* __restrict__ out) {
     __shared__ double lo[256], hi[256];
     double a = 1e300, b = 0.0;
@@ -1212,12 +1233,65 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
     }
     h->firstcall = false;
     if (info > 0) return info;
+    h->qr_active = h->qr2_active = false;
+    if (h->qr_refine > 0) {
+        // the 'qr' mapping: how ill conditioned is the reduced matrix?  (max L_ii / min L_ii)^2 <= cond(S), one tiny kernel and one
+        // more 16-byte read-back per factorisation of this mapping only
+        if (!h->d_cond) {
+            KKT_HIP_CHECK(DEV_ALLOC(&h->d_cond, 2 * sizeof(double)));
+            KKT_HIP_CHECK(hipHostMalloc(&h->h_cond, 2 * sizeof(double)));
+        }
+        hipLaunchKernelGGL(diag_minmax_kernel, dim3(1), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->n, h->d_cond);
+        KKT_HIP_CHECK(hipMemcpyAsync(h->h_cond, h->d_cond, 2 * sizeof(double), hipMemcpyDeviceToHost, h->st));
+        KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+        const double r = h->h_cond[1] / h->h_cond[0], c2 = r * r;
+        h->qr_active = !(c2 < QR_REFINE_COND);                 // (also for inf / nan)
+        const bool cones = !h->q.empty() || !h->s.empty();
+        const int rows = cones ? h->krows : h->ml;
+        if (!(c2 < QR2_COND) && !h->dH && !h->singular && h->kktreg == 0.0 && rows >= h->n && h->n > 0) {
+            rr.next("mi355kkt factor: CholeskyQR2 repair of the factor");
+            const size_t nn = (size_t)h->n, rr_ = (size_t)rows;
+            if (!h->dQt) KKT_HIP_CHECK(DEV_ALLOC(&h->dQt, sizeof(double) * nn * rr_));
+            if (!h->dS2) KKT_HIP_CHECK(DEV_ALLOC(&h->dS2, sizeof(double) * nn * nn));
+            if (!h->pw2_ready) {
+                if (int e = potrf_work_init(h->pw2)) return e;
+                h->pw2_ready = true;
+            }
+            const double* Gs = h->dGs;
+            int64_t ldgs = h->krows;
+            if (!cones) {                                      // the LP cone's Gs is never materialised by the SYRK: form it here
+                if (!h->dQ) KKT_HIP_CHECK(DEV_ALLOC(&h->dQ, sizeof(double) * nn * rr_));
+                hipLaunchKernelGGL(qr_scale_rows_kernel, dim3((rows + 255) / 256, h->n), dim3(256), 0, h->st, h->dG, h->ldG, h->dW, rows,
+                                   h->n, h->dQ);
+                Gs = h->dQ;
+                ldgs = rows;
+            }
+            // Q1' = L1^-1 Gs'
+            hipLaunchKernelGGL(transpose_kernel, dim3((h->n + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, h->st, Gs, ldgs, rows, h->n,
+                               h->dQt);
+            if (int e = launch_trsm_lower(h->dS, h->n, h->n, h->dQt, h->n, rows, 0, h->st)) return e;
+            // Q1 (rows x n) for the SYRK's layout, S2 = Q1'Q1, L2 = chol(S2)
+            if (!h->dQ) KKT_HIP_CHECK(DEV_ALLOC(&h->dQ, sizeof(double) * nn * rr_));
+            hipLaunchKernelGGL(transpose_kernel, dim3((rows + 31) / 32, (h->n + 31) / 32), dim3(32, 8), 0, h->st, h->dQt, (int64_t)h->n,
+                               h->n, rows, h->dQ);
+            if (int e = launch_syrk_scaled(h->planS, h->dQ, rows, nullptr, h->dS2, h->n, nullptr, 0, h->st)) return e;
+            if (int e = launch_potrf(h->dS2, h->n, h->n, h->pw2, h->st)) return e;
+            KKT_HIP_CHECK(hipMemcpyAsync(h->pw2.h_info, h->pw2.d_info, sizeof(int), hipMemcpyDeviceToHost, h->st));
+            KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+            const int info2 = *h->pw2.h_info;
+            if (info2 < 0) { set_last_error("potrf: tile hand-off timeout (info = %d)", info2); return MI355KKT_EHIP; }
+            if (info2 > 0) return info2;
+            h->qr2_active = true;
+        }
+    }
     rr.next("mi355kkt factor: Schur complement / solve preparation");
     if (h->p > 0) {
         // Asct = L^-1 A'
         hipLaunchKernelGGL(transpose_kernel, dim3((h->n + 31) / 32, (h->p + 31) / 32), dim3(32, 8), 0, h->st, h->dA,
                            h->ldA, h->p, h->n, h->dAsct);
         if (int e = launch_trsm_lower(h->dS, h->n, h->n, h->dAsct, h->n, h->p, 0, h->st)) return e;
+        if (h->qr2_active)
+            if (int e = launch_trsm_lower(h->dS2, h->n, h->n, h->dAsct, h->n, h->p, 0, h->st)) return e;
         // K = Asct' Asct [+ reg I]
         if (int e = launch_syrk_scaled(h->planK, h->dAsct, h->n, nullptr, h->dK, h->p, nullptr, 0, h->st)) return e;
         if (h->kktreg != 0.0) hipLaunchKernelGGL(diag_add_kernel, g1(h->p), dim3(256), 0, h->st, h->dK, (int64_t)h->p, h->p, h->kktreg);
@@ -1230,20 +1304,8 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
     // tile Cholesky of S left (not when K went through the tile kernel after it: they are K's then)
     if (trsv_wide_wanted(h) && h->pw.minv_n == h->n && h->pw.minv_of == h->dS)
         if (int e = launch_block_inverse512(h->dS, h->n, h->n, h->pw, h->st)) return e;
-    if (h->qr_refine > 0) {
-        if (!h->d_cond) {
-            KKT_HIP_CHECK(DEV_ALLOC(&h->d_cond, 2 * sizeof(double)));
-            KKT_HIP_CHECK(hipHostMalloc(&h->h_cond, 2 * sizeof(double)));
-        }
-        hipLaunchKernelGGL(diag_minmax_kernel, dim3(1), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->n, h->d_cond);
-        KKT_HIP_CHECK(hipMemcpyAsync(h->h_cond, h->d_cond, 2 * sizeof(double), hipMemcpyDeviceToHost, h->st));
-    }
     KKT_HIP_CHECK(hipEventRecord(h->ev[3], h->st));
     if (int e = fetch_info(h, &info)) return e;
-    if (h->qr_refine > 0) {
-        const double r = h->h_cond[1] / h->h_cond[0];
-        h->qr_active = !(r * r < QR_REFINE_COND);              // (also for inf / nan)
-    }
     (void)hipEventElapsedTime(&h->t_syrk, h->ev[0], h->ev[1]);
     (void)hipEventElapsedTime(&h->t_potrf, h->ev[1], h->ev[2]);
     (void)hipEventElapsedTime(&h->t_schur, h->ev[2], h->ev[3]);
@@ -1355,12 +1417,23 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
     const char* pk = dev_knob("MI355KKT_TRSV_PAIR");
     const bool pair = persistent && have_minv && n % 128 == 0 && n >= 256 && 2 * (n / 128) <= h->num_cus && (pk ? atoi(pk) != 0 : TRSV_PAIR_DEFAULT);
     const int wide_rows = (trsv_wide_wanted(h) && h->pw.m512_n == n && h->pw.m512_of == h->dS) ? trsv_wide_rows(n, h->num_cus, true) : 0;
-    auto tri_solve = [&](int trans, double* xv) -> int {
+    auto tri_solve1 = [&](int trans, double* xv) -> int {
         if (wide_rows) return launch_trsv_wide(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->pw, wide_rows, h->num_cus);
         if (pair) return launch_trsv_pair(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran, h->pw.d_minv);
         if (persistent) return launch_trsv_persistent(h->dS, n, n, xv, trans, ++h->epoch, h->derr, st, h->dgran,
                                                       (h->pw.minv_n == n && h->pw.minv_of == h->dS) ? h->pw.d_minv : nullptr);
         return launch_trsm_lower(h->dS, n, n, xv, n, 1, trans, st);
+    };
+    // S = L1 (L2 L2') L1' after a CholeskyQR2 repair (the 'qr' mapping, ill-conditioned Gs): L1^-1 then L2^-1 forward, L2^-T then
+    // L1^-T backward -- the second factor through the blocked substitution (this mode buys accuracy, not time)
+    auto tri_solve = [&](int trans, double* xv) -> int {
+        if (!h->qr2_active) return tri_solve1(trans, xv);
+        if (!trans) {
+            if (int e = tri_solve1(0, xv)) return e;
+            return launch_trsm_lower(h->dS2, n, n, xv, n, 1, 0, st);
+        }
+        if (int e = launch_trsm_lower(h->dS2, n, n, xv, n, 1, 1, st)) return e;
+        return tri_solve1(1, xv);
     };
     // the reduced system: xv = bx + Gs' zs on entry, (ux, uy) on exit                       (misc.py:1527-1558)
     auto reduced_solve = [&](double* xv, double* yv) -> int {
