@@ -390,12 +390,15 @@ struct mi355kkt_solver {
     // there, but it exists -- Q1 = Gs L1^-T is nearly orthonormal, L2 = chol(Q1'Q1) is accurate, and S = L1 (L2 L2') L1' holds to
     // working precision column by column: the accuracy of a QR factor of Gs (what misc.kkt_qr computes) from three products the
     // engine already has (transpose, triangular solve with many right-hand sides, SYRK, Cholesky).  conelp without H only.
-    bool qr2_active = false;   // this factorisation carries the second factor
-    bool pw2_ready = false;
-    double* dQt = nullptr;     // n x rows: Gs', then Q1' = L1^-1 Gs'
-    double* dQ = nullptr;      // rows x n: (LP cone: Gs first,) then Q1
-    double* dS2 = nullptr;     // n x n: Q1'Q1, then L2
-    PotrfWork pw2;
+    // When even chol(Gs'Gs) breaks down (cond(Gs) beyond ~6e7), L1 = chol(Gs'Gs + sigma I) with sigma = 11 (rows n + n (n + 1)) eps
+    // x (an upper bound of ||Gs||^2) always exists, cond(Q1) = sqrt(sigma) / sigma_min(Gs) is small, and TWO more passes give
+    // S = L1 L2 (L3 L3') L2' L1' (shifted CholeskyQR3, Fukaya et al. 2020).
+    int qr_extra = 0;          // factors this factorisation carries beyond L1 (0: none, 1: CholeskyQR2, 2: shifted CholeskyQR3)
+    bool pwx_ready[2] = {false, false};
+    double* dQt = nullptr;     // n x rows: Gs', then Q_k' = L_k^-1 Q_{k-1}'
+    double* dQ = nullptr;      // rows x n: (LP cone: Gs first,) then Q_k
+    double* dSx[2] = {nullptr, nullptr};     // n x n: Q_k'Q_k, then L_{k+1}
+    PotrfWork pwx[2];
 };
 
 // per-iteration report of a device-resident loop: the scalar block comes back with one small copy (the loop has just
@@ -651,8 +654,10 @@ void mi355kkt_destroy(mi355kkt_solver* h) try {
     if (h->h_cond) (void)hipHostFree(h->h_cond);
     if (h->dQt) (void)dev_free(h->dQt);
     if (h->dQ) (void)dev_free(h->dQ);
-    if (h->dS2) (void)dev_free(h->dS2);
-    if (h->pw2_ready) potrf_work_free(h->pw2);
+    for (int k = 0; k < 2; ++k) {
+        if (h->dSx[k]) (void)dev_free(h->dSx[k]);
+        if (h->pwx_ready[k]) potrf_work_free(h->pwx[k]);
+    }
     if (h->derr) (void)dev_free(h->derr);
     if (h->herr) (void)hipHostFree(h->herr);
     for (double* b : bufs)
@@ -1232,11 +1237,13 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
         if (int e = fetch_info(h, &info)) return e;
     }
     h->firstcall = false;
-    if (info > 0) return info;
-    h->qr_active = h->qr2_active = false;
-    if (h->qr_refine > 0) {
-        // the 'qr' mapping: how ill conditioned is the reduced matrix?  (max L_ii / min L_ii)^2 <= cond(S), one tiny kernel and one
-        // more 16-byte read-back per factorisation of this mapping only
+    h->qr_active = false;
+    h->qr_extra = 0;
+    const bool qr_cones = !h->q.empty() || !h->s.empty();
+    const int qr_rows = qr_cones ? h->krows : h->ml;
+    const bool qr_can = h->qr_refine > 0 && !h->dH && !h->singular && h->kktreg == 0.0 && qr_rows >= h->n && h->n > 0;
+    int qr_passes = 0;
+    auto cond_word = [&]() -> int {            // {min, max} of |diag| of what h->dS holds -> h->h_cond (synchronises)
         if (!h->d_cond) {
             KKT_HIP_CHECK(DEV_ALLOC(&h->d_cond, 2 * sizeof(double)));
             KKT_HIP_CHECK(hipHostMalloc(&h->h_cond, 2 * sizeof(double)));
@@ -1244,44 +1251,68 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
         hipLaunchKernelGGL(diag_minmax_kernel, dim3(1), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->n, h->d_cond);
         KKT_HIP_CHECK(hipMemcpyAsync(h->h_cond, h->d_cond, 2 * sizeof(double), hipMemcpyDeviceToHost, h->st));
         KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+        return 0;
+    };
+    if (info > 0 && qr_can) {
+        // the 'qr' mapping: Gs'Gs is numerically singular where the reference's QR of Gs still works.  Shifted Cholesky of the
+        // re-assembled matrix, then two repair passes
+        rr.next("mi355kkt factor: shifted Cholesky (CholeskyQR3)");
+        if (int e = assemble_S(h, false)) return e;
+        if (int e = cond_word()) return e;
+        const double nrm2 = (double)h->n * h->h_cond[1];       // trace(S) <= n max S_ii, an upper bound of ||Gs||_2^2
+        const double sigma = 11.0 * ((double)qr_rows * h->n + (double)h->n * (h->n + 1)) * 2.220446049250313e-16 * nrm2;
+        if (sigma > 0.0 && sigma == sigma && sigma < 1e300) {
+            hipLaunchKernelGGL(diag_add_kernel, g1(h->n), dim3(256), 0, h->st, h->dS, (int64_t)h->n, h->n, sigma);
+            if (int e = launch_potrf(h->dS, h->n, h->n, h->pw, h->st)) return e;
+            KKT_HIP_CHECK(hipEventRecord(h->ev[2], h->st));
+            if (int e = fetch_info(h, &info)) return e;
+            if (info == 0) qr_passes = 2;
+        }
+    }
+    if (info > 0) return info;
+    if (h->qr_refine > 0) {
+        // the 'qr' mapping: how ill conditioned is the reduced matrix?  (max L_ii / min L_ii)^2 <= cond(S), one tiny kernel and one
+        // more 16-byte read-back per factorisation of this mapping only
+        if (int e = cond_word()) return e;
         const double r = h->h_cond[1] / h->h_cond[0], c2 = r * r;
-        h->qr_active = !(c2 < QR_REFINE_COND);                 // (also for inf / nan)
-        const bool cones = !h->q.empty() || !h->s.empty();
-        const int rows = cones ? h->krows : h->ml;
-        if (!(c2 < QR2_COND) && !h->dH && !h->singular && h->kktreg == 0.0 && rows >= h->n && h->n > 0) {
-            rr.next("mi355kkt factor: CholeskyQR2 repair of the factor");
+        h->qr_active = qr_passes > 0 || !(c2 < QR_REFINE_COND);          // (also for inf / nan)
+        if (qr_passes == 0 && !(c2 < QR2_COND) && qr_can) qr_passes = 1;
+        if (qr_passes > 0) {
+            rr.next("mi355kkt factor: CholeskyQR repair of the factor");
+            const int rows = qr_rows;
             const size_t nn = (size_t)h->n, rr_ = (size_t)rows;
             if (!h->dQt) KKT_HIP_CHECK(DEV_ALLOC(&h->dQt, sizeof(double) * nn * rr_));
-            if (!h->dS2) KKT_HIP_CHECK(DEV_ALLOC(&h->dS2, sizeof(double) * nn * nn));
-            if (!h->pw2_ready) {
-                if (int e = potrf_work_init(h->pw2)) return e;
-                h->pw2_ready = true;
-            }
+            if (!h->dQ) KKT_HIP_CHECK(DEV_ALLOC(&h->dQ, sizeof(double) * nn * rr_));
             const double* Gs = h->dGs;
             int64_t ldgs = h->krows;
-            if (!cones) {                                      // the LP cone's Gs is never materialised by the SYRK: form it here
-                if (!h->dQ) KKT_HIP_CHECK(DEV_ALLOC(&h->dQ, sizeof(double) * nn * rr_));
+            if (!qr_cones) {                                   // the LP cone's Gs is never materialised by the SYRK: form it here
                 hipLaunchKernelGGL(qr_scale_rows_kernel, dim3((rows + 255) / 256, h->n), dim3(256), 0, h->st, h->dG, h->ldG, h->dW, rows,
                                    h->n, h->dQ);
                 Gs = h->dQ;
                 ldgs = rows;
             }
-            // Q1' = L1^-1 Gs'
             hipLaunchKernelGGL(transpose_kernel, dim3((h->n + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, h->st, Gs, ldgs, rows, h->n,
-                               h->dQt);
-            if (int e = launch_trsm_lower(h->dS, h->n, h->n, h->dQt, h->n, rows, 0, h->st)) return e;
-            // Q1 (rows x n) for the SYRK's layout, S2 = Q1'Q1, L2 = chol(S2)
-            if (!h->dQ) KKT_HIP_CHECK(DEV_ALLOC(&h->dQ, sizeof(double) * nn * rr_));
-            hipLaunchKernelGGL(transpose_kernel, dim3((rows + 31) / 32, (h->n + 31) / 32), dim3(32, 8), 0, h->st, h->dQt, (int64_t)h->n,
-                               h->n, rows, h->dQ);
-            if (int e = launch_syrk_scaled(h->planS, h->dQ, rows, nullptr, h->dS2, h->n, nullptr, 0, h->st)) return e;
-            if (int e = launch_potrf(h->dS2, h->n, h->n, h->pw2, h->st)) return e;
-            KKT_HIP_CHECK(hipMemcpyAsync(h->pw2.h_info, h->pw2.d_info, sizeof(int), hipMemcpyDeviceToHost, h->st));
-            KKT_HIP_CHECK(hipStreamSynchronize(h->st));
-            const int info2 = *h->pw2.h_info;
-            if (info2 < 0) { set_last_error("potrf: tile hand-off timeout (info = %d)", info2); return MI355KKT_EHIP; }
-            if (info2 > 0) return info2;
-            h->qr2_active = true;
+                               h->dQt);                        // Q_0' = Gs'
+            for (int k = 0; k < qr_passes; ++k) {
+                if (!h->dSx[k]) KKT_HIP_CHECK(DEV_ALLOC(&h->dSx[k], sizeof(double) * nn * nn));
+                if (!h->pwx_ready[k]) {
+                    if (int e = potrf_work_init(h->pwx[k])) return e;
+                    h->pwx_ready[k] = true;
+                }
+                // Q_{k+1}' = L_{k+1}^-1 Q_k'  (L_1 = the factor in h->dS), Q_{k+1} in the SYRK's layout, S = Q'Q, next factor
+                const double* Lk = k == 0 ? h->dS : h->dSx[k - 1];
+                if (int e = launch_trsm_lower(Lk, h->n, h->n, h->dQt, h->n, rows, 0, h->st)) return e;
+                hipLaunchKernelGGL(transpose_kernel, dim3((rows + 31) / 32, (h->n + 31) / 32), dim3(32, 8), 0, h->st, h->dQt,
+                                   (int64_t)h->n, h->n, rows, h->dQ);
+                if (int e = launch_syrk_scaled(h->planS, h->dQ, rows, nullptr, h->dSx[k], h->n, nullptr, 0, h->st)) return e;
+                if (int e = launch_potrf(h->dSx[k], h->n, h->n, h->pwx[k], h->st)) return e;
+                KKT_HIP_CHECK(hipMemcpyAsync(h->pwx[k].h_info, h->pwx[k].d_info, sizeof(int), hipMemcpyDeviceToHost, h->st));
+                KKT_HIP_CHECK(hipStreamSynchronize(h->st));
+                const int infok = *h->pwx[k].h_info;
+                if (infok < 0) { set_last_error("potrf: tile hand-off timeout (info = %d)", infok); return MI355KKT_EHIP; }
+                if (infok > 0) return infok;
+            }
+            h->qr_extra = qr_passes;
         }
     }
     rr.next("mi355kkt factor: Schur complement / solve preparation");
@@ -1290,8 +1321,8 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
         hipLaunchKernelGGL(transpose_kernel, dim3((h->n + 31) / 32, (h->p + 31) / 32), dim3(32, 8), 0, h->st, h->dA,
                            h->ldA, h->p, h->n, h->dAsct);
         if (int e = launch_trsm_lower(h->dS, h->n, h->n, h->dAsct, h->n, h->p, 0, h->st)) return e;
-        if (h->qr2_active)
-            if (int e = launch_trsm_lower(h->dS2, h->n, h->n, h->dAsct, h->n, h->p, 0, h->st)) return e;
+        for (int k = 0; k < h->qr_extra; ++k)
+            if (int e = launch_trsm_lower(h->dSx[k], h->n, h->n, h->dAsct, h->n, h->p, 0, h->st)) return e;
         // K = Asct' Asct [+ reg I]
         if (int e = launch_syrk_scaled(h->planK, h->dAsct, h->n, nullptr, h->dK, h->p, nullptr, 0, h->st)) return e;
         if (h->kktreg != 0.0) hipLaunchKernelGGL(diag_add_kernel, g1(h->p), dim3(256), 0, h->st, h->dK, (int64_t)h->p, h->p, h->kktreg);
@@ -1424,15 +1455,18 @@ int mi355kkt_solve_device(mi355kkt_solver* h, double* dx, double* dy, double* dz
                                                       (h->pw.minv_n == n && h->pw.minv_of == h->dS) ? h->pw.d_minv : nullptr);
         return launch_trsm_lower(h->dS, n, n, xv, n, 1, trans, st);
     };
-    // S = L1 (L2 L2') L1' after a CholeskyQR2 repair (the 'qr' mapping, ill-conditioned Gs): L1^-1 then L2^-1 forward, L2^-T then
-    // L1^-T backward -- the second factor through the blocked substitution (this mode buys accuracy, not time)
+    // S = L1 L2 [L3] ([L3'] L2') L1' after a CholeskyQR repair (the 'qr' mapping, ill-conditioned Gs): the factors in order forward,
+    // in reverse order backward -- the extra ones through the blocked substitution (this mode buys accuracy, not time)
     auto tri_solve = [&](int trans, double* xv) -> int {
-        if (!h->qr2_active) return tri_solve1(trans, xv);
+        if (h->qr_extra == 0) return tri_solve1(trans, xv);
         if (!trans) {
             if (int e = tri_solve1(0, xv)) return e;
-            return launch_trsm_lower(h->dS2, n, n, xv, n, 1, 0, st);
+            for (int k = 0; k < h->qr_extra; ++k)
+                if (int e = launch_trsm_lower(h->dSx[k], n, n, xv, n, 1, 0, st)) return e;
+            return 0;
         }
-        if (int e = launch_trsm_lower(h->dS2, n, n, xv, n, 1, 1, st)) return e;
+        for (int k = h->qr_extra - 1; k >= 0; --k)
+            if (int e = launch_trsm_lower(h->dSx[k], n, n, xv, n, 1, 1, st)) return e;
         return tri_solve1(1, xv);
     };
     // the reduced system: xv = bx + Gs' zs on entry, (ux, uy) on exit                       (misc.py:1527-1558)

@@ -764,12 +764,14 @@ QR_REFINEMENT = 4     # refinement steps of the 'qr' mapping (only for factorisa
 
 def kkt_qr(G, dims, A):
     """Mirror of misc.kkt_qr (misc.py:1570; conelp only, H = 0).  Same KKT system; the reference factors W^-T G Q2 by QR (error
-    proportional to cond(W^-T G)), this engine factors the reduced matrix Gs'Gs by Cholesky (cond squared).  Round 6: solves of a
-    factorisation whose Cholesky factor shows (max L_ii / min L_ii)^2 >= 1e8 get four steps of iterative refinement against the
-    unreduced 3 x 3 system (option "qr_refinement", include/mi355kkt.h) -- free while the problem is well conditioned; with it the
-    mapping follows the reference's 'qr' (same status, iteration count, objective) up to cond(W^-T G) ~ 3e6, where the plain
-    Cholesky mapping of rounds 1-5 lost it at ~1e5 (as the reference's own 'chol' does); beyond ~1e7 the reduced matrix is
-    numerically singular and only a QR-accurate factor would help (measured: profiles/r06_kkt_qr_conditioning.txt)."""
+    proportional to cond(W^-T G)), this engine factors the reduced matrix Gs'Gs by Cholesky (cond squared).  Round 6 (option
+    "qr_refinement", include/mi355kkt.h), all of it decided per factorisation from (max L_ii / min L_ii)^2 of the Cholesky factor and
+    free while the problem is well conditioned: from 1e8 the solves get four steps of iterative refinement against the unreduced
+    3 x 3 system; from 1e10 the factor is repaired by CholeskyQR2 (Q1 = Gs L1^-T is nearly orthonormal, L2 = chol(Q1'Q1) is accurate,
+    S = L1 L2 L2' L1'); where chol(Gs'Gs) itself breaks down, a shifted Cholesky and two repair passes (shifted CholeskyQR3).  With
+    that the mapping follows the reference's 'qr' -- same status, iteration count, objectives -- from cond(W^-T G) = 3e3 to 3e8, and
+    still solves the probe family at 3e9, where the reference's own 'qr' does not (measured:
+    profiles/r06_kkt_qr_conditioning.txt; the plain Cholesky mapping of rounds 1-5 lost it at ~1e5)."""
     fac = _factory(_capi.CHOL, G, dims, A, 0)
     fac.engine.set_option("qr_refinement", QR_REFINEMENT)
 

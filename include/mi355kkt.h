@@ -145,8 +145,10 @@ int mi355kkt_set_kktreg(mi355kkt_solver* h, double reg);
  *                     (default 2, 0 = the plain reduced solve; not applied with kktreg);
  *   "qr_refinement"   steps of the same refinement for the flavours WITHOUT it (MI355KKT_CHOL / _CHOL2), applied only to the solves
  *                     of a factorisation whose reduced matrix is ill conditioned: (max L_ii / min L_ii)^2 >= 1e8, read back with
- *                     the info word.  This is how misc.kkt_qr (reference misc.py:1570-1699: two QR factorisations, error
- *                     proportional to cond(W^-T G)) is mapped onto the Cholesky engine (cond squared); 0 (default): off.
+ *                     the info word; from 1e10 (conelp without H) the factor itself is repaired by CholeskyQR2, and where
+ *                     chol(Gs'Gs) breaks down by a shifted Cholesky + two repair passes (shifted CholeskyQR3).  This is how
+ *                     misc.kkt_qr (reference misc.py:1570-1699: two QR factorisations, error proportional to cond(W^-T G)) is
+ *                     mapped onto the Cholesky engine (cond squared); 0 (default): off.
  * Unknown names: MI355KKT_EINVAL. */
 int mi355kkt_set_option(mi355kkt_solver* h, const char* name, double value);
 /* options['show_progress'] of the reference drivers (coneprog.py:2161-2208, :984-990) for the device-resident loops

@@ -259,15 +259,16 @@ def _illcond_lp(n, m, eps, seed):
     return c, G, h
 
 
-@pytest.mark.parametrize("eps", [1e-3, 1e-5, 1e-6])
+@pytest.mark.parametrize("eps", [1e-3, 1e-5, 1e-6, 1e-7, 1e-8])
 @pytest.mark.parametrize("device_loop", [True, False])
 def test_kkt_qr_mapping_follows_the_references_qr_where_cholesky_alone_does_not(ref_cvxopt, eps, device_loop):
     """VERDICT r5 item 5(b).  The reference's kkt_qr (misc.py:1570-1699) factors W^-T G by QR; the backend maps 'qr' onto its reduced
     Cholesky engine.  With cond(G) = 3e5 / 3e6 the reference's own 'chol' loses digits or stalls and so did the plain mapping of
-    rounds 1-5 (tests/run_qr_cond_probe.py, profiles/r06_kkt_qr_conditioning.txt); with the conditional refinement against the
-    3 x 3 system ("qr_refinement") the backend's 'qr' gives the reference's status, iteration count and objectives here, through
-    the device loop and through the reference's host driver.  (cond(G) >= 3e7: only the reference's QR survives -- documented
-    limit)"""
+    rounds 1-5 (tests/run_qr_cond_probe.py, profiles/r06_kkt_qr_conditioning.txt).  The mapping now (i) refines its solves against
+    the 3 x 3 system when the factor shows (max L_ii / min L_ii)^2 >= 1e8, (ii) repairs the factor by CholeskyQR2 from 1e10, and
+    (iii) where even chol(Gs'Gs) breaks down (cond(G) = 3e8) starts from a shifted Cholesky and takes two repair passes (shifted
+    CholeskyQR3): the reference's status, iteration count and objectives at every cond(G) from 3e3 to 3e8, through the device loop
+    and through the reference's host driver."""
     import cvxopt_amd.solvers as gs
     cvx = ref_cvxopt
     c, G, h = _illcond_lp(40, 120, eps, 1)
@@ -280,6 +281,20 @@ def test_kkt_qr_mapping_follows_the_references_qr_where_cholesky_alone_does_not(
         assert abs(got[k] - ref[k]) <= 1e-8 * abs(ref[k]), (k, got[k], ref[k])
     record("round6_kkt_qr_eps%g_%s" % (eps, "dev" if device_loop else "host"), pobj=got['primal objective'],
            pobj_ref=ref['primal objective'], gap=got['gap'], gap_ref=ref['gap'])
+
+
+@pytest.mark.parametrize("device_loop", [True, False])
+def test_kkt_qr_mapping_beyond_the_references_own_qr(ref_cvxopt, device_loop):
+    """cond(G) = 3e9: the reference's 'qr' runs into its iteration limit (primal infeasibility 1e32), its pivoted 'ldl' still solves
+    the problem in 8 iterations -- and so does the backend's 'qr' (shifted CholeskyQR3 + refinement), with that objective"""
+    import cvxopt_amd.solvers as gs
+    cvx = ref_cvxopt
+    c, G, h = _illcond_lp(40, 120, 1e-9, 1)
+    M = lambda a: cvx.matrix(np.asfortranarray(np.atleast_2d(a.T).T if a.ndim == 1 else a))
+    ref = cvx.solvers.conelp(M(c), M(G), M(h), kktsolver='ldl')
+    got = gs.conelp(M(c), M(G), M(h), kktsolver='qr', device_loop=device_loop)
+    assert ref['status'] == 'optimal' and got['status'] == 'optimal' and got['iterations'] == ref['iterations']
+    assert abs(got['primal objective'] - ref['primal objective']) <= 1e-8 * abs(ref['primal objective'])
 
 
 def test_sparse_dense_root_through_the_wide_solves():
