@@ -1241,7 +1241,10 @@ int mi355kkt_factor_device(mi355kkt_solver* h, const mi355kkt_scaling* W) try {
     h->qr_extra = 0;
     const bool qr_cones = !h->q.empty() || !h->s.empty();
     const int qr_rows = qr_cones ? h->krows : h->ml;
-    const bool qr_can = h->qr_refine > 0 && !h->dH && !h->singular && h->kktreg == 0.0 && qr_rows >= h->n && h->n > 0;
+    // (the repair's triangular solve with `rows` right-hand sides is scalar code: it is for the small and medium problems 'qr' is
+    //  chosen for -- up to 4e9 multiply-adds, ~10 ms --, larger ones keep the refinement alone and their speed)
+    const bool qr_can = h->qr_refine > 0 && !h->dH && !h->singular && h->kktreg == 0.0 && qr_rows >= h->n && h->n > 0 &&
+                        (double)h->n * h->n * qr_rows <= 4e9;
     int qr_passes = 0;
     auto cond_word = [&]() -> int {            // {min, max} of |diag| of what h->dS holds -> h->h_cond (synchronises)
         if (!h->d_cond) {
