@@ -908,6 +908,24 @@ static void h_unregister(mi355kkt_solver* h) {
  * (hipHostRegister, cached while the same buffer is passed again) and the NEXT factor() only waits for it after the
  * scaled SYRK: S = Gs'Gs runs while H crosses PCIe, then S += tril(H).  The caller keeps H alive and unmodified until
  * that factor() returns, and alive until the next set_H_* call or destroy (the Python mirror holds a reference). */
+// Does [a, b) touch the process's brk heap (the "[heap]" line of /proc/self/maps)?  Memory there is recycled by malloc under the
+// caller's feet -- chunks are split, merged, trimmed and grown back -- and must never be hipHostRegister'ed: round 4's abort (small
+// H, always a heap chunk) and a GPU memory fault in round 6's one-process suite (8-32 MB H from a heap whose mmap threshold glibc had
+// raised) both ended on heap addresses.  Read at every call (the heap moves); ~50 us next to a copy of megabytes.
+static bool touches_brk_heap(uintptr_t a, uintptr_t b) {
+    FILE* f = fopen("/proc/self/maps", "r");
+    if (!f) return true;                                   // cannot tell: do not pin
+    char line[512];
+    bool hit = false;
+    while (fgets(line, sizeof line, f)) {
+        if (!strstr(line, "[heap]")) continue;
+        unsigned long long lo = 0, hi = 0;
+        if (sscanf(line, "%llx-%llx", &lo, &hi) == 2 && a < (uintptr_t)hi && b > (uintptr_t)lo) hit = true;
+    }
+    fclose(f);
+    return hit;
+}
+
 int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH) try {
     if (!h) return MI355KKT_EINVAL;
     if (!H || h->n == 0) { h_unregister(h); h->h_pending = false; return mi355kkt_set_H_dense(h, H, ldH); }
@@ -932,6 +950,10 @@ int mi355kkt_set_H_dense_async(mi355kkt_solver* h, const double* H, int64_t ldH)
     static const uintptr_t pgmask = []() { const long v = sysconf(_SC_PAGESIZE); return (uintptr_t)(v > 0 ? v : 4096) - 1; }();
     uintptr_t p0 = pin_any ? b0 : ((b0 + pgmask) & ~pgmask), p1 = pin_any ? b1 : (b1 & ~pgmask);
     if (!pin_any && (!contiguous || p1 <= p0 || p1 - p0 < ((size_t)2 << 20))) return mi355kkt_set_H_dense(h, H, ldH);
+    // Round 6: ... and never pages of the brk heap, whatever the size (see touches_brk_heap): a registration that is already held for
+    // exactly this range stays (it was checked when it was made)
+    if (!pin_any && !(h->reg_ptr == reinterpret_cast<const void*>(p0) && h->reg_bytes == (size_t)(p1 - p0)) && touches_brk_heap(p0, p1))
+        return mi355kkt_set_H_dense(h, H, ldH);
     const void* rptr = reinterpret_cast<const void*>(p0);
     const size_t rbytes = (size_t)(p1 - p0);
     if (h->reg_ptr != rptr || h->reg_bytes != rbytes) {
