@@ -118,6 +118,7 @@ SIGNATURES = {
     "mi355kkt_test_syrk_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_int_p, C.c_int, c_int_p, c_int_p, c_int_p]),
     "mi355kkt_test_ordering": (C.c_int, [C.c_int, c_i64_p, c_i64_p, C.c_int, c_int_p, c_double_p]),
     "mi355kkt_test_throw": (C.c_int, [C.c_int]),
+    "mi355kkt_test_touches_brk_heap": (C.c_int, [C.c_void_p, C.c_size_t]),
     "mi355kkt_test_set_knob": (C.c_int, [C.c_char_p, C.c_char_p]),
     "mi355kkt_test_install_abort_dump": (C.c_int, [C.c_char_p]),
     "mi355kkt_test_guard_probe": (C.c_int, [C.c_int, C.c_int, c_double_p]),

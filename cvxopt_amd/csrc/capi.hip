@@ -3100,6 +3100,10 @@ int mi355kkt_test_guard_probe(int ndoubles, int at, double* out) try {
     (void)dev_free(res);
     return 0;
 } catch (...) { return kkt_catch("mi355kkt_test_guard_probe"); }
+int mi355kkt_test_touches_brk_heap(const void* ptr, size_t bytes) try {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    return touches_brk_heap(a, a + bytes) ? 1 : 0;
+} catch (...) { return kkt_catch("mi355kkt_test_touches_brk_heap"); }
 int mi355kkt_test_throw(int kind) try {
     if (kind == 0) throw std::bad_alloc();
     if (kind == 1) throw std::runtime_error("requested by the caller");

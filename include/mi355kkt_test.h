@@ -39,6 +39,9 @@ int mi355kkt_test_ordering(int n, const int64_t* colptr, const int64_t* rowind, 
 /* throws inside a guarded entry point (kind 0: std::bad_alloc, 1: std::runtime_error, 2: a non-standard exception);
  * must RETURN MI355KKT_ENOMEM / MI355KKT_EHIP like any entry point in which host code throws */
 int mi355kkt_test_throw(int kind);
+/* 1 when [ptr, ptr + bytes) touches the process's brk heap (the "[heap]" line of /proc/self/maps), 0 when it does not: the test by
+ * which mi355kkt_set_H_dense_async decides never to hipHostRegister a caller's buffer that malloc may recycle (host only) */
+int mi355kkt_test_touches_brk_heap(const void* ptr, size_t bytes);
 /* Knobs of the sparse symbolic analysis and a few kernel-selection thresholds (csrc/knobs.h): "MI355KKT_ORDERING" = nd | amd,
  * "MI355KKT_ND_MODE", "MI355KKT_ND_LEAF", "MI355KKT_ND_LEAF_AMD", "MI355KKT_ND_NOREFINE", "MI355KKT_ORDERING_BOTH",
  * "MI355KKT_SN_MAXW", "MI355KKT_SPARSE_BIG_FLOPS", "MI355KKT_SPARSE_BIG_H", "MI355KKT_SP_WIDE", "MI355KKT_SPARSE_TILES",

@@ -201,3 +201,29 @@ def test_every_knob_the_sources_read_is_documented_in_the_test_header():
     assert used, "no knob found: the pattern of this test is stale"
     missing = sorted(k for k in used if '"%s"' % k not in header)
     assert not missing, missing
+
+
+def test_brk_heap_detection_used_by_the_pinned_upload():
+    """round 6: mi355kkt_set_H_dense_async never hipHostRegisters memory of the brk heap; the detector behind that decision:
+    a small malloc'ed block lies in the heap, an anonymous mmap does not, a huge NumPy array (mmap'ed by glibc) does not"""
+    import ctypes as C
+    import mmap
+    from cvxopt_amd import _capi
+    L = _capi.lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.free.argtypes = [C.c_void_p]
+    p = libc.malloc(1000)
+    try:
+        assert L.mi355kkt_test_touches_brk_heap(C.c_void_p(p), 1000) == 1
+    finally:
+        libc.free(p)
+    mm = mmap.mmap(-1, 1 << 20)
+    buf = (C.c_char * (1 << 20)).from_buffer(mm)
+    assert L.mi355kkt_test_touches_brk_heap(C.addressof(buf), 1 << 20) == 0
+    del buf
+    mm.close()
+    big = np.empty(40 << 20, dtype=np.uint8)            # 40 MB: above glibc's largest dynamic mmap threshold (32 MB)
+    assert L.mi355kkt_test_touches_brk_heap(C.c_void_p(big.ctypes.data), big.nbytes) == 0
+    # a range that straddles the end of the heap counts as touching it
+    assert L.mi355kkt_test_touches_brk_heap(C.c_void_p(0), 1 << 62) == 1
